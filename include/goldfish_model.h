@@ -1,0 +1,74 @@
+/* goldfish_model.h -- plain-C description of a non-matching multi-patch KL-shell model.
+ *
+ * This is the wire format between the Python host layer (goldfish_amd/model.py)
+ * and (a) the HIP product library libgoldfish_hip.so, (b) the CPU oracle
+ * oracle/libkl_oracle.so (test infrastructure).  It replaces, for the hot path,
+ * what the reference passes around as tIGAr ExtractedSpline objects + PENGoLINS
+ * mortar meshes (reference: GOLDFISH/nonmatching_opt.py:12-127 constructor,
+ * :422-431 mortar_meshes_setup; SURVEY.md section 8(a) row a10 for the orderings).
+ *
+ * Conventions:
+ *   - patches are concatenated in list order ("nest" vectors of the reference);
+ *   - inside a patch a scalar field is flattened u-index-fastest: a = i + j*n_u
+ *     (GOLDFISH/utils/bsp_utils.py:14-15);
+ *   - vector fields are node-major: dof = 3*(cp_off[s] + a) + component;
+ *   - control points are HOMOGENEOUS: c_a = w_a * P_a (cpFuncs[field],
+ *     GOLDFISH/nonmatching_opt.py:440-441); weights are not design variables;
+ *   - knot vectors are open, parametric domain [knots[0], knots[-1]] (the mortar
+ *     parametric coordinates of the reference's .npz files live in [0,1]).
+ *   - thickness is a scalar B-spline field h(xi) = sum_b N_b(xi) h_b
+ *     (non-rational N_b: the reference keeps h in spline.V_control,
+ *     GOLDFISH/nonmatching_opt.py:516-525).
+ */
+#ifndef GOLDFISH_MODEL_H
+#define GOLDFISH_MODEL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gf_model_desc {
+    /* ---- patches ---------------------------------------------------- */
+    int32_t        n_patches;
+    const int32_t* degree;     /* [2*n_patches]  (p_u, p_v)                       */
+    const int32_t* ncp;        /* [2*n_patches]  (n_u, n_v) control-net shape     */
+    const int64_t* knot_off;   /* [2*n_patches+1] offsets into knots[]            */
+    const double*  knots;      /* concatenated knot vectors (u of patch 0, v of 0, u of 1, ...) */
+    const int64_t* cp_off;     /* [n_patches+1]  offsets in control points        */
+    const double*  weights;    /* [total_cp]  NURBS weights w_a                   */
+    const double*  young;      /* [n_patches]                                     */
+    const double*  poisson;    /* [n_patches]                                     */
+    const double*  body_force; /* [3*n_patches] force per unit reference area (dWext = f . u dA,
+                                  GOLDFISH/tests/test_dRdt.py:102-106)             */
+    /* ---- Dirichlet dofs and nodal (point) loads ---------------------- */
+    int64_t        n_zero_dofs;
+    const int64_t* zero_dofs;  /* global vector dof ids (spline.zeroDofs)          */
+    int64_t        n_point_loads;
+    const int64_t* pl_dof;     /* R[pl_dof] -= pl_val  (PointSource applied to the */
+    const double*  pl_val;     /* assembled residual, nonmatching_opt.py:735-738)  */
+    /* ---- interfaces (mortar vertices, vertex quadrature) ------------- */
+    int32_t        n_interfaces;
+    const int32_t* if_patch;   /* [2*n_interfaces] mapping_list[i] = (A, B)        */
+    const int64_t* if_off;     /* [n_interfaces+1] offsets into mortar points      */
+    const double*  if_xi;      /* [4*n_pts] (xiA_u, xiA_v, xiB_u, xiB_v)           */
+    const double*  if_tau;     /* [2*n_pts] d(xi_A)/d(mortar parameter)            */
+    const double*  if_wt;      /* [n_pts]   vertex-quadrature weight (mortar param)*/
+    const double*  if_alpha;   /* [2*n_interfaces] (alpha_d, alpha_r), frozen
+                                  (nonmatching_opt.py:928-938: no h / CP derivative)*/
+} gf_model_desc;
+
+/* which-matrix selectors shared by product and oracle */
+enum {
+    GF_MAT_K      = 0,  /* dR/du   ndof x ndof,      rows+cols Dirichlet, diag 1 (nonmatching_opt.py:950-959) */
+    GF_MAT_DRDCP0 = 1,  /* dR/dCP_f ndof x total_cp, rows Dirichlet, diag 0 (nonmatching_opt.py:992-1004)     */
+    GF_MAT_DRDCP1 = 2,
+    GF_MAT_DRDCP2 = 3,
+    GF_MAT_DRDH   = 4   /* dR/dh   ndof x total_cp,  shell terms only, NO Dirichlet treatment (:1006-1015)    */
+};
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,150 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes binding of oracle/libkl_oracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module (the product path under goldfish_amd/ never does)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MAT_K, MAT_DRDCP0, MAT_DRDCP1, MAT_DRDCP2, MAT_DRDH = range(5)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libkl_oracle.so")
+    src = os.path.join(_HERE, "kl_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libkl_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libkl_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        dp = C.POINTER(C.c_double)
+        L.gfo_create.restype = C.c_void_p
+        L.gfo_create.argtypes = [C.c_void_p]
+        L.gfo_destroy.argtypes = [C.c_void_p]
+        for name in ("gfo_total_cp", "gfo_num_gauss_points", "gfo_num_mortar_points"):
+            getattr(L, name).restype = C.c_int64
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.gfo_set_cp.argtypes = [C.c_void_p, C.c_int, dp]
+        L.gfo_set_thickness.argtypes = [C.c_void_p, dp]
+        L.gfo_set_u.argtypes = [C.c_void_p, dp]
+        L.gfo_nnz.restype = C.c_int64
+        L.gfo_nnz.argtypes = [C.c_void_p, C.c_int]
+        L.gfo_pattern.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        L.gfo_residual.argtypes = [C.c_void_p, dp]
+        L.gfo_assemble.argtypes = [C.c_void_p, dp, dp, dp, dp, dp]
+        L.gfo_functionals.argtypes = [C.c_void_p, dp] + [dp] * 9 + [C.c_int]
+        L.gfo_penalty_point.argtypes = [dp, dp, dp, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp]
+        L.gfo_eval_point.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, dp, dp]
+        L.gfo_num_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+class Oracle:
+    """CPU restatement of RIGA / dRIGAduIGA / dRIGAdCPIGA / dRIGAdh_th + functionals."""
+
+    def __init__(self, arrays, thickness=None, u=None):
+        self.arrays = arrays
+        self._desc = arrays.desc()
+        self.h = C.c_void_p(lib().gfo_create(C.byref(self._desc)))
+        if not self.h:
+            raise RuntimeError("gfo_create failed")
+        self.total_cp, self.ndof = arrays.total_cp, arrays.ndof
+        for f in range(3):
+            self.set_cp(f, arrays.cp_hom[f])
+        if thickness is not None:
+            self.set_thickness(thickness)
+        if u is not None:
+            self.set_u(u)
+        self._pat = {}
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().gfo_destroy(self.h)
+            self.h = None
+
+    def set_cp(self, field, v):
+        v = np.ascontiguousarray(v, float)
+        assert v.size == self.total_cp
+        lib().gfo_set_cp(self.h, field, _dp(v))
+
+    def set_thickness(self, v):
+        v = np.ascontiguousarray(v, float)
+        assert v.size == self.total_cp
+        lib().gfo_set_thickness(self.h, _dp(v))
+
+    def set_u(self, v):
+        v = np.ascontiguousarray(v, float)
+        assert v.size == self.ndof
+        lib().gfo_set_u(self.h, _dp(v))
+
+    def pattern(self, which):
+        if which not in self._pat:
+            nnz = lib().gfo_nnz(self.h, which)
+            rowptr = np.zeros(self.ndof + 1, np.int64)
+            col = np.zeros(nnz, np.int32)
+            lib().gfo_pattern(self.h, which, rowptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                              col.ctypes.data_as(C.POINTER(C.c_int32)))
+            self._pat[which] = (rowptr, col)
+        return self._pat[which]
+
+    def residual(self):
+        R = np.zeros(self.ndof)
+        lib().gfo_residual(self.h, _dp(R))
+        return R
+
+    def assemble(self, K=True, dRdCP=(0, 1, 2), dRdh=True):
+        vals = {}
+        if K:
+            vals[MAT_K] = np.zeros(lib().gfo_nnz(self.h, MAT_K))
+        for f in dRdCP:
+            vals[MAT_DRDCP0 + f] = np.zeros(lib().gfo_nnz(self.h, MAT_DRDCP0))
+        if dRdh:
+            vals[MAT_DRDH] = np.zeros(lib().gfo_nnz(self.h, MAT_DRDH))
+        lib().gfo_assemble(self.h, *[_dp(vals.get(w)) for w in range(5)])
+        return vals
+
+    def csr(self, which, vals):
+        rowptr, col = self.pattern(which)
+        ncol = self.ndof if which == MAT_K else self.total_cp
+        return sp.csr_matrix((vals, col, rowptr), shape=(self.ndof, ncol))
+
+    def functionals(self, apply_bcs=True):
+        out = np.zeros(3)
+        g = dict(dWdu=np.zeros(self.ndof),
+                 dWdcp=[np.zeros(self.total_cp) for _ in range(3)], dWdh=np.zeros(self.total_cp),
+                 dVdcp=[np.zeros(self.total_cp) for _ in range(3)], dVdh=np.zeros(self.total_cp))
+        lib().gfo_functionals(self.h, _dp(out), _dp(g["dWdu"]), *[_dp(x) for x in g["dWdcp"]], _dp(g["dWdh"]),
+                              *[_dp(x) for x in g["dVdcp"]], _dp(g["dVdh"]), int(apply_bcs))
+        g.update(Wint=out[0], volume=out[1], Wpen=out[2])
+        return g
+
+    def eval_point(self, patch, xi):
+        X, U = np.zeros(3), np.zeros(3)
+        lib().gfo_eval_point(self.h, patch, float(xi[0]), float(xi[1]), _dp(X), _dp(U))
+        return X, U
+
+
+def penalty_point(y, Y, tau, ad, ar, dt):
+    y, Y, tau = (np.ascontiguousarray(a, float) for a in (y, Y, tau))
+    en = np.zeros(1)
+    g, Hyy, HyY = np.zeros(18), np.zeros((18, 18)), np.zeros((18, 12))
+    lib().gfo_penalty_point(_dp(y), _dp(Y), _dp(tau), ad, ar, dt, _dp(en), _dp(g), _dp(Hyy), _dp(HyY))
+    return en[0], g, Hyy, HyY

@@ -1,0 +1,125 @@
+"""Pins oracle/kl_oracle.c: every gradient / Hessian it assembles is compared with
+torch.autograd of the bare energies (oracle/kl_energy_torch.py) on small multi-patch
+models with true NURBS weights, variable thickness and a finite displacement state.
+(The reference's own verification is analytic-vs-FD `check_partials`,
+GOLDFISH/om_comps/disp_states_comp.py:146-159; autograd is the exact version of it.)"""
+import numpy as np
+import pytest
+import torch
+
+from goldfish_amd import geometry as G
+from goldfish_amd.model import arrays_from_spec
+from oracle import oracle_py
+from oracle.oracle_py import Oracle
+from tests.torch_model import TorchModel
+
+RTOL = 1e-10
+
+
+def _setup(spec, seed=0, uamp=2e-2):
+    rng = np.random.default_rng(seed)
+    th = [spec.h_th * rng.uniform(0.8, 1.2, p.ncp) for p in spec.patches]
+    A = arrays_from_spec(spec, th)
+    h = np.concatenate(th)
+    u = uamp * rng.standard_normal(A.ndof)
+    O = Oracle(A, thickness=h, u=u)
+    T = TorchModel(spec, A)
+    c = torch.tensor(np.stack(A.cp_hom, 1), requires_grad=True)
+    U = torch.tensor(u.reshape(-1, 3), requires_grad=True)
+    ht = torch.tensor(h, requires_grad=True)
+    return A, O, T, c, U, ht
+
+
+def _relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("name", ["slr9", "tbeam"])
+def test_oracle_vs_autograd(oracle_lib, name):
+    spec = G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2]) if name == "slr9" else G.tbeam_2patch(4)
+    A, O, T, c, U, ht = _setup(spec)
+    free = np.ones(A.ndof, bool)
+    free[A.zero_dofs] = False
+
+    def grad_total(U_, c_, h_):
+        return torch.autograd.grad(T.total(c_, U_, h_), U_, create_graph=True)[0].reshape(-1)
+
+    def grad_shell(U_, h_):
+        return torch.autograd.grad(T.shell_energy(c, U_, h_), U_, create_graph=True)[0].reshape(-1)
+
+    R_ref = grad_total(U, c, ht).detach().numpy().copy()
+    for d, v in zip(A.pl_dof, A.pl_val):
+        R_ref[d] -= v
+    R_ref[~free] = 0
+    R = O.residual()
+    assert _relerr(R, R_ref) < RTOL
+
+    vals = O.assemble()
+    K = O.csr(oracle_py.MAT_K, vals[0]).toarray()
+    C = [O.csr(1 + f, vals[1 + f]).toarray() for f in range(3)]
+    H = O.csr(oracle_py.MAT_DRDH, vals[4]).toarray()
+    n = A.ndof
+    JU, Jc, _ = torch.autograd.functional.jacobian(grad_total, (U, c, ht), vectorize=True)
+    K_ref = JU.reshape(n, n).numpy()
+    C_ref = Jc.numpy().transpose(2, 0, 1)
+    # Dirichlet conventions (nonmatching_opt.py:660-724, 992-1015)
+    Kb = K_ref.copy()
+    Kb[~free, :] = 0
+    Kb[:, ~free] = 0
+    Kb[~free, ~free] = 1
+    assert _relerr(K, Kb) < RTOL
+    for f in range(3):
+        Cb = C_ref[f].copy()
+        Cb[~free, :] = 0
+        assert _relerr(C[f], Cb) < RTOL
+    # dR/dh: shell terms only, no BC treatment -> compare with the shell-only energy
+    _, Jh = torch.autograd.functional.jacobian(grad_shell, (U, ht), vectorize=True)
+    H_ref = Jh.numpy()
+    assert _relerr(H, H_ref) < RTOL
+
+
+def test_functionals_vs_autograd(oracle_lib):
+    spec = G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2])
+    A, O, T, c, U, ht = _setup(spec, seed=3)
+    F = O.functionals(apply_bcs=False)
+    W = T.shell_energy(c, U, ht, with_load=False)
+    gU, gc, gh = torch.autograd.grad(W, (U, c, ht))
+    assert abs(F["Wint"] - W.item()) < 1e-12 * abs(W.item())
+    assert _relerr(F["dWdu"], gU.numpy().ravel()) < RTOL
+    for f in range(3):
+        assert _relerr(F["dWdcp"][f], gc.numpy()[:, f]) < RTOL
+    assert _relerr(F["dWdh"], gh.numpy()) < RTOL
+    V = T.volume(c, ht)
+    gc, gh = torch.autograd.grad(V, (c, ht))
+    assert abs(F["volume"] - V.item()) < 1e-13 * abs(V.item())
+    for f in range(3):
+        assert _relerr(F["dVdcp"][f], gc.numpy()[:, f]) < RTOL
+    assert _relerr(F["dVdh"], gh.numpy()) < RTOL
+    Wp = T.penalty_energy(c, U)
+    assert abs(F["Wpen"] - Wp.item()) < 1e-11 * abs(Wp.item())
+
+
+def test_penalty_point_hessians(oracle_lib):
+    """complex-step Hessians of one mortar vertex vs torch autograd."""
+    from oracle import kl_energy_torch as ke
+    rng = np.random.default_rng(5)
+    Y = rng.standard_normal(12) + np.array([1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 1.0]) * 3
+    y = np.zeros(18)
+    y[0:3], y[9:12] = 0.1 * rng.standard_normal(3), 0.1 * rng.standard_normal(3)
+    y[3:9] = Y[0:6] + 0.05 * rng.standard_normal(6)
+    y[12:18] = Y[6:12] + 0.05 * rng.standard_normal(6)
+    tau = np.array([0.3, 0.9])
+    en, g, Hyy, HyY = oracle_py.penalty_point(y, Y, tau, 7.0, 3.0, 0.25)
+    yt, Yt = torch.tensor(y, requires_grad=True), torch.tensor(Y, requires_grad=True)
+
+    def fn(yt, Yt):
+        return ke.penalty_energy_point(yt[0:3], yt[3:9].reshape(2, 3), yt[9:12], yt[12:18].reshape(2, 3),
+                                       Yt[0:6].reshape(2, 3), Yt[6:12].reshape(2, 3), torch.tensor(tau), 7.0, 3.0, 0.25)
+    e = fn(yt, Yt)
+    ge, = torch.autograd.grad(e, yt, create_graph=True)
+    assert abs(en - e.item()) < 1e-13 * abs(en)
+    assert _relerr(g, ge.detach().numpy()) < 1e-12
+    for r in range(18):
+        a, b = torch.autograd.grad(ge[r], (yt, Yt), retain_graph=True)
+        assert np.abs(Hyy[r] - a.numpy()).max() < 1e-10 * np.abs(Hyy).max()
+        assert np.abs(HyY[r] - b.numpy()).max() < 1e-10 * np.abs(HyY).max()

@@ -1,0 +1,122 @@
+"""Whole-model energies in torch (float64) built from oracle/kl_energy_torch.py;
+autograd of these scalars is the derivative ground truth for the oracle tests."""
+import numpy as np
+import torch
+
+from goldfish_amd.splines import basis_ders, find_span
+from oracle import kl_energy_torch as ke
+
+
+def _gauss(n):
+    return np.polynomial.legendre.leggauss(n)
+
+
+def _rational(Nb, wl):
+    """Nb (6, nb) -> Rb (6, nb) for R = N/W (quotient rule)."""
+    W = Nb @ wl
+    R = Nb[0] / W[0]
+    R1 = (Nb[1] - R * W[1]) / W[0]
+    R2 = (Nb[2] - R * W[2]) / W[0]
+    R11 = (Nb[3] - 2 * R1 * W[1] - R * W[3]) / W[0]
+    R22 = (Nb[4] - 2 * R2 * W[2] - R * W[4]) / W[0]
+    R12 = (Nb[5] - R1 * W[2] - R2 * W[1] - R * W[5]) / W[0]
+    return np.stack([R, R1, R2, R11, R22, R12])
+
+
+def _point_basis(P, wflat, xi):
+    su = find_span(P.n_u, P.p, P.knots[0], xi[0])
+    sv = find_span(P.n_v, P.q, P.knots[1], xi[1])
+    du = basis_ders(su, xi[0], P.p, P.knots[0], 2)
+    dv = basis_ders(sv, xi[1], P.q, P.knots[1], 2)
+    ids, Nb = [], []
+    for jv in range(P.q + 1):
+        for ju in range(P.p + 1):
+            ids.append(P.flat(su - P.p + ju, sv - P.q + jv))
+            Nb.append([du[0, ju] * dv[0, jv], du[1, ju] * dv[0, jv], du[0, ju] * dv[1, jv],
+                       du[2, ju] * dv[0, jv], du[0, ju] * dv[2, jv], du[1, ju] * dv[1, jv]])
+    ids = np.array(ids)
+    Nb = np.array(Nb).T
+    return ids, Nb, _rational(Nb, wflat[ids])
+
+
+class TorchModel:
+    def __init__(self, spec, arrays):
+        self.spec, self.A = spec, arrays
+        ids, Rb, N0, wq, pid = [], [], [], [], []
+        for s, P in enumerate(spec.patches):
+            w = P.cp_hom_flat()[:, 3]
+            off = int(arrays.cp_off[s])
+            for d, (kn, deg) in enumerate(((P.knots[0], P.p), (P.knots[1], P.q))):
+                pass
+            ku, kv = np.unique(P.knots[0]), np.unique(P.knots[1])
+            gxu, gwu = _gauss(P.p + 1)
+            gxv, gwv = _gauss(P.q + 1)
+            for b0, b1 in zip(kv[:-1], kv[1:]):
+                for a0, a1 in zip(ku[:-1], ku[1:]):
+                    for gv, wv in zip(gxv, gwv):
+                        for gu, wu in zip(gxu, gwu):
+                            xi = (0.5 * (a0 + a1) + 0.5 * (a1 - a0) * gu, 0.5 * (b0 + b1) + 0.5 * (b1 - b0) * gv)
+                            i, Nb, R = _point_basis(P, w, xi)
+                            ids.append(i + off)
+                            Rb.append(R)
+                            N0.append(Nb[0])
+                            wq.append(0.25 * (a1 - a0) * (b1 - b0) * wu * wv)
+                            pid.append(s)
+        nbmax = max(len(i) for i in ids)
+        assert all(len(i) == nbmax for i in ids), "mixed degrees not supported by the test helper"
+        self.ids = torch.tensor(np.array(ids))
+        self.Rb = torch.tensor(np.array(Rb))
+        self.N0 = torch.tensor(np.array(N0))
+        self.wq = torch.tensor(np.array(wq))
+        self.pid = torch.tensor(np.array(pid))
+        self.E = torch.tensor(arrays.young)[self.pid]
+        self.nu = torch.tensor(arrays.poisson)[self.pid]
+        self.f = torch.tensor(arrays.body_force.reshape(-1, 3))[self.pid]
+        # mortar points
+        self.mp = []
+        for k, itf in enumerate(spec.interfaces):
+            PA, PB = spec.patches[itf.a], spec.patches[itf.b]
+            wA, wB = PA.cp_hom_flat()[:, 3], PB.cp_hom_flat()[:, 3]
+            for v in range(itf.npts):
+                ia, _, RA = _point_basis(PA, wA, itf.xi_a[v])
+                ib, _, RB = _point_basis(PB, wB, itf.xi_b[v])
+                self.mp.append((torch.tensor(ia + int(arrays.cp_off[itf.a])), torch.tensor(RA[:3]),
+                                torch.tensor(ib + int(arrays.cp_off[itf.b])), torch.tensor(RB[:3]),
+                                torch.tensor(itf.tau[v]), float(arrays.if_alpha[2 * k]), float(arrays.if_alpha[2 * k + 1]),
+                                float(itf.wt[v])))
+
+    def shell_energy(self, c, U, h, with_load=True):
+        """c, U: (total_cp, 3); h: (total_cp,).  Returns W_int - W_ext."""
+        cl, dl = c[self.ids], (c + U)[self.ids]
+        Z = torch.einsum("gma,gak->gmk", self.Rb[:, 1:], cl)
+        z = torch.einsum("gma,gak->gmk", self.Rb[:, 1:], dl)
+        t = (self.N0 * h[self.ids]).sum(-1)
+        Psi = ke.shell_energy_density(z, Z, t, self.E, self.nu)
+        W = (self.wq * Psi).sum()
+        if with_load:
+            uphys = torch.einsum("ga,gak->gk", self.Rb[:, 0], U[self.ids])
+            W = W - (self.wq * ke.area_jacobian(Z) * (self.f * uphys).sum(-1)).sum()
+        return W
+
+    def volume(self, c, h):
+        Z = torch.einsum("gma,gak->gmk", self.Rb[:, 1:], c[self.ids])
+        t = (self.N0 * h[self.ids]).sum(-1)
+        return (self.wq * ke.area_jacobian(Z) * t).sum()
+
+    def penalty_energy(self, c, U):
+        W = torch.zeros((), dtype=torch.float64)
+        for ia, RA, ib, RB, tau, ad, ar, wt in self.mp:
+            uA = RA[0] @ U[ia]
+            uB = RB[0] @ U[ib]
+            gA = RA[1:] @ (c + U)[ia]
+            gB = RB[1:] @ (c + U)[ib]
+            GA = RA[1:] @ c[ia]
+            GB = RB[1:] @ c[ib]
+            W = W + ke.penalty_energy_point(uA, gA, uB, gB, GA, GB, tau, ad, ar, wt)
+        return W
+
+    def total(self, c, U, h):
+        W = self.shell_energy(c, U, h)
+        if self.mp:
+            W = W + self.penalty_energy(c, U)
+        return W
