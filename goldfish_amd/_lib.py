@@ -1,0 +1,183 @@
+"""ctypes binding of libgoldfish_hip.so (include/goldfish_hip.h).  There is no CPU
+fallback: a missing library or a missing GPU raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .model import gf_model_desc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgoldfish_hip.so")
+_LIB = None
+
+ASM_R, ASM_K, ASM_DRDCP, ASM_DRDH, ASM_ALL = 1, 2, 4, 8, 15
+MAT_K, MAT_DRDCP0, MAT_DRDCP1, MAT_DRDCP2, MAT_DRDH = range(5)
+BUF_CP, BUF_U, BUF_H, BUF_R, BUF_VAL_K, BUF_VAL_C0, BUF_VAL_C1, BUF_VAL_C2, BUF_VAL_H = range(9)
+
+EXPORTS = ["gf_device_count", "gf_last_error", "gf_create", "gf_destroy", "gf_total_cp", "gf_num_dofs",
+           "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes", "gf_set_cp",
+           "gf_set_thickness", "gf_set_u", "gf_nnz", "gf_pattern", "gf_assemble", "gf_sync", "gf_get_residual",
+           "gf_get_values", "gf_apply", "gf_functionals", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms"]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libgoldfish_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                               "goldfish_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        dp, vp, i64 = C.POINTER(C.c_double), C.c_void_p, C.c_int64
+        L.gf_device_count.restype = C.c_int
+        L.gf_last_error.restype = C.c_char_p
+        L.gf_create.argtypes = [C.POINTER(gf_model_desc), C.c_int, C.POINTER(vp)]
+        L.gf_destroy.argtypes = [vp]
+        L.gf_destroy.restype = None
+        for name in ("gf_total_cp", "gf_num_dofs", "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes"):
+            getattr(L, name).restype = i64
+            getattr(L, name).argtypes = [vp]
+        L.gf_set_cp.argtypes = [vp, C.c_int, dp, i64]
+        L.gf_set_thickness.argtypes = [vp, dp, i64]
+        L.gf_set_u.argtypes = [vp, dp, i64]
+        L.gf_nnz.restype = i64
+        L.gf_nnz.argtypes = [vp, C.c_int]
+        L.gf_pattern.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        L.gf_assemble.argtypes = [vp, C.c_int]
+        L.gf_sync.argtypes = [vp]
+        L.gf_get_residual.argtypes = [vp, dp, i64]
+        L.gf_get_values.argtypes = [vp, C.c_int, dp, i64]
+        L.gf_apply.argtypes = [vp, C.c_int, C.c_int, dp, i64, dp, i64]
+        L.gf_functionals.argtypes = [vp, dp, dp, dp, dp, dp, dp, C.c_int]
+        L.gf_device_ptr.restype = vp
+        L.gf_device_ptr.argtypes = [vp, C.c_int]
+        L.gf_apply_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+        L.gf_kernel_ms.restype = C.c_double
+        L.gf_kernel_ms.argtypes = [vp, C.POINTER(C.c_int)]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _check(rc, exc=RuntimeError):
+    if rc != 0:
+        raise exc(lib().gf_last_error().decode())
+
+
+class DeviceModel:
+    """Owns one gf_handle: device-resident state, static CSR patterns and results."""
+
+    def __init__(self, arrays, device=0):
+        self.arrays = arrays
+        self._desc = arrays.desc()
+        h = C.c_void_p()
+        _check(lib().gf_create(C.byref(self._desc), int(device), C.byref(h)))
+        self.h = h
+        self.total_cp, self.ndof = arrays.total_cp, arrays.ndof
+        self._pat = {}
+        for f in range(3):
+            self.set_cp(f, arrays.cp_hom[f])
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _vec(self, v, n, what):
+        v = np.ascontiguousarray(v, dtype=np.float64).ravel()
+        if v.size != n:
+            raise ValueError("%s: array of length %d, expected %d" % (what, v.size, n))
+        return v
+
+    def set_cp(self, field, v):
+        v = self._vec(v, self.total_cp, "set_cp")
+        _check(lib().gf_set_cp(self.h, int(field), _dp(v), v.size), ValueError)
+
+    def set_thickness(self, v):
+        v = self._vec(v, self.total_cp, "set_thickness")
+        _check(lib().gf_set_thickness(self.h, _dp(v), v.size), ValueError)
+
+    def set_u(self, v):
+        v = self._vec(v, self.ndof, "set_u")
+        _check(lib().gf_set_u(self.h, _dp(v), v.size), ValueError)
+
+    def pattern(self, which):
+        if which not in self._pat:
+            nnz = lib().gf_nnz(self.h, which)
+            rowptr = np.zeros(self.ndof + 1, np.int64)
+            col = np.zeros(nnz, np.int32)
+            _check(lib().gf_pattern(self.h, which, rowptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                                    col.ctypes.data_as(C.POINTER(C.c_int32))))
+            self._pat[which] = (rowptr, col)
+        return self._pat[which]
+
+    def assemble(self, flags=ASM_ALL, sync=True):
+        _check(lib().gf_assemble(self.h, int(flags)))
+        if sync:
+            _check(lib().gf_sync(self.h))
+
+    def sync(self):
+        _check(lib().gf_sync(self.h))
+
+    def residual(self):
+        R = np.zeros(self.ndof)
+        _check(lib().gf_get_residual(self.h, _dp(R), R.size))
+        return R
+
+    def values(self, which):
+        v = np.zeros(lib().gf_nnz(self.h, which))
+        _check(lib().gf_get_values(self.h, which, _dp(v), v.size))
+        return v
+
+    def csr(self, which):
+        import scipy.sparse as sp
+        rowptr, col = self.pattern(which)
+        ncol = self.ndof if which == MAT_K else self.total_cp
+        return sp.csr_matrix((self.values(which), col, rowptr), shape=(self.ndof, ncol))
+
+    def apply(self, which, x, y, transpose=False):
+        """y += A x  (or A^T x), in place on the NumPy array y."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if not (isinstance(y, np.ndarray) and y.dtype == np.float64 and y.flags.c_contiguous):
+            raise ValueError("apply: y must be a contiguous float64 ndarray (updated in place)")
+        _check(lib().gf_apply(self.h, which, int(bool(transpose)), _dp(x), x.size, _dp(y), y.size), ValueError)
+        return y
+
+    def functionals(self, apply_bcs=True):
+        out = np.zeros(3)
+        g = dict(dWdu=np.zeros(self.ndof), dWdcp=np.zeros((3, self.total_cp)), dWdh=np.zeros(self.total_cp),
+                 dVdcp=np.zeros((3, self.total_cp)), dVdh=np.zeros(self.total_cp))
+        _check(lib().gf_functionals(self.h, _dp(out), _dp(g["dWdu"]), _dp(g["dWdcp"]), _dp(g["dWdh"]),
+                                    _dp(g["dVdcp"]), _dp(g["dVdh"]), int(apply_bcs)))
+        g.update(Wint=out[0], volume=out[1], Wpen=out[2])
+        return g
+
+    def kernel_ms(self):
+        n = C.c_int(0)
+        ms = lib().gf_kernel_ms(self.h, C.byref(n))
+        return ms, n.value
+
+    @property
+    def n_gauss_points(self):
+        return lib().gf_num_gauss_points(self.h)
+
+    @property
+    def n_elements(self):
+        return lib().gf_num_elements(self.h)
+
+    @property
+    def n_mortar_points(self):
+        return lib().gf_num_mortar_points(self.h)
+
+    @property
+    def device_bytes(self):
+        return lib().gf_device_bytes(self.h)

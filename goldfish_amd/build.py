@@ -1,0 +1,40 @@
+"""Builds libgoldfish_hip.so (gfx950) in-tree with hipcc.  The .so is git-ignored but
+travels to the GPU box with the gpurun snapshot."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libgoldfish_hip.so")
+SOURCES = ["gf_lib.hip", "gf_kernels.hpp", "gf_setup.hpp", "kl_point.hpp",
+           os.path.join("..", "..", "include", "goldfish_hip.h"), os.path.join("..", "..", "include", "goldfish_model.h")]
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def needs_build(lib=LIB, sources=SOURCES):
+    if not os.path.exists(lib):
+        return True
+    t = os.path.getmtime(lib)
+    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in sources)
+
+
+def build(force=False, verbose=False):
+    if force or needs_build():
+        cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
+               os.path.join(CSRC, "gf_lib.hip"), "-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    host = os.path.join(CSRC, "libgf_point_host_test.so")
+    if force or needs_build(host, ["point_host_test.cpp", "kl_point.hpp"]):
+        subprocess.check_call([_hipcc(), "-O2", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-x", "hip",
+                               os.path.join(CSRC, "point_host_test.cpp"), "-o", host])
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

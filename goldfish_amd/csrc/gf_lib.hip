@@ -1,0 +1,321 @@
+// gf_lib.hip -- C ABI (include/goldfish_hip.h) of the MI355X shell assembly + sensitivity path.
+// Build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC gf_lib.hip -o ../libgoldfish_hip.so
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace gf {
+constexpr int GF_ASM_R_BIT = 1, GF_ASM_K_BIT = 2, GF_ASM_C_BIT = 4, GF_ASM_H_BIT = 8;
+}
+#include "../../include/goldfish_hip.h"
+#include "gf_kernels.hpp"
+
+using namespace gf;
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return 1; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct Chunk { int p0, p1; long long e0, e1, a0, a1; };
+
+struct gf_handle {
+    int device = 0; hipStream_t stream = nullptr;
+    HostModel H;
+    std::vector<void*> allocs; long long bytes = 0;
+    DevModel M{}; DevPenalty Q{};
+    double *d_cp4 = nullptr, *d_u = nullptr, *d_h = nullptr, *d_R = nullptr, *d_blk = nullptr, *d_pbuf = nullptr;
+    double* d_val[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *d_x = nullptr, *d_y = nullptr;           // staging for host-pointer gf_apply
+    long long* d_pl_dof = nullptr; double* d_pl_val = nullptr;
+    std::vector<Chunk> chunks;
+    std::vector<hipEvent_t> ev0, ev1; int ev_n = 0;   // element-kernel timing
+    bool assembled[5] = {false, false, false, false, false};
+
+    template <class T> T* dalloc(size_t n) {
+        void* p = nullptr; const size_t nb = (n > 0 ? n : 1) * sizeof(T);
+        HIPCHK(hipMalloc(&p, nb)); allocs.push_back(p); bytes += (long long)nb; return (T*)p;
+    }
+    template <class T> T* upload(const std::vector<T>& v) {
+        T* p = dalloc<T>(v.size());
+        if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return p;
+    }
+};
+
+extern "C" {
+
+int gf_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+const char* gf_last_error(void) { return g_err.c_str(); }
+
+int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
+    if (!desc || !out) return fail("gf_create: null argument");
+    *out = nullptr;
+    gf_handle* h = nullptr;
+    try {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("gf_create: no HIP device visible (libgoldfish_hip has no CPU fallback)");
+        if (device < 0 || device >= ndev) throw std::runtime_error("gf_create: device index out of range");
+        h = new gf_handle(); h->device = device;
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreate(&h->stream));
+        h->H.build(desc);
+        HostModel& H = h->H;
+        std::vector<long long> nbs(H.nb_ptr_s.begin(), H.nb_ptr_s.end()), nbc(H.nb_ptr_c.begin(), H.nb_ptr_c.end());
+        h->d_cp4 = h->dalloc<double>(4 * H.total_cp); h->d_u = h->dalloc<double>(H.ndof); h->d_h = h->dalloc<double>(H.total_cp); h->d_R = h->dalloc<double>(H.ndof);
+        {   // weights into the 4th slot, rest zero until gf_set_cp
+            std::vector<double> c4(4 * H.total_cp, 0.0);
+            for (long long a = 0; a < H.total_cp; ++a) c4[4 * a + 3] = H.weights[a];
+            HIPCHK(hipMemcpy(h->d_cp4, c4.data(), c4.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK(hipMemset(h->d_u, 0, H.ndof * sizeof(double))); HIPCHK(hipMemset(h->d_h, 0, H.total_cp * sizeof(double)));
+        }
+        DevModel& M = h->M;
+        M.patches = h->upload(H.patches); M.tab = h->upload(H.tab); M.ints = h->upload(H.ints);
+        M.elem_patch = h->upload(H.elem_patch); M.cp_patch = h->upload(H.cp_patch);
+        M.cp4 = h->d_cp4; M.u = h->d_u; M.h = h->d_h; M.zero = h->upload(H.zero);
+        M.nb_ptr_s = h->upload(nbs); M.nb_s = h->upload(H.nb_s); M.nb_ptr_c = h->upload(nbc); M.nb_c = h->upload(H.nb_c);
+        M.total_cp = H.total_cp; M.nelem = H.nelem;
+        std::vector<long long> pld(H.pl_dof.begin(), H.pl_dof.end());
+        h->d_pl_dof = h->upload(pld); h->d_pl_val = h->upload(H.pl_val);
+        // CSR value arrays
+        const long long nnzc = H.nb_ptr_c[H.total_cp], nnzs = H.nb_ptr_s[H.total_cp];
+        h->d_val[GF_MAT_K] = h->dalloc<double>(9 * nnzc);
+        for (int f = 0; f < 3; ++f) h->d_val[GF_MAT_DRDCP0 + f] = h->dalloc<double>(3 * nnzc);
+        h->d_val[GF_MAT_DRDH] = h->dalloc<double>(3 * nnzs);
+        h->d_x = h->dalloc<double>(H.ndof); h->d_y = h->dalloc<double>(H.ndof);
+        // penalty
+        DevPenalty& Q = h->Q;
+        Q.npts = H.npts;
+        if (H.npts > 0) {
+            std::vector<long long> rp(H.row_ptr.begin(), H.row_ptr.end()), bp(H.blk_ptr.begin(), H.blk_ptr.end());
+            Q.pt_iface = h->upload(H.pt_iface); Q.pt_base = h->upload(H.pt_base); Q.pt_nu = h->upload(H.pt_nu);
+            Q.pt_tau = h->upload(H.pt_tau); Q.pt_wt = h->upload(H.pt_wt); Q.if_patch = h->upload(H.if_patch); Q.if_alpha = h->upload(H.if_alpha);
+            Q.row_items = h->upload(H.row_items); Q.row_ptr = h->upload(rp); Q.blk_items = h->upload(H.blk_items); Q.blk_ptr = h->upload(bp);
+            Q.nrow_groups = (long long)rp.size() - 1; Q.nblk_groups = (long long)bp.size() - 1;
+            h->d_pbuf = h->dalloc<double>((size_t)H.npts * PB_STRIDE);
+        }
+        // element-block scratch, chunked over whole patches
+        const int P = H.degree, NB = (P + 1) * (P + 1), ND = 3 * NB;
+        const long long blk_doubles = 2LL * ND * ND + (long long)ND * NB + ND;
+        double budget_gb = 40.0;
+        if (const char* s = getenv("GF_SCRATCH_GB")) budget_gb = atof(s);
+        const long long max_elems = std::max<long long>(1, (long long)(budget_gb * 1e9 / (blk_doubles * 8.0)));
+        long long biggest = 0;
+        for (int s = 0; s < H.np;) {
+            Chunk c; c.p0 = s; c.e0 = H.patches[s].elem_off; c.a0 = H.patches[s].cp_off;
+            long long ne = 0;
+            while (s < H.np) {
+                const long long pe = (long long)H.patches[s].nelu * H.patches[s].nelv;
+                if (ne > 0 && ne + pe > max_elems) break;
+                ne += pe; ++s;
+            }
+            c.p1 = s; c.e1 = c.e0 + ne; c.a1 = (s < H.np) ? H.patches[s].cp_off : H.total_cp;
+            h->chunks.push_back(c); biggest = std::max(biggest, ne);
+        }
+        h->d_blk = h->dalloc<double>((size_t)biggest * blk_doubles);
+        h->ev0.resize(64); h->ev1.resize(64);
+        for (int k = 0; k < 64; ++k) { HIPCHK(hipEventCreate(&h->ev0[k])); HIPCHK(hipEventCreate(&h->ev1[k])); }
+        HIPCHK(hipDeviceSynchronize());
+    } catch (const std::exception& ex) {
+        if (h) gf_destroy(h);
+        return fail(ex.what());
+    }
+    *out = h;
+    return 0;
+}
+
+void gf_destroy(gf_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : h->allocs) (void)hipFree(p);
+    for (auto e : h->ev0) if (e) (void)hipEventDestroy(e);
+    for (auto e : h->ev1) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int64_t gf_total_cp(const gf_handle* h) { return h->H.total_cp; }
+int64_t gf_num_dofs(const gf_handle* h) { return h->H.ndof; }
+int64_t gf_num_elements(const gf_handle* h) { return h->H.nelem; }
+int64_t gf_num_gauss_points(const gf_handle* h) { return h->H.ngp; }
+int64_t gf_num_mortar_points(const gf_handle* h) { return h->H.npts; }
+int64_t gf_device_bytes(const gf_handle* h) { return h->bytes; }
+
+__global__ void strided_set_kernel(double* dst, int stride, int off, const double* src, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i * stride + off] = src[i];
+}
+static int set_strided(gf_handle* h, double* dst, int stride, int off, const double* src, int64_t n, int64_t expect, const char* who) {
+    if (!h || !src) return fail(std::string(who) + ": null argument");
+    if (n != expect) return fail(std::string(who) + ": array length " + std::to_string(n) + " != expected " + std::to_string(expect));
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        if (stride == 1) HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        else {
+            HIPCHK(hipMemcpyAsync(h->d_x, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(strided_set_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dst, stride, off, h->d_x, (long long)n);
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+    } catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
+}
+int gf_set_cp(gf_handle* h, int field, const double* cp, int64_t n) {
+    if (field < 0 || field > 2) return fail("gf_set_cp: field must be 0, 1 or 2");
+    return set_strided(h, h->d_cp4, 4, field, cp, n, h->H.total_cp, "gf_set_cp");
+}
+int gf_set_thickness(gf_handle* h, const double* v, int64_t n) { return set_strided(h, h->d_h, 1, 0, v, n, h->H.total_cp, "gf_set_thickness"); }
+int gf_set_u(gf_handle* h, const double* v, int64_t n) { return set_strided(h, h->d_u, 1, 0, v, n, h->H.ndof, "gf_set_u"); }
+
+int64_t gf_nnz(const gf_handle* h, int which) {
+    const HostModel& H = h->H;
+    if (which == GF_MAT_K) return 9 * H.nb_ptr_c[H.total_cp];
+    if (which == GF_MAT_DRDH) return 3 * H.nb_ptr_s[H.total_cp];
+    if (which >= GF_MAT_DRDCP0 && which <= GF_MAT_DRDCP2) return 3 * H.nb_ptr_c[H.total_cp];
+    return -1;
+}
+int gf_pattern(const gf_handle* h, int which, int64_t* rowptr, int32_t* col) {
+    if (!h || !rowptr || !col) return fail("gf_pattern: null argument");
+    if (which < 0 || which > 4) return fail("gf_pattern: unknown matrix id");
+    const HostModel& H = h->H;
+    const std::vector<int64_t>& ptr = which == GF_MAT_DRDH ? H.nb_ptr_s : H.nb_ptr_c; const std::vector<int>& nb = which == GF_MAT_DRDH ? H.nb_s : H.nb_c;
+    const int bw = which == GF_MAT_K ? 3 : 1; int64_t pos = 0; rowptr[0] = 0;
+    for (int64_t a = 0; a < H.total_cp; ++a) for (int i = 0; i < 3; ++i) {
+        for (int64_t k = ptr[a]; k < ptr[a + 1]; ++k) for (int j = 0; j < bw; ++j) col[pos++] = nb[k] * bw + j;
+        rowptr[3 * a + i + 1] = pos;
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+template <int P> static void run_assemble(gf_handle* h, int flags) {
+    using Cfg = ElemCfg<P>;
+    for (const Chunk& c : h->chunks) {
+        const long long ne = c.e1 - c.e0, na = c.a1 - c.a0;
+        const int slot = h->ev_n % 64;
+        HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
+        hipLaunchKernelGGL(kl_element_kernel<P>, dim3((unsigned)ne), dim3(Cfg::NT), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+        HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
+        h->ev_n++;
+        hipLaunchKernelGGL(kl_gather_kernel<P>, dim3((unsigned)na), dim3(256), 0, h->stream, h->M, c.a0, c.e0, ne, flags, h->d_blk,
+                           h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R);
+    }
+    const HostModel& H = h->H;
+    if (H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP))) {
+        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf);
+        if (flags & GF_ASM_R) hipLaunchKernelGGL(pen_rows_kernel<P>, dim3((unsigned)((h->Q.nrow_groups + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf, h->d_R);
+        if (flags & (GF_ASM_K | GF_ASM_DRDCP))
+            hipLaunchKernelGGL(pen_blocks_kernel<P>, dim3((unsigned)((h->Q.nblk_groups + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, flags, h->d_pbuf,
+                               h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3]);
+    }
+    if (flags & GF_ASM_R) {
+        const long long npl = (long long)H.pl_dof.size();
+        if (npl > 0) hipLaunchKernelGGL(residual_finish_kernel, dim3((unsigned)((npl + 255) / 256)), dim3(256), 0, h->stream, (long long)H.ndof, h->M.zero, npl, h->d_pl_dof, h->d_pl_val, h->d_R);
+        hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((H.ndof + 255) / 256)), dim3(256), 0, h->stream, (long long)H.ndof, h->M.zero, h->d_R);
+    }
+    HIPCHK(hipGetLastError());
+}
+
+extern "C" {
+
+int gf_assemble(gf_handle* h, int flags) {
+    if (!h) return fail("gf_assemble: null handle");
+    if (flags == 0 || (flags & ~GF_ASM_ALL)) return fail("gf_assemble: bad flags");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        switch (h->H.degree) {
+            case 2: run_assemble<2>(h, flags); break;
+            case 3: run_assemble<3>(h, flags); break;
+            case 4: run_assemble<4>(h, flags); break;
+            default: throw std::runtime_error("gf_assemble: unsupported degree");
+        }
+        if (flags & GF_ASM_K) h->assembled[GF_MAT_K] = true;
+        if (flags & GF_ASM_DRDCP) h->assembled[1] = h->assembled[2] = h->assembled[3] = true;
+        if (flags & GF_ASM_DRDH) h->assembled[GF_MAT_DRDH] = true;
+    } catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
+}
+
+int gf_sync(gf_handle* h) {
+    if (!h) return fail("gf_sync: null handle");
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(std::string("gf_sync: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int gf_get_residual(gf_handle* h, double* R, int64_t n) {
+    if (!h || !R) return fail("gf_get_residual: null argument");
+    if (n != h->H.ndof) return fail("gf_get_residual: wrong length");
+    try { HIPCHK(hipMemcpyAsync(R, h->d_R, n * sizeof(double), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); }
+    catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
+}
+int gf_get_values(gf_handle* h, int which, double* vals, int64_t n) {
+    if (!h || !vals) return fail("gf_get_values: null argument");
+    if (which < 0 || which > 4) return fail("gf_get_values: unknown matrix id");
+    if (n != gf_nnz(h, which)) return fail("gf_get_values: wrong length");
+    if (!h->assembled[which]) return fail("gf_get_values: matrix has not been assembled");
+    try { HIPCHK(hipMemcpyAsync(vals, h->d_val[which], n * sizeof(double), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); }
+    catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
+}
+
+int gf_apply_dev(gf_handle* h, int which, int transpose, const double* x, double* y) {
+    if (!h || !x || !y) return fail("gf_apply: null argument");
+    if (which < 0 || which > 4) return fail("gf_apply: unknown matrix id");
+    if (!h->assembled[which]) return fail("gf_apply: matrix has not been assembled");
+    const long long* ptr = which == GF_MAT_DRDH ? h->M.nb_ptr_s : h->M.nb_ptr_c; const int* nb = which == GF_MAT_DRDH ? h->M.nb_s : h->M.nb_c;
+    const int bw = which == GF_MAT_K ? 3 : 1; const long long nrows = h->H.ndof;
+    const unsigned grid = (unsigned)((nrows * 64 + 255) / 256);
+    if (!transpose) hipLaunchKernelGGL(csr_apply_kernel, dim3(grid), dim3(256), 0, h->stream, nrows, ptr, nb, bw, h->d_val[which], x, y);
+    else hipLaunchKernelGGL(csr_apply_t_kernel, dim3(grid), dim3(256), 0, h->stream, nrows, ptr, nb, bw, h->d_val[which], x, y);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(std::string("gf_apply: ") + hipGetErrorString(e));
+    return 0;
+}
+int gf_apply(gf_handle* h, int which, int transpose, const double* x, int64_t nx, double* y, int64_t ny) {
+    if (!h || !x || !y) return fail("gf_apply: null argument");
+    if (which < 0 || which > 4) return fail("gf_apply: unknown matrix id");
+    const int64_t nrow = h->H.ndof, ncol = which == GF_MAT_K ? h->H.ndof : h->H.total_cp;
+    const int64_t ex = transpose ? nrow : ncol, ey = transpose ? ncol : nrow;
+    if (nx != ex || ny != ey) return fail("gf_apply: vector lengths do not match the matrix shape");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipMemcpyAsync(h->d_x, x, nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_y, y, ny * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (gf_apply_dev(h, which, transpose, h->d_x, h->d_y)) return 1;
+        HIPCHK(hipMemcpyAsync(y, h->d_y, ny * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    } catch (const std::exception& ex2) { return fail(ex2.what()); }
+    return 0;
+}
+
+void* gf_device_ptr(gf_handle* h, int which) {
+    if (!h) return nullptr;
+    switch (which) {
+        case GF_BUF_CP: return h->d_cp4; case GF_BUF_U: return h->d_u; case GF_BUF_H: return h->d_h; case GF_BUF_R: return h->d_R;
+        case GF_BUF_VAL_K: return h->d_val[0]; case GF_BUF_VAL_C0: return h->d_val[1]; case GF_BUF_VAL_C1: return h->d_val[2];
+        case GF_BUF_VAL_C2: return h->d_val[3]; case GF_BUF_VAL_H: return h->d_val[4];
+    }
+    return nullptr;
+}
+
+double gf_kernel_ms(gf_handle* h, int* n_launches) {
+    if (!h) return 0.0;
+    (void)hipStreamSynchronize(h->stream);
+    const int n = h->ev_n < 64 ? h->ev_n : 64; double tot = 0.0;
+    for (int k = 0; k < n; ++k) { float ms = 0.f; if (hipEventElapsedTime(&ms, h->ev0[k], h->ev1[k]) == hipSuccess) tot += ms; }
+    if (n_launches) *n_launches = n;
+    h->ev_n = 0;
+    return n > 0 ? tot / n : 0.0;
+}
+
+int gf_functionals(gf_handle* h, double out[3], double* dWdu, double* dWdcp, double* dWdh, double* dVdcp, double* dVdh, int apply_bcs) {
+    (void)h; (void)out; (void)dWdu; (void)dWdcp; (void)dWdh; (void)dVdcp; (void)dVdh; (void)apply_bcs;
+    return fail("gf_functionals: not implemented yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+// gf_setup.hpp -- host-side preprocessing of a gf_model_desc into the flat tables the
+// kernels read: knot-span elements, 1-D Gauss/basis tables, control-point -> element ranges,
+// neighbour (CSR block) lists, mortar-point basis values and the deterministic
+// "owner" lists of the penalty coupling.  Pure C++ (no HIP calls).
+//
+// Reference counterparts: tIGAr ExtractedSpline construction + PENGoLINS
+// create_transfer_matrix_list (nonmatching_opt.py:589-612, 1124-1136) -- here the
+// "transfer matrices" A0/A1 are just the rational basis values/first derivatives at the
+// mortar vertices, and the FE<->IGA extraction does not exist.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/goldfish_model.h"
+
+namespace gf {
+
+constexpr int MAXP = 4;
+constexpr int MAXNB = (MAXP + 1) * (MAXP + 1);
+
+struct PatchDev {            // POD mirrored on the device
+    int p, q, nu, nv, nelu, nelv;
+    int tabu, tabv;          // offsets into tab[] : [nel][ng][3][deg+1]
+    int wu, wv;              // offsets into tab[] : [nel][ng]
+    int spu, spv;            // offsets into ints[] : span index per element
+    int c2u, c2v;            // offsets into ints[] : [n][2] first/last element touching CP index
+    long long cp_off, elem_off;
+    double E, nu_, f[3];
+};
+
+struct PenBlockItem { int a, k, b, code, lo, hi; };   // code = iface*4 + s*2 + t ; points [lo,hi] global ids
+struct PenRowItem { int a, code, lo, hi; };           // code = iface*2 + s
+
+inline void gauss_legendre(int n, double* x, double* w) {
+    for (int i = 0; i < n; ++i) {
+        double z = std::cos(M_PI * (i + 0.75) / (n + 0.5)), pp = 0;
+        for (int it = 0; it < 100; ++it) {
+            double p1 = 1, p2 = 0;
+            for (int j = 1; j <= n; ++j) { double p3 = p2; p2 = p1; p1 = ((2.0 * j - 1) * z * p2 - (j - 1.0) * p3) / j; }
+            pp = n * (z * p1 - p2) / (z * z - 1);
+            double dz = p1 / pp; z -= dz;
+            if (std::fabs(dz) < 1e-16) break;
+        }
+        x[n - 1 - i] = z; w[n - 1 - i] = 2 / ((1 - z * z) * pp * pp);
+    }
+}
+
+inline int find_span(int n, int p, const double* U, double xi) {
+    if (xi >= U[n]) { int i = n - 1; while (i > p && U[i] >= U[i + 1]) --i; return i; }
+    if (xi <= U[p]) { int i = p; while (i < n - 1 && U[i] >= U[i + 1]) ++i; return i; }
+    int lo = p, hi = n, mid = (lo + hi) / 2;
+    while (xi < U[mid] || xi >= U[mid + 1]) { if (xi < U[mid]) hi = mid; else lo = mid; mid = (lo + hi) / 2; }
+    return mid;
+}
+
+// values, first and second derivatives of the p+1 non-zero B-spline basis functions
+inline void basis_ders(int span, double xi, int p, const double* U, double ders[3][MAXP + 1]) {
+    double ndu[MAXP + 1][MAXP + 1], left[MAXP + 1], right[MAXP + 1], a[2][MAXP + 1];
+    ndu[0][0] = 1;
+    for (int j = 1; j <= p; ++j) {
+        left[j] = xi - U[span + 1 - j]; right[j] = U[span + j] - xi;
+        double saved = 0;
+        for (int r = 0; r < j; ++r) {
+            ndu[j][r] = right[r + 1] + left[j - r];
+            double temp = ndu[r][j - 1] / ndu[j][r];
+            ndu[r][j] = saved + right[r + 1] * temp; saved = left[j - r] * temp;
+        }
+        ndu[j][j] = saved;
+    }
+    for (int j = 0; j <= p; ++j) ders[0][j] = ndu[j][p];
+    for (int k = 1; k <= 2; ++k) for (int j = 0; j <= p; ++j) ders[k][j] = 0;
+    const int nd = p < 2 ? p : 2;
+    for (int r = 0; r <= p; ++r) {
+        int s1 = 0, s2 = 1; a[0][0] = 1;
+        for (int k = 1; k <= nd; ++k) {
+            double d = 0; const int rk = r - k, pk = p - k;
+            if (r >= k) { a[s2][0] = a[s1][0] / ndu[pk + 1][rk]; d = a[s2][0] * ndu[rk][pk]; }
+            const int j1 = rk >= -1 ? 1 : -rk, j2 = (r - 1 <= pk) ? k - 1 : p - r;
+            for (int j = j1; j <= j2; ++j) { a[s2][j] = (a[s1][j] - a[s1][j - 1]) / ndu[pk + 1][rk + j]; d += a[s2][j] * ndu[rk + j][pk]; }
+            if (r <= pk) { a[s2][k] = -a[s1][k - 1] / ndu[pk + 1][r]; d += a[s2][k] * ndu[r][pk]; }
+            ders[k][r] = d; std::swap(s1, s2);
+        }
+    }
+    double r = p;
+    for (int k = 1; k <= nd; ++k) { for (int j = 0; j <= p; ++j) ders[k][j] *= r; r *= (p - k); }
+}
+
+struct HostModel {
+    int np = 0, degree = 0, ni = 0;
+    int64_t total_cp = 0, ndof = 0, nelem = 0, ngp = 0, npts = 0;
+    std::vector<PatchDev> patches;
+    std::vector<double> tab;            // 1-D tables
+    std::vector<int> ints;              // spans + cp->element ranges
+    std::vector<int> elem_patch;        // [nelem]
+    std::vector<int> cp_patch;          // [total_cp]
+    std::vector<double> weights;
+    std::vector<unsigned char> zero;    // [ndof]
+    std::vector<int64_t> pl_dof; std::vector<double> pl_val;
+    // neighbour lists (CP level): shell only / shell + coupling
+    std::vector<int64_t> nb_ptr_s, nb_ptr_c; std::vector<int> nb_s, nb_c;
+    // mortar points
+    std::vector<int> pt_iface;          // [npts]
+    std::vector<int> pt_base;           // [npts][2][2] (iu0, iv0) per side
+    std::vector<double> pt_nu;          // [npts][2][3][NB] rational value/d1/d2
+    std::vector<double> pt_tau, pt_wt;  // [npts][2], [npts]
+    std::vector<int> if_patch; std::vector<double> if_alpha; std::vector<int64_t> if_off;
+    // deterministic owner lists
+    std::vector<PenRowItem> row_items; std::vector<int64_t> row_ptr;      // groups by CP a
+    std::vector<PenBlockItem> blk_items; std::vector<int64_t> blk_ptr;    // groups by (a,k)
+
+    void build(const gf_model_desc* D);
+};
+
+inline void HostModel::build(const gf_model_desc* D) {
+    np = D->n_patches;
+    if (np <= 0) throw std::runtime_error("gf_create: model has no patches");
+    degree = D->degree[0];
+    if (degree < 2 || degree > MAXP) throw std::runtime_error("gf_create: degree must be 2.." + std::to_string(MAXP) + " (KL shells need C1)");
+    total_cp = D->cp_off[np]; ndof = 3 * total_cp;
+    if (total_cp >= (int64_t(1) << 31) / 3) throw std::runtime_error("gf_create: too many control points for 32-bit column ids");
+    patches.resize(np); cp_patch.resize(total_cp);
+    weights.assign(D->weights, D->weights + total_cp);
+    nelem = 0; ngp = 0;
+    for (int s = 0; s < np; ++s) {
+        PatchDev& P = patches[s];
+        P.p = D->degree[2 * s]; P.q = D->degree[2 * s + 1];
+        if (P.p != degree || P.q != degree) throw std::runtime_error("gf_create: all patches must share one degree p = q (got a mixed-degree model)");
+        P.nu = D->ncp[2 * s]; P.nv = D->ncp[2 * s + 1];
+        P.cp_off = D->cp_off[s]; P.E = D->young[s]; P.nu_ = D->poisson[s];
+        if (D->cp_off[s + 1] - D->cp_off[s] != int64_t(P.nu) * P.nv) throw std::runtime_error("gf_create: cp_off inconsistent with ncp");
+        for (int k = 0; k < 3; ++k) P.f[k] = D->body_force ? D->body_force[3 * s + k] : 0.0;
+        for (int64_t a = P.cp_off; a < D->cp_off[s + 1]; ++a) cp_patch[a] = s;
+        for (int d = 0; d < 2; ++d) {
+            const int p = d ? P.q : P.p, n = d ? P.nv : P.nu;
+            const double* U = D->knots + D->knot_off[2 * s + d];
+            if (D->knot_off[2 * s + d + 1] - D->knot_off[2 * s + d] != n + p + 1) throw std::runtime_error("gf_create: knot vector length != n + p + 1");
+            std::vector<int> sp;
+            for (int i = p; i < n; ++i) if (U[i + 1] > U[i]) sp.push_back(i);
+            const int nel = (int)sp.size(), ng = p + 1;
+            double gx[MAXP + 2], gw[MAXP + 2]; gauss_legendre(ng, gx, gw);
+            const int t0 = (int)tab.size(); tab.resize(t0 + size_t(nel) * ng * 3 * (p + 1));
+            const int w0 = (int)tab.size(); tab.resize(w0 + size_t(nel) * ng);
+            for (int e = 0; e < nel; ++e) for (int g = 0; g < ng; ++g) {
+                const double a = U[sp[e]], b = U[sp[e] + 1], xi = 0.5 * (a + b) + 0.5 * (b - a) * gx[g];
+                double ders[3][MAXP + 1]; basis_ders(sp[e], xi, p, U, ders);
+                for (int k = 0; k < 3; ++k) for (int j = 0; j <= p; ++j) tab[t0 + ((size_t(e) * ng + g) * 3 + k) * (p + 1) + j] = ders[k][j];
+                tab[w0 + e * ng + g] = 0.5 * (b - a) * gw[g];
+            }
+            const int s0 = (int)ints.size(); ints.insert(ints.end(), sp.begin(), sp.end());
+            const int c0 = (int)ints.size(); ints.resize(c0 + 2 * n);
+            for (int i = 0; i < n; ++i) {            // elements whose support contains CP index i: span in [i, i+p]
+                int lo = nel, hi = -1;
+                for (int e = 0; e < nel; ++e) if (sp[e] >= i && sp[e] <= i + p) { lo = std::min(lo, e); hi = std::max(hi, e); }
+                ints[c0 + 2 * i] = lo; ints[c0 + 2 * i + 1] = hi;
+            }
+            if (d) { P.nelv = nel; P.tabv = t0; P.wv = w0; P.spv = s0; P.c2v = c0; }
+            else   { P.nelu = nel; P.tabu = t0; P.wu = w0; P.spu = s0; P.c2u = c0; }
+        }
+        P.elem_off = nelem; nelem += int64_t(P.nelu) * P.nelv;
+        ngp += int64_t(P.nelu) * P.nelv * (P.p + 1) * (P.q + 1);
+    }
+    if (nelem >= (int64_t(1) << 31)) throw std::runtime_error("gf_create: too many elements");
+    elem_patch.resize(nelem);
+    for (int s = 0; s < np; ++s) std::fill(elem_patch.begin() + patches[s].elem_off, elem_patch.begin() + patches[s].elem_off + int64_t(patches[s].nelu) * patches[s].nelv, s);
+    zero.assign(ndof, 0);
+    for (int64_t k = 0; k < D->n_zero_dofs; ++k) {
+        if (D->zero_dofs[k] < 0 || D->zero_dofs[k] >= ndof) throw std::runtime_error("gf_create: zero_dofs out of range");
+        zero[D->zero_dofs[k]] = 1;
+    }
+    for (int64_t k = 0; k < D->n_point_loads; ++k) {
+        if (D->pl_dof[k] < 0 || D->pl_dof[k] >= ndof) throw std::runtime_error("gf_create: pl_dof out of range");
+        pl_dof.push_back(D->pl_dof[k]); pl_val.push_back(D->pl_val[k]);
+    }
+
+    // ---- mortar points ------------------------------------------------------------
+    ni = D->n_interfaces;
+    const int NB = (degree + 1) * (degree + 1);
+    npts = ni > 0 ? D->if_off[ni] : 0;
+    if_patch.assign(D->if_patch, D->if_patch + 2 * ni); if_alpha.assign(D->if_alpha, D->if_alpha + 2 * ni);
+    if_off.assign(D->if_off, D->if_off + ni + 1);
+    pt_iface.resize(npts); pt_base.resize(4 * npts); pt_nu.assign(size_t(npts) * 2 * 3 * NB, 0.0);
+    pt_tau.assign(D->if_tau, D->if_tau + 2 * npts); pt_wt.assign(D->if_wt, D->if_wt + npts);
+    for (int i = 0; i < ni; ++i) {
+        for (int sd = 0; sd < 2; ++sd) if (if_patch[2 * i + sd] < 0 || if_patch[2 * i + sd] >= np) throw std::runtime_error("gf_create: if_patch out of range");
+        for (int64_t v = if_off[i]; v < if_off[i + 1]; ++v) {
+            pt_iface[v] = i;
+            for (int sd = 0; sd < 2; ++sd) {
+                const int s = if_patch[2 * i + sd]; const PatchDev& P = patches[s];
+                const double* Uu = D->knots + D->knot_off[2 * s]; const double* Uv = D->knots + D->knot_off[2 * s + 1];
+                const double xu = D->if_xi[4 * v + 2 * sd], xv = D->if_xi[4 * v + 2 * sd + 1];
+                const int su = find_span(P.nu, P.p, Uu, xu), sv = find_span(P.nv, P.q, Uv, xv);
+                double du[3][MAXP + 1], dv[3][MAXP + 1]; basis_ders(su, xu, P.p, Uu, du); basis_ders(sv, xv, P.q, Uv, dv);
+                double N[3][MAXNB], W[3] = {0, 0, 0};
+                for (int jv = 0; jv <= P.q; ++jv) for (int ju = 0; ju <= P.p; ++ju) {
+                    const int a = ju + jv * (P.p + 1);
+                    const double w = weights[P.cp_off + (su - P.p + ju) + int64_t(sv - P.q + jv) * P.nu];
+                    N[0][a] = du[0][ju] * dv[0][jv]; N[1][a] = du[1][ju] * dv[0][jv]; N[2][a] = du[0][ju] * dv[1][jv];
+                    for (int k = 0; k < 3; ++k) W[k] += N[k][a] * w;
+                }
+                pt_base[4 * v + 2 * sd] = su - P.p; pt_base[4 * v + 2 * sd + 1] = sv - P.q;
+                double* o = &pt_nu[(size_t(v) * 2 + sd) * 3 * NB];
+                for (int a = 0; a < NB; ++a) {
+                    const double R = N[0][a] / W[0];
+                    o[a] = R; o[NB + a] = (N[1][a] - R * W[1]) / W[0]; o[2 * NB + a] = (N[2][a] - R * W[2]) / W[0];
+                }
+            }
+        }
+    }
+
+    // ---- per (interface, side): CP -> bounding range of mortar points -------------------
+    struct CpRange { int cp, lo, hi; };
+    std::vector<std::vector<CpRange>> ranges(2 * size_t(ni));
+    {
+        std::vector<int> lo(total_cp, -1), hi(total_cp, -1);
+        for (int i = 0; i < ni; ++i) for (int sd = 0; sd < 2; ++sd) {
+            const PatchDev& P = patches[if_patch[2 * i + sd]];
+            std::vector<int> touched;
+            for (int64_t v = if_off[i]; v < if_off[i + 1]; ++v)
+                for (int jv = 0; jv <= P.q; ++jv) for (int ju = 0; ju <= P.p; ++ju) {
+                    const int64_t a = P.cp_off + (pt_base[4 * v + 2 * sd] + ju) + int64_t(pt_base[4 * v + 2 * sd + 1] + jv) * P.nu;
+                    if (lo[a] < 0) { lo[a] = (int)v; touched.push_back((int)a); }
+                    hi[a] = (int)v;
+                }
+            std::sort(touched.begin(), touched.end());
+            for (int a : touched) { ranges[2 * i + sd].push_back({a, lo[a], hi[a]}); lo[a] = hi[a] = -1; }
+        }
+    }
+    // coupling partners per CP and the block / row owner lists
+    std::vector<std::vector<int>> extra(total_cp);
+    for (int i = 0; i < ni; ++i) for (int s = 0; s < 2; ++s) for (int t = 0; t < 2; ++t)
+        for (const CpRange& A : ranges[2 * i + s]) for (const CpRange& B : ranges[2 * i + t])
+            if (A.lo <= B.hi && B.lo <= A.hi) extra[A.cp].push_back(B.cp);
+    nb_ptr_s.assign(total_cp + 1, 0); nb_ptr_c.assign(total_cp + 1, 0);
+    std::vector<int> box;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) { nb_s.resize(nb_ptr_s[total_cp]); nb_c.resize(nb_ptr_c[total_cp]); }
+        for (int s = 0; s < np; ++s) {
+            const PatchDev& P = patches[s];
+            const int *spu = &ints[P.spu], *spv = &ints[P.spv], *c2u = &ints[P.c2u], *c2v = &ints[P.c2v];
+            for (int j = 0; j < P.nv; ++j) for (int i = 0; i < P.nu; ++i) {
+                const int64_t a = P.cp_off + i + int64_t(j) * P.nu;
+                box.clear();
+                if (c2u[2 * i + 1] >= 0 && c2v[2 * j + 1] >= 0) {
+                    const int i0 = spu[c2u[2 * i]] - P.p, i1 = spu[c2u[2 * i + 1]], j0 = spv[c2v[2 * j]] - P.q, j1 = spv[c2v[2 * j + 1]];
+                    for (int jj = j0; jj <= j1; ++jj) for (int ii = i0; ii <= i1; ++ii) box.push_back(int(P.cp_off + ii + int64_t(jj) * P.nu));
+                }
+                if (pass == 0) {
+                    nb_ptr_s[a + 1] = nb_ptr_s[a] + (int64_t)box.size();
+                    std::vector<int>& ex = extra[a];
+                    if (!ex.empty()) {
+                        ex.insert(ex.end(), box.begin(), box.end());
+                        std::sort(ex.begin(), ex.end()); ex.erase(std::unique(ex.begin(), ex.end()), ex.end());
+                        nb_ptr_c[a + 1] = nb_ptr_c[a] + (int64_t)ex.size();
+                    } else nb_ptr_c[a + 1] = nb_ptr_c[a] + (int64_t)box.size();
+                } else {
+                    std::copy(box.begin(), box.end(), nb_s.begin() + nb_ptr_s[a]);
+                    const std::vector<int>& src = extra[a].empty() ? box : extra[a];
+                    std::copy(src.begin(), src.end(), nb_c.begin() + nb_ptr_c[a]);
+                }
+            }
+        }
+    }
+    // owner lists: rows grouped by CP, blocks grouped by (a, slot k)
+    {
+        std::vector<PenRowItem> rows;
+        for (int i = 0; i < ni; ++i) for (int s = 0; s < 2; ++s) for (const CpRange& A : ranges[2 * i + s]) rows.push_back({A.cp, 2 * i + s, A.lo, A.hi});
+        std::stable_sort(rows.begin(), rows.end(), [](const PenRowItem& x, const PenRowItem& y) { return x.a < y.a; });
+        row_items = rows; row_ptr.clear(); row_ptr.push_back(0);
+        for (size_t k = 1; k <= rows.size(); ++k) if (k == rows.size() || rows[k].a != rows[k - 1].a) row_ptr.push_back((int64_t)k);
+        std::vector<PenBlockItem> blks;
+        for (int i = 0; i < ni; ++i) for (int s = 0; s < 2; ++s) for (int t = 0; t < 2; ++t)
+            for (const CpRange& A : ranges[2 * i + s]) for (const CpRange& B : ranges[2 * i + t])
+                if (A.lo <= B.hi && B.lo <= A.hi) {
+                    const int* b0 = &nb_c[nb_ptr_c[A.cp]]; const int* b1 = &nb_c[nb_ptr_c[A.cp + 1]];
+                    const int k = int(std::lower_bound(b0, b1, B.cp) - b0);
+                    blks.push_back({A.cp, k, B.cp, 4 * i + 2 * s + t, std::max(A.lo, B.lo), std::min(A.hi, B.hi)});
+                }
+        std::stable_sort(blks.begin(), blks.end(), [](const PenBlockItem& x, const PenBlockItem& y) { return x.a != y.a ? x.a < y.a : x.k < y.k; });
+        blk_items = blks; blk_ptr.clear(); blk_ptr.push_back(0);
+        for (size_t k = 1; k <= blks.size(); ++k) if (k == blks.size() || blks[k].a != blks[k - 1].a || blks[k].k != blks[k - 1].k) blk_ptr.push_back((int64_t)k);
+    }
+}
+
+}  // namespace gf

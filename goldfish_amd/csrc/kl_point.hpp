@@ -1,0 +1,334 @@
+// kl_point.hpp -- pointwise closed forms of the Kirchhoff-Love / SVK shell energy density
+// Psi(z, Z, t) and of the Herrema penalty energy pi(y, Y), device side (gfx950, FP64 VALU).
+//
+// Replaces what the reference obtains from UFL `derivative()` of ShNAPr's
+// surfaceEnergyDensitySVK / PENGoLINS' penalty_energy + FFC code generation
+// (GOLDFISH/nonmatching_opt.py:433-452 set_residuals, :404-420 mortar_dRmdCPm_symexp;
+// GOLDFISH/utils/opt_utils.py:212-228 dRmdcpm_sub).  Derivation and notation:
+// DESIGN.md section 3; the same formulas are checked against autograd on the host in
+// tests/test_pointwise_forms.py.
+//
+// z = (g1,g2,h11,h22,h12) deformed, Z = (G1,G2,H11,H22,H12) reference; flattened index 3*m+i.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#define GF_HD __host__ __device__
+
+namespace gf {
+
+// ---- layout of the per-Gauss-point intermediate record (doubles) -------------------
+enum : int {
+    IM_J = 0, IM_T = 1, IM_WQ = 2, IM_PSI = 3,
+    IM_W = 4,        // [6]  W and its parametric derivatives (for the rational basis)
+    IM_G = 10,       // [6]  g1, g2
+    IM_N = 16,       // [3]  deformed unit normal
+    IM_NB = 19,      // [3]  reference unit normal
+    IM_BG = 22,      // [3][6] d beta_k / d(g1,g2)
+    IM_CEZ = 40,     // [3][6] J t  C ez
+    IM_CBG = 58,     // [3][6] J t3 C bg
+    IM_CT3 = 76,     // [6]  J t3 C  (00,01,02,11,12,22)
+    IM_JNV = 82,     // [3]  J * membrane resultants (Voigt)
+    IM_HMN = 85,     // [6][6] J * Hessian of (M . n)
+    IM_DN = 121,     // [3][6] dn_i / d(g1,g2)
+    IM_JMOF = 139,   // [3]  J mo_k f_k
+    IM_PZ = 142,     // [15] dPsi/dz
+    IM_PZT = 157,    // [15] d2Psi/dz dt
+    IM_JZJ = 172,    // [6]  (dJ/dZ)/J
+    IM_JDNV = 178,   // [3][6] J d(nv)/dZ
+    IM_JDMO = 196,   // [3][6] J d(mo)/dZ (tangent columns)
+    IM_SIZE = 214
+};
+
+GF_HD __forceinline__ void cross3(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+GF_HD __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// idx of symmetric 3x3 stored as (00,01,02,11,12,22)
+GF_HD __forceinline__ int sym3(int a, int b) {
+    const int lut[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+    return lut[3 * a + b];
+}
+
+// n = unit(g1 x g2), j = |g1 x g2|, Dn[i][c] = dn_i / d(g1,g2)_c  (c = 0..5)
+GF_HD inline void normal_derivs(const double* g1, const double* g2, double* n, double& j, double Dn[3][6]) {
+    double nt[3]; cross3(g1, g2, nt);
+    j = sqrt(dot3(nt, nt));
+    const double ij = 1.0 / j;
+    for (int k = 0; k < 3; ++k) n[k] = nt[k] * ij;
+    // B = [-skew(g2) | skew(g1)], column c: d(g1 x g2)/d(.)_c ; Dn = (I - n n^T)/j * B
+    for (int c = 0; c < 6; ++c) {
+        double e[3] = {0, 0, 0}, col[3];
+        e[c % 3] = 1.0;
+        if (c < 3) cross3(e, g2, col); else cross3(g1, e, col);
+        const double nc = dot3(n, col);
+        for (int i = 0; i < 3; ++i) Dn[i][c] = (col[i] - n[i] * nc) * ij;
+    }
+}
+
+// H[6][6] = Hessian of (M . n(g1,g2)); see oracle/kl_point_numpy.py hess_M_dot_n
+GF_HD inline void hess_M_dot_n(const double* g1, const double* g2, const double* n, double j, const double* M, double H[6][6]) {
+    const double Mn = dot3(M, n), ij2 = 1.0 / (j * j);
+    double Q[3][3], v[3];
+    for (int a = 0; a < 3; ++a) {
+        v[a] = (M[a] - Mn * n[a]) / j;
+        for (int b = 0; b < 3; ++b) Q[a][b] = -(M[a] * n[b] + n[a] * M[b] + Mn * ((a == b ? 1.0 : 0.0) - 3.0 * n[a] * n[b])) * ij2;
+    }
+    double Bc[6][3], QB[6][3];
+    for (int c = 0; c < 6; ++c) {
+        double e[3] = {0, 0, 0}; e[c % 3] = 1.0;
+        if (c < 3) cross3(e, g2, Bc[c]); else cross3(g1, e, Bc[c]);
+        for (int a = 0; a < 3; ++a) QB[c][a] = Q[a][0] * Bc[c][0] + Q[a][1] * Bc[c][1] + Q[a][2] * Bc[c][2];
+    }
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[r][c] = dot3(Bc[r], QB[c]);
+    // +- skew(v) on the (g1,g2) / (g2,g1) blocks
+    const double S[3][3] = {{0, -v[2], v[1]}, {v[2], 0, -v[0]}, {-v[1], v[0], 0}};
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { H[a][3 + b] -= S[a][b]; H[3 + a][b] += S[a][b]; }
+}
+
+// Material tensor (curvilinear Voigt, symmetric 6-storage) and dC/dA_q, q = (A11, A22, A12)
+GF_HD inline void material(const double* G1, const double* G2, double E, double nu, double C[6], double dC[3][6], double& J) {
+    const double A11 = dot3(G1, G1), A22 = dot3(G2, G2), A12 = dot3(G1, G2);
+    const double det = A11 * A22 - A12 * A12, id = 1.0 / det;
+    const double c11 = A22 * id, c22 = A11 * id, c12 = -A12 * id, Eb = E / (1.0 - nu * nu);
+    J = sqrt(det);
+    C[0] = Eb * c11 * c11; C[1] = Eb * (nu * c11 * c22 + (1 - nu) * c12 * c12); C[2] = Eb * c11 * c12;
+    C[3] = Eb * c22 * c22; C[4] = Eb * c22 * c12; C[5] = Eb * 0.5 * ((1 - nu) * c11 * c22 + (1 + nu) * c12 * c12);
+    const double dc[3][3] = {{-c11 * c11, -c12 * c12, -2 * c11 * c12},
+                             {-c12 * c12, -c22 * c22, -2 * c12 * c22},
+                             {-c11 * c12, -c12 * c22, -(c11 * c22 + c12 * c12)}};   // rows (c11,c22,c12), cols q
+    for (int q = 0; q < 3; ++q) {
+        const double d11 = dc[0][q], d22 = dc[1][q], d12 = dc[2][q];
+        dC[q][0] = Eb * 2 * c11 * d11;
+        dC[q][1] = Eb * (nu * (d11 * c22 + c11 * d22) + 2 * (1 - nu) * c12 * d12);
+        dC[q][2] = Eb * (d11 * c12 + c11 * d12);
+        dC[q][3] = Eb * 2 * c22 * d22;
+        dC[q][4] = Eb * (d22 * c12 + c22 * d12);
+        dC[q][5] = Eb * 0.5 * ((1 - nu) * (d11 * c22 + c11 * d22) + 2 * (1 + nu) * c12 * d12);
+    }
+}
+GF_HD __forceinline__ void symmv(const double* C, const double* x, double* y) {
+    y[0] = C[0] * x[0] + C[1] * x[1] + C[2] * x[2];
+    y[1] = C[1] * x[0] + C[3] * x[1] + C[4] * x[2];
+    y[2] = C[2] * x[0] + C[4] * x[1] + C[5] * x[2];
+}
+
+// Everything a Gauss point contributes, in compact form.  z, Z: [15]; out: IM record (W slots untouched).
+GF_HD inline void shell_point(const double* z, const double* Z, double t, double E, double nu, double* im) {
+    const double f3[3] = {1.0, 1.0, 2.0};
+    double n[3], N[3], j, Jn, Dn[3][6], DN[3][6];
+    normal_derivs(z, z + 3, n, j, Dn);
+    normal_derivs(Z, Z + 3, N, Jn, DN);
+    double C[6], dC[3][6], J;
+    material(Z, Z + 3, E, nu, C, dC, J);
+    double eps[3], kap[3];
+    eps[0] = 0.5 * (dot3(z, z) - dot3(Z, Z));
+    eps[1] = 0.5 * (dot3(z + 3, z + 3) - dot3(Z + 3, Z + 3));
+    eps[2] = dot3(z, z + 3) - dot3(Z, Z + 3);
+    for (int k = 0; k < 3; ++k) kap[k] = f3[k] * (dot3(Z + 6 + 3 * k, N) - dot3(z + 6 + 3 * k, n));
+    const double t3 = t * t * t / 12.0;
+    double Ce[3], Ck[3], nv[3], mo[3];
+    symmv(C, eps, Ce); symmv(C, kap, Ck);
+    for (int k = 0; k < 3; ++k) { nv[k] = t * Ce[k]; mo[k] = t3 * Ck[k]; }
+    im[IM_J] = J; im[IM_T] = t;
+    im[IM_PSI] = J * (0.5 * t * dot3(eps, Ce) + 0.5 * t3 * dot3(kap, Ck));
+    for (int c = 0; c < 6; ++c) im[IM_G + c] = z[c];
+    for (int k = 0; k < 3; ++k) { im[IM_N + k] = n[k]; im[IM_NB + k] = N[k]; im[IM_JNV + k] = J * nv[k]; im[IM_JMOF + k] = J * mo[k] * f3[k]; }
+    // ez[k][c] (c<6): row0 [g1,0], row1 [0,g2], row2 [g2,g1];  bg[k][c] = f_k h_k . Dn[:,c]
+    double ez[3][6], bg[3][6], eZ[3][6], bG[3][6];
+    for (int c = 0; c < 3; ++c) {
+        ez[0][c] = z[c]; ez[0][3 + c] = 0; ez[1][c] = 0; ez[1][3 + c] = z[3 + c]; ez[2][c] = z[3 + c]; ez[2][3 + c] = z[c];
+        eZ[0][c] = -Z[c]; eZ[0][3 + c] = 0; eZ[1][c] = 0; eZ[1][3 + c] = -Z[3 + c]; eZ[2][c] = -Z[3 + c]; eZ[2][3 + c] = -Z[c];
+    }
+    for (int k = 0; k < 3; ++k) for (int c = 0; c < 6; ++c) {
+        bg[k][c] = f3[k] * (z[6 + 3 * k] * Dn[0][c] + z[7 + 3 * k] * Dn[1][c] + z[8 + 3 * k] * Dn[2][c]);
+        bG[k][c] = f3[k] * (Z[6 + 3 * k] * DN[0][c] + Z[7 + 3 * k] * DN[1][c] + Z[8 + 3 * k] * DN[2][c]);
+        im[IM_BG + 6 * k + c] = bg[k][c];
+    }
+    for (int i = 0; i < 3; ++i) for (int c = 0; c < 6; ++c) im[IM_DN + 6 * i + c] = Dn[i][c];
+    for (int c = 0; c < 6; ++c) {
+        double a[3] = {ez[0][c], ez[1][c], ez[2][c]}, b[3] = {bg[0][c], bg[1][c], bg[2][c]}, ca[3], cb[3];
+        symmv(C, a, ca); symmv(C, b, cb);
+        for (int k = 0; k < 3; ++k) { im[IM_CEZ + 6 * k + c] = J * t * ca[k]; im[IM_CBG + 6 * k + c] = J * t3 * cb[k]; }
+    }
+    for (int k = 0; k < 6; ++k) im[IM_CT3 + k] = J * t3 * C[k];
+    // Pz, Pzt
+    for (int c = 0; c < 6; ++c) {
+        double pe = 0, pb = 0, he = 0, hb = 0;
+        for (int k = 0; k < 3; ++k) { pe += nv[k] * ez[k][c]; pb += mo[k] * bg[k][c]; he += Ce[k] * ez[k][c]; hb += Ck[k] * bg[k][c]; }
+        im[IM_PZ + c] = J * (pe - pb); im[IM_PZT + c] = J * (he - 0.25 * t * t * hb);
+    }
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) {
+        im[IM_PZ + 6 + 3 * k + i] = -J * mo[k] * f3[k] * n[i];
+        im[IM_PZT + 6 + 3 * k + i] = -J * 0.25 * t * t * Ck[k] * f3[k] * n[i];
+    }
+    // geometric bending term: M = sum_k mo_k f_k h_k
+    double M[3], H[6][6];
+    for (int i = 0; i < 3; ++i) M[i] = mo[0] * z[6 + i] + mo[1] * z[9 + i] + 2.0 * mo[2] * z[12 + i];
+    hess_M_dot_n(z, z + 3, n, j, M, H);
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) im[IM_HMN + 6 * r + c] = J * H[r][c];
+    // reference path: JZ/J, J dnv/dZ, J dmo/dZ (tangent columns)
+    double JZ[6];
+    cross3(Z + 3, N, JZ); cross3(N, Z, JZ + 3);
+    for (int c = 0; c < 6; ++c) im[IM_JZJ + c] = JZ[c] / J;
+    double dCe[3][3], dCk[3][3];
+    for (int q = 0; q < 3; ++q) { symmv(dC[q], eps, dCe[q]); symmv(dC[q], kap, dCk[q]); }
+    for (int c = 0; c < 6; ++c) {
+        // d(A11,A22,A12)/dZ_c
+        const int ic = c % 3;
+        const double a0 = c < 3 ? 2 * Z[ic] : 0.0, a1 = c < 3 ? 0.0 : 2 * Z[3 + ic], a2 = c < 3 ? Z[3 + ic] : Z[ic];
+        double ev[3] = {eZ[0][c], eZ[1][c], eZ[2][c]}, bv[3] = {bG[0][c], bG[1][c], bG[2][c]}, ce[3], cb[3];
+        symmv(C, ev, ce); symmv(C, bv, cb);
+        for (int k = 0; k < 3; ++k) {
+            im[IM_JDNV + 6 * k + c] = J * t * (dCe[0][k] * a0 + dCe[1][k] * a1 + dCe[2][k] * a2 + ce[k]);
+            im[IM_JDMO + 6 * k + c] = J * t3 * (dCk[0][k] * a0 + dCk[1][k] * a1 + dCk[2][k] * a2 + cb[k]);
+        }
+    }
+}
+
+// ---- expansion of single entries of Pzz / PzZ from the intermediate record -----------
+GF_HD __forceinline__ double ez_entry(const double* im, int k, int r) {   // r < 6
+    const int m = r / 3, i = r - 3 * m;
+    if (k == 2) return im[IM_G + 3 * (1 - m) + i];
+    return (k == m) ? im[IM_G + r] : 0.0;
+}
+GF_HD __forceinline__ double bz_entry(const double* im, int k, int r) {
+    const double f3[3] = {1.0, 1.0, 2.0};
+    if (r < 6) return im[IM_BG + 6 * k + r];
+    const int kk = (r - 6) / 3, i = (r - 6) - 3 * kk;
+    return kk == k ? f3[k] * im[IM_N + i] : 0.0;
+}
+GF_HD inline double pzz_entry(const double* im, int r, int s) {
+    const double f3[3] = {1.0, 1.0, 2.0};
+    double v = 0.0;
+    if (r < 6 && s < 6) {
+        for (int k = 0; k < 3; ++k) v += ez_entry(im, k, r) * im[IM_CEZ + 6 * k + s] + im[IM_BG + 6 * k + r] * im[IM_CBG + 6 * k + s];
+        const int m = r / 3, mm = s / 3;
+        if (r - 3 * m == s - 3 * mm) v += im[IM_JNV + (m == mm ? m : 2)];
+        v -= im[IM_HMN + 6 * r + s];
+    } else if (r >= 6 && s >= 6) {
+        const int k = (r - 6) / 3, i = (r - 6) - 3 * k, kk = (s - 6) / 3, jj = (s - 6) - 3 * kk;
+        v = f3[k] * im[IM_N + i] * im[IM_CT3 + sym3(k, kk)] * f3[kk] * im[IM_N + jj];
+    } else {
+        const int hi = r >= 6 ? r : s, lo = r >= 6 ? s : r;          // symmetric
+        const int k = (hi - 6) / 3, i = (hi - 6) - 3 * k;
+        v = f3[k] * im[IM_N + i] * im[IM_CBG + 6 * k + lo] - im[IM_JMOF + k] * im[IM_DN + 6 * i + lo];
+    }
+    return v;
+}
+GF_HD inline double pzZ_entry(const double* im, int r, int s) {
+    const double f3[3] = {1.0, 1.0, 2.0};
+    double v = 0.0;
+    if (s < 6) {
+        v = im[IM_PZ + r] * im[IM_JZJ + s];
+        if (r < 6) for (int k = 0; k < 3; ++k) v += ez_entry(im, k, r) * im[IM_JDNV + 6 * k + s];
+        for (int k = 0; k < 3; ++k) v -= bz_entry(im, k, r) * im[IM_JDMO + 6 * k + s];
+    } else {
+        const int kk = (s - 6) / 3, jj = (s - 6) - 3 * kk;
+        for (int k = 0; k < 3; ++k) v -= bz_entry(im, k, r) * im[IM_CT3 + sym3(k, kk)] * f3[kk] * im[IM_NB + jj];
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------- penalty
+// unit tangent at = unit(tau0 g1 + tau1 g2), Dt[i][c]
+GF_HD inline void tangent_derivs(const double* g1, const double* g2, const double* tau, double* at, double& L, double Dt[3][6]) {
+    double tt[3];
+    for (int k = 0; k < 3; ++k) tt[k] = tau[0] * g1[k] + tau[1] * g2[k];
+    L = sqrt(dot3(tt, tt));
+    for (int k = 0; k < 3; ++k) at[k] = tt[k] / L;
+    for (int c = 0; c < 6; ++c) {
+        const double tc = tau[c / 3];
+        for (int i = 0; i < 3; ++i) Dt[i][c] = tc * ((i == c % 3 ? 1.0 : 0.0) - at[i] * at[c % 3]) / L;
+    }
+}
+GF_HD inline void hess_M_dot_t(const double* at, double L, const double* tau, const double* M, double H[6][6]) {
+    const double Ma = dot3(M, at), iL2 = 1.0 / (L * L);
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+        const int a = r % 3, b = c % 3;
+        const double Q = -(M[a] * at[b] + at[a] * M[b] + Ma * ((a == b ? 1.0 : 0.0) - 3.0 * at[a] * at[b])) * iL2;
+        H[r][c] = tau[r / 3] * tau[c / 3] * Q;
+    }
+}
+// s1 = nA.nB, s2 = at.(nA x nB): gradients (12) and, if H1/H2 != nullptr, Hessians (12x12)
+GF_HD inline void s_terms(const double* gA, const double* gB, const double* tau, double& s1, double& s2,
+                               double* g1, double* g2, double (*H1)[12], double (*H2)[12], double& L, double* at) {
+    double nA[3], nB[3], jA, jB, DnA[3][6], DnB[3][6], Dt[3][6];
+    normal_derivs(gA, gA + 3, nA, jA, DnA);
+    normal_derivs(gB, gB + 3, nB, jB, DnB);
+    tangent_derivs(gA, gA + 3, tau, at, L, Dt);
+    double cAB[3], cBt[3], ctA[3];
+    cross3(nA, nB, cAB); cross3(nB, at, cBt); cross3(at, nA, ctA);
+    s1 = dot3(nA, nB); s2 = dot3(at, cAB);
+    for (int c = 0; c < 6; ++c) {
+        g1[c] = DnA[0][c] * nB[0] + DnA[1][c] * nB[1] + DnA[2][c] * nB[2];
+        g1[6 + c] = DnB[0][c] * nA[0] + DnB[1][c] * nA[1] + DnB[2][c] * nA[2];
+        g2[c] = Dt[0][c] * cAB[0] + Dt[1][c] * cAB[1] + Dt[2][c] * cAB[2] + DnA[0][c] * cBt[0] + DnA[1][c] * cBt[1] + DnA[2][c] * cBt[2];
+        g2[6 + c] = DnB[0][c] * ctA[0] + DnB[1][c] * ctA[1] + DnB[2][c] * ctA[2];
+    }
+    if (!H1) return;
+    double H[6][6];
+    hess_M_dot_n(gA, gA + 3, nA, jA, nB, H);
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H1[r][c] = H[r][c];
+    hess_M_dot_n(gB, gB + 3, nB, jB, nA, H);
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H1[6 + r][6 + c] = H[r][c];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+        const double v = DnA[0][r] * DnB[0][c] + DnA[1][r] * DnB[1][c] + DnA[2][r] * DnB[2][c];
+        H1[r][6 + c] = v; H1[6 + c][r] = v;
+    }
+    // H2
+    double Ht[6][6], Hn[6][6];
+    hess_M_dot_t(at, L, tau, cAB, Ht);
+    hess_M_dot_n(gA, gA + 3, nA, jA, cBt, Hn);
+    // X = -Dt^T skew(nB) DnA ; (skew(v) w = v x w)
+    double SB_DnA[3][6], SA_DnB[3][6], St_DnB[3][6];
+    for (int c = 0; c < 6; ++c) {
+        double colA[3] = {DnA[0][c], DnA[1][c], DnA[2][c]}, colB[3] = {DnB[0][c], DnB[1][c], DnB[2][c]}, t0[3], t1[3], t2[3];
+        cross3(nB, colA, t0); cross3(nA, colB, t1); cross3(at, colB, t2);
+        for (int i = 0; i < 3; ++i) { SB_DnA[i][c] = t0[i]; SA_DnB[i][c] = t1[i]; St_DnB[i][c] = t2[i]; }
+    }
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+        const double X = -(Dt[0][r] * SB_DnA[0][c] + Dt[1][r] * SB_DnA[1][c] + Dt[2][r] * SB_DnA[2][c]);
+        const double Xt = -(Dt[0][c] * SB_DnA[0][r] + Dt[1][c] * SB_DnA[1][r] + Dt[2][c] * SB_DnA[2][r]);
+        H2[r][c] = Ht[r][c] + Hn[r][c] + X + Xt;
+        const double ab = Dt[0][r] * SA_DnB[0][c] + Dt[1][r] * SA_DnB[1][c] + Dt[2][r] * SA_DnB[2][c]
+                        - (DnA[0][r] * St_DnB[0][c] + DnA[1][r] * St_DnB[1][c] + DnA[2][r] * St_DnB[2][c]);
+        H2[r][6 + c] = ab; H2[6 + c][r] = ab;
+    }
+    hess_M_dot_n(gB, gB + 3, nB, jB, ctA, H);
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H2[6 + r][6 + c] = H[r][c];
+}
+
+enum : int { PB_GRAD = 0, PB_HYY = 18, PB_HYY_END = 18 + 324, PB_HYC = 18 + 324, PB_SIZE = 18 + 324 + 216, PB_EN = PB_SIZE };
+constexpr int PB_STRIDE = PB_SIZE + 2;   // + energy + pad
+
+// One mortar vertex: y[18] = (uA, gA1, gA2, uB, gB1, gB2), Y[12] = (GA1, GA2, GB1, GB2).
+// out: grad[18], Hyy[18][18], HyC[18][12] where HyC = Hyy[:, tangent cols] + HyY (the dR/dCP operator).
+GF_HD inline void penalty_point(const double* y, const double* Y, const double* tau, double ad, double ar, double dt, double* out) {
+    const int tan[12] = {3, 4, 5, 6, 7, 8, 12, 13, 14, 15, 16, 17};
+    double s1, s2, S1, S2, g1[12], g2[12], G1[12], G2[12], L, Lr, at[3], At[3];
+    double H1[12][12], H2[12][12];
+    s_terms(y + 3, y + 12, tau, s1, s2, g1, g2, H1, H2, L, at);
+    s_terms(Y, Y + 6, tau, S1, S2, G1, G2, nullptr, nullptr, Lr, At);
+    const double e1 = s1 - S1, e2 = s2 - S2, c0 = dt * Lr;
+    double d[3] = {y[0] - y[9], y[1] - y[10], y[2] - y[11]};
+    out[PB_EN] = c0 * (0.5 * ad * dot3(d, d) + 0.5 * ar * (e1 * e1 + e2 * e2));
+    double* grad = out + PB_GRAD; double* Hyy = out + PB_HYY; double* HyC = out + PB_HYC;
+    for (int k = 0; k < 18; ++k) grad[k] = 0.0;
+    for (int k = 0; k < 3; ++k) { grad[k] = c0 * ad * d[k]; grad[9 + k] = -c0 * ad * d[k]; }
+    for (int k = 0; k < 12; ++k) grad[tan[k]] = c0 * ar * (e1 * g1[k] + e2 * g2[k]);
+    for (int k = 0; k < 324; ++k) Hyy[k] = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        Hyy[k * 18 + k] = c0 * ad; Hyy[(9 + k) * 18 + 9 + k] = c0 * ad; Hyy[k * 18 + 9 + k] = -c0 * ad; Hyy[(9 + k) * 18 + k] = -c0 * ad;
+    }
+    for (int r = 0; r < 12; ++r) for (int c = 0; c < 12; ++c)
+        Hyy[tan[r] * 18 + tan[c]] = c0 * ar * (g1[r] * g1[c] + e1 * H1[r][c] + g2[r] * g2[c] + e2 * H2[r][c]);
+    // HyC[r][c], c over Y slots (GA1,GA2,GB1,GB2) == tangent slots of y
+    for (int r = 0; r < 18; ++r) for (int c = 0; c < 12; ++c) {
+        const double c0Y = c < 6 ? dt * tau[c / 3] * At[c % 3] : 0.0;
+        HyC[r * 12 + c] = Hyy[r * 18 + tan[c]] + grad[r] * c0Y / c0;
+    }
+    for (int r = 0; r < 12; ++r) for (int c = 0; c < 12; ++c) HyC[tan[r] * 12 + c] -= c0 * ar * (g1[r] * G1[c] + g2[r] * G2[c]);
+}
+
+}  // namespace gf

@@ -1,0 +1,104 @@
+/* goldfish_hip.h -- C ABI of libgoldfish_hip.so, the MI355X (gfx950) implementation of
+ * GOLDFISH's shell assembly + sensitivity hot path.
+ *
+ * The reference has NO FFI for this path (it is Python -> pybind dolfin / petsc4py,
+ * SURVEY.md 8(b)); every entry point below therefore cites the Python method of
+ * GOLDFISH/nonmatching_opt.py or GOLDFISH/operations/<name>.py whose work it replaces.
+ * The Python host layer (goldfish_amd/nonmatching_opt.py) binds these with ctypes;
+ * INTEGRATION.md shows the stub a GOLDFISH maintainer would add.
+ *
+ * Ownership: host arrays belong to the caller; device buffers belong to the handle;
+ * pointers returned by gf_device_ptr are borrowed for the handle's lifetime.
+ * Errors: 0 = ok, non-zero = error code, message via gf_last_error() (thread-local).
+ * Threading: one handle per host thread; calls on one handle are not re-entrant.
+ * All work of a handle is issued on one HIP stream; host-pointer calls synchronise
+ * before returning, *_async / device-pointer calls do not (use gf_sync).
+ */
+#ifndef GOLDFISH_HIP_H
+#define GOLDFISH_HIP_H
+
+#include <stdint.h>
+#include "goldfish_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gf_handle gf_handle;
+
+/* assemble flags */
+enum { GF_ASM_R = 1, GF_ASM_K = 2, GF_ASM_DRDCP = 4, GF_ASM_DRDH = 8, GF_ASM_ALL = 15 };
+/* device buffers exposed through gf_device_ptr */
+enum {
+    GF_BUF_CP = 0,      /* double[total_cp][4] (c_x, c_y, c_z, w)           */
+    GF_BUF_U = 1,       /* double[ndof]                                      */
+    GF_BUF_H = 2,       /* double[total_cp]                                  */
+    GF_BUF_R = 3,       /* double[ndof] residual                             */
+    GF_BUF_VAL_K = 4,   /* CSR values, see gf_pattern                        */
+    GF_BUF_VAL_C0 = 5, GF_BUF_VAL_C1 = 6, GF_BUF_VAL_C2 = 7,
+    GF_BUF_VAL_H = 8
+};
+
+int         gf_device_count(void);
+const char* gf_last_error(void);
+
+/* replaces NonMatchingOpt.__init__ + mortar_meshes_setup + set_residuals for the device path
+ * (nonmatching_opt.py:12-127, 422-452): builds element/quadrature tables, static CSR patterns,
+ * coupling lists, and allocates all device state on `device`. */
+int  gf_create(const gf_model_desc* desc, int device, gf_handle** out);
+void gf_destroy(gf_handle* h);
+
+int64_t gf_total_cp(const gf_handle* h);
+int64_t gf_num_dofs(const gf_handle* h);
+int64_t gf_num_elements(const gf_handle* h);
+int64_t gf_num_gauss_points(const gf_handle* h);
+int64_t gf_num_mortar_points(const gf_handle* h);
+int64_t gf_device_bytes(const gf_handle* h);
+
+/* update_CPIGA(cp_array_iga, field) nonmatching_opt.py:495-506 (homogeneous coordinate `field`) */
+int gf_set_cp(gf_handle* h, int field, const double* cp, int64_t n);
+/* update_h_th_IGA nonmatching_opt.py:516-525 (one value per control point) */
+int gf_set_thickness(gf_handle* h, const double* hth, int64_t n);
+/* update_uIGA nonmatching_opt.py:474-484 */
+int gf_set_u(gf_handle* h, const double* u, int64_t n);
+
+/* static CSR patterns (row = vector dof).  which: GF_MAT_* of goldfish_model.h */
+int64_t gf_nnz(const gf_handle* h, int which);
+int     gf_pattern(const gf_handle* h, int which, int64_t* rowptr, int32_t* col);
+
+/* One pass of the hot path over the current state, results left in HBM:
+ *   GF_ASM_R     RIGA()          nonmatching_opt.py:941-948  (assemble_RFE :726-770 + BCs)
+ *   GF_ASM_K     dRIGAduIGA()    nonmatching_opt.py:950-959  (assemble_dRFEduFE :772-841)
+ *   GF_ASM_DRDCP dRIGAdCPIGA(f)  nonmatching_opt.py:992-1004 (assemble_dRFEdCPFE :843-926), all 3 fields
+ *   GF_ASM_DRDH  dRIGAdh_th()    nonmatching_opt.py:1006-1015
+ * i.e. DispImOpeartion.apply_nonlinear + linearize (operations/disp_imop.py:33-56). Asynchronous. */
+int gf_assemble(gf_handle* h, int flags);
+int gf_sync(gf_handle* h);
+
+/* host copies of results (synchronising) */
+int gf_get_residual(gf_handle* h, double* R, int64_t n);
+int gf_get_values(gf_handle* h, int which, double* vals, int64_t n);
+
+/* y += A x (transpose = 0) or y += A^T x (transpose = 1), A = matrix `which` as last assembled:
+ * DispImOpeartion.apply_linear_fwd / apply_linear_rev, operations/disp_imop.py:58-128. Host pointers. */
+int gf_apply(gf_handle* h, int which, int transpose, const double* x, int64_t nx, double* y, int64_t ny);
+
+/* IntEnergyExOperation.Wint/dWintduIGA/dWintdCPIGA/dWintdh_th (operations/int_energy_exop.py:55-107)
+ * and VolumeExOperation.volume/dvoldCPIGA/dvoldh_th (operations/volume_exop.py:46-84).
+ * out[0] = W_int, out[1] = volume, out[2] = penalty energy.  Gradient pointers may be NULL.
+ * dWdu has Dirichlet rows zeroed when apply_bcs != 0. dWdcp/dVdcp: 3 arrays of total_cp. */
+int gf_functionals(gf_handle* h, double out[3], double* dWdu, double* dWdcp, double* dWdh,
+                   double* dVdcp, double* dVdh, int apply_bcs);
+
+/* borrowed device pointer to one of the GF_BUF_* buffers (for zero-copy users: bench, RCCL exchange) */
+void* gf_device_ptr(gf_handle* h, int which);
+/* y_dev += A x_dev on device pointers (no host copies, asynchronous) */
+int gf_apply_dev(gf_handle* h, int which, int transpose, const double* x_dev, double* y_dev);
+/* average duration (ms) of the dominant kernel (shell element kernel) over the launches since the
+ * last call, measured with HIP events on the handle's stream; resets the accumulator. */
+double gf_kernel_ms(gf_handle* h, int* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
