@@ -84,6 +84,10 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         h->d_val[GF_MAT_K] = h->dalloc<double>(9 * nnzc);
         for (int f = 0; f < 3; ++f) h->d_val[GF_MAT_DRDCP0 + f] = h->dalloc<double>(3 * nnzc);
         h->d_val[GF_MAT_DRDH] = h->dalloc<double>(3 * nnzs);
+        HIPCHK(hipMemset(h->d_val[GF_MAT_K], 0, 9 * nnzc * sizeof(double)));
+        for (int f = 0; f < 3; ++f) HIPCHK(hipMemset(h->d_val[GF_MAT_DRDCP0 + f], 0, 3 * nnzc * sizeof(double)));
+        HIPCHK(hipMemset(h->d_val[GF_MAT_DRDH], 0, 3 * nnzs * sizeof(double)));
+        HIPCHK(hipMemset(h->d_R, 0, H.ndof * sizeof(double)));
         h->d_x = h->dalloc<double>(H.ndof); h->d_y = h->dalloc<double>(H.ndof);
         // penalty
         DevPenalty& Q = h->Q;
@@ -103,10 +107,10 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         if (const char* s = getenv("GF_SCRATCH_GB")) budget_gb = atof(s);
         const long long max_elems = std::max<long long>(1, (long long)(budget_gb * 1e9 / (blk_doubles * 8.0)));
         long long biggest = 0;
-        for (int s = 0; s < H.np;) {
+        for (int s = 0; s < H.n_owned;) {
             Chunk c; c.p0 = s; c.e0 = H.patches[s].elem_off; c.a0 = H.patches[s].cp_off;
             long long ne = 0;
-            while (s < H.np) {
+            while (s < H.n_owned) {
                 const long long pe = (long long)H.patches[s].nelu * H.patches[s].nelv;
                 if (ne > 0 && ne + pe > max_elems) break;
                 ne += pe; ++s;

@@ -89,7 +89,8 @@ inline void basis_ders(int span, double xi, int p, const double* U, double ders[
 }
 
 struct HostModel {
-    int np = 0, degree = 0, ni = 0;
+    int np = 0, n_owned = 0, degree = 0, ni = 0;
+    int64_t owned_cp = 0;               // control points of the owned patches (first owned_cp ids)
     int64_t total_cp = 0, ndof = 0, nelem = 0, ngp = 0, npts = 0;
     std::vector<PatchDev> patches;
     std::vector<double> tab;            // 1-D tables
@@ -120,6 +121,8 @@ inline void HostModel::build(const gf_model_desc* D) {
     degree = D->degree[0];
     if (degree < 2 || degree > MAXP) throw std::runtime_error("gf_create: degree must be 2.." + std::to_string(MAXP) + " (KL shells need C1)");
     total_cp = D->cp_off[np]; ndof = 3 * total_cp;
+    n_owned = (D->n_owned_patches > 0 && D->n_owned_patches < np) ? D->n_owned_patches : np;
+    owned_cp = D->cp_off[n_owned];
     if (total_cp >= (int64_t(1) << 31) / 3) throw std::runtime_error("gf_create: too many control points for 32-bit column ids");
     patches.resize(np); cp_patch.resize(total_cp);
     weights.assign(D->weights, D->weights + total_cp);
@@ -160,7 +163,7 @@ inline void HostModel::build(const gf_model_desc* D) {
             else   { P.nelu = nel; P.tabu = t0; P.wu = w0; P.spu = s0; P.c2u = c0; }
         }
         P.elem_off = nelem; nelem += int64_t(P.nelu) * P.nelv;
-        ngp += int64_t(P.nelu) * P.nelv * (P.p + 1) * (P.q + 1);
+        if (s < n_owned) ngp += int64_t(P.nelu) * P.nelv * (P.p + 1) * (P.q + 1);
     }
     if (nelem >= (int64_t(1) << 31)) throw std::runtime_error("gf_create: too many elements");
     elem_patch.resize(nelem);
@@ -266,14 +269,14 @@ inline void HostModel::build(const gf_model_desc* D) {
     // owner lists: rows grouped by CP, blocks grouped by (a, slot k)
     {
         std::vector<PenRowItem> rows;
-        for (int i = 0; i < ni; ++i) for (int s = 0; s < 2; ++s) for (const CpRange& A : ranges[2 * i + s]) rows.push_back({A.cp, 2 * i + s, A.lo, A.hi});
+        for (int i = 0; i < ni; ++i) for (int s = 0; s < 2; ++s) for (const CpRange& A : ranges[2 * i + s]) if (A.cp < owned_cp) rows.push_back({A.cp, 2 * i + s, A.lo, A.hi});
         std::stable_sort(rows.begin(), rows.end(), [](const PenRowItem& x, const PenRowItem& y) { return x.a < y.a; });
         row_items = rows; row_ptr.clear(); row_ptr.push_back(0);
         for (size_t k = 1; k <= rows.size(); ++k) if (k == rows.size() || rows[k].a != rows[k - 1].a) row_ptr.push_back((int64_t)k);
         std::vector<PenBlockItem> blks;
         for (int i = 0; i < ni; ++i) for (int s = 0; s < 2; ++s) for (int t = 0; t < 2; ++t)
             for (const CpRange& A : ranges[2 * i + s]) for (const CpRange& B : ranges[2 * i + t])
-                if (A.lo <= B.hi && B.lo <= A.hi) {
+                if (A.cp < owned_cp && A.lo <= B.hi && B.lo <= A.hi) {
                     const int* b0 = &nb_c[nb_ptr_c[A.cp]]; const int* b1 = &nb_c[nb_ptr_c[A.cp + 1]];
                     const int k = int(std::lower_bound(b0, b1, B.cp) - b0);
                     blks.push_back({A.cp, k, B.cp, 4 * i + 2 * s + t, std::max(A.lo, B.lo), std::min(A.hi, B.hi)});

@@ -71,6 +71,7 @@ class gf_model_desc(C.Structure):
         ("if_patch", C.POINTER(C.c_int32)), ("if_off", C.POINTER(C.c_int64)),
         ("if_xi", C.POINTER(C.c_double)), ("if_tau", C.POINTER(C.c_double)),
         ("if_wt", C.POINTER(C.c_double)), ("if_alpha", C.POINTER(C.c_double)),
+        ("n_owned_patches", C.c_int32),
     ]
 
 
@@ -82,9 +83,10 @@ class ModelArrays:
     """Owns the NumPy buffers behind a ``gf_model_desc`` (keeps them alive)."""
 
     def __init__(self, patches, E, nu, body_force=None, interfaces=(), alphas=(),
-                 point_loads=()):
+                 point_loads=(), n_owned=0):
         n = len(patches)
         self.n_patches = n
+        self.n_owned = int(n_owned) if n_owned else n
         self.degree = np.array([[p.p, p.q] for p in patches], np.int32).ravel()
         self.ncp = np.array([[p.n_u, p.n_v] for p in patches], np.int32).ravel()
         kn, koff = [], [0]
@@ -123,7 +125,7 @@ class ModelArrays:
             self.if_tau = np.zeros(0)
             self.if_wt = np.zeros(0)
             self.if_alpha = np.zeros(0)
-        self.n_gauss_points = int(sum(p.nel[0] * p.nel[1] * (p.p + 1) * (p.q + 1) for p in patches))
+        self.n_gauss_points = int(sum(p.nel[0] * p.nel[1] * (p.p + 1) * (p.q + 1) for p in patches[:self.n_owned]))
         self.n_mortar_points = int(self.if_off[-1])
 
     def desc(self):
@@ -141,6 +143,7 @@ class ModelArrays:
         d.if_patch, d.if_off = _ptr(self.if_patch, C.c_int32), _ptr(self.if_off, C.c_int64)
         d.if_xi, d.if_tau = _ptr(self.if_xi, C.c_double), _ptr(self.if_tau, C.c_double)
         d.if_wt, d.if_alpha = _ptr(self.if_wt, C.c_double), _ptr(self.if_alpha, C.c_double)
+        d.n_owned_patches = self.n_owned
         return d
 
 

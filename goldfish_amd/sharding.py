@@ -1,0 +1,119 @@
+"""Patch sharding for one-process-per-GPU runs.
+
+Shell terms are patch-independent (block-diagonal K, dR/dCP, dR/dh:
+GOLDFISH/nonmatching_opt.py:815-823, 933-937); coupling enters only through the
+interfaces (``mapping_list[i] = [a, b]``, :745-752, 789-801).  Each rank owns a
+contiguous range of patches and assembles exactly the rows of those patches
+("owner computes rows"): for interfaces cut by the partition the neighbour patch
+is carried as a *ghost* (geometry + state only, no rows), so no matrix entries ever
+cross xGMI.  What does cross it is (a) the residual / forward products (row slices ->
+one all-reduce of a zero-padded global vector) and (b) reverse-mode products whose
+columns belong to remote patches (all-reduce of the global-length result).
+The reference's counterpart is ``comm.allgather`` of every vector to every rank
+(GOLDFISH/utils/opt_utils.py:41-54).
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from .geometry import ProblemSpec
+from .model import Interface, arrays_from_spec
+
+
+def partition_patches(spec, world):
+    """Contiguous patch ranges balanced by Gauss-point count."""
+    w = np.array([p.nel[0] * p.nel[1] * (p.p + 1) * (p.q + 1) for p in spec.patches], float)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    bounds = [0]
+    for r in range(1, world):
+        target = cum[-1] * r / world
+        k = int(np.argmin(np.abs(cum - target)))
+        k = max(k, bounds[-1] + 1)
+        k = min(k, len(spec.patches) - (world - r))
+        bounds.append(k)
+    bounds.append(len(spec.patches))
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+@dataclass
+class Shard:
+    rank: int
+    world: int
+    spec: ProblemSpec            # local: owned patches first, then ghosts
+    n_owned: int
+    order: list                  # local patch index -> global patch index
+    cp_off_global: np.ndarray    # global control-point offsets (all patches)
+    cp_off_local: np.ndarray
+
+    @property
+    def total_cp_global(self):
+        return int(self.cp_off_global[-1])
+
+    def to_local(self, vec, width=1):
+        """Slice a global patch-major vector (width values per control point) to local order."""
+        return np.concatenate([vec[width * self.cp_off_global[g]:width * self.cp_off_global[g + 1]] for g in self.order])
+
+    def owned_global_range(self, width=1):
+        g0, g1 = self.order[0], self.order[self.n_owned - 1] + 1
+        return width * int(self.cp_off_global[g0]), width * int(self.cp_off_global[g1])
+
+    def owned_local_size(self, width=1):
+        return width * int(self.cp_off_local[self.n_owned])
+
+    def local_cols_to_global(self):
+        """Global control-point id of every local control point (owned + ghost)."""
+        return np.concatenate([np.arange(self.cp_off_global[g], self.cp_off_global[g + 1]) for g in self.order])
+
+
+def shard_spec(spec, rank, world):
+    start, end = partition_patches(spec, world)[rank]
+    own = list(range(start, end))
+    ghosts = set()
+    for itf in spec.interfaces:
+        if start <= itf.a < end and not (start <= itf.b < end):
+            ghosts.add(itf.b)
+        if start <= itf.b < end and not (start <= itf.a < end):
+            ghosts.add(itf.a)
+    order = own + sorted(ghosts)
+    g2l = {g: l for l, g in enumerate(order)}
+    itfs = []
+    for itf in spec.interfaces:
+        if (start <= itf.a < end) or (start <= itf.b < end):
+            loc = Interface(g2l[itf.a], g2l[itf.b], itf.xi_a, itf.xi_b)   # keeps the (A, B) orientation
+            itfs.append(loc)
+    pls = [(g2l[s], xi, f, v) for (s, xi, f, v) in spec.point_loads if start <= s < end]
+    local = ProblemSpec([spec.patches[g] for g in order], itfs, spec.E, spec.nu, spec.h_th,
+                        [spec.body_force[g] for g in order], pls, spec.penalty_coefficient,
+                        "%s[rank %d/%d]" % (spec.name, rank, world))
+    cpg = np.concatenate([[0], np.cumsum([p.ncp for p in spec.patches])]).astype(np.int64)
+    cpl = np.concatenate([[0], np.cumsum([p.ncp for p in local.patches])]).astype(np.int64)
+    return Shard(rank, world, local, len(own), order, cpg, cpl)
+
+
+def shard_arrays(shard, thickness_global=None):
+    """ModelArrays of the local model (owned + ghost patches); thickness_global is the
+    per-patch list used to freeze the penalty parameters (identical on every rank)."""
+    th = None
+    if thickness_global is not None:
+        th = [thickness_global[g] for g in shard.order]
+    A = arrays_from_spec(shard.spec, th)
+    A.n_owned = shard.n_owned
+    A.n_gauss_points = int(sum(p.nel[0] * p.nel[1] * (p.p + 1) * (p.q + 1) for p in shard.spec.patches[:shard.n_owned]))
+    return A
+
+
+def allreduce_owned_rows(shard, local_rows, dist, width=3, out=None):
+    """Place this rank's owned rows into a zero-padded global vector and sum over ranks
+    (torch.distributed; backend 'nccl' == RCCL over xGMI on the GPU box, 'gloo' in CPU tests).
+    ``local_rows`` is a torch tensor holding at least the owned rows first."""
+    import torch
+    n = width * shard.total_cp_global
+    if out is None:
+        out = torch.zeros(n, dtype=torch.float64, device=local_rows.device)
+    else:
+        out.zero_()
+    g0, g1 = shard.owned_global_range(width)
+    out[g0:g1] = local_rows[:g1 - g0]
+    if shard.world > 1:
+        dist.all_reduce(out)
+    return out

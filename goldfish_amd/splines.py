@@ -244,18 +244,29 @@ class NURBSPatch:
             self.knots[1] = open_uniform_knots(1, q, self.knots[1][0], self.knots[1][-1])
         return self
 
+    def eval_grid(self, us, vs):
+        """Surface points X(us[i], vs[j]) -> (len(us), len(vs), 3) (vectorised, setup only)."""
+        def bmat(kn, p, n, xs):
+            Bm = np.zeros((len(xs), n))
+            for r, x in enumerate(xs):
+                sp = find_span(n, p, kn, x)
+                Bm[r, sp - p:sp + 1] = basis_ders(sp, x, p, kn, 0)[0]
+            return Bm
+        Bu, Bv = bmat(self.knots[0], self.p, self.n_u, us), bmat(self.knots[1], self.q, self.n_v, vs)
+        Aw = np.einsum("ri,sj,ijc->rsc", Bu, Bv, self.control)
+        return Aw[:, :, :3] / Aw[:, :, 3:4]
+
     def mean_element_size(self):
         """Average physical element edge length (PENGoLINS spline_mesh_size analogue,
         used only to freeze the penalty parameters, nonmatching_opt.py:122-127)."""
-        ku, kv = np.unique(self.knots[0]), np.unique(self.knots[1])
-        hs = []
-        for a, b in zip(kv[:-1], kv[1:]):
-            for c, d in zip(ku[:-1], ku[1:]):
-                X00, X10 = self.eval((c, a)), self.eval((d, a))
-                X01, X11 = self.eval((c, b)), self.eval((d, b))
-                hs.append(0.25 * (np.linalg.norm(X10 - X00) + np.linalg.norm(X11 - X01)
-                                  + np.linalg.norm(X01 - X00) + np.linalg.norm(X11 - X10)))
-        return float(np.mean(hs))
+        if getattr(self, "_mes", None) is None:
+            X = self.eval_grid(np.unique(self.knots[0]), np.unique(self.knots[1]))
+            du = np.linalg.norm(X[1:, :, :] - X[:-1, :, :], axis=2)
+            dv = np.linalg.norm(X[:, 1:, :] - X[:, :-1, :], axis=2)
+            hu = 0.5 * (du[:, 1:] + du[:, :-1])
+            hv = 0.5 * (dv[1:, :] + dv[:-1, :])
+            self._mes = float(np.mean(0.5 * (hu + hv)))
+        return self._mes
 
     # -- constructors
     @staticmethod

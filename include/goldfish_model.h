@@ -57,6 +57,11 @@ typedef struct gf_model_desc {
     const double*  if_wt;      /* [n_pts]   vertex-quadrature weight (mortar param)*/
     const double*  if_alpha;   /* [2*n_interfaces] (alpha_d, alpha_r), frozen
                                   (nonmatching_opt.py:928-938: no h / CP derivative)*/
+    /* ---- patch sharding (one process per GPU) -------- */
+    int32_t        n_owned_patches; /* 0 or n_patches: everything is assembled here. Otherwise patches
+                                  [0, n_owned_patches) are owned (their rows are assembled) and the
+                                  remaining ones are ghosts that only provide geometry/state for the
+                                  interfaces cut by the partition ("owner computes rows").          */
 } gf_model_desc;
 
 /* which-matrix selectors shared by product and oracle */
