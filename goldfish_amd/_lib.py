@@ -8,7 +8,7 @@ import numpy as np
 from .model import gf_model_desc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgoldfish_hip.so")
+LIB_PATH = os.environ.get("GF_LIB", os.path.join(_HERE, "libgoldfish_hip.so"))   # GF_LIB: A/B builds while tuning
 _LIB = None
 
 ASM_R, ASM_K, ASM_DRDCP, ASM_DRDH, ASM_ALL = 1, 2, 4, 8, 15

@@ -24,7 +24,10 @@ struct DevModel {
 
 template <int P> struct ElemCfg {
     static constexpr int P1 = P + 1, NB = P1 * P1, NG = NB, ND = 3 * NB;
-    static constexpr int AG = (P == 2) ? 3 : (P == 3 ? 4 : 5);       // a's per lane
+#ifndef GF_AG3
+#define GF_AG3 2
+#endif
+    static constexpr int AG = (P == 2) ? 3 : (P == 3 ? GF_AG3 : 5);  // a's per lane
     static constexpr int NAG = (NB + AG - 1) / AG;
     static constexpr int NT = ((NAG * NB + 63) / 64) * 64;            // threads per element
     static constexpr int BLK = ND * ND + ND * ND + ND * NB + ND;      // doubles per element block (K, C[3], H, R)
@@ -49,7 +52,7 @@ __device__ __forceinline__ void rationalize6(const double* Nb, const double* W, 
 }
 
 template <int P>
-__global__ __launch_bounds__(ElemCfg<P>::NT) void kl_element_kernel(DevModel M, int e_first, int flags, double* __restrict__ blk) {
+__global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_element_kernel(DevModel M, int e_first, int flags, double* __restrict__ blk) {
     using Cfg = ElemCfg<P>;
     constexpr int P1 = Cfg::P1, NB = Cfg::NB, NG = Cfg::NG, ND = Cfg::ND, AG = Cfg::AG, NAG = Cfg::NAG, NT = Cfg::NT;
     const int tid = threadIdx.x;
@@ -116,10 +119,45 @@ __global__ __launch_bounds__(ElemCfg<P>::NT) void kl_element_kernel(DevModel M, 
             for (int k = 0; k < 6; ++k) s_phi[tid][k] = R[k];
             s_n0[tid] = Nb[0];
         }
-        for (int idx = tid; idx < 225; idx += NT) {
-            const int r = idx / 15, s = idx - 15 * r;
-            const double g = pzz_entry(im, r, s);
-            s_G[idx] = g; s_Hc[idx] = g + pzZ_entry(im, r, s);
+        // Expansion of G = Pzz and Hc = Pzz + PzZ from the intermediate record.  The 225 entries are
+        // ordered by structural category [A: tangent x tangent | B: curvature x tangent | B': transpose
+        // of B | C: curvature x curvature] so that a wave executes at most two short code paths per
+        // pass (the generic per-entry form kl_point.hpp::pzz_entry diverges 4-way in every wave).
+#pragma unroll
+        for (int it = 0; it < (225 + NT - 1) / NT; ++it) {
+            const int slot = tid + it * NT;
+            if (slot < 36) {
+                const int r = slot / 6, s = slot - 6 * r, m = r / 3, i = r - 3 * m, mm = s / 3, j = s - 3 * mm;
+                const double gr = im[IM_G + r];
+                const double e0 = m == 0 ? gr : 0.0, e1 = m == 1 ? gr : 0.0, e2 = im[IM_G + 3 * (1 - m) + i];
+                const double b0 = im[IM_BG + r], b1 = im[IM_BG + 6 + r], b2 = im[IM_BG + 12 + r];
+                double g = e0 * im[IM_CEZ + s] + e1 * im[IM_CEZ + 6 + s] + e2 * im[IM_CEZ + 12 + s]
+                         + b0 * im[IM_CBG + s] + b1 * im[IM_CBG + 6 + s] + b2 * im[IM_CBG + 12 + s] - im[IM_HMN + 6 * r + s];
+                if (i == j) g += im[IM_JNV + (m == mm ? m : 2)];
+                const double zz = im[IM_PZ + r] * im[IM_JZJ + s]
+                                + e0 * im[IM_JDNV + s] + e1 * im[IM_JDNV + 6 + s] + e2 * im[IM_JDNV + 12 + s]
+                                - (b0 * im[IM_JDMO + s] + b1 * im[IM_JDMO + 6 + s] + b2 * im[IM_JDMO + 12 + s]);
+                s_G[15 * r + s] = g; s_Hc[15 * r + s] = g + zz;
+            } else if (slot < 90) {
+                const int q = slot - 36, rr = q / 6, s = q - 6 * rr, k = rr / 3, i = rr - 3 * k, r = 6 + rr;
+                const double fn = (k == 2 ? 2.0 : 1.0) * im[IM_N + i];
+                const double g = fn * im[IM_CBG + 6 * k + s] - im[IM_JMOF + k] * im[IM_DN + 6 * i + s];
+                const double zz = im[IM_PZ + r] * im[IM_JZJ + s] - fn * im[IM_JDMO + 6 * k + s];
+                s_G[15 * r + s] = g; s_G[15 * s + r] = g; s_Hc[15 * r + s] = g + zz;
+            } else if (slot < 144) {
+                const int q = slot - 90, ss = q / 6, r = q - 6 * ss, kk = ss / 3, jj = ss - 3 * kk, s = 6 + ss;
+                const double fk = (kk == 2 ? 2.0 : 1.0);
+                const double g = fk * im[IM_N + jj] * im[IM_CBG + 6 * kk + r] - im[IM_JMOF + kk] * im[IM_DN + 6 * jj + r];
+                const int c0 = kk, c1 = kk == 0 ? 1 : 3 + (kk - 1), c2 = 2 + (kk == 0 ? 0 : (kk == 1 ? 2 : 3));   // sym3(0..2, kk)
+                const double zz = -(im[IM_BG + r] * im[IM_CT3 + c0] + im[IM_BG + 6 + r] * im[IM_CT3 + c1] + im[IM_BG + 12 + r] * im[IM_CT3 + c2]) * fk * im[IM_NB + jj];
+                s_Hc[15 * r + s] = g + zz;
+            } else if (slot < 225) {
+                const int q = slot - 144, rr = q / 9, ss = q - 9 * rr, k = rr / 3, i = rr - 3 * k, kk = ss / 3, jj = ss - 3 * kk;
+                const int lo = k < kk ? k : kk, hi = k < kk ? kk : k;
+                const double c = (k == 2 ? 2.0 : 1.0) * (kk == 2 ? 2.0 : 1.0) * im[IM_N + i] * im[IM_CT3 + lo * (5 - lo) / 2 + hi];
+                s_G[15 * (6 + rr) + 6 + ss] = c * im[IM_N + jj];
+                s_Hc[15 * (6 + rr) + 6 + ss] = c * (im[IM_N + jj] - im[IM_NB + jj]);
+            }
         }
         __syncthreads();
         if (tid < ND) {
@@ -197,65 +235,90 @@ __global__ __launch_bounds__(ElemCfg<P>::NT) void kl_element_kernel(DevModel M, 
 }
 
 // -------------------------------------------------------------------------------------------------
-// Row-owner gather: one workgroup per control point a; every CSR entry of the 3 dof rows of a is the
-// ordered sum of the (<= (p+1)^2) element blocks containing both a and the column control point.
+// Row-owner gather: one workgroup per control point a.  Every element containing a contributes the
+// three dof rows (a, i) of its block: they are read as whole contiguous rows (coalesced) and summed,
+// in fixed element order, into LDS accumulators laid out on a's neighbour box; each CSR entry of the
+// rows is then written exactly once (Dirichlet handling fused).  No atomics, bitwise reproducible.
 template <int P>
 __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_first, long long e_first, long long e_count, int flags,
                                                          const double* __restrict__ blk,
                                                          double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1,
                                                          double* __restrict__ valC2, double* __restrict__ valH, double* __restrict__ R) {
     using Cfg = ElemCfg<P>;
-    constexpr int P1 = Cfg::P1, NB = Cfg::NB, ND = Cfg::ND;
+    constexpr int P1 = Cfg::P1, NB = Cfg::NB, ND = Cfg::ND, WB = 2 * P + 1, NBOX = WB * WB;
     const long long a = a_first + blockIdx.x;
     if (a >= M.total_cp) return;
     const PatchDev& Pt = M.patches[M.cp_patch[a]];
     const int la = int(a - Pt.cp_off), ia = la % Pt.nu, ja = la / Pt.nu;
     const int* spu = M.ints + Pt.spu; const int* spv = M.ints + Pt.spv; const int* c2u = M.ints + Pt.c2u; const int* c2v = M.ints + Pt.c2v;
-    const int eu_lo_a = c2u[2 * ia], eu_hi_a = c2u[2 * ia + 1], ev_lo_a = c2v[2 * ja], ev_hi_a = c2v[2 * ja + 1];
+    const int eu0 = c2u[2 * ia], eu1 = c2u[2 * ia + 1], ev0 = c2v[2 * ja], ev1 = c2v[2 * ja + 1];
+    const int i0 = eu1 >= eu0 ? spu[eu0] - P : 0, j0 = ev1 >= ev0 ? spv[ev0] - P : 0;        // neighbour box origin
+    const int i1 = eu1 >= eu0 ? spu[eu1] : -1, j1 = ev1 >= ev0 ? spv[ev1] : -1, wbox = i1 - i0 + 1;
     const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c, ptr_s = M.nb_ptr_s[a], deg_s = M.nb_ptr_s[a + 1] - ptr_s;
+    const long long pbeg = Pt.cp_off, pend = Pt.cp_off + (long long)Pt.nu * Pt.nv;
     const int tid = threadIdx.x;
-    const long long pend = Pt.cp_off + (long long)Pt.nu * Pt.nv;
 
-    // loops over the elements common to a and b, summing block entry `off(la_loc, lb_loc)`
-    auto common_sum = [&](long long bcp, auto&& entry) -> double {
-        if (bcp < Pt.cp_off || bcp >= pend) return 0.0;
-        const int lb = int(bcp - Pt.cp_off), ib = lb % Pt.nu, jb = lb / Pt.nu;
-        const int eu0 = max(eu_lo_a, c2u[2 * ib]), eu1 = min(eu_hi_a, c2u[2 * ib + 1]);
-        const int ev0 = max(ev_lo_a, c2v[2 * jb]), ev1 = min(ev_hi_a, c2v[2 * jb + 1]);
-        double s = 0.0;
-        for (int ev = ev0; ev <= ev1; ++ev) for (int eu = eu0; eu <= eu1; ++eu) {
-            const long long e = Pt.elem_off + eu + (long long)ev * Pt.nelu - e_first;
-            if (e < 0 || e >= e_count) continue;
-            const int bu = spu[eu] - P, bv = spv[ev] - P;
-            const int al = (ia - bu) + (ja - bv) * P1, bl = (ib - bu) + (jb - bv) * P1;
-            s += entry(blk + (size_t)e * Cfg::BLK, al, bl);
+    __shared__ double aK[3][NBOX][3], aC[3][3][NBOX], aH[3][NBOX], aR[3];
+    for (int k = tid; k < 9 * NBOX; k += 256) { (&aK[0][0][0])[k] = 0.0; (&aC[0][0][0])[k] = 0.0; }
+    for (int k = tid; k < 3 * NBOX; k += 256) (&aH[0][0])[k] = 0.0;
+    if (tid < 3) aR[tid] = 0.0;
+    __syncthreads();
+    constexpr int NW = 2 * 3 * ND + 3 * NB + 3;          // K rows, C rows, H rows, R entries of one element
+    for (int ev = ev0; ev <= ev1; ++ev) for (int eu = eu0; eu <= eu1; ++eu) {
+        const long long e = Pt.elem_off + eu + (long long)ev * Pt.nelu - e_first;
+        if (e < 0 || e >= e_count) continue;                                   // uniform over the workgroup
+        const double* B = blk + (size_t)e * Cfg::BLK;
+        const int bu = spu[eu] - P, bv = spv[ev] - P, al = (ia - bu) + (ja - bv) * P1;
+        for (int w = tid; w < NW; w += 256) {
+            if (w < 3 * ND) {
+                if (!(flags & GF_ASM_K_BIT)) continue;
+                const int i = w / ND, c = w - i * ND, bl = c / 3, j = c - 3 * bl;
+                const int ks = (bu + bl % P1 - i0) + (bv + bl / P1 - j0) * wbox;
+                aK[i][ks][j] += B[Cfg::OFF_K + (3 * al + i) * ND + c];
+            } else if (w < 6 * ND) {
+                if (!(flags & GF_ASM_C_BIT)) continue;
+                const int w2 = w - 3 * ND, i = w2 / ND, c = w2 - i * ND, bl = c / 3, f = c - 3 * bl;
+                const int ks = (bu + bl % P1 - i0) + (bv + bl / P1 - j0) * wbox;
+                aC[f][i][ks] += B[Cfg::OFF_C + (3 * al + i) * ND + c];
+            } else if (w < 6 * ND + 3 * NB) {
+                if (!(flags & GF_ASM_H_BIT)) continue;
+                const int w2 = w - 6 * ND, i = w2 / NB, bl = w2 - i * NB;
+                const int ks = (bu + bl % P1 - i0) + (bv + bl / P1 - j0) * wbox;
+                aH[i][ks] += B[Cfg::OFF_H + (3 * al + i) * NB + bl];
+            } else {
+                if (flags & GF_ASM_R_BIT) aR[w - 6 * ND - 3 * NB] += B[Cfg::OFF_R + 3 * al + (w - 6 * ND - 3 * NB)];
+            }
         }
-        return s;
+        __syncthreads();
+    }
+    // box slot of neighbour control point bcp (-1: not a shell neighbour, i.e. coupling-only column)
+    auto box_slot = [&](long long bcp) -> int {
+        if (bcp < pbeg || bcp >= pend) return -1;
+        const int lb = int(bcp - pbeg), ib = lb % Pt.nu, jb = lb / Pt.nu;
+        return (ib >= i0 && ib <= i1 && jb >= j0 && jb <= j1) ? (ib - i0) + (jb - j0) * wbox : -1;
     };
-
-    if (flags & GF_ASM_K_BIT) for (long long idx = tid; idx < 9 * deg_c; idx += blockDim.x) {
+    if (flags & GF_ASM_K_BIT) for (long long idx = tid; idx < 9 * deg_c; idx += 256) {
         const int i = int(idx / (3 * deg_c)), rem = int(idx - (long long)i * 3 * deg_c), k = rem / 3, j = rem - 3 * k;
         const long long bcp = M.nb_c[ptr_c + k], row = 3 * a + i, col = 3 * bcp + j;
-        double v;
+        double v = 0.0;
         if (M.zero[row] || M.zero[col]) v = (row == col) ? 1.0 : 0.0;
-        else v = common_sum(bcp, [&](const double* B, int al, int bl) { return B[Cfg::OFF_K + (3 * al + i) * ND + 3 * bl + j]; });
+        else { const int ks = box_slot(bcp); if (ks >= 0) v = aK[i][ks][j]; }
         valK[9 * ptr_c + idx] = v;
     }
-    if (flags & GF_ASM_C_BIT) for (long long idx = tid; idx < 9 * deg_c; idx += blockDim.x) {
+    if (flags & GF_ASM_C_BIT) for (long long idx = tid; idx < 9 * deg_c; idx += 256) {
         const int f = int(idx / (3 * deg_c)), rem = int(idx - (long long)f * 3 * deg_c), i = int(rem / deg_c), k = int(rem - (long long)i * deg_c);
-        const long long bcp = M.nb_c[ptr_c + k], row = 3 * a + i;
+        const long long bcp = M.nb_c[ptr_c + k];
         double v = 0.0;
-        if (!M.zero[row]) v = common_sum(bcp, [&](const double* B, int al, int bl) { return B[Cfg::OFF_C + (3 * al + i) * ND + 3 * bl + f]; });
+        if (!M.zero[3 * a + i]) { const int ks = box_slot(bcp); if (ks >= 0) v = aC[f][i][ks]; }
         double* dst = f == 0 ? valC0 : (f == 1 ? valC1 : valC2);
         dst[3 * ptr_c + (long long)i * deg_c + k] = v;
     }
-    if (flags & GF_ASM_H_BIT) for (long long idx = tid; idx < 3 * deg_s; idx += blockDim.x) {
+    if (flags & GF_ASM_H_BIT) for (long long idx = tid; idx < 3 * deg_s; idx += 256) {
         const int i = int(idx / deg_s), k = int(idx - (long long)i * deg_s);
-        const long long bcp = M.nb_s[ptr_s + k];
-        valH[3 * ptr_s + idx] = common_sum(bcp, [&](const double* B, int al, int bl) { return B[Cfg::OFF_H + (3 * al + i) * NB + bl]; });
+        const int ks = box_slot(M.nb_s[ptr_s + k]);
+        valH[3 * ptr_s + idx] = ks >= 0 ? aH[i][ks] : 0.0;
     }
-    if ((flags & GF_ASM_R_BIT) && tid < 3)
-        R[3 * a + tid] = common_sum(a, [&](const double* B, int al, int) { return B[Cfg::OFF_R + 3 * al + tid]; });
+    if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * a + tid] = aR[tid];
 }
 
 // ------------------------------------------------------------------------------------------ penalty
@@ -300,67 +363,66 @@ template <int P> __device__ __forceinline__ int pen_local(const DevModel& M, con
     return (i >= 0 && i <= P && j >= 0 && j <= P) ? i + j * (P + 1) : -1;
 }
 
-// residual rows: one thread per owned control point; fixed summation order -> bitwise reproducible
+// Penalty rows of one owned control point a (one workgroup each): residual entries and the coupling
+// blocks of K and dR/dCP.  For every mortar vertex v whose support contains a, the Hessian rows are
+// first contracted with nu_a once (w-vectors, shared through LDS), then every partner control point
+// b of v (both sides, one lane each) adds its 3x3 blocks into LDS accumulators indexed by b's slot
+// in a's neighbour list.  Items and vertices are visited in a fixed order: bitwise reproducible.
+constexpr int PEN_MAXDEG = 320;
 template <int P>
-__global__ __launch_bounds__(64) void pen_rows_kernel(DevModel M, DevPenalty Q, const double* __restrict__ pbuf, double* __restrict__ R) {
-    constexpr int NB = (P + 1) * (P + 1);
-    const long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q, int flags, const double* __restrict__ pbuf, double* __restrict__ R,
+                                                        double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1, double* __restrict__ valC2) {
+    constexpr int P1 = P + 1, NB = P1 * P1;
+    const long long gidx = blockIdx.x;
     if (gidx >= Q.nrow_groups) return;
-    double r[3] = {0, 0, 0}; int a = -1;
-    for (long long it = Q.row_ptr[gidx]; it < Q.row_ptr[gidx + 1]; ++it) {
-        const PenRowItem I = Q.row_items[it]; a = I.a;
-        const int itf = I.code >> 1, sd = I.code & 1;
+    const int tid = threadIdx.x;
+    const long long it0 = Q.row_ptr[gidx], it1 = Q.row_ptr[gidx + 1];
+    const int a = Q.row_items[it0].a;
+    const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c;
+    __shared__ double accK[PEN_MAXDEG][9], accC[PEN_MAXDEG][9], s_wK[3][18], s_wC[3][12], s_r[3];
+    const bool mats = (flags & (GF_ASM_K_BIT | GF_ASM_C_BIT)) != 0 && deg_c <= PEN_MAXDEG;
+    if (mats) for (int k = tid; k < 9 * (int)deg_c; k += 64) { (&accK[0][0])[k] = 0.0; (&accC[0][0])[k] = 0.0; }
+    if (tid < 3) s_r[tid] = 0.0;
+    __syncthreads();
+    for (long long it = it0; it < it1; ++it) {
+        const PenRowItem I = Q.row_items[it];
+        const int itf = I.code >> 1, s = I.code & 1;
         for (long long v = I.lo; v <= I.hi; ++v) {
-            const int al = pen_local<P>(M, Q, v, sd, itf, a);
-            if (al < 0) continue;
-            const double* nu = Q.pt_nu + ((size_t)v * 2 + sd) * 3 * NB; const double* g = pbuf + (size_t)v * PB_STRIDE + PB_GRAD + 9 * sd;
-            for (int m = 0; m < 3; ++m) for (int i = 0; i < 3; ++i) r[i] += nu[m * NB + al] * g[3 * m + i];
-        }
-    }
-    if (a >= 0) for (int i = 0; i < 3; ++i) R[3 * (long long)a + i] += r[i];
-}
-
-// coupling blocks of K and dR/dCP: one thread per owned (a, neighbour slot k)
-template <int P>
-__global__ __launch_bounds__(64) void pen_blocks_kernel(DevModel M, DevPenalty Q, int flags, const double* __restrict__ pbuf,
-                                                         double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1, double* __restrict__ valC2) {
-    constexpr int NB = (P + 1) * (P + 1);
-    const long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gidx >= Q.nblk_groups) return;
-    double kk[9], cc[9];
-    for (int q = 0; q < 9; ++q) { kk[q] = 0.0; cc[q] = 0.0; }
-    int a = -1, kslot = 0, bcp = 0;
-    for (long long it = Q.blk_ptr[gidx]; it < Q.blk_ptr[gidx + 1]; ++it) {
-        const PenBlockItem I = Q.blk_items[it]; a = I.a; kslot = I.k; bcp = I.b;
-        const int itf = I.code >> 2, s = (I.code >> 1) & 1, t = I.code & 1;
-        for (long long v = I.lo; v <= I.hi; ++v) {
-            const int al = pen_local<P>(M, Q, v, s, itf, a), bl = pen_local<P>(M, Q, v, t, itf, bcp);
-            if (al < 0 || bl < 0) continue;
-            const double* na = Q.pt_nu + ((size_t)v * 2 + s) * 3 * NB; const double* nb = Q.pt_nu + ((size_t)v * 2 + t) * 3 * NB;
-            const double* pb = pbuf + (size_t)v * PB_STRIDE;
-            for (int m = 0; m < 3; ++m) {
-                const double ra = na[m * NB + al];
-                for (int mm = 0; mm < 3; ++mm) {
-                    const double rab = ra * nb[mm * NB + bl];
-                    const double* hyy = pb + PB_HYY + (9 * s + 3 * m) * 18 + 9 * t + 3 * mm;
-                    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) kk[3 * i + j] += rab * hyy[i * 18 + j];
-                    if (mm > 0) {
-                        const double* hyc = pb + PB_HYC + (9 * s + 3 * m) * 12 + 6 * t + 3 * (mm - 1);
-                        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) cc[3 * i + j] += rab * hyc[i * 12 + j];
+            const int al = pen_local<P>(M, Q, v, s, itf, a);
+            if (al < 0) continue;                                              // uniform over the workgroup
+            const double* na = Q.pt_nu + ((size_t)v * 2 + s) * 3 * NB; const double* pb = pbuf + (size_t)v * PB_STRIDE;
+            const double n0 = na[al], n1 = na[NB + al], n2 = na[2 * NB + al];
+            // w-vectors: rows (s, m, i) contracted over m with nu_a
+            if (tid < 54) { const int i = tid / 18, c = tid - 18 * i; const double* h = pb + PB_HYY + (9 * s + i) * 18 + c; s_wK[i][c] = n0 * h[0] + n1 * h[3 * 18] + n2 * h[6 * 18]; }
+            if (tid < 36) { const int i = tid / 12, c = tid - 12 * i; const double* h = pb + PB_HYC + (9 * s + i) * 12 + c; s_wC[i][c] = n0 * h[0] + n1 * h[3 * 12] + n2 * h[6 * 12]; }
+            if (tid < 3) { const double* g = pb + PB_GRAD + 9 * s; s_r[tid] += n0 * g[tid] + n1 * g[3 + tid] + n2 * g[6 + tid]; }
+            __syncthreads();
+            if (mats && tid < 2 * NB) {
+                const int t = tid / NB, bl = tid - t * NB;
+                const PatchDev& Pb = M.patches[Q.if_patch[2 * itf + t]];
+                const int bcp = int(Pb.cp_off + (Q.pt_base[4 * v + 2 * t] + bl % P1) + (long long)(Q.pt_base[4 * v + 2 * t + 1] + bl / P1) * Pb.nu);
+                int lo = 0, hi = (int)deg_c - 1, k = -1;                        // slot of b in a's neighbour list
+                while (lo <= hi) { const int mid = (lo + hi) >> 1, c = M.nb_c[ptr_c + mid]; if (c == bcp) { k = mid; break; } if (c < bcp) lo = mid + 1; else hi = mid - 1; }
+                if (k >= 0) {
+                    const double* nb = Q.pt_nu + ((size_t)v * 2 + t) * 3 * NB;
+                    const double b0 = nb[bl], b1 = nb[NB + bl], b2 = nb[2 * NB + bl];
+                    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+                        accK[k][3 * i + j] += s_wK[i][9 * t + j] * b0 + s_wK[i][9 * t + 3 + j] * b1 + s_wK[i][9 * t + 6 + j] * b2;
+                        accC[k][3 * i + j] += s_wC[i][6 * t + j] * b1 + s_wC[i][6 * t + 3 + j] * b2;
                     }
                 }
             }
+            __syncthreads();
         }
     }
-    if (a < 0) return;
-    const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c;
-    for (int i = 0; i < 3; ++i) {
-        const long long row = 3 * (long long)a + i;
+    if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * (long long)a + tid] += s_r[tid];
+    if (!mats) return;
+    for (int idx = tid; idx < 9 * (int)deg_c; idx += 64) {
+        const int k = idx / 9, q = idx - 9 * k, i = q / 3, j = q - 3 * i;
+        const long long row = 3 * (long long)a + i, bcp = M.nb_c[ptr_c + k];
         if (M.zero[row]) continue;
-        for (int j = 0; j < 3; ++j) {
-            if ((flags & GF_ASM_K_BIT) && !M.zero[3 * (long long)bcp + j]) valK[9 * ptr_c + (long long)i * 3 * deg_c + 3 * kslot + j] += kk[3 * i + j];
-            if (flags & GF_ASM_C_BIT) { double* dst = j == 0 ? valC0 : (j == 1 ? valC1 : valC2); dst[3 * ptr_c + (long long)i * deg_c + kslot] += cc[3 * i + j]; }
-        }
+        if ((flags & GF_ASM_K_BIT) && !M.zero[3 * bcp + j]) valK[9 * ptr_c + (long long)i * 3 * deg_c + 3 * k + j] += accK[k][q];
+        if (flags & GF_ASM_C_BIT) { double* dst = j == 0 ? valC0 : (j == 1 ? valC1 : valC2); dst[3 * ptr_c + (long long)i * deg_c + k] += accC[k][q]; }
     }
 }
 

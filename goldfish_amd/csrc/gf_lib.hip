@@ -99,6 +99,9 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             Q.row_items = h->upload(H.row_items); Q.row_ptr = h->upload(rp); Q.blk_items = h->upload(H.blk_items); Q.blk_ptr = h->upload(bp);
             Q.nrow_groups = (long long)rp.size() - 1; Q.nblk_groups = (long long)bp.size() - 1;
             h->d_pbuf = h->dalloc<double>((size_t)H.npts * PB_STRIDE);
+            for (const PenRowItem& it : H.row_items)
+                if (H.nb_ptr_c[it.a + 1] - H.nb_ptr_c[it.a] > PEN_MAXDEG)
+                    throw std::runtime_error("gf_create: a control point couples to more than " + std::to_string(PEN_MAXDEG) + " neighbours (PEN_MAXDEG)");
         }
         // element-block scratch, chunked over whole patches
         const int P = H.degree, NB = (P + 1) * (P + 1), ND = 3 * NB;
@@ -210,10 +213,8 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
     const HostModel& H = h->H;
     if (H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP))) {
         hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf);
-        if (flags & GF_ASM_R) hipLaunchKernelGGL(pen_rows_kernel<P>, dim3((unsigned)((h->Q.nrow_groups + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf, h->d_R);
-        if (flags & (GF_ASM_K | GF_ASM_DRDCP))
-            hipLaunchKernelGGL(pen_blocks_kernel<P>, dim3((unsigned)((h->Q.nblk_groups + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, flags, h->d_pbuf,
-                               h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3]);
+        hipLaunchKernelGGL(pen_owner_kernel<P>, dim3((unsigned)h->Q.nrow_groups), dim3(64), 0, h->stream, h->M, h->Q, flags, h->d_pbuf, h->d_R,
+                           h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3]);
     }
     if (flags & GF_ASM_R) {
         const long long npl = (long long)H.pl_dof.size();

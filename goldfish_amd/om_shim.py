@@ -1,0 +1,133 @@
+"""Minimal stand-in for the part of ``openmdao.api`` the GOLDFISH components use
+(OpenMDAO is not installed in the build image).  The components
+in goldfish_amd/om_comps import the real ``openmdao.api`` when it is available and
+this shim otherwise; the component code is identical in both cases.
+
+Implemented: options.declare / [] access, add_input / add_output / declare_partials,
+Problem(model=<single component>).setup / run_model / [] access, and a directional
+``check_partials`` (analytic J.v by the component's own linearize / apply_linear or
+compute_partials vs central finite differences)."""
+import numpy as np
+
+
+class _Options(dict):
+    def declare(self, name, default=None, **kwargs):
+        self.setdefault(name, default)
+
+
+class _Vec(dict):
+    """name -> ndarray with OpenMDAO-like assignment semantics (values copied into place)."""
+
+    def __setitem__(self, k, v):
+        if k in self:
+            dict.__getitem__(self, k)[...] = np.asarray(v, float).reshape(dict.__getitem__(self, k).shape)
+        else:
+            dict.__setitem__(self, k, np.array(v, float))
+
+
+class _Component:
+    def __init__(self, **kwargs):
+        self.options = _Options()
+        self._in, self._out, self._partials = {}, {}, []
+        self.initialize()
+        for k, v in kwargs.items():
+            self.options[k] = v
+
+    def initialize(self):
+        pass
+
+    def setup(self):
+        pass
+
+    def add_input(self, name, val=1.0, shape=None, **kw):
+        shape = (shape,) if isinstance(shape, (int, np.integer)) else shape
+        arr = np.array(val, float)
+        self._in[name] = np.broadcast_to(arr, shape).copy() if shape is not None else np.atleast_1d(arr).copy()
+
+    def add_output(self, name, val=1.0, shape=None, **kw):
+        shape = (shape,) if isinstance(shape, (int, np.integer)) else shape
+        arr = np.array(val, float)
+        self._out[name] = np.broadcast_to(arr, shape).copy() if shape is not None else np.atleast_1d(arr).copy()
+
+    def declare_partials(self, of, wrt, **kw):
+        self._partials.append((of, wrt, kw))
+
+
+class ImplicitComponent(_Component):
+    pass
+
+
+class ExplicitComponent(_Component):
+    pass
+
+
+class Problem:
+    def __init__(self, model=None):
+        self.model = model
+
+    def setup(self):
+        m = self.model
+        m.setup()
+        self.inputs = _Vec({k: v.copy() for k, v in m._in.items()})
+        self.outputs = _Vec({k: v.copy() for k, v in m._out.items()})
+        self.residuals = _Vec({k: np.zeros_like(v) for k, v in m._out.items()})
+
+    def __getitem__(self, name):
+        return self.inputs[name] if name in self.inputs else self.outputs[name]
+
+    def __setitem__(self, name, val):
+        (self.inputs if name in self.inputs else self.outputs)[name] = val
+
+    def run_model(self):
+        m = self.model
+        if isinstance(m, ImplicitComponent):
+            m.solve_nonlinear(self.inputs, self.outputs)
+        else:
+            m.compute(self.inputs, self.outputs)
+
+    def check_partials(self, step=1e-6, seed=0, compact_print=True):
+        """Relative error of analytic vs FD directional derivatives, per (of, wrt)."""
+        m, rng = self.model, np.random.default_rng(seed)
+        res = {}
+        if isinstance(m, ImplicitComponent):
+            of = list(self.outputs)[0]
+            m.linearize(self.inputs, self.outputs, None)
+            for wrt in list(self.inputs) + [of]:
+                tgt = self.inputs if wrt in self.inputs else self.outputs
+                base = tgt[wrt].copy()
+                v = rng.standard_normal(base.shape)
+                d_in = _Vec({k: np.zeros_like(x) for k, x in self.inputs.items()})
+                d_out = _Vec({k: np.zeros_like(x) for k, x in self.outputs.items()})
+                d_res = _Vec({k: np.zeros_like(x) for k, x in self.outputs.items()})
+                (d_in if wrt in self.inputs else d_out)[wrt] = v
+                m.apply_linear(self.inputs, self.outputs, d_in, d_out, d_res, 'fwd')
+                an = d_res[of].copy()
+                r = []
+                for sgn in (1, -1):
+                    tgt[wrt] = base + sgn * step * v
+                    m.apply_nonlinear(self.inputs, self.outputs, self.residuals)
+                    r.append(self.residuals[of].copy())
+                tgt[wrt] = base
+                fd = (r[0] - r[1]) / (2 * step)
+                res[(of, wrt)] = np.abs(fd - an).max() / max(np.abs(fd).max(), 1e-300)
+        else:
+            partials = {}
+            m.compute(self.inputs, self.outputs)
+            m.compute_partials(self.inputs, partials)
+            for (of, wrt), Jm in partials.items():
+                base = self.inputs[wrt].copy()
+                v = rng.standard_normal(base.shape)
+                an = np.asarray(Jm).reshape(self.outputs[of].size, base.size) @ v.ravel()
+                f = []
+                for sgn in (1, -1):
+                    self.inputs[wrt] = base + sgn * step * v
+                    m.compute(self.inputs, self.outputs)
+                    f.append(self.outputs[of].copy().ravel())
+                self.inputs[wrt] = base
+                fd = (f[0] - f[1]) / (2 * step)
+                res[(of, wrt)] = np.abs(fd - an).max() / max(np.abs(fd).max(), 1e-300)
+            m.compute(self.inputs, self.outputs)
+        if compact_print:
+            for k, e in res.items():
+                print("check_partials %s wrt %s: rel err %.3e" % (k[0], k[1], e))
+        return res
