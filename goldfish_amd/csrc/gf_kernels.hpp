@@ -263,34 +263,31 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
     for (int k = tid; k < 3 * NBOX; k += 256) (&aH[0][0])[k] = 0.0;
     if (tid < 3) aR[tid] = 0.0;
     __syncthreads();
-    constexpr int NW = 2 * 3 * ND + 3 * NB + 3;          // K rows, C rows, H rows, R entries of one element
+    // Wave w < 3 owns dof row i = w of K and dR/dCP, wave 3 owns dR/dh and R: an LDS slot is only ever
+    // touched by one wave, whose LDS operations execute in program order, so the element loop needs
+    // no barrier and the row loads of successive elements overlap.
+    const int wave = tid >> 6, lane = tid & 63;
     for (int ev = ev0; ev <= ev1; ++ev) for (int eu = eu0; eu <= eu1; ++eu) {
         const long long e = Pt.elem_off + eu + (long long)ev * Pt.nelu - e_first;
-        if (e < 0 || e >= e_count) continue;                                   // uniform over the workgroup
+        if (e < 0 || e >= e_count) continue;
         const double* B = blk + (size_t)e * Cfg::BLK;
         const int bu = spu[eu] - P, bv = spv[ev] - P, al = (ia - bu) + (ja - bv) * P1;
-        for (int w = tid; w < NW; w += 256) {
-            if (w < 3 * ND) {
-                if (!(flags & GF_ASM_K_BIT)) continue;
-                const int i = w / ND, c = w - i * ND, bl = c / 3, j = c - 3 * bl;
-                const int ks = (bu + bl % P1 - i0) + (bv + bl / P1 - j0) * wbox;
-                aK[i][ks][j] += B[Cfg::OFF_K + (3 * al + i) * ND + c];
-            } else if (w < 6 * ND) {
-                if (!(flags & GF_ASM_C_BIT)) continue;
-                const int w2 = w - 3 * ND, i = w2 / ND, c = w2 - i * ND, bl = c / 3, f = c - 3 * bl;
-                const int ks = (bu + bl % P1 - i0) + (bv + bl / P1 - j0) * wbox;
-                aC[f][i][ks] += B[Cfg::OFF_C + (3 * al + i) * ND + c];
-            } else if (w < 6 * ND + 3 * NB) {
-                if (!(flags & GF_ASM_H_BIT)) continue;
-                const int w2 = w - 6 * ND, i = w2 / NB, bl = w2 - i * NB;
-                const int ks = (bu + bl % P1 - i0) + (bv + bl / P1 - j0) * wbox;
-                aH[i][ks] += B[Cfg::OFF_H + (3 * al + i) * NB + bl];
-            } else {
-                if (flags & GF_ASM_R_BIT) aR[w - 6 * ND - 3 * NB] += B[Cfg::OFF_R + 3 * al + (w - 6 * ND - 3 * NB)];
+        if (wave < 3) {
+            const int i = wave;
+            for (int c = lane; c < ND; c += 64) {
+                const int bl = c / 3, j = c - 3 * bl, ks = (bu + bl % P1 - i0) + (bv + bl / P1 - j0) * wbox;
+                if (flags & GF_ASM_K_BIT) aK[i][ks][j] += B[Cfg::OFF_K + (3 * al + i) * ND + c];
+                if (flags & GF_ASM_C_BIT) aC[j][i][ks] += B[Cfg::OFF_C + (3 * al + i) * ND + c];
             }
+        } else {
+            if (flags & GF_ASM_H_BIT) for (int w = lane; w < 3 * NB; w += 64) {
+                const int i = w / NB, bl = w - i * NB, ks = (bu + bl % P1 - i0) + (bv + bl / P1 - j0) * wbox;
+                aH[i][ks] += B[Cfg::OFF_H + (3 * al + i) * NB + bl];
+            }
+            if ((flags & GF_ASM_R_BIT) && lane < 3) aR[lane] += B[Cfg::OFF_R + 3 * al + lane];
         }
-        __syncthreads();
     }
+    __syncthreads();
     // box slot of neighbour control point bcp (-1: not a shell neighbour, i.e. coupling-only column)
     auto box_slot = [&](long long bcp) -> int {
         if (bcp < pbeg || bcp >= pend) return -1;
@@ -370,7 +367,7 @@ template <int P> __device__ __forceinline__ int pen_local(const DevModel& M, con
 // in a's neighbour list.  Items and vertices are visited in a fixed order: bitwise reproducible.
 constexpr int PEN_MAXDEG = 320;
 template <int P>
-__global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q, int flags, const double* __restrict__ pbuf, double* __restrict__ R,
+__global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q, int flags, int maxdeg, const double* __restrict__ pbuf, double* __restrict__ R,
                                                         double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1, double* __restrict__ valC2) {
     constexpr int P1 = P + 1, NB = P1 * P1;
     const long long gidx = blockIdx.x;
@@ -379,9 +376,14 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
     const long long it0 = Q.row_ptr[gidx], it1 = Q.row_ptr[gidx + 1];
     const int a = Q.row_items[it0].a;
     const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c;
-    __shared__ double accK[PEN_MAXDEG][9], accC[PEN_MAXDEG][9], s_wK[3][18], s_wC[3][12], s_r[3];
-    const bool mats = (flags & (GF_ASM_K_BIT | GF_ASM_C_BIT)) != 0 && deg_c <= PEN_MAXDEG;
+    extern __shared__ double s_dyn[];                      // [maxdeg][9] K, [maxdeg][9] C, [maxdeg] neighbour ids
+    double (*accK)[9] = reinterpret_cast<double (*)[9]>(s_dyn);
+    double (*accC)[9] = reinterpret_cast<double (*)[9]>(s_dyn + 9 * (size_t)maxdeg);
+    int* s_nb = reinterpret_cast<int*>(s_dyn + 18 * (size_t)maxdeg);
+    __shared__ double s_wK[3][18], s_wC[3][12], s_r[3];
+    const bool mats = (flags & (GF_ASM_K_BIT | GF_ASM_C_BIT)) != 0 && deg_c <= maxdeg;
     if (mats) for (int k = tid; k < 9 * (int)deg_c; k += 64) { (&accK[0][0])[k] = 0.0; (&accC[0][0])[k] = 0.0; }
+    if (mats) for (int k = tid; k < (int)deg_c; k += 64) s_nb[k] = M.nb_c[ptr_c + k];
     if (tid < 3) s_r[tid] = 0.0;
     __syncthreads();
     for (long long it = it0; it < it1; ++it) {
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
                 const PatchDev& Pb = M.patches[Q.if_patch[2 * itf + t]];
                 const int bcp = int(Pb.cp_off + (Q.pt_base[4 * v + 2 * t] + bl % P1) + (long long)(Q.pt_base[4 * v + 2 * t + 1] + bl / P1) * Pb.nu);
                 int lo = 0, hi = (int)deg_c - 1, k = -1;                        // slot of b in a's neighbour list
-                while (lo <= hi) { const int mid = (lo + hi) >> 1, c = M.nb_c[ptr_c + mid]; if (c == bcp) { k = mid; break; } if (c < bcp) lo = mid + 1; else hi = mid - 1; }
+                while (lo <= hi) { const int mid = (lo + hi) >> 1, c = s_nb[mid]; if (c == bcp) { k = mid; break; } if (c < bcp) lo = mid + 1; else hi = mid - 1; }
                 if (k >= 0) {
                     const double* nb = Q.pt_nu + ((size_t)v * 2 + t) * 3 * NB;
                     const double b0 = nb[bl], b1 = nb[NB + bl], b2 = nb[2 * NB + bl];

@@ -33,6 +33,7 @@ struct gf_handle {
     std::vector<Chunk> chunks;
     std::vector<hipEvent_t> ev0, ev1; int ev_n = 0;   // element-kernel timing
     bool assembled[5] = {false, false, false, false, false};
+    int pen_maxdeg = 0;                               // largest neighbour count of an interface control point
 
     template <class T> T* dalloc(size_t n) {
         void* p = nullptr; const size_t nb = (n > 0 ? n : 1) * sizeof(T);
@@ -99,6 +100,8 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             Q.row_items = h->upload(H.row_items); Q.row_ptr = h->upload(rp); Q.blk_items = h->upload(H.blk_items); Q.blk_ptr = h->upload(bp);
             Q.nrow_groups = (long long)rp.size() - 1; Q.nblk_groups = (long long)bp.size() - 1;
             h->d_pbuf = h->dalloc<double>((size_t)H.npts * PB_STRIDE);
+            for (const PenRowItem& it : H.row_items)
+                h->pen_maxdeg = std::max(h->pen_maxdeg, (int)(H.nb_ptr_c[it.a + 1] - H.nb_ptr_c[it.a]));
             for (const PenRowItem& it : H.row_items)
                 if (H.nb_ptr_c[it.a + 1] - H.nb_ptr_c[it.a] > PEN_MAXDEG)
                     throw std::runtime_error("gf_create: a control point couples to more than " + std::to_string(PEN_MAXDEG) + " neighbours (PEN_MAXDEG)");
@@ -213,7 +216,7 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
     const HostModel& H = h->H;
     if (H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP))) {
         hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf);
-        hipLaunchKernelGGL(pen_owner_kernel<P>, dim3((unsigned)h->Q.nrow_groups), dim3(64), 0, h->stream, h->M, h->Q, flags, h->d_pbuf, h->d_R,
+        hipLaunchKernelGGL(pen_owner_kernel<P>, dim3((unsigned)h->Q.nrow_groups), dim3(64), (size_t)h->pen_maxdeg * (18 * 8 + 4) + 8, h->stream, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R,
                            h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3]);
     }
     if (flags & GF_ASM_R) {
