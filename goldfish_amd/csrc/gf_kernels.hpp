@@ -318,6 +318,108 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
     if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * a + tid] = aR[tid];
 }
 
+// ------------------------------------------------------------------------------------- functionals
+// K10 of SURVEY.md 2.2: strain energy W = sum int Psi, volume V = sum int t dA and their gradients.
+// One wave per element; per-element gradients go to a block [NB][11] (+ We, Ve), summed per control
+// point by kl_fgather_kernel in fixed element order.
+template <int P> struct FunCfg { static constexpr int NB = (P + 1) * (P + 1), STRIDE = NB * 11 + 2; };
+
+template <int P>
+__global__ __launch_bounds__(64) void kl_functional_kernel(DevModel M, int e_first, double* __restrict__ blk, size_t blk_stride) {
+    constexpr int P1 = P + 1, NB = P1 * P1, NG = NB, ND = 3 * NB;
+    const int tid = threadIdx.x;
+    const long long e = (long long)e_first + blockIdx.x;
+    if (e >= M.nelem) return;
+    const PatchDev& Pt = M.patches[M.elem_patch[e]];
+    const int le = int(e - Pt.elem_off), eu = le % Pt.nelu, ev = le / Pt.nelu;
+    const int iu0 = M.ints[Pt.spu + eu] - P, iv0 = M.ints[Pt.spv + ev] - P;
+    __shared__ double s_c[NB][3], s_d[NB][3], s_h[NB], s_w[NB];
+    __shared__ double s_tu[P1 * 3 * P1], s_tv[P1 * 3 * P1], s_wg[2 * P1];
+    __shared__ double s_fe[NG][FE_SIZE + 8];            // + W[6], wq, t
+    if (tid < NB) {
+        const long long g = Pt.cp_off + (iu0 + tid % P1) + (long long)(iv0 + tid / P1) * Pt.nu;
+        const double4 c4 = reinterpret_cast<const double4*>(M.cp4)[g];
+        s_c[tid][0] = c4.x; s_c[tid][1] = c4.y; s_c[tid][2] = c4.z; s_w[tid] = c4.w;
+        s_d[tid][0] = c4.x + M.u[3 * g]; s_d[tid][1] = c4.y + M.u[3 * g + 1]; s_d[tid][2] = c4.z + M.u[3 * g + 2];
+        s_h[tid] = M.h[g];
+    }
+    for (int k = tid; k < P1 * 3 * P1; k += 64) { s_tu[k] = M.tab[Pt.tabu + eu * P1 * 3 * P1 + k]; s_tv[k] = M.tab[Pt.tabv + ev * P1 * 3 * P1 + k]; }
+    if (tid < P1) { s_wg[tid] = M.tab[Pt.wu + eu * P1 + tid]; s_wg[P1 + tid] = M.tab[Pt.wv + ev * P1 + tid]; }
+    __syncthreads();
+    if (tid < NG) {
+        const int gu = tid % P1, gv = tid / P1;
+        double W[6] = {0, 0, 0, 0, 0, 0}, Nb[6], R[6];
+        for (int a = 0; a < NB; ++a) { bspline6<P>(s_tu, s_tv, gu, gv, a, Nb); for (int k = 0; k < 6; ++k) W[k] += Nb[k] * s_w[a]; }
+        double z[15], Z[15], t = 0.0;
+        for (int k = 0; k < 15; ++k) { z[k] = 0.0; Z[k] = 0.0; }
+        for (int a = 0; a < NB; ++a) {
+            bspline6<P>(s_tu, s_tv, gu, gv, a, Nb); rationalize6(Nb, W, R);
+            t += Nb[0] * s_h[a];
+            for (int m = 0; m < 5; ++m) for (int i = 0; i < 3; ++i) { Z[3 * m + i] += R[m + 1] * s_c[a][i]; z[3 * m + i] += R[m + 1] * s_d[a][i]; }
+        }
+        shell_energy_point(z, Z, t, Pt.E, Pt.nu_, s_fe[tid]);
+        for (int k = 0; k < 6; ++k) s_fe[tid][FE_SIZE + k] = W[k];
+        s_fe[tid][FE_SIZE + 6] = s_wg[gu] * s_wg[P1 + gv]; s_fe[tid][FE_SIZE + 7] = t;
+    }
+    __syncthreads();
+    double* out = blk + (size_t)blockIdx.x * blk_stride;
+    for (int w = tid; w < ND; w += 64) {
+        const int a = w / 3, i = w - 3 * a;
+        double du = 0.0, dc = 0.0, dv = 0.0, dwh = 0.0, dvh = 0.0;
+        for (int gp = 0; gp < NG; ++gp) {
+            const double* fe = s_fe[gp]; const double wq = fe[FE_SIZE + 6];
+            double Nb[6], R[6];
+            bspline6<P>(s_tu, s_tv, gp % P1, gp / P1, a, Nb); rationalize6(Nb, fe + FE_SIZE, R);
+            double pz = 0.0, pZ = 0.0;
+            for (int m = 0; m < 5; ++m) { pz += R[m + 1] * fe[FE_PZ + 3 * m + i]; pZ += R[m + 1] * fe[FE_PZR + 3 * m + i]; }
+            du += wq * pz; dc += wq * pZ;
+            dv += wq * fe[FE_SIZE + 7] * (R[1] * fe[FE_JZ + i] + R[2] * fe[FE_JZ + 3 + i]);
+            dwh += wq * Nb[0] * fe[FE_PT]; dvh += wq * Nb[0] * fe[FE_J];
+        }
+        out[a * 11 + i] = du; out[a * 11 + 3 + i] = dc; out[a * 11 + 6 + i] = dv;
+        if (i == 0) { out[a * 11 + 9] = dwh; out[a * 11 + 10] = dvh; }
+    }
+    if (tid == 0) {
+        double We = 0.0, Ve = 0.0;
+        for (int gp = 0; gp < NG; ++gp) { const double wq = s_fe[gp][FE_SIZE + 6]; We += wq * s_fe[gp][FE_PSI]; Ve += wq * s_fe[gp][FE_SIZE + 7] * s_fe[gp][FE_J]; }
+        out[NB * 11] = We; out[NB * 11 + 1] = Ve;
+    }
+}
+
+// one thread per owned control point: ordered sum over its elements.  fun: [dWdu ndof | dWdcp 3*tcp | dWdh tcp | dVdcp 3*tcp | dVdh tcp]
+template <int P>
+__global__ __launch_bounds__(256) void kl_fgather_kernel(DevModel M, long long a_first, long long a_end, long long e_first, long long e_count, int apply_bcs,
+                                                          const double* __restrict__ blk, size_t blk_stride, double* __restrict__ fun, double* __restrict__ We, double* __restrict__ Ve) {
+    constexpr int P1 = P + 1;
+    const long long a = a_first + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long eidx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (eidx < e_count) { We[e_first + eidx] = blk[(size_t)eidx * blk_stride + P1 * P1 * 11]; Ve[e_first + eidx] = blk[(size_t)eidx * blk_stride + P1 * P1 * 11 + 1]; }
+    if (a >= a_end) return;
+    const PatchDev& Pt = M.patches[M.cp_patch[a]];
+    const int la = int(a - Pt.cp_off), ia = la % Pt.nu, ja = la / Pt.nu;
+    const int* spu = M.ints + Pt.spu; const int* spv = M.ints + Pt.spv; const int* c2u = M.ints + Pt.c2u; const int* c2v = M.ints + Pt.c2v;
+    double acc[11];
+    for (int k = 0; k < 11; ++k) acc[k] = 0.0;
+    for (int ev = c2v[2 * ja]; ev <= c2v[2 * ja + 1]; ++ev) for (int eu = c2u[2 * ia]; eu <= c2u[2 * ia + 1]; ++eu) {
+        const long long e = Pt.elem_off + eu + (long long)ev * Pt.nelu - e_first;
+        if (e < 0 || e >= e_count) continue;
+        const int al = (ia - (spu[eu] - P)) + (ja - (spv[ev] - P)) * P1;
+        const double* B = blk + (size_t)e * blk_stride + al * 11;
+        for (int k = 0; k < 11; ++k) acc[k] += B[k];
+    }
+    const long long T = M.total_cp;
+    for (int i = 0; i < 3; ++i) {
+        fun[3 * a + i] = (apply_bcs && M.zero[3 * a + i]) ? 0.0 : acc[i];
+        fun[3 * T + i * T + a] = acc[i] + acc[3 + i];
+        fun[7 * T + i * T + a] = acc[6 + i];
+    }
+    fun[6 * T + a] = acc[9]; fun[10 * T + a] = acc[10];
+}
+__global__ void pen_energy_kernel(long long npts, const double* __restrict__ pbuf, double* __restrict__ en) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < npts) en[v] = pbuf[(size_t)v * PB_STRIDE + PB_EN];
+}
+
 // ------------------------------------------------------------------------------------------ penalty
 struct DevPenalty {
     const int* pt_iface; const int* pt_base; const double* pt_nu; const double* pt_tau; const double* pt_wt;

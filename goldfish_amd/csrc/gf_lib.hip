@@ -28,7 +28,8 @@ struct gf_handle {
     DevModel M{}; DevPenalty Q{};
     double *d_cp4 = nullptr, *d_u = nullptr, *d_h = nullptr, *d_R = nullptr, *d_blk = nullptr, *d_pbuf = nullptr;
     double* d_val[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    double *d_x = nullptr, *d_y = nullptr;           // staging for host-pointer gf_apply
+    double *d_x = nullptr, *d_y = nullptr;           // staging for host-pointer gf_apply / per-element partial sums
+    double *d_fun = nullptr, *d_pen_en = nullptr;    // functional gradients [11*total_cp], penalty energies [npts]
     long long* d_pl_dof = nullptr; double* d_pl_val = nullptr;
     std::vector<Chunk> chunks;
     std::vector<hipEvent_t> ev0, ev1; int ev_n = 0;   // element-kernel timing
@@ -90,6 +91,8 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         HIPCHK(hipMemset(h->d_val[GF_MAT_DRDH], 0, 3 * nnzs * sizeof(double)));
         HIPCHK(hipMemset(h->d_R, 0, H.ndof * sizeof(double)));
         h->d_x = h->dalloc<double>(H.ndof); h->d_y = h->dalloc<double>(H.ndof);
+        h->d_fun = h->dalloc<double>(11 * H.total_cp); h->d_pen_en = h->dalloc<double>(H.npts);
+        HIPCHK(hipMemset(h->d_fun, 0, 11 * H.total_cp * sizeof(double)));
         // penalty
         DevPenalty& Q = h->Q;
         Q.npts = H.npts;
@@ -227,6 +230,22 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
     HIPCHK(hipGetLastError());
 }
 
+template <int P> static void run_functionals(gf_handle* h, int apply_bcs) {
+    const size_t stride = (size_t)FunCfg<P>::STRIDE;
+    for (const Chunk& c : h->chunks) {
+        const long long ne = c.e1 - c.e0, na = c.a1 - c.a0, nthr = std::max(ne, na);
+        hipLaunchKernelGGL(kl_functional_kernel<P>, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, h->d_blk, stride);
+        hipLaunchKernelGGL(kl_fgather_kernel<P>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, apply_bcs,
+                           h->d_blk, stride, h->d_fun, h->d_x, h->d_y);
+    }
+    const HostModel& H = h->H;
+    if (H.npts > 0) {
+        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf);
+        hipLaunchKernelGGL(pen_energy_kernel, dim3((unsigned)((H.npts + 255) / 256)), dim3(256), 0, h->stream, (long long)H.npts, h->d_pbuf, h->d_pen_en);
+    }
+    HIPCHK(hipGetLastError());
+}
+
 extern "C" {
 
 int gf_assemble(gf_handle* h, int flags) {
@@ -322,8 +341,34 @@ double gf_kernel_ms(gf_handle* h, int* n_launches) {
 }
 
 int gf_functionals(gf_handle* h, double out[3], double* dWdu, double* dWdcp, double* dWdh, double* dVdcp, double* dVdh, int apply_bcs) {
-    (void)h; (void)out; (void)dWdu; (void)dWdcp; (void)dWdh; (void)dVdcp; (void)dVdh; (void)apply_bcs;
-    return fail("gf_functionals: not implemented yet");
+    if (!h || !out) return fail("gf_functionals: null argument");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        switch (h->H.degree) {
+            case 2: run_functionals<2>(h, apply_bcs); break;
+            case 3: run_functionals<3>(h, apply_bcs); break;
+            case 4: run_functionals<4>(h, apply_bcs); break;
+            default: throw std::runtime_error("gf_functionals: unsupported degree");
+        }
+        const HostModel& H = h->H; const long long T = H.total_cp;
+        std::vector<double> we(H.nelem), ve(H.nelem), pe(H.npts);
+        HIPCHK(hipMemcpyAsync(we.data(), h->d_x, H.nelem * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(ve.data(), h->d_y, H.nelem * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (H.npts > 0) HIPCHK(hipMemcpyAsync(pe.data(), h->d_pen_en, H.npts * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (dWdu) HIPCHK(hipMemcpyAsync(dWdu, h->d_fun, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (dWdcp) HIPCHK(hipMemcpyAsync(dWdcp, h->d_fun + 3 * T, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (dWdh) HIPCHK(hipMemcpyAsync(dWdh, h->d_fun + 6 * T, T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (dVdcp) HIPCHK(hipMemcpyAsync(dVdcp, h->d_fun + 7 * T, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (dVdh) HIPCHK(hipMemcpyAsync(dVdh, h->d_fun + 10 * T, T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        // fixed-order host sums of the per-element / per-vertex partials (owned elements only)
+        const long long e_end = H.n_owned < H.np ? H.patches[H.n_owned].elem_off : H.nelem;
+        long double W = 0, V = 0, Wp = 0;
+        for (long long e = 0; e < e_end; ++e) { W += we[e]; V += ve[e]; }
+        for (long long v = 0; v < H.npts; ++v) Wp += pe[v];
+        out[0] = (double)W; out[1] = (double)V; out[2] = (double)Wp;
+    } catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
 }
 
 }  // extern "C"

@@ -230,6 +230,54 @@ GF_HD inline double pzZ_entry(const double* im, int r, int s) {
     return v;
 }
 
+// ---- energy functionals: first derivatives of Psi wrt z, Z, t and of the area Jacobian ----------
+// out: [0] Psi, [1] J, [2] dPsi/dt, [3..17] dPsi/dz, [18..32] dPsi/dZ, [33..38] dJ/d(G1,G2)
+enum : int { FE_PSI = 0, FE_J = 1, FE_PT = 2, FE_PZ = 3, FE_PZR = 18, FE_JZ = 33, FE_SIZE = 39 };
+GF_HD inline void shell_energy_point(const double* z, const double* Z, double t, double E, double nu, double* out) {
+    const double f3[3] = {1.0, 1.0, 2.0};
+    double n[3], N[3], j, Jn, Dn[3][6], DN[3][6];
+    normal_derivs(z, z + 3, n, j, Dn);
+    normal_derivs(Z, Z + 3, N, Jn, DN);
+    double C[6], dC[3][6], J;
+    material(Z, Z + 3, E, nu, C, dC, J);
+    double eps[3], kap[3];
+    eps[0] = 0.5 * (dot3(z, z) - dot3(Z, Z));
+    eps[1] = 0.5 * (dot3(z + 3, z + 3) - dot3(Z + 3, Z + 3));
+    eps[2] = dot3(z, z + 3) - dot3(Z, Z + 3);
+    for (int k = 0; k < 3; ++k) kap[k] = f3[k] * (dot3(Z + 6 + 3 * k, N) - dot3(z + 6 + 3 * k, n));
+    const double t3 = t * t * t / 12.0;
+    double Ce[3], Ck[3];
+    symmv(C, eps, Ce); symmv(C, kap, Ck);
+    const double psi = 0.5 * t * dot3(eps, Ce) + 0.5 * t3 * dot3(kap, Ck);
+    out[FE_PSI] = J * psi; out[FE_J] = J;
+    out[FE_PT] = J * (0.5 * dot3(eps, Ce) + 0.125 * t * t * dot3(kap, Ck));
+    double JZ[6];
+    cross3(Z + 3, N, JZ); cross3(N, Z, JZ + 3);
+    double qe[3], qk[3];                         // 0.5 eps.dC_q eps, 0.5 kap.dC_q kap
+    for (int q = 0; q < 3; ++q) { double a[3], b[3]; symmv(dC[q], eps, a); symmv(dC[q], kap, b); qe[q] = 0.5 * dot3(eps, a); qk[q] = 0.5 * dot3(kap, b); }
+    for (int c = 0; c < 6; ++c) {
+        const int ic = c % 3;
+        // deformed: d eps/dz, d beta/dz
+        const double e0 = c < 3 ? z[ic] : 0.0, e1 = c < 3 ? 0.0 : z[3 + ic], e2 = c < 3 ? z[3 + ic] : z[ic];
+        double bg[3], bG[3];
+        for (int k = 0; k < 3; ++k) {
+            bg[k] = f3[k] * (z[6 + 3 * k] * Dn[0][c] + z[7 + 3 * k] * Dn[1][c] + z[8 + 3 * k] * Dn[2][c]);
+            bG[k] = f3[k] * (Z[6 + 3 * k] * DN[0][c] + Z[7 + 3 * k] * DN[1][c] + Z[8 + 3 * k] * DN[2][c]);
+        }
+        out[FE_PZ + c] = J * (t * (Ce[0] * e0 + Ce[1] * e1 + Ce[2] * e2) - t3 * dot3(Ck, bg));
+        // reference: d eps/dZ = -(...), d kappa/dZ = +bG, metric chain for C and J
+        const double E0 = c < 3 ? Z[ic] : 0.0, E1 = c < 3 ? 0.0 : Z[3 + ic], E2 = c < 3 ? Z[3 + ic] : Z[ic];
+        const double a0 = c < 3 ? 2 * Z[ic] : 0.0, a1 = c < 3 ? 0.0 : 2 * Z[3 + ic], a2 = c < 3 ? Z[3 + ic] : Z[ic];
+        out[FE_PZR + c] = psi * JZ[c] + J * (-t * (Ce[0] * E0 + Ce[1] * E1 + Ce[2] * E2) + t3 * dot3(Ck, bG)
+                                             + t * (qe[0] * a0 + qe[1] * a1 + qe[2] * a2) + t3 * (qk[0] * a0 + qk[1] * a1 + qk[2] * a2));
+        out[FE_JZ + c] = JZ[c];
+    }
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) {
+        out[FE_PZ + 6 + 3 * k + i] = -J * t3 * Ck[k] * f3[k] * n[i];
+        out[FE_PZR + 6 + 3 * k + i] = J * t3 * Ck[k] * f3[k] * N[i];
+    }
+}
+
 // ---------------------------------------------------------------------------- penalty
 // unit tangent at = unit(tau0 g1 + tau1 g2), Dt[i][c]
 GF_HD inline void tangent_derivs(const double* g1, const double* g2, const double* tau, double* at, double& L, double Dt[3][6]) {

@@ -10,5 +10,6 @@ void gfh_shell_point(const double* z, const double* Z, double t, double E, doubl
 void gfh_penalty_point(const double* y, const double* Y, const double* tau, double ad, double ar, double dt, double* out) {
     gf::penalty_point(y, Y, tau, ad, ar, dt, out);
 }
+void gfh_shell_energy_point(const double* z, const double* Z, double t, double E, double nu, double* out) { gf::shell_energy_point(z, Z, t, E, nu, out); }
 int gfh_sizes(int which) { return which == 0 ? gf::IM_SIZE : which == 1 ? gf::PB_STRIDE : gf::PB_SIZE; }
 }

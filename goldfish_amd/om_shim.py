@@ -85,8 +85,11 @@ class Problem:
         else:
             m.compute(self.inputs, self.outputs)
 
-    def check_partials(self, step=1e-6, seed=0, compact_print=True):
-        """Relative error of analytic vs FD directional derivatives, per (of, wrt)."""
+    def check_partials(self, step=1e-6, seed=0, compact_print=True, free_mask=None):
+        """Relative error of analytic vs FD directional derivatives, per (of, wrt).
+        ``free_mask`` (implicit components): boolean mask of non-Dirichlet state dofs; the
+        reference's Dirichlet conventions (unit diagonal in K, untreated rows in dR/dh,
+        GOLDFISH/nonmatching_opt.py:660-724, 1006-1015) differ from d(residual) on those rows."""
         m, rng = self.model, np.random.default_rng(seed)
         res = {}
         if isinstance(m, ImplicitComponent):
@@ -96,6 +99,8 @@ class Problem:
                 tgt = self.inputs if wrt in self.inputs else self.outputs
                 base = tgt[wrt].copy()
                 v = rng.standard_normal(base.shape)
+                if free_mask is not None and wrt == of:
+                    v = v * free_mask
                 d_in = _Vec({k: np.zeros_like(x) for k, x in self.inputs.items()})
                 d_out = _Vec({k: np.zeros_like(x) for k, x in self.outputs.items()})
                 d_res = _Vec({k: np.zeros_like(x) for k, x in self.outputs.items()})
@@ -109,6 +114,8 @@ class Problem:
                     r.append(self.residuals[of].copy())
                 tgt[wrt] = base
                 fd = (r[0] - r[1]) / (2 * step)
+                if free_mask is not None:
+                    fd, an = fd[free_mask], an[free_mask]
                 res[(of, wrt)] = np.abs(fd - an).max() / max(np.abs(fd).max(), 1e-300)
         else:
             partials = {}

@@ -1,0 +1,69 @@
+"""world_size-2 gloo test of the N > 1 path on CPU: patch sharding, ghost patches and the
+all-reduce exchange of owned rows.  No GPU here, so the CPU oracle stands in for the device
+compute of each rank *in this test only*; the exchange code is the product's."""
+import os
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from goldfish_amd import geometry as G, sharding
+    from oracle.oracle_py import Oracle
+    spec = G.synthetic_shell(3, 2, nel=4, p=3, jitter=1)
+    th = G.random_thickness(spec)
+    u = G.smooth_displacement(spec, 0.5 * spec.h_th)
+    sh = sharding.shard_spec(spec, rank, world)
+    A = sharding.shard_arrays(sh, th)
+    O = Oracle(A, thickness=sh.to_local(np.concatenate(th)), u=sh.to_local(u, 3))
+    Rg = sharding.allreduce_owned_rows(sh, torch.from_numpy(O.residual()), dist, 3).numpy()
+    # reverse-mode product with remote columns: y = sum_ranks (dR/dCP_0 owned rows)^T lambda_owned
+    lam = np.sin(np.arange(3 * sh.total_cp_global) * 0.37)
+    C0 = O.csr(1, O.assemble(K=False, dRdCP=(0,), dRdh=False)[1])
+    g0, g1 = sh.owned_global_range(3)
+    yl = C0[:g1 - g0].T @ lam[g0:g1]
+    yg = torch.zeros(sh.total_cp_global, dtype=torch.float64)
+    yg.index_add_(0, torch.from_numpy(sh.local_cols_to_global()), torch.from_numpy(yl))
+    dist.all_reduce(yg)
+    if rank == 0:
+        q.put((Rg, yg.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_residual_and_adjoint_product(oracle_lib):
+    from goldfish_amd import geometry as G
+    from goldfish_amd.model import arrays_from_spec
+    from oracle.oracle_py import Oracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    Rg, yg = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    spec = G.synthetic_shell(3, 2, nel=4, p=3, jitter=1)
+    th = G.random_thickness(spec)
+    A = arrays_from_spec(spec, th)
+    O = Oracle(A, thickness=np.concatenate(th), u=G.smooth_displacement(spec, 0.5 * spec.h_th))
+    R = O.residual()
+    assert np.abs(Rg - R).max() < 1e-12 * np.abs(R).max()
+    lam = np.sin(np.arange(A.ndof) * 0.37)
+    y = O.csr(1, O.assemble(K=False, dRdCP=(0,), dRdh=False)[1]).T @ lam
+    assert np.abs(yg - y).max() < 1e-12 * np.abs(y).max()

@@ -1,0 +1,195 @@
+"""GPU tests of the drop-in surface: NonMatchingOpt, the operations and the OpenMDAO
+components (reference: GOLDFISH/nonmatching_opt.py, operations/, om_comps/), through the C ABI."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from goldfish_amd import geometry as G
+from goldfish_amd.model import arrays_from_spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _problem(var_thickness=True, seed=0):
+    from goldfish_amd.nonmatching_opt import NonMatchingOptFFD
+    spec = G.tbeam_2patch(4)
+    rng = np.random.default_rng(seed)
+    th = [spec.h_th * rng.uniform(0.8, 1.2, p.ncp) for p in spec.patches] if var_thickness else None
+    nm = NonMatchingOptFFD.from_spec(spec, thickness=th)
+    nm.set_shopt_surf_inds_FFD([0, 1, 2], [[0, 1]] * 3)
+    nm.set_thickness_opt(var_thickness=var_thickness)
+    return spec, th, nm
+
+
+def test_functionals_parity(oracle_lib):
+    from goldfish_amd import _lib
+    from oracle.oracle_py import Oracle
+    spec = G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2])
+    rng = np.random.default_rng(1)
+    th = [spec.h_th * rng.uniform(0.8, 1.2, p.ncp) for p in spec.patches]
+    A = arrays_from_spec(spec, th)
+    h, u = np.concatenate(th), 2e-2 * rng.standard_normal(A.ndof)
+    O = Oracle(A, thickness=h, u=u)
+    D = _lib.DeviceModel(A)
+    D.set_thickness(h)
+    D.set_u(u)
+    for bcs in (True, False):
+        F, Fo = D.functionals(apply_bcs=bcs), O.functionals(apply_bcs=bcs)
+        for k in ("Wint", "volume", "Wpen"):
+            assert abs(F[k] - Fo[k]) < 1e-11 * abs(Fo[k]), k
+        assert _rel(F["dWdu"], Fo["dWdu"]) < 1e-10
+        assert _rel(F["dWdh"], Fo["dWdh"]) < 1e-10 and _rel(F["dVdh"], Fo["dVdh"]) < 1e-10
+        for f in range(3):
+            assert _rel(F["dWdcp"][f], Fo["dWdcp"][f]) < 1e-10 and _rel(F["dVdcp"][f], Fo["dVdcp"][f]) < 1e-10
+    D.close()
+
+
+def test_nonmatching_opt_surface(oracle_lib):
+    from oracle.oracle_py import Oracle
+    spec, th, nm = _problem()
+    A = arrays_from_spec(spec, th)
+    rng = np.random.default_rng(2)
+    u = 1e-2 * rng.standard_normal(A.ndof)
+    nm.update_uIGA(u)
+    O = Oracle(A, thickness=np.concatenate(th), u=u)
+    assert nm.vec_iga_dof == A.ndof and nm.vec_scalar_iga_dof == A.total_cp
+    assert _rel(nm.RIGA(), O.residual()) < 1e-10
+    vals = O.assemble()
+    assert abs(nm.dRIGAduIGA() - O.csr(0, vals[0])).max() < 1e-10 * abs(vals[0]).max()
+    assert abs(nm.dRIGAdCPIGA(1) - O.csr(2, vals[2])).max() < 1e-10 * abs(vals[2]).max()
+    assert abs(nm.dRIGAdh_th() - O.csr(4, vals[4])).max() < 1e-10 * abs(vals[4]).max()
+    with pytest.raises(ValueError):
+        nm.update_uIGA(np.zeros(7))
+    # reference-style FD check of the shape Jacobian on a few columns (nonmatching_opt.py:975-990)
+    cp = nm.get_init_CPIGA()[2].copy()
+    J = nm.dRIGAdCPIGA(2).toarray()
+    dc = rng.standard_normal(cp.size)
+    nm.update_CPIGA(cp + 1e-6 * dc, 2)
+    Rp = nm.RIGA()
+    nm.update_CPIGA(cp - 1e-6 * dc, 2)
+    Rm = nm.RIGA()
+    nm.update_CPIGA(cp, 2)
+    assert _rel((Rp - Rm) / 2e-6, J @ dc) < 1e-6
+
+
+def test_scordelis_lo_on_gpu():
+    from goldfish_amd.nonmatching_opt import NonMatchingOpt
+    from goldfish_amd.splines import basis_ders, find_span
+    spec = G.scordelis_lo_9patch(6)
+    nm = NonMatchingOpt.from_spec(spec)
+    u = nm.solve_linear_nonmatching_problem()
+    P = spec.patches[3]                      # free edge u=0, mid length v=0.5
+    su, sv = find_span(P.n_u, P.p, P.knots[0], 0.0), find_span(P.n_v, P.q, P.knots[1], 0.5)
+    Nu, Nv = basis_ders(su, 0.0, P.p, P.knots[0], 0)[0], basis_ders(sv, 0.5, P.q, P.knots[1], 0)[0]
+    off, num, W = int(nm.cp_off[3]), 0.0, 0.0
+    for jv in range(4):
+        for ju in range(4):
+            a = P.flat(su - 3 + ju, sv - 3 + jv)
+            num += Nu[ju] * Nv[jv] * u[3 * (off + a) + 1]
+            W += Nu[ju] * Nv[jv] * P.cp_hom_flat()[a, 3]
+    assert abs(abs(num / W) - 0.3006) / 0.3006 < 5e-3
+
+
+def test_newton_solve_converges():
+    from goldfish_amd.nonmatching_opt import NonMatchingOpt
+    spec = G.tbeam_2patch(6)
+    nm = NonMatchingOpt.from_spec(spec)
+    _, u = nm.solve_nonlinear_nonmatching_problem(rtol=1e-9, max_it=30)
+    assert np.linalg.norm(nm.RIGA()) < 1e-6 * 10.0 and np.abs(u).max() > 1e-3
+
+
+@pytest.mark.parametrize("var_thickness", [True, False])
+def test_disp_states_comp_partials(var_thickness):
+    from goldfish_amd.om_comps import DispStatesComp, om
+    spec, th, nm = _problem(var_thickness)
+    comp = DispStatesComp(nonmatching_opt=nm)
+    comp.init_parameters(nonlinear_solver_rtol=1e-10)
+    prob = om.Problem(model=comp)
+    prob.setup()
+    prob.run_model()
+    assert np.abs(prob["displacements"]).max() > 1e-4
+    free = np.ones(nm.vec_iga_dof, bool)
+    free[nm.zero_dofs] = False
+    errs = prob.check_partials(compact_print=False, free_mask=free)
+    assert max(errs.values()) < 1e-5, errs
+    # reverse mode == transpose of forward mode; solve_linear inverts K
+    rng = np.random.default_rng(3)
+    n = nm.vec_iga_dof
+    op = comp.disp_state_imop
+    du, lam = rng.standard_normal(n), rng.standard_normal(n)
+    fwd = op.apply_linear_fwd(None, du, np.zeros(n))
+    _, rev = op.apply_linear_rev(None, np.zeros(n), lam)
+    assert abs(lam @ fwd - du @ rev) < 1e-9 * abs(lam @ fwd)
+    x = op.solve_linear_fwd(np.zeros(n), fwd.copy())
+    assert _rel(x[free], du[free]) < 1e-8
+    lt = op.solve_linear_rev(rev.copy(), np.zeros(n))
+    assert _rel(lt[free], lam[free]) < 1e-8
+
+
+@pytest.mark.parametrize("var_thickness", [True, False])
+def test_energy_and_volume_comp_partials(var_thickness):
+    from goldfish_amd.om_comps import IntEnergyComp, VolumeComp, om
+    spec, th, nm = _problem(var_thickness)
+    nm.solve_linear_nonmatching_problem()
+    for Comp in (IntEnergyComp, VolumeComp):
+        comp = Comp(nonmatching_opt=nm)
+        comp.init_parameters()
+        prob = om.Problem(model=comp)
+        prob.setup()
+        prob.run_model()
+        errs = prob.check_partials(compact_print=False, step=1e-6)
+        assert max(errs.values()) < 1e-6, (Comp.__name__, errs)
+
+
+def _rank_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from goldfish_amd import _lib, sharding
+    spec = G.synthetic_shell(3, 2, nel=4, p=3, jitter=1)
+    th, u = G.random_thickness(spec), G.smooth_displacement(spec, 0.5 * spec.h_th)
+    sh = sharding.shard_spec(spec, rank, world)
+    D = _lib.DeviceModel(sharding.shard_arrays(sh, th), device=0)
+    D.set_thickness(sh.to_local(np.concatenate(th)))
+    D.set_u(sh.to_local(u, 3))
+    D.assemble()
+    Rg = sharding.allreduce_owned_rows(sh, torch.from_numpy(D.residual()), dist, 3).numpy()
+    g0, g1 = sh.owned_global_range(3)
+    rows = D.csr(_lib.MAT_K)[:g1 - g0]
+    cols = sh.local_cols_to_global()
+    ck = np.abs(rows).sum()
+    if rank == 0:
+        q.put((Rg, float(ck)))
+    dist.barrier()
+    D.close()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_assembly_on_gpu(oracle_lib):
+    """Two processes (gloo; both on the single GPU of the box) own half of the patches each."""
+    import torch.multiprocessing as mp
+    from oracle.oracle_py import Oracle
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    Rg, _ = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    spec = G.synthetic_shell(3, 2, nel=4, p=3, jitter=1)
+    th = G.random_thickness(spec)
+    O = Oracle(arrays_from_spec(spec, th), thickness=np.concatenate(th), u=G.smooth_displacement(spec, 0.5 * spec.h_th))
+    assert _rel(Rg, O.residual()) < 1e-10
