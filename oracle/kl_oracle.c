@@ -648,6 +648,13 @@ void gfo_functionals(const gfo_model* M, double out[3], double* dWdu, double* dW
     free(Rtmp);
 }
 
+void gfo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 int gfo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -49,6 +49,7 @@ def lib():
         L.gfo_penalty_point.argtypes = [dp, dp, dp, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp]
         L.gfo_eval_point.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, dp, dp]
         L.gfo_num_threads.restype = C.c_int
+        L.gfo_set_num_threads.argtypes = [C.c_int]
         _LIB = L
     return _LIB
 

@@ -1,0 +1,57 @@
+"""Generates tests/golden/*.npz with the CPU oracle (oracle/kl_oracle.c).
+
+PARITY UNPINNED: the reference (FEniCS/PENGoLINS stack) cannot run here and holds no golden
+vectors for this path, so these goldens are the oracle's own outputs on the
+reference's fixture *inputs*; they anchor regressions of both the oracle and the HIP path.
+`ref_plate_int_data.npz` is a verbatim data fixture of the reference
+(demos_csdl_alpha/thickness_opt/plate_int_data.npz: mapping_list = name2, parametric
+coordinates = name4, mortar_nels = name6); it is data, not code.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from goldfish_amd import geometry as G                     # noqa: E402
+from goldfish_amd.model import Interface, arrays_from_spec  # noqa: E402
+from oracle.oracle_py import Oracle                        # noqa: E402
+
+
+def plate_from_reference_data():
+    """C1 plate with the interface vertices of the reference's plate_int_data.npz."""
+    d = np.load(os.path.join(HERE, "ref_plate_int_data.npz"), allow_pickle=True)
+    spec = G.plate_6patch()
+    spec.interfaces = [Interface(int(a), int(b), np.asarray(d["name4"][i][0], float), np.asarray(d["name4"][i][1], float))
+                       for i, (a, b) in enumerate(d["name2"])]
+    assert [i.npts - 1 for i in spec.interfaces] == list(d["name6"])
+    return spec
+
+
+CASES = {"tbeam2": lambda: G.tbeam_2patch(4), "plate6_refdata": plate_from_reference_data}
+
+
+def state(spec, seed=11):
+    rng = np.random.default_rng(seed)
+    th = [spec.h_th * rng.uniform(0.8, 1.2, p.ncp) for p in spec.patches]
+    A = arrays_from_spec(spec, th)
+    return A, np.concatenate(th), 0.2 * spec.h_th * rng.standard_normal(A.ndof)
+
+
+def main():
+    for name, make in CASES.items():
+        A, h, u = state(make())
+        O = Oracle(A, thickness=h, u=u)
+        vals = O.assemble()
+        F = O.functionals()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), R=O.residual(), K=vals[0], C0=vals[1], C1=vals[2], C2=vals[3], H=vals[4],
+                            Wint=F["Wint"], volume=F["volume"], Wpen=F["Wpen"], dWdu=F["dWdu"], dWdh=F["dWdh"])
+        print(name, A.ndof, "dofs")
+
+
+if __name__ == "__main__":
+    main()
