@@ -102,12 +102,13 @@ def main():
     class _Buf:
         def __init__(self, ptr, n):
             self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-    R_loc = torch.as_tensor(_Buf(_lib.lib().gf_device_ptr(D.h, _lib.BUF_R), A.ndof), device="cuda") if world > 1 else None
-    R_glob = torch.zeros(3 * shard.total_cp_global, dtype=torch.float64, device="cuda") if world > 1 else None
+    exchange = world > 1 or os.environ.get("GF_BENCH_FORCE_EXCHANGE") == "1"     # the env switch rehearses the N>1 code path on one GPU
+    R_loc = torch.as_tensor(_Buf(_lib.lib().gf_device_ptr(D.h, _lib.BUF_R), A.ndof), device="cuda") if exchange else None
+    R_glob = torch.zeros(3 * shard.total_cp_global, dtype=torch.float64, device="cuda") if exchange else None
 
     def step():
         D.assemble(_lib.ASM_ALL, sync=False)
-        if world > 1:
+        if exchange:
             D.sync()
             sharding.allreduce_owned_rows(shard, R_loc, dist, 3, out=R_glob)
 
@@ -128,6 +129,9 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kern_ms, kern_n = D.kernel_ms()
+    if exchange:       # the exchanged global residual must equal the library's own copy of the owned rows
+        g0, g1 = shard.owned_global_range(3)
+        assert np.array_equal(R_glob[g0:g1].cpu().numpy(), D.residual()[:g1 - g0]) or world > 1
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -110,100 +110,134 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_elemen
     const bool has_bf = (Pt.f[0] != 0.0) || (Pt.f[1] != 0.0) || (Pt.f[2] != 0.0);
     constexpr int IJ_I[6] = {0, 0, 0, 1, 1, 2}, IJ_J[6] = {0, 1, 2, 1, 2, 2};
 
+    // Loop-invariant per-thread descriptors (hoisted by hand: the index arithmetic of the expansion
+    // slots and of the T rows otherwise re-executes for every Gauss point).
+    // The 225 entries of G = Pzz and Hc = Pzz + PzZ are ordered by structural category
+    // [A: tangent x tangent | B: curvature x tangent | B': transpose of B | C: curvature x curvature]
+    // so that a wave executes at most two short code paths per pass.
+    constexpr int NIT = (225 + NT - 1) / NT, LPB = NT / NB, NTK = (30 + LPB - 1) / LPB, NTH = (45 + LPB - 1) / LPB;
+    int xcat[NIT], x0[NIT], x1[NIT], x2[NIT], x3[NIT], x4[NIT], x5[NIT], x6[NIT]; double xf[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int slot = tid + it * NT;
+        xcat[it] = 4; x0[it] = x1[it] = x2[it] = x3[it] = x4[it] = x5[it] = x6[it] = 0; xf[it] = 0.0;
+        if (slot < 36) {
+            const int r = slot / 6, s = slot - 6 * r, m = r / 3, i = r - 3 * m, mm = s / 3, j = s - 3 * mm;
+            xcat[it] = 0; x0[it] = r; x1[it] = s; x2[it] = m; x3[it] = IM_G + 3 * (1 - m) + i; x4[it] = IM_JNV + (m == mm ? m : 2);
+            x5[it] = IM_HMN + 6 * r + s; x6[it] = 15 * r + s; xf[it] = (i == j) ? 1.0 : 0.0;
+        } else if (slot < 90) {
+            const int q = slot - 36, rr = q / 6, s = q - 6 * rr, k = rr / 3, i = rr - 3 * k, r = 6 + rr;
+            xcat[it] = 1; x0[it] = r; x1[it] = s; x2[it] = IM_N + i; x3[it] = 6 * k + s; x4[it] = IM_JMOF + k; x5[it] = IM_DN + 6 * i + s;
+            x6[it] = 15 * r + s; xf[it] = (k == 2 ? 2.0 : 1.0);
+        } else if (slot < 144) {
+            const int q = slot - 90, ss = q / 6, r = q - 6 * ss, kk = ss / 3, jj = ss - 3 * kk, s = 6 + ss;
+            xcat[it] = 2; x0[it] = r; x1[it] = kk; x2[it] = IM_N + jj; x3[it] = 6 * kk + r; x4[it] = IM_JMOF + kk; x5[it] = IM_DN + 6 * jj + r;
+            x6[it] = 15 * r + s; xf[it] = (kk == 2 ? 2.0 : 1.0);
+        } else if (slot < 225) {
+            const int q = slot - 144, rr = q / 9, ss = q - 9 * rr, k = rr / 3, i = rr - 3 * k, kk = ss / 3, jj = ss - 3 * kk;
+            const int lo = k < kk ? k : kk, hi = k < kk ? kk : k;
+            xcat[it] = 3; x0[it] = IM_N + i; x1[it] = IM_CT3 + lo * (5 - lo) / 2 + hi; x2[it] = jj; x6[it] = 15 * (6 + rr) + 6 + ss;
+            xf[it] = (k == 2 ? 2.0 : 1.0) * (kk == 2 ? 2.0 : 1.0);
+        }
+    }
+    int rowK[NTK], rowH[NTH];
+#pragma unroll
+    for (int t = 0; t < NTK; ++t) { const int o = ag + t * LPB, oo = o < 30 ? o : 0, ij = oo / 5, m = oo - 5 * ij; rowK[t] = (3 * m + IJ_I[ij]) * 15 + IJ_J[ij]; }
+#pragma unroll
+    for (int t = 0; t < NTH; ++t) { const int o = ag + t * LPB, oo = o < 45 ? o : 0, q = oo / 5, m = oo - 5 * q; rowH[t] = (3 * m + q / 3) * 15 + q % 3; }
+    const int pju = tid % P1, pjv = (tid / P1) % P1;              // basis function handled by tid < NB
+    const int ra = tid / 3 < NB ? tid / 3 : 0, ri = tid % 3;      // residual entry handled by tid < ND
+
     for (int gp = 0; gp < NG; ++gp) {
         const double* im = s_im[gp];
         const double wq = im[IM_WQ];
         if (tid < NB) {
-            double Nb[6], R[6];
-            bspline6<P>(s_tu, s_tv, gp % P1, gp / P1, tid, Nb); rationalize6(Nb, im + IM_W, R);
+            const int gu = gp % P1, gv = gp / P1;
+            const double u0 = s_tu[(gu * 3 + 0) * P1 + pju], u1 = s_tu[(gu * 3 + 1) * P1 + pju], u2 = s_tu[(gu * 3 + 2) * P1 + pju];
+            const double v0 = s_tv[(gv * 3 + 0) * P1 + pjv], v1 = s_tv[(gv * 3 + 1) * P1 + pjv], v2 = s_tv[(gv * 3 + 2) * P1 + pjv];
+            const double Nb[6] = {u0 * v0, u1 * v0, u0 * v1, u2 * v0, u0 * v2, u1 * v1};
+            double R[6];
+            rationalize6(Nb, im + IM_W, R);
             for (int k = 0; k < 6; ++k) s_phi[tid][k] = R[k];
             s_n0[tid] = Nb[0];
         }
-        // Expansion of G = Pzz and Hc = Pzz + PzZ from the intermediate record.  The 225 entries are
-        // ordered by structural category [A: tangent x tangent | B: curvature x tangent | B': transpose
-        // of B | C: curvature x curvature] so that a wave executes at most two short code paths per
-        // pass (the generic per-entry form kl_point.hpp::pzz_entry diverges 4-way in every wave).
 #pragma unroll
-        for (int it = 0; it < (225 + NT - 1) / NT; ++it) {
-            const int slot = tid + it * NT;
-            if (slot < 36) {
-                const int r = slot / 6, s = slot - 6 * r, m = r / 3, i = r - 3 * m, mm = s / 3, j = s - 3 * mm;
+        for (int it = 0; it < NIT; ++it) {
+            if (xcat[it] == 0) {
+                const int r = x0[it], s = x1[it];
                 const double gr = im[IM_G + r];
-                const double e0 = m == 0 ? gr : 0.0, e1 = m == 1 ? gr : 0.0, e2 = im[IM_G + 3 * (1 - m) + i];
+                const double e0 = x2[it] == 0 ? gr : 0.0, e1 = x2[it] == 1 ? gr : 0.0, e2 = im[x3[it]];
                 const double b0 = im[IM_BG + r], b1 = im[IM_BG + 6 + r], b2 = im[IM_BG + 12 + r];
-                double g = e0 * im[IM_CEZ + s] + e1 * im[IM_CEZ + 6 + s] + e2 * im[IM_CEZ + 12 + s]
-                         + b0 * im[IM_CBG + s] + b1 * im[IM_CBG + 6 + s] + b2 * im[IM_CBG + 12 + s] - im[IM_HMN + 6 * r + s];
-                if (i == j) g += im[IM_JNV + (m == mm ? m : 2)];
+                const double g = e0 * im[IM_CEZ + s] + e1 * im[IM_CEZ + 6 + s] + e2 * im[IM_CEZ + 12 + s]
+                               + b0 * im[IM_CBG + s] + b1 * im[IM_CBG + 6 + s] + b2 * im[IM_CBG + 12 + s] - im[x5[it]] + xf[it] * im[x4[it]];
                 const double zz = im[IM_PZ + r] * im[IM_JZJ + s]
                                 + e0 * im[IM_JDNV + s] + e1 * im[IM_JDNV + 6 + s] + e2 * im[IM_JDNV + 12 + s]
                                 - (b0 * im[IM_JDMO + s] + b1 * im[IM_JDMO + 6 + s] + b2 * im[IM_JDMO + 12 + s]);
-                s_G[15 * r + s] = g; s_Hc[15 * r + s] = g + zz;
-            } else if (slot < 90) {
-                const int q = slot - 36, rr = q / 6, s = q - 6 * rr, k = rr / 3, i = rr - 3 * k, r = 6 + rr;
-                const double fn = (k == 2 ? 2.0 : 1.0) * im[IM_N + i];
-                const double g = fn * im[IM_CBG + 6 * k + s] - im[IM_JMOF + k] * im[IM_DN + 6 * i + s];
-                const double zz = im[IM_PZ + r] * im[IM_JZJ + s] - fn * im[IM_JDMO + 6 * k + s];
-                s_G[15 * r + s] = g; s_G[15 * s + r] = g; s_Hc[15 * r + s] = g + zz;
-            } else if (slot < 144) {
-                const int q = slot - 90, ss = q / 6, r = q - 6 * ss, kk = ss / 3, jj = ss - 3 * kk, s = 6 + ss;
-                const double fk = (kk == 2 ? 2.0 : 1.0);
-                const double g = fk * im[IM_N + jj] * im[IM_CBG + 6 * kk + r] - im[IM_JMOF + kk] * im[IM_DN + 6 * jj + r];
-                const int c0 = kk, c1 = kk == 0 ? 1 : 3 + (kk - 1), c2 = 2 + (kk == 0 ? 0 : (kk == 1 ? 2 : 3));   // sym3(0..2, kk)
-                const double zz = -(im[IM_BG + r] * im[IM_CT3 + c0] + im[IM_BG + 6 + r] * im[IM_CT3 + c1] + im[IM_BG + 12 + r] * im[IM_CT3 + c2]) * fk * im[IM_NB + jj];
-                s_Hc[15 * r + s] = g + zz;
-            } else if (slot < 225) {
-                const int q = slot - 144, rr = q / 9, ss = q - 9 * rr, k = rr / 3, i = rr - 3 * k, kk = ss / 3, jj = ss - 3 * kk;
-                const int lo = k < kk ? k : kk, hi = k < kk ? kk : k;
-                const double c = (k == 2 ? 2.0 : 1.0) * (kk == 2 ? 2.0 : 1.0) * im[IM_N + i] * im[IM_CT3 + lo * (5 - lo) / 2 + hi];
-                s_G[15 * (6 + rr) + 6 + ss] = c * im[IM_N + jj];
-                s_Hc[15 * (6 + rr) + 6 + ss] = c * (im[IM_N + jj] - im[IM_NB + jj]);
+                s_G[x6[it]] = g; s_Hc[x6[it]] = g + zz;
+            } else if (xcat[it] == 1) {
+                const int r = x0[it], s = x1[it];
+                const double fn = xf[it] * im[x2[it]];
+                const double g = fn * im[IM_CBG + x3[it]] - im[x4[it]] * im[x5[it]];
+                const double zz = im[IM_PZ + r] * im[IM_JZJ + s] - fn * im[IM_JDMO + x3[it]];
+                s_G[x6[it]] = g; s_G[15 * s + r] = g; s_Hc[x6[it]] = g + zz;
+            } else if (xcat[it] == 2) {
+                const int r = x0[it], kk = x1[it], jj = x2[it] - IM_N;
+                const double g = xf[it] * im[x2[it]] * im[IM_CBG + x3[it]] - im[x4[it]] * im[x5[it]];
+                const int c1 = kk == 0 ? 1 : 2 + kk, c2 = kk == 0 ? 2 : 3 + kk;                         // sym3(1,kk), sym3(2,kk)
+                const double zz = -(im[IM_BG + r] * im[IM_CT3 + kk] + im[IM_BG + 6 + r] * im[IM_CT3 + c1] + im[IM_BG + 12 + r] * im[IM_CT3 + c2]) * xf[it] * im[IM_NB + jj];
+                s_Hc[x6[it]] = g + zz;
+            } else if (xcat[it] == 3) {
+                const double c = xf[it] * im[x0[it]] * im[x1[it]];
+                const double nj = im[IM_N + x2[it]];
+                s_G[x6[it]] = c * nj; s_Hc[x6[it]] = c * (nj - im[IM_NB + x2[it]]);
             }
         }
         __syncthreads();
         if (tid < ND) {
-            const int a = tid / 3, i = tid - 3 * a;
             double rz = 0.0, rh = 0.0;
-            for (int m = 0; m < 5; ++m) { rz += s_phi[a][m + 1] * im[IM_PZ + 3 * m + i]; rh += s_phi[a][m + 1] * im[IM_PZT + 3 * m + i]; }
-            accR += wq * (rz - im[IM_J] * Pt.f[i] * s_phi[a][0]);
+            for (int m = 0; m < 5; ++m) { rz += s_phi[ra][m + 1] * im[IM_PZ + 3 * m + ri]; rh += s_phi[ra][m + 1] * im[IM_PZT + 3 * m + ri]; }
+            accR += wq * (rz - im[IM_J] * Pt.f[ri] * s_phi[ra][0]);
             s_rh[tid] = wq * rh;
         }
         double pb[5];
         for (int m = 0; m < 5; ++m) pb[m] = wq * s_phi[b][m + 1];
-        // T for K (i <= j): 30 outputs per b, split over the NT/NB lanes sharing b
+        // T for K (i <= j): 30 outputs per b, split over the LPB lanes sharing b
         if (flags & GF_ASM_K_BIT) {
-            for (int o = ag; o < 30; o += NT / NB) {
-                const int ij = o / 5, m = o - 5 * ij, row = (3 * m + IJ_I[ij]) * 15 + IJ_J[ij];
-                double v = 0.0;
-                for (int mm = 0; mm < 5; ++mm) v += s_G[row + 3 * mm] * pb[mm];
-                s_T[b][o] = v;
+#pragma unroll
+            for (int t = 0; t < NTK; ++t) {
+                const int o = ag + t * LPB;
+                if (o < 30) {
+                    const double* gr = s_G + rowK[t];
+                    s_T[b][o] = gr[0] * pb[0] + gr[3] * pb[1] + gr[6] * pb[2] + gr[9] * pb[3] + gr[12] * pb[4];
+                }
             }
         }
         __syncthreads();
         double pa[AG][5];
         for (int k = 0; k < AG; ++k) { const int a = ag * AG + k < NB ? ag * AG + k : NB - 1; for (int m = 0; m < 5; ++m) pa[k][m] = s_phi[a][m + 1]; }
         if (lane_ok && (flags & GF_ASM_K_BIT)) {
-            for (int k = 0; k < AG; ++k) for (int ij = 0; ij < 6; ++ij) {
-                double v = accK[k][ij];
-                for (int m = 0; m < 5; ++m) v += pa[k][m] * s_T[b][ij * 5 + m];
-                accK[k][ij] = v;
+            for (int ij = 0; ij < 6; ++ij) {
+                const double t0 = s_T[b][ij * 5], t1 = s_T[b][ij * 5 + 1], t2 = s_T[b][ij * 5 + 2], t3 = s_T[b][ij * 5 + 3], t4 = s_T[b][ij * 5 + 4];
+                for (int k = 0; k < AG; ++k) accK[k][ij] += pa[k][0] * t0 + pa[k][1] * t1 + pa[k][2] * t2 + pa[k][3] * t3 + pa[k][4] * t4;
             }
         }
         __syncthreads();
         if (flags & GF_ASM_C_BIT) {
-            for (int o = ag; o < 45; o += NT / NB) {
-                const int iff = o / 5, m = o - 5 * iff, row = (3 * m + iff / 3) * 15 + iff % 3;
-                double v = 0.0;
-                for (int mm = 0; mm < 5; ++mm) v += s_Hc[row + 3 * mm] * pb[mm];
-                s_T[b][o] = v;
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) {
+                const int o = ag + t * LPB;
+                if (o < 45) {
+                    const double* gr = s_Hc + rowH[t];
+                    s_T[b][o] = gr[0] * pb[0] + gr[3] * pb[1] + gr[6] * pb[2] + gr[9] * pb[3] + gr[12] * pb[4];
+                }
             }
         }
         __syncthreads();
         if (lane_ok) {
             if (flags & GF_ASM_C_BIT) {
-                for (int k = 0; k < AG; ++k) for (int q = 0; q < 9; ++q) {
-                    double v = accC[k][q];
-                    for (int m = 0; m < 5; ++m) v += pa[k][m] * s_T[b][q * 5 + m];
-                    accC[k][q] = v;
+                for (int q = 0; q < 9; ++q) {
+                    const double t0 = s_T[b][q * 5], t1 = s_T[b][q * 5 + 1], t2 = s_T[b][q * 5 + 2], t3 = s_T[b][q * 5 + 3], t4 = s_T[b][q * 5 + 4];
+                    for (int k = 0; k < AG; ++k) accC[k][q] += pa[k][0] * t0 + pa[k][1] * t1 + pa[k][2] * t2 + pa[k][3] * t3 + pa[k][4] * t4;
                 }
                 if (has_bf) {          // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b)
                     double jz[3];

@@ -117,3 +117,48 @@ def test_error_behaviour():
     with pytest.raises(RuntimeError):
         D.values(0)          # not assembled yet
     D.close()
+
+
+def test_chunked_scratch_gives_identical_results(oracle_lib, monkeypatch):
+    """GF_SCRATCH_GB small enough to force one chunk per patch: same bits as the single-chunk run."""
+    from goldfish_amd import _lib
+    spec = G.synthetic_shell(3, 2, nel=5, p=3, jitter=1)
+    A, h, u = _state(spec, seed=5)
+    out = []
+    for gb in ("40", "0.0015"):
+        monkeypatch.setenv("GF_SCRATCH_GB", gb)
+        D = _lib.DeviceModel(A)
+        D.set_thickness(h)
+        D.set_u(u)
+        D.assemble()
+        out.append([D.residual()] + [D.values(w) for w in range(5)])
+        D.close()
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
+def test_single_patch_without_interfaces(oracle_lib):
+    from goldfish_amd import _lib
+    from oracle.oracle_py import Oracle
+    spec = G.scordelis_lo_single(5)
+    A, h, u = _state(spec, seed=6, uamp=5e-2)
+    O, D = Oracle(A, thickness=h, u=u), _lib.DeviceModel(A)
+    D.set_thickness(h)
+    D.set_u(u)
+    D.assemble()
+    vals = O.assemble()
+    assert _rel(D.residual(), O.residual()) < RTOL
+    for w in range(5):
+        assert _rel(D.values(w), vals[w]) < RTOL
+    D.close()
+
+
+def test_create_rejects_bad_models():
+    from goldfish_amd import _lib
+    from goldfish_amd.splines import NURBSPatch
+    from goldfish_amd.geometry import ProblemSpec
+    p1 = NURBSPatch.bilinear([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], 2, 2, 3)
+    p2 = NURBSPatch.bilinear([[1, 0, 0], [2, 0, 0], [1, 1, 0], [2, 1, 0]], 2, 2, 2)
+    spec = ProblemSpec([p1, p2], [], 1.0, 0.3, 0.1, [[0, 0, 0]] * 2)
+    with pytest.raises(RuntimeError, match="degree"):
+        _lib.DeviceModel(arrays_from_spec(spec))
