@@ -51,10 +51,17 @@ __device__ __forceinline__ void rationalize6(const double* Nb, const double* W, 
     R[5] = (Nb[5] - R[1] * W[2] - R[2] * W[1] - R[0] * W[5]) * iW;
 }
 
+#ifdef GF_STAMPS
+__device__ unsigned long long g_stamps[8];
+#define GF_STAMP(slot, t0) do { const unsigned long long t1_ = clock64(); stamp_acc[slot] += t1_ - (t0); (t0) = t1_; } while (0)
+#else
+#define GF_STAMP(slot, t0) do { } while (0)
+#endif
 template <int P>
 __global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_element_kernel(DevModel M, int e_first, int flags, double* __restrict__ blk) {
     using Cfg = ElemCfg<P>;
     constexpr int P1 = Cfg::P1, NB = Cfg::NB, NG = Cfg::NG, ND = Cfg::ND, AG = Cfg::AG, NAG = Cfg::NAG, NT = Cfg::NT;
+    constexpr int TS = 5 * 16 + 2;                 // T row per b: [m][16 q-slots] (+2 pad: conflict-free 16-B reads)
     const int tid = threadIdx.x;
     const long long e = (long long)e_first + blockIdx.x;
     if (e >= M.nelem) return;
@@ -62,13 +69,27 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_elemen
     const int le = int(e - Pt.elem_off), eu = le % Pt.nelu, ev = le / Pt.nelu;
     const int iu0 = M.ints[Pt.spu + eu] - P, iv0 = M.ints[Pt.spv + ev] - P;
 
-    __shared__ double s_c[NB][3], s_d[NB][3], s_h[NB], s_w[NB];
+    // LDS: the control-point staging buffers are only live in phases 0-1 and share storage with T (phase 2)
+    constexpr int STAGE = NB * 8, TBUF = NB * TS, UNI = STAGE > TBUF ? STAGE : TBUF;
+    __shared__ __attribute__((aligned(16))) double s_uni[UNI];
+    double (*s_c)[3] = reinterpret_cast<double (*)[3]>(s_uni);
+    double (*s_d)[3] = reinterpret_cast<double (*)[3]>(s_uni + 3 * NB);
+    double* s_h = s_uni + 6 * NB; double* s_w = s_uni + 7 * NB;
+    double* s_T = s_uni;
     __shared__ double s_tu[P1 * 3 * P1], s_tv[P1 * 3 * P1], s_wg[2 * P1];
     __shared__ double s_im[NG][IM_SIZE];
-    __shared__ double s_phi[NB][6], s_n0[NB], s_rh[ND];
-    __shared__ double s_G[225], s_Hc[225];
-    __shared__ double s_T[NB][45];
+    __shared__ __attribute__((aligned(16))) double s_phi[NB][6];   // [a][0..4] = first/second derivatives, [5] = value
+    __shared__ double s_n0[NB];
+    // G = Pzz and Hc = Pzz + PzZ stored as [(m,i)][j][m' (pad 6)]: the 5 operands of one T output are
+    // contiguous and 16-B aligned (ds_read_b128 instead of half-rate ds_read2_b64)
+    __shared__ __attribute__((aligned(16))) double s_GH[2 * 270];
+    double* s_G = s_GH; double* s_Hc = s_GH + 270;
 
+    unsigned long long tstamp = 0; (void)tstamp;
+#ifdef GF_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    tstamp = clock64();
+#endif
     // ---- phase 0: stage control-point data and 1-D tables ------------------------------------
     if (tid < NB) {
         const long long g = Pt.cp_off + (iu0 + tid % P1) + (long long)(iv0 + tid / P1) * Pt.nu;
@@ -81,6 +102,7 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_elemen
     for (int k = tid; k < P1 * 3 * P1; k += NT) { s_tu[k] = M.tab[Pt.tabu + eu * P1 * 3 * P1 + k]; s_tv[k] = M.tab[Pt.tabv + ev * P1 * 3 * P1 + k]; }
     if (tid < P1) { s_wg[tid] = M.tab[Pt.wu + eu * P1 + tid]; s_wg[P1 + tid] = M.tab[Pt.wv + ev * P1 + tid]; }
     __syncthreads();
+    GF_STAMP(0, tstamp);
 
     // ---- phase 1: one lane per Gauss point: kinematics + pointwise closed forms ----------------
     if (tid < NG) {
@@ -100,6 +122,7 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_elemen
         im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
     }
     __syncthreads();
+    GF_STAMP(1, tstamp);
 
     // ---- phase 2: per Gauss point: expand Hessians, T = G phi_b, contract with phi_a --------------
     const int b = tid % NB, ag = tid / NB;
@@ -115,42 +138,49 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_elemen
     // The 225 entries of G = Pzz and Hc = Pzz + PzZ are ordered by structural category
     // [A: tangent x tangent | B: curvature x tangent | B': transpose of B | C: curvature x curvature]
     // so that a wave executes at most two short code paths per pass.
-    constexpr int NIT = (225 + NT - 1) / NT, LPB = NT / NB, NTK = (30 + LPB - 1) / LPB, NTH = (45 + LPB - 1) / LPB;
-    int xcat[NIT], x0[NIT], x1[NIT], x2[NIT], x3[NIT], x4[NIT], x5[NIT], x6[NIT]; double xf[NIT];
+    constexpr int NIT = (225 + NT - 1) / NT, LPB = NT / NB, NTO = (75 + LPB - 1) / LPB;
+    int xcat[NIT], x0[NIT], x1[NIT], x2[NIT], x3[NIT], x4[NIT], x5[NIT], x6[NIT], x7[NIT]; double xf[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int slot = tid + it * NT;
-        xcat[it] = 4; x0[it] = x1[it] = x2[it] = x3[it] = x4[it] = x5[it] = x6[it] = 0; xf[it] = 0.0;
+        xcat[it] = 4; x0[it] = x1[it] = x2[it] = x3[it] = x4[it] = x5[it] = x6[it] = x7[it] = 0; xf[it] = 0.0;
         if (slot < 36) {
             const int r = slot / 6, s = slot - 6 * r, m = r / 3, i = r - 3 * m, mm = s / 3, j = s - 3 * mm;
             xcat[it] = 0; x0[it] = r; x1[it] = s; x2[it] = m; x3[it] = IM_G + 3 * (1 - m) + i; x4[it] = IM_JNV + (m == mm ? m : 2);
-            x5[it] = IM_HMN + 6 * r + s; x6[it] = 15 * r + s; xf[it] = (i == j) ? 1.0 : 0.0;
+            x5[it] = IM_HMN + hmn_idx(r, s); x6[it] = (3 * r + j) * 6 + mm; xf[it] = (i == j) ? 1.0 : 0.0;
         } else if (slot < 90) {
             const int q = slot - 36, rr = q / 6, s = q - 6 * rr, k = rr / 3, i = rr - 3 * k, r = 6 + rr;
             xcat[it] = 1; x0[it] = r; x1[it] = s; x2[it] = IM_N + i; x3[it] = 6 * k + s; x4[it] = IM_JMOF + k; x5[it] = IM_DN + 6 * i + s;
-            x6[it] = 15 * r + s; xf[it] = (k == 2 ? 2.0 : 1.0);
+            x6[it] = (3 * r + s % 3) * 6 + s / 3; x7[it] = (3 * s + i) * 6 + 2 + k; xf[it] = (k == 2 ? 2.0 : 1.0);
         } else if (slot < 144) {
             const int q = slot - 90, ss = q / 6, r = q - 6 * ss, kk = ss / 3, jj = ss - 3 * kk, s = 6 + ss;
             xcat[it] = 2; x0[it] = r; x1[it] = kk; x2[it] = IM_N + jj; x3[it] = 6 * kk + r; x4[it] = IM_JMOF + kk; x5[it] = IM_DN + 6 * jj + r;
-            x6[it] = 15 * r + s; xf[it] = (kk == 2 ? 2.0 : 1.0);
+            x6[it] = (3 * r + jj) * 6 + 2 + kk; (void)s; xf[it] = (kk == 2 ? 2.0 : 1.0);
         } else if (slot < 225) {
             const int q = slot - 144, rr = q / 9, ss = q - 9 * rr, k = rr / 3, i = rr - 3 * k, kk = ss / 3, jj = ss - 3 * kk;
             const int lo = k < kk ? k : kk, hi = k < kk ? kk : k;
-            xcat[it] = 3; x0[it] = IM_N + i; x1[it] = IM_CT3 + lo * (5 - lo) / 2 + hi; x2[it] = jj; x6[it] = 15 * (6 + rr) + 6 + ss;
+            xcat[it] = 3; x0[it] = IM_N + i; x1[it] = IM_CT3 + lo * (5 - lo) / 2 + hi; x2[it] = jj; x6[it] = (3 * (6 + rr) + jj) * 6 + 2 + kk;
             xf[it] = (k == 2 ? 2.0 : 1.0) * (kk == 2 ? 2.0 : 1.0);
         }
     }
-    int rowK[NTK], rowH[NTH];
+    // T outputs of this lane: o < 30 -> K (q = ij, from G), o >= 30 -> dR/dc (q = 6 + 3i + f, from Hc); stored at T[b][m*16 + q]
+    int rowT[NTO], dstT[NTO];
 #pragma unroll
-    for (int t = 0; t < NTK; ++t) { const int o = ag + t * LPB, oo = o < 30 ? o : 0, ij = oo / 5, m = oo - 5 * ij; rowK[t] = (3 * m + IJ_I[ij]) * 15 + IJ_J[ij]; }
-#pragma unroll
-    for (int t = 0; t < NTH; ++t) { const int o = ag + t * LPB, oo = o < 45 ? o : 0, q = oo / 5, m = oo - 5 * q; rowH[t] = (3 * m + q / 3) * 15 + q % 3; }
+    for (int t = 0; t < NTO; ++t) {
+        const int o = ag + t * LPB, oo = o < 75 ? o : 0;
+        if (oo < 30) { const int ij = oo / 5, m = oo - 5 * ij; rowT[t] = ((3 * m + IJ_I[ij]) * 3 + IJ_J[ij]) * 6; dstT[t] = m * 16 + ij; }
+        else { const int q = (oo - 30) / 5, m = (oo - 30) - 5 * q; rowT[t] = 270 + ((3 * m + q / 3) * 3 + q % 3) * 6; dstT[t] = m * 16 + 6 + q; }
+    }
+    const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = (flags & GF_ASM_C_BIT) != 0;
     const int pju = tid % P1, pjv = (tid / P1) % P1;              // basis function handled by tid < NB
     const int ra = tid / 3 < NB ? tid / 3 : 0, ri = tid % 3;      // residual entry handled by tid < ND
+    double* myT = s_T + b * TS;
+    GF_STAMP(2, tstamp);
 
     for (int gp = 0; gp < NG; ++gp) {
         const double* im = s_im[gp];
         const double wq = im[IM_WQ];
+        // -- S1: basis at this Gauss point, expansion of G and Hc
         if (tid < NB) {
             const int gu = gp % P1, gv = gp / P1;
             const double u0 = s_tu[(gu * 3 + 0) * P1 + pju], u1 = s_tu[(gu * 3 + 1) * P1 + pju], u2 = s_tu[(gu * 3 + 2) * P1 + pju];
@@ -158,7 +188,8 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_elemen
             const double Nb[6] = {u0 * v0, u1 * v0, u0 * v1, u2 * v0, u0 * v2, u1 * v1};
             double R[6];
             rationalize6(Nb, im + IM_W, R);
-            for (int k = 0; k < 6; ++k) s_phi[tid][k] = R[k];
+            for (int k = 0; k < 5; ++k) s_phi[tid][k] = R[k + 1];
+            s_phi[tid][5] = R[0];
             s_n0[tid] = Nb[0];
         }
 #pragma unroll
@@ -179,7 +210,7 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_elemen
                 const double fn = xf[it] * im[x2[it]];
                 const double g = fn * im[IM_CBG + x3[it]] - im[x4[it]] * im[x5[it]];
                 const double zz = im[IM_PZ + r] * im[IM_JZJ + s] - fn * im[IM_JDMO + x3[it]];
-                s_G[x6[it]] = g; s_G[15 * s + r] = g; s_Hc[x6[it]] = g + zz;
+                s_G[x6[it]] = g; s_G[x7[it]] = g; s_Hc[x6[it]] = g + zz;
             } else if (xcat[it] == 2) {
                 const int r = x0[it], kk = x1[it], jj = x2[it] - IM_N;
                 const double g = xf[it] * im[x2[it]] * im[IM_CBG + x3[it]] - im[x4[it]] * im[x5[it]];
@@ -192,65 +223,67 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_elemen
                 s_G[x6[it]] = c * nj; s_Hc[x6[it]] = c * (nj - im[IM_NB + x2[it]]);
             }
         }
+        GF_STAMP(3, tstamp);
         __syncthreads();
+        GF_STAMP(4, tstamp);
+        // -- S2: residual / dR/dh prefactors, T = G phi_b and Hc phi_b; operands of S3 are pulled into
+        //    registers here so that S3 only reads T and s_rh and needs no barrier behind it
         if (tid < ND) {
-            double rz = 0.0, rh = 0.0;
-            for (int m = 0; m < 5; ++m) { rz += s_phi[ra][m + 1] * im[IM_PZ + 3 * m + ri]; rh += s_phi[ra][m + 1] * im[IM_PZT + 3 * m + ri]; }
-            accR += wq * (rz - im[IM_J] * Pt.f[ri] * s_phi[ra][0]);
-            s_rh[tid] = wq * rh;
+            const double p1 = s_phi[ra][0], p2 = s_phi[ra][1];
+            double rz = 0.0;
+            for (int m = 0; m < 5; ++m) rz += s_phi[ra][m] * im[IM_PZ + 3 * m + ri];
+            const double g1i = im[IM_G + ri], g2i = im[IM_G + 3 + ri];
+            double rh = p1 * (im[IM_JCE] * g1i + im[IM_JCE + 2] * g2i) + p2 * (im[IM_JCE + 1] * g2i + im[IM_JCE + 2] * g1i);
+            double nn = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                rh -= im[IM_JCK4 + k] * (p1 * im[IM_BG + 6 * k + ri] + p2 * im[IM_BG + 6 * k + 3 + ri]);
+                nn += s_phi[ra][2 + k] * im[IM_JCK4 + k] * (k == 2 ? 2.0 : 1.0);
+            }
+            rh -= im[IM_N + ri] * nn;
+            accR += wq * (rz - im[IM_J] * Pt.f[ri] * s_phi[ra][5]);
+            s_T[(tid / 5) * TS + (tid % 5) * 16 + 15] = wq * rh;       // dR/dh prefactor parked in the unused q-slot 15 of T
         }
-        double pb[5];
-        for (int m = 0; m < 5; ++m) pb[m] = wq * s_phi[b][m + 1];
-        // T for K (i <= j): 30 outputs per b, split over the LPB lanes sharing b
-        if (flags & GF_ASM_K_BIT) {
+        double pb[5], pa[AG][5], pa0[AG];
+        for (int m = 0; m < 5; ++m) pb[m] = wq * s_phi[b][m];
+        for (int k = 0; k < AG; ++k) { const int a = ag * AG + k < NB ? ag * AG + k : NB - 1; pa0[k] = s_phi[a][5]; for (int m = 0; m < 5; ++m) pa[k][m] = s_phi[a][m]; }
+        const double n0b = s_n0[b];
+        double jz[3] = {0.0, 0.0, 0.0};
+        if (has_bf) for (int f = 0; f < 3; ++f) jz[f] = im[IM_J] * (im[IM_JZJ + f] * pb[0] + im[IM_JZJ + 3 + f] * pb[1]);
 #pragma unroll
-            for (int t = 0; t < NTK; ++t) {
-                const int o = ag + t * LPB;
-                if (o < 30) {
-                    const double* gr = s_G + rowK[t];
-                    s_T[b][o] = gr[0] * pb[0] + gr[3] * pb[1] + gr[6] * pb[2] + gr[9] * pb[3] + gr[12] * pb[4];
-                }
+        for (int t = 0; t < NTO; ++t) {
+            const int o = ag + t * LPB;
+            if (o < 75 && (o < 30 ? doK : doC)) {
+                const double* gr = s_GH + rowT[t];                // rowT >= 270 addresses Hc
+                const double2 g01 = *reinterpret_cast<const double2*>(gr), g23 = *reinterpret_cast<const double2*>(gr + 2);
+                myT[dstT[t]] = g01.x * pb[0] + g01.y * pb[1] + g23.x * pb[2] + g23.y * pb[3] + gr[4] * pb[4];
             }
         }
+        GF_STAMP(5, tstamp);
         __syncthreads();
-        double pa[AG][5];
-        for (int k = 0; k < AG; ++k) { const int a = ag * AG + k < NB ? ag * AG + k : NB - 1; for (int m = 0; m < 5; ++m) pa[k][m] = s_phi[a][m + 1]; }
-        if (lane_ok && (flags & GF_ASM_K_BIT)) {
-            for (int ij = 0; ij < 6; ++ij) {
-                const double t0 = s_T[b][ij * 5], t1 = s_T[b][ij * 5 + 1], t2 = s_T[b][ij * 5 + 2], t3 = s_T[b][ij * 5 + 3], t4 = s_T[b][ij * 5 + 4];
-                for (int k = 0; k < AG; ++k) accK[k][ij] += pa[k][0] * t0 + pa[k][1] * t1 + pa[k][2] * t2 + pa[k][3] * t3 + pa[k][4] * t4;
-            }
-        }
-        __syncthreads();
-        if (flags & GF_ASM_C_BIT) {
-#pragma unroll
-            for (int t = 0; t < NTH; ++t) {
-                const int o = ag + t * LPB;
-                if (o < 45) {
-                    const double* gr = s_Hc + rowH[t];
-                    s_T[b][o] = gr[0] * pb[0] + gr[3] * pb[1] + gr[6] * pb[2] + gr[9] * pb[3] + gr[12] * pb[4];
-                }
-            }
-        }
-        __syncthreads();
+        GF_STAMP(6, tstamp);
+        // -- S3: contraction phi_a . T_b in registers
         if (lane_ok) {
-            if (flags & GF_ASM_C_BIT) {
-                for (int q = 0; q < 9; ++q) {
-                    const double t0 = s_T[b][q * 5], t1 = s_T[b][q * 5 + 1], t2 = s_T[b][q * 5 + 2], t3 = s_T[b][q * 5 + 3], t4 = s_T[b][q * 5 + 4];
-                    for (int k = 0; k < AG; ++k) accC[k][q] += pa[k][0] * t0 + pa[k][1] * t1 + pa[k][2] * t2 + pa[k][3] * t3 + pa[k][4] * t4;
-                }
-                if (has_bf) {          // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b)
-                    double jz[3];
-                    for (int f = 0; f < 3; ++f) jz[f] = im[IM_J] * (im[IM_JZJ + f] * pb[0] + im[IM_JZJ + 3 + f] * pb[1]);
-                    for (int k = 0; k < AG; ++k) { const int a = ag * AG + k < NB ? ag * AG + k : NB - 1; for (int i = 0; i < 3; ++i) for (int f = 0; f < 3; ++f) accC[k][3 * i + f] -= Pt.f[i] * s_phi[a][0] * jz[f]; }
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                double tq[16];
+                const double2* src = reinterpret_cast<const double2*>(myT + m * 16);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const double2 v = src[q]; tq[2 * q] = v.x; tq[2 * q + 1] = v.y; }
+                for (int k = 0; k < AG; ++k) {
+                    if (doK) for (int q = 0; q < 6; ++q) accK[k][q] += pa[k][m] * tq[q];
+                    if (doC) for (int q = 0; q < 9; ++q) accC[k][q] += pa[k][m] * tq[6 + q];
                 }
             }
-            if (flags & GF_ASM_H_BIT)
-                for (int k = 0; k < AG; ++k) { const int a = ag * AG + k < NB ? ag * AG + k : NB - 1; for (int i = 0; i < 3; ++i) accH[k][i] += s_n0[b] * s_rh[3 * a + i]; }
+            if (has_bf)            // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b)
+                for (int k = 0; k < AG; ++k) for (int i = 0; i < 3; ++i) for (int f = 0; f < 3; ++f) accC[k][3 * i + f] -= Pt.f[i] * pa0[k] * jz[f];
+            for (int k = 0; k < AG; ++k) { const int a = ag * AG + k < NB ? ag * AG + k : NB - 1; for (int i = 0; i < 3; ++i) { const int w = 3 * a + i; accH[k][i] += n0b * s_T[(w / 5) * TS + (w % 5) * 16 + 15]; } }
         }
-        __syncthreads();
+        GF_STAMP(7, tstamp);
     }
 
+#ifdef GF_STAMPS
+    if ((threadIdx.x & 63) == 0 && (blockIdx.x & 31) == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[k], stamp_acc[k]);
+#endif
     // ---- phase 3: write the element block once -------------------------------------------------------
     double* out = blk + (size_t)blockIdx.x * Cfg::BLK;
     if (tid < ND && (flags & GF_ASM_R_BIT)) out[Cfg::OFF_R + tid] = accR;

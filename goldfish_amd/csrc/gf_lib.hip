@@ -340,6 +340,15 @@ double gf_kernel_ms(gf_handle* h, int* n_launches) {
     return n > 0 ? tot / n : 0.0;
 }
 
+#ifdef GF_STAMPS
+// diagnostic build only: cycle sums per kernel section (lane 0 of every wave), then reset
+int gf_debug_stamps(unsigned long long out[8]) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess;
+}
+#endif
+
 int gf_functionals(gf_handle* h, double out[3], double* dWdu, double* dWdcp, double* dWdh, double* dVdcp, double* dVdh, int apply_bcs) {
     if (!h || !out) return fail("gf_functionals: null argument");
     try {

@@ -18,26 +18,29 @@ namespace gf {
 
 // ---- layout of the per-Gauss-point intermediate record (doubles) -------------------
 enum : int {
-    IM_J = 0, IM_T = 1, IM_WQ = 2, IM_PSI = 3,
-    IM_W = 4,        // [6]  W and its parametric derivatives (for the rational basis)
-    IM_G = 10,       // [6]  g1, g2
-    IM_N = 16,       // [3]  deformed unit normal
-    IM_NB = 19,      // [3]  reference unit normal
-    IM_BG = 22,      // [3][6] d beta_k / d(g1,g2)
-    IM_CEZ = 40,     // [3][6] J t  C ez
-    IM_CBG = 58,     // [3][6] J t3 C bg
-    IM_CT3 = 76,     // [6]  J t3 C  (00,01,02,11,12,22)
-    IM_JNV = 82,     // [3]  J * membrane resultants (Voigt)
-    IM_HMN = 85,     // [6][6] J * Hessian of (M . n)
-    IM_DN = 121,     // [3][6] dn_i / d(g1,g2)
-    IM_JMOF = 139,   // [3]  J mo_k f_k
-    IM_PZ = 142,     // [15] dPsi/dz
-    IM_PZT = 157,    // [15] d2Psi/dz dt
-    IM_JZJ = 172,    // [6]  (dJ/dZ)/J
-    IM_JDNV = 178,   // [3][6] J d(nv)/dZ
-    IM_JDMO = 196,   // [3][6] J d(mo)/dZ (tangent columns)
-    IM_SIZE = 214
+    IM_J = 0, IM_WQ = 1,
+    IM_W = 2,        // [6]  W and its parametric derivatives (for the rational basis)
+    IM_G = 8,        // [6]  g1, g2
+    IM_N = 14,       // [3]  deformed unit normal
+    IM_NB = 17,      // [3]  reference unit normal
+    IM_BG = 20,      // [3][6] d beta_k / d(g1,g2)
+    IM_CEZ = 38,     // [3][6] J t  C ez
+    IM_CBG = 56,     // [3][6] J t3 C bg
+    IM_CT3 = 74,     // [6]  J t3 C  (00,01,02,11,12,22)
+    IM_JNV = 80,     // [3]  J * membrane resultants (Voigt)
+    IM_HMN = 83,     // [21] J * Hessian of (M . n), symmetric 6x6, row-major upper triangle (hmn_idx)
+    IM_DN = 104,     // [3][6] dn_i / d(g1,g2)
+    IM_JMOF = 122,   // [3]  J mo_k f_k
+    IM_PZ = 125,     // [15] dPsi/dz
+    IM_JCE = 140,    // [3]  J C eps            } d2Psi/dz dt is rebuilt from these two
+    IM_JCK4 = 143,   // [3]  J (t^2/4) C kappa  } (pzt_entry)
+    IM_JZJ = 146,    // [6]  (dJ/dZ)/J
+    IM_JDNV = 152,   // [3][6] J d(nv)/dZ
+    IM_JDMO = 170,   // [3][6] J d(mo)/dZ (tangent columns)
+    IM_SIZE = 188
 };
+GF_HD __forceinline__ int hmn_idx(int r, int s) { const int lo = r < s ? r : s, hi = r < s ? s : r; return 6 * lo - lo * (lo - 1) / 2 + hi - lo; }
+
 
 GF_HD __forceinline__ void cross3(const double* a, const double* b, double* c) {
     c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
@@ -130,10 +133,9 @@ GF_HD inline void shell_point(const double* z, const double* Z, double t, double
     double Ce[3], Ck[3], nv[3], mo[3];
     symmv(C, eps, Ce); symmv(C, kap, Ck);
     for (int k = 0; k < 3; ++k) { nv[k] = t * Ce[k]; mo[k] = t3 * Ck[k]; }
-    im[IM_J] = J; im[IM_T] = t;
-    im[IM_PSI] = J * (0.5 * t * dot3(eps, Ce) + 0.5 * t3 * dot3(kap, Ck));
+    im[IM_J] = J;
     for (int c = 0; c < 6; ++c) im[IM_G + c] = z[c];
-    for (int k = 0; k < 3; ++k) { im[IM_N + k] = n[k]; im[IM_NB + k] = N[k]; im[IM_JNV + k] = J * nv[k]; im[IM_JMOF + k] = J * mo[k] * f3[k]; }
+    for (int k = 0; k < 3; ++k) { im[IM_N + k] = n[k]; im[IM_NB + k] = N[k]; im[IM_JNV + k] = J * nv[k]; im[IM_JMOF + k] = J * mo[k] * f3[k]; im[IM_JCE + k] = J * Ce[k]; im[IM_JCK4 + k] = J * 0.25 * t * t * Ck[k]; }
     // ez[k][c] (c<6): row0 [g1,0], row1 [0,g2], row2 [g2,g1];  bg[k][c] = f_k h_k . Dn[:,c]
     double ez[3][6], bg[3][6], eZ[3][6], bG[3][6];
     for (int c = 0; c < 3; ++c) {
@@ -152,21 +154,18 @@ GF_HD inline void shell_point(const double* z, const double* Z, double t, double
         for (int k = 0; k < 3; ++k) { im[IM_CEZ + 6 * k + c] = J * t * ca[k]; im[IM_CBG + 6 * k + c] = J * t3 * cb[k]; }
     }
     for (int k = 0; k < 6; ++k) im[IM_CT3 + k] = J * t3 * C[k];
-    // Pz, Pzt
+    // Pz
     for (int c = 0; c < 6; ++c) {
-        double pe = 0, pb = 0, he = 0, hb = 0;
-        for (int k = 0; k < 3; ++k) { pe += nv[k] * ez[k][c]; pb += mo[k] * bg[k][c]; he += Ce[k] * ez[k][c]; hb += Ck[k] * bg[k][c]; }
-        im[IM_PZ + c] = J * (pe - pb); im[IM_PZT + c] = J * (he - 0.25 * t * t * hb);
+        double pe = 0, pb = 0;
+        for (int k = 0; k < 3; ++k) { pe += nv[k] * ez[k][c]; pb += mo[k] * bg[k][c]; }
+        im[IM_PZ + c] = J * (pe - pb);
     }
-    for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) {
-        im[IM_PZ + 6 + 3 * k + i] = -J * mo[k] * f3[k] * n[i];
-        im[IM_PZT + 6 + 3 * k + i] = -J * 0.25 * t * t * Ck[k] * f3[k] * n[i];
-    }
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) im[IM_PZ + 6 + 3 * k + i] = -J * mo[k] * f3[k] * n[i];
     // geometric bending term: M = sum_k mo_k f_k h_k
     double M[3], H[6][6];
     for (int i = 0; i < 3; ++i) M[i] = mo[0] * z[6 + i] + mo[1] * z[9 + i] + 2.0 * mo[2] * z[12 + i];
     hess_M_dot_n(z, z + 3, n, j, M, H);
-    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) im[IM_HMN + 6 * r + c] = J * H[r][c];
+    for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) im[IM_HMN + hmn_idx(r, c)] = J * H[r][c];
     // reference path: JZ/J, J dnv/dZ, J dmo/dZ (tangent columns)
     double JZ[6];
     cross3(Z + 3, N, JZ); cross3(N, Z, JZ + 3);
@@ -198,6 +197,13 @@ GF_HD __forceinline__ double bz_entry(const double* im, int k, int r) {
     const int kk = (r - 6) / 3, i = (r - 6) - 3 * kk;
     return kk == k ? f3[k] * im[IM_N + i] : 0.0;
 }
+// d2Psi/dz dt [r] rebuilt from the compact record
+GF_HD inline double pzt_entry(const double* im, int r) {
+    double v = 0.0;
+    for (int k = 0; k < 3; ++k) v -= im[IM_JCK4 + k] * bz_entry(im, k, r);
+    if (r < 6) for (int k = 0; k < 3; ++k) v += im[IM_JCE + k] * ez_entry(im, k, r);
+    return v;
+}
 GF_HD inline double pzz_entry(const double* im, int r, int s) {
     const double f3[3] = {1.0, 1.0, 2.0};
     double v = 0.0;
@@ -205,7 +211,7 @@ GF_HD inline double pzz_entry(const double* im, int r, int s) {
         for (int k = 0; k < 3; ++k) v += ez_entry(im, k, r) * im[IM_CEZ + 6 * k + s] + im[IM_BG + 6 * k + r] * im[IM_CBG + 6 * k + s];
         const int m = r / 3, mm = s / 3;
         if (r - 3 * m == s - 3 * mm) v += im[IM_JNV + (m == mm ? m : 2)];
-        v -= im[IM_HMN + 6 * r + s];
+        v -= im[IM_HMN + hmn_idx(r, s)];
     } else if (r >= 6 && s >= 6) {
         const int k = (r - 6) / 3, i = (r - 6) - 3 * k, kk = (s - 6) / 3, jj = (s - 6) - 3 * kk;
         v = f3[k] * im[IM_N + i] * im[IM_CT3 + sym3(k, kk)] * f3[kk] * im[IM_N + jj];

@@ -2,9 +2,10 @@
 // tests/test_pointwise_forms.py to check the device closed forms on the CPU.
 #include "kl_point.hpp"
 extern "C" {
-void gfh_shell_point(const double* z, const double* Z, double t, double E, double nu, double* im, double* Pzz, double* PzZ) {
+void gfh_shell_point(const double* z, const double* Z, double t, double E, double nu, double* im, double* Pzz, double* PzZ, double* Pz, double* Pzt) {
     for (int k = 0; k < gf::IM_SIZE; ++k) im[k] = 0.0;
     gf::shell_point(z, Z, t, E, nu, im);
+    for (int r = 0; r < 15; ++r) { Pz[r] = im[gf::IM_PZ + r]; Pzt[r] = gf::pzt_entry(im, r); }
     for (int r = 0; r < 15; ++r) for (int s = 0; s < 15; ++s) { Pzz[15 * r + s] = gf::pzz_entry(im, r, s); PzZ[15 * r + s] = gf::pzZ_entry(im, r, s); }
 }
 void gfh_penalty_point(const double* y, const double* Y, const double* tau, double ad, double ar, double dt, double* out) {

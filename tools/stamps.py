@@ -1,0 +1,21 @@
+"""Diagnostic (not product): where do the element kernel's wave cycles go?  Needs the -DGF_STAMPS build."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["GF_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "goldfish_amd", "libgoldfish_hip_stamps.so")
+from goldfish_amd import _lib, geometry as G
+from goldfish_amd.model import arrays_from_spec
+spec = G.synthetic_shell(8, 8, nel=48, p=3, jitter=2)
+th = G.random_thickness(spec)
+A = arrays_from_spec(spec, th)
+D = _lib.DeviceModel(A)
+D.set_thickness(np.concatenate(th)); D.set_u(G.smooth_displacement(spec, 0.5 * spec.h_th))
+L = _lib.lib(); out = (C.c_ulonglong * 8)()
+D.assemble(); L.gf_debug_stamps(out)
+D.assemble(); L.gf_debug_stamps(out)
+nw = 2 * ((D.n_elements + 31) // 32)      # 1 in 32 elements sampled, 2 waves each
+names = ["phase0 load", "phase1 pointwise(+barrier wait)", "descriptors", "S1 expansion", "barrier1", "S2 T-formation", "barrier2", "S3 contraction"]
+tot = sum(out)
+for n, v in zip(names, out):
+    print("%-34s %10.0f cycles/wave  %5.1f%%" % (n, v / nw, 100.0 * v / tot))
+print("total %.0f cycles/wave" % (tot / nw))
