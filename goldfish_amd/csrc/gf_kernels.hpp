@@ -334,24 +334,63 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
     // touched by one wave, whose LDS operations execute in program order, so the element loop needs
     // no barrier and the row loads of successive elements overlap.
     const int wave = tid >> 6, lane = tid & 63;
-    for (int ev = ev0; ev <= ev1; ++ev) for (int eu = eu0; eu <= eu1; ++eu) {
-        const long long e = Pt.elem_off + eu + (long long)ev * Pt.nelu - e_first;
-        if (e < 0 || e >= e_count) continue;
-        const double* B = blk + (size_t)e * Cfg::BLK;
-        const int bu = spu[eu] - P, bv = spv[ev] - P, al = (ia - bu) + (ja - bv) * P1;
+    // Elements are taken four at a time: the row loads of a group are all issued before the LDS adds
+    // of the group, so up to 4 x 6 loads per lane are in flight (the adds keep the fixed element order).
+    constexpr int NPASS = (ND + 63) / 64, NPH = (3 * NB + 63) / 64, UNR = 4;
+    const int neu = eu1 - eu0 + 1, nev = ev1 - ev0 + 1, ne = (neu > 0 && nev > 0) ? neu * nev : 0;
+    for (int g0 = 0; g0 < ne; g0 += UNR) {
+        const double* Bp[UNR]; int bu[UNR], bv[UNR], al[UNR]; bool ok[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const int g = g0 + q, gg = g < ne ? g : 0, eu = eu0 + gg % neu, ev = ev0 + gg / neu;
+            const long long e = Pt.elem_off + eu + (long long)ev * Pt.nelu - e_first;
+            ok[q] = g < ne && e >= 0 && e < e_count;
+            Bp[q] = blk + (size_t)(ok[q] ? e : 0) * Cfg::BLK;
+            bu[q] = spu[eu] - P; bv[q] = spv[ev] - P; al[q] = (ia - bu[q]) + (ja - bv[q]) * P1;
+        }
         if (wave < 3) {
             const int i = wave;
-            for (int c = lane; c < ND; c += 64) {
-                const int bl = c / 3, j = c - 3 * bl, ks = (bu + bl % P1 - i0) + (bv + bl / P1 - j0) * wbox;
-                if (flags & GF_ASM_K_BIT) aK[i][ks][j] += B[Cfg::OFF_K + (3 * al + i) * ND + c];
-                if (flags & GF_ASM_C_BIT) aC[j][i][ks] += B[Cfg::OFF_C + (3 * al + i) * ND + c];
-            }
+            double vK[UNR][NPASS], vC[UNR][NPASS];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q)
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int c = lane + 64 * ps;
+                    const bool on = ok[q] && c < ND;
+                    vK[q][ps] = (on && (flags & GF_ASM_K_BIT)) ? Bp[q][Cfg::OFF_K + (3 * al[q] + i) * ND + c] : 0.0;
+                    vC[q][ps] = (on && (flags & GF_ASM_C_BIT)) ? Bp[q][Cfg::OFF_C + (3 * al[q] + i) * ND + c] : 0.0;
+                }
+#pragma unroll
+            for (int q = 0; q < UNR; ++q)
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int c = lane + 64 * ps;
+                    if (ok[q] && c < ND) {
+                        const int bl = c / 3, j = c - 3 * bl, ks = (bu[q] + bl % P1 - i0) + (bv[q] + bl / P1 - j0) * wbox;
+                        aK[i][ks][j] += vK[q][ps]; aC[j][i][ks] += vC[q][ps];
+                    }
+                }
         } else {
-            if (flags & GF_ASM_H_BIT) for (int w = lane; w < 3 * NB; w += 64) {
-                const int i = w / NB, bl = w - i * NB, ks = (bu + bl % P1 - i0) + (bv + bl / P1 - j0) * wbox;
-                aH[i][ks] += B[Cfg::OFF_H + (3 * al + i) * NB + bl];
+            double vH[UNR][NPH], vR[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+#pragma unroll
+                for (int ps = 0; ps < NPH; ++ps) {
+                    const int w = lane + 64 * ps;
+                    vH[q][ps] = (ok[q] && w < 3 * NB && (flags & GF_ASM_H_BIT)) ? Bp[q][Cfg::OFF_H + (3 * al[q] + w / NB) * NB + w % NB] : 0.0;
+                }
+                vR[q] = (ok[q] && lane < 3 && (flags & GF_ASM_R_BIT)) ? Bp[q][Cfg::OFF_R + 3 * al[q] + lane] : 0.0;
             }
-            if ((flags & GF_ASM_R_BIT) && lane < 3) aR[lane] += B[Cfg::OFF_R + 3 * al + lane];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                if (!ok[q]) continue;
+#pragma unroll
+                for (int ps = 0; ps < NPH; ++ps) {
+                    const int w = lane + 64 * ps;
+                    if (w < 3 * NB) { const int i = w / NB, bl = w - i * NB, ks = (bu[q] + bl % P1 - i0) + (bv[q] + bl / P1 - j0) * wbox; aH[i][ks] += vH[q][ps]; }
+                }
+                if (lane < 3) aR[lane] += vR[q];
+            }
         }
     }
     __syncthreads();
@@ -529,13 +568,14 @@ template <int P> __device__ __forceinline__ int pen_local(const DevModel& M, con
     return (i >= 0 && i <= P && j >= 0 && j <= P) ? i + j * (P + 1) : -1;
 }
 
-// Penalty rows of one owned control point a (one workgroup each): residual entries and the coupling
-// blocks of K and dR/dCP.  For every mortar vertex v whose support contains a, the Hessian rows are
-// first contracted with nu_a once (w-vectors, shared through LDS), then every partner control point
-// b of v (both sides, one lane each) adds its 3x3 blocks into LDS accumulators indexed by b's slot
-// in a's neighbour list.  Items and vertices are visited in a fixed order: bitwise reproducible.
-constexpr int PEN_MAXDEG = 320;
-template <int P>
+// Penalty rows of one owned control point a (one wave each): residual entries and the coupling blocks
+// of K and dR/dCP.  Every lane OWNS up to PEN_SL neighbour slots k of a (k = lane + 64 sl) and keeps
+// their 3x3 K and dR/dc blocks in registers.  For every mortar vertex v whose support contains a, the
+// Hessian rows are contracted with nu_a once (w-vectors, double-buffered in LDS: one barrier per
+// vertex); a lane whose slot's control point lies in the support window of v adds its blocks.
+// Items and vertices are visited in a fixed order and nothing is shared: bitwise reproducible.
+constexpr int PEN_MAXDEG = 64 * 5;
+template <int P, int PEN_SL>
 __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q, int flags, int maxdeg, const double* __restrict__ pbuf, double* __restrict__ R,
                                                         double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1, double* __restrict__ valC2) {
     constexpr int P1 = P + 1, NB = P1 * P1;
@@ -545,55 +585,75 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
     const long long it0 = Q.row_ptr[gidx], it1 = Q.row_ptr[gidx + 1];
     const int a = Q.row_items[it0].a;
     const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c;
-    extern __shared__ double s_dyn[];                      // [maxdeg][9] K, [maxdeg][9] C, [maxdeg] neighbour ids
-    double (*accK)[9] = reinterpret_cast<double (*)[9]>(s_dyn);
-    double (*accC)[9] = reinterpret_cast<double (*)[9]>(s_dyn + 9 * (size_t)maxdeg);
-    int* s_nb = reinterpret_cast<int*>(s_dyn + 18 * (size_t)maxdeg);
-    __shared__ double s_wK[3][18], s_wC[3][12], s_r[3];
-    const bool mats = (flags & (GF_ASM_K_BIT | GF_ASM_C_BIT)) != 0 && deg_c <= maxdeg;
-    if (mats) for (int k = tid; k < 9 * (int)deg_c; k += 64) { (&accK[0][0])[k] = 0.0; (&accC[0][0])[k] = 0.0; }
-    if (mats) for (int k = tid; k < (int)deg_c; k += 64) s_nb[k] = M.nb_c[ptr_c + k];
-    if (tid < 3) s_r[tid] = 0.0;
-    __syncthreads();
+    const bool mats = (flags & (GF_ASM_K_BIT | GF_ASM_C_BIT)) != 0;
+    __shared__ double s_w[2][3][32];                    // [buffer][i][0..17 wK | 18..29 wC]
+    // owned slots
+    int sb[PEN_SL], sp[PEN_SL], si[PEN_SL], sj[PEN_SL];
+    double kk[PEN_SL][9], cc[PEN_SL][9];
+#pragma unroll
+    for (int sl = 0; sl < PEN_SL; ++sl) {
+        const int k = tid + 64 * sl;
+        sb[sl] = -1; sp[sl] = -1; si[sl] = 0; sj[sl] = 0;
+        if (mats && sl * 64 < maxdeg && k < deg_c) {
+            const int bcp = M.nb_c[ptr_c + k], pb = M.cp_patch[bcp];
+            const PatchDev& Pb = M.patches[pb];
+            const int lb = int(bcp - Pb.cp_off);
+            sb[sl] = bcp; sp[sl] = pb; si[sl] = lb % Pb.nu; sj[sl] = lb / Pb.nu;
+        }
+        for (int q = 0; q < 9; ++q) { kk[sl][q] = 0.0; cc[sl][q] = 0.0; }
+    }
+    double racc = 0.0;                                  // tid < 3: residual entry (a, tid)
+    int buf = 0;
     for (long long it = it0; it < it1; ++it) {
         const PenRowItem I = Q.row_items[it];
         const int itf = I.code >> 1, s = I.code & 1;
+        const int pA = Q.if_patch[2 * itf], pB = Q.if_patch[2 * itf + 1];
         for (long long v = I.lo; v <= I.hi; ++v) {
             const int al = pen_local<P>(M, Q, v, s, itf, a);
-            if (al < 0) continue;                                              // uniform over the workgroup
+            if (al < 0) continue;                                              // uniform over the wave
             const double* na = Q.pt_nu + ((size_t)v * 2 + s) * 3 * NB; const double* pb = pbuf + (size_t)v * PB_STRIDE;
             const double n0 = na[al], n1 = na[NB + al], n2 = na[2 * NB + al];
-            // w-vectors: rows (s, m, i) contracted over m with nu_a
-            if (tid < 54) { const int i = tid / 18, c = tid - 18 * i; const double* h = pb + PB_HYY + (9 * s + i) * 18 + c; s_wK[i][c] = n0 * h[0] + n1 * h[3 * 18] + n2 * h[6 * 18]; }
-            if (tid < 36) { const int i = tid / 12, c = tid - 12 * i; const double* h = pb + PB_HYC + (9 * s + i) * 12 + c; s_wC[i][c] = n0 * h[0] + n1 * h[3 * 12] + n2 * h[6 * 12]; }
-            if (tid < 3) { const double* g = pb + PB_GRAD + 9 * s; s_r[tid] += n0 * g[tid] + n1 * g[3 + tid] + n2 * g[6 + tid]; }
+            if (tid < 54) { const int i = tid / 18, c = tid - 18 * i; const double* h = pb + PB_HYY + (9 * s + i) * 18 + c; s_w[buf][i][c] = n0 * h[0] + n1 * h[3 * 18] + n2 * h[6 * 18]; }
+            else if (tid < 64) { /* idle in this step */ }
+            if (tid < 36) { const int i = tid / 12, c = tid - 12 * i; const double* h = pb + PB_HYC + (9 * s + i) * 12 + c; s_w[buf][i][18 + c] = n0 * h[0] + n1 * h[3 * 12] + n2 * h[6 * 12]; }
+            if (tid < 3) { const double* g = pb + PB_GRAD + 9 * s; racc += n0 * g[tid] + n1 * g[3 + tid] + n2 * g[6 + tid]; }
             __syncthreads();
-            if (mats && tid < 2 * NB) {
-                const int t = tid / NB, bl = tid - t * NB;
-                const PatchDev& Pb = M.patches[Q.if_patch[2 * itf + t]];
-                const int bcp = int(Pb.cp_off + (Q.pt_base[4 * v + 2 * t] + bl % P1) + (long long)(Q.pt_base[4 * v + 2 * t + 1] + bl / P1) * Pb.nu);
-                int lo = 0, hi = (int)deg_c - 1, k = -1;                        // slot of b in a's neighbour list
-                while (lo <= hi) { const int mid = (lo + hi) >> 1, c = s_nb[mid]; if (c == bcp) { k = mid; break; } if (c < bcp) lo = mid + 1; else hi = mid - 1; }
-                if (k >= 0) {
+            if (mats) {
+                const int* base = Q.pt_base + 4 * v;
+#pragma unroll
+                for (int sl = 0; sl < PEN_SL; ++sl) {
+                    if (sl * 64 >= maxdeg || sb[sl] < 0) continue;
+                    const int t = sp[sl] == pA ? 0 : (sp[sl] == pB ? 1 : -1);
+                    if (t < 0) continue;
+                    // a self-interface (pA == pB) would need both sides per slot; not supported (rejected at create)
+                    const int di = si[sl] - base[2 * t], dj = sj[sl] - base[2 * t + 1];
+                    if (di < 0 || di > P || dj < 0 || dj > P) continue;
+                    const int bl = di + dj * P1;
                     const double* nb = Q.pt_nu + ((size_t)v * 2 + t) * 3 * NB;
                     const double b0 = nb[bl], b1 = nb[NB + bl], b2 = nb[2 * NB + bl];
                     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-                        accK[k][3 * i + j] += s_wK[i][9 * t + j] * b0 + s_wK[i][9 * t + 3 + j] * b1 + s_wK[i][9 * t + 6 + j] * b2;
-                        accC[k][3 * i + j] += s_wC[i][6 * t + j] * b1 + s_wC[i][6 * t + 3 + j] * b2;
+                        kk[sl][3 * i + j] += s_w[buf][i][9 * t + j] * b0 + s_w[buf][i][9 * t + 3 + j] * b1 + s_w[buf][i][9 * t + 6 + j] * b2;
+                        cc[sl][3 * i + j] += s_w[buf][i][18 + 6 * t + j] * b1 + s_w[buf][i][18 + 6 * t + 3 + j] * b2;
                     }
                 }
             }
-            __syncthreads();
+            buf ^= 1;            // the next vertex writes the other buffer: one barrier per vertex suffices
         }
     }
-    if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * (long long)a + tid] += s_r[tid];
+    if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * (long long)a + tid] += racc;
     if (!mats) return;
-    for (int idx = tid; idx < 9 * (int)deg_c; idx += 64) {
-        const int k = idx / 9, q = idx - 9 * k, i = q / 3, j = q - 3 * i;
-        const long long row = 3 * (long long)a + i, bcp = M.nb_c[ptr_c + k];
-        if (M.zero[row]) continue;
-        if ((flags & GF_ASM_K_BIT) && !M.zero[3 * bcp + j]) valK[9 * ptr_c + (long long)i * 3 * deg_c + 3 * k + j] += accK[k][q];
-        if (flags & GF_ASM_C_BIT) { double* dst = j == 0 ? valC0 : (j == 1 ? valC1 : valC2); dst[3 * ptr_c + (long long)i * deg_c + k] += accC[k][q]; }
+#pragma unroll
+    for (int sl = 0; sl < PEN_SL; ++sl) {
+        if (sl * 64 >= maxdeg || sb[sl] < 0) continue;
+        const int k = tid + 64 * sl; const long long bcp = sb[sl];
+        for (int i = 0; i < 3; ++i) {
+            const long long row = 3 * (long long)a + i;
+            if (M.zero[row]) continue;
+            for (int j = 0; j < 3; ++j) {
+                if ((flags & GF_ASM_K_BIT) && !M.zero[3 * bcp + j]) valK[9 * ptr_c + (long long)i * 3 * deg_c + 3 * k + j] += kk[sl][3 * i + j];
+                if (flags & GF_ASM_C_BIT) { double* dst = j == 0 ? valC0 : (j == 1 ? valC1 : valC2); dst[3 * ptr_c + (long long)i * deg_c + k] += cc[sl][3 * i + j]; }
+            }
+        }
     }
 }
 

@@ -105,6 +105,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             h->d_pbuf = h->dalloc<double>((size_t)H.npts * PB_STRIDE);
             for (const PenRowItem& it : H.row_items)
                 h->pen_maxdeg = std::max(h->pen_maxdeg, (int)(H.nb_ptr_c[it.a + 1] - H.nb_ptr_c[it.a]));
+            for (int i = 0; i < H.ni; ++i) if (H.if_patch[2 * i] == H.if_patch[2 * i + 1]) throw std::runtime_error("gf_create: self-interfaces (both sides on one patch) are not supported");
             for (const PenRowItem& it : H.row_items)
                 if (H.nb_ptr_c[it.a + 1] - H.nb_ptr_c[it.a] > PEN_MAXDEG)
                     throw std::runtime_error("gf_create: a control point couples to more than " + std::to_string(PEN_MAXDEG) + " neighbours (PEN_MAXDEG)");
@@ -219,8 +220,12 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
     const HostModel& H = h->H;
     if (H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP))) {
         hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf);
-        hipLaunchKernelGGL(pen_owner_kernel<P>, dim3((unsigned)h->Q.nrow_groups), dim3(64), (size_t)h->pen_maxdeg * (18 * 8 + 4) + 8, h->stream, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R,
-                           h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3]);
+        const dim3 grid((unsigned)h->Q.nrow_groups), blk64(64);
+        const int sl = (h->pen_maxdeg + 63) / 64;         // neighbour slots per lane, register resident
+#define GF_PEN_LAUNCH(SL) hipLaunchKernelGGL((pen_owner_kernel<P, SL>), grid, blk64, 0, h->stream, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \
+                                             h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])
+        if (sl <= 2) GF_PEN_LAUNCH(2); else if (sl == 3) GF_PEN_LAUNCH(3); else GF_PEN_LAUNCH(5);
+#undef GF_PEN_LAUNCH
     }
     if (flags & GF_ASM_R) {
         const long long npl = (long long)H.pl_dof.size();
