@@ -175,6 +175,10 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_elemen
     const int pju = tid % P1, pjv = (tid / P1) % P1;              // basis function handled by tid < NB
     const int ra = tid / 3 < NB ? tid / 3 : 0, ri = tid % 3;      // residual entry handled by tid < ND
     double* myT = s_T + b * TS;
+    // the two small prefactor jobs (residual rz, dR/dh rh) go to different waves when there are two
+    constexpr bool SPLIT_R = (ND <= 64) && (NT >= 128);
+    const bool do_rz = tid < ND, do_rh = SPLIT_R ? (tid >= 64 && tid - 64 < ND) : (tid < ND);
+    const int hidx = SPLIT_R ? (tid >= 64 && tid - 64 < ND ? tid - 64 : 0) : (tid < ND ? tid : 0), ha = hidx / 3, hi = hidx % 3;
     GF_STAMP(2, tstamp);
 
     for (int gp = 0; gp < NG; ++gp) {
@@ -228,20 +232,22 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_elemen
         GF_STAMP(4, tstamp);
         // -- S2: residual / dR/dh prefactors, T = G phi_b and Hc phi_b; operands of S3 are pulled into
         //    registers here so that S3 only reads T and s_rh and needs no barrier behind it
-        if (tid < ND) {
-            const double p1 = s_phi[ra][0], p2 = s_phi[ra][1];
+        if (do_rz) {
             double rz = 0.0;
             for (int m = 0; m < 5; ++m) rz += s_phi[ra][m] * im[IM_PZ + 3 * m + ri];
-            const double g1i = im[IM_G + ri], g2i = im[IM_G + 3 + ri];
+            accR += wq * (rz - im[IM_J] * Pt.f[ri] * s_phi[ra][5]);
+        }
+        if (do_rh) {
+            const double p1 = s_phi[ha][0], p2 = s_phi[ha][1];
+            const double g1i = im[IM_G + hi], g2i = im[IM_G + 3 + hi];
             double rh = p1 * (im[IM_JCE] * g1i + im[IM_JCE + 2] * g2i) + p2 * (im[IM_JCE + 1] * g2i + im[IM_JCE + 2] * g1i);
             double nn = 0.0;
             for (int k = 0; k < 3; ++k) {
-                rh -= im[IM_JCK4 + k] * (p1 * im[IM_BG + 6 * k + ri] + p2 * im[IM_BG + 6 * k + 3 + ri]);
-                nn += s_phi[ra][2 + k] * im[IM_JCK4 + k] * (k == 2 ? 2.0 : 1.0);
+                rh -= im[IM_JCK4 + k] * (p1 * im[IM_BG + 6 * k + hi] + p2 * im[IM_BG + 6 * k + 3 + hi]);
+                nn += s_phi[ha][2 + k] * im[IM_JCK4 + k] * (k == 2 ? 2.0 : 1.0);
             }
-            rh -= im[IM_N + ri] * nn;
-            accR += wq * (rz - im[IM_J] * Pt.f[ri] * s_phi[ra][5]);
-            s_T[(tid / 5) * TS + (tid % 5) * 16 + 15] = wq * rh;       // dR/dh prefactor parked in the unused q-slot 15 of T
+            rh -= im[IM_N + hi] * nn;
+            s_T[(hidx / 5) * TS + (hidx % 5) * 16 + 15] = wq * rh;     // dR/dh prefactor parked in the unused q-slot 15 of T
         }
         double pb[5], pa[AG][5], pa0[AG];
         for (int m = 0; m < 5; ++m) pb[m] = wq * s_phi[b][m];
