@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix (public spec)
-ALG_BYTES_PER_GP = {2: 448.0, 3: 520.0, 4: 548.0}    # SURVEY.md 8(d); p=2: (1800+1800+600+24+64)/9... see DESIGN.md
+ALG_BYTES_PER_GP = {2: 476.4, 3: 520.0, 4: 548.0}    # (K + 3 dR/dCP + dR/dh CSR values written once + in/out vectors) / (p+1)^2
 ALG_FLOP_PER_GP = {2: 2.6e4, 3: 6.3e4, 4: 1.4e5}     # FMA*2 count of the kernel's formulation, DESIGN.md section 4
 
 
@@ -155,9 +155,9 @@ def main():
             "metric": "element-Gauss-point updates/sec (assembly+adjoint)", "value": value, "unit": "GP-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C4 synthetic %dx%d-patch curved NURBS shell, p=%d, %d spans/side +-2 (non-matching), "
+            "config": {"workload": "%s synthetic %dx%d-patch curved NURBS shell, p=%d, %d spans/side +-2 (non-matching), "
                                    "%d dofs, %d Gauss points, %d mortar points; R+K+dRdCP(3)+dRdh incl. penalty coupling"
-                                   % (args.patches[0], args.patches[1], p, args.nel, 3 * shard.total_cp_global, n_gp_total,
+                                   % ("C4" if (args.patches == [16, 16] and args.nel == 48 and p == 3) else "custom", args.patches[0], args.patches[1], p, args.nel, 3 * shard.total_cp_global, n_gp_total,
                                       sum(i.npts for i in spec.interfaces)),
                        "parallelism": "patch-sharded x%d, owner-computes-rows, all-reduce of the residual" % world},
             "roofline": {"bound": "hbm", "kernel": "kl_element_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -536,8 +536,8 @@ __global__ void pen_energy_kernel(long long npts, const double* __restrict__ pbu
 struct DevPenalty {
     const int* pt_iface; const int* pt_base; const double* pt_nu; const double* pt_tau; const double* pt_wt;
     const int* if_patch; const double* if_alpha;
-    const PenRowItem* row_items; const long long* row_ptr; const PenBlockItem* blk_items; const long long* blk_ptr;
-    long long npts, nrow_groups, nblk_groups;
+    const PenRowItem* row_items; const long long* row_ptr;
+    long long npts, nrow_groups;
 };
 
 // one thread per mortar vertex: kinematics of both sides + pointwise gradient/Hessians -> pbuf

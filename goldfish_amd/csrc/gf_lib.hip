@@ -97,11 +97,11 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         DevPenalty& Q = h->Q;
         Q.npts = H.npts;
         if (H.npts > 0) {
-            std::vector<long long> rp(H.row_ptr.begin(), H.row_ptr.end()), bp(H.blk_ptr.begin(), H.blk_ptr.end());
+            std::vector<long long> rp(H.row_ptr.begin(), H.row_ptr.end());
             Q.pt_iface = h->upload(H.pt_iface); Q.pt_base = h->upload(H.pt_base); Q.pt_nu = h->upload(H.pt_nu);
             Q.pt_tau = h->upload(H.pt_tau); Q.pt_wt = h->upload(H.pt_wt); Q.if_patch = h->upload(H.if_patch); Q.if_alpha = h->upload(H.if_alpha);
-            Q.row_items = h->upload(H.row_items); Q.row_ptr = h->upload(rp); Q.blk_items = h->upload(H.blk_items); Q.blk_ptr = h->upload(bp);
-            Q.nrow_groups = (long long)rp.size() - 1; Q.nblk_groups = (long long)bp.size() - 1;
+            Q.row_items = h->upload(H.row_items); Q.row_ptr = h->upload(rp);
+            Q.nrow_groups = (long long)rp.size() - 1;
             h->d_pbuf = h->dalloc<double>((size_t)H.npts * PB_STRIDE);
             for (const PenRowItem& it : H.row_items)
                 h->pen_maxdeg = std::max(h->pen_maxdeg, (int)(H.nb_ptr_c[it.a + 1] - H.nb_ptr_c[it.a]));

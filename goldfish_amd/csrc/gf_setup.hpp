@@ -31,7 +31,6 @@ struct PatchDev {            // POD mirrored on the device
     double E, nu_, f[3];
 };
 
-struct PenBlockItem { int a, k, b, code, lo, hi; };   // code = iface*4 + s*2 + t ; points [lo,hi] global ids
 struct PenRowItem { int a, code, lo, hi; };           // code = iface*2 + s
 
 inline void gauss_legendre(int n, double* x, double* w) {
@@ -110,7 +109,6 @@ struct HostModel {
     std::vector<int> if_patch; std::vector<double> if_alpha; std::vector<int64_t> if_off;
     // deterministic owner lists
     std::vector<PenRowItem> row_items; std::vector<int64_t> row_ptr;      // groups by CP a
-    std::vector<PenBlockItem> blk_items; std::vector<int64_t> blk_ptr;    // groups by (a,k)
 
     void build(const gf_model_desc* D);
 };
@@ -266,24 +264,13 @@ inline void HostModel::build(const gf_model_desc* D) {
             }
         }
     }
-    // owner lists: rows grouped by CP, blocks grouped by (a, slot k)
+    // owner lists: (interface, side, vertex range) items grouped by owned control point
     {
         std::vector<PenRowItem> rows;
         for (int i = 0; i < ni; ++i) for (int s = 0; s < 2; ++s) for (const CpRange& A : ranges[2 * i + s]) if (A.cp < owned_cp) rows.push_back({A.cp, 2 * i + s, A.lo, A.hi});
         std::stable_sort(rows.begin(), rows.end(), [](const PenRowItem& x, const PenRowItem& y) { return x.a < y.a; });
         row_items = rows; row_ptr.clear(); row_ptr.push_back(0);
         for (size_t k = 1; k <= rows.size(); ++k) if (k == rows.size() || rows[k].a != rows[k - 1].a) row_ptr.push_back((int64_t)k);
-        std::vector<PenBlockItem> blks;
-        for (int i = 0; i < ni; ++i) for (int s = 0; s < 2; ++s) for (int t = 0; t < 2; ++t)
-            for (const CpRange& A : ranges[2 * i + s]) for (const CpRange& B : ranges[2 * i + t])
-                if (A.cp < owned_cp && A.lo <= B.hi && B.lo <= A.hi) {
-                    const int* b0 = &nb_c[nb_ptr_c[A.cp]]; const int* b1 = &nb_c[nb_ptr_c[A.cp + 1]];
-                    const int k = int(std::lower_bound(b0, b1, B.cp) - b0);
-                    blks.push_back({A.cp, k, B.cp, 4 * i + 2 * s + t, std::max(A.lo, B.lo), std::min(A.hi, B.hi)});
-                }
-        std::stable_sort(blks.begin(), blks.end(), [](const PenBlockItem& x, const PenBlockItem& y) { return x.a != y.a ? x.a < y.a : x.k < y.k; });
-        blk_items = blks; blk_ptr.clear(); blk_ptr.push_back(0);
-        for (size_t k = 1; k <= blks.size(); ++k) if (k == blks.size() || blks[k].a != blks[k - 1].a || blks[k].k != blks[k - 1].k) blk_ptr.push_back((int64_t)k);
     }
 }
 
