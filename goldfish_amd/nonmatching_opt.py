@@ -339,4 +339,36 @@ class NonMatchingOptFFD(NonMatchingOpt):
         self.shopt_multiffd = False
 
     def set_shopt_FFD(self, shopt_knotsffd, shopt_cpffd):
-        raise NotImplementedError("FFD block maps are SURVEY.md 8(f) row N2 (next); drive CP_IGA directly")
+        """nonmatching_opt_ffd.py:143-182.  ``shopt_cpffd`` is (l, m, n, >=3) in the igakit order
+        convention; the FFD block has the identity geometric mapping.  Returns the constant sparse map
+        ``shopt_dcpsurf_fedcpffd`` (FFD control points -> homogeneous surface control points of the
+        optimised patches; row a is scaled by the weight w_a because cpFuncs are homogeneous)."""
+        from .utils.ffd_utils import CP_FFD_matrix
+        self.shopt_knotsffd = [np.asarray(k, float) for k in shopt_knotsffd]
+        self.shopt_cpffd = np.asarray(shopt_cpffd, float)
+        self.shopt_cpffd_flat = self.shopt_cpffd[..., 0:3].transpose(2, 1, 0, 3).reshape(-1, 3)
+        self.shopt_ffd_degree = [int(np.sum(k == k[0]) - 1) for k in self.shopt_knotsffd]
+        self.shopt_cpffd_shape = self.shopt_cpffd.shape[0:3]
+        self.shopt_cpffd_size = int(np.prod(self.shopt_cpffd_shape))
+        self.shopt_num_desvars = [self.shopt_cpffd_size for _ in self.opt_field]
+        self.shopt_cpffd_design_dof = [list(range(self.shopt_cpffd_size)) for _ in self.opt_field]
+        self.shopt_cpffd_design_dof_full = [list(d) for d in self.shopt_cpffd_design_dof]
+        cols0 = self._shopt_cols[0]
+        for c in self._shopt_cols[1:]:
+            if not np.array_equal(c, cols0):
+                raise NotImplementedError("set_shopt_FFD: every opt field must optimise the same patches (single FFD block)")
+        w = np.concatenate([s.cp_hom_flat()[:, 3] for s in self.splines])[cols0]
+        X = np.stack([self.cp_iga[f][cols0] / w for f in range(3)], 1)           # physical control points
+        D = CP_FFD_matrix(X, self.shopt_ffd_degree, self.shopt_knotsffd).tocsr()
+        self.shopt_dcpsurf_fedcpffd = sp.diags(w).dot(D).tocoo()
+        self.shopt_init_cpffd_full = [self.shopt_cpffd_flat[:, f].copy() for f in self.opt_field]
+        self.shopt_cpffd_pin_dof = [[] for _ in self.opt_field]
+        self.shopt_align_dir = [None for _ in self.opt_field]
+        return self.shopt_dcpsurf_fedcpffd
+
+    @property
+    def cpsurf_lims(self):
+        """Bounding box of the optimised surfaces' physical control points (reference attribute used to
+        size the FFD block, e.g. om_comps/ffd_comps/cpffd2surf_comp.py:71-75)."""
+        w = np.concatenate([s.cp_hom_flat()[:, 3] for s in self.splines])
+        return [[float((self.cp_iga[f] / w).min()), float((self.cp_iga[f] / w).max())] for f in range(3)]

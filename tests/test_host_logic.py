@@ -92,3 +92,19 @@ def test_no_gpu_means_loud_failure():
     spec = G.tbeam_2patch(4)
     with pytest.raises(RuntimeError):
         _lib.DeviceModel(arrays_from_spec(spec))
+
+
+def test_ffd_block_reproduces_surface_control_points():
+    """N2: the FFD operator of an undeformed block is the identity on the surface control points
+    (reference assumption, GOLDFISH/utils/ffd_utils.py:37-39) and its columns sum to one."""
+    from goldfish_amd.utils.ffd_utils import CP_FFD_matrix, create_3D_block
+    rng = np.random.default_rng(1)
+    X = rng.uniform([-1, 0, -2], [1, 20, 0], (50, 3))
+    blk = create_3D_block([3, 2, 1], 3, [[-1, 1], [0, 20], [-2, 0]])
+    D = CP_FFD_matrix(X, blk.degree, blk.knots).tocsr()
+    q = blk.control[..., 0:3].transpose(2, 1, 0, 3).reshape(-1, 3)       # i + j*l + k*l*m ordering
+    assert D.shape == (50, q.shape[0])
+    assert np.abs(D @ q - X).max() < 1e-12
+    assert np.abs(np.asarray(D.sum(1)).ravel() - 1.0).max() < 1e-12
+    flat = create_3D_block([2, 2, 1], 2, [[0, 1], [0, 1], [0.5, 0.5]])    # degenerate direction gets thickened
+    assert flat.knots[2][-1] > flat.knots[2][0]
