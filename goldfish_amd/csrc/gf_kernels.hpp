@@ -42,8 +42,9 @@ template <int P> __device__ __forceinline__ void bspline6(const double* tu, cons
     const double v0 = tv[(gv * 3 + 0) * P1 + jv], v1 = tv[(gv * 3 + 1) * P1 + jv], v2 = tv[(gv * 3 + 2) * P1 + jv];
     Nb[0] = u0 * v0; Nb[1] = u1 * v0; Nb[2] = u0 * v1; Nb[3] = u2 * v0; Nb[4] = u0 * v2; Nb[5] = u1 * v1;
 }
+// W[0] holds 1/W (the reciprocal is taken once per Gauss point by the caller), W[1..5] the derivatives of W
 __device__ __forceinline__ void rationalize6(const double* Nb, const double* W, double* R) {
-    const double iW = 1.0 / W[0];
+    const double iW = W[0];
     R[0] = Nb[0] * iW;
     R[1] = (Nb[1] - R[0] * W[1]) * iW; R[2] = (Nb[2] - R[0] * W[2]) * iW;
     R[3] = (Nb[3] - 2 * R[1] * W[1] - R[0] * W[3]) * iW;
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_elemen
         const int gu = tid % P1, gv = tid / P1;
         double W[6] = {0, 0, 0, 0, 0, 0}, Nb[6], R[6];
         for (int a = 0; a < NB; ++a) { bspline6<P>(s_tu, s_tv, gu, gv, a, Nb); for (int k = 0; k < 6; ++k) W[k] += Nb[k] * s_w[a]; }
+        W[0] = 1.0 / W[0];
         double z[15], Z[15], t = 0.0;
         for (int k = 0; k < 15; ++k) { z[k] = 0.0; Z[k] = 0.0; }
         for (int a = 0; a < NB; ++a) {
@@ -462,6 +464,7 @@ __global__ __launch_bounds__(64) void kl_functional_kernel(DevModel M, int e_fir
         const int gu = tid % P1, gv = tid / P1;
         double W[6] = {0, 0, 0, 0, 0, 0}, Nb[6], R[6];
         for (int a = 0; a < NB; ++a) { bspline6<P>(s_tu, s_tv, gu, gv, a, Nb); for (int k = 0; k < 6; ++k) W[k] += Nb[k] * s_w[a]; }
+        W[0] = 1.0 / W[0];
         double z[15], Z[15], t = 0.0;
         for (int k = 0; k < 15; ++k) { z[k] = 0.0; Z[k] = 0.0; }
         for (int a = 0; a < NB; ++a) {

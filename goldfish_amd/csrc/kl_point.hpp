@@ -19,7 +19,7 @@ namespace gf {
 // ---- layout of the per-Gauss-point intermediate record (doubles) -------------------
 enum : int {
     IM_J = 0, IM_WQ = 1,
-    IM_W = 2,        // [6]  W and its parametric derivatives (for the rational basis)
+    IM_W = 2,        // [6]  1/W, then the five parametric derivatives of W (for the rational basis)
     IM_G = 8,        // [6]  g1, g2
     IM_N = 14,       // [3]  deformed unit normal
     IM_NB = 17,      // [3]  reference unit normal
