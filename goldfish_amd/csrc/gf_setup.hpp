@@ -230,10 +230,22 @@ inline void HostModel::build(const gf_model_desc* D) {
         }
     }
     // coupling partners per CP and the block / row owner lists
+    // two control points couple iff some mortar vertex has both in its support windows (the ranges are
+    // only bounding ranges when an intersection curve is not monotone in the control net)
+    auto in_window = [&](int64_t v, int itf, int sd, int cp) {
+        const PatchDev& P = patches[if_patch[2 * itf + sd]];
+        const int l = int(cp - P.cp_off), di = l % P.nu - pt_base[4 * v + 2 * sd], dj = l / P.nu - pt_base[4 * v + 2 * sd + 1];
+        return di >= 0 && di <= P.p && dj >= 0 && dj <= P.q;
+    };
+    auto cosupport = [&](int itf, int s, const CpRange& A, int t, const CpRange& B) {
+        for (int64_t v = std::max(A.lo, B.lo); v <= std::min(A.hi, B.hi); ++v)
+            if (in_window(v, itf, s, A.cp) && in_window(v, itf, t, B.cp)) return true;
+        return false;
+    };
     std::vector<std::vector<int>> extra(total_cp);
     for (int i = 0; i < ni; ++i) for (int s = 0; s < 2; ++s) for (int t = 0; t < 2; ++t)
         for (const CpRange& A : ranges[2 * i + s]) for (const CpRange& B : ranges[2 * i + t])
-            if (A.lo <= B.hi && B.lo <= A.hi) extra[A.cp].push_back(B.cp);
+            if (A.lo <= B.hi && B.lo <= A.hi && cosupport(i, s, A, t, B)) extra[A.cp].push_back(B.cp);
     nb_ptr_s.assign(total_cp + 1, 0); nb_ptr_c.assign(total_cp + 1, 0);
     std::vector<int> box;
     for (int pass = 0; pass < 2; ++pass) {

@@ -137,6 +137,32 @@ def plate_6patch(p=3):
     return ProblemSpec(patches, itfs, 68e9, 0.35, 1.0e-2, bf, [], 1.0e3, "plate_6patch")
 
 
+def wing_16patch_from_interface_data(int_data, nel=10, p=3, seed=SEED):
+    """C3 of BASELINE.json: 16 bicubic patches coupled through the interface graph and the
+    parametric intersection curves of the reference's ``wing_int_data.npz`` (name2 = mapping_list, name4 =
+    per-side parametric coordinates of the mortar vertices, 62 interfaces incl. surface-edge T junctions).
+    The true wing geometry needs pythonOCC + the IGES file (out of scope), so the patches are synthetic
+    smooth sheets: the penalty then couples the reference's parametric curves on non-coincident surfaces,
+    which is physically meaningless but exercises exactly the general-curve code paths (interior curves,
+    many interfaces per control point) with real data.  Used as a parity-test case."""
+    rng = np.random.default_rng(seed + 3)
+    mapping = np.asarray(int_data["name2"], int)
+    npatch = int(mapping.max()) + 1
+    patches = []
+    for s in range(npatch):
+        ne = (int(nel + rng.integers(-2, 3)), int(nel + rng.integers(-2, 3)))
+        x0, y0, amp, ph = 1.1 * (s % 4), 1.1 * (s // 4), rng.uniform(0.02, 0.08), rng.uniform(0, 2 * np.pi)
+
+        def surf(S, T, x0=x0, y0=y0, amp=amp, ph=ph):
+            return x0 + S, y0 + T, amp * np.sin(np.pi * S + ph) * np.cos(np.pi * T)
+        patches.append(NURBSPatch.from_function(surf, ne[0], ne[1], p))
+    for f in range(3):
+        patches[0].add_zero_dofs(f, patches[0].get_side_dofs(0, 0, 2))
+    itfs = [Interface(int(a), int(b), np.asarray(int_data["name4"][i][0], float), np.asarray(int_data["name4"][i][1], float))
+            for i, (a, b) in enumerate(mapping)]
+    return ProblemSpec(patches, itfs, 68e9, 0.35, 2.0e-3, [[0.0, 0.0, -50.0]] * npatch, [], 1.0e3, "wing_16patch_refdata")
+
+
 def _grid_interfaces(nx, ny, nels, mult=3):
     """Edge-edge interfaces of an nx x ny patch grid, patch index = ix + iy*nx;
     mortar_nel = mult*(nel_a + nel_b) (tests/test_slr.py:124-125)."""

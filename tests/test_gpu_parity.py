@@ -1,6 +1,8 @@
 """GPU parity tests proper: libgoldfish_hip.so (through the C ABI) vs the CPU oracle on the
 same seeded inputs.  FP64 tolerance 1e-10 relative (BASELINE.json north_star); only
 summation order differs, observed ~1e-14."""
+import os
+
 import numpy as np
 import pytest
 
@@ -30,6 +32,10 @@ CASES = {
     "tbeam2_p2": lambda: G.tbeam_2patch(4, p=2),
     "shell3x2_p3": lambda: G.synthetic_shell(3, 2, nel=5, p=3, jitter=1),
     "shell2x2_p4": lambda: G.synthetic_shell(2, 2, nel=4, p=4, jitter=1),
+    "C2_tbeam4_10kdof": lambda: G.tbeam_4patch(),
+    "C3_wing16_refdata": lambda: G.wing_16patch_from_interface_data(
+        np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_wing_int_data.npz"), allow_pickle=True)),
+    "C5_fuselage3x2_p4": lambda: G.synthetic_fuselage(3, 2, nel=6, p=4, jitter=1),
 }
 
 
