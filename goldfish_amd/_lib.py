@@ -18,7 +18,7 @@ BUF_CP, BUF_U, BUF_H, BUF_R, BUF_VAL_K, BUF_VAL_C0, BUF_VAL_C1, BUF_VAL_C2, BUF_
 EXPORTS = ["gf_device_count", "gf_last_error", "gf_create", "gf_destroy", "gf_total_cp", "gf_num_dofs",
            "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes", "gf_set_cp",
            "gf_set_thickness", "gf_set_u", "gf_nnz", "gf_pattern", "gf_assemble", "gf_sync", "gf_get_residual",
-           "gf_get_values", "gf_apply", "gf_functionals", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms"]
+           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms"]
 
 
 def lib():
@@ -49,6 +49,7 @@ def lib():
         L.gf_get_values.argtypes = [vp, C.c_int, dp, i64]
         L.gf_apply.argtypes = [vp, C.c_int, C.c_int, dp, i64, dp, i64]
         L.gf_functionals.argtypes = [vp, dp, dp, dp, dp, dp, dp, C.c_int]
+        L.gf_compliance.argtypes = [vp, dp, i64, dp, dp, dp, C.c_int]
         L.gf_device_ptr.restype = vp
         L.gf_device_ptr.argtypes = [vp, C.c_int]
         L.gf_apply_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp]
@@ -160,6 +161,12 @@ class DeviceModel:
                                     _dp(g["dVdcp"]), _dp(g["dVdh"]), int(apply_bcs)))
         g.update(Wint=out[0], volume=out[1], Wpen=out[2])
         return g
+
+    def compliance(self, forces, apply_bcs=True):
+        f = np.ascontiguousarray(forces, dtype=np.float64).ravel()
+        out, dCdu, dCdcp = np.zeros(1), np.zeros(self.ndof), np.zeros((3, self.total_cp))
+        _check(lib().gf_compliance(self.h, _dp(f), f.size, _dp(out), _dp(dCdu), _dp(dCdcp), int(apply_bcs)), ValueError)
+        return dict(C=out[0], dCdu=dCdu, dCdcp=dCdcp)
 
     def kernel_ms(self):
         n = C.c_int(0)

@@ -501,6 +501,68 @@ __global__ __launch_bounds__(64) void kl_functional_kernel(DevModel M, int e_fir
     }
 }
 
+// Compliance C = sum int f . u_hom dA (homogeneous displacement function, compliance_exop.py:24-26) and its
+// gradients; same block layout as kl_functional_kernel: slots 0-2 dC/du, 6-8 dC/dc, We = C_e (3-5, 9, 10 zero).
+template <int P>
+__global__ __launch_bounds__(64) void kl_compliance_kernel(DevModel M, int e_first, const double* __restrict__ forces, double* __restrict__ blk, size_t blk_stride) {
+    constexpr int P1 = P + 1, NB = P1 * P1, NG = NB, ND = 3 * NB;
+    const int tid = threadIdx.x;
+    const long long e = (long long)e_first + blockIdx.x;
+    if (e >= M.nelem) return;
+    const int pid = M.elem_patch[e];
+    const PatchDev& Pt = M.patches[pid];
+    const int le = int(e - Pt.elem_off), eu = le % Pt.nelu, ev = le / Pt.nelu;
+    const int iu0 = M.ints[Pt.spu + eu] - P, iv0 = M.ints[Pt.spv + ev] - P;
+    const double f0 = forces[3 * pid], f1 = forces[3 * pid + 1], f2 = forces[3 * pid + 2];
+    __shared__ double s_c[NB][3], s_u[NB][3], s_w[NB];
+    __shared__ double s_tu[P1 * 3 * P1], s_tv[P1 * 3 * P1], s_wg[2 * P1];
+    __shared__ double s_g[NG][12];          // wq*J, wq*(f.u_hom), J1[3], J2[3], 1/W, W_1, W_2
+    if (tid < NB) {
+        const long long g = Pt.cp_off + (iu0 + tid % P1) + (long long)(iv0 + tid / P1) * Pt.nu;
+        for (int k = 0; k < 3; ++k) { s_c[tid][k] = M.cp4[4 * g + k]; s_u[tid][k] = M.u[3 * g + k]; }
+        s_w[tid] = M.cp4[4 * g + 3];
+    }
+    for (int k = tid; k < P1 * 3 * P1; k += 64) { s_tu[k] = M.tab[Pt.tabu + eu * P1 * 3 * P1 + k]; s_tv[k] = M.tab[Pt.tabv + ev * P1 * 3 * P1 + k]; }
+    if (tid < P1) { s_wg[tid] = M.tab[Pt.wu + eu * P1 + tid]; s_wg[P1 + tid] = M.tab[Pt.wv + ev * P1 + tid]; }
+    __syncthreads();
+    if (tid < NG) {
+        const int gu = tid % P1, gv = tid / P1;
+        double W[6] = {0, 0, 0, 0, 0, 0}, Nb[6], R[6];
+        for (int a = 0; a < NB; ++a) { bspline6<P>(s_tu, s_tv, gu, gv, a, Nb); for (int k = 0; k < 6; ++k) W[k] += Nb[k] * s_w[a]; }
+        W[0] = 1.0 / W[0];
+        double G1[3] = {0, 0, 0}, G2[3] = {0, 0, 0}, Uh[3] = {0, 0, 0};
+        for (int a = 0; a < NB; ++a) {
+            bspline6<P>(s_tu, s_tv, gu, gv, a, Nb); rationalize6(Nb, W, R);
+            for (int k = 0; k < 3; ++k) { G1[k] += R[1] * s_c[a][k]; G2[k] += R[2] * s_c[a][k]; Uh[k] += Nb[0] * s_u[a][k]; }
+        }
+        double Nt[3]; cross3(G1, G2, Nt);
+        const double J = sqrt(dot3(Nt, Nt)), wq = s_wg[gu] * s_wg[P1 + gv];
+        const double Nn[3] = {Nt[0] / J, Nt[1] / J, Nt[2] / J};
+        double J1[3], J2[3]; cross3(G2, Nn, J1); cross3(Nn, G1, J2);
+        const double fu = f0 * Uh[0] + f1 * Uh[1] + f2 * Uh[2];
+        s_g[tid][0] = wq * J; s_g[tid][1] = wq * fu;
+        for (int k = 0; k < 3; ++k) { s_g[tid][2 + k] = J1[k]; s_g[tid][5 + k] = J2[k]; }
+        s_g[tid][8] = W[0]; s_g[tid][9] = W[1]; s_g[tid][10] = W[2]; s_g[tid][11] = J * fu * wq;
+    }
+    __syncthreads();
+    double* out = blk + (size_t)blockIdx.x * blk_stride;
+    for (int w = tid; w < ND; w += 64) {
+        const int a = w / 3, i = w - 3 * a;
+        const double fi = i == 0 ? f0 : (i == 1 ? f1 : f2);
+        double du = 0.0, dc = 0.0;
+        for (int gp = 0; gp < NG; ++gp) {
+            double Nb[6];
+            bspline6<P>(s_tu, s_tv, gp % P1, gp / P1, a, Nb);
+            const double iW = s_g[gp][8], R0 = Nb[0] * iW, R1 = (Nb[1] - R0 * s_g[gp][9]) * iW, R2 = (Nb[2] - R0 * s_g[gp][10]) * iW;
+            du += s_g[gp][0] * fi * Nb[0];
+            dc += s_g[gp][1] * (s_g[gp][2 + i] * R1 + s_g[gp][5 + i] * R2);
+        }
+        out[a * 11 + i] = du; out[a * 11 + 3 + i] = 0.0; out[a * 11 + 6 + i] = dc;
+        if (i == 0) { out[a * 11 + 9] = 0.0; out[a * 11 + 10] = 0.0; }
+    }
+    if (tid == 0) { double Ce = 0.0; for (int gp = 0; gp < NG; ++gp) Ce += s_g[gp][11]; out[NB * 11] = Ce; out[NB * 11 + 1] = 0.0; }
+}
+
 // one thread per owned control point: ordered sum over its elements.  fun: [dWdu ndof | dWdcp 3*tcp | dWdh tcp | dVdcp 3*tcp | dVdh tcp]
 template <int P>
 __global__ __launch_bounds__(256) void kl_fgather_kernel(DevModel M, long long a_first, long long a_end, long long e_first, long long e_count, int apply_bcs,

@@ -29,7 +29,7 @@ struct gf_handle {
     double *d_cp4 = nullptr, *d_u = nullptr, *d_h = nullptr, *d_R = nullptr, *d_blk = nullptr, *d_pbuf = nullptr;
     double* d_val[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double *d_x = nullptr, *d_y = nullptr;           // staging for host-pointer gf_apply / per-element partial sums
-    double *d_fun = nullptr, *d_pen_en = nullptr;    // functional gradients [11*total_cp], penalty energies [npts]
+    double *d_fun = nullptr, *d_pen_en = nullptr, *d_ve = nullptr;    // functional gradients [11*total_cp], penalty energies [npts]
     long long* d_pl_dof = nullptr; double* d_pl_val = nullptr;
     std::vector<Chunk> chunks;
     std::vector<hipEvent_t> ev0, ev1; int ev_n = 0;   // element-kernel timing
@@ -91,7 +91,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         HIPCHK(hipMemset(h->d_val[GF_MAT_DRDH], 0, 3 * nnzs * sizeof(double)));
         HIPCHK(hipMemset(h->d_R, 0, H.ndof * sizeof(double)));
         h->d_x = h->dalloc<double>(H.ndof); h->d_y = h->dalloc<double>(H.ndof);
-        h->d_fun = h->dalloc<double>(11 * H.total_cp); h->d_pen_en = h->dalloc<double>(H.npts);
+        h->d_fun = h->dalloc<double>(11 * H.total_cp); h->d_pen_en = h->dalloc<double>(H.npts); h->d_ve = h->dalloc<double>(H.nelem);
         HIPCHK(hipMemset(h->d_fun, 0, 11 * H.total_cp * sizeof(double)));
         // penalty
         DevPenalty& Q = h->Q;
@@ -251,6 +251,19 @@ template <int P> static void run_functionals(gf_handle* h, int apply_bcs) {
     HIPCHK(hipGetLastError());
 }
 
+template <int P> static void run_compliance(gf_handle* h, int apply_bcs) {
+    const size_t stride = (size_t)FunCfg<P>::STRIDE;
+    // forces were staged in d_y; the per-element partials of kl_fgather_kernel go to d_x (C_e) and d_fun + 0 (unused V_e slot reuses d_pen_en-safe d_x tail)
+    double* d_forces = h->d_y;
+    for (const Chunk& c : h->chunks) {
+        const long long ne = c.e1 - c.e0, na = c.a1 - c.a0, nthr = std::max(ne, na);
+        hipLaunchKernelGGL(kl_compliance_kernel<P>, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, d_forces, h->d_blk, stride);
+        hipLaunchKernelGGL(kl_fgather_kernel<P>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, apply_bcs,
+                           h->d_blk, stride, h->d_fun, h->d_x, h->d_ve);
+    }
+    HIPCHK(hipGetLastError());
+}
+
 extern "C" {
 
 int gf_assemble(gf_handle* h, int flags) {
@@ -343,6 +356,31 @@ double gf_kernel_ms(gf_handle* h, int* n_launches) {
     if (n_launches) *n_launches = n;
     h->ev_n = 0;
     return n > 0 ? tot / n : 0.0;
+}
+
+int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, double* dCdu, double* dCdcp, int apply_bcs) {
+    if (!h || !forces || !C) return fail("gf_compliance: null argument");
+    if (nf != 3 * (int64_t)h->H.np) return fail("gf_compliance: forces must hold 3 values per patch");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipMemcpyAsync(h->d_y, forces, nf * sizeof(double), hipMemcpyHostToDevice, h->stream));   // d_y: >= 3*n_patches doubles
+        switch (h->H.degree) {
+            case 2: run_compliance<2>(h, apply_bcs); break;
+            case 3: run_compliance<3>(h, apply_bcs); break;
+            case 4: run_compliance<4>(h, apply_bcs); break;
+            default: throw std::runtime_error("gf_compliance: unsupported degree");
+        }
+        const HostModel& H = h->H; const long long T = H.total_cp;
+        std::vector<double> ce(H.nelem);
+        HIPCHK(hipMemcpyAsync(ce.data(), h->d_x, H.nelem * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (dCdu) HIPCHK(hipMemcpyAsync(dCdu, h->d_fun, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (dCdcp) HIPCHK(hipMemcpyAsync(dCdcp, h->d_fun + 7 * T, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const long long e_end = H.n_owned < H.np ? H.patches[H.n_owned].elem_off : H.nelem;
+        long double acc = 0; for (long long e = 0; e < e_end; ++e) acc += ce[e];
+        *C = (double)acc;
+    } catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
 }
 
 #ifdef GF_STAMPS

@@ -90,6 +90,10 @@ int gf_apply(gf_handle* h, int which, int transpose, const double* x, int64_t nx
 int gf_functionals(gf_handle* h, double out[3], double* dWdu, double* dWdcp, double* dWdh,
                    double* dVdcp, double* dVdh, int apply_bcs);
 
+/* ComplianceExOperation.cpl/dcplduIGA/dcpldCPIGA (operations/compliance_exop.py:50-99): C = sum_s int forces[s] . u_hom dA
+ * with forces = 3 values per patch; dCdu [ndof] (Dirichlet rows zeroed when apply_bcs), dCdcp 3 arrays of total_cp. */
+int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, double* dCdu, double* dCdcp, int apply_bcs);
+
 /* borrowed device pointer to one of the GF_BUF_* buffers (for zero-copy users: bench, RCCL exchange) */
 void* gf_device_ptr(gf_handle* h, int which);
 /* y_dev += A x_dev on device pointers (no host copies, asynchronous) */

@@ -655,6 +655,44 @@ void gfo_set_num_threads(int n) {
     (void)n;
 #endif
 }
+/* ComplianceExOperation (operations/compliance_exop.py:21-48): C = sum_s int forces[s] . u_hom dA with the
+ * homogeneous (non-rationalised) displacement function; dC/du, dC/dCP_f.  forces: [3*n_patches]. */
+void gfo_compliance(const gfo_model* M, const double* forces, double* Cout, double* dCdu, double* dCdcp0, double* dCdcp1, double* dCdcp2, int apply_bcs) {
+    double* dC[3] = {dCdcp0, dCdcp1, dCdcp2}; double Ctot = 0;
+    if (dCdu) memset(dCdu, 0, sizeof(double) * M->ndof);
+    for (int f = 0; f < 3; ++f) if (dC[f]) memset(dC[f], 0, sizeof(double) * M->total_cp);
+    for (int s = 0; s < M->np; ++s) {
+        const patch_t* P = &M->P[s]; const int p = P->p, q = P->q, nb = (p + 1) * (q + 1); const double* fs = forces + 3 * s;
+        for (int ev = 0; ev < P->nelv; ++ev) for (int eu = 0; eu < P->nelu; ++eu) {
+            const int iu0 = P->spanu[eu] - p, iv0 = P->spanv[ev] - q; int64_t gid[MAXNB]; double wl[MAXNB];
+            for (int jv = 0; jv <= q; ++jv) for (int ju = 0; ju <= p; ++ju) { int a = ju + jv * (p + 1); gid[a] = P->cp_off + (iu0 + ju) + (int64_t)(iv0 + jv) * P->nu; wl[a] = M->w[gid[a]]; }
+            for (int gv = 0; gv < P->ngv; ++gv) for (int gu = 0; gu < P->ngu; ++gu) {
+                const double* tu = P->bu + (size_t)((eu * P->ngu + gu) * 3) * (p + 1); const double* tv = P->bv + (size_t)((ev * P->ngv + gv) * 3) * (q + 1);
+                const double wq = P->wu[eu * P->ngu + gu] * P->wv[ev * P->ngv + gv];
+                double Nb[6][MAXNB], Rb[6][MAXNB];
+                for (int jv = 0; jv <= q; ++jv) for (int ju = 0; ju <= p; ++ju) {
+                    int a = ju + jv * (p + 1);
+                    double u0 = tu[ju], u1 = tu[(p + 1) + ju], u2 = tu[2 * (p + 1) + ju], v0 = tv[jv], v1 = tv[(q + 1) + jv], v2 = tv[2 * (q + 1) + jv];
+                    Nb[0][a] = u0 * v0; Nb[1][a] = u1 * v0; Nb[2][a] = u0 * v1; Nb[3][a] = u2 * v0; Nb[4][a] = u0 * v2; Nb[5][a] = u1 * v1;
+                }
+                rationalize(nb, Nb, wl, Rb);
+                double G1[3] = {0, 0, 0}, G2[3] = {0, 0, 0}, Uh[3] = {0, 0, 0};
+                for (int a = 0; a < nb; ++a) for (int k = 0; k < 3; ++k) { G1[k] += Rb[1][a] * M->cp[3 * gid[a] + k]; G2[k] += Rb[2][a] * M->cp[3 * gid[a] + k]; Uh[k] += Nb[0][a] * M->u[3 * gid[a] + k]; }
+                double Nt[3]; cross3(G1, G2, Nt); const double J = sqrt(dot3(Nt, Nt)); double Nn[3] = {Nt[0] / J, Nt[1] / J, Nt[2] / J}, J1[3], J2[3];
+                cross3(G2, Nn, J1); cross3(Nn, G1, J2);
+                const double fu = dot3(fs, Uh);
+                Ctot += wq * J * fu;
+                for (int a = 0; a < nb; ++a) for (int k = 0; k < 3; ++k) {
+                    if (dCdu) dCdu[3 * gid[a] + k] += wq * J * fs[k] * Nb[0][a];
+                    if (dC[k]) dC[k][gid[a]] += wq * fu * (J1[k] * Rb[1][a] + J2[k] * Rb[2][a]);
+                }
+            }
+        }
+    }
+    if (dCdu && apply_bcs) for (int64_t r = 0; r < M->ndof; ++r) if (M->zero[r]) dCdu[r] = 0;
+    *Cout = Ctot;
+}
+
 int gfo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -48,6 +48,7 @@ def lib():
         L.gfo_functionals.argtypes = [C.c_void_p, dp] + [dp] * 9 + [C.c_int]
         L.gfo_penalty_point.argtypes = [dp, dp, dp, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp]
         L.gfo_eval_point.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, dp, dp]
+        L.gfo_compliance.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp, C.c_int]
         L.gfo_num_threads.restype = C.c_int
         L.gfo_set_num_threads.argtypes = [C.c_int]
         _LIB = L
@@ -136,6 +137,13 @@ class Oracle:
                               *[_dp(x) for x in g["dVdcp"]], _dp(g["dVdh"]), int(apply_bcs))
         g.update(Wint=out[0], volume=out[1], Wpen=out[2])
         return g
+
+    def compliance(self, forces, apply_bcs=True):
+        f = np.ascontiguousarray(forces, float).ravel()
+        out, dCdu = np.zeros(1), np.zeros(self.ndof)
+        dCdcp = [np.zeros(self.total_cp) for _ in range(3)]
+        lib().gfo_compliance(self.h, _dp(f), _dp(out), _dp(dCdu), *[_dp(x) for x in dCdcp], int(apply_bcs))
+        return dict(C=out[0], dCdu=dCdu, dCdcp=dCdcp)
 
     def eval_point(self, patch, xi):
         X, U = np.zeros(3), np.zeros(3)

@@ -50,6 +50,36 @@ def test_functionals_parity(oracle_lib):
     D.close()
 
 
+def test_compliance_parity_and_comp(oracle_lib):
+    from goldfish_amd import _lib
+    from goldfish_amd.om_comps import ComplianceComp, om
+    from oracle.oracle_py import Oracle
+    spec = G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2])
+    rng = np.random.default_rng(2)
+    A = arrays_from_spec(spec)
+    h, u = np.full(A.total_cp, spec.h_th), 2e-2 * rng.standard_normal(A.ndof)
+    forces = rng.standard_normal((9, 3))
+    O, D = Oracle(A, thickness=h, u=u), _lib.DeviceModel(A)
+    D.set_thickness(h)
+    D.set_u(u)
+    for bcs in (True, False):
+        Cd, Co = D.compliance(forces, apply_bcs=bcs), O.compliance(forces, apply_bcs=bcs)
+        assert abs(Cd["C"] - Co["C"]) < 1e-11 * abs(Co["C"])
+        assert _rel(Cd["dCdu"], Co["dCdu"]) < 1e-10
+        for f in range(3):
+            assert _rel(Cd["dCdcp"][f], Co["dCdcp"][f]) < 1e-10
+    with pytest.raises(ValueError):
+        D.compliance(np.zeros(5))
+    D.close()
+    spec, th, nm = _problem()
+    comp = ComplianceComp(nonmatching_opt=nm, forces=[[0.0, 0.0, 1.0]] * 2)
+    comp.init_parameters()
+    prob = om.Problem(model=comp)
+    prob.setup()
+    prob.run_model()
+    assert max(prob.check_partials(compact_print=False).values()) < 1e-6
+
+
 def test_nonmatching_opt_surface(oracle_lib):
     from oracle.oracle_py import Oracle
     spec, th, nm = _problem()

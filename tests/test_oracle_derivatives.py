@@ -97,6 +97,14 @@ def test_functionals_vs_autograd(oracle_lib):
     assert _relerr(F["dVdh"], gh.numpy()) < RTOL
     Wp = T.penalty_energy(c, U)
     assert abs(F["Wpen"] - Wp.item()) < 1e-11 * abs(Wp.item())
+    forces = np.random.default_rng(7).standard_normal((len(spec.patches), 3))
+    Cg = O.compliance(forces, apply_bcs=False)
+    Ct = T.compliance(c, U, forces)
+    gU, gc = torch.autograd.grad(Ct, (U, c))
+    assert abs(Cg["C"] - Ct.item()) < 1e-12 * abs(Ct.item())
+    assert _relerr(Cg["dCdu"], gU.numpy().ravel()) < RTOL
+    for f in range(3):
+        assert _relerr(Cg["dCdcp"][f], gc.numpy()[:, f]) < RTOL
 
 
 def test_penalty_point_hessians(oracle_lib):

@@ -103,6 +103,13 @@ class TorchModel:
         t = (self.N0 * h[self.ids]).sum(-1)
         return (self.wq * ke.area_jacobian(Z) * t).sum()
 
+    def compliance(self, c, U, forces):
+        """C = sum int forces . u_hom dA with the non-rationalised displacement function."""
+        Z = torch.einsum("gma,gak->gmk", self.Rb[:, 1:], c[self.ids])
+        uh = torch.einsum("ga,gak->gk", self.N0, U[self.ids])
+        f = torch.tensor(np.asarray(forces, float).reshape(-1, 3))[self.pid]
+        return (self.wq * ke.area_jacobian(Z) * (f * uh).sum(-1)).sum()
+
     def penalty_energy(self, c, U):
         W = torch.zeros((), dtype=torch.float64)
         for ia, RA, ib, RB, tau, ad, ar, wt in self.mp:
