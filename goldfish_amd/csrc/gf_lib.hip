@@ -315,7 +315,9 @@ int gf_apply_dev(gf_handle* h, int which, int transpose, const double* x, double
     const long long* ptr = which == GF_MAT_DRDH ? h->M.nb_ptr_s : h->M.nb_ptr_c; const int* nb = which == GF_MAT_DRDH ? h->M.nb_s : h->M.nb_c;
     const int bw = which == GF_MAT_K ? 3 : 1; const long long nrows = h->H.ndof;
     const unsigned grid = (unsigned)((nrows * 64 + 255) / 256);
-    if (!transpose) hipLaunchKernelGGL(csr_apply_kernel, dim3(grid), dim3(256), 0, h->stream, nrows, ptr, nb, bw, h->d_val[which], x, y);
+    // K is symmetric including its Dirichlet treatment (rows+cols zeroed, unit diagonal): K^T x = K x, so the
+    // transposed product uses the atomic-free row kernel as well (bitwise reproducible adjoint products with K)
+    if (!transpose || which == GF_MAT_K) hipLaunchKernelGGL(csr_apply_kernel, dim3(grid), dim3(256), 0, h->stream, nrows, ptr, nb, bw, h->d_val[which], x, y);
     else hipLaunchKernelGGL(csr_apply_t_kernel, dim3(grid), dim3(256), 0, h->stream, nrows, ptr, nb, bw, h->d_val[which], x, y);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("gf_apply: ") + hipGetErrorString(e));

@@ -171,9 +171,17 @@ inline void HostModel::build(const gf_model_desc* D) {
         if (D->zero_dofs[k] < 0 || D->zero_dofs[k] >= ndof) throw std::runtime_error("gf_create: zero_dofs out of range");
         zero[D->zero_dofs[k]] = 1;
     }
-    for (int64_t k = 0; k < D->n_point_loads; ++k) {
-        if (D->pl_dof[k] < 0 || D->pl_dof[k] >= ndof) throw std::runtime_error("gf_create: pl_dof out of range");
-        pl_dof.push_back(D->pl_dof[k]); pl_val.push_back(D->pl_val[k]);
+    {   // point loads: duplicates summed here (fixed order) so that the device applies one value per dof
+        std::vector<std::pair<int64_t, double>> pl;
+        for (int64_t k = 0; k < D->n_point_loads; ++k) {
+            if (D->pl_dof[k] < 0 || D->pl_dof[k] >= ndof) throw std::runtime_error("gf_create: pl_dof out of range");
+            pl.push_back({D->pl_dof[k], D->pl_val[k]});
+        }
+        std::stable_sort(pl.begin(), pl.end(), [](const std::pair<int64_t, double>& a, const std::pair<int64_t, double>& b) { return a.first < b.first; });
+        for (const auto& e : pl) {
+            if (!pl_dof.empty() && pl_dof.back() == e.first) pl_val.back() += e.second;
+            else { pl_dof.push_back(e.first); pl_val.push_back(e.second); }
+        }
     }
 
     // ---- mortar points ------------------------------------------------------------
