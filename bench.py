@@ -132,6 +132,28 @@ def main():
     if exchange:       # the exchanged global residual must equal the library's own copy of the owned rows
         g0, g1 = shard.owned_global_range(3)
         assert np.array_equal(R_glob[g0:g1].cpu().numpy(), D.residual()[:g1 - g0]) or world > 1
+    # the HBM-bound phase of the path: apply_linear = block-CSR SpMV on the assembled K
+    # (DispImOpeartion.apply_linear_fwd, disp_imop.py:58-72), device pointers, HIP events on torch's stream are
+    # not used: the library's own stream is timed by wall clock around a synchronised batch
+    apply = None
+    if rank == 0:
+        xk = torch.ones(A.ndof, dtype=torch.float64, device="cuda")
+        yk = torch.zeros(A.ndof, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        L = _lib.lib()
+        for _ in range(3):
+            L.gf_apply_dev(D.h, _lib.MAT_K, 0, xk.data_ptr(), yk.data_ptr())
+        D.sync()
+        ta = time.perf_counter()
+        nrep = 20
+        for _ in range(nrep):
+            L.gf_apply_dev(D.h, _lib.MAT_K, 0, xk.data_ptr(), yk.data_ptr())
+        D.sync()
+        ta = (time.perf_counter() - ta) / nrep
+        nnzK = L.gf_nnz(D.h, _lib.MAT_K)
+        byt = nnzK * 8.0 + (nnzK / 9.0) * 4.0 + 3 * A.ndof * 8.0       # values + block column ids + x, y(read+write)
+        apply = {"kernel": "csr_apply_kernel (K x)", "bound": "hbm", "ms": 1e3 * ta, "algorithmic_bytes": byt,
+                 "achieved": byt / ta / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / ta / 1e9 / HBM_PEAK_GBS}
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -168,6 +190,7 @@ def main():
                               "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "note": "the tangent / shape-Jacobian contraction is FP64-VALU bound (SURVEY.md 8(d)); "
                                       "this is the binding roofline of the dominant kernel"},
+            "apply_linear_roofline": apply,
             "device_bytes": D.device_bytes,
         }
         out["roofline_fp64"]["frac"] = out["roofline_fp64"]["achieved"] / FP64_PEAK_TFLOPS

@@ -739,19 +739,32 @@ __global__ void zero_rows_kernel(long long ndof, const unsigned char* zero, doub
 }
 
 // ------------------------------------------------------------------------------------------ apply
-// y += A x, one wave per dof row.  bw = 3 (K: block columns) or 1 (dR/dCP, dR/dh).
-__global__ __launch_bounds__(256) void csr_apply_kernel(long long nrows, const long long* nb_ptr, const int* nb, int bw, const double* __restrict__ val,
-                                                         const double* __restrict__ x, double* __restrict__ y) {
-    const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+// y += A x, one wave per control point a (its three dof rows share one pass over the neighbour list and
+// the x gathers; every lane has up to nine independent, lane-contiguous value loads in flight).
+// BW = 3: K (block columns 3*nb + j), BW = 1: dR/dCP, dR/dh (columns nb).  Fixed reduction order.
+template <int BW>
+__global__ __launch_bounds__(256) void csr_apply_kernel(long long ncp, const long long* __restrict__ nb_ptr, const int* __restrict__ nb,
+                                                         const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y) {
+    const long long a = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (row >= nrows) return;
-    const long long a = row / 3; const int i = int(row - 3 * a);
-    const long long ptr = nb_ptr[a], deg = nb_ptr[a + 1] - ptr, n = deg * bw;
-    const double* v = val + 3 * bw * ptr + (long long)i * n;
-    double s = 0.0;
-    for (long long c = lane; c < n; c += 64) { const long long col = (long long)nb[ptr + c / bw] * bw + c % bw; s += v[c] * x[col]; }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) y[row] += s;
+    if (a >= ncp) return;
+    const long long ptr = nb_ptr[a], deg = nb_ptr[a + 1] - ptr;
+    const double* v = val + 3 * BW * ptr;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (long long k = lane; k < deg; k += 64) {
+        const long long col = (long long)nb[ptr + k] * BW;
+        double xv[BW];
+#pragma unroll
+        for (int j = 0; j < BW; ++j) xv[j] = x[col + j];
+#pragma unroll
+        for (int j = 0; j < BW; ++j) {
+            s0 += v[BW * k + j] * xv[j];
+            s1 += v[BW * deg + BW * k + j] * xv[j];
+            s2 += v[2 * BW * deg + BW * k + j] * xv[j];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+    if (lane == 0) { y[3 * a] += s0; y[3 * a + 1] += s1; y[3 * a + 2] += s2; }
 }
 // y += A^T x: scatter with FP64 atomics (summation order not fixed)
 __global__ __launch_bounds__(256) void csr_apply_t_kernel(long long nrows, const long long* nb_ptr, const int* nb, int bw, const double* __restrict__ val,

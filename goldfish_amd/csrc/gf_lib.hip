@@ -313,11 +313,12 @@ int gf_apply_dev(gf_handle* h, int which, int transpose, const double* x, double
     if (which < 0 || which > 4) return fail("gf_apply: unknown matrix id");
     if (!h->assembled[which]) return fail("gf_apply: matrix has not been assembled");
     const long long* ptr = which == GF_MAT_DRDH ? h->M.nb_ptr_s : h->M.nb_ptr_c; const int* nb = which == GF_MAT_DRDH ? h->M.nb_s : h->M.nb_c;
-    const int bw = which == GF_MAT_K ? 3 : 1; const long long nrows = h->H.ndof;
-    const unsigned grid = (unsigned)((nrows * 64 + 255) / 256);
+    const int bw = which == GF_MAT_K ? 3 : 1; const long long nrows = h->H.ndof, ncp = h->H.total_cp;
+    const unsigned grid = (unsigned)((nrows * 64 + 255) / 256), grid_cp = (unsigned)((ncp * 64 + 255) / 256);
     // K is symmetric including its Dirichlet treatment (rows+cols zeroed, unit diagonal): K^T x = K x, so the
     // transposed product uses the atomic-free row kernel as well (bitwise reproducible adjoint products with K)
-    if (!transpose || which == GF_MAT_K) hipLaunchKernelGGL(csr_apply_kernel, dim3(grid), dim3(256), 0, h->stream, nrows, ptr, nb, bw, h->d_val[which], x, y);
+    if (which == GF_MAT_K) hipLaunchKernelGGL(csr_apply_kernel<3>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
+    else if (!transpose) hipLaunchKernelGGL(csr_apply_kernel<1>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
     else hipLaunchKernelGGL(csr_apply_t_kernel, dim3(grid), dim3(256), 0, h->stream, nrows, ptr, nb, bw, h->d_val[which], x, y);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("gf_apply: ") + hipGetErrorString(e));
