@@ -317,7 +317,8 @@ int gf_apply_dev(gf_handle* h, int which, int transpose, const double* x, double
     const unsigned grid = (unsigned)((nrows * 64 + 255) / 256), grid_cp = (unsigned)((ncp * 64 + 255) / 256);
     // K is symmetric including its Dirichlet treatment (rows+cols zeroed, unit diagonal): K^T x = K x, so the
     // transposed product uses the atomic-free row kernel as well (bitwise reproducible adjoint products with K)
-    if (which == GF_MAT_K) hipLaunchKernelGGL(csr_apply_kernel<3>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
+    // (not on a shard: ghost rows are not assembled there, so the local K is not symmetric)
+    if (which == GF_MAT_K && (!transpose || h->H.n_owned == h->H.np)) hipLaunchKernelGGL(csr_apply_kernel<3>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
     else if (!transpose) hipLaunchKernelGGL(csr_apply_kernel<1>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
     else hipLaunchKernelGGL(csr_apply_t_kernel, dim3(grid), dim3(256), 0, h->stream, nrows, ptr, nb, bw, h->d_val[which], x, y);
     hipError_t e = hipGetLastError();
@@ -420,7 +421,8 @@ int gf_functionals(gf_handle* h, double out[3], double* dWdu, double* dWdcp, dou
         const long long e_end = H.n_owned < H.np ? H.patches[H.n_owned].elem_off : H.nelem;
         long double W = 0, V = 0, Wp = 0;
         for (long long e = 0; e < e_end; ++e) { W += we[e]; V += ve[e]; }
-        for (long long v = 0; v < H.npts; ++v) Wp += pe[v];
+        // an interface cut by the partition is present on both ranks: its energy is counted by the owner of side A
+        for (long long v = 0; v < H.npts; ++v) if (H.if_patch[2 * H.pt_iface[v]] < H.n_owned) Wp += pe[v];
         out[0] = (double)W; out[1] = (double)V; out[2] = (double)Wp;
     } catch (const std::exception& ex) { return fail(ex.what()); }
     return 0;

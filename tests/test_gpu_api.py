@@ -185,20 +185,19 @@ def _rank_worker(rank, world, port, q):
     from goldfish_amd import _lib, sharding
     spec = G.synthetic_shell(3, 2, nel=4, p=3, jitter=1)
     th, u = G.random_thickness(spec), G.smooth_displacement(spec, 0.5 * spec.h_th)
-    sh = sharding.shard_spec(spec, rank, world)
-    D = _lib.DeviceModel(sharding.shard_arrays(sh, th), device=0)
-    D.set_thickness(sh.to_local(np.concatenate(th)))
-    D.set_u(sh.to_local(u, 3))
-    D.assemble()
-    Rg = sharding.allreduce_owned_rows(sh, torch.from_numpy(D.residual()), dist, 3).numpy()
-    g0, g1 = sh.owned_global_range(3)
-    rows = D.csr(_lib.MAT_K)[:g1 - g0]
-    cols = sh.local_cols_to_global()
-    ck = np.abs(rows).sum()
+    S = sharding.ShardedDeviceModel(spec, dist, rank, world, device=0, thickness_global=th)
+    S.set_thickness(np.concatenate(th))
+    S.set_u(u)
+    S.assemble()
+    rng = np.random.default_rng(11)                       # same seed on every rank: replicated inputs
+    xu, xc, lam = rng.standard_normal(S.ndof), rng.standard_normal(S.total_cp), rng.standard_normal(S.ndof)
+    res = dict(R=S.residual(), Ku=S.apply(_lib.MAT_K, xu), KTl=S.apply(_lib.MAT_K, lam, transpose=True),
+               Cc=S.apply(_lib.MAT_DRDCP1, xc), CTl=S.apply(_lib.MAT_DRDCP1, lam, transpose=True),
+               HTl=S.apply(_lib.MAT_DRDH, lam, transpose=True), F=S.functionals(apply_bcs=False), xu=xu, xc=xc, lam=lam)
     if rank == 0:
-        q.put((Rg, float(ck)))
+        q.put(res)
     dist.barrier()
-    D.close()
+    S.close()
     dist.destroy_process_group()
 
 
@@ -215,14 +214,24 @@ def test_two_rank_sharded_assembly_on_gpu(oracle_lib):
     procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    Rg, _ = q.get(timeout=600)
+    res = q.get(timeout=600)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
     spec = G.synthetic_shell(3, 2, nel=4, p=3, jitter=1)
     th = G.random_thickness(spec)
     O = Oracle(arrays_from_spec(spec, th), thickness=np.concatenate(th), u=G.smooth_displacement(spec, 0.5 * spec.h_th))
-    assert _rel(Rg, O.residual()) < 1e-10
+    assert _rel(res["R"], O.residual()) < 1e-10
+    vals = O.assemble()
+    K, C1, H = O.csr(0, vals[0]), O.csr(2, vals[2]), O.csr(4, vals[4])
+    assert _rel(res["Ku"], K @ res["xu"]) < 1e-10 and _rel(res["KTl"], K.T @ res["lam"]) < 1e-10
+    assert _rel(res["Cc"], C1 @ res["xc"]) < 1e-10 and _rel(res["CTl"], C1.T @ res["lam"]) < 1e-10
+    assert _rel(res["HTl"], H.T @ res["lam"]) < 1e-10
+    Fo, F = O.functionals(apply_bcs=False), res["F"]
+    for k in ("Wint", "volume", "Wpen"):
+        assert abs(F[k] - Fo[k]) < 1e-11 * abs(Fo[k]), k
+    assert _rel(F["dWdu"], Fo["dWdu"]) < 1e-10 and _rel(F["dWdh"], Fo["dWdh"]) < 1e-10
+    assert _rel(F["dWdcp"][2], Fo["dWdcp"][2]) < 1e-10 and _rel(F["dVdcp"][0], Fo["dVdcp"][0]) < 1e-10
 
 
 def test_ffd_chain_rule_through_the_gpu_path():
