@@ -1,0 +1,253 @@
+// gf_element_mfma.hpp -- p = 3 element kernel whose a-b contraction runs on the FP64 matrix pipe.
+//
+// Why: the VALU kernel (kl_element_kernel) is bound by per-wave instruction issue (~900 instructions per
+// Gauss point and wave for ~340 FP64 operations; the T tile makes a round trip through LDS).  With (p+1)^2 = 16
+// basis functions the element matrices are exactly one 16x16 MFMA tile per (i,j) component:
+//     K^{ij}[a][b] = sum_gp sum_m  phi_a[gp][m] * T^{ij}_b[gp][m],   T^{ij}_b[gp][m] = w_gp sum_m' G[(m,i),(m',j)] phi_b[gp][m']
+// and v_mfma_f64_16x16x4 contracts 4 Gauss points at once (k = Gauss point of the lane's 16-lane group).
+// Lane (x, kk) = (lane % 16, lane / 16) holds phi_x at Gauss point 4*grp + kk in registers: it supplies the A operand
+// (row a = x) and computes the B operand T_b (column b = x) on the fly from the expanded rows of G in LDS -- no T tile,
+// no cross-wave barrier (one wave per element), 300 MFMAs instead of 4800 FMA instructions per element.
+// tools/ubench_mfma_loop.hip measures this inner loop at 68 cycles per (component, m) unit and checks the operand layout:
+//     A[i][k]: lane = i + 16 k      B[k][j]: lane = j + 16 k      D[i][j]: lane = j + 16 (i % 4), register i / 4.
+// Reference path: the same integrals as kl_element_kernel (GOLDFISH/nonmatching_opt.py:941-1015 via PENGoLINS assembly).
+#pragma once
+
+namespace gf {
+
+typedef double gf_d4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_first, int flags, double* __restrict__ blk) {
+    using Cfg = ElemCfg<3>;
+    constexpr int P = 3, P1 = 4, NB = 16, NG = 16, ND = 48;
+    constexpr int GU = 450;                    // doubles of expanded rows per Gauss point: (6 K + 9 C components) x 5 m x (5 m' + 1 pad)
+    constexpr int DUMP = 4 * GU;               // rows nobody reads (lower-triangular K components, idle lane 15)
+    const int tid = threadIdx.x, x = tid & 15, kk = tid >> 4;
+    const long long e = (long long)e_first + blockIdx.x;
+    if (e >= M.nelem) return;
+    const PatchDev& Pt = M.patches[M.elem_patch[e]];
+    const int le = int(e - Pt.elem_off), eu = le % Pt.nelu, ev = le / Pt.nelu;
+    const int iu0 = M.ints[Pt.spu + eu] - P, iv0 = M.ints[Pt.spv + ev] - P;
+
+    __shared__ __attribute__((aligned(16))) double s_g[4 * GU + 8];     // control-point staging (phases 0-1), then expanded rows
+    double (*s_c)[3] = reinterpret_cast<double (*)[3]>(s_g);
+    double (*s_d)[3] = reinterpret_cast<double (*)[3]>(s_g + 3 * NB);
+    double* s_h = s_g + 6 * NB; double* s_w = s_g + 7 * NB;
+    __shared__ double s_tu[P1 * 3 * P1], s_tv[P1 * 3 * P1], s_wg[2 * P1];
+    __shared__ __attribute__((aligned(16))) double s_im[NG][IM_SIZE];
+
+    // ---- phase 0: stage control-point data and 1-D tables ------------------------------------
+    if (tid < NB) {
+        const long long g = Pt.cp_off + (iu0 + tid % P1) + (long long)(iv0 + tid / P1) * Pt.nu;
+        const double4 c4 = reinterpret_cast<const double4*>(M.cp4)[g];
+        const double ux = M.u[3 * g], uy = M.u[3 * g + 1], uz = M.u[3 * g + 2];
+        s_c[tid][0] = c4.x; s_c[tid][1] = c4.y; s_c[tid][2] = c4.z; s_w[tid] = c4.w;
+        s_d[tid][0] = c4.x + ux; s_d[tid][1] = c4.y + uy; s_d[tid][2] = c4.z + uz;
+        s_h[tid] = M.h[g];
+    }
+    if (tid < P1 * 3 * P1) { s_tu[tid] = M.tab[Pt.tabu + eu * P1 * 3 * P1 + tid]; s_tv[tid] = M.tab[Pt.tabv + ev * P1 * 3 * P1 + tid]; }
+    if (tid < P1) { s_wg[tid] = M.tab[Pt.wu + eu * P1 + tid]; s_wg[P1 + tid] = M.tab[Pt.wv + ev * P1 + tid]; }
+    __syncthreads();
+
+    // ---- phase 1: one lane per Gauss point: kinematics + pointwise closed forms ----------------
+    if (tid < NG) {
+        const int gu = tid % P1, gv = tid / P1;
+        double W[6] = {0, 0, 0, 0, 0, 0}, Nb[6], R[6];
+        for (int a = 0; a < NB; ++a) { bspline6<P>(s_tu, s_tv, gu, gv, a, Nb); for (int k = 0; k < 6; ++k) W[k] += Nb[k] * s_w[a]; }
+        W[0] = 1.0 / W[0];
+        double z[15], Z[15], t = 0.0;
+        for (int k = 0; k < 15; ++k) { z[k] = 0.0; Z[k] = 0.0; }
+        for (int a = 0; a < NB; ++a) {
+            bspline6<P>(s_tu, s_tv, gu, gv, a, Nb); rationalize6(Nb, W, R);
+            t += Nb[0] * s_h[a];
+            for (int m = 0; m < 5; ++m) for (int i = 0; i < 3; ++i) { Z[3 * m + i] += R[m + 1] * s_c[a][i]; z[3 * m + i] += R[m + 1] * s_d[a][i]; }
+        }
+        double* im = s_im[tid];
+        shell_point(z, Z, t, Pt.E, Pt.nu_, im);
+        for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
+        im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
+    }
+    __syncthreads();
+
+    // ---- lane constants of the row expansion: lane x < 15 expands row r = x = 3 m_r + i_r of G = Pzz and Hc = Pzz + PzZ
+    const bool tang = x < 6, curv = x >= 6 && x < 15;
+    const int r = x < 15 ? x : 14, mr = r / 3, ir = r - 3 * mr;
+    const int kr = mr >= 2 ? mr - 2 : 0;                                      // curvature component of a curvature row
+    const double m0 = (mr == 0) ? 1.0 : 0.0, m1 = (mr == 1) ? 1.0 : 0.0, f3k = (kr == 2) ? 2.0 : 1.0;
+    const double dij[3] = {ir == 0 ? 1.0 : 0.0, ir == 1 ? 1.0 : 0.0, ir == 2 ? 1.0 : 0.0};
+    const int oE2 = IM_G + (tang ? 3 * (1 - mr) + ir : 0);
+    const int oJ0 = IM_JNV + (mr == 0 ? 0 : 2), oJ1 = IM_JNV + (mr == 1 ? 1 : 2);
+    int oHM[6];
+    for (int s = 0; s < 6; ++s) oHM[s] = IM_HMN + hmn_idx(tang ? r : 0, s);
+    const int oCT[3] = {IM_CT3 + sym3(kr, 0), IM_CT3 + sym3(kr, 1), IM_CT3 + sym3(kr, 2)};
+    // destinations: K component (i_r, j) only for j >= i_r (the rest is obtained by symmetry), dR/dc component (i_r, f)
+    double* const gk = s_g + kk * GU;
+    const int base_i = ir == 0 ? 0 : (ir == 1 ? 2 : 3);
+    double* wK[3]; double* wC[3];
+    for (int j = 0; j < 3; ++j) {
+        wK[j] = (x < 15 && j >= ir) ? gk + ((base_i + j) * 5 + mr) * 6 : s_g + DUMP;
+        wC[j] = (x < 15) ? gk + (30 + (3 * ir + j) * 5 + mr) * 6 : s_g + DUMP;
+    }
+    const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = (flags & GF_ASM_C_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
+    const bool has_bf = (Pt.f[0] != 0.0) || (Pt.f[1] != 0.0) || (Pt.f[2] != 0.0);
+    const int ju = x % P1, jv = x / P1;
+
+    gf_d4 accK[6], accC[9], accH[3];
+    for (int q = 0; q < 6; ++q) accK[q] = gf_d4{0, 0, 0, 0};
+    for (int q = 0; q < 9; ++q) accC[q] = gf_d4{0, 0, 0, 0};
+    for (int q = 0; q < 3; ++q) accH[q] = gf_d4{0, 0, 0, 0};
+    double accR[3] = {0.0, 0.0, 0.0};
+
+    for (int grp = 0; grp < 4; ++grp) {
+        const int gu = kk, gv = grp;                         // Gauss point of this lane's group: gp = gu + 4 gv
+        const double* im = s_im[4 * grp + kk];
+        const double wq = im[IM_WQ];
+        // -- basis function x at this Gauss point (registers)
+        double phi[5], R0, n0;
+        {
+            const double u0 = s_tu[(gu * 3 + 0) * P1 + ju], u1 = s_tu[(gu * 3 + 1) * P1 + ju], u2 = s_tu[(gu * 3 + 2) * P1 + ju];
+            const double v0 = s_tv[(gv * 3 + 0) * P1 + jv], v1 = s_tv[(gv * 3 + 1) * P1 + jv], v2 = s_tv[(gv * 3 + 2) * P1 + jv];
+            const double Nb[6] = {u0 * v0, u1 * v0, u0 * v1, u2 * v0, u0 * v2, u1 * v1};
+            double R[6];
+            rationalize6(Nb, im + IM_W, R);
+            for (int k = 0; k < 5; ++k) phi[k] = R[k + 1];
+            R0 = R[0]; n0 = Nb[0];
+        }
+        // -- row r of G and Hc at this Gauss point
+        if (doK || doC) {
+            double gR[15], hR[15];
+            for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
+            if (tang) {
+                const double gr = im[IM_G + r], e0 = m0 * gr, e1 = m1 * gr, e2 = im[oE2];
+                const double b0 = im[IM_BG + r], b1 = im[IM_BG + 6 + r], b2 = im[IM_BG + 12 + r], pzr = im[IM_PZ + r];
+                const double jn[2] = {im[oJ0], im[oJ1]};
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
+                    const double g = e0 * im[IM_CEZ + s] + e1 * im[IM_CEZ + 6 + s] + e2 * im[IM_CEZ + 12 + s]
+                                   + b0 * im[IM_CBG + s] + b1 * im[IM_CBG + 6 + s] + b2 * im[IM_CBG + 12 + s] - im[oHM[s]] + dij[s % 3] * jn[s / 3];
+                    const double zz = pzr * im[IM_JZJ + s] + e0 * im[IM_JDNV + s] + e1 * im[IM_JDNV + 6 + s] + e2 * im[IM_JDNV + 12 + s]
+                                    - (b0 * im[IM_JDMO + s] + b1 * im[IM_JDMO + 6 + s] + b2 * im[IM_JDMO + 12 + s]);
+                    gR[s] = g; hR[s] = g + zz;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {                                       // curvature columns (c, jj)
+                    const double fc = (c == 2) ? 2.0 : 1.0;
+                    const double cbg = fc * im[IM_CBG + 6 * c + r], jm = im[IM_JMOF + c];
+                    const double bt = fc * (b0 * im[IM_CT3 + sym3(0, c)] + b1 * im[IM_CT3 + sym3(1, c)] + b2 * im[IM_CT3 + sym3(2, c)]);
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) {
+                        const double g = im[IM_N + jj] * cbg - jm * im[IM_DN + 6 * jj + r];
+                        gR[6 + 3 * c + jj] = g; hR[6 + 3 * c + jj] = g - bt * im[IM_NB + jj];
+                    }
+                }
+            } else if (curv) {
+                const double fn = f3k * im[IM_N + ir], pzr = im[IM_PZ + r], jm = im[IM_JMOF + kr];
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
+                    const double g = fn * im[IM_CBG + 6 * kr + s] - jm * im[IM_DN + 6 * ir + s];
+                    gR[s] = g; hR[s] = g + pzr * im[IM_JZJ + s] - fn * im[IM_JDMO + 6 * kr + s];
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double cc = fn * ((c == 2) ? 2.0 : 1.0) * im[oCT[c]];
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) { const double nj = im[IM_N + jj]; gR[6 + 3 * c + jj] = cc * nj; hR[6 + 3 * c + jj] = cc * (nj - im[IM_NB + jj]); }
+                }
+            }
+            __syncthreads();                                   // the previous group's operand reads are complete
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                for (int mp = 0; mp < 5; ++mp) { wK[j][mp] = gR[3 * mp + j]; wC[j][mp] = hR[3 * mp + j]; }
+            }
+            __syncthreads();
+        }
+        // -- residual and dR/dh prefactors of basis function x at this Gauss point
+        {
+            const double J = im[IM_J];
+            for (int i = 0; i < 3; ++i) {
+                double rz = 0.0;
+                for (int m = 0; m < 5; ++m) rz += phi[m] * im[IM_PZ + 3 * m + i];
+                accR[i] += wq * (rz - J * Pt.f[i] * R0);
+            }
+        }
+        double pb[5];
+        for (int m = 0; m < 5; ++m) pb[m] = wq * phi[m];
+        if (doH) {
+            double nn = 0.0;
+            for (int k = 0; k < 3; ++k) nn += phi[2 + k] * im[IM_JCK4 + k] * (k == 2 ? 2.0 : 1.0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double g1i = im[IM_G + i], g2i = im[IM_G + 3 + i];
+                double rh = phi[0] * (im[IM_JCE] * g1i + im[IM_JCE + 2] * g2i) + phi[1] * (im[IM_JCE + 1] * g2i + im[IM_JCE + 2] * g1i);
+                for (int k = 0; k < 3; ++k) rh -= im[IM_JCK4 + k] * (phi[0] * im[IM_BG + 6 * k + i] + phi[1] * im[IM_BG + 6 * k + 3 + i]);
+                rh -= im[IM_N + i] * nn;
+                accH[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wq * rh, n0, accH[i], 0, 0, 0);
+            }
+        }
+        // -- contraction: one MFMA per (component, m); the B operand T_b is formed from the expanded row on the fly
+        if (doK) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const double* row = gk + (q * 5 + m) * 6;
+                    const double2 g01 = *reinterpret_cast<const double2*>(row), g23 = *reinterpret_cast<const double2*>(row + 2);
+                    const double t = g01.x * pb[0] + g01.y * pb[1] + g23.x * pb[2] + g23.y * pb[3] + row[4] * pb[4];
+                    accK[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], t, accK[q], 0, 0, 0);
+                }
+        }
+        if (doC) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    const double* row = gk + (30 + q * 5 + m) * 6;
+                    const double2 g01 = *reinterpret_cast<const double2*>(row), g23 = *reinterpret_cast<const double2*>(row + 2);
+                    const double t = g01.x * pb[0] + g01.y * pb[1] + g23.x * pb[2] + g23.y * pb[3] + row[4] * pb[4];
+                    accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], t, accC[q], 0, 0, 0);
+                }
+            if (has_bf) {                    // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b)
+                const double J = im[IM_J];
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    const double jz = J * (im[IM_JZJ + f] * pb[0] + im[IM_JZJ + 3 + f] * pb[1]);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) accC[3 * i + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pt.f[i] * R0, jz, accC[3 * i + f], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- residual: sum the four Gauss-point groups
+    __syncthreads();
+    for (int i = 0; i < 3; ++i) s_g[(kk * NB + x) * 3 + i] = accR[i];
+    __syncthreads();
+    double* out = blk + (size_t)blockIdx.x * Cfg::BLK;
+    if (tid < ND && (flags & GF_ASM_R_BIT)) out[Cfg::OFF_R + tid] = s_g[tid] + s_g[ND + tid] + s_g[2 * ND + tid] + s_g[3 * ND + tid];
+    // ---- write the element block once: register rr of lane (x, kk) is entry (a, b) = (kk + 4 rr, x)
+    constexpr int IJ_I[6] = {0, 0, 0, 1, 1, 2}, IJ_J[6] = {0, 1, 2, 1, 2, 2};
+    const int b = x;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int a = kk + 4 * rr;
+        if (doK) {
+#pragma unroll
+            for (int ij = 0; ij < 6; ++ij) {
+                const int i = IJ_I[ij], j = IJ_J[ij];
+                out[Cfg::OFF_K + (3 * a + i) * ND + 3 * b + j] = accK[ij][rr];
+                if (i < j) out[Cfg::OFF_K + (3 * b + j) * ND + 3 * a + i] = accK[ij][rr];
+            }
+        }
+        if (doC) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) out[Cfg::OFF_C + (3 * a + q / 3) * ND + 3 * b + q % 3] = accC[q][rr];
+        }
+        if (doH) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) out[Cfg::OFF_H + (3 * a + i) * NB + b] = accH[i][rr];
+        }
+    }
+}
+
+}  // namespace gf

@@ -12,6 +12,7 @@ constexpr int GF_ASM_R_BIT = 1, GF_ASM_K_BIT = 2, GF_ASM_C_BIT = 4, GF_ASM_H_BIT
 }
 #include "../../include/goldfish_hip.h"
 #include "gf_kernels.hpp"
+#include "gf_element_mfma.hpp"
 
 using namespace gf;
 
@@ -34,6 +35,7 @@ struct gf_handle {
     std::vector<Chunk> chunks;
     std::vector<hipEvent_t> ev0, ev1; int ev_n = 0;   // element-kernel timing
     bool assembled[5] = {false, false, false, false, false};
+    bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
     int pen_maxdeg = 0;                               // largest neighbour count of an interface control point
 
     template <class T> T* dalloc(size_t n) {
@@ -64,6 +66,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreate(&h->stream));
         h->H.build(desc);
+        if (const char* s = getenv("GF_ELEMENT")) h->mfma = std::string(s) != "valu";
         HostModel& H = h->H;
         std::vector<long long> nbs(H.nb_ptr_s.begin(), H.nb_ptr_s.end()), nbc(H.nb_ptr_c.begin(), H.nb_ptr_c.end());
         h->d_cp4 = h->dalloc<double>(4 * H.total_cp); h->d_u = h->dalloc<double>(H.ndof); h->d_h = h->dalloc<double>(H.total_cp); h->d_R = h->dalloc<double>(H.ndof);
@@ -211,7 +214,8 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
         const long long ne = c.e1 - c.e0, na = c.a1 - c.a0;
         const int slot = h->ev_n % 64;
         HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
-        hipLaunchKernelGGL(kl_element_kernel<P>, dim3((unsigned)ne), dim3(Cfg::NT), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+        if (P == 3 && h->mfma) hipLaunchKernelGGL(kl_element_mfma_kernel, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+        else hipLaunchKernelGGL(kl_element_kernel<P>, dim3((unsigned)ne), dim3(Cfg::NT), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
         HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
         h->ev_n++;
         hipLaunchKernelGGL(kl_gather_kernel<P>, dim3((unsigned)na), dim3(256), 0, h->stream, h->M, c.a0, c.e0, ne, flags, h->d_blk,
