@@ -12,16 +12,45 @@
 //     A[i][k]: lane = i + 16 k      B[k][j]: lane = j + 16 k      D[i][j]: lane = j + 16 (i % 4), register i / 4.
 // Reference path: the same integrals as kl_element_kernel (GOLDFISH/nonmatching_opt.py:941-1015 via PENGoLINS assembly).
 #pragma once
+#include <type_traits>
 
 namespace gf {
 
 typedef double gf_d4 __attribute__((ext_vector_type(4)));
 
+// t += (value of g held by lane LANE of this lane's 16-lane row) * p.   gfx950 has the DPP form of v_fmac_f64 (row_newbcast
+// only); the compiler does not fold a DPP move into FP64 FMAs, hence the inline assembly.  The DPP source must not have been
+// written by a VALU instruction in the two preceding slots (here it always comes from an LDS load).
+template <int LANE> __device__ __forceinline__ void fmac_bcast(double& t, double g, double p) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(g), "v"(p), "n"(LANE));
+}
+// dot product of the 5 row entries F .. F+4 (distributed as above) with p[0..4]
+template <int F> __device__ __forceinline__ double row_dot(const double (&g)[24], const double (&p)[5]) {
+    double t = 0.0;
+    fmac_bcast<(F + 0) % 16>(t, g[(F + 0) / 16], p[0]);
+    fmac_bcast<(F + 1) % 16>(t, g[(F + 1) / 16], p[1]);
+    fmac_bcast<(F + 2) % 16>(t, g[(F + 2) / 16], p[2]);
+    fmac_bcast<(F + 3) % 16>(t, g[(F + 3) / 16], p[3]);
+    fmac_bcast<(F + 4) % 16>(t, g[(F + 4) / 16], p[4]);
+    return t;
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+// VALU result -> MFMA operand needs two wait states; the FMAs above are opaque to the compiler's hazard recogniser
+// (the operands are tied to the nop so that it stays between the last FMA and the first MFMA of a batch)
+__device__ __forceinline__ void mfma_hazard_gap(double (&t)[6]) {
+    asm volatile("s_nop 1" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]));
+}
+__device__ __forceinline__ void mfma_hazard_gap(double (&t)[9]) {
+    asm volatile("s_nop 1" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]));
+}
+
 __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_first, int flags, double* __restrict__ blk) {
     using Cfg = ElemCfg<3>;
     constexpr int P = 3, P1 = 4, NB = 16, NG = 16, ND = 48;
-    constexpr int GU = 450;                    // doubles of expanded rows per Gauss point: (6 K + 9 C components) x 5 m x (5 m' + 1 pad)
-    constexpr int DUMP = 4 * GU;               // rows nobody reads (lower-triangular K components, idle lane 15)
+    constexpr int GU = 384;                    // doubles of expanded rows per Gauss point: (6 K + 9 C components) x 5 m x 5 m' = 375, packed
+    constexpr int DUMP = 376;                  // 5 pad slots per Gauss point nobody reads (lower-triangular K components, idle lane 15)
     const int tid = threadIdx.x, x = tid & 15, kk = tid >> 4;
     const long long e = (long long)e_first + blockIdx.x;
     if (e >= M.nelem) return;
@@ -29,13 +58,18 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     const int le = int(e - Pt.elem_off), eu = le % Pt.nelu, ev = le / Pt.nelu;
     const int iu0 = M.ints[Pt.spu + eu] - P, iv0 = M.ints[Pt.spv + ev] - P;
 
-    __shared__ __attribute__((aligned(16))) double s_g[4 * GU + 8];     // control-point staging (phases 0-1), then expanded rows
+    __shared__ __attribute__((aligned(16))) double s_g[4 * GU];     // control-point staging (phases 0-1), then expanded rows
     double (*s_c)[3] = reinterpret_cast<double (*)[3]>(s_g);
     double (*s_d)[3] = reinterpret_cast<double (*)[3]>(s_g + 3 * NB);
     double* s_h = s_g + 6 * NB; double* s_w = s_g + 7 * NB;
     __shared__ double s_tu[P1 * 3 * P1], s_tv[P1 * 3 * P1], s_wg[2 * P1];
     __shared__ __attribute__((aligned(16))) double s_im[NG][IM_SIZE];
 
+    unsigned long long tstamp = 0; (void)tstamp;
+#ifdef GF_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    tstamp = clock64();
+#endif
     // ---- phase 0: stage control-point data and 1-D tables ------------------------------------
     if (tid < NB) {
         const long long g = Pt.cp_off + (iu0 + tid % P1) + (long long)(iv0 + tid / P1) * Pt.nu;
@@ -48,6 +82,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     if (tid < P1 * 3 * P1) { s_tu[tid] = M.tab[Pt.tabu + eu * P1 * 3 * P1 + tid]; s_tv[tid] = M.tab[Pt.tabv + ev * P1 * 3 * P1 + tid]; }
     if (tid < P1) { s_wg[tid] = M.tab[Pt.wu + eu * P1 + tid]; s_wg[P1 + tid] = M.tab[Pt.wv + ev * P1 + tid]; }
     __syncthreads();
+    GF_STAMP(0, tstamp);
 
     // ---- phase 1: one lane per Gauss point: kinematics + pointwise closed forms ----------------
     if (tid < NG) {
@@ -68,6 +103,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
         im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
     }
     __syncthreads();
+    GF_STAMP(1, tstamp);
 
     // ---- lane constants of the row expansion: lane x < 15 expands row r = x = 3 m_r + i_r of G = Pzz and Hc = Pzz + PzZ
     const bool tang = x < 6, curv = x >= 6 && x < 15;
@@ -85,8 +121,8 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     const int base_i = ir == 0 ? 0 : (ir == 1 ? 2 : 3);
     double* wK[3]; double* wC[3];
     for (int j = 0; j < 3; ++j) {
-        wK[j] = (x < 15 && j >= ir) ? gk + ((base_i + j) * 5 + mr) * 6 : s_g + DUMP;
-        wC[j] = (x < 15) ? gk + (30 + (3 * ir + j) * 5 + mr) * 6 : s_g + DUMP;
+        wK[j] = (x < 15 && j >= ir) ? gk + ((base_i + j) * 5 + mr) * 5 : gk + DUMP;
+        wC[j] = (x < 15) ? gk + (30 + (3 * ir + j) * 5 + mr) * 5 : gk + DUMP;
     }
     const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = (flags & GF_ASM_C_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
     const bool has_bf = (Pt.f[0] != 0.0) || (Pt.f[1] != 0.0) || (Pt.f[2] != 0.0);
@@ -98,6 +134,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     for (int q = 0; q < 3; ++q) accH[q] = gf_d4{0, 0, 0, 0};
     double accR[3] = {0.0, 0.0, 0.0};
 
+    GF_STAMP(2, tstamp);
     for (int grp = 0; grp < 4; ++grp) {
         const int gu = kk, gv = grp;                         // Gauss point of this lane's group: gp = gu + 4 gv
         const double* im = s_im[4 * grp + kk];
@@ -113,6 +150,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
             for (int k = 0; k < 5; ++k) phi[k] = R[k + 1];
             R0 = R[0]; n0 = Nb[0];
         }
+        GF_STAMP(3, tstamp);
         // -- row r of G and Hc at this Gauss point
         if (doK || doC) {
             double gR[15], hR[15];
@@ -154,6 +192,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
                     for (int jj = 0; jj < 3; ++jj) { const double nj = im[IM_N + jj]; gR[6 + 3 * c + jj] = cc * nj; hR[6 + 3 * c + jj] = cc * (nj - im[IM_NB + jj]); }
                 }
             }
+            GF_STAMP(4, tstamp);
             __syncthreads();                                   // the previous group's operand reads are complete
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -162,6 +201,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
             }
             __syncthreads();
         }
+        GF_STAMP(5, tstamp);
         // -- residual and dR/dh prefactors of basis function x at this Gauss point
         {
             const double J = im[IM_J];
@@ -185,28 +225,36 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
                 accH[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wq * rh, n0, accH[i], 0, 0, 0);
             }
         }
+        GF_STAMP(6, tstamp);
         // -- contraction: one MFMA per (component, m); the B operand T_b is formed from the expanded row on the fly
+        // The 375 row entries of this Gauss point are spread over the 16 lanes of the group (entry f in register f / 16
+        // of lane f % 16: 24 conflict-free loads instead of 225 broadcast reads that each occupy the LDS pipe for a full
+        // wave) and reach the FMAs through DPP row_newbcast.  The B operands of all components of one m are formed as
+        // independent FMA chains before their MFMAs are issued.
+        double g[24];
+        if (doK || doC) {
+#pragma unroll
+            for (int j = 0; j < 24; ++j) g[j] = gk[16 * j + x];
+        }
         if (doK) {
+            static_for<5>([&](auto m_) {
+                constexpr int m = decltype(m_)::value;
+                double t[6];
+                static_for<6>([&](auto q_) { constexpr int q = decltype(q_)::value; t[q] = row_dot<(q * 5 + m) * 5>(g, pb); });
+                mfma_hazard_gap(t);
 #pragma unroll
-            for (int m = 0; m < 5; ++m)
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    const double* row = gk + (q * 5 + m) * 6;
-                    const double2 g01 = *reinterpret_cast<const double2*>(row), g23 = *reinterpret_cast<const double2*>(row + 2);
-                    const double t = g01.x * pb[0] + g01.y * pb[1] + g23.x * pb[2] + g23.y * pb[3] + row[4] * pb[4];
-                    accK[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], t, accK[q], 0, 0, 0);
-                }
+                for (int q = 0; q < 6; ++q) accK[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], t[q], accK[q], 0, 0, 0);
+            });
         }
         if (doC) {
+            static_for<5>([&](auto m_) {
+                constexpr int m = decltype(m_)::value;
+                double t[9];
+                static_for<9>([&](auto q_) { constexpr int q = decltype(q_)::value; t[q] = row_dot<(30 + q * 5 + m) * 5>(g, pb); });
+                mfma_hazard_gap(t);
 #pragma unroll
-            for (int m = 0; m < 5; ++m)
-#pragma unroll
-                for (int q = 0; q < 9; ++q) {
-                    const double* row = gk + (30 + q * 5 + m) * 6;
-                    const double2 g01 = *reinterpret_cast<const double2*>(row), g23 = *reinterpret_cast<const double2*>(row + 2);
-                    const double t = g01.x * pb[0] + g01.y * pb[1] + g23.x * pb[2] + g23.y * pb[3] + row[4] * pb[4];
-                    accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], t, accC[q], 0, 0, 0);
-                }
+                for (int q = 0; q < 9; ++q) accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], t[q], accC[q], 0, 0, 0);
+            });
             if (has_bf) {                    // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b)
                 const double J = im[IM_J];
 #pragma unroll
@@ -220,6 +268,10 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     }
 
     // ---- residual: sum the four Gauss-point groups
+#ifdef GF_STAMPS
+    { const unsigned long long t1_ = clock64(); stamp_acc[7] += t1_ - tstamp; tstamp = t1_; }
+    if ((blockIdx.x & 31) == 0 && tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[k], stamp_acc[k]);
+#endif
     __syncthreads();
     for (int i = 0; i < 3; ++i) s_g[(kk * NB + x) * 3 + i] = accR[i];
     __syncthreads();

@@ -13,8 +13,10 @@ D.set_thickness(np.concatenate(th)); D.set_u(G.smooth_displacement(spec, 0.5 * s
 L = _lib.lib(); out = (C.c_ulonglong * 8)()
 D.assemble(); L.gf_debug_stamps(out)
 D.assemble(); L.gf_debug_stamps(out)
-nw = 2 * ((D.n_elements + 31) // 32)      # 1 in 32 elements sampled, 2 waves each
-names = ["phase0 load", "phase1 pointwise(+barrier wait)", "descriptors", "S1 expansion", "barrier1", "S2 T-formation", "barrier2", "S3 contraction"]
+mfma = os.environ.get("GF_ELEMENT", "mfma") != "valu"
+nw = (1 if mfma else 2) * ((D.n_elements + 31) // 32)      # 1 in 32 elements sampled
+names = (["phase0 load", "phase1 pointwise", "lane constants", "basis at GP", "row expansion", "row write + sync", "rz/rh + H MFMA", "T + MFMA contraction (+last: phase 3 excluded)"] if mfma else
+         ["phase0 load", "phase1 pointwise(+barrier wait)", "descriptors", "S1 expansion", "barrier1", "S2 T-formation", "barrier2", "S3 contraction"])
 tot = sum(out)
 for n, v in zip(names, out):
     print("%-34s %10.0f cycles/wave  %5.1f%%" % (n, v / nw, 100.0 * v / tot))
