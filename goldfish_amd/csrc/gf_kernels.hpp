@@ -18,6 +18,7 @@ namespace gf {
 struct DevModel {
     const PatchDev* patches; const double* tab; const int* ints; const int* elem_patch; const int* cp_patch;
     const double* cp4; const double* u; const double* h; const unsigned char* zero;
+    const unsigned char* pen_row;    // 1: the control point owns penalty rows (pen_owner_kernel writes them before the gather adds the shell part)
     const long long* nb_ptr_s; const int* nb_s; const long long* nb_ptr_c; const int* nb_c;
     long long total_cp, nelem;
 };
@@ -318,7 +319,7 @@ template <int P>
 __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_first, long long e_first, long long e_count, int flags,
                                                          const double* __restrict__ blk,
                                                          double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1,
-                                                         double* __restrict__ valC2, double* __restrict__ valH, double* __restrict__ R) {
+                                                         double* __restrict__ valC2, double* __restrict__ valH, double* __restrict__ R, int pen_add) {
     using Cfg = ElemCfg<P>;
     constexpr int P1 = Cfg::P1, NB = Cfg::NB, ND = Cfg::ND, WB = 2 * P + 1, NBOX = WB * WB;
     const long long a = a_first + blockIdx.x;
@@ -402,6 +403,8 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
         }
     }
     __syncthreads();
+    // the penalty rows of an interface control point were written before (pen_owner_kernel); the shell part is added to them
+    const bool padd = pen_add && M.pen_row[a];
     // box slot of neighbour control point bcp (-1: not a shell neighbour, i.e. coupling-only column)
     auto box_slot = [&](long long bcp) -> int {
         if (bcp < pbeg || bcp >= pend) return -1;
@@ -413,15 +416,15 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
         const long long bcp = M.nb_c[ptr_c + k], row = 3 * a + i, col = 3 * bcp + j;
         double v = 0.0;
         if (M.zero[row] || M.zero[col]) v = (row == col) ? 1.0 : 0.0;
-        else { const int ks = box_slot(bcp); if (ks >= 0) v = aK[i][ks][j]; }
+        else { const int ks = box_slot(bcp); if (ks >= 0) v = aK[i][ks][j]; if (padd) v += valK[9 * ptr_c + idx]; }
         valK[9 * ptr_c + idx] = v;
     }
     if (flags & GF_ASM_C_BIT) for (long long idx = tid; idx < 9 * deg_c; idx += 256) {
         const int f = int(idx / (3 * deg_c)), rem = int(idx - (long long)f * 3 * deg_c), i = int(rem / deg_c), k = int(rem - (long long)i * deg_c);
         const long long bcp = M.nb_c[ptr_c + k];
         double v = 0.0;
-        if (!M.zero[3 * a + i]) { const int ks = box_slot(bcp); if (ks >= 0) v = aC[f][i][ks]; }
         double* dst = f == 0 ? valC0 : (f == 1 ? valC1 : valC2);
+        if (!M.zero[3 * a + i]) { const int ks = box_slot(bcp); if (ks >= 0) v = aC[f][i][ks]; if (padd) v += dst[3 * ptr_c + (long long)i * deg_c + k]; }
         dst[3 * ptr_c + (long long)i * deg_c + k] = v;
     }
     if (flags & GF_ASM_H_BIT) for (long long idx = tid; idx < 3 * deg_s; idx += 256) {
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
         const int ks = box_slot(M.nb_s[ptr_s + k]);
         valH[3 * ptr_s + idx] = ks >= 0 ? aH[i][ks] : 0.0;
     }
-    if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * a + tid] = aR[tid];
+    if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * a + tid] = aR[tid] + (padd ? R[3 * a + tid] : 0.0);
 }
 
 // ------------------------------------------------------------------------------------- functionals
@@ -601,7 +604,7 @@ __global__ void pen_energy_kernel(long long npts, const double* __restrict__ pbu
 struct DevPenalty {
     const int* pt_iface; const int* pt_base; const double* pt_nu; const double* pt_tau; const double* pt_wt;
     const int* if_patch; const double* if_alpha;
-    const PenRowItem* row_items; const long long* row_ptr;
+    const PenEntry* entries; const long long* ent_ptr; const int* row_cp;
     long long npts, nrow_groups;
 };
 
@@ -632,19 +635,15 @@ __global__ __launch_bounds__(64) void pen_point_kernel(DevModel M, DevPenalty Q,
     penalty_point(y, Y, Q.pt_tau + 2 * v, Q.if_alpha[2 * itf], Q.if_alpha[2 * itf + 1], Q.pt_wt[v], pbuf + (size_t)v * PB_STRIDE);
 }
 
-// local index of control point cp in the support window of mortar vertex v on side sd (-1 if outside)
-template <int P> __device__ __forceinline__ int pen_local(const DevModel& M, const DevPenalty& Q, long long v, int sd, int itf, long long cp) {
-    const PatchDev& Pt = M.patches[Q.if_patch[2 * itf + sd]];
-    const int l = int(cp - Pt.cp_off), i = l % Pt.nu - Q.pt_base[4 * v + 2 * sd], j = l / Pt.nu - Q.pt_base[4 * v + 2 * sd + 1];
-    return (i >= 0 && i <= P && j >= 0 && j <= P) ? i + j * (P + 1) : -1;
-}
-
 // Penalty rows of one owned control point a (one wave each): residual entries and the coupling blocks
 // of K and dR/dCP.  Every lane OWNS up to PEN_SL neighbour slots k of a (k = lane + 64 sl) and keeps
-// their 3x3 K and dR/dc blocks in registers.  For every mortar vertex v whose support contains a, the
-// Hessian rows are contracted with nu_a once (w-vectors, double-buffered in LDS: one barrier per
-// vertex); a lane whose slot's control point lies in the support window of v adds its blocks.
-// Items and vertices are visited in a fixed order and nothing is shared: bitwise reproducible.
+// their 3x3 K and dR/dc blocks in registers.  The visits (mortar vertices whose support contains a) come
+// from a host-built list that carries the vertex id, side, local index and both support windows, so the
+// kernel has no dependent index loads; two visits are processed per iteration with all their loads issued
+// together (the loop is latency bound).  Per visit the Hessian rows are contracted with nu_a once
+// (w-vectors in LDS, four buffers: one barrier per pair); a lane whose slot's control point lies in the
+// support window adds its blocks.  Fixed visit order, nothing shared: bitwise reproducible.
+// The kernel WRITES the rows (the gather of these control points adds the shell part afterwards).
 constexpr int PEN_MAXDEG = 64 * 5;
 template <int P, int PEN_SL>
 __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q, int flags, int maxdeg, const double* __restrict__ pbuf, double* __restrict__ R,
@@ -653,76 +652,95 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
     const long long gidx = blockIdx.x;
     if (gidx >= Q.nrow_groups) return;
     const int tid = threadIdx.x;
-    const long long it0 = Q.row_ptr[gidx], it1 = Q.row_ptr[gidx + 1];
-    const int a = Q.row_items[it0].a;
+    const long long e0 = Q.ent_ptr[gidx], e1 = Q.ent_ptr[gidx + 1];
+    const int a = Q.row_cp[gidx];
     const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c;
     const bool mats = (flags & (GF_ASM_K_BIT | GF_ASM_C_BIT)) != 0;
-    __shared__ double s_w[2][3][32];                    // [buffer][i][0..17 wK | 18..29 wC]
+    __shared__ double s_w[4][3][32];                    // [buffer][i][0..17 wK | 18..29 wC]
     // owned slots
-    int sb[PEN_SL], sp[PEN_SL], si[PEN_SL], sj[PEN_SL];
+    int sp[PEN_SL], si[PEN_SL], sj[PEN_SL];
     double kk[PEN_SL][9], cc[PEN_SL][9];
 #pragma unroll
     for (int sl = 0; sl < PEN_SL; ++sl) {
         const int k = tid + 64 * sl;
-        sb[sl] = -1; sp[sl] = -1; si[sl] = 0; sj[sl] = 0;
+        sp[sl] = -1; si[sl] = 0; sj[sl] = 0;
         if (mats && sl * 64 < maxdeg && k < deg_c) {
             const int bcp = M.nb_c[ptr_c + k], pb = M.cp_patch[bcp];
             const PatchDev& Pb = M.patches[pb];
             const int lb = int(bcp - Pb.cp_off);
-            sb[sl] = bcp; sp[sl] = pb; si[sl] = lb % Pb.nu; sj[sl] = lb / Pb.nu;
+            sp[sl] = pb; si[sl] = lb % Pb.nu; sj[sl] = lb / Pb.nu;
         }
         for (int q = 0; q < 9; ++q) { kk[sl][q] = 0.0; cc[sl][q] = 0.0; }
     }
     double racc = 0.0;                                  // tid < 3: residual entry (a, tid)
-    int buf = 0;
-    for (long long it = it0; it < it1; ++it) {
-        const PenRowItem I = Q.row_items[it];
-        const int itf = I.code >> 1, s = I.code & 1;
-        const int pA = Q.if_patch[2 * itf], pB = Q.if_patch[2 * itf + 1];
-        for (long long v = I.lo; v <= I.hi; ++v) {
-            const int al = pen_local<P>(M, Q, v, s, itf, a);
-            if (al < 0) continue;                                              // uniform over the wave
+    const int iK = tid < 54 ? tid / 18 : 0, cK = tid < 54 ? tid - 18 * iK : 0, iC = tid < 36 ? tid / 12 : 0, cC = tid < 36 ? tid - 12 * iC : 0;
+    int pair = 0;
+    for (long long e = e0; e < e1; e += 2) {
+        const int nu_ = (e + 1 < e1) ? 2 : 1;
+        PenEntry E[2];
+        E[0] = Q.entries[e]; E[1] = Q.entries[e + nu_ - 1];
+        // -- all loads of the pair
+        double n3[2][3], hk[2][3], hc[2][3], g3[2][3], bv[2][PEN_SL][3]; int tt[2][PEN_SL];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long v = E[u].v; const int s = E[u].sal >> 8, al = E[u].sal & 255;
             const double* na = Q.pt_nu + ((size_t)v * 2 + s) * 3 * NB; const double* pb = pbuf + (size_t)v * PB_STRIDE;
-            const double n0 = na[al], n1 = na[NB + al], n2 = na[2 * NB + al];
-            if (tid < 54) { const int i = tid / 18, c = tid - 18 * i; const double* h = pb + PB_HYY + (9 * s + i) * 18 + c; s_w[buf][i][c] = n0 * h[0] + n1 * h[3 * 18] + n2 * h[6 * 18]; }
-            else if (tid < 64) { /* idle in this step */ }
-            if (tid < 36) { const int i = tid / 12, c = tid - 12 * i; const double* h = pb + PB_HYC + (9 * s + i) * 12 + c; s_w[buf][i][18 + c] = n0 * h[0] + n1 * h[3 * 12] + n2 * h[6 * 12]; }
-            if (tid < 3) { const double* g = pb + PB_GRAD + 9 * s; racc += n0 * g[tid] + n1 * g[3 + tid] + n2 * g[6 + tid]; }
-            __syncthreads();
-            if (mats) {
-                const int* base = Q.pt_base + 4 * v;
+            n3[u][0] = na[al]; n3[u][1] = na[NB + al]; n3[u][2] = na[2 * NB + al];
+            { const double* h = pb + PB_HYY + (9 * s + iK) * 18 + cK; hk[u][0] = h[0]; hk[u][1] = h[3 * 18]; hk[u][2] = h[6 * 18]; }
+            { const double* h = pb + PB_HYC + (9 * s + iC) * 12 + cC; hc[u][0] = h[0]; hc[u][1] = h[3 * 12]; hc[u][2] = h[6 * 12]; }
+            { const double* g = pb + PB_GRAD + 9 * s + (tid < 3 ? tid : 0); g3[u][0] = g[0]; g3[u][1] = g[3]; g3[u][2] = g[6]; }
+#pragma unroll
+            for (int sl = 0; sl < PEN_SL; ++sl) {
+                // a self-interface (pA == pB) would need both sides per slot; not supported (rejected at create)
+                const int t = sp[sl] < 0 ? -1 : (sp[sl] == E[u].pA ? 0 : (sp[sl] == E[u].pB ? 1 : -1));
+                const int base = t == 1 ? E[u].baseB : E[u].baseA;
+                const int di = si[sl] - (base & 0xffff), dj = sj[sl] - (base >> 16);
+                const bool in = t >= 0 && di >= 0 && di <= P && dj >= 0 && dj <= P;
+                tt[u][sl] = in ? t : -1;
+                const double* nb = Q.pt_nu + ((size_t)v * 2 + (in ? t : 0)) * 3 * NB + (in ? di + dj * P1 : 0);
+                bv[u][sl][0] = nb[0]; bv[u][sl][1] = nb[NB]; bv[u][sl][2] = nb[2 * NB];
+            }
+        }
+        // -- w-vectors of both visits, one barrier
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u < nu_) {
+                double (*w)[32] = s_w[2 * pair + u];
+                if (tid < 54) w[iK][cK] = n3[u][0] * hk[u][0] + n3[u][1] * hk[u][1] + n3[u][2] * hk[u][2];
+                if (tid < 36) w[iC][18 + cC] = n3[u][0] * hc[u][0] + n3[u][1] * hc[u][1] + n3[u][2] * hc[u][2];
+                if (tid < 3) racc += n3[u][0] * g3[u][0] + n3[u][1] * g3[u][1] + n3[u][2] * g3[u][2];
+            }
+        }
+        __syncthreads();
+        if (mats) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u >= nu_) continue;
+                const double (*w)[32] = s_w[2 * pair + u];
 #pragma unroll
                 for (int sl = 0; sl < PEN_SL; ++sl) {
-                    if (sl * 64 >= maxdeg || sb[sl] < 0) continue;
-                    const int t = sp[sl] == pA ? 0 : (sp[sl] == pB ? 1 : -1);
+                    const int t = tt[u][sl];
                     if (t < 0) continue;
-                    // a self-interface (pA == pB) would need both sides per slot; not supported (rejected at create)
-                    const int di = si[sl] - base[2 * t], dj = sj[sl] - base[2 * t + 1];
-                    if (di < 0 || di > P || dj < 0 || dj > P) continue;
-                    const int bl = di + dj * P1;
-                    const double* nb = Q.pt_nu + ((size_t)v * 2 + t) * 3 * NB;
-                    const double b0 = nb[bl], b1 = nb[NB + bl], b2 = nb[2 * NB + bl];
+                    const double b0 = bv[u][sl][0], b1 = bv[u][sl][1], b2 = bv[u][sl][2];
                     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-                        kk[sl][3 * i + j] += s_w[buf][i][9 * t + j] * b0 + s_w[buf][i][9 * t + 3 + j] * b1 + s_w[buf][i][9 * t + 6 + j] * b2;
-                        cc[sl][3 * i + j] += s_w[buf][i][18 + 6 * t + j] * b1 + s_w[buf][i][18 + 6 * t + 3 + j] * b2;
+                        kk[sl][3 * i + j] += w[i][9 * t + j] * b0 + w[i][9 * t + 3 + j] * b1 + w[i][9 * t + 6 + j] * b2;
+                        cc[sl][3 * i + j] += w[i][18 + 6 * t + j] * b1 + w[i][18 + 6 * t + 3 + j] * b2;
                     }
                 }
             }
-            buf ^= 1;            // the next vertex writes the other buffer: one barrier per vertex suffices
         }
+        pair ^= 1;            // the next pair writes the other two buffers: one barrier per pair suffices
     }
-    if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * (long long)a + tid] += racc;
+    if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * (long long)a + tid] = racc;          // the gather adds the shell part
     if (!mats) return;
 #pragma unroll
     for (int sl = 0; sl < PEN_SL; ++sl) {
-        if (sl * 64 >= maxdeg || sb[sl] < 0) continue;
-        const int k = tid + 64 * sl; const long long bcp = sb[sl];
-        for (int i = 0; i < 3; ++i) {
-            const long long row = 3 * (long long)a + i;
-            if (M.zero[row]) continue;
+        if (sl * 64 >= maxdeg || sp[sl] < 0) continue;
+        const int k = tid + 64 * sl;
+        for (int i = 0; i < 3; ++i) {                    // every entry of the rows is written (Dirichlet rows/columns are overwritten by the gather)
             for (int j = 0; j < 3; ++j) {
-                if ((flags & GF_ASM_K_BIT) && !M.zero[3 * bcp + j]) valK[9 * ptr_c + (long long)i * 3 * deg_c + 3 * k + j] += kk[sl][3 * i + j];
-                if (flags & GF_ASM_C_BIT) { double* dst = j == 0 ? valC0 : (j == 1 ? valC1 : valC2); dst[3 * ptr_c + (long long)i * deg_c + k] += cc[sl][3 * i + j]; }
+                if (flags & GF_ASM_K_BIT) valK[9 * ptr_c + (long long)i * 3 * deg_c + 3 * k + j] = kk[sl][3 * i + j];
+                if (flags & GF_ASM_C_BIT) { double* dst = j == 0 ? valC0 : (j == 1 ? valC1 : valC2); dst[3 * ptr_c + (long long)i * deg_c + k] = cc[sl][3 * i + j]; }
             }
         }
     }

@@ -98,13 +98,15 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         HIPCHK(hipMemset(h->d_fun, 0, 11 * H.total_cp * sizeof(double)));
         // penalty
         DevPenalty& Q = h->Q;
+        std::vector<unsigned char> pen_row(H.total_cp, 0);
         Q.npts = H.npts;
         if (H.npts > 0) {
-            std::vector<long long> rp(H.row_ptr.begin(), H.row_ptr.end());
+            std::vector<long long> rp(H.row_ptr.begin(), H.row_ptr.end()), ep(H.ent_ptr.begin(), H.ent_ptr.end());
             Q.pt_iface = h->upload(H.pt_iface); Q.pt_base = h->upload(H.pt_base); Q.pt_nu = h->upload(H.pt_nu);
             Q.pt_tau = h->upload(H.pt_tau); Q.pt_wt = h->upload(H.pt_wt); Q.if_patch = h->upload(H.if_patch); Q.if_alpha = h->upload(H.if_alpha);
-            Q.row_items = h->upload(H.row_items); Q.row_ptr = h->upload(rp);
+            Q.entries = h->upload(H.pen_entries); Q.ent_ptr = h->upload(ep); Q.row_cp = h->upload(H.row_cp);
             Q.nrow_groups = (long long)rp.size() - 1;
+            for (long long g = 0; g + 1 < (long long)rp.size(); ++g) if (rp[g + 1] > rp[g]) pen_row[H.row_items[rp[g]].a] = 1;
             h->d_pbuf = h->dalloc<double>((size_t)H.npts * PB_STRIDE);
             for (const PenRowItem& it : H.row_items)
                 h->pen_maxdeg = std::max(h->pen_maxdeg, (int)(H.nb_ptr_c[it.a + 1] - H.nb_ptr_c[it.a]));
@@ -113,6 +115,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
                 if (H.nb_ptr_c[it.a + 1] - H.nb_ptr_c[it.a] > PEN_MAXDEG)
                     throw std::runtime_error("gf_create: a control point couples to more than " + std::to_string(PEN_MAXDEG) + " neighbours (PEN_MAXDEG)");
         }
+        M.pen_row = h->upload(pen_row);
         // element-block scratch, chunked over whole patches
         const int P = H.degree, NB = (P + 1) * (P + 1), ND = 3 * NB;
         const long long blk_doubles = 2LL * ND * ND + (long long)ND * NB + ND;
@@ -210,6 +213,21 @@ int gf_pattern(const gf_handle* h, int which, int64_t* rowptr, int32_t* col) {
 
 template <int P> static void run_assemble(gf_handle* h, int flags) {
     using Cfg = ElemCfg<P>;
+    const HostModel& H = h->H;
+    // Penalty rows first: pen_owner_kernel WRITES the rows of the interface control points, the gather adds the shell part to
+    // them (no read-modify-write pass over those rows afterwards).  Running the penalty kernels on a second stream was measured
+    // and dropped: next to the element kernel they cost it LDS occupancy (17.7 -> 22.8 ms), next to the gather both slow down
+    // by what the overlap saves (profiles/r01_v8_*).
+    const int pen = (H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP))) ? 1 : 0;
+    if (pen) {
+        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf);
+        const dim3 grid((unsigned)h->Q.nrow_groups), blk64(64);
+        const int sl = (h->pen_maxdeg + 63) / 64;         // neighbour slots per lane, register resident
+#define GF_PEN_LAUNCH(SL) hipLaunchKernelGGL((pen_owner_kernel<P, SL>), grid, blk64, 0, h->stream, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \
+                                             h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])
+        if (sl <= 2) GF_PEN_LAUNCH(2); else if (sl == 3) GF_PEN_LAUNCH(3); else GF_PEN_LAUNCH(5);
+#undef GF_PEN_LAUNCH
+    }
     for (const Chunk& c : h->chunks) {
         const long long ne = c.e1 - c.e0, na = c.a1 - c.a0;
         const int slot = h->ev_n % 64;
@@ -219,17 +237,7 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
         HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
         h->ev_n++;
         hipLaunchKernelGGL(kl_gather_kernel<P>, dim3((unsigned)na), dim3(256), 0, h->stream, h->M, c.a0, c.e0, ne, flags, h->d_blk,
-                           h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R);
-    }
-    const HostModel& H = h->H;
-    if (H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP))) {
-        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf);
-        const dim3 grid((unsigned)h->Q.nrow_groups), blk64(64);
-        const int sl = (h->pen_maxdeg + 63) / 64;         // neighbour slots per lane, register resident
-#define GF_PEN_LAUNCH(SL) hipLaunchKernelGGL((pen_owner_kernel<P, SL>), grid, blk64, 0, h->stream, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \
-                                             h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])
-        if (sl <= 2) GF_PEN_LAUNCH(2); else if (sl == 3) GF_PEN_LAUNCH(3); else GF_PEN_LAUNCH(5);
-#undef GF_PEN_LAUNCH
+                           h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R, pen);
     }
     if (flags & GF_ASM_R) {
         const long long npl = (long long)H.pl_dof.size();

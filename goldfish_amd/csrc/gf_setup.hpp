@@ -32,6 +32,9 @@ struct PatchDev {            // POD mirrored on the device
 };
 
 struct PenRowItem { int a, code, lo, hi; };           // code = iface*2 + s
+// one (owned control point, mortar vertex) visit of the penalty row kernel: everything the kernel needs to address the
+// vertex record and both support windows without dependent index loads
+struct PenEntry { int v, sal, baseA, baseB, pA, pB, pad0, pad1; };   // sal = side << 8 | local index; base = iu0 | iv0 << 16
 
 inline void gauss_legendre(int n, double* x, double* w) {
     for (int i = 0; i < n; ++i) {
@@ -109,6 +112,7 @@ struct HostModel {
     std::vector<int> if_patch; std::vector<double> if_alpha; std::vector<int64_t> if_off;
     // deterministic owner lists
     std::vector<PenRowItem> row_items; std::vector<int64_t> row_ptr;      // groups by CP a
+    std::vector<PenEntry> pen_entries; std::vector<int64_t> ent_ptr; std::vector<int> row_cp;   // per group: its visits in fixed order
 
     void build(const gf_model_desc* D);
 };
@@ -291,6 +295,24 @@ inline void HostModel::build(const gf_model_desc* D) {
         std::stable_sort(rows.begin(), rows.end(), [](const PenRowItem& x, const PenRowItem& y) { return x.a < y.a; });
         row_items = rows; row_ptr.clear(); row_ptr.push_back(0);
         for (size_t k = 1; k <= rows.size(); ++k) if (k == rows.size() || rows[k].a != rows[k - 1].a) row_ptr.push_back((int64_t)k);
+        pen_entries.clear(); ent_ptr.assign(1, 0); row_cp.clear();
+        for (size_t g = 0; g + 1 < row_ptr.size(); ++g) {
+            const int a = rows[row_ptr[g]].a;
+            for (int64_t it = row_ptr[g]; it < row_ptr[g + 1]; ++it) {
+                const PenRowItem& I = rows[it];
+                const int itf = I.code >> 1, sd = I.code & 1;
+                const PatchDev& P = patches[if_patch[2 * itf + sd]];
+                const int l = int(a - P.cp_off), ia = l % P.nu, ja = l / P.nu;
+                for (int v = I.lo; v <= I.hi; ++v) {
+                    const int di = ia - pt_base[4 * v + 2 * sd], dj = ja - pt_base[4 * v + 2 * sd + 1];
+                    if (di < 0 || di > P.p || dj < 0 || dj > P.q) continue;
+                    for (int k = 0; k < 4; ++k) if (pt_base[4 * v + k] < 0 || pt_base[4 * v + k] > 32767) throw std::runtime_error("gf_create: patch too large for the packed mortar windows");
+                    pen_entries.push_back({v, (sd << 8) | (di + dj * (P.p + 1)), pt_base[4 * v] | (pt_base[4 * v + 1] << 16), pt_base[4 * v + 2] | (pt_base[4 * v + 3] << 16),
+                                           if_patch[2 * itf], if_patch[2 * itf + 1], 0, 0});
+                }
+            }
+            ent_ptr.push_back((int64_t)pen_entries.size()); row_cp.push_back(a);
+        }
     }
 }
 
