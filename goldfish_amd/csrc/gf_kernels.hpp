@@ -411,26 +411,42 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
         const int lb = int(bcp - pbeg), ib = lb % Pt.nu, jb = lb / Pt.nu;
         return (ib >= i0 && ib <= i1 && jb >= j0 && jb <= j1) ? (ib - i0) + (jb - j0) * wbox : -1;
     };
-    if (flags & GF_ASM_K_BIT) for (long long idx = tid; idx < 9 * deg_c; idx += 256) {
-        const int i = int(idx / (3 * deg_c)), rem = int(idx - (long long)i * 3 * deg_c), k = rem / 3, j = rem - 3 * k;
-        const long long bcp = M.nb_c[ptr_c + k], row = 3 * a + i, col = 3 * bcp + j;
-        double v = 0.0;
-        if (M.zero[row] || M.zero[col]) v = (row == col) ? 1.0 : 0.0;
-        else { const int ks = box_slot(bcp); if (ks >= 0) v = aK[i][ks][j]; if (padd) v += valK[9 * ptr_c + idx]; }
-        valK[9 * ptr_c + idx] = v;
-    }
-    if (flags & GF_ASM_C_BIT) for (long long idx = tid; idx < 9 * deg_c; idx += 256) {
-        const int f = int(idx / (3 * deg_c)), rem = int(idx - (long long)f * 3 * deg_c), i = int(rem / deg_c), k = int(rem - (long long)i * deg_c);
-        const long long bcp = M.nb_c[ptr_c + k];
-        double v = 0.0;
-        double* dst = f == 0 ? valC0 : (f == 1 ? valC1 : valC2);
-        if (!M.zero[3 * a + i]) { const int ks = box_slot(bcp); if (ks >= 0) v = aC[f][i][ks]; if (padd) v += dst[3 * ptr_c + (long long)i * deg_c + k]; }
-        dst[3 * ptr_c + (long long)i * deg_c + k] = v;
-    }
-    if (flags & GF_ASM_H_BIT) for (long long idx = tid; idx < 3 * deg_s; idx += 256) {
-        const int i = int(idx / deg_s), k = int(idx - (long long)i * deg_s);
-        const int ks = box_slot(M.nb_s[ptr_s + k]);
-        valH[3 * ptr_s + idx] = ks >= 0 ? aH[i][ks] : 0.0;
+    // wave i < 3 writes dof row i of K and dR/dCP (one neighbour per lane: one box lookup serves its 3 + 3 entries),
+    // wave 3 writes dR/dh; no index divisions in the loops
+    if (wave < 3) {
+        const int i = wave;
+        const long long row = 3 * a + i;
+        const bool zrow = M.zero[row] != 0;
+        for (int k = lane; k < (int)deg_c; k += 64) {
+            const long long bcp = M.nb_c[ptr_c + k];
+            const int ks = box_slot(bcp);
+            if (flags & GF_ASM_K_BIT) {
+                double* dst = valK + 9 * ptr_c + (long long)i * 3 * deg_c + 3 * k;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const long long col = 3 * bcp + j;
+                    double v = 0.0;
+                    if (zrow || M.zero[col]) v = (row == col) ? 1.0 : 0.0;
+                    else { if (ks >= 0) v = aK[i][ks][j]; if (padd) v += dst[j]; }
+                    dst[j] = v;
+                }
+            }
+            if (flags & GF_ASM_C_BIT) {
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    double* dst = (f == 0 ? valC0 : (f == 1 ? valC1 : valC2)) + 3 * ptr_c + (long long)i * deg_c + k;
+                    double v = 0.0;
+                    if (!zrow) { if (ks >= 0) v = aC[f][i][ks]; if (padd) v += *dst; }
+                    *dst = v;
+                }
+            }
+        }
+    } else if (flags & GF_ASM_H_BIT) {
+        for (int k = lane; k < (int)deg_s; k += 64) {
+            const int ks = box_slot(M.nb_s[ptr_s + k]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) valH[3 * ptr_s + (long long)i * deg_s + k] = ks >= 0 ? aH[i][ks] : 0.0;
+        }
     }
     if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * a + tid] = aR[tid] + (padd ? R[3 * a + tid] : 0.0);
 }
