@@ -170,9 +170,11 @@ def main():
             try:
                 tj = json.load(open(tf))
                 if tj.get("workload_gps") == n_gp_local:
-                    traffic = tj.get("kl_element_kernel_bytes_per_launch")
+                    traffic = tj.get("element_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
+        mfma = (p == 3 and os.environ.get("GF_ELEMENT", "mfma") != "valu")
+        kname = "kl_element_mfma_kernel" if mfma else "kl_element_kernel"
         out = {
             "metric": "element-Gauss-point updates/sec (assembly+adjoint)", "value": value, "unit": "GP-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -182,14 +184,15 @@ def main():
                                    % ("C4" if (args.patches == [16, 16] and args.nel == 48 and p == 3) else "custom", args.patches[0], args.patches[1], p, args.nel, 3 * shard.total_cp_global, n_gp_total,
                                       sum(i.npts for i in spec.interfaces)),
                        "parallelism": "patch-sharded x%d, owner-computes-rows, all-reduce of the residual" % world},
-            "roofline": {"bound": "hbm", "kernel": "kl_element_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms, "launches_timed": kern_n},
-            "roofline_fp64": {"bound": "fp64-valu", "kernel": "kl_element_kernel",
+            "roofline_fp64": {"bound": "fp64 (v_mfma_f64 + FP64 VALU share one pipe)" if mfma else "fp64-valu", "kernel": kname,
                               "achieved": ALG_FLOP_PER_GP[p] * n_gp_local / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
                               "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "note": "the tangent / shape-Jacobian contraction is FP64-VALU bound (SURVEY.md 8(d)); "
-                                      "this is the binding roofline of the dominant kernel"},
+                              "note": "the tangent / shape-Jacobian contraction is FP64 bound (SURVEY.md 8(d)); "
+                                      "this is the binding roofline of the dominant kernel; flop count = the formulation's "
+                                      "FMA*2 per Gauss-point update (DESIGN.md section 4), not hardware-issued flops"},
             "apply_linear_roofline": apply,
             "device_bytes": D.device_bytes,
         }

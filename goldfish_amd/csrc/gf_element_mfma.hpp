@@ -6,8 +6,10 @@
 //     K^{ij}[a][b] = sum_gp sum_m  phi_a[gp][m] * T^{ij}_b[gp][m],   T^{ij}_b[gp][m] = w_gp sum_m' G[(m,i),(m',j)] phi_b[gp][m']
 // and v_mfma_f64_16x16x4 contracts 4 Gauss points at once (k = Gauss point of the lane's 16-lane group).
 // Lane (x, kk) = (lane % 16, lane / 16) holds phi_x at Gauss point 4*grp + kk in registers: it supplies the A operand
-// (row a = x) and computes the B operand T_b (column b = x) on the fly from the expanded rows of G in LDS -- no T tile,
-// no cross-wave barrier (one wave per element), 300 MFMAs instead of 4800 FMA instructions per element.
+// (row a = x) and computes the B operand T_b (column b = x) on the fly.  Lane x < 15 also expands row x of the pointwise
+// Hessians G, Hc of its group's Gauss point and KEEPS it in registers; the FMAs that form T read those entries from the
+// owning lane through DPP row_newbcast (v_fmac_f64_dpp) -- no T tile, no expanded Hessian in LDS, no cross-wave barrier
+// (one wave per element), 300 MFMAs instead of 4800 FMA instructions per element.
 // tools/ubench_mfma_loop.hip measures this inner loop at 68 cycles per (component, m) unit and checks the operand layout:
 //     A[i][k]: lane = i + 16 k      B[k][j]: lane = j + 16 k      D[i][j]: lane = j + 16 (i % 4), register i / 4.
 // Reference path: the same integrals as kl_element_kernel (GOLDFISH/nonmatching_opt.py:941-1015 via PENGoLINS assembly).
@@ -20,19 +22,25 @@ typedef double gf_d4 __attribute__((ext_vector_type(4)));
 
 // t += (value of g held by lane LANE of this lane's 16-lane row) * p.   gfx950 has the DPP form of v_fmac_f64 (row_newbcast
 // only); the compiler does not fold a DPP move into FP64 FMAs, hence the inline assembly.  The DPP source must not have been
-// written by a VALU instruction in the two preceding slots (here it always comes from an LDS load).
+// written by a VALU instruction in the two preceding slots (dpp_source_fence below).
 template <int LANE> __device__ __forceinline__ void fmac_bcast(double& t, double g, double p) {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(g), "v"(p), "n"(LANE));
 }
-// dot product of the 5 row entries F .. F+4 (distributed as above) with p[0..4]
-template <int F> __device__ __forceinline__ double row_dot(const double (&g)[24], const double (&p)[5]) {
+// sum_m' (entry [3 m' + J] of the row held by lane LANE of this lane's 16-lane group) * p[m']
+template <int LANE, int J> __device__ __forceinline__ double row_dot(const double (&g)[15], const double (&p)[5]) {
     double t = 0.0;
-    fmac_bcast<(F + 0) % 16>(t, g[(F + 0) / 16], p[0]);
-    fmac_bcast<(F + 1) % 16>(t, g[(F + 1) / 16], p[1]);
-    fmac_bcast<(F + 2) % 16>(t, g[(F + 2) / 16], p[2]);
-    fmac_bcast<(F + 3) % 16>(t, g[(F + 3) / 16], p[3]);
-    fmac_bcast<(F + 4) % 16>(t, g[(F + 4) / 16], p[4]);
+    fmac_bcast<LANE>(t, g[J], p[0]);
+    fmac_bcast<LANE>(t, g[3 + J], p[1]);
+    fmac_bcast<LANE>(t, g[6 + J], p[2]);
+    fmac_bcast<LANE>(t, g[9 + J], p[3]);
+    fmac_bcast<LANE>(t, g[12 + J], p[4]);
     return t;
+}
+// The row registers are written by VALU instructions and read through DPP by inline assembly the hazard recogniser cannot
+// see: tying them to a 2-wait-state nop keeps every producer in front of it and every DPP read behind it.
+__device__ __forceinline__ void dpp_source_fence(double (&g)[15]) {
+    asm volatile("s_nop 1" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7]),
+                             "+v"(g[8]), "+v"(g[9]), "+v"(g[10]), "+v"(g[11]), "+v"(g[12]), "+v"(g[13]), "+v"(g[14]));
 }
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
@@ -49,8 +57,6 @@ __device__ __forceinline__ void mfma_hazard_gap(double (&t)[9]) {
 __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_first, int flags, double* __restrict__ blk) {
     using Cfg = ElemCfg<3>;
     constexpr int P = 3, P1 = 4, NB = 16, NG = 16, ND = 48;
-    constexpr int GU = 384;                    // doubles of expanded rows per Gauss point: (6 K + 9 C components) x 5 m x 5 m' = 375, packed
-    constexpr int DUMP = 376;                  // 5 pad slots per Gauss point nobody reads (lower-triangular K components, idle lane 15)
     const int tid = threadIdx.x, x = tid & 15, kk = tid >> 4;
     const long long e = (long long)e_first + blockIdx.x;
     if (e >= M.nelem) return;
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     const int le = int(e - Pt.elem_off), eu = le % Pt.nelu, ev = le / Pt.nelu;
     const int iu0 = M.ints[Pt.spu + eu] - P, iv0 = M.ints[Pt.spv + ev] - P;
 
-    __shared__ __attribute__((aligned(16))) double s_g[4 * GU];     // control-point staging (phases 0-1), then expanded rows
+    __shared__ __attribute__((aligned(16))) double s_g[4 * ND];     // control-point staging (phases 0-1), residual reduction at the end
     double (*s_c)[3] = reinterpret_cast<double (*)[3]>(s_g);
     double (*s_d)[3] = reinterpret_cast<double (*)[3]>(s_g + 3 * NB);
     double* s_h = s_g + 6 * NB; double* s_w = s_g + 7 * NB;
@@ -141,14 +147,6 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     int oHM[6];
     for (int s = 0; s < 6; ++s) oHM[s] = IM_HMN + hmn_idx(tang ? r : 0, s);
     const int oCT[3] = {IM_CT3 + sym3(kr, 0), IM_CT3 + sym3(kr, 1), IM_CT3 + sym3(kr, 2)};
-    // destinations: K component (i_r, j) only for j >= i_r (the rest is obtained by symmetry), dR/dc component (i_r, f)
-    double* const gk = s_g + kk * GU;
-    const int base_i = ir == 0 ? 0 : (ir == 1 ? 2 : 3);
-    double* wK[3]; double* wC[3];
-    for (int j = 0; j < 3; ++j) {
-        wK[j] = (x < 15 && j >= ir) ? gk + ((base_i + j) * 5 + mr) * 5 : gk + DUMP;
-        wC[j] = (x < 15) ? gk + (30 + (3 * ir + j) * 5 + mr) * 5 : gk + DUMP;
-    }
     const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = (flags & GF_ASM_C_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
     const bool has_bf = (Pt.f[0] != 0.0) || (Pt.f[1] != 0.0) || (Pt.f[2] != 0.0);
     const int ju = x % P1, jv = x / P1;
@@ -177,9 +175,9 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
         }
         GF_STAMP(3, tstamp);
         // -- row r of G and Hc at this Gauss point
+        double gR[15], hR[15];                     // row r of G and Hc; entry (m', j) at [3 m' + j]
+        for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
         if (doK || doC) {
-            double gR[15], hR[15];
-            for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
             if (tang) {
                 const double gr = im[IM_G + r], e0 = m0 * gr, e1 = m1 * gr, e2 = im[oE2];
                 const double b0 = im[IM_BG + r], b1 = im[IM_BG + 6 + r], b2 = im[IM_BG + 12 + r], pzr = im[IM_PZ + r];
@@ -218,13 +216,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
                 }
             }
             GF_STAMP(4, tstamp);
-            __syncthreads();                                   // the previous group's operand reads are complete
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-#pragma unroll
-                for (int mp = 0; mp < 5; ++mp) { wK[j][mp] = gR[3 * mp + j]; wC[j][mp] = hR[3 * mp + j]; }
-            }
-            __syncthreads();
+            dpp_source_fence(gR); dpp_source_fence(hR);
         }
         GF_STAMP(5, tstamp);
         // -- residual and dR/dh prefactors of basis function x at this Gauss point
@@ -252,20 +244,14 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
         }
         GF_STAMP(6, tstamp);
         // -- contraction: one MFMA per (component, m); the B operand T_b is formed from the expanded row on the fly
-        // The 375 row entries of this Gauss point are spread over the 16 lanes of the group (entry f in register f / 16
-        // of lane f % 16: 24 conflict-free loads instead of 225 broadcast reads that each occupy the LDS pipe for a full
-        // wave) and reach the FMAs through DPP row_newbcast.  The B operands of all components of one m are formed as
-        // independent FMA chains before their MFMAs are issued.
-        double g[24];
-        if (doK || doC) {
-#pragma unroll
-            for (int j = 0; j < 24; ++j) g[j] = gk[16 * j + x];
-        }
+        // K component (i, j), m: T_b = w sum_m' G[(m,i),(m',j)] phi_b[m'] -- the five entries are gR[3 m' + j] of lane 3 m + i.
+        // The B operands of all components of one m are formed as independent FMA chains before their MFMAs are issued.
+        constexpr int QI[6] = {0, 0, 0, 1, 1, 2}, QJ[6] = {0, 1, 2, 1, 2, 2};
         if (doK) {
             static_for<5>([&](auto m_) {
                 constexpr int m = decltype(m_)::value;
                 double t[6];
-                static_for<6>([&](auto q_) { constexpr int q = decltype(q_)::value; t[q] = row_dot<(q * 5 + m) * 5>(g, pb); });
+                static_for<6>([&](auto q_) { constexpr int q = decltype(q_)::value; t[q] = row_dot<3 * m + QI[q], QJ[q]>(gR, pb); });
                 mfma_hazard_gap(t);
 #pragma unroll
                 for (int q = 0; q < 6; ++q) accK[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], t[q], accK[q], 0, 0, 0);
@@ -275,7 +261,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
             static_for<5>([&](auto m_) {
                 constexpr int m = decltype(m_)::value;
                 double t[9];
-                static_for<9>([&](auto q_) { constexpr int q = decltype(q_)::value; t[q] = row_dot<(30 + q * 5 + m) * 5>(g, pb); });
+                static_for<9>([&](auto q_) { constexpr int q = decltype(q_)::value; t[q] = row_dot<3 * m + q / 3, q % 3>(hR, pb); });
                 mfma_hazard_gap(t);
 #pragma unroll
                 for (int q = 0; q < 9; ++q) accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], t[q], accC[q], 0, 0, 0);
