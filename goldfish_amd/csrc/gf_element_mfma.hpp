@@ -47,6 +47,9 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
 }
 // VALU result -> MFMA operand needs two wait states; the FMAs above are opaque to the compiler's hazard recogniser
 // (the operands are tied to the nop so that it stays between the last FMA and the first MFMA of a batch)
+// One wave per workgroup: its LDS operations execute in order, so cross-lane hand-over through LDS needs neither s_barrier
+// nor the global-memory fence of __syncthreads().
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void mfma_hazard_gap(double (&t)[6]) {
     asm volatile("s_nop 1" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]));
 }
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     }
     if (tid < P1 * 3 * P1) { s_tu[tid] = M.tab[Pt.tabu + eu * P1 * 3 * P1 + tid]; s_tv[tid] = M.tab[Pt.tabv + ev * P1 * 3 * P1 + tid]; }
     if (tid < P1) { s_wg[tid] = M.tab[Pt.wu + eu * P1 + tid]; s_wg[P1 + tid] = M.tab[Pt.wv + ev * P1 + tid]; }
-    __syncthreads();
+    wave_lds_sync();
     GF_STAMP(0, tstamp);
 
     // ---- phase 1: one lane per Gauss point: kinematics + pointwise closed forms ----------------
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
         for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
         im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
     }
-    __syncthreads();
+    wave_lds_sync();
     GF_STAMP(1, tstamp);
 
     // ---- lane constants of the row expansion: lane x < 15 expands row r = x = 3 m_r + i_r of G = Pzz and Hc = Pzz + PzZ
@@ -283,9 +286,9 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     { const unsigned long long t1_ = clock64(); stamp_acc[7] += t1_ - tstamp; tstamp = t1_; }
     if ((blockIdx.x & 31) == 0 && tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[k], stamp_acc[k]);
 #endif
-    __syncthreads();
+    wave_lds_sync();
     for (int i = 0; i < 3; ++i) s_g[(kk * NB + x) * 3 + i] = accR[i];
-    __syncthreads();
+    wave_lds_sync();
     double* out = blk + (size_t)blockIdx.x * Cfg::BLK;
     if (tid < ND && (flags & GF_ASM_R_BIT)) out[Cfg::OFF_R + tid] = s_g[tid] + s_g[ND + tid] + s_g[2 * ND + tid] + s_g[3 * ND + tid];
     // ---- write the element block once: register rr of lane (x, kk) is entry (a, b) = (kk + 4 rr, x)
