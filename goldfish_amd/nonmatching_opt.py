@@ -366,6 +366,218 @@ class NonMatchingOptFFD(NonMatchingOpt):
         self.shopt_align_dir = [None for _ in self.opt_field]
         return self.shopt_dcpsurf_fedcpffd
 
+    # ------------------------------------------------------------------ FFD lattice helpers
+    @staticmethod
+    def _lattice(shape):
+        """(i, j, k) of every FFD control point in dof order i + j*l + k*l*m (ijk2dof of the reference)."""
+        l, m, nn = (int(s) for s in shape)
+        k, j, i = np.meshgrid(np.arange(nn), np.arange(m), np.arange(l), indexing="ij")
+        return np.stack([i.ravel(), j.ravel(), k.ravel()], 1)
+
+    # ------------------------------------------------------------------ shape FFD: linear constraint maps
+    def dCPaligndCPFFD(self, field, align_dir, cpffd_shape, side=0):
+        """nonmatching_opt_ffd.py:1034-1083.  Control points of the block take the same value along the directions in
+        ``align_dir``: the design dofs are the points of the face/edge ``side`` and the returned map replicates them
+        (full FFD dofs x design dofs, 0/1 entries)."""
+        align_dir = sorted(int(d) for d in align_dir)
+        if field in align_dir:
+            raise ValueError("Illegal CPFFD align direction %s for opt field %d" % (align_dir, field))
+        if not align_dir or any(d not in (0, 1, 2) for d in align_dir) or len(set(align_dir)) != len(align_dir) or len(align_dir) > 2:
+            raise ValueError("Undefined CPFFD ailgn direction %s" % (align_dir,))
+        ijk = self._lattice(cpffd_shape)
+        l, m, _ = (int(s) for s in cpffd_shape)
+        rep = ijk.copy()
+        for d in align_dir:
+            rep[:, d] = side * (int(cpffd_shape[d]) - 1)
+        rep_dof = rep[:, 0] + rep[:, 1] * l + rep[:, 2] * l * m
+        free_dof = np.unique(rep_dof)                                    # ascending = the reference's loop order
+        cols = np.searchsorted(free_dof, rep_dof)
+        deriv = sp.coo_matrix((np.ones(rep_dof.size), (np.arange(rep_dof.size), cols)), shape=(rep_dof.size, free_dof.size))
+        return [int(d) for d in free_dof], deriv
+
+    def set_shopt_align_CPFFD(self, align_dir=None):
+        """nonmatching_opt_ffd.py:691-724 (linear equality constraint built into the parametrisation)."""
+        self.shopt_align_dir = [None for _ in self.opt_field] if align_dir is None else list(align_dir)
+        assert len(self.shopt_align_dir) == len(self.opt_field)
+        size = self.shopt_cpffd_size
+        self.shopt_dcpaligndcpffd = []
+        for field_ind, field in enumerate(self.opt_field):
+            sub = self.shopt_align_dir[field_ind]
+            if sub is not None:
+                free_dof, deriv = self.dCPaligndCPFFD(field, sub, self.shopt_cpffd_shape)
+            else:
+                free_dof, deriv = list(range(size)), sp.identity(size, format="coo")
+            self.shopt_cpffd_design_dof[field_ind] = free_dof
+            self.shopt_dcpaligndcpffd.append(deriv)
+        self.shopt_init_cpffd_design = [self.shopt_init_cpffd_full[i][self.shopt_cpffd_design_dof[i]] for i in range(len(self.opt_field))]
+        return self.shopt_dcpaligndcpffd
+
+    def CPpinDoFs(self, pin_dir0, pin_side0, pin_dir1, pin_side1, cpffd_shape):
+        """nonmatching_opt_ffd.py:1120-1196: dofs of the faces ``pin_dir0``/``pin_side0`` (a surface), restricted to the
+        edges ``pin_dir1``/``pin_side1`` when given (a line)."""
+        if pin_dir0 not in (0, 1, 2):
+            raise ValueError("Unsupported pin_dir0 {}".format(pin_dir0))
+        if pin_dir1 is not None and (pin_dir1 not in (0, 1, 2) or pin_dir1 == pin_dir0):
+            raise ValueError("Unsupported pin_dir1 {}".format(pin_dir1))
+        ijk = self._lattice(cpffd_shape)
+        l, m, _ = (int(s) for s in cpffd_shape)
+        dof = ijk[:, 0] + ijk[:, 1] * l + ijk[:, 2] * l * m
+        out = []
+        for side0 in pin_side0:
+            on0 = ijk[:, pin_dir0] == int(side0 * (int(cpffd_shape[pin_dir0]) - 1))
+            if pin_dir1 is None:
+                out.append(dof[on0])
+            else:
+                for side1 in pin_side1:
+                    out.append(dof[on0 & (ijk[:, pin_dir1] == int(side1 * (int(cpffd_shape[pin_dir1]) - 1)))])
+        return np.concatenate(out) if out else np.zeros(0, int)
+
+    def dCPpindCPFFD(self, cpffd_des_dof, cpffd_pin_dof):
+        """nonmatching_opt_ffd.py:1198-1204: selection of the pinned design dofs."""
+        pos = {d: c for c, d in enumerate(cpffd_des_dof)}
+        cols = [pos[d] for d in cpffd_pin_dof]
+        return sp.coo_matrix((np.ones(len(cols)), (np.arange(len(cols)), cols)), shape=(len(cols), len(cpffd_des_dof)))
+
+    def set_shopt_pin_CPFFD(self, pin_dir0, pin_side0, pin_dir1=None, pin_side1=None):
+        """nonmatching_opt_ffd.py:758-815 (linear equality constraint: pinned design dofs keep their initial values)."""
+        assert len(pin_dir0) == len(self.opt_field) and len(pin_side0) == len(self.opt_field)
+        if not hasattr(self, "shopt_dcpaligndcpffd"):
+            self.set_shopt_align_CPFFD(None)
+        for field_ind, field in enumerate(self.opt_field):
+            if pin_dir0[field_ind] is None:
+                continue
+            d1 = None if pin_dir1 is None else pin_dir1[field_ind]
+            s1 = None if pin_dir1 is None else pin_side1[field_ind]
+            cand = self.CPpinDoFs(pin_dir0[field_ind], pin_side0[field_ind], d1, s1, self.shopt_cpffd_shape)
+            design = set(self.shopt_cpffd_design_dof[field_ind])
+            self.shopt_cpffd_pin_dof[field_ind] += [int(d) for d in cand if int(d) in design]
+        self.shopt_cpffd_pin_dof = [sorted(set(p)) for p in self.shopt_cpffd_pin_dof]
+        self.shopt_pin_vals = [None for _ in self.opt_field]
+        self.shopt_dcppindcpffd = [None for _ in self.opt_field]
+        for field_ind, field in enumerate(self.opt_field):
+            pins = self.shopt_cpffd_pin_dof[field_ind]
+            if len(pins) > 0:
+                self.shopt_dcppindcpffd[field_ind] = self.dCPpindCPFFD(self.shopt_cpffd_design_dof[field_ind], pins)
+                self.shopt_pin_vals[field_ind] = self.shopt_cpffd_flat[:, field][pins]
+        self.pin_field = [f for i, f in enumerate(self.opt_field) if self.shopt_dcppindcpffd[i] is not None]
+        return self.shopt_dcppindcpffd
+
+    def dCPregudCPFFD(self, field, l, m, n, cpffd_design_dof):
+        """nonmatching_opt_ffd.py:1206-1244: differences of neighbouring design control points along the optimised
+        coordinate (keeps the block from folding; linear inequality constraint).  Rows in the reference's loop order."""
+        shape = (int(l), int(m), int(n))
+        if field not in (0, 1, 2):
+            raise ValueError("Unsupported field {}".format(field))
+        idx = [np.arange(s - 1 if d == field else s) for d, s in enumerate(shape)]
+        gi, gj, gk = np.meshgrid(*idx, indexing="ij")                   # i outermost, k innermost
+        lo = gi.ravel() + gj.ravel() * shape[0] + gk.ravel() * shape[0] * shape[1]
+        step = (1, shape[0], shape[0] * shape[1])[field]
+        nrow = lo.size
+        rows = np.concatenate([np.arange(nrow), np.arange(nrow)])
+        cols = np.concatenate([lo, lo + step])
+        vals = np.concatenate([-np.ones(nrow), np.ones(nrow)])
+        return sp.coo_matrix((vals, (rows, cols)), shape=(nrow, len(cpffd_design_dof)))
+
+    def set_shopt_regu_CPFFD(self):
+        """nonmatching_opt_ffd.py:870-883."""
+        if not hasattr(self, "shopt_dcpaligndcpffd"):
+            self.set_shopt_align_CPFFD(None)
+        self.shopt_dcpregudcpffd = []
+        for field_ind, field in enumerate(self.opt_field):
+            l, m, nn = self.shopt_cpffd_shape
+            align = self.shopt_align_dir[field_ind]
+            if align is not None:
+                l, m, nn = (1 if 0 in align else l), (1 if 1 in align else m), (1 if 2 in align else nn)
+            self.shopt_dcpregudcpffd.append(self.dCPregudCPFFD(field, l, m, nn, self.shopt_cpffd_design_dof[field_ind]))
+        return self.shopt_dcpregudcpffd
+
+    # ------------------------------------------------------------------ thickness FFD
+    def set_thopt_surf_inds_FFD(self, thopt_surf_inds):
+        """nonmatching_opt_ffd.py:434-464: patches whose thickness field is driven by one FFD block."""
+        self.thopt_multiffd = False
+        self.thopt_surf_inds = list(thopt_surf_inds)
+        self._thopt_cols = np.concatenate([np.arange(self.cp_off[s], self.cp_off[s + 1]) for s in self.thopt_surf_inds])
+        w = np.concatenate([s.cp_hom_flat()[:, 3] for s in self.splines])[self._thopt_cols]
+        self.thopt_cpsurf_des = np.stack([self.cp_iga[f][self._thopt_cols] / w for f in range(3)], 1)
+        self.thopt_cpsurf_des_lims = [[float(self.thopt_cpsurf_des[:, f].min()), float(self.thopt_cpsurf_des[:, f].max())] for f in range(3)]
+
+    def set_thopt_FFD(self, thopt_knotsffd, thopt_cpffd):
+        """nonmatching_opt_ffd.py:497-521: the thickness at a control point is the trivariate B-spline of the block's
+        thickness coefficients evaluated at the control point's physical position (variable-thickness path)."""
+        from .utils.ffd_utils import CP_FFD_matrix
+        if not getattr(self, "var_thickness", False):
+            self.set_thickness_opt(var_thickness=True)
+        self.thopt_knotsffd = [np.asarray(k, float) for k in thopt_knotsffd]
+        self.thopt_cpffd = np.asarray(thopt_cpffd, float)
+        self.thopt_cpffd_flat = self.thopt_cpffd[..., 0:3].transpose(2, 1, 0, 3).reshape(-1, 3)
+        self.thopt_ffd_degree = int(np.sum(self.thopt_knotsffd[0] == self.thopt_knotsffd[0][0]) - 1)
+        self.thopt_cpffd_shape = self.thopt_cpffd.shape[0:3]
+        self.thopt_cpffd_size = int(np.prod(self.thopt_cpffd_shape))
+        self.thopt_cpffd_design_size = self.thopt_cpffd_size
+        self.thopt_dcpsurf_fedcpffd = CP_FFD_matrix(self.thopt_cpsurf_des, [self.thopt_ffd_degree] * 3, self.thopt_knotsffd).tocoo()
+        self.init_h_th_ffd = None
+        return self.thopt_dcpsurf_fedcpffd
+
+    def get_init_h_th_FFD(self):
+        """nonmatching_opt_ffd.py:523-532: least-squares block coefficients reproducing the initial thickness."""
+        if self.init_h_th_ffd is None:
+            A = self.thopt_dcpsurf_fedcpffd.toarray()
+            h0 = np.concatenate(self.h_th)[self._thopt_cols]
+            self.init_h_th_ffd = np.linalg.lstsq(A, h0, rcond=None)[0]
+        return self.init_h_th_ffd
+
+    def dCPaligndCPFFD_thopt(self, align_dir, cp_align_size, cpffd_size, cpffd_shape):
+        """nonmatching_opt_ffd.py:1085-1118: coefficient(first layer) - coefficient(layer i) = 0 along each direction."""
+        ijk = self._lattice(cpffd_shape)
+        l, m, _ = (int(s) for s in cpffd_shape)
+        rows, cols, vals, r0 = [], [], [], 0
+        for d in align_dir:
+            order = {0: (2, 1, 0), 1: (2, 0, 1), 2: (1, 0, 2)}[int(d)]     # loop nest of the reference, outer -> inner
+            pts = ijk[ijk[:, d] > 0]
+            pts = pts[np.lexsort((pts[:, order[2]], pts[:, order[1]], pts[:, order[0]]))]
+            first = pts.copy(); first[:, d] = 0
+            nr = len(pts)
+            rows += [np.arange(r0, r0 + nr)] * 2
+            cols += [first[:, 0] + first[:, 1] * l + first[:, 2] * l * m, pts[:, 0] + pts[:, 1] * l + pts[:, 2] * l * m]
+            vals += [np.ones(nr), -np.ones(nr)]
+            r0 += nr
+        assert r0 == cp_align_size
+        return sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(cp_align_size, cpffd_size))
+
+    def set_thopt_align_CPFFD(self, align_dir):
+        """nonmatching_opt_ffd.py:915-941."""
+        self.thopt_align_dir = list(align_dir) if isinstance(align_dir, (list, tuple)) else [align_dir]
+        shape = [int(s) for s in self.thopt_cpffd_shape]
+        self.thopt_cp_align_size = int(sum(np.prod([s - 1 if i == d else s for i, s in enumerate(shape)]) for d in self.thopt_align_dir))
+        self.thopt_dcpaligndcpffd = self.dCPaligndCPFFD_thopt(self.thopt_align_dir, self.thopt_cp_align_size, self.thopt_cpffd_size, self.thopt_cpffd_shape)
+        return self.thopt_dcpaligndcpffd
+
+    def set_thopt_regu_CPFFD(self, regu_dir, regu_side, regu_align=None):
+        """nonmatching_opt_ffd.py:943-997 with opt_field = [2] as there: differences of neighbouring block coefficients
+        along direction 2, optionally only on the face ``regu_dir``/``regu_side`` or on the first layer of an aligned
+        direction ``regu_align``."""
+        self.thopt_regu_dir, self.thopt_regu_side, self.thopt_regu_align = regu_dir, regu_side, regu_align
+        shape = [int(s) for s in self.thopt_cpffd_shape]
+        field = 2
+        ijk = self._lattice(shape)
+        keep = ijk[:, field] < shape[field] - 1
+        if regu_dir[0] is not None:
+            keep &= ijk[:, regu_dir[0]] == (0 if regu_side[0] == 0 else shape[regu_dir[0]] - 1)
+        elif regu_align is not None and regu_align[0] is not None:
+            if regu_align[0] == field:
+                raise ValueError("Optimization filed cannot equal to align direction")
+            keep &= ijk[:, regu_align[0]] == 0
+        pts = ijk[keep]
+        pts = pts[np.lexsort((pts[:, 0], pts[:, 1], pts[:, 2]))]        # k outermost as in the reference's face loops (row order is immaterial)
+        l, m = shape[0], shape[1]
+        lo = pts[:, 0] + pts[:, 1] * l + pts[:, 2] * l * m
+        nr = lo.size
+        deriv = sp.coo_matrix((np.concatenate([-np.ones(nr), np.ones(nr)]), (np.concatenate([np.arange(nr)] * 2), np.concatenate([lo, lo + l * m]))),
+                              shape=(nr, self.thopt_cpffd_size))
+        self.thopt_cpregu_sizes = [nr]
+        self.thopt_dcpregudcpffd_list = [deriv]
+        return self.thopt_dcpregudcpffd_list
+
     @property
     def cpsurf_lims(self):
         """Bounding box of the optimised surfaces' physical control points (reference attribute used to

@@ -1,0 +1,96 @@
+"""Thickness design-variable maps (constant sparse linear maps; same option and variable names as the reference):
+HthFFD2FEComp   GOLDFISH/om_comps/ffd_comps/hthffd2fe_comp.py:4-36    FFD thickness coefficients -> thickness at the control points
+HthFFDAlignComp GOLDFISH/om_comps/ffd_comps/hthffd_align_comp.py:4-36 equality constraint rows (aligned layers)
+HthFFDReguComp  GOLDFISH/om_comps/ffd_comps/hthffd_regu_comp.py:4-45  inequality constraint rows (neighbour differences)
+HthMapComp      GOLDFISH/om_comps/ffd_comps/hth_map_comp.py:6-50      one thickness per patch -> full thickness vector"""
+import numpy as np
+import scipy.sparse as sp
+
+from .. import om
+
+
+class _LinearMapComp(om.ExplicitComponent):
+    """y = A x with a constant sparse A (subclasses fill in_name, out_name, deriv, init)."""
+
+    def setup(self):
+        self.add_input(self.in_name, shape=self.deriv.shape[1], val=self.init)
+        self.add_output(self.out_name, shape=self.deriv.shape[0])
+        self.declare_partials(self.out_name, self.in_name, val=self.deriv.data, rows=self.deriv.row, cols=self.deriv.col)
+
+    def compute(self, inputs, outputs):
+        outputs[self.out_name] = self.deriv * inputs[self.in_name]
+
+    def compute_partials(self, inputs, partials):
+        partials[self.out_name, self.in_name] = self.deriv.toarray()
+
+
+class HthFFD2FEComp(_LinearMapComp):
+
+    def initialize(self):
+        self.options.declare('nonmatching_opt_ffd')
+        self.options.declare('input_h_th_ffd_name', default='thickness_FFD')
+        self.options.declare('output_h_th_fe_name', default='thickness_FE')
+
+    def init_parameters(self):
+        nm = self.nonmatching_opt_ffd = self.options['nonmatching_opt_ffd']
+        self.in_name = self.input_h_th_ffd_name = self.options['input_h_th_ffd_name']
+        self.out_name = self.output_h_th_fe_name = self.options['output_h_th_fe_name']
+        self.init = self.init_h_th_ffd = nm.get_init_h_th_FFD()
+        self.deriv = self.deriv_mat = nm.thopt_dcpsurf_fedcpffd.tocoo()
+
+
+class HthFFDAlignComp(_LinearMapComp):
+
+    def initialize(self):
+        self.options.declare('nonmatching_opt_ffd')
+        self.options.declare('input_h_th_name', default='thickness_FFD')
+        self.options.declare('output_h_th_align_name', default='thickness_FFD_align')
+
+    def init_parameters(self):
+        nm = self.nonmatching_opt_ffd = self.options['nonmatching_opt_ffd']
+        self.in_name = self.input_h_th_name = self.options['input_h_th_name']
+        self.out_name = self.output_h_th_align_name = self.options['output_h_th_align_name']
+        self.init = self.init_h_th_ffd = nm.get_init_h_th_FFD()
+        self.deriv = nm.thopt_dcpaligndcpffd.tocoo()
+
+
+class HthFFDReguComp(_LinearMapComp):
+
+    def initialize(self):
+        self.options.declare('nonmatching_opt_ffd')
+        self.options.declare('input_h_th_name', default='thickness_FFD')
+        self.options.declare('output_h_th_regu_name', default='thickness_FFD_regu')
+
+    def init_parameters(self):
+        nm = self.nonmatching_opt_ffd = self.options['nonmatching_opt_ffd']
+        self.in_name = self.input_h_th_name = self.options['input_h_th_name']
+        self.out_name = self.output_h_th_regu_name = self.options['output_h_th_regu_name']
+        self.init = self.init_h_th_ffd = nm.get_init_h_th_FFD()
+        self.deriv = nm.thopt_dcpregudcpffd_list[0].tocoo()
+        self.input_shape, self.output_shape = nm.thopt_cpffd_size, nm.thopt_cpregu_sizes[0]
+
+
+class HthMapComp(_LinearMapComp):
+
+    def initialize(self):
+        self.options.declare('nonmatching_opt')
+        self.options.declare('order', default=0)
+        self.options.declare('input_h_th_name_design', default='thickness')
+        self.options.declare('output_h_th_name_full', default='thickness_full')
+
+    def init_parameters(self):
+        nm = self.nonmatching_opt = self.options['nonmatching_opt']
+        self.order = self.options['order']
+        if self.order != 0:
+            raise ValueError("Order {:2d} is not supported yet".format(self.order))
+        self.in_name = self.input_h_th_name_design = self.options['input_h_th_name_design']
+        self.out_name = self.output_h_th_name_full = self.options['output_h_th_name_full']
+        self.num_splines = nm.num_splines
+        sizes = [int(n) for n in nm.vec_scalar_iga_dof_list]      # one thickness value per control point of each patch
+        self.init = self.init_val = np.array([float(np.mean(h)) for h in nm.h_th])
+        rows = np.arange(sum(sizes))
+        cols = np.repeat(np.arange(self.num_splines), sizes)
+        self.deriv = self.deriv_mat = sp.coo_matrix((np.ones(rows.size), (rows, cols)), shape=(rows.size, self.num_splines))
+
+    def get_derivative(self, coo=True):
+        return self.deriv if coo else self.deriv.toarray()

@@ -268,6 +268,26 @@ def test_ffd_chain_rule_through_the_gpu_path():
         R.append(nm.RIGA())
     nm.update_CPIGA(D @ q0, field)
     assert _rel((R[0] - R[1]) / 2e-6, J @ dq) < 1e-6
+    # design dofs after alignment (CPFFDesign2FullComp): dR/d(design) = dR/dCP @ FFD map @ align map
+    from goldfish_amd.om_comps.ffd_comps import CPFFDesign2FullComp
+    fi = nm.opt_field.index(field)
+    al = [None] * len(nm.opt_field)
+    al[fi] = [1]
+    A = nm.set_shopt_align_CPFFD(al)[fi].tocsr()
+    c3 = CPFFDesign2FullComp(nonmatching_opt_ffd=nm)
+    c3.init_parameters()
+    p3 = om.Problem(model=c3)
+    p3.setup()
+    p3.run_model()
+    assert max(p3.check_partials(compact_print=False).values()) < 1e-8
+    d0 = nm.shopt_init_cpffd_design[fi].copy()
+    dd = np.random.default_rng(5).standard_normal(d0.size)
+    R = []
+    for sgn in (1, -1):
+        nm.update_CPIGA(D @ (A @ (d0 + sgn * 1e-6 * dd)), field)
+        R.append(nm.RIGA())
+    nm.update_CPIGA(D @ (A @ d0), field)
+    assert _rel((R[0] - R[1]) / 2e-6, J @ (A @ dd)) < 1e-6
 
 
 def test_adjoint_total_derivatives_vs_finite_differences():

@@ -108,3 +108,110 @@ def test_ffd_block_reproduces_surface_control_points():
     assert np.abs(np.asarray(D.sum(1)).ravel() - 1.0).max() < 1e-12
     flat = create_3D_block([2, 2, 1], 2, [[0, 1], [0, 1], [0.5, 0.5]])    # degenerate direction gets thickened
     assert flat.knots[2][-1] > flat.knots[2][0]
+
+
+def _ffd_problem():
+    from goldfish_amd.nonmatching_opt import NonMatchingOptFFD
+    from goldfish_amd.utils.ffd_utils import create_3D_block
+    pb = NonMatchingOptFFD.from_spec(G.tbeam_2patch(4), klass=NonMatchingOptFFD)
+    pb.set_shopt_surf_inds_FFD([1, 2], [[0, 1], [0, 1]])
+    lims = [list(x) for x in pb.cpsurf_lims]
+    for f in range(3):
+        pad = 0.1 * max(lims[f][1] - lims[f][0], 1.0)
+        lims[f] = [lims[f][0] - pad, lims[f][1] + pad]
+    blk = create_3D_block([3, 2, 2], 2, lims)
+    pb.set_shopt_FFD(blk.knots, blk.control)
+    return pb, blk
+
+
+def test_ffd_constraint_maps_against_their_definitions():
+    """N2: align / pin / regularisation maps of the FFD block, checked against brute-force
+    constructions of their definitions (GOLDFISH/nonmatching_opt_ffd.py:691-883, 1034-1244)."""
+    pb, blk = _ffd_problem()
+    l, m, n = pb.shopt_cpffd_shape
+    dof = lambda i, j, k: i + j * l + k * l * m
+    # -- align: every full dof copies the design dof that has the aligned coordinates replaced by the side-0 layer
+    for field, dirs in [(2, [0]), (2, [1]), (0, [2]), (0, [1, 2]), (1, [0, 2]), (2, [0, 1])]:
+        free, D = pb.dCPaligndCPFFD(field, dirs, (l, m, n))
+        D = D.toarray()
+        assert D.shape == (l * m * n, len(free)) and sorted(free) == list(free)
+        for k in range(n):
+            for j in range(m):
+                for i in range(l):
+                    src = [i, j, k]
+                    for d in dirs:
+                        src[d] = 0
+                    row = D[dof(i, j, k)]
+                    assert row.sum() == 1.0 and row[free.index(dof(*src))] == 1.0
+    with pytest.raises(ValueError):
+        pb.dCPaligndCPFFD(1, [1], (l, m, n))
+    maps = pb.set_shopt_align_CPFFD([[0], None])
+    assert maps[0].shape == (l * m * n, m * n) and maps[1].shape == (l * m * n, l * m * n)
+    assert len(pb.shopt_init_cpffd_design[0]) == m * n
+    full = maps[0] @ pb.shopt_init_cpffd_design[0]                  # the undeformed block is already aligned along x for field y
+    assert np.allclose(full, pb.shopt_init_cpffd_full[0])
+    # -- pin: face j = 0 of field 1 (only design dofs survive), edge (i = l-1, k = 0) of field 2
+    pins = pb.set_shopt_pin_CPFFD([1, 0], [[0], [1]], [None, 2], [None, [0]])
+    want0 = sorted(d for d in (dof(i, 0, k) for i in range(l) for k in range(n)) if d in pb.shopt_cpffd_design_dof[0])
+    want1 = sorted(dof(l - 1, j, 0) for j in range(m))
+    assert pb.shopt_cpffd_pin_dof == [want0, want1] and pb.pin_field == [1, 2]
+    for fi in range(2):
+        P = pins[fi].toarray()
+        des = pb.shopt_cpffd_design_dof[fi]
+        assert P.shape == (len(pb.shopt_cpffd_pin_dof[fi]), len(des))
+        x = np.arange(len(des), dtype=float)
+        assert np.array_equal(P @ x, [des.index(d) for d in pb.shopt_cpffd_pin_dof[fi]])
+        assert np.allclose(pb.shopt_pin_vals[fi], pb.shopt_cpffd_flat[:, pb.opt_field[fi]][pb.shopt_cpffd_pin_dof[fi]])
+    # -- regularisation: neighbour differences along the optimised coordinate on the reduced lattice
+    regs = pb.set_shopt_regu_CPFFD()
+    R0 = regs[0].toarray()                                          # field 1, aligned along 0 -> lattice (1, m, n)
+    rows = [(dof0, dof0 + 1) for i in range(1) for j in range(m - 1) for k in range(n) for dof0 in [i + j * 1 + k * 1 * m]]
+    assert R0.shape == (len(rows), m * n)
+    for r, (a, b) in enumerate(rows):
+        assert R0[r, a] == -1.0 and R0[r, b] == 1.0 and np.abs(R0[r]).sum() == 2.0
+    R1 = regs[1].toarray()                                          # field 2, no alignment
+    rows = [(dof(i, j, k), dof(i, j, k + 1)) for i in range(l) for j in range(m) for k in range(n - 1)]
+    assert R1.shape == (len(rows), l * m * n)
+    for r, (a, b) in enumerate(rows):
+        assert R1[r, a] == -1.0 and R1[r, b] == 1.0
+    z = pb.shopt_init_cpffd_design[1]
+    assert (regs[1] @ z > 0).all()                                   # an undeformed block is not folded
+
+
+def test_thickness_ffd_maps_and_design_components():
+    """N2: thickness FFD (nonmatching_opt_ffd.py:434-532, 915-997) and the constant-map components run through
+    the OpenMDAO protocol shim: outputs, declared sparsity and partials."""
+    from goldfish_amd import om_shim
+    from goldfish_amd.om_comps.ffd_comps import (CPFFDesign2FullComp, CPFFDPinComp, CPFFDReguComp, HthFFD2FEComp,
+                                                 HthFFDAlignComp, HthFFDReguComp, HthMapComp)
+    from goldfish_amd.utils.ffd_utils import create_3D_block
+    pb, blk = _ffd_problem()
+    pb.set_shopt_align_CPFFD([[0], None])
+    pb.set_shopt_pin_CPFFD([1, 0], [[0], [1]], [None, 2], [None, [0]])
+    pb.set_shopt_regu_CPFFD()
+    pb.set_thopt_surf_inds_FFD([0, 1])
+    lims = [[a - 0.1 * max(b - a, 1.0), b + 0.1 * max(b - a, 1.0)] for a, b in pb.thopt_cpsurf_des_lims]
+    tb = create_3D_block([2, 2, 1], 2, lims)
+    A = pb.set_thopt_FFD(tb.knots, tb.control)
+    h0 = pb.get_init_h_th_FFD()
+    assert np.allclose(A @ h0, np.concatenate(pb.h_th)[pb._thopt_cols], atol=1e-12)      # a constant field is reproduced
+    l, m, n = pb.thopt_cpffd_shape
+    Al = pb.set_thopt_align_CPFFD([2]).toarray()
+    assert Al.shape == (l * m * (n - 1), l * m * n) and np.abs(Al.sum(1)).max() == 0.0 and np.abs(Al @ np.ones(l * m * n)).max() == 0.0
+    Rg = pb.set_thopt_regu_CPFFD([None], [None])[0].toarray()
+    assert Rg.shape == (l * m * (n - 1), l * m * n) and pb.thopt_cpregu_sizes == [l * m * (n - 1)]
+    Rf = pb.set_thopt_regu_CPFFD([0], [1])[0].toarray()                                  # only the face i = l-1
+    assert Rf.shape == (m * (n - 1), l * m * n) and set(np.nonzero(Rf)[1] % l) == {l - 1}
+    for comp, key in [(CPFFDesign2FullComp(nonmatching_opt_ffd=pb), None), (CPFFDPinComp(nonmatching_opt_ffd=pb), None),
+                      (CPFFDReguComp(nonmatching_opt_ffd=pb), None), (HthFFD2FEComp(nonmatching_opt_ffd=pb), None),
+                      (HthFFDAlignComp(nonmatching_opt_ffd=pb), None), (HthFFDReguComp(nonmatching_opt_ffd=pb), None),
+                      (HthMapComp(nonmatching_opt=pb), None)]:
+        comp.init_parameters()
+        prob = om_shim.Problem(model=comp)
+        prob.setup()
+        prob.run_model()
+        errs = prob.check_partials(step=1e-3)
+        assert errs and max(errs.values()) < 1e-9, (type(comp).__name__, errs)
+    hm = HthMapComp(nonmatching_opt=pb)
+    hm.init_parameters()
+    assert hm.deriv.shape == (pb.vec_scalar_iga_dof, pb.num_splines) and np.allclose(hm.deriv @ hm.init, np.concatenate(pb.h_th))
