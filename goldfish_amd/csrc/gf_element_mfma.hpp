@@ -63,9 +63,8 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     const int tid = threadIdx.x, x = tid & 15, kk = tid >> 4;
     const long long e = (long long)e_first + blockIdx.x;
     if (e >= M.nelem) return;
-    const PatchDev& Pt = M.patches[M.elem_patch[e]];
-    const int le = int(e - Pt.elem_off), eu = le % Pt.nelu, ev = le / Pt.nelu;
-    const int iu0 = M.ints[Pt.spu + eu] - P, iv0 = M.ints[Pt.spv + ev] - P;
+    const ElemDesc ed = M.edesc[e];
+    const PatchDev& Pt = M.patches[ed.patch];
 
     __shared__ __attribute__((aligned(16))) double s_g[4 * ND];     // control-point staging (phases 0-1), residual reduction at the end
     double (*s_c)[3] = reinterpret_cast<double (*)[3]>(s_g);
@@ -79,17 +78,35 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     tstamp = clock64();
 #endif
-    // ---- phase 0: stage control-point data and 1-D tables ------------------------------------
+    // ---- phase 0: stage control-point data and 1-D tables (the loads are issued first; the lane constants of the row
+    //      expansion further down do not depend on them)
+    double4 c4 = {0, 0, 0, 0}; double ux = 0, uy = 0, uz = 0, hh = 0, ttu = 0, ttv = 0, twu = 0, twv = 0;
     if (tid < NB) {
-        const long long g = Pt.cp_off + (iu0 + tid % P1) + (long long)(iv0 + tid / P1) * Pt.nu;
-        const double4 c4 = reinterpret_cast<const double4*>(M.cp4)[g];
-        const double ux = M.u[3 * g], uy = M.u[3 * g + 1], uz = M.u[3 * g + 2];
+        const long long g = ed.g0 + (tid % P1) + (long long)(tid / P1) * ed.nu;
+        c4 = reinterpret_cast<const double4*>(M.cp4)[g];
+        ux = M.u[3 * g]; uy = M.u[3 * g + 1]; uz = M.u[3 * g + 2];
+        hh = M.h[g];
+    }
+    if (tid < P1 * 3 * P1) { ttu = M.tab[ed.tabu + tid]; ttv = M.tab[ed.tabv + tid]; }
+    if (tid < P1) { twu = M.tab[ed.wu + tid]; twv = M.tab[ed.wv + tid]; }
+    // ---- lane constants of the row expansion: lane x < 15 expands row r = x = 3 m_r + i_r of G = Pzz and Hc = Pzz + PzZ
+    const bool tang = x < 6, curv = x >= 6 && x < 15;
+    const int r = x < 15 ? x : 14, mr = r / 3, ir = r - 3 * mr;
+    const int kr = mr >= 2 ? mr - 2 : 0;                                      // curvature component of a curvature row
+    const double m0 = (mr == 0) ? 1.0 : 0.0, m1 = (mr == 1) ? 1.0 : 0.0, f3k = (kr == 2) ? 2.0 : 1.0;
+    const double dij[3] = {ir == 0 ? 1.0 : 0.0, ir == 1 ? 1.0 : 0.0, ir == 2 ? 1.0 : 0.0};
+    const int oE2 = IM_G + (tang ? 3 * (1 - mr) + ir : 0);
+    const int oJ0 = IM_JNV + (mr == 0 ? 0 : 2), oJ1 = IM_JNV + (mr == 1 ? 1 : 2);
+    int oHM[6];
+    for (int s = 0; s < 6; ++s) oHM[s] = IM_HMN + hmn_idx(tang ? r : 0, s);
+    const int oCT[3] = {IM_CT3 + sym3(kr, 0), IM_CT3 + sym3(kr, 1), IM_CT3 + sym3(kr, 2)};
+    if (tid < NB) {
         s_c[tid][0] = c4.x; s_c[tid][1] = c4.y; s_c[tid][2] = c4.z; s_w[tid] = c4.w;
         s_d[tid][0] = c4.x + ux; s_d[tid][1] = c4.y + uy; s_d[tid][2] = c4.z + uz;
-        s_h[tid] = M.h[g];
+        s_h[tid] = hh;
     }
-    if (tid < P1 * 3 * P1) { s_tu[tid] = M.tab[Pt.tabu + eu * P1 * 3 * P1 + tid]; s_tv[tid] = M.tab[Pt.tabv + ev * P1 * 3 * P1 + tid]; }
-    if (tid < P1) { s_wg[tid] = M.tab[Pt.wu + eu * P1 + tid]; s_wg[P1 + tid] = M.tab[Pt.wv + ev * P1 + tid]; }
+    if (tid < P1 * 3 * P1) { s_tu[tid] = ttu; s_tv[tid] = ttv; }
+    if (tid < P1) { s_wg[tid] = twu; s_wg[P1 + tid] = twv; }
     wave_lds_sync();
     GF_STAMP(0, tstamp);
 
@@ -139,17 +156,6 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     wave_lds_sync();
     GF_STAMP(1, tstamp);
 
-    // ---- lane constants of the row expansion: lane x < 15 expands row r = x = 3 m_r + i_r of G = Pzz and Hc = Pzz + PzZ
-    const bool tang = x < 6, curv = x >= 6 && x < 15;
-    const int r = x < 15 ? x : 14, mr = r / 3, ir = r - 3 * mr;
-    const int kr = mr >= 2 ? mr - 2 : 0;                                      // curvature component of a curvature row
-    const double m0 = (mr == 0) ? 1.0 : 0.0, m1 = (mr == 1) ? 1.0 : 0.0, f3k = (kr == 2) ? 2.0 : 1.0;
-    const double dij[3] = {ir == 0 ? 1.0 : 0.0, ir == 1 ? 1.0 : 0.0, ir == 2 ? 1.0 : 0.0};
-    const int oE2 = IM_G + (tang ? 3 * (1 - mr) + ir : 0);
-    const int oJ0 = IM_JNV + (mr == 0 ? 0 : 2), oJ1 = IM_JNV + (mr == 1 ? 1 : 2);
-    int oHM[6];
-    for (int s = 0; s < 6; ++s) oHM[s] = IM_HMN + hmn_idx(tang ? r : 0, s);
-    const int oCT[3] = {IM_CT3 + sym3(kr, 0), IM_CT3 + sym3(kr, 1), IM_CT3 + sym3(kr, 2)};
     const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = (flags & GF_ASM_C_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
     const bool has_bf = (Pt.f[0] != 0.0) || (Pt.f[1] != 0.0) || (Pt.f[2] != 0.0);
     const int ju = x % P1, jv = x / P1;

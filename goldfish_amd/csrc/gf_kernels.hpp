@@ -18,6 +18,7 @@ namespace gf {
 struct DevModel {
     const PatchDev* patches; const double* tab; const int* ints; const int* elem_patch; const int* cp_patch;
     const double* cp4; const double* u; const double* h; const unsigned char* zero;
+    const ElemDesc* edesc;           // per-element descriptors (MFMA element kernel)
     const unsigned char* pen_row;    // 1: the control point owns penalty rows (pen_owner_kernel writes them before the gather adds the shell part)
     const long long* nb_ptr_s; const int* nb_s; const long long* nb_ptr_c; const int* nb_c;
     long long total_cp, nelem;

@@ -31,6 +31,9 @@ struct PatchDev {            // POD mirrored on the device
     double E, nu_, f[3];
 };
 
+// per-element descriptor: one load instead of the elem_patch -> patch -> span-table chain of dependent scalar loads
+struct ElemDesc { int patch, g0, nu, tabu, tabv, wu, wv, pad; };   // g0: global id of the element's first control point; offsets into tab[]
+
 struct PenRowItem { int a, code, lo, hi; };           // code = iface*2 + s
 // one (owned control point, mortar vertex) visit of the penalty row kernel: everything the kernel needs to address the
 // vertex record and both support windows without dependent index loads
@@ -98,6 +101,7 @@ struct HostModel {
     std::vector<double> tab;            // 1-D tables
     std::vector<int> ints;              // spans + cp->element ranges
     std::vector<int> elem_patch;        // [nelem]
+    std::vector<ElemDesc> elem_desc;    // [nelem]
     std::vector<int> cp_patch;          // [total_cp]
     std::vector<double> weights;
     std::vector<unsigned char> zero;    // [ndof]
@@ -170,6 +174,16 @@ inline void HostModel::build(const gf_model_desc* D) {
     if (nelem >= (int64_t(1) << 31)) throw std::runtime_error("gf_create: too many elements");
     elem_patch.resize(nelem);
     for (int s = 0; s < np; ++s) std::fill(elem_patch.begin() + patches[s].elem_off, elem_patch.begin() + patches[s].elem_off + int64_t(patches[s].nelu) * patches[s].nelv, s);
+    elem_desc.resize(nelem);
+    for (int s = 0; s < np; ++s) {
+        const PatchDev& P = patches[s];
+        const int p1 = P.p + 1, q1 = P.q + 1;
+        for (int ev = 0; ev < P.nelv; ++ev) for (int eu = 0; eu < P.nelu; ++eu) {
+            const int iu0 = ints[P.spu + eu] - P.p, iv0 = ints[P.spv + ev] - P.q;
+            elem_desc[P.elem_off + eu + int64_t(ev) * P.nelu] = {s, int(P.cp_off + iu0 + int64_t(iv0) * P.nu), P.nu, P.tabu + eu * p1 * 3 * p1, P.tabv + ev * q1 * 3 * q1,
+                                                                  P.wu + eu * p1, P.wv + ev * q1, 0};
+        }
+    }
     zero.assign(ndof, 0);
     for (int64_t k = 0; k < D->n_zero_dofs; ++k) {
         if (D->zero_dofs[k] < 0 || D->zero_dofs[k] >= ndof) throw std::runtime_error("gf_create: zero_dofs out of range");
