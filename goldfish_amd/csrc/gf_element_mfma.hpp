@@ -89,17 +89,23 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     }
     if (tid < P1 * 3 * P1) { ttu = M.tab[ed.tabu + tid]; ttv = M.tab[ed.tabv + tid]; }
     if (tid < P1) { twu = M.tab[ed.wu + tid]; twv = M.tab[ed.wv + tid]; }
-    // ---- lane constants of the row expansion: lane x < 15 expands row r = x = 3 m_r + i_r of G = Pzz and Hc = Pzz + PzZ
-    const bool tang = x < 6, curv = x >= 6 && x < 15;
+    // ---- lane constants of the row expansion: lane x < 15 expands row r = x = 3 m_r + i_r of G = Pzz and Hc = Pzz + PzZ.
+    //      Tangent rows (r < 6) and curvature rows share ONE code path: the closed forms have the same shape
+    //          G[r][s]  = sum_k e_k(r) CEZ[k][s] + b_k(r) CBG[k][s] - X(r,s) + delta      (tangent columns s < 6)
+    //          PzZ[r][s] = Pz[r] JZJ[s] + sum_k e_k(r) JDNV[k][s] - b_k(r) JDMO[k][s]
+    //      with e_k = 0, b_k = f_k n_i delta_{k,k_r}, X = Jmo_k dn_i/dg_s on curvature rows (kl_point.hpp ez_entry/bz_entry),
+    //      so the row type only selects lane-constant masks and offsets -- no divergent branches.
+    const bool tang = x < 6;
     const int r = x < 15 ? x : 14, mr = r / 3, ir = r - 3 * mr;
-    const int kr = mr >= 2 ? mr - 2 : 0;                                      // curvature component of a curvature row
-    const double m0 = (mr == 0) ? 1.0 : 0.0, m1 = (mr == 1) ? 1.0 : 0.0, f3k = (kr == 2) ? 2.0 : 1.0;
-    const double dij[3] = {ir == 0 ? 1.0 : 0.0, ir == 1 ? 1.0 : 0.0, ir == 2 ? 1.0 : 0.0};
+    const int kr = mr >= 2 ? mr - 2 : 0, rt = tang ? r : 0;                   // curvature component of a curvature row; tangent row index (clamped)
+    const double mt = tang ? 1.0 : 0.0, m0 = (mr == 0) ? 1.0 : 0.0, m1 = (mr == 1) ? 1.0 : 0.0;
+    const double f3c = tang ? 0.0 : ((kr == 2) ? 2.0 : 1.0);
+    const double ck[3] = {(!tang && kr == 0) ? 1.0 : 0.0, (!tang && kr == 1) ? 1.0 : 0.0, (!tang && kr == 2) ? 1.0 : 0.0};
+    const double dij[3] = {(tang && ir == 0) ? 1.0 : 0.0, (tang && ir == 1) ? 1.0 : 0.0, (tang && ir == 2) ? 1.0 : 0.0};
     const int oE2 = IM_G + (tang ? 3 * (1 - mr) + ir : 0);
     const int oJ0 = IM_JNV + (mr == 0 ? 0 : 2), oJ1 = IM_JNV + (mr == 1 ? 1 : 2);
-    int oHM[6];
-    for (int s = 0; s < 6; ++s) oHM[s] = IM_HMN + hmn_idx(tang ? r : 0, s);
-    const int oCT[3] = {IM_CT3 + sym3(kr, 0), IM_CT3 + sym3(kr, 1), IM_CT3 + sym3(kr, 2)};
+    int oX[6];
+    for (int s = 0; s < 6; ++s) oX[s] = tang ? IM_HMN + hmn_idx(r, s) : IM_DN + 6 * ir + s;
     if (tid < NB) {
         s_c[tid][0] = c4.x; s_c[tid][1] = c4.y; s_c[tid][2] = c4.z; s_w[tid] = c4.w;
         s_d[tid][0] = c4.x + ux; s_d[tid][1] = c4.y + uy; s_d[tid][2] = c4.z + uz;
@@ -187,41 +193,28 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
         double gR[15], hR[15];                     // row r of G and Hc; entry (m', j) at [3 m' + j]
         for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
         if (doK || doC) {
-            if (tang) {
-                const double gr = im[IM_G + r], e0 = m0 * gr, e1 = m1 * gr, e2 = im[oE2];
-                const double b0 = im[IM_BG + r], b1 = im[IM_BG + 6 + r], b2 = im[IM_BG + 12 + r], pzr = im[IM_PZ + r];
-                const double jn[2] = {im[oJ0], im[oJ1]};
+            const double gr = im[IM_G + rt], e0 = m0 * gr, e1 = m1 * gr, e2 = mt * im[oE2];
+            const double fnr = f3c * im[IM_N + ir];
+            const double b0 = mt * im[IM_BG + rt] + ck[0] * fnr, b1 = mt * im[IM_BG + 6 + rt] + ck[1] * fnr, b2 = mt * im[IM_BG + 12 + rt] + ck[2] * fnr;
+            const double pzr = im[IM_PZ + r], xfac = mt + (1.0 - mt) * im[IM_JMOF + kr];
+            const double jn[2] = {im[oJ0], im[oJ1]};
 #pragma unroll
-                for (int s = 0; s < 6; ++s) {
-                    const double g = e0 * im[IM_CEZ + s] + e1 * im[IM_CEZ + 6 + s] + e2 * im[IM_CEZ + 12 + s]
-                                   + b0 * im[IM_CBG + s] + b1 * im[IM_CBG + 6 + s] + b2 * im[IM_CBG + 12 + s] - im[oHM[s]] + dij[s % 3] * jn[s / 3];
-                    const double zz = pzr * im[IM_JZJ + s] + e0 * im[IM_JDNV + s] + e1 * im[IM_JDNV + 6 + s] + e2 * im[IM_JDNV + 12 + s]
-                                    - (b0 * im[IM_JDMO + s] + b1 * im[IM_JDMO + 6 + s] + b2 * im[IM_JDMO + 12 + s]);
-                    gR[s] = g; hR[s] = g + zz;
-                }
+            for (int s = 0; s < 6; ++s) {
+                const double g = e0 * im[IM_CEZ + s] + e1 * im[IM_CEZ + 6 + s] + e2 * im[IM_CEZ + 12 + s]
+                               + b0 * im[IM_CBG + s] + b1 * im[IM_CBG + 6 + s] + b2 * im[IM_CBG + 12 + s] - xfac * im[oX[s]] + dij[s % 3] * jn[s / 3];
+                const double zz = pzr * im[IM_JZJ + s] + e0 * im[IM_JDNV + s] + e1 * im[IM_JDNV + 6 + s] + e2 * im[IM_JDNV + 12 + s]
+                                - (b0 * im[IM_JDMO + s] + b1 * im[IM_JDMO + 6 + s] + b2 * im[IM_JDMO + 12 + s]);
+                gR[s] = g; hR[s] = g + zz;
+            }
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {                                       // curvature columns (c, jj)
-                    const double fc = (c == 2) ? 2.0 : 1.0;
-                    const double cbg = fc * im[IM_CBG + 6 * c + r], jm = im[IM_JMOF + c];
-                    const double bt = fc * (b0 * im[IM_CT3 + sym3(0, c)] + b1 * im[IM_CT3 + sym3(1, c)] + b2 * im[IM_CT3 + sym3(2, c)]);
+            for (int c = 0; c < 3; ++c) {                                       // curvature columns (c, jj)
+                const double fc = (c == 2) ? 2.0 : 1.0;
+                const double gam = fc * (b0 * im[IM_CT3 + sym3(0, c)] + b1 * im[IM_CT3 + sym3(1, c)] + b2 * im[IM_CT3 + sym3(2, c)]);
+                const double alpha = mt * (fc * im[IM_CBG + 6 * c + rt]) + (1.0 - mt) * gam, beta = mt * im[IM_JMOF + c];
 #pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) {
-                        const double g = im[IM_N + jj] * cbg - jm * im[IM_DN + 6 * jj + r];
-                        gR[6 + 3 * c + jj] = g; hR[6 + 3 * c + jj] = g - bt * im[IM_NB + jj];
-                    }
-                }
-            } else if (curv) {
-                const double fn = f3k * im[IM_N + ir], pzr = im[IM_PZ + r], jm = im[IM_JMOF + kr];
-#pragma unroll
-                for (int s = 0; s < 6; ++s) {
-                    const double g = fn * im[IM_CBG + 6 * kr + s] - jm * im[IM_DN + 6 * ir + s];
-                    gR[s] = g; hR[s] = g + pzr * im[IM_JZJ + s] - fn * im[IM_JDMO + 6 * kr + s];
-                }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const double cc = fn * ((c == 2) ? 2.0 : 1.0) * im[oCT[c]];
-#pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) { const double nj = im[IM_N + jj]; gR[6 + 3 * c + jj] = cc * nj; hR[6 + 3 * c + jj] = cc * (nj - im[IM_NB + jj]); }
+                for (int jj = 0; jj < 3; ++jj) {
+                    const double g = im[IM_N + jj] * alpha - beta * im[IM_DN + 6 * jj + rt];
+                    gR[6 + 3 * c + jj] = g; hR[6 + 3 * c + jj] = g - gam * im[IM_NB + jj];
                 }
             }
             GF_STAMP(4, tstamp);
