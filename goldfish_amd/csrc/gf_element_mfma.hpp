@@ -116,48 +116,60 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     wave_lds_sync();
     GF_STAMP(0, tstamp);
 
-    // ---- phase 1: one lane per Gauss point: kinematics + pointwise closed forms ----------------
-    if (tid < NG) {
-        const int gu = tid % P1, gv = tid / P1;
-        // sum factorisation over the tensor-product basis: for every row jv of control points first the three
-        // u-sums (derivative orders 0, 1, 2), then the six (du, dv) combinations; the rational derivatives follow from
-        // the sums by the quotient rule (rationalize6 is linear in the B-spline values)
-        double Ac[3][6], Ad[3][6], W[6], t = 0.0;
-        for (int k = 0; k < 6; ++k) { W[k] = 0.0; for (int i = 0; i < 3; ++i) { Ac[i][k] = 0.0; Ad[i][k] = 0.0; } }
-        double U[3][P1];
-        for (int d = 0; d < 3; ++d) for (int j = 0; j < P1; ++j) U[d][j] = s_tu[(gu * 3 + d) * P1 + j];
+    // ---- phase 1: three lanes per Gauss point (gp = x, part ic = kk < 3): kinematics + pointwise closed forms --------
+    // Lane (gp, ic) sums component ic of the reference and deformed control points (sum factorisation over the tensor-product
+    // basis: per row jv of control points the three u-sums, then the six (du, dv) combinations; the rational derivatives
+    // follow by the quotient rule, rationalize6 being linear in the B-spline values), the three lanes exchange their
+    // components through the Gauss point's (not yet written) record, and each produces the record columns c = ic, 3 + ic.
+    {
+        const int gp = x, ic = kk < 3 ? kk : 0, gu = gp % P1, gv = gp / P1;
+        const bool act = kk < 3;
+        double* im = s_im[gp];
+        double W[6], t = 0.0;
+        if (act) {
+            double Ac[6], Ad[6];
+            for (int k = 0; k < 6; ++k) { W[k] = 0.0; Ac[k] = 0.0; Ad[k] = 0.0; }
+            double U[3][P1];
+            for (int d = 0; d < 3; ++d) for (int j = 0; j < P1; ++j) U[d][j] = s_tu[(gu * 3 + d) * P1 + j];
 #pragma unroll
-        for (int jv = 0; jv < P1; ++jv) {
-            const double v0 = s_tv[(gv * 3 + 0) * P1 + jv], v1 = s_tv[(gv * 3 + 1) * P1 + jv], v2 = s_tv[(gv * 3 + 2) * P1 + jv];
-            double S[7][3], Sh = 0.0;
-            for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) S[q][d] = 0.0;
+            for (int jv = 0; jv < P1; ++jv) {
+                const double v0 = s_tv[(gv * 3 + 0) * P1 + jv], v1 = s_tv[(gv * 3 + 1) * P1 + jv], v2 = s_tv[(gv * 3 + 2) * P1 + jv];
+                double S[3][3], Sh = 0.0;
+                for (int q = 0; q < 3; ++q) for (int d = 0; d < 3; ++d) S[q][d] = 0.0;
 #pragma unroll
-            for (int ju = 0; ju < P1; ++ju) {
-                const int a = ju + P1 * jv;
-                const double qv[7] = {s_c[a][0], s_c[a][1], s_c[a][2], s_d[a][0], s_d[a][1], s_d[a][2], s_w[a]};
-                for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) S[q][d] += U[d][ju] * qv[q];
-                Sh += U[0][ju] * s_h[a];
+                for (int ju = 0; ju < P1; ++ju) {
+                    const int a = ju + P1 * jv;
+                    const double qv[3] = {s_c[a][ic], s_d[a][ic], s_w[a]};
+                    for (int q = 0; q < 3; ++q) for (int d = 0; d < 3; ++d) S[q][d] += U[d][ju] * qv[q];
+                    Sh += U[0][ju] * s_h[a];
+                }
+                t += v0 * Sh;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    double* A = q == 0 ? Ac : (q == 1 ? Ad : W);
+                    A[0] += v0 * S[q][0]; A[1] += v0 * S[q][1]; A[2] += v1 * S[q][0];
+                    A[3] += v0 * S[q][2]; A[4] += v2 * S[q][0]; A[5] += v1 * S[q][1];
+                }
             }
-            t += v0 * Sh;
-#pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                double* A = q < 3 ? Ac[q] : (q < 6 ? Ad[q - 3] : W);
-                A[0] += v0 * S[q][0]; A[1] += v0 * S[q][1]; A[2] += v1 * S[q][0];
-                A[3] += v0 * S[q][2]; A[4] += v2 * S[q][0]; A[5] += v1 * S[q][1];
+            W[0] = 1.0 / W[0];
+            double R[6];
+            rationalize6(Ac, W, R);
+            for (int mm = 0; mm < 5; ++mm) im[3 * mm + ic] = R[mm + 1];
+            rationalize6(Ad, W, R);
+            for (int mm = 0; mm < 5; ++mm) im[15 + 3 * mm + ic] = R[mm + 1];
+        }
+        wave_lds_sync();
+        double z[15], Z[15];
+        if (act) for (int k = 0; k < 15; ++k) { Z[k] = im[k]; z[k] = im[15 + k]; }
+        wave_lds_sync();                                   // all three lanes hold z, Z before the record overwrites the exchange slots
+        if (act) {
+            const double dsel[3] = {ic == 0 ? 1.0 : 0.0, ic == 1 ? 1.0 : 0.0, ic == 2 ? 1.0 : 0.0};
+            shell_point_cols(z, Z, t, Pt.E, Pt.nu_, ic, dsel, kk == 0, im);
+            if (kk == 0) {
+                for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
+                im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
             }
         }
-        W[0] = 1.0 / W[0];
-        double z[15], Z[15], R[6];
-        for (int i = 0; i < 3; ++i) {
-            rationalize6(Ac[i], W, R);
-            for (int m = 0; m < 5; ++m) Z[3 * m + i] = R[m + 1];
-            rationalize6(Ad[i], W, R);
-            for (int m = 0; m < 5; ++m) z[3 * m + i] = R[m + 1];
-        }
-        double* im = s_im[tid];
-        shell_point(z, Z, t, Pt.E, Pt.nu_, im);
-        for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
-        im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
     }
     wave_lds_sync();
     GF_STAMP(1, tstamp);

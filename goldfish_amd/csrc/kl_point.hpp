@@ -185,6 +185,95 @@ GF_HD inline void shell_point(const double* z, const double* Z, double t, double
     }
 }
 
+// shell_point split by columns: every record array indexed by a tangent column c = 0..5 (d/dg1_i for c = i, d/dg2_i for
+// c = 3 + i) is produced for the two columns c = ic and c = 3 + ic only; the three callers ic = 0, 1, 2 (three lanes of the
+// MFMA element kernel, which run this code in lock-step) fill the whole record.  d[i] = delta(i, ic) selects components
+// arithmetically (no register-array indexing by ic).  The scalar part is computed by every caller (same instruction
+// stream on the GPU) and written by the caller with lead = true.  Same formulas as shell_point above.
+GF_HD inline void shell_point_cols(const double* z, const double* Z, double t, double E, double nu, int ic, const double* d, bool lead, double* im) {
+    const double f3[3] = {1.0, 1.0, 2.0};
+    double nt[3], n[3], Nt[3], N[3];
+    cross3(z, z + 3, nt); const double j = sqrt(dot3(nt, nt)), ij = 1.0 / j;
+    cross3(Z, Z + 3, Nt); const double Jn = sqrt(dot3(Nt, Nt)), iJn = 1.0 / Jn;
+    for (int k = 0; k < 3; ++k) { n[k] = nt[k] * ij; N[k] = Nt[k] * iJn; }
+    double C[6], dC[3][6], J;
+    material(Z, Z + 3, E, nu, C, dC, J);
+    double eps[3], kap[3];
+    eps[0] = 0.5 * (dot3(z, z) - dot3(Z, Z));
+    eps[1] = 0.5 * (dot3(z + 3, z + 3) - dot3(Z + 3, Z + 3));
+    eps[2] = dot3(z, z + 3) - dot3(Z, Z + 3);
+    for (int k = 0; k < 3; ++k) kap[k] = f3[k] * (dot3(Z + 6 + 3 * k, N) - dot3(z + 6 + 3 * k, n));
+    const double t3 = t * t * t / 12.0;
+    double Ce[3], Ck[3], nv[3], mo[3];
+    symmv(C, eps, Ce); symmv(C, kap, Ck);
+    for (int k = 0; k < 3; ++k) { nv[k] = t * Ce[k]; mo[k] = t3 * Ck[k]; }
+    if (lead) {
+        im[IM_J] = J;
+        for (int c = 0; c < 6; ++c) im[IM_G + c] = z[c];
+        for (int k = 0; k < 3; ++k) { im[IM_N + k] = n[k]; im[IM_NB + k] = N[k]; im[IM_JNV + k] = J * nv[k]; im[IM_JMOF + k] = J * mo[k] * f3[k]; im[IM_JCE + k] = J * Ce[k]; im[IM_JCK4 + k] = J * 0.25 * t * t * Ck[k]; }
+        for (int k = 0; k < 6; ++k) im[IM_CT3 + k] = J * t3 * C[k];
+        for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) im[IM_PZ + 6 + 3 * k + i] = -J * mo[k] * f3[k] * n[i];
+    }
+    // quantities shared by the two columns
+    double JZ[6];
+    cross3(Z + 3, N, JZ); cross3(N, Z, JZ + 3);
+    double dCe[3][3], dCk[3][3];
+    for (int q = 0; q < 3; ++q) { symmv(dC[q], eps, dCe[q]); symmv(dC[q], kap, dCk[q]); }
+    double M[3];
+    for (int i = 0; i < 3; ++i) M[i] = mo[0] * z[6 + i] + mo[1] * z[9 + i] + 2.0 * mo[2] * z[12 + i];
+    const double Mn = dot3(M, n), ij2 = ij * ij;
+    double Q[3][3], v[3];
+    for (int a = 0; a < 3; ++a) {
+        v[a] = (M[a] - Mn * n[a]) * ij;
+        for (int b = 0; b < 3; ++b) Q[a][b] = -(M[a] * n[b] + n[a] * M[b] + Mn * ((a == b ? 1.0 : 0.0) - 3.0 * n[a] * n[b])) * ij2;
+    }
+    const double g1c = dot3(d, z), g2c = dot3(d, z + 3), G1c = dot3(d, Z), G2c = dot3(d, Z + 3);
+    // skew(v)[a][ic]: S = [[0,-v2,v1],[v2,0,-v0],[-v1,v0,0]]
+    const double Sic[3] = {d[1] * (-v[2]) + d[2] * v[1], d[0] * v[2] + d[2] * (-v[0]), d[0] * (-v[1]) + d[1] * v[0]};
+    for (int cc = 0; cc < 2; ++cc) {
+        const int c = ic + 3 * cc;
+        double col[3], COL[3];
+        if (cc == 0) { cross3(d, z + 3, col); cross3(d, Z + 3, COL); } else { cross3(z, d, col); cross3(Z, d, COL); }
+        const double nc = dot3(n, col), NC = dot3(N, COL);
+        double Dn[3], DN[3];
+        for (int i = 0; i < 3; ++i) { Dn[i] = (col[i] - n[i] * nc) * ij; DN[i] = (COL[i] - N[i] * NC) * iJn; }
+        double ez[3], eZ[3], bg[3], bG[3];
+        if (cc == 0) { ez[0] = g1c; ez[1] = 0.0; ez[2] = g2c; eZ[0] = -G1c; eZ[1] = 0.0; eZ[2] = -G2c; }
+        else { ez[0] = 0.0; ez[1] = g2c; ez[2] = g1c; eZ[0] = 0.0; eZ[1] = -G2c; eZ[2] = -G1c; }
+        for (int k = 0; k < 3; ++k) {
+            bg[k] = f3[k] * dot3(z + 6 + 3 * k, Dn);
+            bG[k] = f3[k] * dot3(Z + 6 + 3 * k, DN);
+            im[IM_BG + 6 * k + c] = bg[k];
+        }
+        for (int i = 0; i < 3; ++i) im[IM_DN + 6 * i + c] = Dn[i];
+        double ca[3], cb[3];
+        symmv(C, ez, ca); symmv(C, bg, cb);
+        for (int k = 0; k < 3; ++k) { im[IM_CEZ + 6 * k + c] = J * t * ca[k]; im[IM_CBG + 6 * k + c] = J * t3 * cb[k]; }
+        double pe = 0, pb = 0;
+        for (int k = 0; k < 3; ++k) { pe += nv[k] * ez[k]; pb += mo[k] * bg[k]; }
+        im[IM_PZ + c] = J * (pe - pb);
+        im[IM_JZJ + c] = dot3(d, JZ + 3 * cc) / J;
+        const double a0 = cc == 0 ? 2 * G1c : 0.0, a1 = cc == 0 ? 0.0 : 2 * G2c, a2 = cc == 0 ? G2c : G1c;
+        double ce[3], cb2[3];
+        symmv(C, eZ, ce); symmv(C, bG, cb2);
+        for (int k = 0; k < 3; ++k) {
+            im[IM_JDNV + 6 * k + c] = J * t * (dCe[0][k] * a0 + dCe[1][k] * a1 + dCe[2][k] * a2 + ce[k]);
+            im[IM_JDMO + 6 * k + c] = J * t3 * (dCk[0][k] * a0 + dCk[1][k] * a1 + dCk[2][k] * a2 + cb2[k]);
+        }
+        // Hessian of M . n, column c, rows r <= c (symmetric storage): H[r][c] = Bc[r] . (Q Bc[c]) -+ skew(v)
+        double QB[3];
+        for (int a = 0; a < 3; ++a) QB[a] = Q[a][0] * col[0] + Q[a][1] * col[1] + Q[a][2] * col[2];
+        for (int r = 0; r < 6; ++r) {
+            double e[3] = {0, 0, 0}, Br[3];
+            e[r % 3] = 1.0;
+            if (r < 3) cross3(e, z + 3, Br); else cross3(z, e, Br);
+            double h = dot3(Br, QB);
+            if (cc == 1 && r < 3) h -= Sic[r];
+            if (r <= c) im[IM_HMN + 6 * r - r * (r - 1) / 2 - r + c] = J * h;
+        }
+    }
+}
+
 // ---- expansion of single entries of Pzz / PzZ from the intermediate record -----------
 GF_HD __forceinline__ double ez_entry(const double* im, int k, int r) {   // r < 6
     const int m = r / 3, i = r - 3 * m;

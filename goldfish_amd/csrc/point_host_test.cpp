@@ -8,6 +8,13 @@ void gfh_shell_point(const double* z, const double* Z, double t, double E, doubl
     for (int r = 0; r < 15; ++r) { Pz[r] = im[gf::IM_PZ + r]; Pzt[r] = gf::pzt_entry(im, r); }
     for (int r = 0; r < 15; ++r) for (int s = 0; s < 15; ++s) { Pzz[15 * r + s] = gf::pzz_entry(im, r, s); PzZ[15 * r + s] = gf::pzZ_entry(im, r, s); }
 }
+void gfh_shell_point_cols(const double* z, const double* Z, double t, double E, double nu, double* im) {
+    for (int k = 0; k < gf::IM_SIZE; ++k) im[k] = 0.0;
+    for (int ic = 0; ic < 3; ++ic) {
+        const double d[3] = {ic == 0 ? 1.0 : 0.0, ic == 1 ? 1.0 : 0.0, ic == 2 ? 1.0 : 0.0};
+        gf::shell_point_cols(z, Z, t, E, nu, ic, d, ic == 0, im);
+    }
+}
 void gfh_penalty_point(const double* y, const double* Y, const double* tau, double ad, double ar, double dt, double* out) {
     gf::penalty_point(y, Y, tau, ad, ar, dt, out);
 }

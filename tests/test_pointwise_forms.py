@@ -57,3 +57,39 @@ def test_penalty_point_closed_form(oracle_lib):
         assert np.abs(g - g2).max() < 1e-12 * np.abs(g2).max()
         assert np.abs(Hyy - Hyy2).max() < 1e-11 * np.abs(Hyy2).max()
         assert np.abs(HyY - HyY2).max() < 1e-11 * np.abs(HyY2).max()
+
+
+def _host_kernel_lib():
+    """kl_point.hpp (the header the HIP kernels include) compiled for the host: goldfish_amd/csrc/point_host_test.cpp."""
+    import ctypes as C
+    import os
+    from goldfish_amd import build
+    build.build()
+    return C.CDLL(os.path.join(os.path.dirname(build.__file__), "csrc", "libgf_point_host_test.so"))
+
+
+def test_kernel_header_pointwise_forms_on_host():
+    """The kernels' own closed forms (kl_point.hpp: shell_point + the entry expansions) against the numpy statement
+    of the formulation, and the column-split variant used by the MFMA element kernel against shell_point."""
+    import ctypes as C
+    L = _host_kernel_lib()
+    dp = C.POINTER(C.c_double)
+    L.gfh_shell_point.argtypes = [dp, dp, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp, dp]
+    L.gfh_shell_point_cols.argtypes = [dp, dp, C.c_double, C.c_double, C.c_double, dp]
+    L.gfh_sizes.restype = C.c_int
+    n = L.gfh_sizes(0)
+    P = lambda a: a.ctypes.data_as(dp)
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        z, Z = _rand_state(rng)
+        z, Z = np.ascontiguousarray(z.ravel()), np.ascontiguousarray(Z.ravel())
+        t, E, nu = 0.21 + 0.1 * trial, 2.5, 0.3
+        im, im2 = np.zeros(n), np.zeros(n)
+        Pzz, PzZ, Pz, Pzt = np.zeros((15, 15)), np.zeros((15, 15)), np.zeros(15), np.zeros(15)
+        L.gfh_shell_point(P(z), P(Z), t, E, nu, P(im), P(Pzz), P(PzZ), P(Pz), P(Pzt))
+        ref = kp.shell_point(z, Z, t, E, nu)
+        for name, got in (("Pz", Pz), ("Pzz", Pzz), ("PzZ", PzZ), ("Pzt", Pzt)):
+            assert np.abs(got - ref[name]).max() < 1e-12 * np.abs(ref[name]).max(), name
+        L.gfh_shell_point_cols(P(z), P(Z), t, E, nu, P(im2))
+        scale = np.abs(im).max()
+        assert np.abs(im2 - im).max() < 1e-13 * scale, np.argmax(np.abs(im2 - im))
