@@ -692,10 +692,13 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
     double racc = 0.0;                                  // tid < 3: residual entry (a, tid)
     const int iK = tid < 54 ? tid / 18 : 0, cK = tid < 54 ? tid - 18 * iK : 0, iC = tid < 36 ? tid / 12 : 0, cC = tid < 36 ? tid - 12 * iC : 0;
     int pair = 0;
+    PenEntry En[2];                                     // visits of the next iteration, fetched one iteration ahead
+    if (e0 < e1) { En[0] = Q.entries[e0]; En[1] = Q.entries[e0 + 1 < e1 ? e0 + 1 : e0]; }
     for (long long e = e0; e < e1; e += 2) {
         const int nu_ = (e + 1 < e1) ? 2 : 1;
         PenEntry E[2];
-        E[0] = Q.entries[e]; E[1] = Q.entries[e + nu_ - 1];
+        E[0] = En[0]; E[1] = En[1];
+        if (e + 2 < e1) { En[0] = Q.entries[e + 2]; En[1] = Q.entries[e + 3 < e1 ? e + 3 : e + 2]; }
         // -- all loads of the pair
         double n3[2][3], hk[2][3], hc[2][3], g3[2][3], bv[2][PEN_SL][3]; int tt[2][PEN_SL];
 #pragma unroll
