@@ -110,7 +110,7 @@ def main():
         D.assemble(_lib.ASM_ALL, sync=False)
         if exchange:
             D.sync()
-            sharding.allreduce_owned_rows(shard, R_loc, dist, 3, out=R_glob)
+            sharding.allgather_owned_rows(shard, R_loc, dist, 3, out=R_glob)
 
     def fence():
         D.sync()
@@ -183,7 +183,7 @@ def main():
                                    "%d dofs, %d Gauss points, %d mortar points; R+K+dRdCP(3)+dRdh incl. penalty coupling"
                                    % ("C4" if (args.patches == [16, 16] and args.nel == 48 and p == 3) else "custom", args.patches[0], args.patches[1], p, args.nel, 3 * shard.total_cp_global, n_gp_total,
                                       sum(i.npts for i in spec.interfaces)),
-                       "parallelism": "patch-sharded x%d, owner-computes-rows, all-reduce of the residual" % world},
+                       "parallelism": "patch-sharded x%d, owner-computes-rows, all-gather of the owned residual rows" % world},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms, "launches_timed": kern_n},

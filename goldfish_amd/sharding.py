@@ -44,6 +44,7 @@ class Shard:
     order: list                  # local patch index -> global patch index
     cp_off_global: np.ndarray    # global control-point offsets (all patches)
     cp_off_local: np.ndarray
+    patch_ranges: list = None    # (first, end) owned patch range of every rank
 
     @property
     def total_cp_global(self):
@@ -87,7 +88,7 @@ def shard_spec(spec, rank, world):
                         "%s[rank %d/%d]" % (spec.name, rank, world))
     cpg = np.concatenate([[0], np.cumsum([p.ncp for p in spec.patches])]).astype(np.int64)
     cpl = np.concatenate([[0], np.cumsum([p.ncp for p in local.patches])]).astype(np.int64)
-    return Shard(rank, world, local, len(own), order, cpg, cpl)
+    return Shard(rank, world, local, len(own), order, cpg, cpl, partition_patches(spec, world))
 
 
 def shard_arrays(shard, thickness_global=None):
@@ -116,6 +117,32 @@ def allreduce_owned_rows(shard, local_rows, dist, width=3, out=None):
     out[g0:g1] = local_rows[:g1 - g0]
     if shard.world > 1:
         dist.all_reduce(out)
+    return out
+
+
+def allgather_owned_rows(shard, local_rows, dist, width=3, out=None):
+    """Same result as allreduce_owned_rows with half the traffic: the owned row slices are disjoint and contiguous in the
+    global vector, so they are exchanged by ONE all-gather of slices padded to the largest one ((N-1)/N of the vector per
+    rank over xGMI instead of 2(N-1)/N for the ring all-reduce of a zero-padded vector) and copied into place."""
+    import torch
+    n = width * shard.total_cp_global
+    if out is None:
+        out = torch.zeros(n, dtype=torch.float64, device=local_rows.device)
+    rng = [(width * int(shard.cp_off_global[a]), width * int(shard.cp_off_global[b])) for (a, b) in shard.patch_ranges]
+    g0, g1 = rng[shard.rank]
+    if shard.world == 1:
+        out[g0:g1] = local_rows[:g1 - g0]
+        return out
+    mx = max(b - a for a, b in rng)
+    send = torch.zeros(mx, dtype=torch.float64, device=local_rows.device)
+    send[:g1 - g0] = local_rows[:g1 - g0]
+    recv = torch.empty(shard.world * mx, dtype=torch.float64, device=local_rows.device)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(recv, send)
+    else:
+        dist.all_gather(list(recv.view(shard.world, mx).unbind(0)), send)
+    for r, (a, b) in enumerate(rng):
+        out[a:b] = recv[r * mx:r * mx + (b - a)]
     return out
 
 

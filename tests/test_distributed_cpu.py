@@ -30,6 +30,8 @@ def _worker(rank, world, port, q):
     A = sharding.shard_arrays(sh, th)
     O = Oracle(A, thickness=sh.to_local(np.concatenate(th)), u=sh.to_local(u, 3))
     Rg = sharding.allreduce_owned_rows(sh, torch.from_numpy(O.residual()), dist, 3).numpy()
+    Rg2 = sharding.allgather_owned_rows(sh, torch.from_numpy(O.residual()), dist, 3).numpy()
+    assert np.array_equal(Rg, Rg2)                      # the all-gather of owned slices is the same exchange at half the traffic
     # reverse-mode product with remote columns: y = sum_ranks (dR/dCP_0 owned rows)^T lambda_owned
     lam = np.sin(np.arange(3 * sh.total_cp_global) * 0.37)
     C0 = O.csr(1, O.assemble(K=False, dRdCP=(0,), dRdh=False)[1])
