@@ -64,6 +64,11 @@ def test_assembly_parity(oracle_lib, case):
     assert _rel(D.residual(), O.residual()) < RTOL
     D.assemble(_lib.ASM_K)
     assert _rel(D.values(0), vals[0]) < RTOL
+    D.assemble(_lib.ASM_DRDCP)
+    for which in (1, 2, 3):
+        assert _rel(D.values(which), vals[which]) < RTOL, "dR/dCP-only pass, matrix %d" % which
+    D.assemble(_lib.ASM_DRDH)
+    assert _rel(D.values(4), vals[4]) < RTOL
     D.close()
 
 
