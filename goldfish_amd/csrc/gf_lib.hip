@@ -13,6 +13,7 @@ constexpr int GF_ASM_R_BIT = 1, GF_ASM_K_BIT = 2, GF_ASM_C_BIT = 4, GF_ASM_H_BIT
 #include "../../include/goldfish_hip.h"
 #include "gf_kernels.hpp"
 #include "gf_element_mfma.hpp"
+#include "gf_element_mfma4.hpp"
 
 using namespace gf;
 
@@ -233,6 +234,7 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
         const int slot = h->ev_n % 64;
         HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
         if (P == 3 && h->mfma) hipLaunchKernelGGL(kl_element_mfma_kernel, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+        else if (P == 4 && h->mfma) hipLaunchKernelGGL(kl_element_mfma4_kernel, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
         else hipLaunchKernelGGL(kl_element_kernel<P>, dim3((unsigned)ne), dim3(Cfg::NT), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
         HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
         h->ev_n++;
