@@ -72,6 +72,25 @@ def test_assembly_parity(oracle_lib, case):
     D.close()
 
 
+def test_valu_element_kernel_still_matches(oracle_lib, monkeypatch):
+    """The FP64-VALU element kernel (p = 2 always; p = 3, 4 with GF_ELEMENT=valu) stays a supported path."""
+    from goldfish_amd import _lib
+    from oracle.oracle_py import Oracle
+    monkeypatch.setenv("GF_ELEMENT", "valu")
+    for case in ("shell3x2_p3", "shell2x2_p4"):
+        A, h, u = _state(CASES[case]())
+        O = Oracle(A, thickness=h, u=u)
+        D = _lib.DeviceModel(A)
+        D.set_thickness(h)
+        D.set_u(u)
+        D.assemble(_lib.ASM_ALL)
+        assert _rel(D.residual(), O.residual()) < RTOL
+        vals = O.assemble()
+        for which in range(5):
+            assert _rel(D.values(which), vals[which]) < RTOL, (case, which)
+        D.close()
+
+
 def test_zero_state_and_reproducible(oracle_lib):
     """u = 0 (reference == deformed) and bitwise run-to-run reproducibility of the assembly
     (atomic-free owner gathers)."""

@@ -1,0 +1,14 @@
+import sys, time, numpy as np
+sys.path.insert(0, "/root/repo")
+from goldfish_amd import _lib, geometry as G
+from goldfish_amd.model import arrays_from_spec
+spec = G.synthetic_shell(16, 16, nel=48, p=3, jitter=2)
+th = G.random_thickness(spec)
+D = _lib.DeviceModel(arrays_from_spec(spec, th))
+D.set_thickness(np.concatenate(th)); D.set_u(G.smooth_displacement(spec, 0.5 * spec.h_th))
+for name, fn in (("functionals", lambda: D.functionals()), ("compliance", lambda: D.compliance(np.ones((256, 3))))):
+    fn(); D.sync()
+    t0 = time.perf_counter()
+    for _ in range(3): fn()
+    D.sync()
+    print(name, "%.2f ms per call (incl. host copies of the gradients)" % ((time.perf_counter() - t0) / 3 * 1e3))
