@@ -44,3 +44,21 @@ def test_hip_matches_golden(name):
     F = D.functionals()
     assert abs(F["Wint"] - g["Wint"]) < 1e-11 * abs(g["Wint"]) and _rel(F["dWdu"], g["dWdu"]) < 1e-10
     D.close()
+
+
+def test_iges_reader_on_the_reference_plate_geometry():
+    """N2: the minimal IGES-128 reader on the reference's own CAD file
+    (demos_csdl_alpha/thickness_opt/geometry/plate_geometry.igs, committed as data): six cubic B-spline
+    surfaces, identical (to the file's 9 digits) to the six-patch plate the parity fixtures are built on."""
+    import os
+    from goldfish_amd import geometry as G
+    from goldfish_amd.utils.iges import read_iges_surfaces
+    S = read_iges_surfaces(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_plate_geometry.igs"))
+    spec = G.plate_6patch()
+    assert len(S) == 6 == len(spec.patches)
+    for s, p in zip(S, spec.patches):
+        assert (s.p, s.q) == (p.p, p.q) == (3, 3) and s.control.shape == p.control.shape
+        assert np.abs(s.control - p.control).max() < 1e-8
+        for d in range(2):
+            assert np.abs(s.knots[d] - p.knots[d]).max() < 1e-8
+        assert np.abs(s.control[..., 3] - 1.0).max() == 0.0              # polynomial surfaces
