@@ -320,7 +320,8 @@ template <int P>
 __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_first, long long e_first, long long e_count, int flags,
                                                          const double* __restrict__ blk,
                                                          double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1,
-                                                         double* __restrict__ valC2, double* __restrict__ valH, double* __restrict__ R, int pen_add) {
+                                                         double* __restrict__ valC2, double* __restrict__ valH, double* __restrict__ R, int pen_add,
+                                                         const StripDesc* __restrict__ strips, const int* __restrict__ strip_off) {
     using Cfg = ElemCfg<P>;
     constexpr int P1 = Cfg::P1, NB = Cfg::NB, ND = Cfg::ND, WB = 2 * P + 1, NBOX = WB * WB;
     const long long a = a_first + blockIdx.x;
@@ -348,6 +349,68 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
     // of the group, so up to 4 x 6 loads per lane are in flight (the adds keep the fixed element order).
     constexpr int NPASS = (ND + 63) / 64, NPH = (3 * NB + 63) / 64, UNR = 4;
     const int neu = eu1 - eu0 + 1, nev = ev1 - ev0 + 1, ne = (neu > 0 && nev > 0) ? neu * nev : 0;
+    if (strips != nullptr) {
+        // Strip records (gf_element_strip.hpp): every strip eu containing a holds, per dof row i, the sums over the strip's
+        // elements against the 28 neighbours (local u index 0..3 of the strip) x (row offset -3..3).  At most p + 1 strips;
+        // all their loads are issued before the fixed-order accumulation.
+        constexpr int RS = 200, MAXS = P1;
+        const double* rec[MAXS]; int iu0s[MAXS]; bool sok[MAXS];
+#pragma unroll
+        for (int q = 0; q < MAXS; ++q) {
+            const int eu = eu0 + q; sok[q] = q < neu && ne > 0;
+            const int euc = sok[q] ? eu : eu0;
+            const StripDesc sd = strips[strip_off[M.cp_patch[a]] + (ne > 0 ? euc : 0)];
+            iu0s[q] = spu[ne > 0 ? euc : 0] - P;
+            rec[q] = blk + sd.out_off + (size_t)((ja * 4 + (ia - iu0s[q])) * 3) * RS;
+        }
+        if (wave < 3) {
+            const int i = wave;
+            double v[MAXS][3];
+#pragma unroll
+            for (int q = 0; q < MAXS; ++q)
+#pragma unroll
+                for (int ps = 0; ps < 3; ++ps) {
+                    const int c = lane + 64 * ps;
+                    const bool on = sok[q] && c < 168 && (c < 84 ? (flags & GF_ASM_K_BIT) != 0 : (flags & GF_ASM_C_BIT) != 0);
+                    v[q][ps] = on ? rec[q][i * RS + c] : 0.0;
+                }
+#pragma unroll
+            for (int q = 0; q < MAXS; ++q)
+#pragma unroll
+                for (int ps = 0; ps < 3; ++ps) {
+                    const int c = lane + 64 * ps;
+                    if (!sok[q] || c >= 168) continue;
+                    const int cc = c < 84 ? c : c - 84, slot = cc / 3, jf = cc - 3 * slot, jb = ja + slot / 4 - 3;
+                    if (jb < j0 || jb > j1) continue;                     // rows that never share an element with a: slot not written
+                    const int ks = (iu0s[q] + slot % 4 - i0) + (jb - j0) * wbox;
+                    if (c < 84) aK[i][ks][jf] += v[q][ps]; else aC[jf][i][ks] += v[q][ps];
+                }
+        } else {
+            double vh[MAXS][2], vr[MAXS];
+#pragma unroll
+            for (int q = 0; q < MAXS; ++q) {
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int w = lane + 64 * ps;
+                    vh[q][ps] = (sok[q] && w < 84 && (flags & GF_ASM_H_BIT)) ? rec[q][(w / 28) * RS + 168 + w % 28] : 0.0;
+                }
+                vr[q] = (sok[q] && lane < 3 && (flags & GF_ASM_R_BIT)) ? rec[q][lane * RS + 196] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < MAXS; ++q) {
+                if (!sok[q]) continue;
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int w = lane + 64 * ps;
+                    if (w >= 84) continue;
+                    const int i = w / 28, slot = w - 28 * i, jb = ja + slot / 4 - 3;
+                    if (jb < j0 || jb > j1) continue;
+                    aH[i][(iu0s[q] + slot % 4 - i0) + (jb - j0) * wbox] += vh[q][ps];
+                }
+                if (lane < 3) aR[lane] += vr[q];
+            }
+        }
+    } else
     for (int g0 = 0; g0 < ne; g0 += UNR) {
         const double* Bp[UNR]; int bu[UNR], bv[UNR], al[UNR]; bool ok[UNR];
 #pragma unroll

@@ -14,6 +14,7 @@ constexpr int GF_ASM_R_BIT = 1, GF_ASM_K_BIT = 2, GF_ASM_C_BIT = 4, GF_ASM_H_BIT
 #include "gf_kernels.hpp"
 #include "gf_element_mfma.hpp"
 #include "gf_element_mfma4.hpp"
+#include "gf_element_strip.hpp"
 
 using namespace gf;
 
@@ -21,7 +22,7 @@ static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return 1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
-struct Chunk { int p0, p1; long long e0, e1, a0, a1; };
+struct Chunk { int p0, p1; long long e0, e1, a0, a1; int s0 = 0, s1 = 0; };     // s0..s1: strips of the chunk
 
 struct gf_handle {
     int device = 0; hipStream_t stream = nullptr;
@@ -36,6 +37,8 @@ struct gf_handle {
     std::vector<Chunk> chunks;
     std::vector<hipEvent_t> ev0, ev1; int ev_n = 0;   // element-kernel timing
     bool assembled[5] = {false, false, false, false, false};
+    bool strip = false;                               // p = 3 MFMA path: accumulate along element strips (GF_STRIP=1; see gf_element_strip.hpp for the measured trade-off)
+    const StripDesc* d_strips = nullptr; const int* d_strip_off = nullptr;
     bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
     int pen_maxdeg = 0;                               // largest neighbour count of an interface control point
 
@@ -68,6 +71,8 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         HIPCHK(hipStreamCreate(&h->stream));
         h->H.build(desc);
         if (const char* s = getenv("GF_ELEMENT")) h->mfma = std::string(s) != "valu";
+        if (const char* s = getenv("GF_STRIP")) h->strip = std::string(s) == "1";
+        h->strip = h->strip && h->mfma && h->H.degree == 3;
         HostModel& H = h->H;
         std::vector<long long> nbs(H.nb_ptr_s.begin(), H.nb_ptr_s.end()), nbc(H.nb_ptr_c.begin(), H.nb_ptr_c.end());
         h->d_cp4 = h->dalloc<double>(4 * H.total_cp); h->d_u = h->dalloc<double>(H.ndof); h->d_h = h->dalloc<double>(H.total_cp); h->d_R = h->dalloc<double>(H.ndof);
@@ -135,7 +140,18 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             c.p1 = s; c.e1 = c.e0 + ne; c.a1 = (s < H.np) ? H.patches[s].cp_off : H.total_cp;
             h->chunks.push_back(c); biggest = std::max(biggest, ne);
         }
-        h->d_blk = h->dalloc<double>((size_t)biggest * blk_doubles);
+        long long scratch_doubles = biggest * blk_doubles;
+        if (h->strip) {                               // strip records instead of element blocks: offsets relative to the chunk's scratch base
+            scratch_doubles = 0;
+            for (Chunk& c : h->chunks) {
+                long long off = 0;
+                c.s0 = H.strip_off[c.p0]; c.s1 = H.strip_off[c.p1];
+                for (int s = c.s0; s < c.s1; ++s) { H.strips[s].out_off = off; off += (long long)H.strips[s].nv * 12 * STRIP_RS; }
+                scratch_doubles = std::max(scratch_doubles, off);
+            }
+            h->d_strips = h->upload(H.strips); h->d_strip_off = h->upload(H.strip_off);
+        }
+        h->d_blk = h->dalloc<double>((size_t)scratch_doubles);
         h->ev0.resize(64); h->ev1.resize(64);
         for (int k = 0; k < 64; ++k) { HIPCHK(hipEventCreate(&h->ev0[k])); HIPCHK(hipEventCreate(&h->ev1[k])); }
         HIPCHK(hipDeviceSynchronize());
@@ -233,13 +249,15 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
         const long long ne = c.e1 - c.e0, na = c.a1 - c.a0;
         const int slot = h->ev_n % 64;
         HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
-        if (P == 3 && h->mfma) hipLaunchKernelGGL(kl_element_mfma_kernel, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+        if (P == 3 && h->strip) hipLaunchKernelGGL(kl_element_strip_kernel, dim3((unsigned)(c.s1 - c.s0)), dim3(64), 0, h->stream, h->M, h->d_strips, c.s0, flags, h->d_blk);
+        else if (P == 3 && h->mfma) hipLaunchKernelGGL(kl_element_mfma_kernel, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
         else if (P == 4 && h->mfma) hipLaunchKernelGGL(kl_element_mfma4_kernel, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
         else hipLaunchKernelGGL(kl_element_kernel<P>, dim3((unsigned)ne), dim3(Cfg::NT), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
         HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
         h->ev_n++;
         hipLaunchKernelGGL(kl_gather_kernel<P>, dim3((unsigned)na), dim3(256), 0, h->stream, h->M, c.a0, c.e0, ne, flags, h->d_blk,
-                           h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R, pen);
+                           h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R, pen,
+                           (P == 3 && h->strip) ? h->d_strips : nullptr, h->d_strip_off);
     }
     if (flags & GF_ASM_R) {
         const long long npl = (long long)H.pl_dof.size();

@@ -34,6 +34,9 @@ struct PatchDev {            // POD mirrored on the device
 // per-element descriptor: one load instead of the elem_patch -> patch -> span-table chain of dependent scalar loads
 struct ElemDesc { int patch, g0, nu, tabu, tabv, wu, wv, pad; };   // g0: global id of the element's first control point; offsets into tab[]
 
+// one strip of elements (fixed u-span eu of a patch, all v-spans) of the strip-accumulating element kernel
+struct StripDesc { int patch, eu, e_first, nelv, nv, pad; long long out_off; };   // out_off: doubles from the chunk's scratch base
+
 struct PenRowItem { int a, code, lo, hi; };           // code = iface*2 + s
 // one (owned control point, mortar vertex) visit of the penalty row kernel: everything the kernel needs to address the
 // vertex record and both support windows without dependent index loads
@@ -102,6 +105,7 @@ struct HostModel {
     std::vector<int> ints;              // spans + cp->element ranges
     std::vector<int> elem_patch;        // [nelem]
     std::vector<ElemDesc> elem_desc;    // [nelem]
+    std::vector<StripDesc> strips; std::vector<int> strip_off;   // owned patches' strips (patch-major), first strip of every patch
     std::vector<int> cp_patch;          // [total_cp]
     std::vector<double> weights;
     std::vector<unsigned char> zero;    // [ndof]
@@ -174,6 +178,14 @@ inline void HostModel::build(const gf_model_desc* D) {
     if (nelem >= (int64_t(1) << 31)) throw std::runtime_error("gf_create: too many elements");
     elem_patch.resize(nelem);
     for (int s = 0; s < np; ++s) std::fill(elem_patch.begin() + patches[s].elem_off, elem_patch.begin() + patches[s].elem_off + int64_t(patches[s].nelu) * patches[s].nelv, s);
+    strips.clear(); strip_off.assign(np + 1, 0);
+    for (int s = 0; s < np; ++s) {
+        strip_off[s] = (int)strips.size();
+        if (s >= n_owned) continue;
+        const PatchDev& P = patches[s];
+        for (int eu = 0; eu < P.nelu; ++eu) strips.push_back({s, eu, int(P.elem_off + eu), P.nelv, P.nv, 0, 0});
+    }
+    strip_off[np] = (int)strips.size();
     elem_desc.resize(nelem);
     for (int s = 0; s < np; ++s) {
         const PatchDev& P = patches[s];

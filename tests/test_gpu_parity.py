@@ -91,6 +91,28 @@ def test_valu_element_kernel_still_matches(oracle_lib, monkeypatch):
         D.close()
 
 
+def test_strip_accumulating_element_kernel(oracle_lib, monkeypatch):
+    """GF_STRIP=1: the element kernel that sums along element strips before writing (gf_element_strip.hpp) and the
+    strip branch of the gather give the same matrices, also when the scratch is chunked."""
+    from goldfish_amd import _lib
+    from oracle.oracle_py import Oracle
+    monkeypatch.setenv("GF_STRIP", "1")
+    for case, gb in (("shell3x2_p3", None), ("slr9_nurbs_p3", None), ("C3_wing16_refdata", "0.002")):
+        if gb is not None:
+            monkeypatch.setenv("GF_SCRATCH_GB", gb)
+        A, h, u = _state(CASES[case]())
+        O = Oracle(A, thickness=h, u=u)
+        D = _lib.DeviceModel(A)
+        D.set_thickness(h)
+        D.set_u(u)
+        D.assemble(_lib.ASM_ALL)
+        assert _rel(D.residual(), O.residual()) < RTOL
+        vals = O.assemble()
+        for which in range(5):
+            assert _rel(D.values(which), vals[which]) < RTOL, (case, which)
+        D.close()
+
+
 def test_zero_state_and_reproducible(oracle_lib):
     """u = 0 (reference == deformed) and bitwise run-to-run reproducibility of the assembly
     (atomic-free owner gathers)."""
