@@ -13,8 +13,9 @@
 // Status (measured, C4): gather 7.5 -> 4.9 ms and element-kernel traffic 26 -> 11.5 GB, but this kernel takes 22.6 ms against
 // 15.1 ms for kl_element_mfma_kernel: the DPP shifts of the 72 accumulator doubles cost 16 % and the flush stores 15 % (in a
 // persistent loop the next element's input loads queue behind them: vmcnt is in order).  Net 31.0 vs 26.4 ms per step, so the
-// path is OFF by default (GF_STRIP=1 enables it; parity-tested).  Next: rotate the lane/register <-> control-point-row mapping
-// instead of moving data, and stage the flush through LDS for wide stores issued after the next element's loads.
+// path is OFF by default (GF_STRIP=1 enables it; parity-tested).  Rotating the lane/register <-> control-point-row mapping
+// instead of moving data was tried (four compile-time flush instances) and is slower still (register spills).  Next: stage the
+// flush through LDS for wide stores issued after the next element's loads.
 #pragma once
 #include "gf_element_mfma.hpp"
 
