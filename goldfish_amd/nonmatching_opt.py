@@ -491,6 +491,142 @@ class NonMatchingOptFFD(NonMatchingOpt):
             self.shopt_dcpregudcpffd.append(self.dCPregudCPFFD(field, l, m, nn, self.shopt_cpffd_design_dof[field_ind]))
         return self.shopt_dcpregudcpffd
 
+    # ------------------------------------------------------------------ shape optimisation with several FFD blocks
+    def set_shopt_surf_inds_multiFFD(self, opt_field_mffd, shopt_surf_ind_list_mffd):
+        """nonmatching_opt_ffd.py:184-310: block ``k`` drives the coordinates ``opt_field_mffd[k]`` of the patches
+        ``shopt_surf_ind_list_mffd[k]``.  ``opt_field`` becomes the sorted union of the fields and
+        ``shopt_surf_inds[field]`` the sorted union of the patches of the blocks that drive that field."""
+        assert len(opt_field_mffd) == len(shopt_surf_ind_list_mffd)
+        self.opt_field_mffd = [list(f) for f in opt_field_mffd]
+        self.shopt_surf_ind_list_mffd = [list(s) for s in shopt_surf_ind_list_mffd]
+        self.shopt_num_ffd = len(self.shopt_surf_ind_list_mffd)
+        opt_field = sorted({f for fl in self.opt_field_mffd for f in fl})
+        surf_inds = [sorted({s for k in range(self.shopt_num_ffd) if f in self.opt_field_mffd[k] for s in self.shopt_surf_ind_list_mffd[k]}) for f in opt_field]
+        for f in opt_field:                          # a patch may be driven by one block only per field
+            drv = [s for k in range(self.shopt_num_ffd) if f in self.opt_field_mffd[k] for s in self.shopt_surf_ind_list_mffd[k]]
+            if len(drv) != len(set(drv)):
+                raise ValueError("set_shopt_surf_inds_multiFFD: field %d of a patch is driven by more than one FFD block" % f)
+        self.set_shopt_surf_inds(opt_field, surf_inds)
+        self.shopt_multiffd = True
+        self.opt_field_ffdinds = [[k for k in range(self.shopt_num_ffd) if f in self.opt_field_mffd[k]] for f in self.opt_field]
+        w = np.concatenate([s.cp_hom_flat()[:, 3] for s in self.splines])
+        self._mffd_cols = [np.concatenate([np.arange(self.cp_off[s], self.cp_off[s + 1]) for s in blk]) for blk in self.shopt_surf_ind_list_mffd]
+        self._mffd_w = [w[c] for c in self._mffd_cols]
+        self._mffd_X = [np.stack([self.cp_iga[f][c] / w[c] for f in range(3)], 1) for c in self._mffd_cols]
+        self.shopt_cpsurf_lims_mffd = [[[float(X[:, f].min()), float(X[:, f].max())] for f in range(3)] for X in self._mffd_X]
+        self.init_cp_iga = None
+        self.get_init_CPIGA()
+
+    def set_shopt_multiFFD(self, shopt_knots_mffd, shopt_cp_mffd):
+        """nonmatching_opt_ffd.py:312-390.  Returns, per opt field, the constant sparse map from the concatenated
+        control points of the blocks driving that field to the homogeneous surface control points of
+        ``shopt_surf_inds[field]`` (rows in that patch order)."""
+        from .utils.ffd_utils import CP_FFD_matrix
+        assert len(shopt_knots_mffd) == self.shopt_num_ffd and len(shopt_cp_mffd) == self.shopt_num_ffd
+        self.shopt_knots_mffd = [[np.asarray(k, float) for k in kn] for kn in shopt_knots_mffd]
+        self.shopt_cp_mffd = [np.asarray(c, float) for c in shopt_cp_mffd]
+        self.shopt_cp_mffd_flat_decate = [c[..., 0:3].transpose(2, 1, 0, 3).reshape(-1, 3) for c in self.shopt_cp_mffd]
+        self.shopt_cp_mffd_flat = np.concatenate(self.shopt_cp_mffd_flat_decate, axis=0)
+        self.shopt_cp_mffd_degree = [[int(np.sum(k == k[0]) - 1) for k in kn] for kn in self.shopt_knots_mffd]
+        self.shopt_cp_mffd_shape = [c.shape[0:3] for c in self.shopt_cp_mffd]
+        self.shopt_cp_mffd_size = [int(np.prod(s)) for s in self.shopt_cp_mffd_shape]
+        self.shopt_cp_mffd_design_size = int(np.sum(self.shopt_cp_mffd_size))
+        self.shopt_dcpsurf_fedcp_mffd_list = [sp.diags(self._mffd_w[k]).dot(CP_FFD_matrix(self._mffd_X[k], self.shopt_cp_mffd_degree[k],
+                                                                                        self.shopt_knots_mffd[k]).tocsr())
+                                              for k in range(self.shopt_num_ffd)]
+        self.shopt_dcpsurf_fedcp_mffd = []
+        for field_ind, field in enumerate(self.opt_field):
+            blocks = self.opt_field_ffdinds[field_ind]
+            D = sp.block_diag([self.shopt_dcpsurf_fedcp_mffd_list[k] for k in blocks], format="csr")
+            # rows of D follow (block, patch of the block); reorder them to the sorted patch order of shopt_surf_inds[field]
+            src = np.concatenate([self._mffd_cols[k] for k in blocks])
+            order = np.argsort(src, kind="stable")
+            assert np.array_equal(src[order], self._shopt_cols[field_ind])
+            self.shopt_dcpsurf_fedcp_mffd.append(D[order].tocoo())
+        self.shopt_num_desvars = [int(sum(self.shopt_cp_mffd_size[k] for k in self.opt_field_ffdinds[fi])) for fi in range(len(self.opt_field))]
+        self.shopt_cp_mffd_design_dof = []
+        for fi in range(len(self.opt_field)):
+            off, lst = 0, []
+            for k in self.opt_field_ffdinds[fi]:
+                lst.append(list(range(off, off + self.shopt_cp_mffd_size[k])))
+                off += self.shopt_cp_mffd_size[k]
+            self.shopt_cp_mffd_design_dof.append(lst)
+        self.shopt_cp_mffd_design_dof_full = [[d for sub in lst for d in sub] for lst in self.shopt_cp_mffd_design_dof]
+        self.shopt_cp_mffd_design_dof_full_decate = [[list(sub) for sub in lst] for lst in self.shopt_cp_mffd_design_dof]
+        self._mffd_block_off = [[sub[0] for sub in lst] for lst in self.shopt_cp_mffd_design_dof]
+        self.shopt_init_cp_mffd_full = [self.get_init_CP_multiFFD(f) for f in self.opt_field]
+        self.shopt_init_cp_mffd_design = [v.copy() for v in self.shopt_init_cp_mffd_full]
+        self.shopt_align_dir_mffd = [None for _ in range(self.shopt_num_ffd)]
+        self.shopt_dcpaligndcp_mffd_list = [[sp.identity(self.shopt_cp_mffd_size[k], format="coo") for k in self.opt_field_ffdinds[fi]]
+                                            for fi in range(len(self.opt_field))]
+        self.shopt_dcpaligndcp_mffd = [sp.block_diag(l, format="coo") for l in self.shopt_dcpaligndcp_mffd_list]
+        self.shopt_cp_mffd_pin_dof = [[] for _ in self.opt_field]
+        self.shopt_pin_vals = [None for _ in self.opt_field]
+        self.shopt_dcppindcp_mffd = [None for _ in self.opt_field]
+        self.pin_field = []
+        return self.shopt_dcpsurf_fedcp_mffd
+
+    def get_init_CP_multiFFD(self, field):
+        """nonmatching_opt_ffd.py:422-429."""
+        fi = self.opt_field.index(field)
+        return np.concatenate([self.shopt_cp_mffd_flat_decate[k][:, field] for k in self.opt_field_ffdinds[fi]])
+
+    def _mffd_local(self, ffd_ind, field):
+        fi = self.opt_field.index(field)
+        return fi, self.opt_field_ffdinds[fi].index(ffd_ind)
+
+    def set_shopt_align_CP_multiFFD(self, ffd_ind, align_dir):
+        """nonmatching_opt_ffd.py:726-756."""
+        assert len(align_dir) == len(self.opt_field_mffd[ffd_ind])
+        self.shopt_align_dir_mffd[ffd_ind] = list(align_dir)
+        for k, field in enumerate(self.opt_field_mffd[ffd_ind]):
+            fi, bi = self._mffd_local(ffd_ind, field)
+            if align_dir[k] is not None:
+                free_dof, deriv = self.dCPaligndCPFFD(field, align_dir[k], self.shopt_cp_mffd_shape[ffd_ind])
+                self.shopt_dcpaligndcp_mffd_list[fi][bi] = deriv
+                self.shopt_cp_mffd_design_dof[fi][bi] = [d + self._mffd_block_off[fi][bi] for d in free_dof]
+        self.shopt_init_cp_mffd_design = [self.shopt_init_cp_mffd_full[fi][[d for sub in self.shopt_cp_mffd_design_dof[fi] for d in sub]]
+                                          for fi in range(len(self.opt_field))]
+        self.shopt_dcpaligndcp_mffd = [sp.block_diag(l, format="coo") for l in self.shopt_dcpaligndcp_mffd_list]
+        return self.shopt_dcpaligndcp_mffd
+
+    def set_shopt_pin_CP_multiFFD(self, ffd_ind, pin_dir0, pin_side0, pin_dir1=None, pin_side1=None):
+        """nonmatching_opt_ffd.py:817-868."""
+        assert len(pin_dir0) == len(self.opt_field_mffd[ffd_ind]) and len(pin_side0) == len(self.opt_field_mffd[ffd_ind])
+        for k, field in enumerate(self.opt_field_mffd[ffd_ind]):
+            fi, bi = self._mffd_local(ffd_ind, field)
+            if pin_dir0[k] is None:
+                continue
+            d1 = None if pin_dir1 is None else pin_dir1[k]
+            s1 = None if pin_dir1 is None else pin_side1[k]
+            cand = self.CPpinDoFs(pin_dir0[k], pin_side0[k], d1, s1, self.shopt_cp_mffd_shape[ffd_ind]) + self._mffd_block_off[fi][bi]
+            design = set(self.shopt_cp_mffd_design_dof[fi][bi])
+            self.shopt_cp_mffd_pin_dof[fi] += [int(d) for d in cand if int(d) in design]
+        for k, field in enumerate(self.opt_field_mffd[ffd_ind]):
+            fi = self.opt_field.index(field)
+            pins = self.shopt_cp_mffd_pin_dof[fi]
+            if len(pins) > 0:
+                design = [d for sub in self.shopt_cp_mffd_design_dof[fi] for d in sub]
+                self.shopt_dcppindcp_mffd[fi] = self.dCPpindCPFFD(design, pins)
+                self.shopt_pin_vals[fi] = self.shopt_init_cp_mffd_full[fi][pins]
+        self.pin_field = [f for fi, f in enumerate(self.opt_field) if self.shopt_dcppindcp_mffd[fi] is not None]
+        return self.shopt_dcppindcp_mffd
+
+    def set_shopt_regu_CP_multiFFD(self):
+        """nonmatching_opt_ffd.py:885-913."""
+        lists = [[None for _ in self.opt_field_ffdinds[fi]] for fi in range(len(self.opt_field))]
+        for ffd_ind in range(self.shopt_num_ffd):
+            for k, field in enumerate(self.opt_field_mffd[ffd_ind]):
+                fi, bi = self._mffd_local(ffd_ind, field)
+                l, m, nn = self.shopt_cp_mffd_shape[ffd_ind]
+                align = None if self.shopt_align_dir_mffd[ffd_ind] is None else self.shopt_align_dir_mffd[ffd_ind][k]
+                if align is not None:
+                    l, m, nn = (1 if 0 in align else l), (1 if 1 in align else m), (1 if 2 in align else nn)
+                lists[fi][bi] = self.dCPregudCPFFD(field, l, m, nn, self.shopt_cp_mffd_design_dof[fi][bi])
+        self.shopt_dcpregudcp_mffd_list = lists
+        self.shopt_dcpregudcp_mffd = [sp.block_diag(l, format="coo") for l in lists]
+        return self.shopt_dcpregudcp_mffd
+
     # ------------------------------------------------------------------ thickness FFD
     def set_thopt_surf_inds_FFD(self, thopt_surf_inds):
         """nonmatching_opt_ffd.py:434-464: patches whose thickness field is driven by one FFD block."""

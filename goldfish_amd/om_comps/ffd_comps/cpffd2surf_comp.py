@@ -16,10 +16,15 @@ class CPFFD2SurfComp(om.ExplicitComponent):
         self.output_cpsurf_name_pre = self.options['output_cpsurf_name_pre']
         nm = self.nonmatching_opt_ffd
         self.opt_field = nm.opt_field
-        deriv = nm.shopt_dcpsurf_fedcpffd
-        self.derivs = [deriv] * len(self.opt_field)
-        self.input_shapes = [len(d) for d in nm.shopt_cpffd_design_dof_full]
-        self.init_cpffd = [nm.shopt_cpffd_flat[:, f] for f in self.opt_field]
+        if getattr(nm, 'shopt_multiffd', False):
+            self.derivs = [d.tocoo() for d in nm.shopt_dcpsurf_fedcp_mffd]
+            self.input_shapes = [len(d) for d in nm.shopt_cp_mffd_design_dof_full]
+            self.init_cpffd = nm.shopt_init_cp_mffd_full
+        else:
+            deriv = nm.shopt_dcpsurf_fedcpffd
+            self.derivs = [deriv] * len(self.opt_field)
+            self.input_shapes = [len(d) for d in nm.shopt_cpffd_design_dof_full]
+            self.init_cpffd = [nm.shopt_cpffd_flat[:, f] for f in self.opt_field]
         self.output_shapes = [c.size for c in nm._shopt_cols]
         self.input_cpffd_name_list = [self.input_cpffd_name_pre + str(f) for f in self.opt_field]
         self.output_cpsurf_name_list = [self.output_cpsurf_name_pre + str(f) for f in self.opt_field]

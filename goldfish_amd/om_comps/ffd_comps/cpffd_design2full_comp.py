@@ -15,8 +15,9 @@ class CPFFDesign2FullComp(om.ExplicitComponent):
         self.input_cpffd_design_name_pre = self.options['input_cpffd_design_name_pre']
         self.output_cpffd_full_name_pre = self.options['output_cpffd_full_name_pre']
         self.opt_field = nm.opt_field
-        self.deriv = [d.tocoo() for d in nm.shopt_dcpaligndcpffd]
-        self.init_cpffd = nm.shopt_init_cpffd_design
+        multi = getattr(nm, 'shopt_multiffd', False)
+        self.deriv = [d.tocoo() for d in (nm.shopt_dcpaligndcp_mffd if multi else nm.shopt_dcpaligndcpffd)]
+        self.init_cpffd = nm.shopt_init_cp_mffd_design if multi else nm.shopt_init_cpffd_design
         self.input_shapes = [m.shape[1] for m in self.deriv]
         self.output_shapes = [m.shape[0] for m in self.deriv]
         self.input_cpffd_name_list = [self.input_cpffd_design_name_pre + str(f) for f in self.opt_field]

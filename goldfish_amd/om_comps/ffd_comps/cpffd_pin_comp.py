@@ -16,8 +16,9 @@ class CPFFDPinComp(om.ExplicitComponent):
         self.output_cppin_name_pre = self.options['output_cppin_name_pre']
         self.opt_field = nm.opt_field
         self.pin_field = nm.pin_field
-        self.init_cpffd = nm.shopt_init_cpffd_design
-        self.derivs = [None if d is None else d.tocoo() for d in nm.shopt_dcppindcpffd]
+        multi = getattr(nm, 'shopt_multiffd', False)
+        self.init_cpffd = nm.shopt_init_cp_mffd_design if multi else nm.shopt_init_cpffd_design
+        self.derivs = [None if d is None else d.tocoo() for d in (nm.shopt_dcppindcp_mffd if multi else nm.shopt_dcppindcpffd)]
         self.field_inds = [self.opt_field.index(f) for f in self.pin_field]
         self.input_shapes = [self.derivs[k].shape[1] for k in self.field_inds]
         self.output_shapes = [self.derivs[k].shape[0] for k in self.field_inds]

@@ -215,3 +215,44 @@ def test_thickness_ffd_maps_and_design_components():
     hm = HthMapComp(nonmatching_opt=pb)
     hm.init_parameters()
     assert hm.deriv.shape == (pb.vec_scalar_iga_dof, pb.num_splines) and np.allclose(hm.deriv @ hm.init, np.concatenate(pb.h_th))
+
+
+def test_multi_ffd_blocks():
+    """N2: two FFD blocks driving different patches / fields (GOLDFISH/nonmatching_opt_ffd.py:184-428, 726-913):
+    identity at the start, block structure of the maps, constraint maps per block, components."""
+    from goldfish_amd import om_shim
+    from goldfish_amd.nonmatching_opt import NonMatchingOptFFD
+    from goldfish_amd.om_comps.ffd_comps import CPFFD2SurfComp, CPFFDesign2FullComp, CPFFDPinComp, CPFFDReguComp
+    from goldfish_amd.utils.ffd_utils import create_3D_block
+    pb = NonMatchingOptFFD.from_spec(G.tbeam_4patch(), klass=NonMatchingOptFFD)
+    pb.set_shopt_surf_inds_multiFFD([[1, 2], [2]], [[1, 0], [2, 3]])           # block 0 -> y,z of patches 1,0; block 1 -> z of patches 2,3
+    assert pb.opt_field == [1, 2] and pb.shopt_surf_inds == [[0, 1], [0, 1, 2, 3]] and pb.opt_field_ffdinds == [[0], [0, 1]]
+    blks = []
+    for lims in pb.shopt_cpsurf_lims_mffd:
+        lims = [[a - 0.1 * max(b - a, 1.0), b + 0.1 * max(b - a, 1.0)] for a, b in lims]
+        blks.append(create_3D_block([2, 2, 1], 2, lims))
+    maps = pb.set_shopt_multiFFD([b.knots for b in blks], [b.control for b in blks])
+    sizes = pb.shopt_cp_mffd_size
+    assert maps[0].shape == (pb._shopt_cols[0].size, sizes[0]) and maps[1].shape == (pb._shopt_cols[1].size, sizes[0] + sizes[1])
+    for fi, f in enumerate(pb.opt_field):                                       # undeformed blocks reproduce the control points
+        assert np.abs(maps[fi] @ pb.shopt_init_cp_mffd_full[fi] - pb.get_init_CPIGA()[fi]).max() < 1e-12
+    M1 = maps[1].tocsr()                                                        # patches 0,1 depend on block 0 only, patches 2,3 on block 1 only
+    n01 = int(pb.cp_off[2])
+    assert abs(M1[:n01, sizes[0]:]).sum() == 0.0 and abs(M1[n01:, :sizes[0]]).sum() == 0.0
+    al = pb.set_shopt_align_CP_multiFFD(0, [[0], None])
+    assert al[0].shape == (sizes[0], sizes[0] // pb.shopt_cp_mffd_shape[0][0]) and al[1].shape == (sizes[0] + sizes[1],) * 2
+    pins = pb.set_shopt_pin_CP_multiFFD(1, [0], [[0]])
+    assert pb.pin_field == [2] and pins[0] is None and pins[1].shape[1] == sizes[0] + sizes[1]
+    assert min(pb.shopt_cp_mffd_pin_dof[1]) >= sizes[0]                        # the pinned dofs belong to block 1
+    regs = pb.set_shopt_regu_CP_multiFFD()
+    assert regs[0].shape[1] == al[0].shape[1] and regs[1].shape[1] == sizes[0] + sizes[1]
+    for Comp in (CPFFD2SurfComp, CPFFDesign2FullComp, CPFFDPinComp, CPFFDReguComp):
+        comp = Comp(nonmatching_opt_ffd=pb)
+        comp.init_parameters()
+        prob = om_shim.Problem(model=comp)
+        prob.setup()
+        prob.run_model()
+        errs = prob.check_partials(step=1e-3)
+        assert errs and max(errs.values()) < 1e-9, (Comp.__name__, errs)
+    with pytest.raises(ValueError):
+        pb.set_shopt_surf_inds_multiFFD([[2], [2]], [[0, 1], [1, 2]])
