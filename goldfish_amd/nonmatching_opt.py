@@ -714,6 +714,75 @@ class NonMatchingOptFFD(NonMatchingOpt):
         self.thopt_dcpregudcpffd_list = [deriv]
         return self.thopt_dcpregudcpffd_list
 
+    # ------------------------------------------------------------------ thickness with several FFD blocks
+    def set_thopt_multiFFD_surf_inds(self, thopt_multiffd_surf_ind_list):
+        """nonmatching_opt_ffd.py:534-598: block k drives the thickness field of the patches in
+        ``thopt_multiffd_surf_ind_list[k]``; the remaining patches keep one constant thickness each."""
+        self.thopt_multiffd = True
+        self.thopt_multiffd_surf_ind_list = [list(s) for s in thopt_multiffd_surf_ind_list]
+        self.num_thopt_ffd = len(self.thopt_multiffd_surf_ind_list)
+        self.thopt_ffd_shell_inds = [s for blk in self.thopt_multiffd_surf_ind_list for s in blk]
+        if len(set(self.thopt_ffd_shell_inds)) != len(self.thopt_ffd_shell_inds):
+            raise ValueError("set_thopt_multiFFD_surf_inds: a patch is driven by more than one thickness FFD block")
+        self.thopt_nonffd_shell_inds = [s for s in range(self.num_splines) if s not in self.thopt_ffd_shell_inds]
+        self.num_thopt_nonffd_shells = len(self.thopt_nonffd_shell_inds)
+        w = np.concatenate([s.cp_hom_flat()[:, 3] for s in self.splines])
+        self._thm_cols = [np.concatenate([np.arange(self.cp_off[s], self.cp_off[s + 1]) for s in blk]) for blk in self.thopt_multiffd_surf_ind_list]
+        self._thm_X = [np.stack([self.cp_iga[f][c] / w[c] for f in range(3)], 1) for c in self._thm_cols]
+        self.thopt_cpsurf_lims_multiffd = [[[float(X[:, f].min()), float(X[:, f].max())] for f in range(3)] for X in self._thm_X]
+
+    def set_thopt_multiFFD(self, thopt_knotsffd_list, thopt_cpffd_list):
+        """nonmatching_opt_ffd.py:621-664.  Returns the map [block coefficients of all blocks | constant thicknesses of the
+        remaining patches] -> thickness at every control point (all patches, patch order)."""
+        from .utils.ffd_utils import CP_FFD_matrix
+        if not getattr(self, "var_thickness", False):
+            self.set_thickness_opt(var_thickness=True)
+        self.thopt_knotsffd_list = [[np.asarray(k, float) for k in kn] for kn in thopt_knotsffd_list]
+        self.thopt_cpffd_list = [np.asarray(c, float) for c in thopt_cpffd_list]
+        self.thopt_cpffd_flat_list = [c[..., 0:3].transpose(2, 1, 0, 3).reshape(-1, 3) for c in self.thopt_cpffd_list]
+        self.thopt_cpffd_degree_list = [int(np.sum(kn[0] == kn[0][0]) - 1) for kn in self.thopt_knotsffd_list]
+        self.thopt_cpffd_shape_list = [c.shape[0:3] for c in self.thopt_cpffd_list]
+        self.thopt_cpffd_size_list = [int(np.prod(s)) for s in self.thopt_cpffd_shape_list]
+        self.thopt_dcpsurf_fedcpffd_list = [CP_FFD_matrix(self._thm_X[k], [self.thopt_cpffd_degree_list[k]] * 3, self.thopt_knotsffd_list[k]).tocsr()
+                                            for k in range(self.num_thopt_ffd)]
+        blocks = list(self.thopt_dcpsurf_fedcpffd_list)
+        src = list(self._thm_cols)
+        for s in self.thopt_nonffd_shell_inds:
+            blocks.append(sp.csr_matrix(np.ones((self.vec_scalar_iga_dof_list[s], 1))))
+            src.append(np.arange(self.cp_off[s], self.cp_off[s + 1]))
+        self.thopt_cpffd_design_size = int(sum(self.thopt_cpffd_size_list)) + self.num_thopt_nonffd_shells
+        D = sp.block_diag(blocks, format="csr")
+        order = np.argsort(np.concatenate(src), kind="stable")               # rows back to patch order (h_th_FE_reorder, :600-619)
+        self.thopt_dcpsurf_fedcpmultiffd = D[order].tocoo()
+        self.init_h_th_multiffd = None
+        return self.thopt_dcpsurf_fedcpmultiffd
+
+    def get_init_h_th_multiFFD(self):
+        """nonmatching_opt_ffd.py:666-685."""
+        if self.init_h_th_multiffd is None:
+            h = np.concatenate(self.h_th)
+            parts = [np.linalg.lstsq(self.thopt_dcpsurf_fedcpffd_list[k].toarray(), h[self._thm_cols[k]], rcond=None)[0] for k in range(self.num_thopt_ffd)]
+            parts += [np.array([float(np.mean(self.h_th[s]))]) for s in self.thopt_nonffd_shell_inds]
+            self.init_h_th_multiffd = np.concatenate(parts)
+        return self.init_h_th_multiffd
+
+    def set_thopt_align_CP_multiFFD(self, align_dir_list):
+        """nonmatching_opt_ffd.py:999-1032: per-block alignment rows, zero columns for the constant thicknesses."""
+        assert len(align_dir_list) == self.num_thopt_ffd
+        self.thopt_align_dir_list = list(align_dir_list)
+        mats = []
+        for k, ad in enumerate(self.thopt_align_dir_list):
+            ad = list(ad) if isinstance(ad, (list, tuple)) else [ad]
+            shape = [int(s) for s in self.thopt_cpffd_shape_list[k]]
+            size = int(sum(np.prod([s - 1 if i == d else s for i, s in enumerate(shape)]) for d in ad))
+            mats.append(self.dCPaligndCPFFD_thopt(ad, size, self.thopt_cpffd_size_list[k], shape))
+        self.thopt_dcpaligndcpffd_list = mats
+        A = sp.block_diag(mats, format="coo")
+        if self.num_thopt_nonffd_shells > 0:
+            A = sp.hstack([A, sp.coo_matrix((A.shape[0], self.num_thopt_nonffd_shells))], format="coo")
+        self.thopt_dcpaligndcpmultiffd = A
+        return self.thopt_dcpaligndcpmultiffd
+
     @property
     def cpsurf_lims(self):
         """Bounding box of the optimised surfaces' physical control points (reference attribute used to

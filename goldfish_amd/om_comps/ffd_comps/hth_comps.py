@@ -35,8 +35,12 @@ class HthFFD2FEComp(_LinearMapComp):
         nm = self.nonmatching_opt_ffd = self.options['nonmatching_opt_ffd']
         self.in_name = self.input_h_th_ffd_name = self.options['input_h_th_ffd_name']
         self.out_name = self.output_h_th_fe_name = self.options['output_h_th_fe_name']
-        self.init = self.init_h_th_ffd = nm.get_init_h_th_FFD()
-        self.deriv = self.deriv_mat = nm.thopt_dcpsurf_fedcpffd.tocoo()
+        if getattr(nm, 'thopt_multiffd', False):
+            self.init = self.init_h_th_ffd = nm.get_init_h_th_multiFFD()
+            self.deriv = self.deriv_mat = nm.thopt_dcpsurf_fedcpmultiffd.tocoo()
+        else:
+            self.init = self.init_h_th_ffd = nm.get_init_h_th_FFD()
+            self.deriv = self.deriv_mat = nm.thopt_dcpsurf_fedcpffd.tocoo()
 
 
 class HthFFDAlignComp(_LinearMapComp):
@@ -50,8 +54,12 @@ class HthFFDAlignComp(_LinearMapComp):
         nm = self.nonmatching_opt_ffd = self.options['nonmatching_opt_ffd']
         self.in_name = self.input_h_th_name = self.options['input_h_th_name']
         self.out_name = self.output_h_th_align_name = self.options['output_h_th_align_name']
-        self.init = self.init_h_th_ffd = nm.get_init_h_th_FFD()
-        self.deriv = nm.thopt_dcpaligndcpffd.tocoo()
+        if getattr(nm, 'thopt_multiffd', False):
+            self.init = self.init_h_th_ffd = nm.get_init_h_th_multiFFD()
+            self.deriv = nm.thopt_dcpaligndcpmultiffd.tocoo()
+        else:
+            self.init = self.init_h_th_ffd = nm.get_init_h_th_FFD()
+            self.deriv = nm.thopt_dcpaligndcpffd.tocoo()
 
 
 class HthFFDReguComp(_LinearMapComp):

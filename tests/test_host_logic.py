@@ -256,3 +256,33 @@ def test_multi_ffd_blocks():
         assert errs and max(errs.values()) < 1e-9, (Comp.__name__, errs)
     with pytest.raises(ValueError):
         pb.set_shopt_surf_inds_multiFFD([[2], [2]], [[0, 1], [1, 2]])
+
+
+def test_multi_ffd_thickness():
+    """N2: thickness driven by two FFD blocks, remaining patches constant (nonmatching_opt_ffd.py:534-685, 999-1032)."""
+    from goldfish_amd import om_shim
+    from goldfish_amd.nonmatching_opt import NonMatchingOptFFD
+    from goldfish_amd.om_comps.ffd_comps import HthFFD2FEComp, HthFFDAlignComp
+    from goldfish_amd.utils.ffd_utils import create_3D_block
+    pb = NonMatchingOptFFD.from_spec(G.tbeam_4patch(), klass=NonMatchingOptFFD)
+    pb.set_thopt_multiFFD_surf_inds([[2], [0, 1]])                              # patch 3 keeps a constant thickness
+    assert pb.thopt_nonffd_shell_inds == [3]
+    blks = [create_3D_block([2, 1, 1], 2, [[a - 0.1 * max(b - a, 1.0), b + 0.1 * max(b - a, 1.0)] for a, b in lims]) for lims in pb.thopt_cpsurf_lims_multiffd]
+    A = pb.set_thopt_multiFFD([b.knots for b in blks], [b.control for b in blks])
+    nd = sum(pb.thopt_cpffd_size_list) + 1
+    assert A.shape == (pb.vec_scalar_iga_dof, nd) and pb.thopt_cpffd_design_size == nd
+    h0 = pb.get_init_h_th_multiFFD()
+    assert np.allclose(A @ h0, np.concatenate(pb.h_th), atol=1e-12)
+    Ac = A.tocsr()
+    c3 = np.arange(pb.cp_off[3], pb.cp_off[4])
+    assert np.array_equal(Ac[c3].toarray(), np.eye(nd)[[-1] * c3.size])           # constant patch: one column of ones
+    Al = pb.set_thopt_align_CP_multiFFD([2, [1, 2]])
+    assert Al.shape[1] == nd and abs(Al.tocsr()[:, -1]).sum() == 0.0 and np.abs(Al @ np.ones(nd)).max() == 0.0
+    for Comp in (HthFFD2FEComp, HthFFDAlignComp):
+        comp = Comp(nonmatching_opt_ffd=pb)
+        comp.init_parameters()
+        prob = om_shim.Problem(model=comp)
+        prob.setup()
+        prob.run_model()
+        errs = prob.check_partials(step=1e-3)
+        assert errs and max(errs.values()) < 1e-9, (Comp.__name__, errs)
