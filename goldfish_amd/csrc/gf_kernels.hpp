@@ -18,6 +18,7 @@ namespace gf {
 struct DevModel {
     const PatchDev* patches; const double* tab; const int* ints; const int* elem_patch; const int* cp_patch;
     const double* cp4; const double* u; const double* h; const unsigned char* zero;
+    const unsigned short* nb_meta;   // per nb_c entry: box slot | Dirichlet flags of the column dofs | self (gf_setup.hpp)
     const ElemDesc* edesc;           // per-element descriptors (MFMA element kernel)
     const unsigned char* pen_row;    // 1: the control point owns penalty rows (pen_owner_kernel writes them before the gather adds the shell part)
     const long long* nb_ptr_s; const int* nb_s; const long long* nb_ptr_c; const int* nb_c;
@@ -469,32 +470,27 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
     __syncthreads();
     // the penalty rows of an interface control point were written before (pen_owner_kernel); the shell part is added to them
     const bool padd = pen_add && M.pen_row[a];
-    // box slot of neighbour control point bcp (-1: not a shell neighbour, i.e. coupling-only column)
-    auto box_slot = [&](long long bcp) -> int {
-        if (bcp < pbeg || bcp >= pend) return -1;
-        const int lb = int(bcp - pbeg), ib = lb % Pt.nu, jb = lb / Pt.nu;
-        return (ib >= i0 && ib <= i1 && jb >= j0 && jb <= j1) ? (ib - i0) + (jb - j0) * wbox : -1;
-    };
-    // wave i < 3 writes dof row i of K and dR/dCP (one neighbour per lane: one box lookup serves its 3 + 3 entries),
-    // wave 3 writes dR/dh; no index divisions in the loops
+    // wave i < 3 writes dof row i of K and dR/dCP, one neighbour per lane: its box slot, the Dirichlet flags of its dofs and
+    // the diagonal flag come from one 16-bit load (nb_meta) -- no dependent index loads, no divisions; wave 3 writes dR/dh,
+    // whose neighbour list IS the box in slot order
     if (wave < 3) {
         const int i = wave;
-        const long long row = 3 * a + i;
-        const bool zrow = M.zero[row] != 0;
-        for (int k = lane; k < (int)deg_c; k += 64) {
-            const long long bcp = M.nb_c[ptr_c + k];
-            const int ks = box_slot(bcp);
-            if (flags & GF_ASM_K_BIT) {
-                double* dst = valK + 9 * ptr_c + (long long)i * 3 * deg_c + 3 * k;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const long long col = 3 * bcp + j;
-                    double v = 0.0;
-                    if (zrow || M.zero[col]) v = (row == col) ? 1.0 : 0.0;
-                    else { if (ks >= 0) v = aK[i][ks][j]; if (padd) v += dst[j]; }
-                    dst[j] = v;
-                }
+        const bool zrow = M.zero[3 * a + i] != 0;
+        if (flags & GF_ASM_K_BIT) {                        // one matrix entry per lane: consecutive lanes write consecutive doubles
+            double* dst = valK + 9 * ptr_c + (long long)i * 3 * deg_c;
+            for (int c = lane; c < 3 * (int)deg_c; c += 64) {
+                const int k = c / 3, j = c - 3 * k;
+                const unsigned meta = M.nb_meta[ptr_c + k];
+                const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
+                double v = 0.0;
+                if (zrow || (meta & (128u << j))) v = ((meta & 1024u) && i == j) ? 1.0 : 0.0;
+                else { if (ks >= 0) v = aK[i][ks][j]; if (padd) v += dst[c]; }
+                dst[c] = v;
             }
+        }
+        for (int k = lane; k < (int)deg_c; k += 64) {
+            const unsigned meta = M.nb_meta[ptr_c + k];
+            const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
             if (flags & GF_ASM_C_BIT) {
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {
@@ -507,9 +503,8 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
         }
     } else if (flags & GF_ASM_H_BIT) {
         for (int k = lane; k < (int)deg_s; k += 64) {
-            const int ks = box_slot(M.nb_s[ptr_s + k]);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) valH[3 * ptr_s + (long long)i * deg_s + k] = ks >= 0 ? aH[i][ks] : 0.0;
+            for (int i = 0; i < 3; ++i) valH[3 * ptr_s + (long long)i * deg_s + k] = aH[i][k];
         }
     }
     if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * a + tid] = aR[tid] + (padd ? R[3 * a + tid] : 0.0);

@@ -112,6 +112,7 @@ struct HostModel {
     std::vector<int64_t> pl_dof; std::vector<double> pl_val;
     // neighbour lists (CP level): shell only / shell + coupling
     std::vector<int64_t> nb_ptr_s, nb_ptr_c; std::vector<int> nb_s, nb_c;
+    std::vector<unsigned short> nb_meta;   // per nb_c entry: bits 0-6 box slot of the neighbour (127: coupling-only column), 7-9 Dirichlet flags of its dofs, 10 self
     // mortar points
     std::vector<int> pt_iface;          // [npts]
     std::vector<int> pt_base;           // [npts][2][2] (iu0, iv0) per side
@@ -311,6 +312,28 @@ inline void HostModel::build(const gf_model_desc* D) {
                     const std::vector<int>& src = extra[a].empty() ? box : extra[a];
                     std::copy(src.begin(), src.end(), nb_c.begin() + nb_ptr_c[a]);
                 }
+            }
+        }
+    }
+    // per-entry metadata of the coupling lists: what the gather's write phase would otherwise derive from dependent loads
+    nb_meta.assign(nb_c.size(), 0);
+    for (int s = 0; s < np; ++s) {
+        const PatchDev& P = patches[s];
+        const int *spu = &ints[P.spu], *spv = &ints[P.spv], *c2u = &ints[P.c2u], *c2v = &ints[P.c2v];
+        for (int j = 0; j < P.nv; ++j) for (int i = 0; i < P.nu; ++i) {
+            const int64_t a = P.cp_off + i + int64_t(j) * P.nu;
+            const bool has = c2u[2 * i + 1] >= 0 && c2v[2 * j + 1] >= 0;
+            const int i0 = has ? spu[c2u[2 * i]] - P.p : 0, i1 = has ? spu[c2u[2 * i + 1]] : -1, j0 = has ? spv[c2v[2 * j]] - P.q : 0, j1 = has ? spv[c2v[2 * j + 1]] : -1;
+            const int wbox = i1 - i0 + 1;
+            for (int64_t k = nb_ptr_c[a]; k < nb_ptr_c[a + 1]; ++k) {
+                const int64_t b = nb_c[k];
+                int slot = 127;
+                if (b >= P.cp_off && b < P.cp_off + int64_t(P.nu) * P.nv) {
+                    const int lb = int(b - P.cp_off), ib = lb % P.nu, jb = lb / P.nu;
+                    if (ib >= i0 && ib <= i1 && jb >= j0 && jb <= j1) slot = (ib - i0) + (jb - j0) * wbox;
+                }
+                if (slot != 127 && slot > 126) throw std::runtime_error("gf_create: neighbour box too large");
+                nb_meta[k] = (unsigned short)(slot | (zero[3 * b] ? 128 : 0) | (zero[3 * b + 1] ? 256 : 0) | (zero[3 * b + 2] ? 512 : 0) | (b == a ? 1024 : 0));
             }
         }
     }
