@@ -108,3 +108,49 @@ def test_c4_rigid_body_and_reproducibility(c4):
     R0, K0 = D.residual(), D.values(_lib.MAT_K)
     D.assemble(_lib.ASM_ALL)
     assert np.array_equal(R0, D.residual()) and np.array_equal(K0, D.values(_lib.MAT_K))
+
+
+def test_c5_family_p4_properties():
+    """p = 4 (BASELINE.json configs[4] family: synthetic fuselage, MFMA 2x2-tile element kernel) at a size the oracle does
+    not run in seconds (32 patches, 0.3 M dofs): K x and (dR/dCP) x against residual differences, symmetry of K, and
+    bitwise agreement of two assemblies."""
+    from goldfish_amd import _lib
+    spec = G.synthetic_fuselage(8, 4, nel=24, p=4, jitter=2)
+    th = G.random_thickness(spec)
+    A = arrays_from_spec(spec, th)
+    D = _lib.DeviceModel(A)
+    h, u = np.concatenate(th), G.smooth_displacement(spec, 0.5 * spec.h_th)
+    D.set_thickness(h)
+    D.set_u(u)
+    D.assemble(_lib.ASM_ALL)
+    vals = [D.values(w).copy() for w in range(5)]
+    R0 = D.residual().copy()
+    D.assemble(_lib.ASM_ALL)
+    assert np.array_equal(R0, D.residual()) and all(np.array_equal(vals[w], D.values(w)) for w in range(5))
+    rng = np.random.default_rng(1)
+    free = np.ones(A.ndof, bool)
+    free[A.zero_dofs] = False
+    x1, x2 = rng.standard_normal(A.ndof) * free, rng.standard_normal(A.ndof) * free
+    y1, y2 = np.zeros(A.ndof), np.zeros(A.ndof)
+    D.apply(_lib.MAT_K, x1, y1)
+    D.apply(_lib.MAT_K, x2, y2)
+    assert abs(x2 @ y1 - x1 @ y2) < 1e-9 * abs(x2 @ y1)                      # symmetry
+
+    def R_at(setter, base, d, eps):
+        out = []
+        for sgn in (1, -1):
+            setter(base + sgn * eps * d)
+            D.assemble(_lib.ASM_R)
+            out.append(D.residual())
+        setter(base)
+        return (out[0] - out[1]) / (2 * eps)
+
+    fd = R_at(D.set_u, u, x1, 1e-4 * np.abs(u).max())
+    assert _rel(fd[free], y1[free]) < 1e-6
+    c1 = A.cp_hom[1].copy()
+    dc = rng.standard_normal(A.total_cp)
+    yc = np.zeros(A.ndof)
+    D.apply(_lib.MAT_DRDCP1, dc, yc)
+    fd = R_at(lambda v: D.set_cp(1, v), c1, dc, 1e-6 * spec.h_th)
+    assert _rel(fd[free], yc[free]) < 1e-5
+    D.close()
