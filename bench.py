@@ -173,8 +173,8 @@ def main():
                     traffic = tj.get("element_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
-        mfma = (p in (3, 4) and os.environ.get("GF_ELEMENT", "mfma") != "valu")
-        kname = ("kl_element_mfma_kernel" if p == 3 else "kl_element_mfma4_kernel") if mfma else "kl_element_kernel"
+        mfma = os.environ.get("GF_ELEMENT", "mfma") != "valu"
+        kname = ("kl_element_mfma4_kernel" if p == 4 else "kl_element_mfma_kernel") if mfma else "kl_element_kernel"
         out = {
             "metric": "element-Gauss-point updates/sec (assembly+adjoint)", "value": value, "unit": "GP-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,

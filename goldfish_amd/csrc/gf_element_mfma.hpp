@@ -57,16 +57,20 @@ __device__ __forceinline__ void mfma_hazard_gap(double (&t)[9]) {
     asm volatile("s_nop 1" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]));
 }
 
+// P = 3: the tile is exactly full.  P = 2: 9 basis functions / 9 Gauss points use the same code with the lanes x >= 9 and the
+// Gauss-point slots >= 9 of the third group padded by zeros (a third of the tile, still far fewer instructions than the VALU path).
+template <int P>
 __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_first, int flags, double* __restrict__ blk) {
-    using Cfg = ElemCfg<3>;
-    constexpr int P = 3, P1 = 4, NB = 16, NG = 16, ND = 48;
+    static_assert(P == 2 || P == 3, "one 16 x 16 tile: p <= 3");
+    using Cfg = ElemCfg<P>;
+    constexpr int P1 = P + 1, NB = P1 * P1, NG = NB, ND = 3 * NB, NGRP = (NG + 3) / 4;
     const int tid = threadIdx.x, x = tid & 15, kk = tid >> 4;
     const long long e = (long long)e_first + blockIdx.x;
     if (e >= M.nelem) return;
     const ElemDesc ed = M.edesc[e];
     const PatchDev& Pt = M.patches[ed.patch];
 
-    __shared__ __attribute__((aligned(16))) double s_g[4 * ND];     // control-point staging (phases 0-1), residual reduction at the end
+    __shared__ __attribute__((aligned(16))) double s_g[4 * 3 * 16];  // control-point staging (phases 0-1), residual reduction at the end
     double (*s_c)[3] = reinterpret_cast<double (*)[3]>(s_g);
     double (*s_d)[3] = reinterpret_cast<double (*)[3]>(s_g + 3 * NB);
     double* s_h = s_g + 6 * NB; double* s_w = s_g + 7 * NB;
@@ -122,8 +126,8 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     // follow by the quotient rule, rationalize6 being linear in the B-spline values), the three lanes exchange their
     // components through the Gauss point's (not yet written) record, and each produces the record columns c = ic, 3 + ic.
     {
-        const int gp = x, ic = kk < 3 ? kk : 0, gu = gp % P1, gv = gp / P1;
-        const bool act = kk < 3;
+        const int gp = x < NG ? x : NG - 1, ic = kk < 3 ? kk : 0, gu = gp % P1, gv = gp / P1;
+        const bool act = kk < 3 && x < NG;
         double* im = s_im[gp];
         double W[6], t = 0.0;
         if (act) {
@@ -176,7 +180,8 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
 
     const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = (flags & GF_ASM_C_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
     const bool has_bf = (Pt.f[0] != 0.0) || (Pt.f[1] != 0.0) || (Pt.f[2] != 0.0);
-    const int ju = x % P1, jv = x / P1;
+    const int xb = x < NB ? x : 0, ju = xb % P1, jv = xb / P1;
+    const double bval = x < NB ? 1.0 : 0.0;                  // lanes beyond the basis functions contribute zero rows / columns
 
     gf_d4 accK[6], accC[9], accH[3];
     for (int q = 0; q < 6; ++q) accK[q] = gf_d4{0, 0, 0, 0};
@@ -185,10 +190,10 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     double accR[3] = {0.0, 0.0, 0.0};
 
     GF_STAMP(2, tstamp);
-    for (int grp = 0; grp < 4; ++grp) {
-        const int gu = kk, gv = grp;                         // Gauss point of this lane's group: gp = gu + 4 gv
-        const double* im = s_im[4 * grp + kk];
-        const double wq = im[IM_WQ];
+    for (int grp = 0; grp < NGRP; ++grp) {
+        const int gp = 4 * grp + kk, gpc = gp < NG ? gp : NG - 1, gu = gpc % P1, gv = gpc / P1;   // Gauss point of this lane's group
+        const double* im = s_im[gpc];
+        const double wq = gp < NG ? im[IM_WQ] : 0.0;        // padded Gauss-point slots contribute nothing
         // -- basis function x at this Gauss point (registers)
         double phi[5], R0, n0;
         {
@@ -197,8 +202,8 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
             const double Nb[6] = {u0 * v0, u1 * v0, u0 * v1, u2 * v0, u0 * v2, u1 * v1};
             double R[6];
             rationalize6(Nb, im + IM_W, R);
-            for (int k = 0; k < 5; ++k) phi[k] = R[k + 1];
-            R0 = R[0]; n0 = Nb[0];
+            for (int k = 0; k < 5; ++k) phi[k] = bval * R[k + 1];
+            R0 = bval * R[0]; n0 = bval * Nb[0];
         }
         GF_STAMP(3, tstamp);
         // -- row r of G and Hc at this Gauss point
@@ -298,16 +303,17 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     if ((blockIdx.x & 31) == 0 && tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[k], stamp_acc[k]);
 #endif
     wave_lds_sync();
-    for (int i = 0; i < 3; ++i) s_g[(kk * NB + x) * 3 + i] = accR[i];
+    for (int i = 0; i < 3; ++i) s_g[(kk * 16 + x) * 3 + i] = accR[i];
     wave_lds_sync();
     double* out = blk + (size_t)blockIdx.x * Cfg::BLK;
-    if (tid < ND && (flags & GF_ASM_R_BIT)) out[Cfg::OFF_R + tid] = s_g[tid] + s_g[ND + tid] + s_g[2 * ND + tid] + s_g[3 * ND + tid];
+    if (tid < ND && (flags & GF_ASM_R_BIT)) out[Cfg::OFF_R + tid] = s_g[tid] + s_g[48 + tid] + s_g[96 + tid] + s_g[144 + tid];
     // ---- write the element block once: register rr of lane (x, kk) is entry (a, b) = (kk + 4 rr, x)
     constexpr int IJ_I[6] = {0, 0, 0, 1, 1, 2}, IJ_J[6] = {0, 1, 2, 1, 2, 2};
     const int b = x;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int a = kk + 4 * rr;
+        if (a >= NB || b >= NB) continue;
         if (doK) {
 #pragma unroll
             for (int ij = 0; ij < 6; ++ij) {

@@ -73,11 +73,11 @@ def test_assembly_parity(oracle_lib, case):
 
 
 def test_valu_element_kernel_still_matches(oracle_lib, monkeypatch):
-    """The FP64-VALU element kernel (p = 2 always; p = 3, 4 with GF_ELEMENT=valu) stays a supported path."""
+    """The FP64-VALU element kernel (GF_ELEMENT=valu) stays a supported path for every degree."""
     from goldfish_amd import _lib
     from oracle.oracle_py import Oracle
     monkeypatch.setenv("GF_ELEMENT", "valu")
-    for case in ("shell3x2_p3", "shell2x2_p4"):
+    for case in ("tbeam2_p2", "shell3x2_p3", "shell2x2_p4"):
         A, h, u = _state(CASES[case]())
         O = Oracle(A, thickness=h, u=u)
         D = _lib.DeviceModel(A)
