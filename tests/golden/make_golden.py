@@ -32,7 +32,8 @@ def plate_from_reference_data():
     return spec
 
 
-CASES = {"tbeam2": lambda: G.tbeam_2patch(4), "plate6_refdata": plate_from_reference_data}
+CASES = {"tbeam2": lambda: G.tbeam_2patch(4), "plate6_refdata": plate_from_reference_data,
+         "tbeam2_p2": lambda: G.tbeam_2patch(4, p=2), "shell2x2_p4": lambda: G.synthetic_shell(2, 2, nel=3, p=4, jitter=1)}
 
 
 def state(spec, seed=11):
@@ -44,6 +45,8 @@ def state(spec, seed=11):
 
 def main():
     for name, make in CASES.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         A, h, u = state(make())
         O = Oracle(A, thickness=h, u=u)
         vals = O.assemble()
