@@ -113,6 +113,27 @@ def test_strip_accumulating_element_kernel(oracle_lib, monkeypatch):
         D.close()
 
 
+@pytest.mark.parametrize("p", [2, 3, 4])
+def test_large_deformation_and_thickness_contrast(oracle_lib, p):
+    """Parity away from the small-strain regime: displacements of 30x the thickness scale, thickness varying 4x."""
+    from goldfish_amd import _lib
+    from oracle.oracle_py import Oracle
+    spec = G.synthetic_shell(3, 2, nel=4, p=p, jitter=1)
+    rng = np.random.default_rng(7)
+    th = [spec.h_th * rng.uniform(0.5, 2.0, q.ncp) for q in spec.patches]
+    A = arrays_from_spec(spec, th)
+    h, u = np.concatenate(th), 0.3 * rng.standard_normal(A.ndof)
+    O, D = Oracle(A, thickness=h, u=u), _lib.DeviceModel(A)
+    D.set_thickness(h)
+    D.set_u(u)
+    D.assemble(_lib.ASM_ALL)
+    assert _rel(D.residual(), O.residual()) < RTOL
+    vals = O.assemble()
+    for which in range(5):
+        assert _rel(D.values(which), vals[which]) < RTOL, which
+    D.close()
+
+
 def test_zero_state_and_reproducible(oracle_lib):
     """u = 0 (reference == deformed) and bitwise run-to-run reproducibility of the assembly
     (atomic-free owner gathers)."""
