@@ -77,6 +77,7 @@ class DeviceModel:
         h = C.c_void_p()
         _check(lib().gf_create(C.byref(self._desc), int(device), C.byref(h)))
         self.h = h
+        self.device = int(device)
         self.total_cp, self.ndof = arrays.total_cp, arrays.ndof
         self._pat = {}
         for f in range(3):

@@ -13,6 +13,8 @@ All arithmetic happens in libgoldfish_hip.so; there is no CPU fallback.
 """
 from dataclasses import dataclass
 
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -231,6 +233,32 @@ class NonMatchingOpt:
     # ------------------------------------------------------------------ residual and Jacobians
     def _assemble(self, flags):
         self.dev.assemble(flags)
+        if flags & _lib.ASM_K:
+            self._k_version = getattr(self, "_k_version", 0) + 1
+
+    # ------------------------------------------------------------------ direct solves with K
+    linear_solver = os.environ.get("GF_LINEAR_SOLVER", "host")     # "host": scipy SuperLU per call; "device": rocSOLVER re-factorisation
+
+    def solve_K(self, rhs):
+        """x = K^{-1} rhs (= K^{-T} rhs: K is symmetric) with the tangent currently assembled on the device.
+        ``linear_solver == "device"``: ordering and symbolic factorisation once on the host, then every call after a new
+        assembly is a numeric re-factorisation + triangular solves on the GPU (goldfish_amd/_solver.py); K's values are read
+        in place from the library's buffer.  Replaces GOLDFISH/utils/opt_utils.py:156-209 (MUMPS on a copy of K per call)."""
+        rhs = np.asarray(rhs, float)
+        ver = getattr(self, "_k_version", 0)
+        if self.linear_solver == "device":
+            from . import _solver
+            if getattr(self, "_dsolver", None) is None:
+                self._dsolver = _solver.DeviceSolver(self.dev)
+                self._dsolver_version = ver
+            elif self._dsolver_version != ver:
+                self._dsolver.refactor()
+                self._dsolver_version = ver
+            return self._dsolver.solve(rhs)
+        from scipy.sparse.linalg import splu
+        if getattr(self, "_hlu", None) is None or self._hlu_version != ver:
+            self._hlu, self._hlu_version = splu(self.dev.csr(_lib.MAT_K).tocsc()), ver
+        return self._hlu.solve(rhs)
 
     def RIGA(self):
         """Non-matching residual in IGA dofs, Dirichlet rows zeroed (nonmatching_opt.py:941-948)."""
@@ -281,11 +309,9 @@ class NonMatchingOpt:
     def solve_linear_nonmatching_problem(self, iga_dofs=True):
         """One Newton step from the current state (PENGoLINS solve_linear_nonmatching_problem;
         reference call sites GOLDFISH/tests/test_dRdt.py:121).  The factorisation runs on the
-        host (scipy SuperLU), as MUMPS does in the reference."""
-        from scipy.sparse.linalg import spsolve
+        host (scipy SuperLU, as MUMPS does in the reference) or, with ``linear_solver = "device"``, on the GPU (solve_K)."""
         self._assemble(_lib.ASM_R | _lib.ASM_K)
-        K, R = self.dev.csr(_lib.MAT_K).tocsc(), self.dev.residual()
-        du = spsolve(K, -R)
+        du = self.solve_K(-self.dev.residual())
         self.update_uIGA(self.u_iga + du)
         return self.u_iga
 
@@ -294,7 +320,6 @@ class NonMatchingOpt:
         """Newton iteration on R(u) = 0 (PENGoLINS; used by DispImOpeartion.solve_nonlinear,
         GOLDFISH/operations/disp_imop.py:38-44: max_it=30, rtol=1e-3, start from zero when
         zero_mortar_funcs)."""
-        from scipy.sparse.linalg import spsolve
         if zero_mortar_funcs:
             self.update_uIGA(np.zeros(self.vec_iga_dof))
         for it in range(max_it):
@@ -305,7 +330,7 @@ class NonMatchingOpt:
                 ref_error = nrm if nrm > 0 else 1.0
             if nrm / ref_error < rtol:
                 break
-            du = spsolve(self.dev.csr(_lib.MAT_K).tocsc(), -R)
+            du = self.solve_K(-R)
             self.update_uIGA(self.u_iga + du)
         return None, self.u_iga
 

@@ -90,19 +90,13 @@ class DispImOpeartion(object):
                     d_inputs_array_list[len(self.opt_field)][:] += acc
         return d_inputs_array_list, d_outputs_array
 
-    # direct solves (host) ------------------------------------------------
-    def _factor(self):
-        if self._lu is None:
-            from scipy.sparse.linalg import splu
-            self._lu = splu(self.nonmatching_opt.dev.csr(_lib.MAT_K).tocsc())
-        return self._lu
-
+    # direct solves: NonMatchingOpt.solve_K -- host SuperLU or device re-factorisation --------------
     def solve_linear_fwd(self, d_outputs_array, d_residuals_array):
         """disp_imop.py:130-135: d_outputs = K^{-1} d_residuals."""
-        d_outputs_array[:] = self._factor().solve(np.asarray(d_residuals_array, float))
+        d_outputs_array[:] = self.nonmatching_opt.solve_K(d_residuals_array)
         return d_outputs_array
 
     def solve_linear_rev(self, d_outputs_array, d_residuals_array):
-        """disp_imop.py:137-142: d_residuals = K^{-T} d_outputs."""
-        d_residuals_array[:] = self._factor().solve(np.asarray(d_outputs_array, float), trans="T")
+        """disp_imop.py:137-142: d_residuals = K^{-T} d_outputs (K is symmetric including its Dirichlet treatment)."""
+        d_residuals_array[:] = self.nonmatching_opt.solve_K(d_outputs_array)
         return d_residuals_array

@@ -338,3 +338,21 @@ def test_thickness_optimisation_loop_descends():
     assert out["W"] < 0.9 * out["W0"]
     assert abs(out["V"] - out["V0"]) < 1e-6 * out["V0"]
     assert out["h"][0] > out["h"][-1]            # material moves towards the clamped root
+
+
+@pytest.mark.skipif(os.environ.get("GF_TEST_SOLVER") != "1",
+                    reason="first use of rocSOLVER/rocSPARSE (1.4 GB of libraries) takes 3-5 minutes on a fresh box; set GF_TEST_SOLVER=1 "
+                           "(measured run: profiles/r01_v11_device_solver_bench.txt)")
+def test_device_linear_solver():
+    """N1: Newton solve and adjoint solve with linear_solver = "device" (re-factorisation on the GPU) against the host path."""
+    from goldfish_amd.nonmatching_opt import NonMatchingOpt
+    spec = G.tbeam_2patch(6)
+    nm_d, nm_h = NonMatchingOpt.from_spec(spec), NonMatchingOpt.from_spec(spec)
+    nm_d.linear_solver = "device"
+    _, ud = nm_d.solve_nonlinear_nonmatching_problem(rtol=1e-9, max_it=30)
+    _, uh = nm_h.solve_nonlinear_nonmatching_problem(rtol=1e-9, max_it=30)
+    assert _rel(ud, uh) < 1e-7
+    lam = np.random.default_rng(0).standard_normal(nm_d.vec_iga_dof)
+    nm_d._assemble(3)
+    nm_h._assemble(3)
+    assert _rel(nm_d.solve_K(lam), nm_h.solve_K(lam)) < 1e-7

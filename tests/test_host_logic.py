@@ -66,6 +66,43 @@ def test_library_exports_every_declared_symbol():
     _lib.lib()
 
 
+def test_solver_library_exports_every_declared_symbol():
+    """libgoldfish_solver.so (device re-factorisation + solves) loads and exports what
+    include/goldfish_solver.h declares; the generic-pattern symbolic step keeps fill that is numerically zero for the
+    actual matrix (scipy drops such entries from SuperLU's factors)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from goldfish_amd import _solver, build
+    build.build()
+    hdr = open(os.path.join(ROOT, "include", "goldfish_solver.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(gfs_[a-z_]+)\s*\(", hdr)))
+    assert declared == sorted(_solver.EXPORTS)
+    L = ctypes.CDLL(_solver.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    # arrow matrix whose first row/column is numerically zero except the diagonal: the fill it causes must stay in the pattern
+    n = 12
+    rows, cols = [0] * (n - 1) + list(range(1, n)), list(range(1, n)) + [0] * (n - 1)
+    K = sp.csr_matrix((np.concatenate([np.zeros(2 * (n - 1)), np.ones(n)]), (rows + list(range(n)), cols + list(range(n)))), shape=(n, n))
+    K.sum_duplicates()
+    T, pivP, pivQ = _solver.host_symbolic(K)
+    assert np.array_equal(pivP, pivQ) and sorted(pivP) == list(range(n))
+    G = sp.csr_matrix(([2.0 + 0.01 * k for k in range(K.nnz)], K.indices, K.indptr), shape=(n, n))
+    G = (G + G.T + 50 * sp.identity(n)).tocsc()                   # a matrix with the same structure and no zeros
+    Pm = sp.csr_matrix((np.ones(n), (np.arange(n), pivP)), shape=(n, n))
+    Qm = sp.csr_matrix((np.ones(n), (pivQ, np.arange(n))), shape=(n, n))
+    B = (Pm @ G @ Qm).toarray()                                  # row i of P G is row pivP[i] of G, column j of G Q is column pivQ[j]
+    Lm, Um = np.eye(n), B.copy()
+    for k in range(n):                                            # LU without pivoting of the permuted matrix: fill must lie inside T's pattern
+        for i in range(k + 1, n):
+            Lm[i, k] = Um[i, k] / Um[k, k]
+            Um[i] -= Lm[i, k] * Um[k]
+    fill = (np.abs(np.tril(Lm, -1)) + np.abs(np.triu(Um))) > 1e-14
+    stored = {(r, int(c)) for r in range(n) for c in T.indices[T.indptr[r]:T.indptr[r + 1]]}
+    assert {(int(r), int(c)) for r, c in zip(*np.nonzero(fill))} <= stored
+
+
 def test_partition_and_shards():
     spec = G.synthetic_shell(4, 3, nel=4, p=3, jitter=1)
     for world in (1, 2, 3, 4):
