@@ -341,7 +341,7 @@ def test_thickness_optimisation_loop_descends():
 
 
 @pytest.mark.skipif(os.environ.get("GF_TEST_SOLVER") != "1",
-                    reason="first use of rocSOLVER/rocSPARSE (1.4 GB of libraries) takes 3-5 minutes on a fresh box; set GF_TEST_SOLVER=1 "
+                    reason="first use of rocSOLVER/rocSPARSE (1.4 GB of libraries) takes 3-11 minutes on a fresh box of this pool; set GF_TEST_SOLVER=1 "
                            "(measured run: profiles/r01_v11_device_solver_bench.txt)")
 def test_device_linear_solver():
     """N1: Newton solve and adjoint solve with linear_solver = "device" (re-factorisation on the GPU) against the host path."""
