@@ -9,7 +9,8 @@ t = time.time(); ctypes.CDLL("/root/repo/goldfish_amd/libgoldfish_solver.so", mo
 from goldfish_amd import _lib, _solver, geometry as G
 from goldfish_amd.model import arrays_from_spec
 import scipy.sparse as sp, scipy.sparse.linalg as spla
-for name, spec in (("tbeam2 (342 dofs)", G.tbeam_2patch(6)), ("C2 tbeam4", G.tbeam_4patch()), ("shell 4x4 patches nel=24", G.synthetic_shell(4, 4, nel=24, p=3, jitter=2))):
+for name, spec in (("tbeam2 (342 dofs)", G.tbeam_2patch(6)), ("C2 tbeam4", G.tbeam_4patch()), ("shell 4x4 patches nel=24", G.synthetic_shell(4, 4, nel=24, p=3, jitter=2)),
+                   ("shell 6x6 patches nel=24", G.synthetic_shell(6, 6, nel=24, p=3, jitter=2))):
     A = arrays_from_spec(spec)
     D = _lib.DeviceModel(A)
     D.set_thickness(np.full(A.total_cp, spec.h_th)); D.set_u(np.zeros(A.ndof))
