@@ -1,4 +1,4 @@
-// gf_element_mfma.hpp -- p = 3 element kernel whose a-b contraction runs on the FP64 matrix pipe.
+// gf_element_mfma.hpp -- element kernel (p = 3, and p = 2 with a padded tile) whose a-b contraction runs on the FP64 matrix pipe.
 //
 // Why: the VALU kernel (kl_element_kernel) is bound by per-wave instruction issue (~900 instructions per
 // Gauss point and wave for ~340 FP64 operations; the T tile makes a round trip through LDS).  With (p+1)^2 = 16
@@ -45,11 +45,11 @@ __device__ __forceinline__ void dpp_source_fence(double (&g)[15]) {
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
 }
-// VALU result -> MFMA operand needs two wait states; the FMAs above are opaque to the compiler's hazard recogniser
-// (the operands are tied to the nop so that it stays between the last FMA and the first MFMA of a batch)
 // One wave per workgroup: its LDS operations execute in order, so cross-lane hand-over through LDS needs neither s_barrier
 // nor the global-memory fence of __syncthreads().
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// VALU result -> MFMA operand needs two wait states; the FMAs above are opaque to the compiler's hazard recogniser
+// (the operands are tied to the nop so that it stays between the last FMA and the first MFMA of a batch)
 __device__ __forceinline__ void mfma_hazard_gap(double (&t)[6]) {
     asm volatile("s_nop 1" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]));
 }
