@@ -139,8 +139,10 @@ def allgather_owned_rows(shard, local_rows, dist, width=3, out=None):
     recv = torch.empty(shard.world * mx, dtype=torch.float64, device=local_rows.device)
     if dist.get_backend() == "nccl":
         dist.all_gather_into_tensor(recv, send)
-    else:
-        dist.all_gather(list(recv.view(shard.world, mx).unbind(0)), send)
+    else:                                                       # gloo (tests, rehearsal): host tensors
+        parts = [torch.empty(mx, dtype=torch.float64) for _ in range(shard.world)]
+        dist.all_gather(parts, send.cpu())
+        recv = torch.cat(parts).to(local_rows.device)
     for r, (a, b) in enumerate(rng):
         out[a:b] = recv[r * mx:r * mx + (b - a)]
     return out
