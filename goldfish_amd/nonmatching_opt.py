@@ -166,6 +166,42 @@ class NonMatchingOpt:
             self.init_h_th_list = [np.array([float(np.mean(h))]) for h in self.h_th]
             self.init_h_th = np.concatenate(self.init_h_th_list)
 
+    # ------------------------------------------------------------------ attributes the reference's components read
+    # (SURVEY.md 8(b)).  "FE" and "IGA" dofs coincide here (assembly is done directly in IGA dofs), so the FE-named
+    # attributes are views of the same data.
+    @property
+    def vec_scalar_fe_dof(self):
+        return self.vec_scalar_iga_dof
+
+    @property
+    def init_h_th_fe(self):
+        return np.concatenate(self.h_th)
+
+    @property
+    def h_th_fe_list(self):
+        return [h.copy() for h in self.h_th]
+
+    @property
+    def cpdes_iga_nest(self):
+        """Current homogeneous control-point coordinates of the optimised patches, one array per opt field
+        (nested PETSc vectors in the reference, nonmatching_opt.py:158-185)."""
+        return [self.cp_iga[f][self._shopt_cols[i]].copy() for i, f in enumerate(self.opt_field)]
+
+    cpdes_fe_nest = cpdes_iga_nest
+
+    @property
+    def shopt_cpsurf_fe_hom_list(self):
+        """(n, 4) homogeneous control points of the optimised patches (nonmatching_opt_ffd.py:60-141)."""
+        cols = self._shopt_cols[0]
+        w = np.concatenate([s.cp_hom_flat()[:, 3] for s in self.splines])[cols]
+        return np.stack([self.cp_iga[f][cols] for f in range(3)] + [w], 1)
+
+    @property
+    def cpsurf_des_lims(self):
+        """Bounding box of the optimised patches' physical control points (used to size the FFD block)."""
+        H = self.shopt_cpsurf_fe_hom_list
+        return [[float((H[:, f] / H[:, 3]).min()), float((H[:, f] / H[:, 3]).max())] for f in range(3)]
+
     # ------------------------------------------------------------------ device model
     def _arrays(self):
         alphas = [penalty_parameters(self.splines, self.h_th, self.E, self.nu, itf, self.penalty_coefficient)

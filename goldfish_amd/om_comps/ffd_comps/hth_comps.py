@@ -2,7 +2,8 @@
 HthFFD2FEComp   GOLDFISH/om_comps/ffd_comps/hthffd2fe_comp.py:4-36    FFD thickness coefficients -> thickness at the control points
 HthFFDAlignComp GOLDFISH/om_comps/ffd_comps/hthffd_align_comp.py:4-36 equality constraint rows (aligned layers)
 HthFFDReguComp  GOLDFISH/om_comps/ffd_comps/hthffd_regu_comp.py:4-45  inequality constraint rows (neighbour differences)
-HthMapComp      GOLDFISH/om_comps/ffd_comps/hth_map_comp.py:6-50      one thickness per patch -> full thickness vector"""
+HthMapComp      GOLDFISH/om_comps/ffd_comps/hth_map_comp.py:6-50      one thickness per patch -> full thickness vector
+HthFE2IGAComp   GOLDFISH/om_comps/hthfe2iga_comp.py:5-70               thickness "FE dofs" -> IGA control-point values: the identity here"""
 import numpy as np
 import scipy.sparse as sp
 
@@ -102,3 +103,22 @@ class HthMapComp(_LinearMapComp):
 
     def get_derivative(self, coo=True):
         return self.deriv if coo else self.deriv.toarray()
+
+
+class HthFE2IGAComp(_LinearMapComp):
+    """In the reference an implicit L2 projection of the FE thickness function onto the IGA control-point values
+    (operations/hthfe2iga_imop.py); thickness lives directly on the control points here, so the map is the identity.
+    Kept so that the demos' wiring thickness_FE -> thickness_IGA works unchanged."""
+
+    def initialize(self):
+        self.options.declare('nonmatching_opt')
+        self.options.declare('input_h_th_fe_name', default='thickness_FE')
+        self.options.declare('output_h_th_iga_name', default='thickness_IGA')
+
+    def init_parameters(self):
+        nm = self.nonmatching_opt = self.options['nonmatching_opt']
+        self.in_name = self.input_h_th_fe_name = self.options['input_h_th_fe_name']
+        self.out_name = self.output_h_th_iga_name = self.options['output_h_th_iga_name']
+        self.input_shape = self.output_shape = nm.vec_scalar_iga_dof
+        self.init = nm.init_h_th_fe
+        self.deriv = sp.identity(nm.vec_scalar_iga_dof, format="coo")

@@ -249,6 +249,16 @@ def test_thickness_ffd_maps_and_design_components():
         prob.run_model()
         errs = prob.check_partials(step=1e-3)
         assert errs and max(errs.values()) < 1e-9, (type(comp).__name__, errs)
+    from goldfish_amd.om_comps.ffd_comps import HthFE2IGAComp
+    fe = HthFE2IGAComp(nonmatching_opt=pb)
+    fe.init_parameters()
+    prob = om_shim.Problem(model=fe)
+    prob.setup()
+    prob.run_model()
+    assert np.array_equal(prob["thickness_IGA"], pb.init_h_th_fe) and max(prob.check_partials(step=1e-3).values()) < 1e-9
+    for attr in ("vec_scalar_fe_dof", "init_h_th_fe", "h_th_fe_list", "cpdes_iga_nest", "cpdes_fe_nest", "shopt_cpsurf_fe_hom_list", "cpsurf_des_lims"):
+        assert getattr(pb, attr) is not None, attr
+    assert pb.shopt_cpsurf_fe_hom_list.shape == (pb._shopt_cols[0].size, 4)
     hm = HthMapComp(nonmatching_opt=pb)
     hm.init_parameters()
     assert hm.deriv.shape == (pb.vec_scalar_iga_dof, pb.num_splines) and np.allclose(hm.deriv @ hm.init, np.concatenate(pb.h_th))
