@@ -62,7 +62,7 @@ __device__ unsigned long long g_stamps[8];
 #define GF_STAMP(slot, t0) do { } while (0)
 #endif
 template <int P>
-__global__ __launch_bounds__(ElemCfg<P>::NT, ElemCfg<P>::NT / 64) void kl_element_kernel(DevModel M, int e_first, int flags, double* __restrict__ blk) {
+__global__ __launch_bounds__(ElemCfg<P>::NT, (P >= 4 ? 1 : ElemCfg<P>::NT / 64)) void kl_element_kernel(DevModel M, int e_first, int flags, double* __restrict__ blk) {
     using Cfg = ElemCfg<P>;
     constexpr int P1 = Cfg::P1, NB = Cfg::NB, NG = Cfg::NG, ND = Cfg::ND, AG = Cfg::AG, NAG = Cfg::NAG, NT = Cfg::NT;
     constexpr int TS = 5 * 16 + 2;                 // T row per b: [m][16 q-slots] (+2 pad: conflict-free 16-B reads)
