@@ -510,6 +510,30 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
     if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * a + tid] = aR[tid] + (padd ? R[3 * a + tid] : 0.0);
 }
 
+// Residual-only gather (flags == R, e.g. DispImOpeartion.apply_nonlinear, line searches): one thread per owned control
+// point sums the three residual entries of its <= (p+1)^2 element blocks in the same fixed order as kl_gather_kernel.
+template <int P>
+__global__ __launch_bounds__(256) void kl_rgather_kernel(DevModel M, long long a_first, long long a_end, long long e_first, long long e_count,
+                                                          const double* __restrict__ blk, double* __restrict__ R, int pen_add) {
+    using Cfg = ElemCfg<P>;
+    constexpr int P1 = P + 1;
+    const long long a = a_first + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= a_end) return;
+    const PatchDev& Pt = M.patches[M.cp_patch[a]];
+    const int la = int(a - Pt.cp_off), ia = la % Pt.nu, ja = la / Pt.nu;
+    const int* spu = M.ints + Pt.spu; const int* spv = M.ints + Pt.spv; const int* c2u = M.ints + Pt.c2u; const int* c2v = M.ints + Pt.c2v;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int ev = c2v[2 * ja]; ev <= c2v[2 * ja + 1]; ++ev) for (int eu = c2u[2 * ia]; eu <= c2u[2 * ia + 1]; ++eu) {
+        const long long e = Pt.elem_off + eu + (long long)ev * Pt.nelu - e_first;
+        if (e < 0 || e >= e_count) continue;
+        const int al = (ia - (spu[eu] - P)) + (ja - (spv[ev] - P)) * P1;
+        const double* B = blk + (size_t)e * Cfg::BLK + Cfg::OFF_R + 3 * al;
+        for (int i = 0; i < 3; ++i) acc[i] += B[i];
+    }
+    const bool padd = pen_add && M.pen_row[a];
+    for (int i = 0; i < 3; ++i) R[3 * a + i] = acc[i] + (padd ? R[3 * a + i] : 0.0);
+}
+
 // ------------------------------------------------------------------------------------- functionals
 // K10 of SURVEY.md 2.2: strain energy W = sum int Psi, volume V = sum int t dA and their gradients.
 // One wave per element; per-element gradients go to a block [NB][11] (+ We, Ve), summed per control

@@ -255,6 +255,9 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
         else hipLaunchKernelGGL(kl_element_kernel<P>, dim3((unsigned)ne), dim3(Cfg::NT), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
         HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
         h->ev_n++;
+        if (flags == GF_ASM_R && !(P == 3 && h->strip))
+            hipLaunchKernelGGL(kl_rgather_kernel<P>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, h->d_blk, h->d_R, pen);
+        else
         hipLaunchKernelGGL(kl_gather_kernel<P>, dim3((unsigned)na), dim3(256), 0, h->stream, h->M, c.a0, c.e0, ne, flags, h->d_blk,
                            h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R, pen,
                            (P == 3 && h->strip) ? h->d_strips : nullptr, h->d_strip_off);
