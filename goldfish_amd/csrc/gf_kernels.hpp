@@ -709,7 +709,7 @@ struct DevPenalty {
 
 // one thread per mortar vertex: kinematics of both sides + pointwise gradient/Hessians -> pbuf
 template <int P>
-__global__ __launch_bounds__(64) void pen_point_kernel(DevModel M, DevPenalty Q, double* __restrict__ pbuf) {
+__global__ __launch_bounds__(64) void pen_point_kernel(DevModel M, DevPenalty Q, double* __restrict__ pbuf, int grad_only) {
     constexpr int P1 = P + 1, NB = P1 * P1;
     const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= Q.npts) return;
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(64) void pen_point_kernel(DevModel M, DevPenalty Q,
             }
         }
     }
-    penalty_point(y, Y, Q.pt_tau + 2 * v, Q.if_alpha[2 * itf], Q.if_alpha[2 * itf + 1], Q.pt_wt[v], pbuf + (size_t)v * PB_STRIDE);
+    penalty_point(y, Y, Q.pt_tau + 2 * v, Q.if_alpha[2 * itf], Q.if_alpha[2 * itf + 1], Q.pt_wt[v], pbuf + (size_t)v * PB_STRIDE, grad_only != 0);
 }
 
 // Penalty rows of one owned control point a (one wave each): residual entries and the coupling blocks
@@ -788,8 +788,10 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
             const long long v = E[u].v; const int s = E[u].sal >> 8, al = E[u].sal & 255;
             const double* na = Q.pt_nu + ((size_t)v * 2 + s) * 3 * NB; const double* pb = pbuf + (size_t)v * PB_STRIDE;
             n3[u][0] = na[al]; n3[u][1] = na[NB + al]; n3[u][2] = na[2 * NB + al];
-            { const double* h = pb + PB_HYY + (9 * s + iK) * 18 + cK; hk[u][0] = h[0]; hk[u][1] = h[3 * 18]; hk[u][2] = h[6 * 18]; }
-            { const double* h = pb + PB_HYC + (9 * s + iC) * 12 + cC; hc[u][0] = h[0]; hc[u][1] = h[3 * 12]; hc[u][2] = h[6 * 12]; }
+            if (mats) {                                  // residual-only: the Hessian slots of the vertex record are not even computed
+                { const double* h = pb + PB_HYY + (9 * s + iK) * 18 + cK; hk[u][0] = h[0]; hk[u][1] = h[3 * 18]; hk[u][2] = h[6 * 18]; }
+                { const double* h = pb + PB_HYC + (9 * s + iC) * 12 + cC; hc[u][0] = h[0]; hc[u][1] = h[3 * 12]; hc[u][2] = h[6 * 12]; }
+            } else { for (int q = 0; q < 3; ++q) { hk[u][q] = 0.0; hc[u][q] = 0.0; } }
             { const double* g = pb + PB_GRAD + 9 * s + (tid < 3 ? tid : 0); g3[u][0] = g[0]; g3[u][1] = g[3]; g3[u][2] = g[6]; }
 #pragma unroll
             for (int sl = 0; sl < PEN_SL; ++sl) {
@@ -800,7 +802,7 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
                 const bool in = t >= 0 && di >= 0 && di <= P && dj >= 0 && dj <= P;
                 tt[u][sl] = in ? t : -1;
                 const double* nb = Q.pt_nu + ((size_t)v * 2 + (in ? t : 0)) * 3 * NB + (in ? di + dj * P1 : 0);
-                bv[u][sl][0] = nb[0]; bv[u][sl][1] = nb[NB]; bv[u][sl][2] = nb[2 * NB];
+                if (mats) { bv[u][sl][0] = nb[0]; bv[u][sl][1] = nb[NB]; bv[u][sl][2] = nb[2 * NB]; } else { bv[u][sl][0] = bv[u][sl][1] = bv[u][sl][2] = 0.0; }
             }
         }
         // -- w-vectors of both visits, one barrier
@@ -808,8 +810,8 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
         for (int u = 0; u < 2; ++u) {
             if (u < nu_) {
                 double (*w)[32] = s_w[2 * pair + u];
-                if (tid < 54) w[iK][cK] = n3[u][0] * hk[u][0] + n3[u][1] * hk[u][1] + n3[u][2] * hk[u][2];
-                if (tid < 36) w[iC][18 + cC] = n3[u][0] * hc[u][0] + n3[u][1] * hc[u][1] + n3[u][2] * hc[u][2];
+                if (mats && tid < 54) w[iK][cK] = n3[u][0] * hk[u][0] + n3[u][1] * hk[u][1] + n3[u][2] * hk[u][2];
+                if (mats && tid < 36) w[iC][18 + cC] = n3[u][0] * hc[u][0] + n3[u][1] * hc[u][1] + n3[u][2] * hc[u][2];
                 if (tid < 3) racc += n3[u][0] * g3[u][0] + n3[u][1] * g3[u][1] + n3[u][2] * g3[u][2];
             }
         }

@@ -237,7 +237,7 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
     // by what the overlap saves (profiles/r01_v8_*).
     const int pen = (H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP))) ? 1 : 0;
     if (pen) {
-        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf);
+        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf, (flags & (GF_ASM_K | GF_ASM_DRDCP)) ? 0 : 1);
         const dim3 grid((unsigned)h->Q.nrow_groups), blk64(64);
         const int sl = (h->pen_maxdeg + 63) / 64;         // neighbour slots per lane, register resident
 #define GF_PEN_LAUNCH(SL) hipLaunchKernelGGL((pen_owner_kernel<P, SL>), grid, blk64, 0, h->stream, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \
@@ -280,7 +280,7 @@ template <int P> static void run_functionals(gf_handle* h, int apply_bcs) {
     }
     const HostModel& H = h->H;
     if (H.npts > 0) {
-        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf);
+        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf, 1);
         hipLaunchKernelGGL(pen_energy_kernel, dim3((unsigned)((H.npts + 255) / 256)), dim3(256), 0, h->stream, (long long)H.npts, h->d_pbuf, h->d_pen_en);
     }
     HIPCHK(hipGetLastError());

@@ -447,11 +447,12 @@ constexpr int PB_STRIDE = PB_SIZE + 2;   // + energy + pad
 
 // One mortar vertex: y[18] = (uA, gA1, gA2, uB, gB1, gB2), Y[12] = (GA1, GA2, GB1, GB2).
 // out: grad[18], Hyy[18][18], HyC[18][12] where HyC = Hyy[:, tangent cols] + HyY (the dR/dCP operator).
-GF_HD inline void penalty_point(const double* y, const double* Y, const double* tau, double ad, double ar, double dt, double* out) {
+// grad_only: energy and gradient only (residual-only assemblies, functionals); the Hessian slots are left untouched.
+GF_HD inline void penalty_point(const double* y, const double* Y, const double* tau, double ad, double ar, double dt, double* out, bool grad_only = false) {
     const int tan[12] = {3, 4, 5, 6, 7, 8, 12, 13, 14, 15, 16, 17};
     double s1, s2, S1, S2, g1[12], g2[12], G1[12], G2[12], L, Lr, at[3], At[3];
     double H1[12][12], H2[12][12];
-    s_terms(y + 3, y + 12, tau, s1, s2, g1, g2, H1, H2, L, at);
+    s_terms(y + 3, y + 12, tau, s1, s2, g1, g2, grad_only ? nullptr : H1, grad_only ? nullptr : H2, L, at);
     s_terms(Y, Y + 6, tau, S1, S2, G1, G2, nullptr, nullptr, Lr, At);
     const double e1 = s1 - S1, e2 = s2 - S2, c0 = dt * Lr;
     double d[3] = {y[0] - y[9], y[1] - y[10], y[2] - y[11]};
@@ -460,6 +461,7 @@ GF_HD inline void penalty_point(const double* y, const double* Y, const double* 
     for (int k = 0; k < 18; ++k) grad[k] = 0.0;
     for (int k = 0; k < 3; ++k) { grad[k] = c0 * ad * d[k]; grad[9 + k] = -c0 * ad * d[k]; }
     for (int k = 0; k < 12; ++k) grad[tan[k]] = c0 * ar * (e1 * g1[k] + e2 * g2[k]);
+    if (grad_only) return;
     for (int k = 0; k < 324; ++k) Hyy[k] = 0.0;
     for (int k = 0; k < 3; ++k) {
         Hyy[k * 18 + k] = c0 * ad; Hyy[(9 + k) * 18 + 9 + k] = c0 * ad; Hyy[k * 18 + 9 + k] = -c0 * ad; Hyy[(9 + k) * 18 + k] = -c0 * ad;
