@@ -564,15 +564,38 @@ __global__ __launch_bounds__(64) void kl_functional_kernel(DevModel M, int e_fir
     __syncthreads();
     if (tid < NG) {
         const int gu = tid % P1, gv = tid / P1;
-        double W[6] = {0, 0, 0, 0, 0, 0}, Nb[6], R[6];
-        for (int a = 0; a < NB; ++a) { bspline6<P>(s_tu, s_tv, gu, gv, a, Nb); for (int k = 0; k < 6; ++k) W[k] += Nb[k] * s_w[a]; }
+        // sum factorisation over the tensor-product basis + quotient rule (as in the MFMA element kernels)
+        double Ac[3][6], Ad[3][6], W[6], t = 0.0;
+        for (int k = 0; k < 6; ++k) { W[k] = 0.0; for (int i = 0; i < 3; ++i) { Ac[i][k] = 0.0; Ad[i][k] = 0.0; } }
+        double U[3][P1];
+        for (int d = 0; d < 3; ++d) for (int j = 0; j < P1; ++j) U[d][j] = s_tu[(gu * 3 + d) * P1 + j];
+#pragma unroll
+        for (int jv = 0; jv < P1; ++jv) {
+            const double v0 = s_tv[(gv * 3 + 0) * P1 + jv], v1 = s_tv[(gv * 3 + 1) * P1 + jv], v2 = s_tv[(gv * 3 + 2) * P1 + jv];
+            double S[7][3], Sh = 0.0;
+            for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) S[q][d] = 0.0;
+#pragma unroll
+            for (int ju = 0; ju < P1; ++ju) {
+                const int a = ju + P1 * jv;
+                const double qv[7] = {s_c[a][0], s_c[a][1], s_c[a][2], s_d[a][0], s_d[a][1], s_d[a][2], s_w[a]};
+                for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) S[q][d] += U[d][ju] * qv[q];
+                Sh += U[0][ju] * s_h[a];
+            }
+            t += v0 * Sh;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                double* A = q < 3 ? Ac[q] : (q < 6 ? Ad[q - 3] : W);
+                A[0] += v0 * S[q][0]; A[1] += v0 * S[q][1]; A[2] += v1 * S[q][0];
+                A[3] += v0 * S[q][2]; A[4] += v2 * S[q][0]; A[5] += v1 * S[q][1];
+            }
+        }
         W[0] = 1.0 / W[0];
-        double z[15], Z[15], t = 0.0;
-        for (int k = 0; k < 15; ++k) { z[k] = 0.0; Z[k] = 0.0; }
-        for (int a = 0; a < NB; ++a) {
-            bspline6<P>(s_tu, s_tv, gu, gv, a, Nb); rationalize6(Nb, W, R);
-            t += Nb[0] * s_h[a];
-            for (int m = 0; m < 5; ++m) for (int i = 0; i < 3; ++i) { Z[3 * m + i] += R[m + 1] * s_c[a][i]; z[3 * m + i] += R[m + 1] * s_d[a][i]; }
+        double z[15], Z[15], R[6];
+        for (int i = 0; i < 3; ++i) {
+            rationalize6(Ac[i], W, R);
+            for (int m = 0; m < 5; ++m) Z[3 * m + i] = R[m + 1];
+            rationalize6(Ad[i], W, R);
+            for (int m = 0; m < 5; ++m) z[3 * m + i] = R[m + 1];
         }
         shell_energy_point(z, Z, t, Pt.E, Pt.nu_, s_fe[tid]);
         for (int k = 0; k < 6; ++k) s_fe[tid][FE_SIZE + k] = W[k];
