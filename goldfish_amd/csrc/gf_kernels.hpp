@@ -338,6 +338,10 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
     const int tid = threadIdx.x;
 
     __shared__ double aK[3][NBOX][3], aC[3][3][NBOX], aH[3][NBOX], aR[3];
+    // metadata of the row's entries: fetched now, used in the write phase (the loads overlap the element loop)
+    constexpr int MAXMETA = 320;
+    __shared__ unsigned short s_meta[MAXMETA];
+    for (int k = tid; k < (int)deg_c && k < MAXMETA; k += 256) s_meta[k] = M.nb_meta[ptr_c + k];
     for (int k = tid; k < 9 * NBOX; k += 256) { (&aK[0][0][0])[k] = 0.0; (&aC[0][0][0])[k] = 0.0; }
     for (int k = tid; k < 3 * NBOX; k += 256) (&aH[0][0])[k] = 0.0;
     if (tid < 3) aR[tid] = 0.0;
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
             double* dst = valK + 9 * ptr_c + (long long)i * 3 * deg_c;
             for (int c = lane; c < 3 * (int)deg_c; c += 64) {
                 const int k = c / 3, j = c - 3 * k;
-                const unsigned meta = M.nb_meta[ptr_c + k];
+                const unsigned meta = k < MAXMETA ? s_meta[k] : M.nb_meta[ptr_c + k];
                 const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
                 double v = 0.0;
                 if (zrow || (meta & (128u << j))) v = ((meta & 1024u) && i == j) ? 1.0 : 0.0;
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
             }
         }
         for (int k = lane; k < (int)deg_c; k += 64) {
-            const unsigned meta = M.nb_meta[ptr_c + k];
+            const unsigned meta = k < MAXMETA ? s_meta[k] : M.nb_meta[ptr_c + k];
             const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
             if (flags & GF_ASM_C_BIT) {
 #pragma unroll
