@@ -19,6 +19,7 @@ struct DevModel {
     const PatchDev* patches; const double* tab; const int* ints; const int* elem_patch; const int* cp_patch;
     const double* cp4; const double* u; const double* h; const unsigned char* zero;
     const unsigned short* nb_meta;   // per nb_c entry: box slot | Dirichlet flags of the column dofs | self (gf_setup.hpp)
+    const CpDesc* cpdesc;            // per-control-point descriptors (gather)
     const ElemDesc* edesc;           // per-element descriptors (MFMA element kernel)
     const unsigned char* pen_row;    // 1: the control point owns penalty rows (pen_owner_kernel writes them before the gather adds the shell part)
     const long long* nb_ptr_s; const int* nb_s; const long long* nb_ptr_c; const int* nb_c;
@@ -327,14 +328,9 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
     constexpr int P1 = Cfg::P1, NB = Cfg::NB, ND = Cfg::ND, WB = 2 * P + 1, NBOX = WB * WB;
     const long long a = a_first + blockIdx.x;
     if (a >= M.total_cp) return;
-    const PatchDev& Pt = M.patches[M.cp_patch[a]];
-    const int la = int(a - Pt.cp_off), ia = la % Pt.nu, ja = la / Pt.nu;
-    const int* spu = M.ints + Pt.spu; const int* spv = M.ints + Pt.spv; const int* c2u = M.ints + Pt.c2u; const int* c2v = M.ints + Pt.c2v;
-    const int eu0 = c2u[2 * ia], eu1 = c2u[2 * ia + 1], ev0 = c2v[2 * ja], ev1 = c2v[2 * ja + 1];
-    const int i0 = eu1 >= eu0 ? spu[eu0] - P : 0, j0 = ev1 >= ev0 ? spv[ev0] - P : 0;        // neighbour box origin
-    const int i1 = eu1 >= eu0 ? spu[eu1] : -1, j1 = ev1 >= ev0 ? spv[ev1] : -1, wbox = i1 - i0 + 1;
+    const CpDesc& cd = M.cpdesc[a];                       // uniform (scalar) loads of one 96-byte record: no dependent index chain in front of the row loads
+    const int ia = cd.ia, ja = cd.ja, eu0 = cd.eu0, ev0 = cd.ev0, i0 = cd.i0, j0 = cd.j0, j1 = cd.j1, wbox = cd.i1 - cd.i0 + 1;
     const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c, ptr_s = M.nb_ptr_s[a], deg_s = M.nb_ptr_s[a + 1] - ptr_s;
-    const long long pbeg = Pt.cp_off, pend = Pt.cp_off + (long long)Pt.nu * Pt.nv;
     const int tid = threadIdx.x;
 
     __shared__ double aK[3][NBOX][3], aC[3][3][NBOX], aH[3][NBOX], aR[3];
@@ -353,7 +349,7 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
     // Elements are taken four at a time: the row loads of a group are all issued before the LDS adds
     // of the group, so up to 4 x 6 loads per lane are in flight (the adds keep the fixed element order).
     constexpr int NPASS = (ND + 63) / 64, NPH = (3 * NB + 63) / 64, UNR = 4;
-    const int neu = eu1 - eu0 + 1, nev = ev1 - ev0 + 1, ne = (neu > 0 && nev > 0) ? neu * nev : 0;
+    const int neu = cd.neu, nev = cd.nev, ne = neu * nev;
     if (strips != nullptr) {
         // Strip records (gf_element_strip.hpp): every strip eu containing a holds, per dof row i, the sums over the strip's
         // elements against the 28 neighbours (local u index 0..3 of the strip) x (row offset -3..3).  At most p + 1 strips;
@@ -364,8 +360,8 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
         for (int q = 0; q < MAXS; ++q) {
             const int eu = eu0 + q; sok[q] = q < neu && ne > 0;
             const int euc = sok[q] ? eu : eu0;
-            const StripDesc sd = strips[strip_off[M.cp_patch[a]] + (ne > 0 ? euc : 0)];
-            iu0s[q] = spu[ne > 0 ? euc : 0] - P;
+            const StripDesc sd = strips[strip_off[cd.patch] + (ne > 0 ? euc : 0)];
+            iu0s[q] = cd.bu[sok[q] ? q : 0];
             rec[q] = blk + sd.out_off + (size_t)((ja * 4 + (ia - iu0s[q])) * 3) * RS;
         }
         if (wave < 3) {
@@ -420,11 +416,11 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
         const double* Bp[UNR]; int bu[UNR], bv[UNR], al[UNR]; bool ok[UNR];
 #pragma unroll
         for (int q = 0; q < UNR; ++q) {
-            const int g = g0 + q, gg = g < ne ? g : 0, eu = eu0 + gg % neu, ev = ev0 + gg / neu;
-            const long long e = Pt.elem_off + eu + (long long)ev * Pt.nelu - e_first;
+            const int g = g0 + q, gg = g < ne ? g : 0, ku = gg % (neu > 0 ? neu : 1), kv = gg / (neu > 0 ? neu : 1);
+            const long long e = cd.e00 + ku + (long long)kv * cd.nelu - e_first;
             ok[q] = g < ne && e >= 0 && e < e_count;
             Bp[q] = blk + (size_t)(ok[q] ? e : 0) * Cfg::BLK;
-            bu[q] = spu[eu] - P; bv[q] = spv[ev] - P; al[q] = (ia - bu[q]) + (ja - bv[q]) * P1;
+            bu[q] = cd.bu[ku]; bv[q] = cd.bv[kv]; al[q] = (ia - bu[q]) + (ja - bv[q]) * P1;
         }
         if (wave < 3) {
             const int i = wave;

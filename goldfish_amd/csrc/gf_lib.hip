@@ -84,7 +84,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         }
         DevModel& M = h->M;
         M.patches = h->upload(H.patches); M.tab = h->upload(H.tab); M.ints = h->upload(H.ints);
-        M.elem_patch = h->upload(H.elem_patch); M.cp_patch = h->upload(H.cp_patch); M.edesc = h->upload(H.elem_desc); M.nb_meta = h->upload(H.nb_meta);
+        M.elem_patch = h->upload(H.elem_patch); M.cp_patch = h->upload(H.cp_patch); M.edesc = h->upload(H.elem_desc); M.cpdesc = h->upload(H.cp_desc); M.nb_meta = h->upload(H.nb_meta);
         M.cp4 = h->d_cp4; M.u = h->d_u; M.h = h->d_h; M.zero = h->upload(H.zero);
         M.nb_ptr_s = h->upload(nbs); M.nb_s = h->upload(H.nb_s); M.nb_ptr_c = h->upload(nbc); M.nb_c = h->upload(H.nb_c);
         M.total_cp = H.total_cp; M.nelem = H.nelem;

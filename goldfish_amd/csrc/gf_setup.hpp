@@ -34,6 +34,10 @@ struct PatchDev {            // POD mirrored on the device
 // per-element descriptor: one load instead of the elem_patch -> patch -> span-table chain of dependent scalar loads
 struct ElemDesc { int patch, g0, nu, tabu, tabv, wu, wv, pad; };   // g0: global id of the element's first control point; offsets into tab[]
 
+// per-control-point descriptor of the gather: element range, neighbour box and local indices in one load instead of the
+// cp_patch -> patch -> c2u/c2v -> span-table chain of dependent loads
+struct CpDesc { int patch, ia, ja, eu0, neu, ev0, nev, i0, j0, i1, j1, nelu; long long e00; int bu[5], bv[5]; };   // bu[k] = first CP index of element eu0 + k
+
 // one strip of elements (fixed u-span eu of a patch, all v-spans) of the strip-accumulating element kernel
 struct StripDesc { int patch, eu, e_first, nelv, nv, pad; long long out_off; };   // out_off: doubles from the chunk's scratch base
 
@@ -105,6 +109,7 @@ struct HostModel {
     std::vector<int> ints;              // spans + cp->element ranges
     std::vector<int> elem_patch;        // [nelem]
     std::vector<ElemDesc> elem_desc;    // [nelem]
+    std::vector<CpDesc> cp_desc;        // [total_cp]
     std::vector<StripDesc> strips; std::vector<int> strip_off;   // owned patches' strips (patch-major), first strip of every patch
     std::vector<int> cp_patch;          // [total_cp]
     std::vector<double> weights;
@@ -313,6 +318,21 @@ inline void HostModel::build(const gf_model_desc* D) {
                     std::copy(src.begin(), src.end(), nb_c.begin() + nb_ptr_c[a]);
                 }
             }
+        }
+    }
+    cp_desc.assign(total_cp, CpDesc{});
+    for (int s = 0; s < np; ++s) {
+        const PatchDev& P = patches[s];
+        const int *spu = &ints[P.spu], *spv = &ints[P.spv], *c2u = &ints[P.c2u], *c2v = &ints[P.c2v];
+        for (int j = 0; j < P.nv; ++j) for (int i = 0; i < P.nu; ++i) {
+            CpDesc& c = cp_desc[P.cp_off + i + int64_t(j) * P.nu];
+            const int eu0 = c2u[2 * i], eu1 = c2u[2 * i + 1], ev0 = c2v[2 * j], ev1 = c2v[2 * j + 1];
+            const bool has = eu1 >= eu0 && ev1 >= ev0;
+            c.patch = s; c.ia = i; c.ja = j; c.eu0 = has ? eu0 : 0; c.neu = has ? eu1 - eu0 + 1 : 0; c.ev0 = has ? ev0 : 0; c.nev = has ? ev1 - ev0 + 1 : 0;
+            c.i0 = has ? spu[eu0] - P.p : 0; c.j0 = has ? spv[ev0] - P.q : 0; c.i1 = has ? spu[eu1] : -1; c.j1 = has ? spv[ev1] : -1;
+            c.nelu = P.nelu; c.e00 = P.elem_off + c.eu0 + int64_t(c.ev0) * P.nelu;
+            if (c.neu > 5 || c.nev > 5) throw std::runtime_error("gf_create: a control point lies in more than 5 knot spans per direction");
+            for (int k = 0; k < 5; ++k) { c.bu[k] = k < c.neu ? spu[eu0 + k] - P.p : 0; c.bv[k] = k < c.nev ? spv[ev0 + k] - P.q : 0; }
         }
     }
     // per-entry metadata of the coupling lists: what the gather's write phase would otherwise derive from dependent loads
