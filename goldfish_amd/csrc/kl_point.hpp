@@ -458,22 +458,34 @@ GF_HD inline void penalty_point(const double* y, const double* Y, const double* 
     double d[3] = {y[0] - y[9], y[1] - y[10], y[2] - y[11]};
     out[PB_EN] = c0 * (0.5 * ad * dot3(d, d) + 0.5 * ar * (e1 * e1 + e2 * e2));
     double* grad = out + PB_GRAD; double* Hyy = out + PB_HYY; double* HyC = out + PB_HYC;
-    for (int k = 0; k < 18; ++k) grad[k] = 0.0;
-    for (int k = 0; k < 3; ++k) { grad[k] = c0 * ad * d[k]; grad[9 + k] = -c0 * ad * d[k]; }
-    for (int k = 0; k < 12; ++k) grad[tan[k]] = c0 * ar * (e1 * g1[k] + e2 * g2[k]);
+    double gl[18];                                           // local copy: out is global memory on the device
+    for (int k = 0; k < 18; ++k) gl[k] = 0.0;
+    for (int k = 0; k < 3; ++k) { gl[k] = c0 * ad * d[k]; gl[9 + k] = -c0 * ad * d[k]; }
+    for (int k = 0; k < 12; ++k) gl[tan[k]] = c0 * ar * (e1 * g1[k] + e2 * g2[k]);
+    for (int k = 0; k < 18; ++k) grad[k] = gl[k];
     if (grad_only) return;
-    for (int k = 0; k < 324; ++k) Hyy[k] = 0.0;
-    for (int k = 0; k < 3; ++k) {
-        Hyy[k * 18 + k] = c0 * ad; Hyy[(9 + k) * 18 + 9 + k] = c0 * ad; Hyy[k * 18 + 9 + k] = -c0 * ad; Hyy[(9 + k) * 18 + k] = -c0 * ad;
+    // every entry is computed and stored exactly once (out is global memory on the device: no zero-fill / read-modify-write)
+    // slot kinds of y: 0..2 uA, 3..8 tangents of A, 9..11 uB, 12..17 tangents of B;  tslot[r] = index into the 12 tangent slots or -1
+    const int tslot[18] = {-1, -1, -1, 0, 1, 2, 3, 4, 5, -1, -1, -1, 6, 7, 8, 9, 10, 11};
+    for (int r = 0; r < 18; ++r) {
+        const int tr = tslot[r];
+        double row[18];
+        for (int c = 0; c < 18; ++c) {
+            const int tc = tslot[c];
+            double v = 0.0;
+            if (tr < 0 && tc < 0) { if (r % 9 == c % 9) v = (r == c) ? c0 * ad : -c0 * ad; }            // displacement block: +-alpha_d I
+            else if (tr >= 0 && tc >= 0) v = c0 * ar * (g1[tr] * g1[tc] + e1 * H1[tr][tc] + g2[tr] * g2[tc] + e2 * H2[tr][tc]);
+            row[c] = v;
+            Hyy[r * 18 + c] = v;
+        }
+        // HyC[r][c], c over Y slots (GA1,GA2,GB1,GB2) == tangent slots of y
+        for (int c = 0; c < 12; ++c) {
+            const double c0Y = c < 6 ? dt * tau[c / 3] * At[c % 3] : 0.0;
+            double v = row[tan[c]] + gl[r] * c0Y / c0;
+            if (tr >= 0) v -= c0 * ar * (g1[tr] * G1[c] + g2[tr] * G2[c]);
+            HyC[r * 12 + c] = v;
+        }
     }
-    for (int r = 0; r < 12; ++r) for (int c = 0; c < 12; ++c)
-        Hyy[tan[r] * 18 + tan[c]] = c0 * ar * (g1[r] * g1[c] + e1 * H1[r][c] + g2[r] * g2[c] + e2 * H2[r][c]);
-    // HyC[r][c], c over Y slots (GA1,GA2,GB1,GB2) == tangent slots of y
-    for (int r = 0; r < 18; ++r) for (int c = 0; c < 12; ++c) {
-        const double c0Y = c < 6 ? dt * tau[c / 3] * At[c % 3] : 0.0;
-        HyC[r * 12 + c] = Hyy[r * 18 + tan[c]] + grad[r] * c0Y / c0;
-    }
-    for (int r = 0; r < 12; ++r) for (int c = 0; c < 12; ++c) HyC[tan[r] * 12 + c] -= c0 * ar * (g1[r] * G1[c] + g2[r] * G2[c]);
 }
 
 }  // namespace gf
