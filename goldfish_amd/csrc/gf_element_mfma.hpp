@@ -188,6 +188,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     for (int q = 0; q < 9; ++q) accC[q] = gf_d4{0, 0, 0, 0};
     for (int q = 0; q < 3; ++q) accH[q] = gf_d4{0, 0, 0, 0};
     double accR[3] = {0.0, 0.0, 0.0};
+    gf_d4 accB[3] = {gf_d4{0, 0, 0, 0}, gf_d4{0, 0, 0, 0}, gf_d4{0, 0, 0, 0}};   // body force: sum_gp R_a (dJ/dZ . phi_b)_f, scaled by -f_i at the end
 
     GF_STAMP(2, tstamp);
     for (int grp = 0; grp < NGRP; ++grp) {
@@ -285,16 +286,21 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
 #pragma unroll
                 for (int q = 0; q < 9; ++q) accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], t[q], accC[q], 0, 0, 0);
             });
-            if (has_bf) {                    // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b)
+            if (has_bf) {                    // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b): one tile per f, the factor -f_i is applied once at the end
                 const double J = im[IM_J];
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {
                     const double jz = J * (im[IM_JZJ + f] * pb[0] + im[IM_JZJ + 3 + f] * pb[1]);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) accC[3 * i + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pt.f[i] * R0, jz, accC[3 * i + f], 0, 0, 0);
+                    accB[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(R0, jz, accB[f], 0, 0, 0);
                 }
             }
         }
+    }
+    if (has_bf && doC) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int f = 0; f < 3; ++f) accC[3 * i + f] -= Pt.f[i] * accB[f];
     }
 
     // ---- residual: sum the four Gauss-point groups
