@@ -373,6 +373,73 @@ GF_HD inline void shell_energy_point(const double* z, const double* Z, double t,
     }
 }
 
+// ---- von Mises stress at a through-thickness station (max_vmstress_exop.py:17-47, PENGoLINS ShellStressSVK) -----
+// Contravariant 2nd Piola-Kirchhoff components s = C (eps + xi kap) at xi = sgn * t/2 (sgn = +1 top, -1 bottom,
+// 0 middle).  A plane-stress tensor has sigma_vM^2 = (tr)^2 - 3 det, both invariants written with the metric of
+// the basis the components refer to, so no local Cartesian basis is needed:
+//   measure 0 (Cauchy, sigma = F S F^T / Jr on the deformed tangents, metric a, Jr^2 = det a / det A):
+//       q = [ (s:a)^2 / det a - 3 det s ] det A
+//   measure 1 (2nd Piola-Kirchhoff, metric A):   q = (s:A)^2 - 3 det s det A
+// out: [0] sigma_vM, [1] J, [2] d sigma/dt, [3..17] d sigma/dz, [18..32] d sigma/dZ, [33..38] dJ/d(G1,G2)
+// (same slots as shell_energy_point, so the functional kernels share their contraction code).
+GF_HD inline void shell_stress_point(const double* z, const double* Z, double t, double E, double nu, double sgn, int measure, double* out) {
+    const double f3[3] = {1.0, 1.0, 2.0};
+    double n[3], N[3], j, Jn, Dn[3][6], DN[3][6];
+    normal_derivs(z, z + 3, n, j, Dn);
+    normal_derivs(Z, Z + 3, N, Jn, DN);
+    double C[6], dC[3][6], J;
+    material(Z, Z + 3, E, nu, C, dC, J);
+    const double A[3] = {dot3(Z, Z), dot3(Z + 3, Z + 3), dot3(Z, Z + 3)};
+    const double a[3] = {dot3(z, z), dot3(z + 3, z + 3), dot3(z, z + 3)};
+    double eps[3], kap[3], e[3], s[3];
+    eps[0] = 0.5 * (a[0] - A[0]); eps[1] = 0.5 * (a[1] - A[1]); eps[2] = a[2] - A[2];
+    for (int k = 0; k < 3; ++k) kap[k] = f3[k] * (dot3(Z + 6 + 3 * k, N) - dot3(z + 6 + 3 * k, n));
+    const double xi = 0.5 * sgn * t;
+    for (int k = 0; k < 3; ++k) e[k] = eps[k] + xi * kap[k];
+    symmv(C, e, s);
+    const double* mt = measure == 0 ? a : A;
+    const double tr = s[0] * mt[0] + s[1] * mt[1] + 2.0 * s[2] * mt[2];
+    const double dS = s[0] * s[1] - s[2] * s[2], dm = mt[0] * mt[1] - mt[2] * mt[2], dA = A[0] * A[1] - A[2] * A[2];
+    const double r = measure == 0 ? dA / dm : 1.0;
+    const double q = tr * tr * r - 3.0 * dS * dA;
+    const double sig = q > 0.0 ? sqrt(q) : 0.0;
+    out[0] = sig; out[1] = J;
+    double JZ[6];
+    cross3(Z + 3, N, JZ); cross3(N, Z, JZ + 3);
+    // adjoints of sigma
+    const double qb = sig > 0.0 ? 0.5 / sig : 0.0;
+    const double trb = qb * 2.0 * tr * r, dSb = -3.0 * qb * dA;
+    double dAb = -3.0 * qb * dS, dmb = 0.0;
+    if (measure == 0) { const double rb = qb * tr * tr; dAb += rb / dm; dmb = -rb * r / dm; }
+    const double sb[3] = {trb * mt[0] + dSb * s[1], trb * mt[1] + dSb * s[0], 2.0 * trb * mt[2] - 2.0 * dSb * s[2]};
+    const double mb[3] = {trb * s[0] + dmb * mt[1], trb * s[1] + dmb * mt[0], 2.0 * trb * s[2] - 2.0 * dmb * mt[2]};
+    double eb[3];
+    symmv(C, sb, eb);
+    const double kb[3] = {xi * eb[0], xi * eb[1], xi * eb[2]};
+    out[2] = 0.5 * sgn * dot3(eb, kap);
+    double Ab[3] = {dAb * A[1], dAb * A[0], -2.0 * dAb * A[2]};
+    for (int qq = 0; qq < 3; ++qq) { double w[3]; symmv(dC[qq], e, w); Ab[qq] += dot3(sb, w); }
+    double ab[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < 3; ++k) { if (measure == 0) ab[k] = mb[k]; else Ab[k] += mb[k]; }
+    for (int c = 0; c < 6; ++c) {
+        const int ic = c % 3;
+        const double e0 = c < 3 ? z[ic] : 0.0, e1 = c < 3 ? 0.0 : z[3 + ic], e2 = c < 3 ? z[3 + ic] : z[ic];
+        const double E0 = c < 3 ? Z[ic] : 0.0, E1 = c < 3 ? 0.0 : Z[3 + ic], E2 = c < 3 ? Z[3 + ic] : Z[ic];
+        double bg = 0.0, bG = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            bg += kb[k] * f3[k] * (z[6 + 3 * k] * Dn[0][c] + z[7 + 3 * k] * Dn[1][c] + z[8 + 3 * k] * Dn[2][c]);
+            bG += kb[k] * f3[k] * (Z[6 + 3 * k] * DN[0][c] + Z[7 + 3 * k] * DN[1][c] + Z[8 + 3 * k] * DN[2][c]);
+        }
+        out[FE_PZ + c] = (eb[0] + 2.0 * ab[0]) * e0 + (eb[1] + 2.0 * ab[1]) * e1 + (eb[2] + ab[2]) * e2 - bg;
+        out[FE_PZR + c] = (2.0 * Ab[0] - eb[0]) * E0 + (2.0 * Ab[1] - eb[1]) * E1 + (Ab[2] - eb[2]) * E2 + bG;
+        out[FE_JZ + c] = JZ[c];
+    }
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) {
+        out[FE_PZ + 6 + 3 * k + i] = -kb[k] * f3[k] * n[i];
+        out[FE_PZR + 6 + 3 * k + i] = kb[k] * f3[k] * N[i];
+    }
+}
+
 // ---------------------------------------------------------------------------- penalty
 // unit tangent at = unit(tau0 g1 + tau1 g2), Dt[i][c]
 GF_HD inline void tangent_derivs(const double* g1, const double* g2, const double* tau, double* at, double& L, double Dt[3][6]) {

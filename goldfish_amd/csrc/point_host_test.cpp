@@ -19,5 +19,6 @@ void gfh_penalty_point(const double* y, const double* Y, const double* tau, doub
     gf::penalty_point(y, Y, tau, ad, ar, dt, out);
 }
 void gfh_shell_energy_point(const double* z, const double* Z, double t, double E, double nu, double* out) { gf::shell_energy_point(z, Z, t, E, nu, out); }
+void gfh_shell_stress_point(const double* z, const double* Z, double t, double E, double nu, double sgn, int measure, double* out) { gf::shell_stress_point(z, Z, t, E, nu, sgn, measure, out); }
 int gfh_sizes(int which) { return which == 0 ? gf::IM_SIZE : which == 1 ? gf::PB_STRIDE : gf::PB_SIZE; }
 }

@@ -80,6 +80,47 @@ def shell_energy_density(z, Z, t, E, nu):
     return psi * J
 
 
+def von_mises_stress(z, Z, t, E, nu, sgn=1.0, measure="cauchy"):
+    """von Mises stress of the SVK Kirchhoff-Love shell at the through-thickness station xi3 = sgn*t/2
+    (GOLDFISH/operations/max_vmstress_exop.py:17-47 evaluates PENGoLINS' ``ShellStressSVK(...).vonMisesStress(xi2)``
+    at +h/2, -h/2 or 0; PENGoLINS is not vendored, so this restates the published route in the classical
+    local-Cartesian form -- deliberately not the invariant form of goldfish_amd/csrc/kl_point.hpp):
+
+      E_ab = eps_ab + xi3 kappa_ab                       (covariant Green-Lagrange strain, Kiendl 2009)
+      e1 = A1/|A1|, e2 = unit(A2 - (A2.e1) e1)           (ShNAPr orthonormalize2D)
+      Ebar_ij = E_ab (A^a.e_i)(A^b.e_j)                  (covariantRank2TensorToCartesian2D)
+      Sbar = E/(1-nu^2) [[1,nu,0],[nu,1,0],[0,0,(1-nu)/2]] voigt(Ebar)      (2nd Piola-Kirchhoff)
+      measure "pk2":    vM of Sbar
+      measure "cauchy": sigma = F S F^T / Jr,  F = a_a (x) A^a,  Jr = |a1 x a2| / |A1 x A2|,
+                        vM^2 = 3/2 tr(sigma^2) - 1/2 tr(sigma)^2   (plane stress in the deformed tangent plane)
+    """
+    A1, A2 = Z[0], Z[1]
+    a1, a2 = z[0], z[1]
+    eps = 0.5 * (metric_voigt(z) - metric_voigt(Z))          # (e11, e22, 2 e12)
+    kap = curvature_voigt(Z) - curvature_voigt(z)
+    Ev = eps + 0.5 * sgn * t * kap
+    Ecov = torch.stack([torch.stack([Ev[0], 0.5 * Ev[2]]), torch.stack([0.5 * Ev[2], Ev[1]])])
+    Am = torch.stack([torch.stack([A1 @ A1, A1 @ A2]), torch.stack([A1 @ A2, A2 @ A2])])
+    Ai = torch.linalg.inv(Am)
+    Ac = [Ai[0, 0] * A1 + Ai[0, 1] * A2, Ai[1, 0] * A1 + Ai[1, 1] * A2]     # contravariant basis
+    e1 = A1 / torch.linalg.norm(A1)
+    e2 = A2 - (A2 @ e1) * e1
+    e2 = e2 / torch.linalg.norm(e2)
+    T = torch.stack([torch.stack([Ac[0] @ e1, Ac[0] @ e2]), torch.stack([Ac[1] @ e1, Ac[1] @ e2])])   # T[a, i] = A^a . e_i
+    Eb = T.T @ Ecov @ T
+    D = E / (1 - nu * nu)
+    S11 = D * (Eb[0, 0] + nu * Eb[1, 1])
+    S22 = D * (Eb[1, 1] + nu * Eb[0, 0])
+    S12 = D * (1 - nu) * Eb[0, 1]
+    if measure == "pk2":
+        return torch.sqrt(S11 * S11 - S11 * S22 + S22 * S22 + 3 * S12 * S12)
+    Fe1 = a1 * T[0, 0] + a2 * T[1, 0]                         # F e_i = a_a (A^a . e_i)
+    Fe2 = a1 * T[0, 1] + a2 * T[1, 1]
+    Jr = torch.linalg.norm(torch.linalg.cross(a1, a2)) / torch.linalg.norm(torch.linalg.cross(A1, A2))
+    sig = (S11 * torch.outer(Fe1, Fe1) + S22 * torch.outer(Fe2, Fe2) + S12 * (torch.outer(Fe1, Fe2) + torch.outer(Fe2, Fe1))) / Jr
+    return torch.sqrt(1.5 * (sig * sig).sum() - 0.5 * torch.trace(sig) ** 2)
+
+
 def area_jacobian(Z):
     return torch.linalg.norm(torch.linalg.cross(Z[..., 0, :], Z[..., 1, :]), dim=-1)
 

@@ -693,6 +693,102 @@ void gfo_compliance(const gfo_model* M, const double* forces, double* Cout, doub
     *Cout = Ctot;
 }
 
+/* ---- stress aggregation forms ---------------------------------------------------------------
+ * MaxvMStressExOperation (operations/max_vmstress_exop.py:167-186): per patch s the form
+ *     I_s = int g(sigma_vM) dA,   g = exp(rho (sigma - m_s))  [mode 0, KS_symexp :167]
+ *                                 g = (sigma / m_s)^rho       [mode 1, pnorm_symexp :170 / induced_power :173]
+ * sigma_vM = ShellStressSVK(...).vonMisesStress(xi2) of PENGoLINS (not vendored) at xi2 = sgn * h/2 (:29-36),
+ * restated in the classical local-Cartesian route: strain E = eps + xi2 kappa, orthonormal basis from A1, A2,
+ * plane-stress SVK law, and (measure 0) push-forward to the Cauchy stress sigma = F S F^T / Jr or (measure 1) the
+ * 2nd Piola-Kirchhoff stress itself.  Every derivative is a complex-step derivative of the integrand J g(sigma). */
+static cplx vm_integrand(const cplx* z, const cplx* Z, cplx t, double E, double nu, double sgn, int measure, int mode, double rho, double ms, cplx* sig_out) {
+    const cplx *A1 = Z, *A2 = Z + 3, *a1 = z, *a2 = z + 3;
+    cplx N[3], n[3], Jn, jn; cunit_normal(A1, A2, N, &Jn); cunit_normal(a1, a2, n, &jn);
+    cplx Ev[3];
+    Ev[0] = 0.5 * (cdot(a1, a1) - cdot(A1, A1)); Ev[1] = 0.5 * (cdot(a2, a2) - cdot(A2, A2)); Ev[2] = 0.5 * (cdot(a1, a2) - cdot(A1, A2));
+    const cplx xi = 0.5 * sgn * t;
+    for (int k = 0; k < 3; ++k) Ev[k] += xi * (cdot(Z + 6 + 3 * k, N) - cdot(z + 6 + 3 * k, n));     /* (E11, E22, E12) tensor components */
+    cplx A11 = cdot(A1, A1), A22 = cdot(A2, A2), A12 = cdot(A1, A2), det = A11 * A22 - A12 * A12;
+    cplx Ac1[3], Ac2[3], e1[3], e2[3];
+    for (int k = 0; k < 3; ++k) { Ac1[k] = (A22 * A1[k] - A12 * A2[k]) / det; Ac2[k] = (A11 * A2[k] - A12 * A1[k]) / det; }
+    cplx l1 = csqrt(A11); for (int k = 0; k < 3; ++k) e1[k] = A1[k] / l1;
+    cplx pr = cdot(A2, e1); for (int k = 0; k < 3; ++k) e2[k] = A2[k] - pr * e1[k];
+    cplx l2 = csqrt(cdot(e2, e2)); for (int k = 0; k < 3; ++k) e2[k] /= l2;
+    cplx T[2][2] = {{cdot(Ac1, e1), cdot(Ac1, e2)}, {cdot(Ac2, e1), cdot(Ac2, e2)}};                   /* T[a][i] = A^a . e_i */
+    cplx Ec[2][2] = {{Ev[0], Ev[2]}, {Ev[2], Ev[1]}}, Eb[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { Eb[i][j] = 0; for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) Eb[i][j] += T[a][i] * Ec[a][b] * T[b][j]; }
+    const double D = E / (1 - nu * nu);
+    cplx S11 = D * (Eb[0][0] + nu * Eb[1][1]), S22 = D * (Eb[1][1] + nu * Eb[0][0]), S12 = D * (1 - nu) * Eb[0][1], sig;
+    if (measure == 1) sig = csqrt(S11 * S11 - S11 * S22 + S22 * S22 + 3 * S12 * S12);
+    else {
+        cplx F1[3], F2[3], s[3][3], tr = 0, tr2 = 0;
+        for (int k = 0; k < 3; ++k) { F1[k] = a1[k] * T[0][0] + a2[k] * T[1][0]; F2[k] = a1[k] * T[0][1] + a2[k] * T[1][1]; }
+        cplx Jr = jn / Jn;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) s[i][j] = (S11 * F1[i] * F1[j] + S22 * F2[i] * F2[j] + S12 * (F1[i] * F2[j] + F2[i] * F1[j])) / Jr;
+        for (int i = 0; i < 3; ++i) { tr += s[i][i]; for (int j = 0; j < 3; ++j) tr2 += s[i][j] * s[j][i]; }
+        sig = csqrt(1.5 * tr2 - 0.5 * tr * tr);
+    }
+    if (sig_out) *sig_out = sig;
+    cplx g = mode == 0 ? cexp(rho * (sig - ms)) : cpow(sig / ms, rho);
+    return Jn * g;
+}
+
+/* Is_out[np], vmax[np] (largest Gauss-point sigma_vM per patch), dIdu [ndof], dIdcp_f [total_cp], dIdh [total_cp]; pointers may be NULL */
+void gfo_stress_forms(const gfo_model* M, int mode, double rho, const double* m_list, double sgn, int measure, double* Is_out, double* vmax,
+                      double* dIdu, double* dIdcp0, double* dIdcp1, double* dIdcp2, double* dIdh, int apply_bcs) {
+    double* dC[3] = {dIdcp0, dIdcp1, dIdcp2}; const double hs = 1e-30;
+    if (dIdu) memset(dIdu, 0, sizeof(double) * M->ndof);
+    for (int f = 0; f < 3; ++f) if (dC[f]) memset(dC[f], 0, sizeof(double) * M->total_cp);
+    if (dIdh) memset(dIdh, 0, sizeof(double) * M->total_cp);
+    const int want_grad = dIdu || dIdcp0 || dIdcp1 || dIdcp2 || dIdh;
+    for (int s = 0; s < M->np; ++s) {
+        const patch_t* P = &M->P[s]; const int p = P->p, q = P->q, nb = (p + 1) * (q + 1);
+        double Is = 0, vm = 0;
+        for (int ev = 0; ev < P->nelv; ++ev) for (int eu = 0; eu < P->nelu; ++eu) {
+            const int iu0 = P->spanu[eu] - p, iv0 = P->spanv[ev] - q; int64_t gid[MAXNB]; double wl[MAXNB];
+            for (int jv = 0; jv <= q; ++jv) for (int ju = 0; ju <= p; ++ju) { int a = ju + jv * (p + 1); gid[a] = P->cp_off + (iu0 + ju) + (int64_t)(iv0 + jv) * P->nu; wl[a] = M->w[gid[a]]; }
+            for (int gv = 0; gv < P->ngv; ++gv) for (int gu = 0; gu < P->ngu; ++gu) {
+                const double* tu = P->bu + (size_t)((eu * P->ngu + gu) * 3) * (p + 1); const double* tv = P->bv + (size_t)((ev * P->ngv + gv) * 3) * (q + 1);
+                const double wq = P->wu[eu * P->ngu + gu] * P->wv[ev * P->ngv + gv];
+                double Nb[6][MAXNB], Rb[6][MAXNB];
+                for (int jv = 0; jv <= q; ++jv) for (int ju = 0; ju <= p; ++ju) {
+                    int a = ju + jv * (p + 1);
+                    double u0 = tu[ju], u1 = tu[(p + 1) + ju], u2 = tu[2 * (p + 1) + ju], v0 = tv[jv], v1 = tv[(q + 1) + jv], v2 = tv[2 * (q + 1) + jv];
+                    Nb[0][a] = u0 * v0; Nb[1][a] = u1 * v0; Nb[2][a] = u0 * v1; Nb[3][a] = u2 * v0; Nb[4][a] = u0 * v2; Nb[5][a] = u1 * v1;
+                }
+                rationalize(nb, Nb, wl, Rb);
+                cplx z[15], Z[15], t = 0, sg;
+                for (int k = 0; k < 15; ++k) { z[k] = 0; Z[k] = 0; }
+                for (int a = 0; a < nb; ++a) {
+                    t += Nb[0][a] * M->h[gid[a]];
+                    for (int mm = 0; mm < 5; ++mm) for (int k = 0; k < 3; ++k) { Z[3 * mm + k] += Rb[mm + 1][a] * M->cp[3 * gid[a] + k]; z[3 * mm + k] += Rb[mm + 1][a] * (M->cp[3 * gid[a] + k] + M->u[3 * gid[a] + k]); }
+                }
+                cplx val = vm_integrand(z, Z, t, P->E, P->nu_, sgn, measure, mode, rho, m_list[s], &sg);
+                Is += wq * creal(val); if (creal(sg) > vm) vm = creal(sg);
+                if (!want_grad) continue;
+                double gz[15], gZ[15], gt;
+                for (int c = 0; c < 15; ++c) {
+                    cplx keep = z[c]; z[c] = keep + hs * I; gz[c] = cimag(vm_integrand(z, Z, t, P->E, P->nu_, sgn, measure, mode, rho, m_list[s], NULL)) / hs; z[c] = keep;
+                    keep = Z[c]; Z[c] = keep + hs * I; gZ[c] = cimag(vm_integrand(z, Z, t, P->E, P->nu_, sgn, measure, mode, rho, m_list[s], NULL)) / hs; Z[c] = keep;
+                }
+                gt = cimag(vm_integrand(z, Z, t + hs * I, P->E, P->nu_, sgn, measure, mode, rho, m_list[s], NULL)) / hs;
+                for (int a = 0; a < nb; ++a) {
+                    for (int k = 0; k < 3; ++k) {
+                        double du = 0, dc = 0;
+                        for (int mm = 0; mm < 5; ++mm) { du += Rb[mm + 1][a] * gz[3 * mm + k]; dc += Rb[mm + 1][a] * (gz[3 * mm + k] + gZ[3 * mm + k]); }
+                        if (dIdu) dIdu[3 * gid[a] + k] += wq * du;
+                        if (dC[k]) dC[k][gid[a]] += wq * dc;
+                    }
+                    if (dIdh) dIdh[gid[a]] += wq * Nb[0][a] * gt;
+                }
+            }
+        }
+        if (Is_out) Is_out[s] = Is;
+        if (vmax) vmax[s] = vm;
+    }
+    if (dIdu && apply_bcs) for (int64_t r = 0; r < M->ndof; ++r) if (M->zero[r]) dIdu[r] = 0;
+}
+
 int gfo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

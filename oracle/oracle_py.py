@@ -49,6 +49,7 @@ def lib():
         L.gfo_penalty_point.argtypes = [dp, dp, dp, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp]
         L.gfo_eval_point.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, dp, dp]
         L.gfo_compliance.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp, C.c_int]
+        L.gfo_stress_forms.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, C.c_double, C.c_int] + [dp] * 7 + [C.c_int]
         L.gfo_num_threads.restype = C.c_int
         L.gfo_set_num_threads.argtypes = [C.c_int]
         _LIB = L
@@ -144,6 +145,16 @@ class Oracle:
         dCdcp = [np.zeros(self.total_cp) for _ in range(3)]
         lib().gfo_compliance(self.h, _dp(f), _dp(out), _dp(dCdu), *[_dp(x) for x in dCdcp], int(apply_bcs))
         return dict(C=out[0], dCdu=dCdu, dCdcp=dCdcp)
+
+    def stress_forms(self, mode, rho, m_list, sgn=1.0, measure=0, apply_bcs=True, npatch=None):
+        """Per-patch aggregation forms of the von Mises stress and their gradients (gfo_stress_forms)."""
+        ml = np.ascontiguousarray(m_list, float)
+        I, vmax = np.zeros(ml.size), np.zeros(ml.size)
+        dIdu, dIdh = np.zeros(self.ndof), np.zeros(self.total_cp)
+        dIdcp = [np.zeros(self.total_cp) for _ in range(3)]
+        lib().gfo_stress_forms(self.h, int(mode), float(rho), _dp(ml), float(sgn), int(measure), _dp(I), _dp(vmax), _dp(dIdu),
+                               *[_dp(x) for x in dIdcp], _dp(dIdh), int(apply_bcs))
+        return dict(I=I, vmax=vmax, dIdu=dIdu, dIdcp=dIdcp, dIdh=dIdh)
 
     def eval_point(self, patch, xi):
         X, U = np.zeros(3), np.zeros(3)

@@ -107,6 +107,30 @@ def test_functionals_vs_autograd(oracle_lib):
         assert _relerr(Cg["dCdcp"][f], gc.numpy()[:, f]) < RTOL
 
 
+def test_stress_forms_vs_autograd(oracle_lib):
+    """C oracle's stress aggregation forms (complex-step gradients) vs torch.autograd of the same statement:
+    KS and p-norm integrands, Cauchy / 2nd PK measure, top and bottom surface."""
+    spec = G.scordelis_lo_9patch(3, nels=[2, 1, 2, 1, 2, 1, 2, 1, 2])
+    A, O, T, c, U, ht = _setup(spec, seed=4)
+    npatch = len(spec.patches)
+    base = O.stress_forms(1, 1.0, np.ones(npatch))["vmax"]
+    for mode, rho, sgn, measure in ((0, 3.0, 1.0, 0), (1, 4.0, -1.0, 0), (1, 3.0, 1.0, 1)):
+        m_list = base * (1.0 + 0.1 * np.arange(npatch))
+        if mode == 0:
+            rho = rho / base.max()
+        F = O.stress_forms(mode, rho, m_list, sgn, measure, apply_bcs=False)
+        I = T.stress_forms(c, U, ht, mode, rho, m_list, sgn, "cauchy" if measure == 0 else "pk2")
+        assert _relerr(F["I"], I.detach().numpy()) < 1e-12
+        wts = torch.tensor(np.random.default_rng(1).uniform(0.5, 1.5, npatch))
+        gU, gc, gh = torch.autograd.grad((wts * I).sum(), (U, c, ht))
+        # the oracle returns the un-weighted per-patch gradients in one field (every control point belongs to one patch)
+        wcp = np.repeat(wts.numpy(), [P.ncp for P in spec.patches])
+        assert _relerr(F["dIdu"] * np.repeat(wcp, 3), gU.numpy().ravel()) < RTOL
+        for f in range(3):
+            assert _relerr(F["dIdcp"][f] * wcp, gc.numpy()[:, f]) < RTOL
+        assert _relerr(F["dIdh"] * wcp, gh.numpy()) < RTOL
+
+
 def test_penalty_point_hessians(oracle_lib):
     """complex-step Hessians of one mortar vertex vs torch autograd."""
     from oracle import kl_energy_torch as ke

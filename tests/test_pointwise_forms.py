@@ -93,3 +93,29 @@ def test_kernel_header_pointwise_forms_on_host():
         L.gfh_shell_point_cols(P(z), P(Z), t, E, nu, P(im2))
         scale = np.abs(im).max()
         assert np.abs(im2 - im).max() < 1e-13 * scale, np.argmax(np.abs(im2 - im))
+
+
+def test_kernel_header_stress_point_vs_autograd():
+    """kl_point.hpp shell_stress_point (invariant form, hand-written adjoints) against torch.autograd of the
+    local-Cartesian statement of the von Mises stress (oracle/kl_energy_torch.py) -- value and all 31 derivatives,
+    Cauchy and 2nd Piola-Kirchhoff measures, top / bottom / middle surface."""
+    import ctypes as C
+    L = _host_kernel_lib()
+    dp = C.POINTER(C.c_double)
+    L.gfh_shell_stress_point.argtypes = [dp, dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, dp]
+    P = lambda a: a.ctypes.data_as(dp)
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        z, Z = _rand_state(rng)
+        t, E, nu = 0.15 + 0.05 * trial, 4.0, 0.3
+        sgn = (1.0, -1.0, 0.0)[trial % 3]
+        for mi, measure in enumerate(("cauchy", "pk2")):
+            out = np.zeros(39)
+            L.gfh_shell_stress_point(P(np.ascontiguousarray(z.ravel())), P(np.ascontiguousarray(Z.ravel())), t, E, nu, sgn, mi, P(out))
+            zt, Zt, tt = torch.tensor(z, requires_grad=True), torch.tensor(Z, requires_grad=True), torch.tensor(t, requires_grad=True)
+            s = ke.von_mises_stress(zt, Zt, tt, E, nu, sgn, measure)
+            gz, gZ, gt = torch.autograd.grad(s, (zt, Zt, tt), allow_unused=True)
+            assert abs(out[0] - s.item()) < 1e-12 * abs(s.item()), (measure, sgn)
+            assert np.abs(out[3:18] - gz.numpy().ravel()).max() < 1e-11 * np.abs(gz.numpy()).max(), (measure, sgn)
+            assert np.abs(out[18:33] - gZ.numpy().ravel()).max() < 1e-11 * np.abs(gZ.numpy()).max(), (measure, sgn)
+            assert abs(out[2] - (0.0 if gt is None else gt.item())) < 1e-11 * max(abs(out[2]), 1e-30) + 1e-14, (measure, sgn)

@@ -110,6 +110,20 @@ class TorchModel:
         f = torch.tensor(np.asarray(forces, float).reshape(-1, 3))[self.pid]
         return (self.wq * ke.area_jacobian(Z) * (f * uh).sum(-1)).sum()
 
+    def stress_forms(self, c, U, h, mode, rho, m_list, sgn, measure):
+        """Per-patch forms int g(sigma_vM) dA (max_vmstress_exop.py:167-175) from the pointwise torch statement."""
+        Z = torch.einsum("gma,gak->gmk", self.Rb[:, 1:], c[self.ids])
+        z = torch.einsum("gma,gak->gmk", self.Rb[:, 1:], (c + U)[self.ids])
+        t = (self.N0 * h[self.ids]).sum(-1)
+        J = ke.area_jacobian(Z)
+        out = [torch.zeros((), dtype=torch.float64) for _ in m_list]
+        for g in range(z.shape[0]):
+            s = int(self.pid[g])
+            sig = ke.von_mises_stress(z[g], Z[g], t[g], self.E[g], self.nu[g], sgn, measure)
+            val = torch.exp(rho * (sig - m_list[s])) if mode == 0 else (sig / m_list[s]) ** rho
+            out[s] = out[s] + self.wq[g] * J[g] * val
+        return torch.stack(out)
+
     def penalty_energy(self, c, U):
         W = torch.zeros((), dtype=torch.float64)
         for ia, RA, ib, RB, tau, ad, ar, wt in self.mp:
