@@ -18,7 +18,7 @@ BUF_CP, BUF_U, BUF_H, BUF_R, BUF_VAL_K, BUF_VAL_C0, BUF_VAL_C1, BUF_VAL_C2, BUF_
 EXPORTS = ["gf_device_count", "gf_last_error", "gf_create", "gf_destroy", "gf_total_cp", "gf_num_dofs",
            "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes", "gf_set_cp",
            "gf_set_thickness", "gf_set_u", "gf_nnz", "gf_pattern", "gf_assemble", "gf_sync", "gf_get_residual",
-           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms"]
+           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms"]
 
 
 def lib():
@@ -50,6 +50,7 @@ def lib():
         L.gf_apply.argtypes = [vp, C.c_int, C.c_int, dp, i64, dp, i64]
         L.gf_functionals.argtypes = [vp, dp, dp, dp, dp, dp, dp, C.c_int]
         L.gf_compliance.argtypes = [vp, dp, i64, dp, dp, dp, C.c_int]
+        L.gf_stress_forms.argtypes = [vp, C.c_int, C.c_double, dp, i64, C.c_int, C.c_int, dp, dp, dp, dp, dp, C.c_int]
         L.gf_device_ptr.restype = vp
         L.gf_device_ptr.argtypes = [vp, C.c_int]
         L.gf_apply_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp]
@@ -168,6 +169,17 @@ class DeviceModel:
         out, dCdu, dCdcp = np.zeros(1), np.zeros(self.ndof), np.zeros((3, self.total_cp))
         _check(lib().gf_compliance(self.h, _dp(f), f.size, _dp(out), _dp(dCdu), _dp(dCdcp), int(apply_bcs)), ValueError)
         return dict(C=out[0], dCdu=dCdu, dCdcp=dCdcp)
+
+    def stress_forms(self, mode, rho, m_list, surf=1, measure=0, apply_bcs=True, gradients=True):
+        """Per-patch von Mises aggregation forms and their gradients (gf_stress_forms)."""
+        ml = np.ascontiguousarray(m_list, dtype=np.float64).ravel()
+        I, vmax = np.zeros(ml.size), np.zeros(ml.size)
+        g = dict(dIdu=np.zeros(self.ndof), dIdcp=np.zeros((3, self.total_cp)), dIdh=np.zeros(self.total_cp)) if gradients else \
+            dict(dIdu=None, dIdcp=None, dIdh=None)
+        _check(lib().gf_stress_forms(self.h, int(mode), float(rho), _dp(ml), ml.size, int(surf), int(measure), _dp(I), _dp(vmax),
+                                     _dp(g["dIdu"]), _dp(g["dIdcp"]), _dp(g["dIdh"]), int(apply_bcs)), ValueError)
+        g.update(I=I, vmax=vmax)
+        return g
 
     def kernel_ms(self):
         n = C.c_int(0)

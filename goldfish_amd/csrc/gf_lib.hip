@@ -299,6 +299,17 @@ template <int P> static void run_compliance(gf_handle* h, int apply_bcs) {
     HIPCHK(hipGetLastError());
 }
 
+template <int P> static void run_stress(gf_handle* h, const StressCfg& S, int apply_bcs) {
+    const size_t stride = (size_t)FunCfg<P>::STRIDE;
+    for (const Chunk& c : h->chunks) {
+        const long long ne = c.e1 - c.e0, na = c.a1 - c.a0, nthr = std::max(ne, na);
+        hipLaunchKernelGGL(kl_stress_kernel<P>, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, S, h->d_blk, stride);
+        hipLaunchKernelGGL(kl_fgather_kernel<P>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, apply_bcs,
+                           h->d_blk, stride, h->d_fun, h->d_x, h->d_ve);
+    }
+    HIPCHK(hipGetLastError());
+}
+
 extern "C" {
 
 int gf_assemble(gf_handle* h, int flags) {
@@ -418,6 +429,42 @@ int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, dou
         const long long e_end = H.n_owned < H.np ? H.patches[H.n_owned].elem_off : H.nelem;
         long double acc = 0; for (long long e = 0; e < e_end; ++e) acc += ce[e];
         *C = (double)acc;
+    } catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
+}
+
+int gf_stress_forms(gf_handle* h, int mode, double rho, const double* m_list, int64_t nm, int surf, int measure,
+                    double* forms, double* vmax, double* dIdu, double* dIdcp, double* dIdh, int apply_bcs) {
+    if (!h || !m_list) return fail("gf_stress_forms: null argument");
+    if (nm != (int64_t)h->H.np) return fail("gf_stress_forms: m_list must hold one value per patch");
+    if ((mode != 0 && mode != 1) || (measure != 0 && measure != 1) || surf < -1 || surf > 1) return fail("gf_stress_forms: bad mode / measure / surf");
+    for (int64_t s = 0; s < nm; ++s) if (!(m_list[s] > 0.0)) return fail("gf_stress_forms: m_list entries must be positive");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipMemcpyAsync(h->d_y, m_list, nm * sizeof(double), hipMemcpyHostToDevice, h->stream));   // d_y: >= 3*n_patches doubles
+        StressCfg S; S.mode = mode; S.measure = measure; S.rho = rho; S.sgn = (double)surf; S.m_list = h->d_y;
+        switch (h->H.degree) {
+            case 2: run_stress<2>(h, S, apply_bcs); break;
+            case 3: run_stress<3>(h, S, apply_bcs); break;
+            case 4: run_stress<4>(h, S, apply_bcs); break;
+            default: throw std::runtime_error("gf_stress_forms: unsupported degree");
+        }
+        const HostModel& H = h->H; const long long T = H.total_cp;
+        std::vector<double> ie(H.nelem), se(H.nelem);
+        HIPCHK(hipMemcpyAsync(ie.data(), h->d_x, H.nelem * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(se.data(), h->d_ve, H.nelem * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (dIdu) HIPCHK(hipMemcpyAsync(dIdu, h->d_fun, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (dIdcp) HIPCHK(hipMemcpyAsync(dIdcp, h->d_fun + 3 * T, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (dIdh) HIPCHK(hipMemcpyAsync(dIdh, h->d_fun + 6 * T, T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        // fixed-order host sums per patch (ghost patches of a shard report their own values too: they are complete)
+        for (int s = 0; s < H.np; ++s) {
+            const long long e0 = H.patches[s].elem_off, e1 = s + 1 < H.np ? H.patches[s + 1].elem_off : H.nelem;
+            long double acc = 0; double mx = 0;
+            for (long long e = e0; e < e1; ++e) { acc += ie[e]; mx = std::max(mx, se[e]); }
+            if (forms) forms[s] = (double)acc;
+            if (vmax) vmax[s] = mx;
+        }
     } catch (const std::exception& ex) { return fail(ex.what()); }
     return 0;
 }

@@ -397,7 +397,8 @@ GF_HD inline void shell_stress_point(const double* z, const double* Z, double t,
     const double xi = 0.5 * sgn * t;
     for (int k = 0; k < 3; ++k) e[k] = eps[k] + xi * kap[k];
     symmv(C, e, s);
-    const double* mt = measure == 0 ? a : A;
+    const bool cau = measure == 0;
+    const double mt[3] = {cau ? a[0] : A[0], cau ? a[1] : A[1], cau ? a[2] : A[2]};      // by value: a pointer select would push a[], A[] to scratch
     const double tr = s[0] * mt[0] + s[1] * mt[1] + 2.0 * s[2] * mt[2];
     const double dS = s[0] * s[1] - s[2] * s[2], dm = mt[0] * mt[1] - mt[2] * mt[2], dA = A[0] * A[1] - A[2] * A[2];
     const double r = measure == 0 ? dA / dm : 1.0;

@@ -11,3 +11,4 @@ from .disp_states_comp import DispStatesComp      # noqa: E402,F401
 from .int_energy_comp import IntEnergyComp        # noqa: E402,F401
 from .volume_comp import VolumeComp               # noqa: E402,F401
 from .compliance_comp import ComplianceComp       # noqa: E402,F401
+from .max_vmstress_comp import MaxvMStressComp   # noqa: E402,F401

@@ -124,6 +124,8 @@ class Problem:
             for (of, wrt), Jm in partials.items():
                 base = self.inputs[wrt].copy()
                 v = rng.standard_normal(base.shape)
+                if free_mask is not None and base.size == np.size(free_mask):      # gradients with Dirichlet rows zeroed (apply_bcs=True)
+                    v = v * np.reshape(free_mask, base.shape)
                 an = np.asarray(Jm).reshape(self.outputs[of].size, base.size) @ v.ravel()
                 f = []
                 for sgn in (1, -1):

@@ -94,6 +94,20 @@ int gf_functionals(gf_handle* h, double out[3], double* dWdu, double* dWdcp, dou
  * with forces = 3 values per patch; dCdu [ndof] (Dirichlet rows zeroed when apply_bcs), dCdcp 3 arrays of total_cp. */
 int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, double* dCdu, double* dCdcp, int apply_bcs);
 
+/* MaxvMStressExOperation (operations/max_vmstress_exop.py): the per-patch aggregation forms
+ *   forms[s] = int g(sigma_vM) dA,  g = exp(rho (sigma - m_list[s]))   mode 0  (KS_symexp :167)
+ *                                   g = (sigma / m_list[s])^rho        mode 1  (pnorm_symexp :170; induced_power :173
+ *                                                                               = two calls, rho+1 and rho)
+ * of the von Mises stress at the station xi2 = surf * h/2 (surf = +1 "top", -1 "bottom", 0 "middle", :29-36), which the
+ * reference takes from PENGoLINS ShellStressSVK.vonMisesStress (:38-47); measure 0 = Cauchy stress, 1 = 2nd Piola-Kirchhoff.
+ * vmax[s] = largest Gauss-point sigma_vM of patch s (compute_m / compute_max_vM :147-165 use an L2 projection onto
+ * linears there).  Gradients of the forms (un-weighted; every control point belongs to one patch, so the caller applies
+ * its per-patch chain-rule factors, :330-440): dIdu [ndof] (dmax_vMdu_forms :78-95; Dirichlet rows zeroed when
+ * apply_bcs), dIdcp 3 arrays of total_cp (dmax_vMdcp_forms :98-118), dIdh [total_cp] (dmax_vMdh_th_forms :122-137).
+ * forms, vmax: [n_patches].  Any output pointer may be NULL. */
+int gf_stress_forms(gf_handle* h, int mode, double rho, const double* m_list, int64_t nm, int surf, int measure,
+                    double* forms, double* vmax, double* dIdu, double* dIdcp, double* dIdh, int apply_bcs);
+
 /* borrowed device pointer to one of the GF_BUF_* buffers (for zero-copy users: bench, RCCL exchange) */
 void* gf_device_ptr(gf_handle* h, int which);
 /* y_dev += A x_dev on device pointers (no host copies, asynchronous) */

@@ -333,3 +333,43 @@ def test_multi_ffd_thickness():
         prob.run_model()
         errs = prob.check_partials(step=1e-3)
         assert errs and max(errs.values()) < 1e-9, (Comp.__name__, errs)
+
+
+@pytest.mark.parametrize("method", ["KS", "pnorm", "induced power"])
+def test_max_vm_stress_aggregation_chain_rule(method):
+    """Host part of MaxvMStressExOperation (max_vmstress_exop.py:188-328): local + global aggregation of per-patch
+    form values and the chain-rule factors d(global)/d(form), against central differences; no device involved."""
+    from types import SimpleNamespace
+    from goldfish_amd.operations.max_vmstress_exop import MaxvMStressExOperation
+    nm = SimpleNamespace(num_splines=4, splines=[None] * 4, opt_field=[0], opt_shape=False, opt_thickness=False)
+    m = 3.0e6
+    rho = 5.0 / m if method == "KS" else 5.0
+    op = MaxvMStressExOperation(nm, rho=rho, alpha=0.02, m=m, method=method)
+    rng = np.random.default_rng(0)
+
+    def total(vals):
+        return op.discrete_max_vM_stress([op.continuous_max_vM_stress(vals[s], s) for s in range(4)])
+
+    if method == "induced power":
+        vals = [(rng.uniform(0.5, 2.0), rng.uniform(0.5, 2.0)) for _ in range(4)]
+    else:
+        vals = list(rng.uniform(0.005, 0.05, 4))
+    fac = op._patch_factors(vals)
+    for s in range(4):
+        for k in range(len(fac[s])):
+            def pert(eps):
+                v = [tuple(x) if isinstance(x, tuple) else x for x in vals]
+                if method == "induced power":
+                    t = list(v[s]); t[k] += eps; v[s] = tuple(t)
+                else:
+                    v[s] += eps
+                return total(v)
+            eps = 1e-6 * (vals[s][k] if method == "induced power" else vals[s])
+            num = (pert(eps) - pert(-eps)) / (2 * eps)
+            assert abs(num - fac[s][k]) < 1e-6 * abs(num), (method, s, k)
+    with pytest.raises(ValueError):
+        MaxvMStressExOperation(nm, alpha=1.0, m=1.0, surf="inside")
+    with pytest.raises(ValueError):
+        MaxvMStressExOperation(nm, alpha=1.0, m=1.0, method="max")
+    with pytest.raises(NotImplementedError):
+        MaxvMStressExOperation(nm, alpha=1.0, m=1.0, linearize_stress=True)

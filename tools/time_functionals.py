@@ -6,7 +6,9 @@ spec = G.synthetic_shell(16, 16, nel=48, p=3, jitter=2)
 th = G.random_thickness(spec)
 D = _lib.DeviceModel(arrays_from_spec(spec, th))
 D.set_thickness(np.concatenate(th)); D.set_u(G.smooth_displacement(spec, 0.5 * spec.h_th))
-for name, fn in (("functionals", lambda: D.functionals()), ("compliance", lambda: D.compliance(np.ones((256, 3))))):
+for name, fn in (("functionals", lambda: D.functionals()), ("compliance", lambda: D.compliance(np.ones((256, 3)))),
+                 ("stress forms (KS, top, Cauchy)", lambda: D.stress_forms(0, 1e-8, np.full(256, 1e8))),
+                 ("stress forms, values only", lambda: D.stress_forms(1, 8.0, np.full(256, 1e8), gradients=False))):
     fn(); D.sync()
     t0 = time.perf_counter()
     for _ in range(3): fn()
