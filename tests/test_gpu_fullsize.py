@@ -103,7 +103,23 @@ def test_c4_rigid_body_and_reproducibility(c4):
     # translation leaves the penalty energy at zero (a rotation moves the mismatched points apart)
     D.set_u((A.weights[:, None] * np.array([0.3, -0.1, 0.2])).ravel())
     assert D.functionals()["Wpen"] < 1e-12 * max(F0["Wpen"], 1e-300)
+    # von Mises aggregation forms at full size: a rigid motion is stress free; size-independent inequalities between the
+    # power forms I_k = int sigma^k dA (Cauchy-Schwarz, mean <= max) and the directional derivative of I_2 along u
+    n = len(spec.patches)
+    one = np.ones(n)
+    D.set_u(U.ravel())
+    rigid = D.stress_forms(1, 1.0, one, 1, 0, gradients=False)
     D.set_u(u)
+    S1 = D.stress_forms(1, 1.0, one, 1, 0, gradients=False)
+    S2 = D.stress_forms(1, 2.0, one, 1, 0, apply_bcs=False)
+    assert rigid["vmax"].max() < 1e-9 * S1["vmax"].max()
+    assert np.all(S1["I"] > 0) and np.all(S1["vmax"] > 0)
+    assert np.all(S2["I"] <= S1["vmax"] * S1["I"] * (1 + 1e-12))              # int s^2 <= max(s) int s
+    eps = 1e-6
+    D.set_u(u * (1 + eps)); Ip = D.stress_forms(1, 2.0, one, 1, 0, gradients=False)["I"].sum()
+    D.set_u(u * (1 - eps)); Im = D.stress_forms(1, 2.0, one, 1, 0, gradients=False)["I"].sum()
+    D.set_u(u)
+    assert abs((Ip - Im) / (2 * eps) - S2["dIdu"] @ u) < 1e-6 * abs(S2["dIdu"] @ u)
     D.assemble(_lib.ASM_ALL)
     R0, K0 = D.residual(), D.values(_lib.MAT_K)
     D.assemble(_lib.ASM_ALL)
