@@ -457,11 +457,11 @@ int gf_stress_forms(gf_handle* h, int mode, double rho, const double* m_list, in
         if (dIdcp) HIPCHK(hipMemcpyAsync(dIdcp, h->d_fun + 3 * T, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         if (dIdh) HIPCHK(hipMemcpyAsync(dIdh, h->d_fun + 6 * T, T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        // fixed-order host sums per patch (ghost patches of a shard report their own values too: they are complete)
+        // fixed-order host sums per patch; the ghost patches of a shard are not evaluated here (their owner reports them): 0
         for (int s = 0; s < H.np; ++s) {
             const long long e0 = H.patches[s].elem_off, e1 = s + 1 < H.np ? H.patches[s + 1].elem_off : H.nelem;
             long double acc = 0; double mx = 0;
-            for (long long e = e0; e < e1; ++e) { acc += ie[e]; mx = std::max(mx, se[e]); }
+            if (s < H.n_owned) for (long long e = e0; e < e1; ++e) { acc += ie[e]; mx = std::max(mx, se[e]); }
             if (forms) forms[s] = (double)acc;
             if (vmax) vmax[s] = mx;
         }

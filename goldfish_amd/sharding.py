@@ -249,3 +249,26 @@ class ShardedDeviceModel:
         out["dWdcp"] = [self._rows_to_global(own(F["dWdcp"][f]), 1) for f in range(3)]
         out["dVdcp"] = [self._rows_to_global(own(F["dVdcp"][f]), 1) for f in range(3)]
         return out
+
+    def stress_forms(self, mode, rho, m_list, surf=1, measure=0, apply_bcs=True, gradients=True):
+        """Global per-patch von Mises aggregation forms (gf_stress_forms): every rank evaluates its owned patches,
+        the per-patch values and the owned gradient rows are summed over ranks."""
+        order = np.asarray(self.shard.order)
+        ml = np.asarray(m_list, float)
+        F = self.D.stress_forms(mode, rho, ml[order], surf, measure, apply_bcs=apply_bcs, gradients=gradients)
+        no, npg = self.shard.n_owned, ml.size
+        I, vmax = np.zeros(npg), np.zeros(npg)
+        I[order[:no]], vmax[order[:no]] = F["I"][:no], F["vmax"][:no]
+        sc = self._allreduce(np.concatenate([I, vmax]))
+        out = dict(I=sc[:npg], vmax=sc[npg:])
+        if gradients:
+            n = self.n_owned_cp
+
+            def own(v, width=1):
+                w = np.array(v, float)
+                w[width * n:] = 0.0
+                return w
+            out["dIdu"] = self._rows_to_global(own(F["dIdu"], 3), 3)
+            out["dIdh"] = self._rows_to_global(own(F["dIdh"]), 1)
+            out["dIdcp"] = np.stack([self._rows_to_global(own(F["dIdcp"][f]), 1) for f in range(3)])
+        return out

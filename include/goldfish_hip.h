@@ -104,7 +104,7 @@ int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, dou
  * linears there).  Gradients of the forms (un-weighted; every control point belongs to one patch, so the caller applies
  * its per-patch chain-rule factors, :330-440): dIdu [ndof] (dmax_vMdu_forms :78-95; Dirichlet rows zeroed when
  * apply_bcs), dIdcp 3 arrays of total_cp (dmax_vMdcp_forms :98-118), dIdh [total_cp] (dmax_vMdh_th_forms :122-137).
- * forms, vmax: [n_patches].  Any output pointer may be NULL. */
+ * forms, vmax: [n_patches] (0 for the ghost patches of a shard).  Any output pointer may be NULL. */
 int gf_stress_forms(gf_handle* h, int mode, double rho, const double* m_list, int64_t nm, int surf, int measure,
                     double* forms, double* vmax, double* dIdu, double* dIdcp, double* dIdh, int apply_bcs);
 

@@ -193,7 +193,8 @@ def _rank_worker(rank, world, port, q):
     xu, xc, lam = rng.standard_normal(S.ndof), rng.standard_normal(S.total_cp), rng.standard_normal(S.ndof)
     res = dict(R=S.residual(), Ku=S.apply(_lib.MAT_K, xu), KTl=S.apply(_lib.MAT_K, lam, transpose=True),
                Cc=S.apply(_lib.MAT_DRDCP1, xc), CTl=S.apply(_lib.MAT_DRDCP1, lam, transpose=True),
-               HTl=S.apply(_lib.MAT_DRDH, lam, transpose=True), F=S.functionals(apply_bcs=False), xu=xu, xc=xc, lam=lam)
+               HTl=S.apply(_lib.MAT_DRDH, lam, transpose=True), F=S.functionals(apply_bcs=False), xu=xu, xc=xc, lam=lam,
+               S=S.stress_forms(1, 3.0, 1e6 * (1.0 + np.arange(len(spec.patches))), -1, 0, apply_bcs=False))
     if rank == 0:
         q.put(res)
     dist.barrier()
@@ -232,6 +233,10 @@ def test_two_rank_sharded_assembly_on_gpu(oracle_lib):
         assert abs(F[k] - Fo[k]) < 1e-11 * abs(Fo[k]), k
     assert _rel(F["dWdu"], Fo["dWdu"]) < 1e-10 and _rel(F["dWdh"], Fo["dWdh"]) < 1e-10
     assert _rel(F["dWdcp"][2], Fo["dWdcp"][2]) < 1e-10 and _rel(F["dVdcp"][0], Fo["dVdcp"][0]) < 1e-10
+    So, Sd = O.stress_forms(1, 3.0, 1e6 * (1.0 + np.arange(len(spec.patches))), -1.0, 0, apply_bcs=False), res["S"]
+    assert _rel(Sd["I"], So["I"]) < 1e-11 and _rel(Sd["vmax"], So["vmax"]) < 1e-11
+    assert _rel(Sd["dIdu"], So["dIdu"]) < 1e-10 and _rel(Sd["dIdh"], So["dIdh"]) < 1e-10
+    assert _rel(Sd["dIdcp"][1], So["dIdcp"][1]) < 1e-10
 
 
 def test_ffd_chain_rule_through_the_gpu_path():
