@@ -373,3 +373,65 @@ def test_max_vm_stress_aggregation_chain_rule(method):
         MaxvMStressExOperation(nm, alpha=1.0, m=1.0, method="max")
     with pytest.raises(NotImplementedError):
         MaxvMStressExOperation(nm, alpha=1.0, m=1.0, linearize_stress=True)
+
+
+def _tbeam_intersection_data():
+    from goldfish_amd.cpiga2xi import IntersectionData
+    spec = G.tbeam_2patch(4)
+    itf = spec.interfaces[0]
+    return spec, IntersectionData(patches=spec.patches, mapping_list=[[itf.a, itf.b]],
+                                  intersections_para_coords=[[itf.xi_a, itf.xi_b]])
+
+
+def test_cpiga2xi_residual_and_derivatives():
+    """N3 host part (cpiga2xi.py:401-790): the intersection residual vanishes at the stored parametric coordinates,
+    dR/dxi and dR/dCP agree with central differences."""
+    from goldfish_amd.cpiga2xi import CPIGA2Xi
+    spec, pre = _tbeam_intersection_data()
+    c2x = CPIGA2Xi(pre, opt_surf_inds=[[0, 1]] * 3, opt_field=[0, 1, 2])
+    n = c2x.diff_int_num_pts[0]
+    assert c2x.xi_size_global == 4 * n and c2x.cp_size_global == sum(P.ncp for P in spec.patches)
+    xi0 = c2x.xi_flat_global.copy()
+    assert np.abs(c2x.residual(xi0)).max() < 1e-12
+    rng = np.random.default_rng(0)
+    xi = np.clip(xi0 + 0.02 * rng.standard_normal(xi0.size), 0.01, 0.99)
+    J = c2x.dRdxi(xi)
+    assert J.shape == (4 * n, 4 * n)
+    for k in rng.choice(xi.size, 8, replace=False):
+        e = np.zeros(xi.size)
+        e[k] = 1e-6
+        fd = (c2x.residual(xi + e) - c2x.residual(xi - e)) / 2e-6
+        assert np.abs(fd - J[:, k]).max() < 1e-7 * max(1.0, np.abs(J[:, k]).max())
+    for field in (0, 2):
+        Jc = c2x.dRdCP(xi, field, coo=False)
+        assert Jc.shape == (4 * n, c2x.cp_size_global)
+        base = c2x.cp_flat_global[:, field].copy()
+        for k in rng.choice(base.size, 6, replace=False):
+            r = []
+            for s in (1, -1):
+                v = base.copy()
+                v[k] += s * 1e-6
+                c2x.update_CPs(v, field)
+                r.append(c2x.residual(xi))
+            c2x.update_CPs(base, field)
+            assert np.abs((r[0] - r[1]) / 2e-6 - Jc[:, k]).max() < 1e-7 * max(1.0, np.abs(Jc[:, k]).max())
+
+
+def test_cpiga2xi_follows_a_moved_patch():
+    """Shifting the web of the T-beam by +0.1 in x moves the intersection to xi_u = 0.55 on the flange; the implicit
+    derivative d xi / d CP = -(dR/dxi)^-1 dR/dCP predicts the same move."""
+    from goldfish_amd.cpiga2xi import CPIGA2Xi
+    spec, pre = _tbeam_intersection_data()
+    c2x = CPIGA2Xi(pre, opt_surf_inds=[[0, 1]] * 3, opt_field=[0, 1, 2])
+    n = c2x.diff_int_num_pts[0]
+    xi0 = c2x.xi_flat_global.copy()
+    dxidcp = -np.linalg.solve(c2x.dRdxi(xi0), c2x.dRdCP(xi0, 0, coo=False))
+    shift = np.zeros(c2x.cp_size_global)
+    shift[c2x.cp_flat_inds[1]:c2x.cp_flat_inds[2]] = 0.1 * spec.patches[1].cp_hom_flat()[:, 3]      # homogeneous x-coefficients of the web
+    c2x.update_CPs(c2x.cp_flat_global[:, 0] + shift, 0)
+    xi = c2x.solve_xi(xi0)
+    assert np.abs(c2x.residual(xi)).max() < 1e-10
+    xa, xb = xi[:2 * n].reshape(-1, 2), xi[2 * n:].reshape(-1, 2)
+    assert np.abs(xa[:, 0] - 0.55).max() < 1e-10 and np.abs(xa[:, 1] - xi0[:2 * n].reshape(-1, 2)[:, 1]).max() < 1e-9
+    assert np.abs(xb - xi0[2 * n:].reshape(-1, 2)).max() < 1e-9
+    assert np.abs(xi0 + dxidcp @ shift - xi).max() < 1e-9                     # the map is linear for this geometry
