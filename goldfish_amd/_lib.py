@@ -18,7 +18,7 @@ BUF_CP, BUF_U, BUF_H, BUF_R, BUF_VAL_K, BUF_VAL_C0, BUF_VAL_C1, BUF_VAL_C2, BUF_
 EXPORTS = ["gf_device_count", "gf_last_error", "gf_create", "gf_destroy", "gf_total_cp", "gf_num_dofs",
            "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes", "gf_set_cp",
            "gf_set_thickness", "gf_set_u", "gf_nnz", "gf_pattern", "gf_assemble", "gf_sync", "gf_get_residual",
-           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms"]
+           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms"]
 
 
 def lib():
@@ -50,6 +50,7 @@ def lib():
         L.gf_apply.argtypes = [vp, C.c_int, C.c_int, dp, i64, dp, i64]
         L.gf_functionals.argtypes = [vp, dp, dp, dp, dp, dp, dp, C.c_int]
         L.gf_compliance.argtypes = [vp, dp, i64, dp, dp, dp, C.c_int]
+        L.gf_penalty_dxi.argtypes = [vp, dp, i64, C.POINTER(C.c_int32), i64]
         L.gf_stress_forms.argtypes = [vp, C.c_int, C.c_double, dp, i64, C.c_int, C.c_int, dp, dp, dp, dp, dp, C.c_int]
         L.gf_device_ptr.restype = vp
         L.gf_device_ptr.argtypes = [vp, C.c_int]
@@ -180,6 +181,14 @@ class DeviceModel:
                                      _dp(g["dIdu"]), _dp(g["dIdcp"]), _dp(g["dIdh"]), int(apply_bcs)), ValueError)
         g.update(I=I, vmax=vmax)
         return g
+
+    def penalty_dxi(self, npts, degree):
+        """Per-vertex blocks of d(penalty residual)/d(xi, tau) and the support windows (gf_penalty_dxi)."""
+        nb = (degree + 1) ** 2
+        blocks = np.zeros((npts, 6, 2, nb, 3))
+        win = np.zeros((npts, 2, 2), dtype=np.int32)
+        _check(lib().gf_penalty_dxi(self.h, _dp(blocks), blocks.size, win.ctypes.data_as(C.POINTER(C.c_int32)), win.size), ValueError)
+        return blocks, win
 
     def kernel_ms(self):
         n = C.c_int(0)

@@ -855,6 +855,60 @@ __global__ __launch_bounds__(64) void pen_point_kernel(DevModel M, DevPenalty Q,
     penalty_point(y, Y, Q.pt_tau + 2 * v, Q.if_alpha[2 * itf], Q.if_alpha[2 * itf + 1], Q.pt_wt[v], pbuf + (size_t)v * PB_STRIDE, grad_only != 0);
 }
 
+// Moving intersections (reference nonmatching_opt.py:1042-1341 dRIGAdxi_sub): derivative of the penalty
+// residual rows of a mortar vertex along six directions -- 0..3: the vertex slides on side sd = dir / 2 in parametric
+// direction d = dir % 2 (y, Y move with the second derivatives of the basis, and the row weights nu_a move), 4..5: the
+// curve tangent tau_d changes (a neighbouring vertex of side A moved).  One thread per (vertex, direction): forward-mode
+// pass of the vertex gradient in dual numbers, then the contraction with both sides' basis values:
+//   out[(v*6 + dir)][sd'][a][i] = sum_m nu_m,a^(sd') d(grad)[9 sd' + 3 m + i] + [sd' == sd] sum_m d(nu_m,a)/d(xi_d) grad[9 sd + 3 m + i]
+template <int P>
+__global__ __launch_bounds__(64) void pen_dxi_kernel(DevModel M, DevPenalty Q, const double* __restrict__ pt_nu2, double* __restrict__ out) {
+    constexpr int P1 = P + 1, NB = P1 * P1;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Q.npts * 6) return;
+    const long long v = t / 6; const int dir = int(t - 6 * v), sdd = dir >> 1, d = dir & 1;
+    const int itf = Q.pt_iface[v];
+    Dual y[18], Y[12], tau[2], gr[18];
+    for (int k = 0; k < 18; ++k) y[k] = {0.0, 0.0};
+    for (int k = 0; k < 12; ++k) Y[k] = {0.0, 0.0};
+    for (int sd = 0; sd < 2; ++sd) {
+        const PatchDev& Pt = M.patches[Q.if_patch[2 * itf + sd]];
+        const int iu0 = Q.pt_base[4 * v + 2 * sd], iv0 = Q.pt_base[4 * v + 2 * sd + 1];
+        const double* nu = Q.pt_nu + ((size_t)v * 2 + sd) * 3 * NB;
+        const double* n2 = pt_nu2 + ((size_t)v * 2 + sd) * 3 * NB;
+        const bool seed = dir < 4 && sd == sdd;
+        for (int a = 0; a < NB; ++a) {
+            const long long g = Pt.cp_off + (iu0 + a % P1) + (long long)(iv0 + a / P1) * Pt.nu;
+            const double r0 = nu[a], r1 = nu[NB + a], r2 = nu[2 * NB + a];
+            // d/dxi_d of (R, R_u, R_v): d = 0 -> (R_u, R_uu, R_uv), d = 1 -> (R_v, R_uv, R_vv)
+            const double s0 = seed ? (d == 0 ? r1 : r2) : 0.0, s1 = seed ? (d == 0 ? n2[a] : n2[2 * NB + a]) : 0.0, s2 = seed ? (d == 0 ? n2[2 * NB + a] : n2[NB + a]) : 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double c = M.cp4[4 * g + k], uu = M.u[3 * g + k];
+                y[9 * sd + k] = y[9 * sd + k] + Dual{r0 * uu, s0 * uu};
+                y[9 * sd + 3 + k] = y[9 * sd + 3 + k] + Dual{r1 * (c + uu), s1 * (c + uu)};
+                y[9 * sd + 6 + k] = y[9 * sd + 6 + k] + Dual{r2 * (c + uu), s2 * (c + uu)};
+                Y[6 * sd + k] = Y[6 * sd + k] + Dual{r1 * c, s1 * c};
+                Y[6 * sd + 3 + k] = Y[6 * sd + 3 + k] + Dual{r2 * c, s2 * c};
+            }
+        }
+    }
+    tau[0] = {Q.pt_tau[2 * v], dir == 4 ? 1.0 : 0.0}; tau[1] = {Q.pt_tau[2 * v + 1], dir == 5 ? 1.0 : 0.0};
+    penalty_grad_t<Dual>(y, Y, tau, Q.if_alpha[2 * itf], Q.if_alpha[2 * itf + 1], Q.pt_wt[v], gr);
+    double* o = out + (size_t)t * (2 * NB * 3);
+    for (int sd = 0; sd < 2; ++sd) {
+        const double* nu = Q.pt_nu + ((size_t)v * 2 + sd) * 3 * NB;
+        const double* n2 = pt_nu2 + ((size_t)v * 2 + sd) * 3 * NB;
+        const bool seed = dir < 4 && sd == sdd;
+        for (int a = 0; a < NB; ++a) {
+            const double r0 = nu[a], r1 = nu[NB + a], r2 = nu[2 * NB + a];
+            const double s0 = seed ? (d == 0 ? r1 : r2) : 0.0, s1 = seed ? (d == 0 ? n2[a] : n2[2 * NB + a]) : 0.0, s2 = seed ? (d == 0 ? n2[2 * NB + a] : n2[NB + a]) : 0.0;
+            for (int i = 0; i < 3; ++i)
+                o[(sd * NB + a) * 3 + i] = r0 * gr[9 * sd + i].d + r1 * gr[9 * sd + 3 + i].d + r2 * gr[9 * sd + 6 + i].d
+                                         + s0 * gr[9 * sd + i].v + s1 * gr[9 * sd + 3 + i].v + s2 * gr[9 * sd + 6 + i].v;
+        }
+    }
+}
+
 // Penalty rows of one owned control point a (one wave each): residual entries and the coupling blocks
 // of K and dR/dCP.  Every lane OWNS up to PEN_SL neighbour slots k of a (k = lane + 64 sl) and keeps
 // their 3x3 K and dR/dc blocks in registers.  The visits (mortar vertices whose support contains a) come

@@ -32,6 +32,7 @@ struct gf_handle {
     double *d_cp4 = nullptr, *d_u = nullptr, *d_h = nullptr, *d_R = nullptr, *d_blk = nullptr, *d_pbuf = nullptr;
     double* d_val[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double *d_x = nullptr, *d_y = nullptr;           // staging for host-pointer gf_apply / per-element partial sums
+    double* d_pt_nu2 = nullptr;                                        // second derivatives of the basis at the mortar vertices (gf_penalty_dxi)
     double *d_fun = nullptr, *d_pen_en = nullptr, *d_ve = nullptr;    // functional gradients [11*total_cp], penalty energies [npts]
     long long* d_pl_dof = nullptr; double* d_pl_val = nullptr;
     std::vector<Chunk> chunks;
@@ -465,6 +466,39 @@ int gf_stress_forms(gf_handle* h, int mode, double rho, const double* m_list, in
             if (forms) forms[s] = (double)acc;
             if (vmax) vmax[s] = mx;
         }
+    } catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
+}
+
+int gf_penalty_dxi(gf_handle* h, double* blocks, int64_t n, int32_t* windows, int64_t nw) {
+    if (!h || !blocks) return fail("gf_penalty_dxi: null argument");
+    const HostModel& H = h->H;
+    const int NB = (H.degree + 1) * (H.degree + 1);
+    const int64_t need = (int64_t)H.npts * 6 * 2 * NB * 3;
+    if (n != need) return fail("gf_penalty_dxi: blocks must hold npts * 6 * 2 * (p+1)^2 * 3 doubles");
+    if (windows && nw != 4 * (int64_t)H.npts) return fail("gf_penalty_dxi: windows must hold 4 ints per mortar vertex");
+    if (H.npts == 0) return 0;
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        if (!h->d_pt_nu2) {                                  // uploaded on first use: only moving-intersection problems need it
+            h->d_pt_nu2 = h->dalloc<double>(H.pt_nu2.size());
+            HIPCHK(hipMemcpy(h->d_pt_nu2, H.pt_nu2.data(), H.pt_nu2.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        double* d_out = nullptr;
+        HIPCHK(hipMalloc(&d_out, need * sizeof(double)));
+        const long long nt = (long long)H.npts * 6;
+        switch (H.degree) {
+            case 2: hipLaunchKernelGGL(pen_dxi_kernel<2>, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pt_nu2, d_out); break;
+            case 3: hipLaunchKernelGGL(pen_dxi_kernel<3>, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pt_nu2, d_out); break;
+            case 4: hipLaunchKernelGGL(pen_dxi_kernel<4>, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pt_nu2, d_out); break;
+            default: (void)hipFree(d_out); throw std::runtime_error("gf_penalty_dxi: unsupported degree");
+        }
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(blocks, d_out, need * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        (void)hipFree(d_out);
+        if (e != hipSuccess) throw std::runtime_error(std::string("gf_penalty_dxi: ") + hipGetErrorString(e));
+        if (windows) for (int64_t k = 0; k < 4 * (int64_t)H.npts; ++k) windows[k] = H.pt_base[k];
     } catch (const std::exception& ex) { return fail(ex.what()); }
     return 0;
 }

@@ -122,6 +122,7 @@ struct HostModel {
     std::vector<int> pt_iface;          // [npts]
     std::vector<int> pt_base;           // [npts][2][2] (iu0, iv0) per side
     std::vector<double> pt_nu;          // [npts][2][3][NB] rational value/d1/d2
+    std::vector<double> pt_nu2;         // [npts][2][3][NB] rational second derivatives uu/vv/uv (moving intersections, dR/dxi)
     std::vector<double> pt_tau, pt_wt;  // [npts][2], [npts]
     std::vector<int> if_patch; std::vector<double> if_alpha; std::vector<int64_t> if_off;
     // deterministic owner lists
@@ -226,7 +227,7 @@ inline void HostModel::build(const gf_model_desc* D) {
     npts = ni > 0 ? D->if_off[ni] : 0;
     if_patch.assign(D->if_patch, D->if_patch + 2 * ni); if_alpha.assign(D->if_alpha, D->if_alpha + 2 * ni);
     if_off.assign(D->if_off, D->if_off + ni + 1);
-    pt_iface.resize(npts); pt_base.resize(4 * npts); pt_nu.assign(size_t(npts) * 2 * 3 * NB, 0.0);
+    pt_iface.resize(npts); pt_base.resize(4 * npts); pt_nu.assign(size_t(npts) * 2 * 3 * NB, 0.0); pt_nu2.assign(size_t(npts) * 2 * 3 * NB, 0.0);
     pt_tau.assign(D->if_tau, D->if_tau + 2 * npts); pt_wt.assign(D->if_wt, D->if_wt + npts);
     for (int i = 0; i < ni; ++i) {
         for (int sd = 0; sd < 2; ++sd) if (if_patch[2 * i + sd] < 0 || if_patch[2 * i + sd] >= np) throw std::runtime_error("gf_create: if_patch out of range");
@@ -238,18 +239,24 @@ inline void HostModel::build(const gf_model_desc* D) {
                 const double xu = D->if_xi[4 * v + 2 * sd], xv = D->if_xi[4 * v + 2 * sd + 1];
                 const int su = find_span(P.nu, P.p, Uu, xu), sv = find_span(P.nv, P.q, Uv, xv);
                 double du[3][MAXP + 1], dv[3][MAXP + 1]; basis_ders(su, xu, P.p, Uu, du); basis_ders(sv, xv, P.q, Uv, dv);
-                double N[3][MAXNB], W[3] = {0, 0, 0};
+                double N[6][MAXNB], W[6] = {0, 0, 0, 0, 0, 0};
                 for (int jv = 0; jv <= P.q; ++jv) for (int ju = 0; ju <= P.p; ++ju) {
                     const int a = ju + jv * (P.p + 1);
                     const double w = weights[P.cp_off + (su - P.p + ju) + int64_t(sv - P.q + jv) * P.nu];
                     N[0][a] = du[0][ju] * dv[0][jv]; N[1][a] = du[1][ju] * dv[0][jv]; N[2][a] = du[0][ju] * dv[1][jv];
-                    for (int k = 0; k < 3; ++k) W[k] += N[k][a] * w;
+                    N[3][a] = du[2][ju] * dv[0][jv]; N[4][a] = du[0][ju] * dv[2][jv]; N[5][a] = du[1][ju] * dv[1][jv];
+                    for (int k = 0; k < 6; ++k) W[k] += N[k][a] * w;
                 }
                 pt_base[4 * v + 2 * sd] = su - P.p; pt_base[4 * v + 2 * sd + 1] = sv - P.q;
                 double* o = &pt_nu[(size_t(v) * 2 + sd) * 3 * NB];
                 for (int a = 0; a < NB; ++a) {
                     const double R = N[0][a] / W[0];
-                    o[a] = R; o[NB + a] = (N[1][a] - R * W[1]) / W[0]; o[2 * NB + a] = (N[2][a] - R * W[2]) / W[0];
+                    const double R1 = (N[1][a] - R * W[1]) / W[0], R2 = (N[2][a] - R * W[2]) / W[0];
+                    o[a] = R; o[NB + a] = R1; o[2 * NB + a] = R2;
+                    double* o2 = &pt_nu2[(size_t(v) * 2 + sd) * 3 * NB];
+                    o2[a] = (N[3][a] - 2 * R1 * W[1] - R * W[3]) / W[0];
+                    o2[NB + a] = (N[4][a] - 2 * R2 * W[2] - R * W[4]) / W[0];
+                    o2[2 * NB + a] = (N[5][a] - R1 * W[2] - R2 * W[1] - R * W[5]) / W[0];
                 }
             }
         }

@@ -556,4 +556,62 @@ GF_HD inline void penalty_point(const double* y, const double* Y, const double* 
     }
 }
 
+// ---- moving intersections: derivative of the vertex gradient along one direction -------------
+// d(R_pen)/d(xi) (nonmatching_opt.py:1042-1341) needs d(grad_y psi)/d(direction) for directions that move y and Y
+// (the vertex slides on a patch: seeds from the second derivatives of the basis) or the curve tangent tau (a
+// neighbouring vertex moves).  One forward-mode pass of the gradient in dual numbers gives it without Hessians.
+struct Dual { double v, d; };
+GF_HD __forceinline__ Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+GF_HD __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+GF_HD __forceinline__ Dual operator-(Dual a) { return {-a.v, -a.d}; }
+GF_HD __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.v * b.d + a.d * b.v}; }
+GF_HD __forceinline__ Dual operator*(double a, Dual b) { return {a * b.v, a * b.d}; }
+GF_HD __forceinline__ Dual operator*(Dual a, double b) { return {a.v * b, a.d * b}; }
+GF_HD __forceinline__ Dual operator/(Dual a, Dual b) { const double q = a.v / b.v; return {q, (a.d - q * b.d) / b.v}; }
+GF_HD __forceinline__ Dual dsqrt(Dual a) { const double s = sqrt(a.v); return {s, 0.5 * a.d / s}; }
+GF_HD __forceinline__ double dsqrt(double a) { return sqrt(a); }
+
+template <class T> GF_HD __forceinline__ void cross3t(const T* a, const T* b, T* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+template <class T> GF_HD __forceinline__ T dot3t(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <class T> GF_HD __forceinline__ void unit_normal_t(const T* g1, const T* g2, T* n, T& j) {
+    T t[3]; cross3t(g1, g2, t); j = dsqrt(dot3t(t, t));
+    for (int k = 0; k < 3; ++k) n[k] = t[k] / j;
+}
+// gradient of (n(g1, g2) . v) wrt g1, g2 with v held fixed: w = (v - n (n.v)) / j, (g2 x w, w x g1)
+template <class T> GF_HD __forceinline__ void normal_pullback_t(const T* g1, const T* g2, const T* n, T j, const T* v, T* o1, T* o2) {
+    const T nv = dot3t(n, v); T w[3];
+    for (int k = 0; k < 3; ++k) w[k] = (v[k] - n[k] * nv) / j;
+    cross3t(g2, w, o1); cross3t(w, g1, o2);
+}
+// gradient (18) of the vertex penalty energy wrt y = (uA, gA1, gA2, uB, gB1, gB2); Y = (GA1, GA2, GB1, GB2); same energy
+// as penalty_point (Herrema 2019: displacement jump + the two rotation measures, line element dt |tau . G_A|)
+template <class T> GF_HD inline void penalty_grad_t(const T* y, const T* Y, const T* tau, double ad, double ar, double dt, T* gr) {
+    const T *uA = y, *gA1 = y + 3, *gA2 = y + 6, *uB = y + 9, *gB1 = y + 12, *gB2 = y + 15;
+    const T *GA1 = Y, *GA2 = Y + 3, *GB1 = Y + 6, *GB2 = Y + 9;
+    T tref[3], tdef[3], At[3], at[3];
+    for (int k = 0; k < 3; ++k) { tref[k] = tau[0] * GA1[k] + tau[1] * GA2[k]; tdef[k] = tau[0] * gA1[k] + tau[1] * gA2[k]; }
+    const T L = dsqrt(dot3t(tref, tref)), lt = dsqrt(dot3t(tdef, tdef));
+    for (int k = 0; k < 3; ++k) { At[k] = tref[k] / L; at[k] = tdef[k] / lt; }
+    T nA[3], nB[3], NA[3], NB[3], jA, jB, JA, JB;
+    unit_normal_t(gA1, gA2, nA, jA); unit_normal_t(gB1, gB2, nB, jB); unit_normal_t(GA1, GA2, NA, JA); unit_normal_t(GB1, GB2, NB, JB);
+    T an[3], An[3]; cross3t(at, nA, an); cross3t(At, NA, An);
+    const T e1 = dot3t(nA, nB) - dot3t(NA, NB), e2 = dot3t(an, nB) - dot3t(An, NB);
+    const T c0 = dt * L;
+    for (int k = 0; k < 3; ++k) { const T dk = uA[k] - uB[k]; gr[k] = ad * (c0 * dk); gr[9 + k] = -(ad * (c0 * dk)); }
+    T s1A1[3], s1A2[3], s1B1[3], s1B2[3];
+    normal_pullback_t(gA1, gA2, nA, jA, nB, s1A1, s1A2); normal_pullback_t(gB1, gB2, nB, jB, nA, s1B1, s1B2);
+    T cx[3], v1[3], v2[3], s2A1[3], s2A2[3], s2B1[3], s2B2[3];
+    cross3t(nA, nB, cx); cross3t(nB, at, v1); cross3t(at, nA, v2);
+    normal_pullback_t(gA1, gA2, nA, jA, v1, s2A1, s2A2); normal_pullback_t(gB1, gB2, nB, jB, v2, s2B1, s2B2);
+    const T ac = dot3t(at, cx);
+    for (int k = 0; k < 3; ++k) { const T ptc = (cx[k] - at[k] * ac) / lt; s2A1[k] = s2A1[k] + tau[0] * ptc; s2A2[k] = s2A2[k] + tau[1] * ptc; }
+    const T c1 = ar * (c0 * e1), c2 = ar * (c0 * e2);
+    for (int k = 0; k < 3; ++k) {
+        gr[3 + k] = c1 * s1A1[k] + c2 * s2A1[k]; gr[6 + k] = c1 * s1A2[k] + c2 * s2A2[k];
+        gr[12 + k] = c1 * s1B1[k] + c2 * s2B1[k]; gr[15 + k] = c1 * s1B2[k] + c2 * s2B2[k];
+    }
+}
+
 }  // namespace gf

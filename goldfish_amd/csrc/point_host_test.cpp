@@ -20,5 +20,15 @@ void gfh_penalty_point(const double* y, const double* Y, const double* tau, doub
 }
 void gfh_shell_energy_point(const double* z, const double* Z, double t, double E, double nu, double* out) { gf::shell_energy_point(z, Z, t, E, nu, out); }
 void gfh_shell_stress_point(const double* z, const double* Z, double t, double E, double nu, double sgn, int measure, double* out) { gf::shell_stress_point(z, Z, t, E, nu, sgn, measure, out); }
+// value and directional derivative of the vertex gradient: seeds dy[18], dY[12], dtau[2]
+void gfh_penalty_grad_dual(const double* y, const double* Y, const double* tau, const double* dy, const double* dY, const double* dtau,
+                           double ad, double ar, double dt, double* gr, double* dgr) {
+    gf::Dual yd[18], Yd[12], td[2], g[18];
+    for (int k = 0; k < 18; ++k) yd[k] = {y[k], dy[k]};
+    for (int k = 0; k < 12; ++k) Yd[k] = {Y[k], dY[k]};
+    for (int k = 0; k < 2; ++k) td[k] = {tau[k], dtau[k]};
+    gf::penalty_grad_t<gf::Dual>(yd, Yd, td, ad, ar, dt, g);
+    for (int k = 0; k < 18; ++k) { gr[k] = g[k].v; dgr[k] = g[k].d; }
+}
 int gfh_sizes(int which) { return which == 0 ? gf::IM_SIZE : which == 1 ? gf::PB_STRIDE : gf::PB_SIZE; }
 }

@@ -341,6 +341,98 @@ class NonMatchingOpt:
         self.update_CPIGA(CP, field)
         return J
 
+    # ------------------------------------------------------------------ moving intersections
+    def create_diff_intersections(self, num_edge_pts=None, preprocessor=None):
+        """nonmatching_opt.py:533-556: the intersections listed in ``preprocessor.diff_int_inds`` (default: all) become
+        functions of the control points through ``CPIGA2Xi``; ``preprocessor`` is a ``cpiga2xi.IntersectionData``
+        (default: built from the patches and the interfaces of ``mortar_meshes_setup``)."""
+        from .cpiga2xi import CPIGA2Xi, IntersectionData
+        if preprocessor is None:
+            preprocessor = IntersectionData(patches=self.splines, mapping_list=self.mapping_list,
+                                            intersections_para_coords=[[itf.xi_a, itf.xi_b] for itf in self.interfaces])
+        self.preprocessor = preprocessor
+        self.cpiga2xi = CPIGA2Xi(preprocessor, self.shopt_surf_inds, self.opt_field, num_edge_pts)
+        self.diff_int_inds = list(preprocessor.diff_int_inds)
+        self.update_xi(self.cpiga2xi.xi_flat_global)
+        self.xi_size = self.cpiga2xi.xi_size_global
+
+    def update_xi(self, xi_flat):
+        """nonmatching_opt.py:560-565: store the parametric coordinates; ``update_transfer_matrices`` applies them."""
+        xi = np.asarray(xi_flat, float).ravel()
+        if xi.size != self.cpiga2xi.xi_size_global:
+            raise ValueError("update_xi: expected %d values, got %d" % (self.cpiga2xi.xi_size_global, xi.size))
+        self.xi_flat = xi.copy()
+
+    def update_transfer_matrices(self):
+        """nonmatching_opt.py:567-600 rebuilds the mortar transfer matrices at the new coordinates; here the mortar-vertex
+        tables (support windows, basis values, curve tangents, coupling pattern) live in the device model, which is
+        re-created; control points, thickness and displacement are pushed again by ``dev``."""
+        c2x = self.cpiga2xi
+        for i, g in enumerate(self.diff_int_inds):
+            n = c2x.diff_int_num_pts[i]
+            sub = self.xi_flat[c2x.xi_flat_inds[i]:c2x.xi_flat_inds[i + 1]]
+            a, b = self.mapping_list[g]
+            self.interfaces[g] = Interface(a, b, sub[:2 * n].reshape(-1, 2), sub[2 * n:].reshape(-1, 2))
+        if self._dev is not None:
+            self._dev.close()
+        self._dev = None
+        self._dsolver = self._hlu = None                       # factorisations belong to the old coupling pattern
+
+    def dRIGAdxi(self):
+        """d RIGA / d xi_flat (nonmatching_opt.py:1042-1088), ndof x xi_size, Dirichlet rows zeroed: the device returns the
+        per-vertex blocks (gf_penalty_dxi -> pen_dxi_kernel); here they are scattered to dofs / coordinates, and the
+        tangent blocks are chained with d(tau)/d(xi_A) of the vertex stencil (model.Interface: second-order differences)."""
+        c2x, dev = self.cpiga2xi, self.dev
+        A = self._arrays_cache
+        p = self.splines[0].p
+        P1, nb = p + 1, (p + 1) ** 2
+        blocks, win = dev.penalty_dxi(int(A.if_off[-1]), p)
+        rows, cols, vals = [], [], []
+        al = np.arange(nb)
+        for i, g in enumerate(self.diff_int_inds):
+            n = c2x.diff_int_num_pts[i]
+            v0, base = int(A.if_off[g]), c2x.xi_flat_inds[i]
+            B, W = blocks[v0:v0 + n], win[v0:v0 + n]                                  # (n, 6, 2, nb, 3), (n, 2, 2)
+            dof = np.zeros((n, 2, nb, 3), dtype=np.int64)
+            for sd, s in enumerate(self.mapping_list[g]):
+                cp = self.cp_off[s] + (W[:, sd, 0][:, None] + al % P1) + (W[:, sd, 1][:, None] + al // P1) * self.splines[s].n_u
+                dof[:, sd] = 3 * cp[:, :, None] + np.arange(3)
+            dof = dof.reshape(n, -1)
+            k = np.arange(n)
+            for d in range(4):                                                        # the vertex itself
+                col = base + (d // 2) * 2 * n + 2 * k + d % 2
+                rows.append(dof.ravel()); cols.append(np.repeat(col, dof.shape[1])); vals.append(B[:, d].reshape(n, -1).ravel())
+            Gm = np.gradient(np.eye(n), 1.0 / (n - 1), axis=0, edge_order=2 if n > 2 else 1)   # tau = Gm @ xi_A
+            for d in range(2):                                                        # neighbours through the tangent
+                T = B[:, 4 + d].reshape(n, -1)
+                kk, kp = np.nonzero(Gm)
+                rows.append(dof[kk].ravel()); cols.append(np.repeat(base + 2 * kp + d, dof.shape[1]))
+                vals.append((T[kk] * Gm[kk, kp][:, None]).ravel())
+        if rows:
+            J = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(self.vec_iga_dof, c2x.xi_size_global)).tocsr()
+        else:
+            J = sp.csr_matrix((self.vec_iga_dof, c2x.xi_size_global))
+        keep = np.ones(self.vec_iga_dof)
+        keep[self.zero_dofs] = 0.0
+        return sp.diags(keep) @ J
+
+    def dRIGAdxi_FD(self, xi_flat, h=1e-8):
+        """Forward-difference check of dRIGAdxi (nonmatching_opt.py:1018-1040): one model rebuild per column."""
+        xi0 = np.asarray(xi_flat, float).copy()
+        self.update_xi(xi0)
+        self.update_transfer_matrices()
+        R0 = self.RIGA()
+        J = np.zeros((R0.size, xi0.size))
+        for k in range(xi0.size):
+            x = xi0.copy()
+            x[k] += h
+            self.update_xi(x)
+            self.update_transfer_matrices()
+            J[:, k] = (self.RIGA() - R0) / h
+        self.update_xi(xi0)
+        self.update_transfer_matrices()
+        return J
+
     # ------------------------------------------------------------------ solves (host sparse direct: "next" row N1)
     def solve_linear_nonmatching_problem(self, iga_dofs=True):
         """One Newton step from the current state (PENGoLINS solve_linear_nonmatching_problem;

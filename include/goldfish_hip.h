@@ -108,6 +108,16 @@ int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, dou
 int gf_stress_forms(gf_handle* h, int mode, double rho, const double* m_list, int64_t nm, int surf, int measure,
                     double* forms, double* vmax, double* dIdu, double* dIdcp, double* dIdh, int apply_bcs);
 
+/* Moving intersections: NonMatchingOpt.dRIGAdxi / dRIGAdxi_sub (nonmatching_opt.py:1042-1341) -- derivative of the penalty
+ * residual with respect to the parametric coordinates of the mortar vertices, at the current u / CP / thickness.
+ * blocks[v][dir][side'][a][i] (npts x 6 x 2 x (p+1)^2 x 3 doubles): d(residual entry i of the a-th support control point of
+ * side') for dir 0..3 = d/d(xi of side dir/2, parametric direction dir%2) of vertex v itself and dir 4,5 = d/d(tau_0, tau_1),
+ * the parametric curve tangent the model was created with (if_tau): the caller chains it with its own d(tau)/d(xi of the
+ * neighbouring vertices).  windows (may be NULL): first support control-point indices (iu0, iv0) per vertex and side,
+ * [npts][2][2]; the a-th support control point of a patch with nu control points in u is (iu0 + a % (p+1)) + (iv0 + a / (p+1)) * nu.
+ * No Dirichlet treatment (the reference zeroes the rows afterwards, :1057-1062). */
+int gf_penalty_dxi(gf_handle* h, double* blocks, int64_t n, int32_t* windows, int64_t nw);
+
 /* borrowed device pointer to one of the GF_BUF_* buffers (for zero-copy users: bench, RCCL exchange) */
 void* gf_device_ptr(gf_handle* h, int which);
 /* y_dev += A x_dev on device pointers (no host copies, asynchronous) */

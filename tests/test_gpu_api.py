@@ -439,3 +439,45 @@ def test_max_vm_stress_operation_and_comp(method):
     free[nm.zero_dofs] = False
     errs = prob.check_partials(compact_print=False, free_mask=free, step=1e-6)
     assert max(errs.values()) < 1e-4, errs       # the CP_IGA1 directional derivative is a small difference of large terms
+
+
+def test_moving_intersection_residual_derivative(oracle_lib):
+    """N3: NonMatchingOpt.dRIGAdxi (gf_penalty_dxi -> pen_dxi_kernel, dual-number pass per mortar vertex) against central
+    differences of the ORACLE's residual with the interface rebuilt at perturbed parametric coordinates, and against the
+    reference-style forward-difference check dRIGAdxi_FD of the device path."""
+    from goldfish_amd.model import Interface
+    from oracle.oracle_py import Oracle
+    spec, th, nm = _problem()
+    rng = np.random.default_rng(9)
+    # a curved, non-uniformly spaced intersection strictly inside both patches exercises every term
+    n = 6
+    t = np.linspace(0, 1, n)
+    xa = np.stack([0.45 + 0.1 * t + 0.03 * np.sin(3 * t), 0.1 + 0.8 * t ** 1.3], 1)
+    xb = np.stack([0.3 + 0.2 * t ** 2, 0.15 + 0.7 * t], 1)
+    nm.mortar_nels = [n - 1]
+    nm.mortar_meshes_setup(nm.mapping_list, [[xa, xb]], nm.penalty_coefficient)
+    nm.update_uIGA(2e-2 * rng.standard_normal(nm.vec_iga_dof))
+    nm.create_diff_intersections()
+    assert nm.xi_size == 4 * n
+    xi0 = nm.cpiga2xi.xi_flat_global.copy()
+    J = nm.dRIGAdxi().toarray()
+    assert J.shape == (nm.vec_iga_dof, 4 * n) and np.abs(J[nm.zero_dofs]).max() == 0.0
+
+    def oracle_residual(xi):
+        itf = Interface(nm.mapping_list[0][0], nm.mapping_list[0][1], xi[:2 * n].reshape(-1, 2), xi[2 * n:].reshape(-1, 2))
+        A = nm._arrays()
+        A2 = type(A)(nm.splines, nm.E, nm.nu, [list(r.body_force) for r in nm.residuals], [itf],
+                     [(A.if_alpha[0], A.if_alpha[1])], [])
+        O = Oracle(A2, thickness=np.concatenate(nm.h_th), u=nm.u_iga)
+        for f in range(3):
+            O.set_cp(f, nm.cp_iga[f])
+        return O.residual()
+
+    eps = 1e-6
+    for k in rng.choice(4 * n, 10, replace=False):
+        e = np.zeros(4 * n)
+        e[k] = eps
+        fd = (oracle_residual(xi0 + e) - oracle_residual(xi0 - e)) / (2 * eps)
+        assert np.abs(fd - J[:, k]).max() < 2e-6 * np.abs(J).max(), k
+    Jfd = nm.dRIGAdxi_FD(xi0, h=1e-7)
+    assert np.abs(Jfd - J).max() < 1e-4 * np.abs(J).max()

@@ -119,3 +119,34 @@ def test_kernel_header_stress_point_vs_autograd():
             assert np.abs(out[3:18] - gz.numpy().ravel()).max() < 1e-11 * np.abs(gz.numpy()).max(), (measure, sgn)
             assert np.abs(out[18:33] - gZ.numpy().ravel()).max() < 1e-11 * np.abs(gZ.numpy()).max(), (measure, sgn)
             assert abs(out[2] - (0.0 if gt is None else gt.item())) < 1e-11 * max(abs(out[2]), 1e-30) + 1e-14, (measure, sgn)
+
+
+def test_kernel_header_penalty_gradient_in_dual_numbers(oracle_lib):
+    """kl_point.hpp penalty_grad_t<Dual> (moving intersections, N3): value = the oracle's vertex gradient, directional
+    derivative = Hyy dy + HyY dY (complex-step oracle) for y / Y seeds and a central difference for the tangent seed."""
+    import ctypes as C
+    L = _host_kernel_lib()
+    dp = C.POINTER(C.c_double)
+    L.gfh_penalty_grad_dual.argtypes = [dp] * 6 + [C.c_double] * 3 + [dp, dp]
+    P = lambda a: a.ctypes.data_as(dp)
+    rng = np.random.default_rng(21)
+    for trial in range(3):
+        Y = rng.standard_normal(12) + np.array([1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 1.0]) * 3
+        y = np.zeros(18)
+        y[0:3], y[9:12] = 0.1 * rng.standard_normal(3), 0.1 * rng.standard_normal(3)
+        y[3:9] = Y[0:6] + 0.05 * rng.standard_normal(6)
+        y[12:18] = Y[6:12] + 0.05 * rng.standard_normal(6)
+        tau = rng.standard_normal(2)
+        dy, dY, dtau = rng.standard_normal(18), rng.standard_normal(12), rng.standard_normal(2)
+        en, g, Hyy, HyY = oracle_py.penalty_point(y, Y, tau, 7.0, 3.0, 0.25)
+        gr, dgr, z18, z12, z2 = np.zeros(18), np.zeros(18), np.zeros(18), np.zeros(12), np.zeros(2)
+        L.gfh_penalty_grad_dual(P(y), P(Y), P(tau), P(dy), P(dY), P(z2), 7.0, 3.0, 0.25, P(gr), P(dgr))
+        assert np.abs(gr - g).max() < 1e-12 * np.abs(g).max()
+        ref = Hyy @ dy + HyY @ dY
+        assert np.abs(dgr - ref).max() < 1e-10 * np.abs(ref).max()
+        L.gfh_penalty_grad_dual(P(y), P(Y), P(tau), P(z18), P(z12), P(dtau), 7.0, 3.0, 0.25, P(gr), P(dgr))
+        eps = 1e-6
+        gp = oracle_py.penalty_point(y, Y, tau + eps * dtau, 7.0, 3.0, 0.25)[1]
+        gm = oracle_py.penalty_point(y, Y, tau - eps * dtau, 7.0, 3.0, 0.25)[1]
+        fd = (gp - gm) / (2 * eps)
+        assert np.abs(dgr - fd).max() < 1e-7 * np.abs(fd).max()
