@@ -12,3 +12,6 @@ from .int_energy_comp import IntEnergyComp        # noqa: E402,F401
 from .volume_comp import VolumeComp               # noqa: E402,F401
 from .compliance_comp import ComplianceComp       # noqa: E402,F401
 from .max_vmstress_comp import MaxvMStressComp   # noqa: E402,F401
+from .cpiga2xi_comp import CPIGA2XiComp           # noqa: E402,F401
+from .disp_states_mi_comp import DispMintStatesComp   # noqa: E402,F401
+from .int_xi_edge_comp import IntXiEdgeComp         # noqa: E402,F401

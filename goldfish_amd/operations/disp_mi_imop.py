@@ -1,0 +1,56 @@
+"""DispMintImOpeartion -- implicit operation for the displacement states with moving intersections
+(reference: GOLDFISH/operations/disp_mi_imop.py:3-126; the class name keeps the reference's spelling).
+The last entry of ``d_inputs_array_list`` is the vector of intersection parametric coordinates."""
+import numpy as np
+
+from .. import _lib
+from .disp_imop import DispImOpeartion
+
+
+class DispMintImOpeartion(DispImOpeartion):
+
+    def __init__(self, nonmatching_opt, save_files=False):
+        super().__init__(nonmatching_opt)
+        self.save_files = save_files
+
+    def linearize(self):
+        """disp_mi_imop.py:34-42: dR/du and dR/dCP_f in one device pass, dR/dxi from the mortar-vertex kernel."""
+        self.nonmatching_opt._assemble(_lib.ASM_K | _lib.ASM_DRDCP)
+        self.dRigadxi = self.nonmatching_opt.dRIGAdxi()
+        self._lin_dev = self.nonmatching_opt.dev
+        return self.dRigadxi
+
+    def stale(self):
+        """True when update_transfer_matrices re-created the device model after the last linearize (its matrices are gone)."""
+        return getattr(self, "_lin_dev", None) is not self.nonmatching_opt.dev
+
+    def apply_linear_fwd(self, d_inputs_array_list=None, d_outputs_array=None, d_residuals_array=None):
+        """disp_mi_imop.py:44-73."""
+        nm, dev = self.nonmatching_opt, self.nonmatching_opt.dev
+        if d_residuals_array is not None:
+            acc = np.zeros(nm.vec_iga_dof)
+            if d_outputs_array is not None:
+                dev.apply(_lib.MAT_K, d_outputs_array, acc)
+            if d_inputs_array_list is not None:
+                for i, field in enumerate(self.opt_field):
+                    dev.apply(_lib.MAT_DRDCP0 + field, self._cp_full(i, d_inputs_array_list[i]), acc)
+                acc += self.dRigadxi @ np.asarray(d_inputs_array_list[-1], float)
+            d_residuals_array[:] += acc
+        return d_residuals_array
+
+    def apply_linear_rev(self, d_inputs_array_list=None, d_outputs_array=None, d_residuals_array=None):
+        """disp_mi_imop.py:75-104."""
+        nm, dev = self.nonmatching_opt, self.nonmatching_opt.dev
+        if d_residuals_array is not None:
+            dres = np.ascontiguousarray(d_residuals_array, float)
+            if d_outputs_array is not None:
+                acc = np.zeros(nm.vec_iga_dof)
+                dev.apply(_lib.MAT_K, dres, acc, transpose=True)
+                d_outputs_array[:] += acc
+            if d_inputs_array_list is not None:
+                for i, field in enumerate(self.opt_field):
+                    acc = np.zeros(nm.vec_scalar_iga_dof)
+                    dev.apply(_lib.MAT_DRDCP0 + field, dres, acc, transpose=True)
+                    d_inputs_array_list[i][:] += acc[nm._shopt_cols[i]]
+                d_inputs_array_list[-1][:] += self.dRigadxi.T @ dres
+        return d_inputs_array_list, d_outputs_array

@@ -481,3 +481,38 @@ def test_moving_intersection_residual_derivative(oracle_lib):
         assert np.abs(fd - J[:, k]).max() < 2e-6 * np.abs(J).max(), k
     Jfd = nm.dRIGAdxi_FD(xi0, h=1e-7)
     assert np.abs(Jfd - J).max() < 1e-4 * np.abs(J).max()
+
+
+def test_disp_states_with_moving_intersections_component():
+    """DispMintStatesComp (om_comps/disp_states_mi_comp.py:6-117): partials of R(u; CP_IGA, int_para) through the
+    OpenMDAO protocol -- K du, dR/dCP dcp and dR/dxi dxi against central differences of apply_nonlinear (the device model
+    is re-created for every perturbed set of parametric coordinates) -- and the reverse products against the forward ones."""
+    from goldfish_amd.om_comps import DispMintStatesComp, om
+    spec, th, nm = _problem()
+    rng = np.random.default_rng(12)
+    n = 5
+    t = np.linspace(0, 1, n)
+    xa = np.stack([0.45 + 0.1 * t + 0.03 * np.sin(3 * t), 0.1 + 0.8 * t ** 1.3], 1)
+    xb = np.stack([0.3 + 0.2 * t ** 2, 0.15 + 0.7 * t], 1)
+    nm.mortar_nels = [n - 1]
+    nm.mortar_meshes_setup(nm.mapping_list, [[xa, xb]], nm.penalty_coefficient)
+    nm.create_diff_intersections()
+    comp = DispMintStatesComp(nonmatching_opt=nm)
+    comp.init_parameters()
+    prob = om.Problem(model=comp)
+    prob.setup()
+    prob["displacements"] = 1e-2 * rng.standard_normal(nm.vec_iga_dof)
+    free = np.ones(nm.vec_iga_dof, bool)
+    free[np.asarray(nm.dev and nm.zero_dofs)] = False
+    errs = prob.check_partials(compact_print=False, free_mask=free, step=1e-6)
+    assert max(errs.values()) < 2e-5, errs
+    assert ("displacements", "int_para") in errs
+    # reverse mode: <lam, J dx> == <J^T lam, dx> for the xi block
+    op = comp.disp_mint_state_imop
+    lam, dxi = rng.standard_normal(nm.vec_iga_dof), rng.standard_normal(nm.xi_size)
+    dres = np.zeros(nm.vec_iga_dof)
+    din = [np.zeros(s) for s in comp.input_cp_shapes] + [dxi]
+    op.apply_linear_fwd(din, None, dres)
+    back = [np.zeros(s) for s in comp.input_cp_shapes] + [np.zeros(nm.xi_size)]
+    op.apply_linear_rev(back, None, lam)
+    assert abs(lam @ dres - back[-1] @ dxi) < 1e-10 * abs(lam @ dres)

@@ -435,3 +435,64 @@ def test_cpiga2xi_follows_a_moved_patch():
     assert np.abs(xa[:, 0] - 0.55).max() < 1e-10 and np.abs(xa[:, 1] - xi0[:2 * n].reshape(-1, 2)[:, 1]).max() < 1e-9
     assert np.abs(xb - xi0[2 * n:].reshape(-1, 2)).max() < 1e-9
     assert np.abs(xi0 + dxidcp @ shift - xi).max() < 1e-9                     # the map is linear for this geometry
+
+
+def test_cpiga2xi_component_partials():
+    """CPIGA2XiComp (om_comps/cpiga2xi_comp.py:6-103) through the OpenMDAO protocol: solve_nonlinear reproduces the
+    stored coordinates, apply_linear (fwd) matches central differences, solve_linear inverts dR/dxi in both modes."""
+    from goldfish_amd.nonmatching_opt import NonMatchingOptFFD
+    from goldfish_amd.om_comps import CPIGA2XiComp, om
+    spec = G.tbeam_2patch(4)
+    nm = NonMatchingOptFFD.from_spec(spec)
+    nm.set_shopt_surf_inds_FFD([0, 1, 2], [[0, 1]] * 3)
+    nm.create_diff_intersections()
+    comp = CPIGA2XiComp(nonmatching_opt=nm)
+    comp.init_parameters()
+    prob = om.Problem(model=comp)
+    prob.setup()
+    prob.run_model()
+    assert np.abs(prob["int_para_coord"] - nm.cpiga2xi.xi_flat_global).max() < 1e-10
+    errs = prob.check_partials(compact_print=False)
+    assert max(errs.values()) < 1e-6, errs
+    op = comp.cpiga2xi_imop
+    rng = np.random.default_rng(2)
+    b = rng.standard_normal(nm.xi_size)
+    x = op.solve_linear_fwd(np.zeros(nm.xi_size), b.copy())
+    assert np.abs(op.dRdxi_mat @ x - b).max() < 1e-9
+    y = op.solve_linear_rev(b.copy(), np.zeros(nm.xi_size))
+    assert np.abs(op.dRdxi_mat.T @ y - b).max() < 1e-9
+
+
+def test_cpiga2xi_edge_intersection_and_edge_component():
+    """'edge-surf' / 'surf-edge' bookkeeping of CPIGA2Xi (cpiga2xi.py:151-304): the pinned end coordinates, the
+    coordinates that stay on the patch edge, and IntXiEdgeComp (om_comps/int_xi_edge_comp.py) on top of them."""
+    from goldfish_amd.cpiga2xi import CPIGA2Xi, IntersectionData
+    from goldfish_amd.nonmatching_opt import NonMatchingOptFFD
+    from goldfish_amd.om_comps import IntXiEdgeComp, om
+    spec = G.tbeam_2patch(4)
+    itf = spec.interfaces[0]
+    edge_dir = int(np.argmin(np.ptp(itf.xi_b, axis=0)))                 # the web's coordinate that is constant along the curve
+    edge_val = int(round(itf.xi_b[0, edge_dir]))
+    pre = IntersectionData(patches=spec.patches, mapping_list=[[itf.a, itf.b]], intersections_para_coords=[[itf.xi_a, itf.xi_b]],
+                           intersections_type=[["surf-edge", "1-%d.%d" % (edge_dir, edge_val)]],
+                           diff_int_edge_cons=["1-%d.%d" % (edge_dir, edge_val)])
+    c2x = CPIGA2Xi(pre, opt_surf_inds=[[0, 1]] * 3, opt_field=[0, 1, 2])
+    n = c2x.diff_int_num_pts[0]
+    want = 2 * n + 2 * np.arange(n) + edge_dir                         # side-1 coordinates in direction edge_dir
+    assert np.array_equal(c2x.int_edge_cons_dofs, want) and np.all(c2x.int_edge_cons_vals == edge_val)
+    assert len(c2x.int_xi_free_dofs) == 4 * n - n
+    assert np.abs(c2x.residual(c2x.xi_flat_global)).max() < 1e-12
+    J = c2x.dRdxi(c2x.xi_flat_global)
+    assert np.linalg.matrix_rank(J) == 4 * n                            # the 4n x 4n system is regular
+    c2x.implicit_edge = True                                            # edge coordinates replace one coincidence equation
+    assert np.abs(c2x.residual(c2x.xi_flat_global)).max() < 1e-12
+    nm = NonMatchingOptFFD.from_spec(spec)
+    nm.set_shopt_surf_inds_FFD([0, 1, 2], [[0, 1]] * 3)
+    nm.create_diff_intersections(preprocessor=pre)
+    comp = IntXiEdgeComp(nonmatching_opt=nm)
+    comp.init_parameters()
+    prob = om.Problem(model=comp)
+    prob.setup()
+    prob.run_model()
+    assert np.abs(prob["int_xi_edge"]).max() < 1e-14
+    assert max(prob.check_partials(compact_print=False).values()) < 1e-8
