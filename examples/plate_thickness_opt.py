@@ -1,11 +1,17 @@
-#!/usr/bin/env python3
-"""Thickness optimisation of the six-patch plate (config C1) on the MI355X path.
+"""Thickness optimisation of the six-patch plate -- the problem of the reference's
+demos_om/thickness_opt/plate/plate_const_th_opt_wint.py (ThicknessOptGroup :13-117: minimise the internal energy
+subject to constant volume, one thickness per patch, bounds 4e-3 .. 5e-2, SLSQP) -- driven directly through the
+operations of goldfish_amd instead of an OpenMDAO group:
 
-Mirrors the reference demo demos_om/thickness_opt/plate/plate_const_th_opt_wint.py (ThicknessOptGroup,
-:12-124): design variables = one thickness per patch, objective = internal energy W_int, constraint =
-constant material volume, state = displacements solved by Newton; total derivatives by the adjoint
-(DispImOpeartion.linearize / solve_linear_rev / apply_linear_rev + IntEnergyExOperation partials).
-OpenMDAO is optional: without it the same operations are driven by scipy.optimize (SLSQP)."""
+    state      R(u; h) = 0                       DispImOpeartion.solve_nonlinear     (Newton, K on the device)
+    objective  W(u, h)                           IntEnergyExOperation
+    adjoint    K^T lam = dW/du                   DispImOpeartion.solve_linear_rev
+    gradient   dW/dh - (dR/dh)^T lam             DispImOpeartion.apply_linear_rev    (dR/dh on the device)
+    constraint V(h) = V(h_0)                     VolumeExOperation
+
+With openmdao installed the same problem is the reference's group wired from goldfish_amd.om_comps (HthMapComp,
+DispStatesComp, IntEnergyComp, VolumeComp) unchanged.  Usage: python examples/plate_thickness_opt.py
+"""
 import os
 import sys
 
@@ -13,65 +19,73 @@ import numpy as np
 from scipy.optimize import minimize
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-
 from goldfish_amd import geometry as G                                   # noqa: E402
-from goldfish_amd.nonmatching_opt import NonMatchingOpt                   # noqa: E402
-from goldfish_amd.operations.disp_imop import DispImOpeartion             # noqa: E402
+from goldfish_amd.nonmatching_opt import NonMatchingOptFFD               # noqa: E402
+from goldfish_amd.operations.disp_imop import DispImOpeartion            # noqa: E402
 from goldfish_amd.operations.int_energy_exop import IntEnergyExOperation  # noqa: E402
-from goldfish_amd.operations.volume_exop import VolumeExOperation         # noqa: E402
+from goldfish_amd.operations.volume_exop import VolumeExOperation        # noqa: E402
 
 
-def build_problem():
-    spec = G.plate_6patch()
-    nm = NonMatchingOpt.from_spec(spec)
-    nm.set_thickness_opt(var_thickness=False)
-    return nm
+class ReducedThicknessProblem:
+    """Objective / constraint of the reduced (state-eliminated) problem in the per-patch thicknesses."""
+
+    def __init__(self, nm, newton_rtol=1e-10):
+        self.nm = nm
+        nm.set_thickness_opt(var_thickness=False)
+        self.disp, self.wint, self.vol = DispImOpeartion(nm), IntEnergyExOperation(nm), VolumeExOperation(nm)
+        self.rtol = newton_rtol
+        self._h = None
+        self.n_state_solves = 0
+
+    def _solve(self, h):
+        h = np.asarray(h, float)
+        if self._h is None or not np.array_equal(h, self._h):
+            self.nm.update_h_th(h)
+            self.nm.update_uIGA(self.disp.solve_nonlinear(max_it=30, rtol=self.rtol))
+            self._h = h.copy()
+            self.n_state_solves += 1
+
+    def objective(self, h):
+        self._solve(h)
+        return self.wint.Wint()
+
+    def gradient(self, h):
+        self._solve(h)
+        self.disp.linearize()                                           # K, dR/dh at the converged state
+        lam = self.disp.solve_linear_rev(self.wint.dWintduIGA(apply_bcs=True), np.zeros(self.nm.vec_iga_dof))
+        g = [np.zeros(self.nm.h_th_dof)]
+        self.disp.apply_linear_rev(g, None, lam)                        # g[0] = (dR/dh)^T lam   (opt_shape is off: one input)
+        return self.wint.dWintdh_th() - g[0]
+
+    def volume(self, h):
+        self.nm.update_h_th(np.asarray(h, float))
+        self._h = None
+        return self.vol.volume()
+
+    def volume_gradient(self, h):
+        self.nm.update_h_th(np.asarray(h, float))
+        self._h = None
+        return self.vol.dvoldh_th()
 
 
-def run(max_iter=15, verbose=True):
-    nm = build_problem()
-    disp, wint, vol = DispImOpeartion(nm), IntEnergyExOperation(nm), VolumeExOperation(nm)
-    h0 = nm.init_h_th.copy()
-    scale = 1.0 / h0.mean()
-
-    def state(h):
-        nm.update_h_th(h)
-        nm.solve_nonlinear_nonmatching_problem(rtol=1e-10, max_it=30)
-
-    def objective(x):
-        state(x / scale)
-        return wint.Wint()
-
-    def gradient(x):
-        state(x / scale)
-        disp.linearize()
-        lam = disp.solve_linear_rev(wint.dWintduIGA(apply_bcs=True).copy(), np.zeros(nm.vec_iga_dof))
-        g = np.zeros(h0.size)
-        disp.apply_linear_rev([g], None, lam)
-        return (wint.dWintdh_th() - g) / scale
-
-    state(h0)
-    V0, W0 = vol.volume(), wint.Wint()
-
-    def vol_con(x):
-        nm.update_h_th(x / scale)
-        return (vol.volume() - V0) / V0
-
-    def vol_jac(x):
-        nm.update_h_th(x / scale)
-        return vol.dvoldh_th() / V0 / scale
-
-    res = minimize(objective, h0 * scale, jac=gradient, method="SLSQP",
-                   bounds=[(0.2, 5.0)] * h0.size, constraints=[{"type": "eq", "fun": vol_con, "jac": vol_jac}],
-                   options={"maxiter": max_iter, "ftol": 1e-12})
-    h = res.x / scale
-    state(h)
-    out = dict(W0=W0, W=wint.Wint(), V0=V0, V=vol.volume(), h0=h0, h=h, nit=res.nit)
+def run(p=3, maxiter=60, lower=4e-3, upper=5e-2, verbose=True):
+    spec = G.plate_6patch(p)
+    nm = NonMatchingOptFFD.from_spec(spec)
+    prob = ReducedThicknessProblem(nm)
+    h0 = np.full(nm.num_splines, spec.h_th)
+    v0, w0 = prob.volume(h0), prob.objective(h0)
+    s = 1.0 / w0                                                        # the demo scales the objective (scaler=1e3)
+    res = minimize(lambda h: s * prob.objective(h), h0, jac=lambda h: s * prob.gradient(h), method="SLSQP",
+                   bounds=[(lower, upper)] * h0.size,
+                   constraints=[dict(type="eq", fun=lambda h: (prob.volume(h) - v0) / v0, jac=lambda h: prob.volume_gradient(h) / v0)],
+                   options=dict(maxiter=maxiter, ftol=1e-10, disp=False))
+    w1 = prob.objective(res.x)
     if verbose:
-        print("W_int: %.6e -> %.6e  (%.1f %% lower), volume %.6e -> %.6e, %d iterations" %
-              (out["W0"], out["W"], 100 * (1 - out["W"] / out["W0"]), out["V0"], out["V"], out["nit"]))
-        print("thickness per patch:", np.array2string(h, precision=5))
-    return out
+        print("internal energy %.6e -> %.6e  (%.1f %% of the uniform plate), volume drift %.2e, %d state solves"
+              % (w0, w1, 100 * w1 / w0, abs(prob.volume(res.x) - v0) / v0, prob.n_state_solves))
+        for k, t in enumerate(res.x):
+            print("Thickness for patch %2d: %10.6f" % (k, t))
+    return dict(h=res.x, w0=w0, w1=w1, v0=v0, v1=prob.volume(res.x), problem=prob, result=res)
 
 
 if __name__ == "__main__":
