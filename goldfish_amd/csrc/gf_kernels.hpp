@@ -923,7 +923,10 @@ template <int P, int PEN_SL>
 __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q, int flags, int maxdeg, const double* __restrict__ pbuf, double* __restrict__ R,
                                                         double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1, double* __restrict__ valC2) {
     constexpr int P1 = P + 1, NB = P1 * P1;
-    const long long gidx = blockIdx.x;
+    // workgroup w runs on XCD w % 8: give every XCD a contiguous range of row groups, so that the vertex records shared by
+    // neighbouring control points are fetched into one L2 instead of eight (2.82 -> 2.73 ms at C4)
+    const long long chunk = (Q.nrow_groups + 7) / 8;
+    const long long gidx = (long long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if (gidx >= Q.nrow_groups) return;
     const int tid = threadIdx.x;
     const long long e0 = Q.ent_ptr[gidx], e1 = Q.ent_ptr[gidx + 1];
