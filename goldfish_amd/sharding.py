@@ -136,6 +136,12 @@ def allgather_owned_rows(shard, local_rows, dist, width=3, out=None):
     mx = max(b - a for a, b in rng)
     send = torch.zeros(mx, dtype=torch.float64, device=local_rows.device)
     send[:g1 - g0] = local_rows[:g1 - g0]
+    if send.is_cuda:
+        # local_rows is usually a view of the library's residual buffer, which the next assembly (on the library's own
+        # stream) overwrites: wait for this one copy, not for the collective, so that the exchange overlaps the next step
+        ev = torch.cuda.Event()
+        ev.record()
+        ev.synchronize()
     recv = torch.empty(shard.world * mx, dtype=torch.float64, device=local_rows.device)
     if dist.get_backend() == "nccl":
         dist.all_gather_into_tensor(recv, send)
