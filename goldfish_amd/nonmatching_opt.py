@@ -82,7 +82,7 @@ class NonMatchingOpt:
         self.mortar_nels = None
         self.penalty_coefficient = 1000.0
         self._dev = None
-        self._dirty = True
+        self._touch()
 
     # ------------------------------------------------------------------ setup (PENGoLINS surface)
     def create_mortar_meshes(self, mortar_nels):
@@ -223,7 +223,7 @@ class NonMatchingOpt:
             self._dev.set_thickness(np.concatenate(self.h_th))
             self._dev.set_u(self.u_iga)
             self.zero_dofs = self._arrays_cache.zero_dofs
-            self._dirty = True
+            self._touch()
         return self._dev
 
     # ------------------------------------------------------------------ state updates
@@ -234,7 +234,7 @@ class NonMatchingOpt:
             raise ValueError("update_uIGA: expected %d values, got %d" % (self.vec_iga_dof, u.size))
         self.u_iga = u.copy()
         self.dev.set_u(self.u_iga)
-        self._dirty = True
+        self._touch()
 
     def update_CPIGA(self, cp_array_iga, field):
         """nonmatching_opt.py:495-506: homogeneous coordinate ``field`` of the patches in
@@ -246,7 +246,7 @@ class NonMatchingOpt:
             raise ValueError("update_CPIGA: expected %d values, got %d" % (cols.size, v.size))
         self.cp_iga[field][cols] = v
         self.dev.set_cp(field, self.cp_iga[field])
-        self._dirty = True
+        self._touch()
 
     def update_h_th_IGA(self, h_th_iga_array):
         """nonmatching_opt.py:516-525 (variable thickness, one value per control point)."""
@@ -255,7 +255,7 @@ class NonMatchingOpt:
             raise ValueError("update_h_th_IGA: expected %d values, got %d" % (self.vec_scalar_iga_dof, v.size))
         self.h_th = [v[self.cp_off[s]:self.cp_off[s + 1]].copy() for s in range(self.num_splines)]
         self.dev.set_thickness(v)
-        self._dirty = True
+        self._touch()
 
     def update_h_th(self, h_th_array):
         """nonmatching_opt.py:527-531 (constant thickness per patch)."""
@@ -264,13 +264,50 @@ class NonMatchingOpt:
             raise ValueError("update_h_th: expected %d values, got %d" % (self.num_splines, v.size))
         self.h_th = [np.full(s.ncp, v[i]) for i, s in enumerate(self.splines)]
         self.dev.set_thickness(np.concatenate(self.h_th))
-        self._dirty = True
+        self._touch()
 
     # ------------------------------------------------------------------ residual and Jacobians
+    def _touch(self):
+        """A state input (u, CP, thickness, intersections) changed: what was assembled / evaluated is stale."""
+        self._state_version = getattr(self, "_state_version", 0) + 1
+
     def _assemble(self, flags):
-        self.dev.assemble(flags)
-        if flags & _lib.ASM_K:
-            self._k_version = getattr(self, "_k_version", 0) + 1
+        """Device assembly of the outputs in ``flags`` that are not current for the present state: the reference re-assembles
+        on every call (RIGA, dRIGAduIGA, dRIGAdCPIGA, ... each assemble their forms); an OpenMDAO iteration asks for the same
+        state several times (apply_nonlinear after solve_nonlinear, linearize after the last Newton step)."""
+        dev, sv = self.dev, getattr(self, "_state_version", 0)
+        if getattr(self, "_asm_state", None) != (sv, id(dev)):
+            self._asm_state, self._asm_flags = (sv, id(dev)), 0
+        need = flags & ~self._asm_flags
+        if need:
+            dev.assemble(need)
+            self._asm_flags |= need
+            if need & _lib.ASM_K:
+                self._k_version = getattr(self, "_k_version", 0) + 1
+
+    def _cached(self, key, fn):
+        """One device evaluation of a functional (value + all gradient fields) per state: the operations ask for the value and
+        for each gradient separately (IntEnergyExOperation.Wint / dWintduIGA / dWintdCPIGA / dWintdh_th, ...)."""
+        tag = (getattr(self, "_state_version", 0), id(self.dev))
+        if getattr(self, "_fun_state", None) != tag:
+            self._fun_state, self._fun_cache = tag, {}
+        if key not in self._fun_cache:
+            self._fun_cache[key] = fn()
+        return self._fun_cache[key]
+
+    def functionals(self, apply_bcs=True):
+        return self._cached(("functionals", bool(apply_bcs)), lambda: self.dev.functionals(apply_bcs=apply_bcs))
+
+    def compliance(self, forces, apply_bcs=True):
+        f = np.ascontiguousarray(forces, float)
+        return self._cached(("compliance", f.tobytes(), bool(apply_bcs)), lambda: self.dev.compliance(f, apply_bcs=apply_bcs))
+
+    def stress_forms(self, mode, rho, m_list, surf, measure, apply_bcs=True, gradients=True):
+        ml = np.ascontiguousarray(m_list, float)
+        key = ("stress", int(mode), float(rho), ml.tobytes(), int(surf), int(measure), bool(apply_bcs))
+        if not gradients and (key + (True,)) in getattr(self, "_fun_cache", {}) and getattr(self, "_fun_state", None) == (getattr(self, "_state_version", 0), id(self.dev)):
+            return self._fun_cache[key + (True,)]
+        return self._cached(key + (bool(gradients),), lambda: self.dev.stress_forms(mode, rho, ml, surf, measure, apply_bcs=apply_bcs, gradients=gradients))
 
     # ------------------------------------------------------------------ direct solves with K (SURVEY.md 8(f) N1)
     linear_solver = os.environ.get("GF_LINEAR_SOLVER", "host")     # "host": scipy SuperLU per call; "device": rocSOLVER re-factorisation

@@ -19,7 +19,7 @@ class ComplianceExOperation(object):
             self.shopt_surf_inds = nonmatching_opt.shopt_surf_inds
 
     def _c(self, apply_bcs=True):
-        return self.nonmatching_opt.dev.compliance(self.forces, apply_bcs=apply_bcs)
+        return self.nonmatching_opt.compliance(self.forces, apply_bcs=apply_bcs)
 
     def cpl(self):
         """compliance_exop.py:50-54."""

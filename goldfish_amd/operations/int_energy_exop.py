@@ -19,7 +19,7 @@ class IntEnergyExOperation(object):
             self.shopt_surf_inds = nonmatching_opt.shopt_surf_inds
 
     def _f(self, apply_bcs=True):
-        return self.nonmatching_opt.dev.functionals(apply_bcs=apply_bcs)
+        return self.nonmatching_opt.functionals(apply_bcs=apply_bcs)
 
     def Wint(self):
         """int_energy_exop.py:55-59."""

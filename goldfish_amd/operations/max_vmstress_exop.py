@@ -57,11 +57,11 @@ class MaxvMStressExOperation(object):
     def _forms(self, exponent=None, gradients=False, apply_bcs=True):
         mode = 0 if self.method == "KS" else 1
         rho = self.rho if exponent is None else exponent
-        return self.nonmatching_opt.dev.stress_forms(mode, rho, self.m_list, _SURF[self.surf], self._measure,
+        return self.nonmatching_opt.stress_forms(mode, rho, self.m_list, _SURF[self.surf], self._measure,
                                                      apply_bcs=apply_bcs, gradients=gradients)
 
     def _gp_max(self):
-        return self.nonmatching_opt.dev.stress_forms(1, 1.0, np.ones(self.num_splines), _SURF[self.surf], self._measure,
+        return self.nonmatching_opt.stress_forms(1, 1.0, np.ones(self.num_splines), _SURF[self.surf], self._measure,
                                                      gradients=False)["vmax"]
 
     # ---- setup -------------------------------------------------------------------------------

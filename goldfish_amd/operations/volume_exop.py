@@ -19,7 +19,7 @@ class VolumeExOperation(object):
             self.shopt_surf_inds = nonmatching_opt.shopt_surf_inds
 
     def _f(self):
-        return self.nonmatching_opt.dev.functionals()
+        return self.nonmatching_opt.functionals()
 
     def volume(self):
         """volume_exop.py:46-50."""
