@@ -241,11 +241,11 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
         GF_STAMP(5, tstamp);
         // -- residual and dR/dh prefactors of basis function x at this Gauss point
         {
-            const double J = im[IM_J];
+            const double ls = has_bf ? load_scalar(im, load_geom(im, Pt.pd)) : 0.0;
             for (int i = 0; i < 3; ++i) {
                 double rz = 0.0;
                 for (int m = 0; m < 5; ++m) rz += phi[m] * im[IM_PZ + 3 * m + i];
-                accR[i] += wq * (rz - J * Pt.f[i] * R0);
+                accR[i] += wq * (rz - ls * Pt.f[i] * R0);
             }
         }
         double pb[5];
@@ -287,10 +287,10 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
                 for (int q = 0; q < 9; ++q) accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], t[q], accC[q], 0, 0, 0);
             });
             if (has_bf) {                    // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b): one tile per f, the factor -f_i is applied once at the end
-                const double J = im[IM_J];
+                const LoadGeom lg = load_geom(im, Pt.pd);
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {
-                    const double jz = J * (im[IM_JZJ + f] * pb[0] + im[IM_JZJ + 3 + f] * pb[1]);
+                    const double jz = load_dz_dot(im, lg, f, pb[0], pb[1]);
                     accB[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(R0, jz, accB[f], 0, 0, 0);
                 }
             }

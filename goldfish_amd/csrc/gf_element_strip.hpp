@@ -250,11 +250,11 @@ __global__ __launch_bounds__(64) void kl_element_strip_kernel(DevModel M, const 
             }
             // -- residual and dR/dh prefactors of basis function x at this Gauss point
             {
-                const double J = im[IM_J];
+                const double ls = has_bf ? load_scalar(im, load_geom(im, Pt.pd)) : 0.0;
                 for (int i = 0; i < 3; ++i) {
                     double rz = 0.0;
                     for (int m = 0; m < 5; ++m) rz += phi[m] * im[IM_PZ + 3 * m + i];
-                    accR[i] += wq * (rz - J * Pt.f[i] * R0);
+                    accR[i] += wq * (rz - ls * Pt.f[i] * R0);
                 }
             }
             double pb[5];
@@ -295,10 +295,10 @@ __global__ __launch_bounds__(64) void kl_element_strip_kernel(DevModel M, const 
                     for (int q = 0; q < 9; ++q) accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], t[q], accC[q], 0, 0, 0);
                 });
                 if (has_bf) {                    // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b)
-                    const double J = im[IM_J];
+                    const LoadGeom lg = load_geom(im, Pt.pd);
     #pragma unroll
                     for (int f = 0; f < 3; ++f) {
-                        const double jz = J * (im[IM_JZJ + f] * pb[0] + im[IM_JZJ + 3 + f] * pb[1]);
+                        const double jz = load_dz_dot(im, lg, f, pb[0], pb[1]);
     #pragma unroll
                         for (int i = 0; i < 3; ++i) accC[3 * i + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pt.f[i] * R0, jz, accC[3 * i + f], 0, 0, 0);
                     }

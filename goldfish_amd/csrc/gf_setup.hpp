@@ -28,7 +28,7 @@ struct PatchDev {            // POD mirrored on the device
     int spu, spv;            // offsets into ints[] : span index per element
     int c2u, c2v;            // offsets into ints[] : [n][2] first/last element touching CP index
     long long cp_off, elem_off;
-    double E, nu_, f[3];
+    double E, nu_, f[3], pd[3];   // pd != 0: load per unit projected area (gf_model_desc.load_proj)
 };
 
 // per-element descriptor: one load instead of the elem_patch -> patch -> span-table chain of dependent scalar loads
@@ -151,7 +151,7 @@ inline void HostModel::build(const gf_model_desc* D) {
         P.nu = D->ncp[2 * s]; P.nv = D->ncp[2 * s + 1];
         P.cp_off = D->cp_off[s]; P.E = D->young[s]; P.nu_ = D->poisson[s];
         if (D->cp_off[s + 1] - D->cp_off[s] != int64_t(P.nu) * P.nv) throw std::runtime_error("gf_create: cp_off inconsistent with ncp");
-        for (int k = 0; k < 3; ++k) P.f[k] = D->body_force ? D->body_force[3 * s + k] : 0.0;
+        for (int k = 0; k < 3; ++k) { P.f[k] = D->body_force ? D->body_force[3 * s + k] : 0.0; P.pd[k] = D->load_proj ? D->load_proj[3 * s + k] : 0.0; }
         for (int64_t a = P.cp_off; a < D->cp_off[s + 1]; ++a) cp_patch[a] = s;
         for (int d = 0; d < 2; ++d) {
             const int p = d ? P.q : P.p, n = d ? P.nv : P.nu;

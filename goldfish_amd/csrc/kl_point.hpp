@@ -325,6 +325,25 @@ GF_HD inline double pzZ_entry(const double* im, int r, int s) {
     return v;
 }
 
+// ---- distributed load: per unit area (pd == 0) or per unit PROJECTED area (pd != 0; gf_model_desc.load_proj) ----------
+// load scalar s = |G1 x G2| = J, or pd . (G1 x G2) = J (pd . N); reference derivative from the record alone:
+//   ds/dG1 = G2 x pd = (pd.N)(G2 x N) - (pd.(G2 x N)) N,  ds/dG2 = pd x G1 = (pd.N)(N x G1) - (pd.(N x G1)) N,
+// with G2 x N = J * JZJ[0..2], N x G1 = J * JZJ[3..5].  pd == 0 gives pn = 1, q = 0: s = J, ds/dZ = dJ/dZ.
+struct LoadGeom { double pn, q0, q1; };
+GF_HD __forceinline__ LoadGeom load_geom(const double* im, const double* pd) {
+    const bool proj = pd[0] != 0.0 || pd[1] != 0.0 || pd[2] != 0.0;
+    LoadGeom g;
+    g.pn = proj ? dot3(pd, im + IM_NB) : 1.0;
+    g.q0 = proj ? dot3(pd, im + IM_JZJ) : 0.0;
+    g.q1 = proj ? dot3(pd, im + IM_JZJ + 3) : 0.0;
+    return g;
+}
+GF_HD __forceinline__ double load_scalar(const double* im, const LoadGeom& g) { return im[IM_J] * g.pn; }
+// (ds/dZ . phi_b)_f = ds/dG1_f phi_b,1 + ds/dG2_f phi_b,2
+GF_HD __forceinline__ double load_dz_dot(const double* im, const LoadGeom& g, int f, double pb0, double pb1) {
+    return im[IM_J] * ((g.pn * im[IM_JZJ + f] - g.q0 * im[IM_NB + f]) * pb0 + (g.pn * im[IM_JZJ + 3 + f] - g.q1 * im[IM_NB + f]) * pb1);
+}
+
 // ---- energy functionals: first derivatives of Psi wrt z, Z, t and of the area Jacobian ----------
 // out: [0] Psi, [1] J, [2] dPsi/dt, [3..17] dPsi/dz, [18..32] dPsi/dZ, [33..38] dJ/d(G1,G2)
 enum : int { FE_PSI = 0, FE_J = 1, FE_PT = 2, FE_PZ = 3, FE_PZR = 18, FE_JZ = 33, FE_SIZE = 39 };

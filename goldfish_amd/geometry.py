@@ -26,6 +26,7 @@ class ProblemSpec:
     point_loads: list = dc_field(default_factory=list)   # (patch, xi, field, value)
     penalty_coefficient: float = 1.0e3
     name: str = ""
+    load_proj: list = None                 # per patch (3,): non-zero = load per unit projected area (gf_model_desc.load_proj)
 
 
 def tbeam_2patch(num_el=10, p=3, load=(0.0, 0.0, 1.0), tip_load=-10.0):

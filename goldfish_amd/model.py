@@ -72,6 +72,7 @@ class gf_model_desc(C.Structure):
         ("if_xi", C.POINTER(C.c_double)), ("if_tau", C.POINTER(C.c_double)),
         ("if_wt", C.POINTER(C.c_double)), ("if_alpha", C.POINTER(C.c_double)),
         ("n_owned_patches", C.c_int32),
+        ("load_proj", C.POINTER(C.c_double)),
     ]
 
 
@@ -83,7 +84,7 @@ class ModelArrays:
     """Owns the NumPy buffers behind a ``gf_model_desc`` (keeps them alive)."""
 
     def __init__(self, patches, E, nu, body_force=None, interfaces=(), alphas=(),
-                 point_loads=(), n_owned=0):
+                 point_loads=(), n_owned=0, load_proj=None):
         n = len(patches)
         self.n_patches = n
         self.n_owned = int(n_owned) if n_owned else n
@@ -106,6 +107,8 @@ class ModelArrays:
         self.poisson = np.ascontiguousarray(np.broadcast_to(np.asarray(nu, float), (n,)))
         bf = np.zeros((n, 3)) if body_force is None else np.asarray(body_force, float).reshape(n, 3)
         self.body_force = np.ascontiguousarray(bf).ravel()
+        lp = np.zeros((n, 3)) if load_proj is None else np.asarray(load_proj, float).reshape(n, 3)
+        self.load_proj = np.ascontiguousarray(lp).ravel()
         zd = []
         for s, p in enumerate(patches):
             zd += [3 * int(self.cp_off[s]) + d for d in sorted(p.zero_dofs)]
@@ -144,6 +147,7 @@ class ModelArrays:
         d.if_xi, d.if_tau = _ptr(self.if_xi, C.c_double), _ptr(self.if_tau, C.c_double)
         d.if_wt, d.if_alpha = _ptr(self.if_wt, C.c_double), _ptr(self.if_alpha, C.c_double)
         d.n_owned_patches = self.n_owned
+        d.load_proj = _ptr(self.load_proj, C.c_double)
         return d
 
 
@@ -180,4 +184,4 @@ def arrays_from_spec(spec, thickness=None):
               for itf in spec.interfaces]
     cp_off = np.concatenate([[0], np.cumsum([p.ncp for p in spec.patches])])
     pls = point_load_entries(spec.patches, cp_off, spec.point_loads)
-    return ModelArrays(spec.patches, E, nu, spec.body_force, spec.interfaces, alphas, pls)
+    return ModelArrays(spec.patches, E, nu, spec.body_force, spec.interfaces, alphas, pls, load_proj=getattr(spec, "load_proj", None))

@@ -25,8 +25,11 @@ from .model import Interface, ModelArrays, penalty_parameters, point_load_entrie
 @dataclass
 class SVKResidual:
     """Declarative stand-in for ``SVK_residual(spline, u, v, E, nu, h, dWext)`` with
-    ``dWext = inner(f, rationalize(v)) * dx`` (GOLDFISH/tests/test_dRdt.py:100-110)."""
+    ``dWext = inner(f, rationalize(v)) * dx`` (GOLDFISH/tests/test_dRdt.py:100-110).  ``projected`` = a direction d makes
+    the load act per unit projected area, ``f cos(beta)`` with ``cos(beta) = d . A2`` -- the source term of
+    demos_om/shape_opt/arch/arch_shape_opt_wint.py:294-301 (``force = -load * inner(e_z, A2) e_z``)."""
     body_force: tuple = (0.0, 0.0, 0.0)
+    projected: tuple = (0.0, 0.0, 0.0)
 
 
 @dataclass
@@ -211,7 +214,8 @@ class NonMatchingOpt:
             pls = point_load_entries(self.splines, self.cp_off,
                                      [(s, ps.xi, ps.field, ps.value) for ps, s in zip(self.point_sources, self.point_source_inds)])
         bf = [list(r.body_force) for r in self.residuals]
-        return ModelArrays(self.splines, self.E, self.nu, bf, self.interfaces, alphas, pls)
+        lp = [list(getattr(r, "projected", (0.0, 0.0, 0.0))) for r in self.residuals]
+        return ModelArrays(self.splines, self.E, self.nu, bf, self.interfaces, alphas, pls, load_proj=lp)
 
     @property
     def dev(self):
@@ -510,7 +514,8 @@ class NonMatchingOpt:
             pb.create_mortar_meshes([i.npts - 1 for i in spec.interfaces])
             pb.mortar_meshes_setup([[i.a, i.b] for i in spec.interfaces], [[i.xi_a, i.xi_b] for i in spec.interfaces],
                                    spec.penalty_coefficient)
-        pb.set_residuals([SVKResidual(tuple(f)) for f in spec.body_force])
+        lp = spec.load_proj if getattr(spec, "load_proj", None) is not None else [(0.0, 0.0, 0.0)] * len(spec.patches)
+        pb.set_residuals([SVKResidual(tuple(f), tuple(d)) for f, d in zip(spec.body_force, lp)])
         if spec.point_loads:
             pb.set_point_sources([PointSource(xi, f, v) for (_, xi, f, v) in spec.point_loads],
                                  [s for (s, _, _, _) in spec.point_loads])

@@ -85,7 +85,8 @@ def shard_spec(spec, rank, world):
     pls = [(g2l[s], xi, f, v) for (s, xi, f, v) in spec.point_loads if start <= s < end]
     local = ProblemSpec([spec.patches[g] for g in order], itfs, spec.E, spec.nu, spec.h_th,
                         [spec.body_force[g] for g in order], pls, spec.penalty_coefficient,
-                        "%s[rank %d/%d]" % (spec.name, rank, world))
+                        "%s[rank %d/%d]" % (spec.name, rank, world),
+                        None if getattr(spec, "load_proj", None) is None else [spec.load_proj[g] for g in order])
     cpg = np.concatenate([[0], np.cumsum([p.ncp for p in spec.patches])]).astype(np.int64)
     cpl = np.concatenate([[0], np.cumsum([p.ncp for p in local.patches])]).astype(np.int64)
     return Shard(rank, world, local, len(own), order, cpg, cpl, partition_patches(spec, world))

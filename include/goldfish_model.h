@@ -62,6 +62,12 @@ typedef struct gf_model_desc {
                                   [0, n_owned_patches) are owned (their rows are assembled) and the
                                   remaining ones are ghosts that only provide geometry/state for the
                                   interfaces cut by the partition ("owner computes rows").          */
+    /* ---- load variant (appended: older callers that zero-initialise the struct keep their meaning) ---- */
+    const double*  load_proj;  /* NULL or [3*n_patches]: a non-zero vector d makes the distributed load of that patch act per
+                                  unit PROJECTED area, dWext = f . u (d . (X_,1 x X_,2)) dxi instead of f . u |X_,1 x X_,2| dxi,
+                                  i.e. f cos(beta) per unit surface area with cos(beta) = d . A2 -- the "snow" load of
+                                  demos_om/shape_opt/arch/arch_shape_opt_wint.py:294-301 (d = e_z); geometry dependent:
+                                  it enters dR/dCP                                                         */
 } gf_model_desc;
 
 /* which-matrix selectors shared by product and oracle */

@@ -54,7 +54,7 @@ typedef struct {
     double *bu, *bv;         /* [nel][ng][3][deg+1] 1-D basis values/1st/2nd derivatives */
     double *wu, *wv;         /* [nel][ng] Gauss weight * span length/2 */
     int64_t cp_off;
-    double E, nu_, f[3];
+    double E, nu_, f[3], pd[3];   /* pd != 0: load per unit projected area (gf_model_desc.load_proj) */
 } patch_t;
 
 typedef struct {
@@ -231,7 +231,7 @@ gfo_model* gfo_create(const gf_model_desc* D) {
         P->ku = (double*)malloc(sizeof(double) * (o1 - o0)); memcpy(P->ku, D->knots + o0, sizeof(double) * (o1 - o0));
         P->kv = (double*)malloc(sizeof(double) * (o2 - o1)); memcpy(P->kv, D->knots + o1, sizeof(double) * (o2 - o1));
         P->cp_off = D->cp_off[s]; P->E = D->young[s]; P->nu_ = D->poisson[s];
-        for (int k = 0; k < 3; ++k) P->f[k] = D->body_force ? D->body_force[3 * s + k] : 0.0;
+        for (int k = 0; k < 3; ++k) { P->f[k] = D->body_force ? D->body_force[3 * s + k] : 0.0; P->pd[k] = D->load_proj ? D->load_proj[3 * s + k] : 0.0; }
         patch_tables(P);
     }
     M->cp = (double*)calloc(M->ndof, sizeof(double)); M->u = (double*)calloc(M->ndof, sizeof(double));
@@ -413,13 +413,15 @@ static void shell_element(const gfo_model* M, const patch_t* P, int eu, int ev, 
             double Ra[6]; for (int k = 0; k < 6; ++k) Ra[k] = Rb[k][a];
             first_var(g, n, jn, Ra, i, &Vd[3 * a + i]); first_var(G, Nn, Jn, Ra, i, &Vr[3 * a + i]);
         }
-        /* residual: dPsi/dU_r - body force */
+        /* residual: dPsi/dU_r - distributed load (per unit area: J, or per unit projected area: pd . (G1 x G2)) */
+        const int proj = P->pd[0] != 0 || P->pd[1] != 0 || P->pd[2] != 0;
+        const double sload = proj ? dot3(P->pd, Nt) : J;
         double rint[3 * MAXNB];
         for (int r = 0; r < nd; ++r) {
             double de[3] = {0.5 * Vd[r].dm[0], 0.5 * Vd[r].dm[1], 0.5 * Vd[r].dm[2]};
             double dk[3] = {-Vd[r].db[0], -Vd[r].db[1], -Vd[r].db[2]};
             rint[r] = dot3(nv, de) + dot3(mo, dk);
-            Re[r] += wq * J * (rint[r] - P->f[r % 3] * Rb[0][r / 3]);
+            Re[r] += wq * (J * rint[r] - sload * P->f[r % 3] * Rb[0][r / 3]);
         }
         if (want_fun) {
             for (int s = 0; s < nd; ++s) {
@@ -452,7 +454,7 @@ static void shell_element(const gfo_model* M, const patch_t* P, int eu, int ev, 
             double dCe[3], dCk[3], Cder[3], Cdkr[3]; mv3(dC, eps, dCe); mv3(dC, kap, dCk);
             double de_ref[3] = {-0.5 * dA[0], -0.5 * dA[1], -0.5 * dA[2]}; mv3(C, de_ref, Cder); mv3(C, dB, Cdkr);
             double dnv[3], dmo[3]; for (int k = 0; k < 3; ++k) { dnv[k] = th * (dCe[k] + Cder[k]); dmo[k] = t3 * (dCk[k] + Cdkr[k]); }
-            const double dJ = Vr[s].dj;
+            const double dJ = Vr[s].dj, dsl = proj ? dot3(P->pd, Vr[s].dnt) : dJ;
             for (int r = 0; r < nd; ++r) {
                 const int a = r / 3, ir = r % 3;
                 double der[3] = {0.5 * Vd[r].dm[0], 0.5 * Vd[r].dm[1], 0.5 * Vd[r].dm[2]}, dkr[3] = {-Vd[r].db[0], -Vd[r].db[1], -Vd[r].db[2]};
@@ -467,7 +469,7 @@ static void shell_element(const gfo_model* M, const patch_t* P, int eu, int ev, 
                 for (int k = 0; k < 3; ++k) ddk[k] = -f3[k] * (Rb[3 + k][a] * Vd[s].dn[ir] + Rb[3 + k][b] * Vd[r].dn[js] + dot3(g[2 + k], ddn));
                 double krs = th * dot3(der, Cde) + t3 * dot3(dkr, Cdk) + dot3(nv, dde) + dot3(mo, ddk);
                 Ke[r * nd + s] += wq * J * krs;
-                double phi21 = dJ * rint[r] + J * (dot3(dnv, der) + dot3(dmo, dkr)) - dJ * P->f[ir] * Rb[0][a];
+                double phi21 = dJ * rint[r] + J * (dot3(dnv, der) + dot3(dmo, dkr)) - dsl * P->f[ir] * Rb[0][a];
                 Ce[r * nd + s] += wq * (J * krs + phi21);
             }
         }

@@ -36,7 +36,16 @@ CASES = {
     "C3_wing16_refdata": lambda: G.wing_16patch_from_interface_data(
         np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_wing_int_data.npz"), allow_pickle=True)),
     "C5_fuselage3x2_p4": lambda: G.synthetic_fuselage(3, 2, nel=6, p=4, jitter=1),
+    # load per unit projected area along a general direction (gf_model_desc.load_proj; the arch demo's source term)
+    "slr9_nurbs_p3_projected_load": lambda: _with_projected_load(G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2])),
+    "slr9_p2_projected_load": lambda: _with_projected_load(G.scordelis_lo_9patch(4, p=2)),
+    "shell2x2_p4_projected_load": lambda: _with_projected_load(G.synthetic_shell(2, 2, nel=4, p=4, jitter=1)),
 }
+
+
+def _with_projected_load(spec):
+    spec.load_proj = [[0.3, -0.2, 1.0]] * len(spec.patches)
+    return spec
 
 
 @pytest.mark.parametrize("case", list(CASES))
@@ -77,7 +86,7 @@ def test_valu_element_kernel_still_matches(oracle_lib, monkeypatch):
     from goldfish_amd import _lib
     from oracle.oracle_py import Oracle
     monkeypatch.setenv("GF_ELEMENT", "valu")
-    for case in ("tbeam2_p2", "shell3x2_p3", "shell2x2_p4"):
+    for case in ("tbeam2_p2", "shell3x2_p3", "shell2x2_p4", "slr9_nurbs_p3_projected_load"):
         A, h, u = _state(CASES[case]())
         O = Oracle(A, thickness=h, u=u)
         D = _lib.DeviceModel(A)

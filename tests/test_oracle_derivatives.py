@@ -34,9 +34,11 @@ def _relerr(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-@pytest.mark.parametrize("name", ["slr9", "tbeam"])
+@pytest.mark.parametrize("name", ["slr9", "tbeam", "slr9_projected_load"])
 def test_oracle_vs_autograd(oracle_lib, name):
-    spec = G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2]) if name == "slr9" else G.tbeam_2patch(4)
+    spec = G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2]) if name.startswith("slr9") else G.tbeam_2patch(4)
+    if name == "slr9_projected_load":                 # load per unit projected area along a general direction (arch demo: e_z)
+        spec.load_proj = [[0.3, -0.2, 1.0]] * len(spec.patches)
     A, O, T, c, U, ht = _setup(spec)
     free = np.ones(A.ndof, bool)
     free[A.zero_dofs] = False

@@ -72,6 +72,8 @@ class TorchModel:
         self.E = torch.tensor(arrays.young)[self.pid]
         self.nu = torch.tensor(arrays.poisson)[self.pid]
         self.f = torch.tensor(arrays.body_force.reshape(-1, 3))[self.pid]
+        self.pd = torch.tensor(arrays.load_proj.reshape(-1, 3))[self.pid]
+        self.proj = (self.pd.abs().sum(-1) > 0).to(torch.float64)
         # mortar points
         self.mp = []
         for k, itf in enumerate(spec.interfaces):
@@ -95,7 +97,10 @@ class TorchModel:
         W = (self.wq * Psi).sum()
         if with_load:
             uphys = torch.einsum("ga,gak->gk", self.Rb[:, 0], U[self.ids])
-            W = W - (self.wq * ke.area_jacobian(Z) * (self.f * uphys).sum(-1)).sum()
+            # distributed load per unit area (|G1 x G2|) or per unit projected area (d . (G1 x G2), gf_model_desc.load_proj)
+            Nt = torch.linalg.cross(Z[:, 0, :], Z[:, 1, :])
+            s = self.proj * (self.pd * Nt).sum(-1) + (1 - self.proj) * ke.area_jacobian(Z)
+            W = W - (self.wq * s * (self.f * uphys).sum(-1)).sum()
         return W
 
     def volume(self, c, h):
