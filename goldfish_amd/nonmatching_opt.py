@@ -529,8 +529,12 @@ class NonMatchingOptFFD(NonMatchingOpt):
     needs are provided so that fixtures written against NonMatchingOptFFD run unchanged."""
 
     def set_shopt_surf_inds_FFD(self, opt_field, shopt_surf_inds):
-        """nonmatching_opt_ffd.py:60: same bookkeeping as set_shopt_surf_inds."""
-        self.set_shopt_surf_inds(opt_field, shopt_surf_inds)
+        """nonmatching_opt_ffd.py:60-72: ``shopt_surf_inds`` is ONE list of patch indices shared by every opt field (a list
+        per field, as ``set_shopt_surf_inds`` takes it, is accepted too)."""
+        inds = list(shopt_surf_inds)
+        if len(inds) == 0 or not isinstance(inds[0], (list, tuple, np.ndarray)):
+            inds = [list(inds)] * len(opt_field)
+        self.set_shopt_surf_inds(opt_field, inds)
         self.shopt_multiffd = False
 
     def set_shopt_FFD(self, shopt_knotsffd, shopt_cpffd):

@@ -559,3 +559,25 @@ def test_incremental_assembly_and_functional_cache():
     assert not np.array_equal(nm.RIGA(), R) and len(calls) == n0 + 1
     w.Wint()
     assert sum(1 for c in calls if c[0] == "fun") == 2
+
+
+def test_arch_shape_optimisation_known_answer():
+    """examples/arch_shape_opt.py: the reference's arch demo (demos_om/shape_opt/arch/arch_shape_opt_wint.py prints
+    "Maximum F2 ... (reference: 5.4779)") through the device path -- load per unit projected area, dR/dCP, FFD maps,
+    adjoint.  5.4779 is the analytical optimum rise of a parabolic arch of span 10 (0.547789 L); start: rise 3."""
+    import importlib.util
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec_ = importlib.util.spec_from_file_location("arch_shape_opt", os.path.join(here, "examples", "arch_shape_opt.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    out = mod.run(verbose=False)
+    assert abs(out["h0"] - 3.0) < 1e-12
+    assert abs(out["h1"] - 5.4779) < 5e-3, out["h1"]
+    assert out["w1"] < 0.8 * out["w0"]
+    prob = out["problem"]
+    rng = np.random.default_rng(1)
+    d = prob.d0 * (1 + 0.05 * rng.standard_normal(prob.d0.size))
+    g, v = prob.gradient(d), rng.standard_normal(prob.d0.size)
+    eps = 1e-5
+    fd = (prob.objective(d + eps * v) - prob.objective(d - eps * v)) / (2 * eps)
+    assert abs(fd - g @ v) < 1e-4 * abs(fd), (fd, g @ v)          # W ~ 1e-8: the difference quotient carries ~1e-5 of noise
