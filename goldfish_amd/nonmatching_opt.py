@@ -142,7 +142,111 @@ class NonMatchingOpt:
             self.cpdes_iga_dofs_full_list.append(lst)
             self._shopt_cols.append(np.concatenate(cols))
         self.cpdes_iga_dofs_full = [np.concatenate(l) for l in self.cpdes_iga_dofs_full_list]
+        self.cpdes_iga_dofs = [[list(sub) for sub in lst] for lst in self.cpdes_iga_dofs_full_list]
+        self.cp_shapes = [(s.n_u, s.n_v) for s in self.splines]
         self.shopt_pin_dofs = [[] for _ in self.opt_field]
+
+    def set_geom_preprocessor(self, preprocessor):
+        """nonmatching_opt.py:129-141: ``preprocessor`` is a ``cpiga2xi.IntersectionData`` here."""
+        self.preprocessor = preprocessor
+        self.cp_shapes = [(P.n_u, P.n_v) for P in preprocessor.patches]
+
+    def solve_init_CPIGA(self):
+        """nonmatching_opt.py:216-229 L2-projects the FE control functions to IGA dofs; the IGA control points are the
+        primary data here."""
+        return self.get_init_CPIGA()
+
+    def set_shopt_align_CP(self, align_surf_inds=[], align_dir=[]):
+        """nonmatching_opt.py:232-301 (shape optimisation directly on surface control points): the control points of the
+        listed patches take one value along parametric direction ``align_dir`` (0: rows of the net move together, the design
+        dofs are the first column; 1: columns move together, the design dofs are the first row).  Returns
+        ``shopt_dcpaligndcpsurf`` (full control points of the optimised patches x design dofs).  The reference stores the
+        block of an aligned patch at its position in ``align_surf_inds``; here at its position among the optimised patches."""
+        assert len(align_surf_inds) == len(self.opt_field) and len(align_dir) == len(self.opt_field)
+        self.align_surf_inds, self.align_dir = align_surf_inds, align_dir
+        sizes = self.vec_scalar_iga_dof_list
+        self.align_cp_deriv_list = [[sp.identity(sizes[s], format="csr") for s in inds] for inds in self.shopt_surf_inds]
+        self.cpdes_iga_dofs = [[list(sub) for sub in lst] for lst in self.cpdes_iga_dofs_full_list]
+        self.shopt_num_desvars = [int(sum(sizes[s] for s in inds)) for inds in self.shopt_surf_inds]
+        for fi, field in enumerate(self.opt_field):
+            if self.align_surf_inds[fi] is None:
+                continue
+            for k, s in enumerate(self.align_surf_inds[fi]):
+                if s not in self.shopt_surf_inds[fi]:
+                    raise ValueError(f"Aligned surface {s} is not optimized.")
+                ncol, nrow = self.cp_shapes[s]
+                pos = self.shopt_surf_inds[fi].index(s)
+                full = np.asarray(self.cpdes_iga_dofs_full_list[fi][pos])
+                a = np.arange(sizes[s])
+                if self.align_dir[fi][k] == 0:
+                    D = sp.coo_matrix((np.ones(sizes[s]), (a, a // ncol)), shape=(sizes[s], nrow))
+                    self.cpdes_iga_dofs[fi][pos] = list(full[0:sizes[s]:ncol])
+                elif self.align_dir[fi][k] == 1:
+                    D = sp.coo_matrix((np.ones(sizes[s]), (a, a % ncol)), shape=(sizes[s], ncol))
+                    self.cpdes_iga_dofs[fi][pos] = list(full[0:ncol])
+                else:
+                    raise ValueError("Undefined direction: {}".format(self.align_dir[fi][k]))
+                self.shopt_num_desvars[fi] += D.shape[1] - sizes[s]
+                self.align_cp_deriv_list[fi][pos] = D.tocsr()
+        self.cpdes_iga_dofs = [np.concatenate(l).astype(int) for l in self.cpdes_iga_dofs]
+        init = self.get_init_CPIGA()
+        self.shopt_dcpaligndcpsurf = [sp.block_diag(blocks, format="coo") for blocks in self.align_cp_deriv_list]
+        self.init_cp_iga_design = [init[fi][self.cpdes_iga_dofs[fi]] for fi in range(len(self.opt_field))]
+        return self.shopt_dcpaligndcpsurf
+
+    def set_shopt_pin_CP(self, pin_surf_inds=[], pin_dir=[], pin_side=[], pin_dofs=None, pin_vals=None):
+        """nonmatching_opt.py:303-364: design control points on the edge ``pin_side`` of direction ``pin_dir`` of the listed
+        patches keep their initial values (linear equality constraint ``shopt_dcppindcpsurf``)."""
+        des = [np.asarray(d).ravel() if not isinstance(d, np.ndarray) else d
+               for d in (self.cpdes_iga_dofs if isinstance(self.cpdes_iga_dofs[0], np.ndarray) else [np.concatenate(l) for l in self.cpdes_iga_dofs])]
+        if pin_dofs is None:
+            assert len(pin_surf_inds) == len(self.opt_field) and len(pin_dir) == len(self.opt_field) and len(pin_side) == len(self.opt_field)
+            self.pin_surf_inds, self.pin_dir, self.pin_side = pin_surf_inds, pin_dir, pin_side
+            sizes = self.vec_scalar_iga_dof_list
+            for fi, field in enumerate(self.opt_field):
+                for k, s in enumerate(self.pin_surf_inds[fi]):
+                    if s not in self.shopt_surf_inds[fi]:
+                        raise ValueError(f"Pinned surface {s} is not optimized.")
+                    pos = self.shopt_surf_inds[fi].index(s)
+                    ncol, nrow = self.cp_shapes[s]
+                    full = self.cpdes_iga_dofs_full_list[fi][pos]
+                    d, side = self.pin_dir[fi][k], self.pin_side[fi][k]
+                    if d == 0:
+                        local = range(0, sizes[s], ncol) if side == 0 else range(ncol - 1, sizes[s], ncol)
+                    elif d == 1:
+                        local = range(0, ncol) if side == 0 else range(sizes[s] - ncol, sizes[s])
+                    else:
+                        raise ValueError("Undefined direction: {}".format(d))
+                    keep = set(int(x) for x in des[fi])
+                    self.shopt_pin_dofs[fi] += [full[i] for i in local if full[i] in keep]
+        else:
+            self.shopt_pin_dofs = pin_dofs
+        init = self.get_init_CPIGA()
+        self.shopt_pin_vals = [init[fi][self.shopt_pin_dofs[fi]] for fi in range(len(self.opt_field))] if pin_vals is None else pin_vals
+        self.shopt_dcppindcpsurf = []
+        for fi in range(len(self.opt_field)):
+            pos = {int(d): c for c, d in enumerate(des[fi])}
+            cols = [pos[int(d)] for d in self.shopt_pin_dofs[fi]]
+            self.shopt_dcppindcpsurf.append(sp.coo_matrix((np.ones(len(cols)), (np.arange(len(cols)), cols)), shape=(len(cols), des[fi].size)))
+        return self.shopt_dcppindcpsurf
+
+    # FE <-> IGA: the reference keeps every field twice (FE dofs of the extraction mesh and IGA dofs); here the IGA
+    # control variables are the only representation, so the FE-side entry points are the IGA ones
+    def vec_IGA2FE(self, v_iga, v_fe=None, s_ind=None):
+        """nonmatching_opt.py:433-441."""
+        return np.asarray(v_iga, float)
+
+    def vec_scalar_IGA2FE(self, v_iga, v_fe=None, s_ind=None):
+        """nonmatching_opt.py:443-451."""
+        return np.asarray(v_iga, float)
+
+    def update_CPFE(self, cp_array_fe, field):
+        """nonmatching_opt.py:486-493."""
+        self.update_CPIGA(cp_array_fe, field)
+
+    def update_h_th_FE(self, h_th_array):
+        """nonmatching_opt.py:508-514."""
+        self.update_h_th_IGA(h_th_array)
 
     def set_init_CPIGA(self, cp_iga):
         self.init_cp_iga = cp_iga

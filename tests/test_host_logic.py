@@ -496,3 +496,31 @@ def test_cpiga2xi_edge_intersection_and_edge_component():
     prob.run_model()
     assert np.abs(prob["int_xi_edge"]).max() < 1e-14
     assert max(prob.check_partials(compact_print=False).values()) < 1e-8
+
+
+def test_shape_design_on_surface_control_points():
+    """set_shopt_align_CP / set_shopt_pin_CP (nonmatching_opt.py:232-364): design dofs, replication map and pin selection
+    for shape optimisation directly on the control nets (the moving-intersection demos)."""
+    from goldfish_amd.nonmatching_opt import NonMatchingOpt
+    spec = G.tbeam_2patch(4)
+    nm = NonMatchingOpt.from_spec(spec)
+    nm.set_shopt_surf_inds([0, 2], [[0, 1], [1]])
+    n0, n1 = spec.patches[0].ncp, spec.patches[1].ncp
+    (c0, r0), (c1, r1) = nm.cp_shapes
+    D = nm.set_shopt_align_CP(align_surf_inds=[[1], [1]], align_dir=[[0], [1]])
+    assert D[0].shape == (n0 + n1, n0 + r1) and D[1].shape == (n1, c1)
+    assert nm.shopt_num_desvars == [n0 + r1, c1]
+    init = nm.get_init_CPIGA()
+    # replicating the design values reproduces a net that is constant along the aligned direction
+    full0 = D[0] @ nm.init_cp_iga_design[0]
+    web = full0[n0:].reshape(r1, c1)
+    assert np.all(web == web[:, :1]) and np.array_equal(full0[:n0], init[0][:n0])
+    full1 = (D[1] @ nm.init_cp_iga_design[1]).reshape(r1, c1)
+    assert np.all(full1 == full1[:1, :])
+    P = nm.set_shopt_pin_CP(pin_surf_inds=[[0], [1]], pin_dir=[[1], [0]], pin_side=[[0], [1]])
+    assert P[0].shape == (c0, n0 + r1) and np.array_equal(nm.shopt_pin_dofs[0], np.arange(c0))
+    # field 2: only the design dofs (first row of the web) that lie on the u = 1 edge are pinned -> the last one
+    assert nm.shopt_pin_dofs[1] == [c1 - 1] and P[1].shape == (1, c1)
+    assert np.array_equal(P[0] @ nm.init_cp_iga_design[0], nm.shopt_pin_vals[0])
+    with pytest.raises(ValueError):
+        nm.set_shopt_align_CP(align_surf_inds=[[1], [0]], align_dir=[[0], [1]])
