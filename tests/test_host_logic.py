@@ -524,3 +524,34 @@ def test_shape_design_on_surface_control_points():
     assert np.array_equal(P[0] @ nm.init_cp_iga_design[0], nm.shopt_pin_vals[0])
     with pytest.raises(ValueError):
         nm.set_shopt_align_CP(align_surf_inds=[[1], [0]], align_dir=[[0], [1]])
+
+
+def test_reference_module_paths_and_identity_projections():
+    """The reference's module layout resolves (GOLDFISH/nonmatching_opt_om.py aggregator, nonmatching_opt_ffd.py, one module
+    per component / operation), and the FE->IGA projection operations are the identity with unit Jacobians here."""
+    import importlib
+    for name in ("nonmatching_opt_om", "nonmatching_opt_ffd", "cpiga2xi", "om_comps.cpfe2iga_comp", "om_comps.hthfe2iga_comp",
+                 "om_comps.cpiga2xi_comp", "om_comps.int_xi_edge_comp", "om_comps.disp_states_mi_comp", "om_comps.max_vmstress_comp",
+                 "om_comps.ffd_comps.hth_map_comp", "om_comps.ffd_comps.hthffd2fe_comp", "om_comps.ffd_comps.hthffd_align_comp",
+                 "om_comps.ffd_comps.hthffd_regu_comp", "operations.cpfe2iga_imop", "operations.hthfe2iga_imop", "operations.custom_exop",
+                 "operations.cpiga2xi_imop", "operations.disp_mi_imop", "operations.max_vmstress_exop"):
+        importlib.import_module("goldfish_amd." + name)
+    ns = {}
+    exec("from goldfish_amd.nonmatching_opt_om import *", ns)
+    for cls in ("NonMatchingOptFFD", "DispStatesComp", "DispMintStatesComp", "CPIGA2XiComp", "IntXiEdgeComp", "MaxvMStressComp",
+                "CPFFD2SurfComp", "HthMapComp", "create_3D_block", "CP_FFD_matrix"):
+        assert cls in ns, cls
+    from types import SimpleNamespace
+    from goldfish_amd.operations.cpfe2iga_imop import CPFE2IGAImOperation
+    from goldfish_amd.operations.custom_exop import CustomExOperation
+    nm = SimpleNamespace(opt_field=[0], opt_shape=True, num_splines=1)
+    op = CPFE2IGAImOperation(nm)
+    x = np.arange(4.0)
+    assert np.array_equal(op.solve_nonlinear(x), x) and np.abs(op.apply_nonlinear(x, op.solve_nonlinear(x))).max() == 0
+    r = np.zeros(4)
+    op.apply_linear_fwd(2 * x, 3 * x, r)
+    assert np.array_equal(r, x)
+    c = CustomExOperation(nm, lambda p: 3.0, lambda p: np.ones(2))
+    assert c.func() == 3.0 and np.array_equal(c.func_deriv(), np.ones(2))
+    with pytest.raises(TypeError):
+        CustomExOperation(nm, "ufl form", "ufl form")
