@@ -63,3 +63,35 @@ def CP_FFD_matrix(CP_S, p_V, knots_V, coo=True):
                         vals.append(v)
     M = coo_matrix((vals, (rows, cols)), shape=(CP_S.shape[0], n[0] * n[1] * n[2]))
     return M if coo else M.toarray()
+
+
+def scale_knots(knots, CP):
+    """ffd_utils.py:10-33: knot vectors on [0, 1] stretched to the limits of the control points, one per coordinate."""
+    nf = len(knots)
+    flat = np.asarray(CP, float).reshape(-1, np.asarray(CP).shape[-1])[:, :nf]
+    return [np.asarray(knots[f], float) * (flat[:, f].max() - flat[:, f].min()) + flat[:, f].min() for f in range(nf)]
+
+
+def rationalized_control(nurbs):
+    """ffd_utils.py:126-151: physical control points of an object with homogeneous ``control`` (..., 4)."""
+    c = np.asarray(nurbs.control, float)
+    return c[..., 0:3] / c[..., -1:]
+
+
+def refine_knot(knot, ref_level=1):
+    """ffd_utils.py:154-161: every knot interval (empty ones included, as there) gets its midpoint, ``ref_level`` times."""
+    k = np.asarray(knot, float).copy()
+    for _ in range(ref_level):
+        k = np.sort(np.concatenate([k, 0.5 * (k[:-1] + k[1:])]))
+    return k
+
+
+def update_FFD_block(FFD_block, new_cps, opt_field):
+    """ffd_utils.py:348-358: block with the coordinates ``opt_field`` of its control points replaced by ``new_cps``
+    (flat order i + j*l + k*l*m)."""
+    ctrl = np.asarray(FFD_block.control, float).copy()
+    flat = ctrl[..., 0:3].transpose(2, 1, 0, 3).reshape(-1, 3).copy()
+    for i, field in enumerate(opt_field):
+        flat[:, field] = np.asarray(new_cps[i], float)
+    ctrl[..., 0:3] = flat.reshape(ctrl[..., 0:3].transpose(2, 1, 0, 3).shape).transpose(2, 1, 0, 3)
+    return FFDBlock(FFD_block.knots, ctrl, FFD_block.degree)

@@ -555,3 +555,23 @@ def test_reference_module_paths_and_identity_projections():
     assert c.func() == 3.0 and np.array_equal(c.func_deriv(), np.ones(2))
     with pytest.raises(TypeError):
         CustomExOperation(nm, "ufl form", "ufl form")
+
+
+def test_small_utils_with_reference_names():
+    """utils/ffd_utils.py (scale_knots, rationalized_control, refine_knot, update_FFD_block :10-33,126-161,348-358) and
+    utils/opt_utils.py (solve_Ax_b / solve_ATx_b :156-209) counterparts."""
+    import scipy.sparse as sps
+    from goldfish_amd.utils.ffd_utils import create_3D_block, rationalized_control, refine_knot, scale_knots, update_FFD_block
+    from goldfish_amd.utils.opt_utils import solve_ATx_b, solve_Ax_b
+    blk = create_3D_block([2, 1, 1], 2, [[0, 2], [0, 1], [0, 3]])
+    k = scale_knots([np.array([0, 0, .5, 1, 1.]), np.array([0, 1.]), np.array([0, 1.])], blk.control)
+    assert np.allclose(k[0], [0, 0, 1, 2, 2]) and np.allclose(k[2], [0, 3])
+    assert np.allclose(rationalized_control(blk), blk.control[..., :3])
+    assert np.allclose(refine_knot(np.array([0, 0, 1, 1.]), 1), [0, 0, 0, .5, 1, 1, 1])
+    n = int(np.prod(blk.shape))
+    b2 = update_FFD_block(blk, [np.arange(n, dtype=float)], [2])
+    assert np.allclose(b2.control[..., :3].transpose(2, 1, 0, 3).reshape(-1, 3)[:, 2], np.arange(n))
+    assert np.allclose(b2.control[..., 0], blk.control[..., 0])
+    A = sps.csr_matrix(np.array([[4, 1, 0], [2, 3, 0], [0, 1, 5.]]))
+    b = np.array([1, 2, 3.])
+    assert np.allclose(A @ solve_Ax_b(A, b), b) and np.allclose(A.T @ solve_ATx_b(A, b), b)
