@@ -536,196 +536,146 @@ __global__ __launch_bounds__(256) void kl_rgather_kernel(DevModel M, long long a
 
 // ------------------------------------------------------------------------------------- functionals
 // K10 of SURVEY.md 2.2: strain energy W = sum int Psi, volume V = sum int t dA and their gradients.
-// One wave per element; per-element gradients go to a block [NB][11] (+ We, Ve), summed per control
-// point by kl_fgather_kernel in fixed element order.
+// One wave works on NE = 64 / (p+1)^2 elements at once (4 for p = 3): phase A one lane per (element, Gauss point) --
+// sum-factorised kinematics and the pointwise function --, phase B one lane per (element, control point, component)
+// contraction with the basis.  Per-element gradients go to a block [NB][11] (+ We, Ve), summed per control point by
+// kl_fgather_kernel in fixed element order.
+//   KIND 0  strain energy and volume (IntEnergyExOperation / VolumeExOperation): slots 0-2 dW/du, 3-5 the reference part
+//           of dW/dc, 6-8 dV/dc, 9 dW/dh, 10 dV/dh; We = W_e, Ve = V_e
+//   KIND 1  stress aggregation forms (MaxvMStressExOperation, operations/max_vmstress_exop.py:167-186): per element
+//           sum_gp wq J g(sigma_vM), g = exp(rho (sigma - m_s)) [mode 0] or (sigma / m_s)^rho [mode 1], sigma_vM at the
+//           station xi3 = sgn t/2 (shell_stress_point): slots 0-2 dI/du, 3-5 reference part of dI/dc, 9 dI/dh (6-8, 10
+//           zero); We = I_e, Ve = max_gp sigma_vM
 template <int P> struct FunCfg { static constexpr int NB = (P + 1) * (P + 1), STRIDE = NB * 11 + 2; };
+struct StressCfg { int mode, measure; double rho, sgn; const double* m_list; };
 
-template <int P>
-__global__ __launch_bounds__(64) void kl_functional_kernel(DevModel M, int e_first, double* __restrict__ blk, size_t blk_stride) {
-    constexpr int P1 = P + 1, NB = P1 * P1, NG = NB, ND = 3 * NB;
+template <int P, int KIND>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void kl_pointfun_kernel(DevModel M, int e_first, int e_count, StressCfg S,
+                                                                                                 double* __restrict__ blk, size_t blk_stride) {
+    constexpr int P1 = P + 1, NB = P1 * P1, NG = NB, ND = 3 * NB, NE = 64 / NG, TS = P1 * 3 * P1;
     const int tid = threadIdx.x;
-    const long long e = (long long)e_first + blockIdx.x;
-    if (e >= M.nelem) return;
-    const PatchDev& Pt = M.patches[M.elem_patch[e]];
-    const int le = int(e - Pt.elem_off), eu = le % Pt.nelu, ev = le / Pt.nelu;
-    const int iu0 = M.ints[Pt.spu + eu] - P, iv0 = M.ints[Pt.spv + ev] - P;
-    __shared__ double s_c[NB][3], s_d[NB][3], s_h[NB], s_w[NB];
-    __shared__ double s_tu[P1 * 3 * P1], s_tv[P1 * 3 * P1], s_wg[2 * P1];
-    __shared__ double s_fe[NG][FE_SIZE + 8];            // + W[6], wq, t
-    if (tid < NB) {
-        const long long g = Pt.cp_off + (iu0 + tid % P1) + (long long)(iv0 + tid / P1) * Pt.nu;
+    const long long eb = (long long)blockIdx.x * NE;                   // first element of this wave (local to the chunk)
+    __shared__ double s_c[NE][NB][3], s_d[NE][NB][3], s_h[NE][NB], s_w[NE][NB];
+    __shared__ double s_tu[NE][TS], s_tv[NE][TS], s_wg[NE][2 * P1];
+    __shared__ double s_fe[NE][NG][FE_SIZE + 8];                       // + W[6], wq, t (KIND 0) / sigma (KIND 1)
+    for (int k = tid; k < NE * NB; k += 64) {
+        const int el = k / NB, a = k - el * NB;
+        if (eb + el >= e_count) continue;
+        const ElemDesc& ed = M.edesc[e_first + eb + el];
+        const long long g = ed.g0 + (a % P1) + (long long)(a / P1) * ed.nu;
         const double4 c4 = reinterpret_cast<const double4*>(M.cp4)[g];
-        s_c[tid][0] = c4.x; s_c[tid][1] = c4.y; s_c[tid][2] = c4.z; s_w[tid] = c4.w;
-        s_d[tid][0] = c4.x + M.u[3 * g]; s_d[tid][1] = c4.y + M.u[3 * g + 1]; s_d[tid][2] = c4.z + M.u[3 * g + 2];
-        s_h[tid] = M.h[g];
+        s_c[el][a][0] = c4.x; s_c[el][a][1] = c4.y; s_c[el][a][2] = c4.z; s_w[el][a] = c4.w;
+        s_d[el][a][0] = c4.x + M.u[3 * g]; s_d[el][a][1] = c4.y + M.u[3 * g + 1]; s_d[el][a][2] = c4.z + M.u[3 * g + 2];
+        s_h[el][a] = M.h[g];
     }
-    for (int k = tid; k < P1 * 3 * P1; k += 64) { s_tu[k] = M.tab[Pt.tabu + eu * P1 * 3 * P1 + k]; s_tv[k] = M.tab[Pt.tabv + ev * P1 * 3 * P1 + k]; }
-    if (tid < P1) { s_wg[tid] = M.tab[Pt.wu + eu * P1 + tid]; s_wg[P1 + tid] = M.tab[Pt.wv + ev * P1 + tid]; }
-    __syncthreads();
-    if (tid < NG) {
-        const int gu = tid % P1, gv = tid / P1;
-        // sum factorisation over the tensor-product basis + quotient rule (as in the MFMA element kernels)
-        double Ac[3][6], Ad[3][6], W[6], t = 0.0;
-        for (int k = 0; k < 6; ++k) { W[k] = 0.0; for (int i = 0; i < 3; ++i) { Ac[i][k] = 0.0; Ad[i][k] = 0.0; } }
-        double U[3][P1];
-        for (int d = 0; d < 3; ++d) for (int j = 0; j < P1; ++j) U[d][j] = s_tu[(gu * 3 + d) * P1 + j];
-#pragma unroll
-        for (int jv = 0; jv < P1; ++jv) {
-            const double v0 = s_tv[(gv * 3 + 0) * P1 + jv], v1 = s_tv[(gv * 3 + 1) * P1 + jv], v2 = s_tv[(gv * 3 + 2) * P1 + jv];
-            double S[7][3], Sh = 0.0;
-            for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) S[q][d] = 0.0;
-#pragma unroll
-            for (int ju = 0; ju < P1; ++ju) {
-                const int a = ju + P1 * jv;
-                const double qv[7] = {s_c[a][0], s_c[a][1], s_c[a][2], s_d[a][0], s_d[a][1], s_d[a][2], s_w[a]};
-                for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) S[q][d] += U[d][ju] * qv[q];
-                Sh += U[0][ju] * s_h[a];
-            }
-            t += v0 * Sh;
-#pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                double* A = q < 3 ? Ac[q] : (q < 6 ? Ad[q - 3] : W);
-                A[0] += v0 * S[q][0]; A[1] += v0 * S[q][1]; A[2] += v1 * S[q][0];
-                A[3] += v0 * S[q][2]; A[4] += v2 * S[q][0]; A[5] += v1 * S[q][1];
-            }
-        }
-        W[0] = 1.0 / W[0];
-        double z[15], Z[15], R[6];
-        for (int i = 0; i < 3; ++i) {
-            rationalize6(Ac[i], W, R);
-            for (int m = 0; m < 5; ++m) Z[3 * m + i] = R[m + 1];
-            rationalize6(Ad[i], W, R);
-            for (int m = 0; m < 5; ++m) z[3 * m + i] = R[m + 1];
-        }
-        shell_energy_point(z, Z, t, Pt.E, Pt.nu_, s_fe[tid]);
-        for (int k = 0; k < 6; ++k) s_fe[tid][FE_SIZE + k] = W[k];
-        s_fe[tid][FE_SIZE + 6] = s_wg[gu] * s_wg[P1 + gv]; s_fe[tid][FE_SIZE + 7] = t;
+    for (int k = tid; k < NE * TS; k += 64) {
+        const int el = k / TS, j = k - el * TS;
+        if (eb + el >= e_count) continue;
+        const ElemDesc& ed = M.edesc[e_first + eb + el];
+        s_tu[el][j] = M.tab[ed.tabu + j]; s_tv[el][j] = M.tab[ed.tabv + j];
+    }
+    for (int k = tid; k < NE * 2 * P1; k += 64) {
+        const int el = k / (2 * P1), j = k - el * 2 * P1;
+        if (eb + el >= e_count) continue;
+        const ElemDesc& ed = M.edesc[e_first + eb + el];
+        s_wg[el][j] = j < P1 ? M.tab[ed.wu + j] : M.tab[ed.wv + j - P1];
     }
     __syncthreads();
-    double* out = blk + (size_t)blockIdx.x * blk_stride;
-    for (int w = tid; w < ND; w += 64) {
-        const int a = w / 3, i = w - 3 * a;
+    {
+        const int el = tid / NG, gpi = tid - el * NG;
+        if (el < NE && eb + el < e_count) {
+            const int pid = M.edesc[e_first + eb + el].patch;
+            const PatchDev& Pt = M.patches[pid];
+            const int gu = gpi % P1, gv = gpi / P1;
+            // sum factorisation over the tensor-product basis + quotient rule (as in the MFMA element kernels)
+            double Ac[3][6], Ad[3][6], W[6], t = 0.0;
+            for (int k = 0; k < 6; ++k) { W[k] = 0.0; for (int i = 0; i < 3; ++i) { Ac[i][k] = 0.0; Ad[i][k] = 0.0; } }
+            double U[3][P1];
+            for (int d = 0; d < 3; ++d) for (int j = 0; j < P1; ++j) U[d][j] = s_tu[el][(gu * 3 + d) * P1 + j];
+#pragma unroll
+            for (int jv = 0; jv < P1; ++jv) {
+                const double v0 = s_tv[el][(gv * 3 + 0) * P1 + jv], v1 = s_tv[el][(gv * 3 + 1) * P1 + jv], v2 = s_tv[el][(gv * 3 + 2) * P1 + jv];
+                double Sm[7][3], Sh = 0.0;
+                for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) Sm[q][d] = 0.0;
+#pragma unroll
+                for (int ju = 0; ju < P1; ++ju) {
+                    const int a = ju + P1 * jv;
+                    const double qv[7] = {s_c[el][a][0], s_c[el][a][1], s_c[el][a][2], s_d[el][a][0], s_d[el][a][1], s_d[el][a][2], s_w[el][a]};
+                    for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) Sm[q][d] += U[d][ju] * qv[q];
+                    Sh += U[0][ju] * s_h[el][a];
+                }
+                t += v0 * Sh;
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    double* A = q < 3 ? Ac[q] : (q < 6 ? Ad[q - 3] : W);
+                    A[0] += v0 * Sm[q][0]; A[1] += v0 * Sm[q][1]; A[2] += v1 * Sm[q][0];
+                    A[3] += v0 * Sm[q][2]; A[4] += v2 * Sm[q][0]; A[5] += v1 * Sm[q][1];
+                }
+            }
+            W[0] = 1.0 / W[0];
+            double z[15], Z[15], R[6];
+            for (int i = 0; i < 3; ++i) {
+                rationalize6(Ac[i], W, R);
+                for (int m = 0; m < 5; ++m) Z[3 * m + i] = R[m + 1];
+                rationalize6(Ad[i], W, R);
+                for (int m = 0; m < 5; ++m) z[3 * m + i] = R[m + 1];
+            }
+            double* fe = s_fe[el][gpi];
+            if constexpr (KIND == 0) {
+                shell_energy_point(z, Z, t, Pt.E, Pt.nu_, fe);
+                fe[FE_SIZE + 7] = t;
+            } else {
+                shell_stress_point(z, Z, t, Pt.E, Pt.nu_, S.sgn, S.measure, fe);
+                const double sig = fe[0], J = fe[1], ms = S.m_list[pid];
+                double g, gp;                                           // g(sigma), g'(sigma)
+                if (S.mode == 0) { g = exp(S.rho * (sig - ms)); gp = S.rho * g; }
+                else { const double r = sig / ms; gp = sig > 0.0 ? S.rho * pow(r, S.rho - 1.0) / ms : 0.0; g = sig > 0.0 ? pow(r, S.rho) : 0.0; }
+                const double Jgp = J * gp;
+                fe[FE_PSI] = J * g; fe[FE_PT] *= Jgp;
+                for (int c = 0; c < 15; ++c) { fe[FE_PZ + c] *= Jgp; fe[FE_PZR + c] = Jgp * fe[FE_PZR + c] + (c < 6 ? g * fe[FE_JZ + c] : 0.0); }
+                fe[FE_SIZE + 7] = sig;
+            }
+            for (int k = 0; k < 6; ++k) fe[FE_SIZE + k] = W[k];
+            fe[FE_SIZE + 6] = s_wg[el][gu] * s_wg[el][P1 + gv];
+        }
+    }
+    __syncthreads();
+    for (int w = tid; w < NE * ND; w += 64) {
+        const int el = w / ND, r = w - el * ND;
+        if (eb + el >= e_count) continue;
+        const int a = r / 3, i = r - 3 * a;
         double du = 0.0, dc = 0.0, dv = 0.0, dwh = 0.0, dvh = 0.0;
         for (int gp = 0; gp < NG; ++gp) {
-            const double* fe = s_fe[gp]; const double wq = fe[FE_SIZE + 6];
+            const double* fe = s_fe[el][gp]; const double wq = fe[FE_SIZE + 6];
             double Nb[6], R[6];
-            bspline6<P>(s_tu, s_tv, gp % P1, gp / P1, a, Nb); rationalize6(Nb, fe + FE_SIZE, R);
-            double pz = 0.0, pZ = 0.0;
-            for (int m = 0; m < 5; ++m) { pz += R[m + 1] * fe[FE_PZ + 3 * m + i]; pZ += R[m + 1] * fe[FE_PZR + 3 * m + i]; }
-            du += wq * pz; dc += wq * pZ;
-            dv += wq * fe[FE_SIZE + 7] * (R[1] * fe[FE_JZ + i] + R[2] * fe[FE_JZ + 3 + i]);
-            dwh += wq * Nb[0] * fe[FE_PT]; dvh += wq * Nb[0] * fe[FE_J];
-        }
-        out[a * 11 + i] = du; out[a * 11 + 3 + i] = dc; out[a * 11 + 6 + i] = dv;
-        if (i == 0) { out[a * 11 + 9] = dwh; out[a * 11 + 10] = dvh; }
-    }
-    if (tid == 0) {
-        double We = 0.0, Ve = 0.0;
-        for (int gp = 0; gp < NG; ++gp) { const double wq = s_fe[gp][FE_SIZE + 6]; We += wq * s_fe[gp][FE_PSI]; Ve += wq * s_fe[gp][FE_SIZE + 7] * s_fe[gp][FE_J]; }
-        out[NB * 11] = We; out[NB * 11 + 1] = Ve;
-    }
-}
-
-// Stress aggregation forms (MaxvMStressExOperation, operations/max_vmstress_exop.py:167-186): per element
-// sum_gp wq J g(sigma_vM), g = exp(rho (sigma - m_s)) [mode 0] or (sigma / m_s)^rho [mode 1], sigma_vM at the station
-// xi3 = sgn t/2 (shell_stress_point).  Same block layout and contraction as kl_functional_kernel: slots 0-2 dI/du,
-// 3-5 the reference-configuration part of dI/dc, 9 dI/dh (6-8, 10 zero); We = I_e, Ve = max_gp sigma_vM.
-struct StressCfg { int mode, measure; double rho, sgn; const double* m_list; };
-template <int P>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void kl_stress_kernel(DevModel M, int e_first, StressCfg S, double* __restrict__ blk, size_t blk_stride) {
-    constexpr int P1 = P + 1, NB = P1 * P1, NG = NB, ND = 3 * NB;
-    const int tid = threadIdx.x;
-    const long long e = (long long)e_first + blockIdx.x;
-    if (e >= M.nelem) return;
-    const int pid = M.elem_patch[e];
-    const PatchDev& Pt = M.patches[pid];
-    const int le = int(e - Pt.elem_off), eu = le % Pt.nelu, ev = le / Pt.nelu;
-    const int iu0 = M.ints[Pt.spu + eu] - P, iv0 = M.ints[Pt.spv + ev] - P;
-    __shared__ double s_c[NB][3], s_d[NB][3], s_h[NB], s_w[NB];
-    __shared__ double s_tu[P1 * 3 * P1], s_tv[P1 * 3 * P1], s_wg[2 * P1];
-    __shared__ double s_fe[NG][FE_SIZE + 8];            // + W[6], wq, sigma
-    if (tid < NB) {
-        const long long g = Pt.cp_off + (iu0 + tid % P1) + (long long)(iv0 + tid / P1) * Pt.nu;
-        const double4 c4 = reinterpret_cast<const double4*>(M.cp4)[g];
-        s_c[tid][0] = c4.x; s_c[tid][1] = c4.y; s_c[tid][2] = c4.z; s_w[tid] = c4.w;
-        s_d[tid][0] = c4.x + M.u[3 * g]; s_d[tid][1] = c4.y + M.u[3 * g + 1]; s_d[tid][2] = c4.z + M.u[3 * g + 2];
-        s_h[tid] = M.h[g];
-    }
-    for (int k = tid; k < P1 * 3 * P1; k += 64) { s_tu[k] = M.tab[Pt.tabu + eu * P1 * 3 * P1 + k]; s_tv[k] = M.tab[Pt.tabv + ev * P1 * 3 * P1 + k]; }
-    if (tid < P1) { s_wg[tid] = M.tab[Pt.wu + eu * P1 + tid]; s_wg[P1 + tid] = M.tab[Pt.wv + ev * P1 + tid]; }
-    __syncthreads();
-    if (tid < NG) {
-        const int gu = tid % P1, gv = tid / P1;
-        double Ac[3][6], Ad[3][6], W[6], t = 0.0;
-        for (int k = 0; k < 6; ++k) { W[k] = 0.0; for (int i = 0; i < 3; ++i) { Ac[i][k] = 0.0; Ad[i][k] = 0.0; } }
-        double U[3][P1];
-        for (int d = 0; d < 3; ++d) for (int j = 0; j < P1; ++j) U[d][j] = s_tu[(gu * 3 + d) * P1 + j];
-#pragma unroll
-        for (int jv = 0; jv < P1; ++jv) {
-            const double v0 = s_tv[(gv * 3 + 0) * P1 + jv], v1 = s_tv[(gv * 3 + 1) * P1 + jv], v2 = s_tv[(gv * 3 + 2) * P1 + jv];
-            double Sm[7][3], Sh = 0.0;
-            for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) Sm[q][d] = 0.0;
-#pragma unroll
-            for (int ju = 0; ju < P1; ++ju) {
-                const int a = ju + P1 * jv;
-                const double qv[7] = {s_c[a][0], s_c[a][1], s_c[a][2], s_d[a][0], s_d[a][1], s_d[a][2], s_w[a]};
-                for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) Sm[q][d] += U[d][ju] * qv[q];
-                Sh += U[0][ju] * s_h[a];
-            }
-            t += v0 * Sh;
-#pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                double* A = q < 3 ? Ac[q] : (q < 6 ? Ad[q - 3] : W);
-                A[0] += v0 * Sm[q][0]; A[1] += v0 * Sm[q][1]; A[2] += v1 * Sm[q][0];
-                A[3] += v0 * Sm[q][2]; A[4] += v2 * Sm[q][0]; A[5] += v1 * Sm[q][1];
-            }
-        }
-        W[0] = 1.0 / W[0];
-        double z[15], Z[15], R[6];
-        for (int i = 0; i < 3; ++i) {
-            rationalize6(Ac[i], W, R);
-            for (int m = 0; m < 5; ++m) Z[3 * m + i] = R[m + 1];
-            rationalize6(Ad[i], W, R);
-            for (int m = 0; m < 5; ++m) z[3 * m + i] = R[m + 1];
-        }
-        double* fe = s_fe[tid];
-        shell_stress_point(z, Z, t, Pt.E, Pt.nu_, S.sgn, S.measure, fe);
-        const double sig = fe[0], J = fe[1], ms = S.m_list[pid];
-        double g, gp;                                       // g(sigma), g'(sigma)
-        if (S.mode == 0) { g = exp(S.rho * (sig - ms)); gp = S.rho * g; }
-        else { const double r = sig / ms; gp = sig > 0.0 ? S.rho * pow(r, S.rho - 1.0) / ms : 0.0; g = sig > 0.0 ? pow(r, S.rho) : 0.0; }
-        const double Jgp = J * gp;
-        fe[FE_PSI] = J * g; fe[FE_PT] *= Jgp;
-        for (int c = 0; c < 15; ++c) { fe[FE_PZ + c] *= Jgp; fe[FE_PZR + c] = Jgp * fe[FE_PZR + c] + (c < 6 ? g * fe[FE_JZ + c] : 0.0); }
-        for (int k = 0; k < 6; ++k) fe[FE_SIZE + k] = W[k];
-        fe[FE_SIZE + 6] = s_wg[gu] * s_wg[P1 + gv]; fe[FE_SIZE + 7] = sig;
-    }
-    __syncthreads();
-    double* out = blk + (size_t)blockIdx.x * blk_stride;
-    for (int w = tid; w < ND; w += 64) {
-        const int a = w / 3, i = w - 3 * a;
-        double du = 0.0, dc = 0.0, dwh = 0.0;
-        for (int gp = 0; gp < NG; ++gp) {
-            const double* fe = s_fe[gp]; const double wq = fe[FE_SIZE + 6];
-            double Nb[6], R[6];
-            bspline6<P>(s_tu, s_tv, gp % P1, gp / P1, a, Nb); rationalize6(Nb, fe + FE_SIZE, R);
+            bspline6<P>(s_tu[el], s_tv[el], gp % P1, gp / P1, a, Nb); rationalize6(Nb, fe + FE_SIZE, R);
             double pz = 0.0, pZ = 0.0;
             for (int m = 0; m < 5; ++m) { pz += R[m + 1] * fe[FE_PZ + 3 * m + i]; pZ += R[m + 1] * fe[FE_PZR + 3 * m + i]; }
             du += wq * pz; dc += wq * pZ;
             dwh += wq * Nb[0] * fe[FE_PT];
+            if constexpr (KIND == 0) {
+                dv += wq * fe[FE_SIZE + 7] * (R[1] * fe[FE_JZ + i] + R[2] * fe[FE_JZ + 3 + i]);
+                dvh += wq * Nb[0] * fe[FE_J];
+            }
         }
-        out[a * 11 + i] = du; out[a * 11 + 3 + i] = dc; out[a * 11 + 6 + i] = 0.0;
-        if (i == 0) { out[a * 11 + 9] = dwh; out[a * 11 + 10] = 0.0; }
+        double* out = blk + (size_t)(eb + el) * blk_stride;
+        out[a * 11 + i] = du; out[a * 11 + 3 + i] = dc; out[a * 11 + 6 + i] = dv;
+        if (i == 0) { out[a * 11 + 9] = dwh; out[a * 11 + 10] = dvh; }
     }
-    if (tid == 0) {
-        double Ie = 0.0, smax = 0.0;
-        for (int gp = 0; gp < NG; ++gp) { Ie += s_fe[gp][FE_SIZE + 6] * s_fe[gp][FE_PSI]; smax = fmax(smax, s_fe[gp][FE_SIZE + 7]); }
-        out[NB * 11] = Ie; out[NB * 11 + 1] = smax;
+    if (tid < NE && eb + tid < e_count) {
+        double We = 0.0, Ve = 0.0;
+        for (int gp = 0; gp < NG; ++gp) {
+            const double* fe = s_fe[tid][gp]; const double wq = fe[FE_SIZE + 6];
+            We += wq * fe[FE_PSI];
+            if constexpr (KIND == 0) Ve += wq * fe[FE_SIZE + 7] * fe[FE_J]; else Ve = fmax(Ve, fe[FE_SIZE + 7]);
+        }
+        double* out = blk + (size_t)(eb + tid) * blk_stride;
+        out[NB * 11] = We; out[NB * 11 + 1] = Ve;
     }
 }
 
 // Compliance C = sum int f . u_hom dA (homogeneous displacement function, compliance_exop.py:24-26) and its
-// gradients; same block layout as kl_functional_kernel: slots 0-2 dC/du, 6-8 dC/dc, We = C_e (3-5, 9, 10 zero).
+// gradients; same block layout as kl_pointfun_kernel: slots 0-2 dC/du, 6-8 dC/dc, We = C_e (3-5, 9, 10 zero).
 template <int P>
 __global__ __launch_bounds__(64) void kl_compliance_kernel(DevModel M, int e_first, const double* __restrict__ forces, double* __restrict__ blk, size_t blk_stride) {
     constexpr int P1 = P + 1, NB = P1 * P1, NG = NB, ND = 3 * NB;

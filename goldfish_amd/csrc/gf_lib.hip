@@ -275,7 +275,8 @@ template <int P> static void run_functionals(gf_handle* h, int apply_bcs) {
     const size_t stride = (size_t)FunCfg<P>::STRIDE;
     for (const Chunk& c : h->chunks) {
         const long long ne = c.e1 - c.e0, na = c.a1 - c.a0, nthr = std::max(ne, na);
-        hipLaunchKernelGGL(kl_functional_kernel<P>, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, h->d_blk, stride);
+        constexpr int NE = 64 / ((P + 1) * (P + 1));                     // elements per wave
+        hipLaunchKernelGGL((kl_pointfun_kernel<P, 0>), dim3((unsigned)((ne + NE - 1) / NE)), dim3(64), 0, h->stream, h->M, (int)c.e0, (int)ne, StressCfg{}, h->d_blk, stride);
         hipLaunchKernelGGL(kl_fgather_kernel<P>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, apply_bcs,
                            h->d_blk, stride, h->d_fun, h->d_x, h->d_y);
     }
@@ -304,7 +305,8 @@ template <int P> static void run_stress(gf_handle* h, const StressCfg& S, int ap
     const size_t stride = (size_t)FunCfg<P>::STRIDE;
     for (const Chunk& c : h->chunks) {
         const long long ne = c.e1 - c.e0, na = c.a1 - c.a0, nthr = std::max(ne, na);
-        hipLaunchKernelGGL(kl_stress_kernel<P>, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, S, h->d_blk, stride);
+        constexpr int NE = 64 / ((P + 1) * (P + 1));
+        hipLaunchKernelGGL((kl_pointfun_kernel<P, 1>), dim3((unsigned)((ne + NE - 1) / NE)), dim3(64), 0, h->stream, h->M, (int)c.e0, (int)ne, S, h->d_blk, stride);
         hipLaunchKernelGGL(kl_fgather_kernel<P>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, apply_bcs,
                            h->d_blk, stride, h->d_fun, h->d_x, h->d_ve);
     }

@@ -5,7 +5,7 @@ and method names).
 Per patch s the reference assembles the form  I_s = int g(sigma_vM) dA  (KS_symexp :167, pnorm_symexp :170,
 induced_power :173), turns it into a local maximum (continuous_*_function :188-219) and aggregates the local
 maxima with the discrete version of the same function (discrete_*_function :233-265).  Here one device pass
-(gf_stress_forms -> kl_stress_kernel) returns all I_s, the largest Gauss-point stress of every patch and the
+(gf_stress_forms -> kl_pointfun_kernel<P, 1>) returns all I_s, the largest Gauss-point stress of every patch and the
 gradient fields of the forms; the chain rule through the two aggregation levels (:330-440) is host arithmetic
 on n_patches numbers.
 
