@@ -113,6 +113,34 @@ def scordelis_lo_9patch(num_el=6, p=3, nels=None):
     return ProblemSpec(patches, itfs, 4.32e8, 0.0, 0.25, [[0.0, -90.0, 0.0]] * 9, [], 1.0e3, "slr_9patch")
 
 
+def edge_traction_point_loads(patches, s, direction, side, force, ngauss=None):
+    """Dead edge traction ``inner(force, rationalize(v)) * ds`` on the edge ``xi_direction = side`` of patch ``s``
+    (force per unit physical length) as consistent nodal forces: Gauss points along the edge, each a point load
+    (patch, xi, field, value) of ProblemSpec.point_loads with value = force_i |dX/dt| w_gp / W(xi) (the 1/W turns the
+    non-rational test function of a point load into the rational one).  Valid while the geometry is fixed (thickness
+    optimisation, analysis); a shape-dependent edge load is not on the device path."""
+    P = patches[s]
+    t_dir = 1 - direction                                   # the parameter that runs along the edge
+    kn = np.unique(P.knots[t_dir])
+    deg = (P.p, P.q)[t_dir]
+    ng = ngauss or deg + 1
+    gx, gw = np.polynomial.legendre.leggauss(ng)
+    fixed = P.knots[direction][0] if side == 0 else P.knots[direction][-1]
+    out = []
+    for a, b in zip(kn[:-1], kn[1:]):
+        for x, w in zip(gx, gw):
+            t = 0.5 * (a + b) + 0.5 * (b - a) * x
+            xi = [0.0, 0.0]
+            xi[direction], xi[t_dir] = fixed, t
+            X, Xu, Xv = P.eval_ders(xi)
+            jac = np.linalg.norm(Xv if t_dir == 1 else Xu)
+            W = P.eval_hom(xi, 0)[0, 0, 3]
+            for i in range(3):
+                if force[i] != 0.0:
+                    out.append((s, tuple(xi), i, float(force[i]) * jac * 0.5 * (b - a) * w / W))
+    return out
+
+
 def plate_6patch(p=3):
     """C1: the six-strip unit plate of demos_csdl_alpha/thickness_opt/geometry/plate_geometry.igs
     (control nets 7 x {11,12,13,12,11,10}: 4 x {8,9,10,9,8,7} cubic elements, strips of
@@ -131,11 +159,11 @@ def plate_6patch(p=3):
         s0.add_zero_dofs(f, s0.get_side_dofs(0, 0, 2))
     mn = [17, 19, 19, 17, 16]
     itfs = [Interface.from_endpoints(k, k + 1, [[1.0, 0.0], [1.0, 1.0]], [[0.0, 0.0], [0.0, 1.0]], mn[k]) for k in range(5)]
-    # the reference loads the xi_0 = 1 edge of the last patch with -100 (per unit length);
-    # here it is a body force on that patch scaled to the same resultant (edge tractions are
-    # not part of the device path yet, DESIGN.md "out of scope")
-    bf = [[0, 0, 0]] * 5 + [[0.0, 0.0, -100.0 * 6.0]]
-    return ProblemSpec(patches, itfs, 68e9, 0.35, 1.0e-2, bf, [], 1.0e3, "plate_6patch")
+    # the reference loads the xi_0 = 1 edge of the last patch with -100 per unit length (inner(f1 * bdry1, v) * ds,
+    # plate_const_th_opt_wint.py:235-250): a dead load on a fixed geometry, i.e. consistent nodal forces
+    bf = [[0.0, 0.0, 0.0]] * 6
+    pls = edge_traction_point_loads(patches, 5, 0, 1, (0.0, 0.0, -100.0))
+    return ProblemSpec(patches, itfs, 68e9, 0.35, 1.0e-2, bf, pls, 1.0e3, "plate_6patch")
 
 
 def wing_16patch_from_interface_data(int_data, nel=10, p=3, seed=SEED):
