@@ -510,6 +510,129 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
     if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * a + tid] = aR[tid] + (padd ? R[3 * a + tid] : 0.0);
 }
 
+// One-wave gather: ONE wave per control point takes the three dof rows itself (WITHC: 24 row loads in flight per group of
+// four elements, otherwise 12).  The four-wave gather above is bound by the latency chain of a workgroup rather than by
+// bandwidth when few bytes are asked for (Newton pass R + K: 5.7 ms for 42 % of the bytes of the full pass); with one wave
+// per control point 2-3x as many control points are resident per CU: R + K pass 19.7 -> 16.9 ms, dR/dh-only 10.5 -> 7.1,
+// dR/dCP-only 21.7 -> 19.1, full pass 26.4 -> 25.9 ms at C4.  Same fixed element order per accumulator slot: bitwise the
+// same sums as the four-wave kernel (which stays for GF_GATHER1=0 and the strip path).
+template <int P, bool WITHC>
+__global__ __launch_bounds__(64) void kl_gather1_kernel(DevModel M, long long a_first, long long e_first, long long e_count, int flags,
+                                                        const double* __restrict__ blk, double* __restrict__ valK, double* __restrict__ valC0,
+                                                        double* __restrict__ valC1, double* __restrict__ valC2, double* __restrict__ valH,
+                                                        double* __restrict__ R, int pen_add) {
+    using Cfg = ElemCfg<P>;
+    constexpr int P1 = Cfg::P1, NB = Cfg::NB, ND = Cfg::ND, WB = 2 * P + 1, NBOX = WB * WB;
+    const long long a = a_first + blockIdx.x;
+    if (a >= M.total_cp) return;
+    const CpDesc& cd = M.cpdesc[a];
+    const int ia = cd.ia, ja = cd.ja, i0 = cd.i0, j0 = cd.j0, wbox = cd.i1 - cd.i0 + 1;
+    const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c, ptr_s = M.nb_ptr_s[a], deg_s = M.nb_ptr_s[a + 1] - ptr_s;
+    const int lane = threadIdx.x;
+    __shared__ double aK[3][NBOX][3], aC[WITHC ? 3 : 1][3][NBOX], aH[3][NBOX], aR[3];
+    constexpr int MAXMETA = 320;
+    __shared__ unsigned short s_meta[MAXMETA];
+    for (int k = lane; k < (int)deg_c && k < MAXMETA; k += 64) s_meta[k] = M.nb_meta[ptr_c + k];
+    for (int k = lane; k < 9 * NBOX; k += 64) { (&aK[0][0][0])[k] = 0.0; if constexpr (WITHC) (&aC[0][0][0])[k] = 0.0; }
+    for (int k = lane; k < 3 * NBOX; k += 64) (&aH[0][0])[k] = 0.0;
+    if (lane < 3) aR[lane] = 0.0;
+    __syncthreads();
+    constexpr int NPASS = (ND + 63) / 64, NPH = (3 * NB + 63) / 64, UNR = 4;
+    const int neu = cd.neu, nev = cd.nev, ne = neu * nev;
+    const bool doC = WITHC && (flags & GF_ASM_C_BIT) != 0;
+    const bool doK = (flags & GF_ASM_K_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0, doR = (flags & GF_ASM_R_BIT) != 0;
+    for (int g0 = 0; g0 < ne; g0 += UNR) {
+        const double* Bp[UNR]; int bu[UNR], bv[UNR], al[UNR]; bool ok[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const int g = g0 + q, gg = g < ne ? g : 0, ku = gg % (neu > 0 ? neu : 1), kv = gg / (neu > 0 ? neu : 1);
+            const long long e = cd.e00 + ku + (long long)kv * cd.nelu - e_first;
+            ok[q] = g < ne && e >= 0 && e < e_count;
+            Bp[q] = blk + (size_t)(ok[q] ? e : 0) * Cfg::BLK;
+            bu[q] = cd.bu[ku]; bv[q] = cd.bv[kv]; al[q] = (ia - bu[q]) + (ja - bv[q]) * P1;
+        }
+        double vK[UNR][3][NPASS], vC[WITHC ? UNR : 1][3][NPASS], vH[UNR][NPH], vR[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int c = lane + 64 * ps;
+                    vK[q][i][ps] = (ok[q] && c < ND && doK) ? Bp[q][Cfg::OFF_K + (3 * al[q] + i) * ND + c] : 0.0;
+                    if constexpr (WITHC) vC[q][i][ps] = (ok[q] && c < ND && doC) ? Bp[q][Cfg::OFF_C + (3 * al[q] + i) * ND + c] : 0.0;
+                }
+#pragma unroll
+            for (int ps = 0; ps < NPH; ++ps) {
+                const int w = lane + 64 * ps;
+                vH[q][ps] = (ok[q] && w < 3 * NB && doH) ? Bp[q][Cfg::OFF_H + (3 * al[q] + w / NB) * NB + w % NB] : 0.0;
+            }
+            vR[q] = (ok[q] && lane < 3 && doR) ? Bp[q][Cfg::OFF_R + 3 * al[q] + lane] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            if (!ok[q]) continue;
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int c = lane + 64 * ps;
+                if (c < ND) {
+                    const int bl = c / 3, j = c - 3 * bl, ks = (bu[q] + bl % P1 - i0) + (bv[q] + bl / P1 - j0) * wbox;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { aK[i][ks][j] += vK[q][i][ps]; if constexpr (WITHC) aC[j][i][ks] += vC[q][i][ps]; }
+                }
+            }
+#pragma unroll
+            for (int ps = 0; ps < NPH; ++ps) {
+                const int w = lane + 64 * ps;
+                if (w < 3 * NB) { const int i = w / NB, bl = w - i * NB, ks = (bu[q] + bl % P1 - i0) + (bv[q] + bl / P1 - j0) * wbox; aH[i][ks] += vH[q][ps]; }
+            }
+            if (lane < 3) aR[lane] += vR[q];
+        }
+    }
+    __syncthreads();
+    const bool padd = pen_add && M.pen_row[a];
+    if (doK) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const bool zrow = M.zero[3 * a + i] != 0;
+            double* dst = valK + 9 * ptr_c + (long long)i * 3 * deg_c;
+            for (int c = lane; c < 3 * (int)deg_c; c += 64) {
+                const int k = c / 3, j = c - 3 * k;
+                const unsigned meta = k < MAXMETA ? s_meta[k] : M.nb_meta[ptr_c + k];
+                const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
+                double v = 0.0;
+                if (zrow || (meta & (128u << j))) v = ((meta & 1024u) && i == j) ? 1.0 : 0.0;
+                else { if (ks >= 0) v = aK[i][ks][j]; if (padd) v += dst[c]; }
+                dst[c] = v;
+            }
+        }
+    }
+    if constexpr (WITHC) if (doC) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const bool zrow = M.zero[3 * a + i] != 0;
+            for (int k = lane; k < (int)deg_c; k += 64) {
+                const unsigned meta = k < MAXMETA ? s_meta[k] : M.nb_meta[ptr_c + k];
+                const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    double* dst = (f == 0 ? valC0 : (f == 1 ? valC1 : valC2)) + 3 * ptr_c + (long long)i * deg_c + k;
+                    double v = 0.0;
+                    if (!zrow) { if (ks >= 0) v = aC[f][i][ks]; if (padd) v += *dst; }
+                    *dst = v;
+                }
+            }
+        }
+    }
+    if (doH) {
+        for (int k = lane; k < (int)deg_s; k += 64) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) valH[3 * ptr_s + (long long)i * deg_s + k] = aH[i][k];
+        }
+    }
+    if (doR && lane < 3) R[3 * a + lane] = aR[lane] + (padd ? R[3 * a + lane] : 0.0);
+}
+
 // Residual-only gather (flags == R, e.g. DispImOpeartion.apply_nonlinear, line searches): one thread per owned control
 // point sums the three residual entries of its <= (p+1)^2 element blocks in the same fixed order as kl_gather_kernel.
 template <int P>

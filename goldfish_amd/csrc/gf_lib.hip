@@ -41,6 +41,7 @@ struct gf_handle {
     bool strip = false;                               // p = 3 MFMA path: accumulate along element strips (GF_STRIP=1; see gf_element_strip.hpp for the measured trade-off)
     const StripDesc* d_strips = nullptr; const int* d_strip_off = nullptr;
     bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
+    bool gather1 = true;                              // one-wave gather (GF_GATHER1=0 selects the four-wave gather, which the strip path also uses)
     int pen_maxdeg = 0;                               // largest neighbour count of an interface control point
 
     template <class T> T* dalloc(size_t n) {
@@ -73,6 +74,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         h->H.build(desc);
         if (const char* s = getenv("GF_ELEMENT")) h->mfma = std::string(s) != "valu";
         if (const char* s = getenv("GF_STRIP")) h->strip = std::string(s) == "1";
+        if (const char* s = getenv("GF_GATHER1")) h->gather1 = std::string(s) != "0";
         h->strip = h->strip && h->mfma && h->H.degree == 3;
         HostModel& H = h->H;
         std::vector<long long> nbs(H.nb_ptr_s.begin(), H.nb_ptr_s.end()), nbc(H.nb_ptr_c.begin(), H.nb_ptr_c.end());
@@ -258,6 +260,12 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
         h->ev_n++;
         if (flags == GF_ASM_R && !(P == 3 && h->strip))
             hipLaunchKernelGGL(kl_rgather_kernel<P>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, h->d_blk, h->d_R, pen);
+        else if (!(flags & GF_ASM_DRDCP) && !(P == 3 && h->strip) && h->gather1)      // one wave per control point; without dR/dCP (Newton pass) the leaner instance
+            hipLaunchKernelGGL((kl_gather1_kernel<P, false>), dim3((unsigned)na), dim3(64), 0, h->stream, h->M, c.a0, c.e0, ne, flags, h->d_blk,
+                               h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R, pen);
+        else if (!(P == 3 && h->strip) && h->gather1)
+            hipLaunchKernelGGL((kl_gather1_kernel<P, true>), dim3((unsigned)na), dim3(64), 0, h->stream, h->M, c.a0, c.e0, ne, flags, h->d_blk,
+                               h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R, pen);
         else
         hipLaunchKernelGGL(kl_gather_kernel<P>, dim3((unsigned)na), dim3(256), 0, h->stream, h->M, c.a0, c.e0, ne, flags, h->d_blk,
                            h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R, pen,

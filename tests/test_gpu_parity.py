@@ -244,3 +244,27 @@ def test_create_rejects_bad_models():
     spec = ProblemSpec([p1, p2], [], 1.0, 0.3, 0.1, [[0, 0, 0]] * 2)
     with pytest.raises(RuntimeError, match="degree"):
         _lib.DeviceModel(arrays_from_spec(spec))
+
+
+def test_four_wave_gather_is_bitwise_the_one_wave_gather(oracle_lib, monkeypatch):
+    """The one-wave gather (default) and the four-wave gather (GF_GATHER1=0; also what the strip path uses) add the element
+    blocks in the same fixed order: identical bits for every output, for p = 2, 3, 4."""
+    from goldfish_amd import _lib
+    for case in ("tbeam2_p2", "shell3x2_p3", "shell2x2_p4"):
+        A, h, u = _state(CASES[case]())
+        out = []
+        for env in (None, "0"):
+            if env is None:
+                monkeypatch.delenv("GF_GATHER1", raising=False)
+            else:
+                monkeypatch.setenv("GF_GATHER1", env)
+            D = _lib.DeviceModel(A)
+            D.set_thickness(h)
+            D.set_u(u)
+            D.assemble(_lib.ASM_ALL)
+            out.append([D.residual().copy()] + [D.values(w).copy() for w in range(5)])
+            D.assemble(_lib.ASM_R | _lib.ASM_K)                      # the Newton pass uses the leaner instance
+            out[-1] += [D.residual().copy(), D.values(0).copy()]
+            D.close()
+        for x, y in zip(*out):
+            assert np.array_equal(x, y), case
