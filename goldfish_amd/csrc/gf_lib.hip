@@ -74,6 +74,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         h->H.build(desc);
         if (const char* s = getenv("GF_ELEMENT")) h->mfma = std::string(s) != "valu";
         if (const char* s = getenv("GF_STRIP")) h->strip = std::string(s) == "1";
+        h->gather1 = h->H.degree <= 3;                    // p = 4: 25 elements x 75-wide rows per control point are bandwidth bound either way (57.9 vs 57.6 ms per step)
         if (const char* s = getenv("GF_GATHER1")) h->gather1 = std::string(s) != "0";
         h->strip = h->strip && h->mfma && h->H.degree == 3;
         HostModel& H = h->H;
