@@ -18,7 +18,7 @@ BUF_CP, BUF_U, BUF_H, BUF_R, BUF_VAL_K, BUF_VAL_C0, BUF_VAL_C1, BUF_VAL_C2, BUF_
 EXPORTS = ["gf_device_count", "gf_last_error", "gf_create", "gf_destroy", "gf_total_cp", "gf_num_dofs",
            "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes", "gf_set_cp",
            "gf_set_thickness", "gf_set_u", "gf_nnz", "gf_pattern", "gf_assemble", "gf_sync", "gf_get_residual",
-           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms"]
+           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_shape_regu", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms"]
 
 
 def lib():
@@ -50,6 +50,7 @@ def lib():
         L.gf_apply.argtypes = [vp, C.c_int, C.c_int, dp, i64, dp, i64]
         L.gf_functionals.argtypes = [vp, dp, dp, dp, dp, dp, dp, C.c_int]
         L.gf_compliance.argtypes = [vp, dp, i64, dp, dp, dp, C.c_int]
+        L.gf_shape_regu.argtypes = [vp, C.c_int, dp, i64, dp, i64, dp, dp]
         L.gf_penalty_dxi.argtypes = [vp, dp, i64, C.POINTER(C.c_int32), i64]
         L.gf_stress_forms.argtypes = [vp, C.c_int, C.c_double, dp, i64, C.c_int, C.c_int, dp, dp, dp, dp, dp, C.c_int]
         L.gf_device_ptr.restype = vp
@@ -181,6 +182,14 @@ class DeviceModel:
                                      _dp(g["dIdu"]), _dp(g["dIdcp"]), _dp(g["dIdh"]), int(apply_bcs)), ValueError)
         g.update(I=I, vmax=vmax)
         return g
+
+    def shape_regu(self, field, cp0, coef):
+        """Shape regularisation term and its gradient wrt the three homogeneous coordinate fields (gf_shape_regu)."""
+        cp0 = np.ascontiguousarray(cp0, dtype=np.float64).ravel()
+        coef = np.ascontiguousarray(coef, dtype=np.float64).ravel()
+        val, dcp = np.zeros(1), np.zeros((3, self.total_cp))
+        _check(lib().gf_shape_regu(self.h, int(field), _dp(cp0), cp0.size, _dp(coef), coef.size, _dp(val), _dp(dcp)), ValueError)
+        return dict(value=val[0], dcp=dcp)
 
     def penalty_dxi(self, npts, degree):
         """Per-vertex blocks of d(penalty residual)/d(xi, tau) and the support windows (gf_penalty_dxi)."""

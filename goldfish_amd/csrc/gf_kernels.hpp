@@ -669,8 +669,12 @@ __global__ __launch_bounds__(256) void kl_rgather_kernel(DevModel M, long long a
 //           sum_gp wq J g(sigma_vM), g = exp(rho (sigma - m_s)) [mode 0] or (sigma / m_s)^rho [mode 1], sigma_vM at the
 //           station xi3 = sgn t/2 (shell_stress_point): slots 0-2 dI/du, 3-5 reference part of dI/dc, 9 dI/dh (6-8, 10
 //           zero); We = I_e, Ve = max_gp sigma_vM
+//   KIND 2  shape regularisation of the eVTOL demo (demos_om/shape_opt/eVTOL/int_energy_regu_exop.py:30-38):
+//           sum_gp wq c_s |grad_s(P_f - P_f^0)|^2 J with the surface gradient on the CURRENT geometry,
+//           |grad_s D|^2 J = |D_,1 G2 - D_,2 G1|^2 / J (D = homogeneous coordinate f minus its initial value);
+//           slots 3-5 d/dc (0-2, 6-10 zero); We = value, Ve = 0
 template <int P> struct FunCfg { static constexpr int NB = (P + 1) * (P + 1), STRIDE = NB * 11 + 2; };
-struct StressCfg { int mode, measure; double rho, sgn; const double* m_list; };
+struct StressCfg { int mode, measure; double rho, sgn; const double* m_list; int field; const double* cp0; };   // KIND 2: field, cp0 (initial homogeneous coordinate), m_list = coefficient per patch
 
 template <int P, int KIND>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void kl_pointfun_kernel(DevModel M, int e_first, int e_count, StressCfg S,
@@ -681,6 +685,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void kl
     __shared__ double s_c[NE][NB][3], s_d[NE][NB][3], s_h[NE][NB], s_w[NE][NB];
     __shared__ double s_tu[NE][TS], s_tv[NE][TS], s_wg[NE][2 * P1];
     __shared__ double s_fe[NE][NG][FE_SIZE + 8];                       // + W[6], wq, t (KIND 0) / sigma (KIND 1)
+    __shared__ double s_c0[KIND == 2 ? NE : 1][NB];                    // KIND 2: initial coordinate of the regularised field
     for (int k = tid; k < NE * NB; k += 64) {
         const int el = k / NB, a = k - el * NB;
         if (eb + el >= e_count) continue;
@@ -690,6 +695,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void kl
         s_c[el][a][0] = c4.x; s_c[el][a][1] = c4.y; s_c[el][a][2] = c4.z; s_w[el][a] = c4.w;
         s_d[el][a][0] = c4.x + M.u[3 * g]; s_d[el][a][1] = c4.y + M.u[3 * g + 1]; s_d[el][a][2] = c4.z + M.u[3 * g + 2];
         s_h[el][a] = M.h[g];
+        if constexpr (KIND == 2) s_c0[el][a] = S.cp0[g];
     }
     for (int k = tid; k < NE * TS; k += 64) {
         const int el = k / TS, j = k - el * TS;
@@ -744,7 +750,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void kl
                 for (int m = 0; m < 5; ++m) z[3 * m + i] = R[m + 1];
             }
             double* fe = s_fe[el][gpi];
-            if constexpr (KIND == 0) {
+            if constexpr (KIND == 2) {
+                // D_,alpha: non-rational derivatives of the homogeneous coordinate difference (spline.grad(cpFuncs[f]) of the reference)
+                double D1 = 0.0, D2 = 0.0;
+                for (int jv = 0; jv < P1; ++jv) for (int ju = 0; ju < P1; ++ju) {
+                    const int a = ju + P1 * jv; const double dc = s_c[el][a][S.field] - s_c0[el][a];
+                    D1 += U[1][ju] * s_tv[el][(gv * 3 + 0) * P1 + jv] * dc; D2 += U[0][ju] * s_tv[el][(gv * 3 + 1) * P1 + jv] * dc;
+                }
+                double wv[3], nt[3];
+                for (int k = 0; k < 3; ++k) wv[k] = D1 * Z[3 + k] - D2 * Z[k];
+                cross3(Z, Z + 3, nt);
+                const double J = sqrt(dot3(nt, nt)), iJ = 1.0 / J, r = dot3(wv, wv) * iJ, cf = S.m_list[pid];
+                double JZ[6], nn[3] = {nt[0] * iJ, nt[1] * iJ, nt[2] * iJ};
+                cross3(Z + 3, nn, JZ); cross3(nn, Z, JZ + 3);
+                for (int c = 0; c < FE_SIZE; ++c) fe[c] = 0.0;
+                fe[FE_PSI] = cf * r;
+                for (int k = 0; k < 3; ++k) {
+                    fe[FE_PZR + k] = cf * (-2.0 * D2 * wv[k] * iJ - r * JZ[k] * iJ);
+                    fe[FE_PZR + 3 + k] = cf * (2.0 * D1 * wv[k] * iJ - r * JZ[3 + k] * iJ);
+                }
+                fe[FE_PT] = cf * 2.0 * dot3(wv, Z + 3) * iJ;            // d/dD_,1  (slots reused: no thickness derivative here)
+                fe[FE_J] = -cf * 2.0 * dot3(wv, Z) * iJ;                 // d/dD_,2
+                fe[FE_SIZE + 7] = 0.0;
+            } else if constexpr (KIND == 0) {
                 shell_energy_point(z, Z, t, Pt.E, Pt.nu_, fe);
                 fe[FE_SIZE + 7] = t;
             } else {
@@ -775,7 +803,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void kl
             double pz = 0.0, pZ = 0.0;
             for (int m = 0; m < 5; ++m) { pz += R[m + 1] * fe[FE_PZ + 3 * m + i]; pZ += R[m + 1] * fe[FE_PZR + 3 * m + i]; }
             du += wq * pz; dc += wq * pZ;
-            dwh += wq * Nb[0] * fe[FE_PT];
+            if constexpr (KIND == 2) { if (i == S.field) dc += wq * (Nb[1] * fe[FE_PT] + Nb[2] * fe[FE_J]); }
+            else dwh += wq * Nb[0] * fe[FE_PT];
             if constexpr (KIND == 0) {
                 dv += wq * fe[FE_SIZE + 7] * (R[1] * fe[FE_JZ + i] + R[2] * fe[FE_JZ + 3 + i]);
                 dvh += wq * Nb[0] * fe[FE_J];
@@ -790,7 +819,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void kl
         for (int gp = 0; gp < NG; ++gp) {
             const double* fe = s_fe[tid][gp]; const double wq = fe[FE_SIZE + 6];
             We += wq * fe[FE_PSI];
-            if constexpr (KIND == 0) Ve += wq * fe[FE_SIZE + 7] * fe[FE_J]; else Ve = fmax(Ve, fe[FE_SIZE + 7]);
+            if constexpr (KIND == 0) Ve += wq * fe[FE_SIZE + 7] * fe[FE_J]; else if constexpr (KIND == 1) Ve = fmax(Ve, fe[FE_SIZE + 7]);
         }
         double* out = blk + (size_t)(eb + tid) * blk_stride;
         out[NB * 11] = We; out[NB * 11 + 1] = Ve;

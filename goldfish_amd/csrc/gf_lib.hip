@@ -310,6 +310,18 @@ template <int P> static void run_compliance(gf_handle* h, int apply_bcs) {
     HIPCHK(hipGetLastError());
 }
 
+template <int P> static void run_regu(gf_handle* h, const StressCfg& S) {
+    const size_t stride = (size_t)FunCfg<P>::STRIDE;
+    constexpr int NE = 64 / ((P + 1) * (P + 1));
+    for (const Chunk& c : h->chunks) {
+        const long long ne = c.e1 - c.e0, na = c.a1 - c.a0, nthr = std::max(ne, na);
+        hipLaunchKernelGGL((kl_pointfun_kernel<P, 2>), dim3((unsigned)((ne + NE - 1) / NE)), dim3(64), 0, h->stream, h->M, (int)c.e0, (int)ne, S, h->d_blk, stride);
+        hipLaunchKernelGGL(kl_fgather_kernel<P>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, 0,
+                           h->d_blk, stride, h->d_fun, h->d_x, h->d_ve);
+    }
+    HIPCHK(hipGetLastError());
+}
+
 template <int P> static void run_stress(gf_handle* h, const StressCfg& S, int apply_bcs) {
     const size_t stride = (size_t)FunCfg<P>::STRIDE;
     for (const Chunk& c : h->chunks) {
@@ -441,6 +453,33 @@ int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, dou
         const long long e_end = H.n_owned < H.np ? H.patches[H.n_owned].elem_off : H.nelem;
         long double acc = 0; for (long long e = 0; e < e_end; ++e) acc += ce[e];
         *C = (double)acc;
+    } catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
+}
+
+int gf_shape_regu(gf_handle* h, int field, const double* cp0, int64_t ncp, const double* coef, int64_t nc, double* value, double* dcp) {
+    if (!h || !cp0 || !coef || !value) return fail("gf_shape_regu: null argument");
+    if (field < 0 || field > 2) return fail("gf_shape_regu: field must be 0, 1 or 2");
+    if (ncp != (int64_t)h->H.total_cp || nc != (int64_t)h->H.np) return fail("gf_shape_regu: cp0 must hold total_cp values and coef one value per patch");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        const HostModel& H = h->H; const long long T = H.total_cp;
+        HIPCHK(hipMemcpyAsync(h->d_y, coef, nc * sizeof(double), hipMemcpyHostToDevice, h->stream));          // d_y, d_x: >= ndof doubles each
+        HIPCHK(hipMemcpyAsync(h->d_y + H.np, cp0, ncp * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        StressCfg S{}; S.m_list = h->d_y; S.cp0 = h->d_y + H.np; S.field = field;
+        switch (H.degree) {
+            case 2: run_regu<2>(h, S); break;
+            case 3: run_regu<3>(h, S); break;
+            case 4: run_regu<4>(h, S); break;
+            default: throw std::runtime_error("gf_shape_regu: unsupported degree");
+        }
+        std::vector<double> ve(H.nelem);
+        HIPCHK(hipMemcpyAsync(ve.data(), h->d_x, H.nelem * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (dcp) HIPCHK(hipMemcpyAsync(dcp, h->d_fun + 3 * T, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const long long e_end = H.n_owned < H.np ? H.patches[H.n_owned].elem_off : H.nelem;
+        long double acc = 0; for (long long e = 0; e < e_end; ++e) acc += ve[e];
+        *value = (double)acc;
     } catch (const std::exception& ex) { return fail(ex.what()); }
     return 0;
 }

@@ -15,3 +15,4 @@ from .max_vmstress_comp import MaxvMStressComp   # noqa: E402,F401
 from .cpiga2xi_comp import CPIGA2XiComp           # noqa: E402,F401
 from .disp_states_mi_comp import DispMintStatesComp   # noqa: E402,F401
 from .int_xi_edge_comp import IntXiEdgeComp         # noqa: E402,F401
+from .int_energy_regu_comp import IntEnergyReguComp   # noqa: E402,F401

@@ -108,6 +108,13 @@ int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, dou
 int gf_stress_forms(gf_handle* h, int mode, double rho, const double* m_list, int64_t nm, int surf, int measure,
                     double* forms, double* vmax, double* dIdu, double* dIdcp, double* dIdh, int apply_bcs);
 
+/* Shape regularisation of demos_om/shape_opt/eVTOL/int_energy_regu_exop.py:30-38 (IntEnergyReguExOperation adds it to W_int):
+ *   value = sum_s coef[s] int |grad_s(P_f - P_f^0)|^2 dA,   grad_s = surface gradient on the CURRENT geometry (spline.grad),
+ * P_f = homogeneous coordinate `field` of the control net (cpFuncs[field]), P_f^0 = cp0 (its initial value, [total_cp]).
+ * dcp (may be NULL): 3 arrays of total_cp, d value / d (homogeneous coordinates 0, 1, 2) -- the geometry enters through the
+ * metric and the area element too.  No dependence on u or the thickness. */
+int gf_shape_regu(gf_handle* h, int field, const double* cp0, int64_t ncp, const double* coef, int64_t nc, double* value, double* dcp);
+
 /* Moving intersections: NonMatchingOpt.dRIGAdxi / dRIGAdxi_sub (nonmatching_opt.py:1042-1341) -- derivative of the penalty
  * residual with respect to the parametric coordinates of the mortar vertices, at the current u / CP / thickness.
  * blocks[v][dir][side'][a][i] (npts x 6 x 2 x (p+1)^2 x 3 doubles): d(residual entry i of the a-th support control point of

@@ -791,6 +791,57 @@ void gfo_stress_forms(const gfo_model* M, int mode, double rho, const double* m_
     if (dIdu && apply_bcs) for (int64_t r = 0; r < M->ndof; ++r) if (M->zero[r]) dIdu[r] = 0;
 }
 
+/* ---- shape regularisation (demos_om/shape_opt/eVTOL/int_energy_regu_exop.py:30-38) ------------------------------------
+ * value = sum_s coef[s] int |grad_s(P_f - P_f^0)|^2 dA with spline.grad on the current geometry: grad_s D = D_,a A^ab G_b
+ * (contravariant metric by explicit inversion), D_,a = non-rational derivatives of the homogeneous coordinate difference.
+ * Gradient wrt the three homogeneous coordinate fields by complex step of the integrand. */
+static cplx regu_integrand(const cplx* G1, const cplx* G2, cplx D1, cplx D2) {
+    cplx A11 = cdot(G1, G1), A22 = cdot(G2, G2), A12 = cdot(G1, G2), det = A11 * A22 - A12 * A12;
+    cplx c11 = A22 / det, c22 = A11 / det, c12 = -A12 / det, gr[3];
+    for (int k = 0; k < 3; ++k) gr[k] = (D1 * c11 + D2 * c12) * G1[k] + (D1 * c12 + D2 * c22) * G2[k];
+    return cdot(gr, gr) * csqrt(det);
+}
+void gfo_shape_regu(const gfo_model* M, int field, const double* cp0, const double* coef, double* value, double* dcp0, double* dcp1, double* dcp2) {
+    double* dC[3] = {dcp0, dcp1, dcp2}; const double hs = 1e-30; double tot = 0;
+    for (int f = 0; f < 3; ++f) if (dC[f]) memset(dC[f], 0, sizeof(double) * M->total_cp);
+    for (int s = 0; s < M->np; ++s) {
+        const patch_t* P = &M->P[s]; const int p = P->p, q = P->q, nb = (p + 1) * (q + 1);
+        for (int ev = 0; ev < P->nelv; ++ev) for (int eu = 0; eu < P->nelu; ++eu) {
+            const int iu0 = P->spanu[eu] - p, iv0 = P->spanv[ev] - q; int64_t gid[MAXNB]; double wl[MAXNB];
+            for (int jv = 0; jv <= q; ++jv) for (int ju = 0; ju <= p; ++ju) { int a = ju + jv * (p + 1); gid[a] = P->cp_off + (iu0 + ju) + (int64_t)(iv0 + jv) * P->nu; wl[a] = M->w[gid[a]]; }
+            for (int gv = 0; gv < P->ngv; ++gv) for (int gu = 0; gu < P->ngu; ++gu) {
+                const double* tu = P->bu + (size_t)((eu * P->ngu + gu) * 3) * (p + 1); const double* tv = P->bv + (size_t)((ev * P->ngv + gv) * 3) * (q + 1);
+                const double wq = P->wu[eu * P->ngu + gu] * P->wv[ev * P->ngv + gv];
+                double Nb[6][MAXNB], Rb[6][MAXNB];
+                for (int jv = 0; jv <= q; ++jv) for (int ju = 0; ju <= p; ++ju) {
+                    int a = ju + jv * (p + 1);
+                    double u0 = tu[ju], u1 = tu[(p + 1) + ju], u2 = tu[2 * (p + 1) + ju], v0 = tv[jv], v1 = tv[(q + 1) + jv], v2 = tv[2 * (q + 1) + jv];
+                    Nb[0][a] = u0 * v0; Nb[1][a] = u1 * v0; Nb[2][a] = u0 * v1; Nb[3][a] = u2 * v0; Nb[4][a] = u0 * v2; Nb[5][a] = u1 * v1;
+                }
+                rationalize(nb, Nb, wl, Rb);
+                cplx G[6], D[2] = {0, 0};
+                for (int k = 0; k < 6; ++k) G[k] = 0;
+                for (int a = 0; a < nb; ++a) {
+                    for (int k = 0; k < 3; ++k) { G[k] += Rb[1][a] * M->cp[3 * gid[a] + k]; G[3 + k] += Rb[2][a] * M->cp[3 * gid[a] + k]; }
+                    const double dc = M->cp[3 * gid[a] + field] - cp0[gid[a]];
+                    D[0] += Nb[1][a] * dc; D[1] += Nb[2][a] * dc;
+                }
+                tot += wq * coef[s] * creal(regu_integrand(G, G + 3, D[0], D[1]));
+                if (!dcp0 && !dcp1 && !dcp2) continue;
+                double gG[6], gD[2];
+                for (int c = 0; c < 6; ++c) { cplx keep = G[c]; G[c] = keep + hs * I; gG[c] = cimag(regu_integrand(G, G + 3, D[0], D[1])) / hs; G[c] = keep; }
+                gD[0] = cimag(regu_integrand(G, G + 3, D[0] + hs * I, D[1])) / hs; gD[1] = cimag(regu_integrand(G, G + 3, D[0], D[1] + hs * I)) / hs;
+                for (int a = 0; a < nb; ++a) for (int k = 0; k < 3; ++k) {
+                    double g = Rb[1][a] * gG[k] + Rb[2][a] * gG[3 + k];
+                    if (k == field) g += Nb[1][a] * gD[0] + Nb[2][a] * gD[1];
+                    if (dC[k]) dC[k][gid[a]] += wq * coef[s] * g;
+                }
+            }
+        }
+    }
+    *value = tot;
+}
+
 int gfo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

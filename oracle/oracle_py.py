@@ -50,6 +50,7 @@ def lib():
         L.gfo_eval_point.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, dp, dp]
         L.gfo_compliance.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp, C.c_int]
         L.gfo_stress_forms.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, C.c_double, C.c_int] + [dp] * 7 + [C.c_int]
+        L.gfo_shape_regu.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp]
         L.gfo_num_threads.restype = C.c_int
         L.gfo_set_num_threads.argtypes = [C.c_int]
         _LIB = L
@@ -155,6 +156,14 @@ class Oracle:
         lib().gfo_stress_forms(self.h, int(mode), float(rho), _dp(ml), float(sgn), int(measure), _dp(I), _dp(vmax), _dp(dIdu),
                                *[_dp(x) for x in dIdcp], _dp(dIdh), int(apply_bcs))
         return dict(I=I, vmax=vmax, dIdu=dIdu, dIdcp=dIdcp, dIdh=dIdh)
+
+    def shape_regu(self, field, cp0, coef):
+        """Shape regularisation term of the eVTOL demo and its gradient wrt the three coordinate fields (gfo_shape_regu)."""
+        cp0, coef = np.ascontiguousarray(cp0, float), np.ascontiguousarray(coef, float)
+        val = np.zeros(1)
+        dcp = [np.zeros(self.total_cp) for _ in range(3)]
+        lib().gfo_shape_regu(self.h, int(field), _dp(cp0), _dp(coef), _dp(val), *[_dp(x) for x in dcp])
+        return dict(value=val[0], dcp=dcp)
 
     def eval_point(self, patch, xi):
         X, U = np.zeros(3), np.zeros(3)

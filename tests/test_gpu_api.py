@@ -630,3 +630,57 @@ def test_total_derivative_through_a_moving_intersection():
     fd = (wp - wm) / (2 * eps)
     assert abs(back[1] @ dxi) > 1e-3 * abs(total)                        # the moving-intersection term matters here
     assert abs(fd - total) < 1e-5 * abs(fd), (fd, total, back[1] @ dxi)
+
+
+@pytest.mark.parametrize("p", [2, 3, 4])
+def test_shape_regularisation_parity(oracle_lib, p):
+    """gf_shape_regu (kl_pointfun_kernel<P, 2>) against the oracle: value and the gradient wrt all three coordinate fields."""
+    from goldfish_amd import _lib
+    from oracle.oracle_py import Oracle
+    spec = G.scordelis_lo_9patch(p, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2])
+    rng = np.random.default_rng(20 + p)
+    A = arrays_from_spec(spec)
+    O, D = Oracle(A, thickness=np.full(A.total_cp, spec.h_th), u=np.zeros(A.ndof)), _lib.DeviceModel(A)
+    cp = np.stack(A.cp_hom, 1)
+    for field in (2, 1):
+        cp0 = cp[:, field] + 0.05 * rng.standard_normal(A.total_cp)
+        coef = rng.uniform(0.5, 2.0, len(spec.patches))
+        Fd, Fo = D.shape_regu(field, cp0, coef), O.shape_regu(field, cp0, coef)
+        assert abs(Fd["value"] - Fo["value"]) < 1e-11 * abs(Fo["value"])
+        for f in range(3):
+            assert _rel(Fd["dcp"][f], Fo["dcp"][f]) < 1e-10, (field, f)
+    assert D.shape_regu(2, cp[:, 2], np.ones(len(spec.patches)))["value"] == 0.0        # no change of shape, no penalty
+    with pytest.raises(ValueError):
+        D.shape_regu(3, cp[:, 2], np.ones(len(spec.patches)))
+    D.close()
+
+
+def test_regularised_energy_operation_and_comp():
+    """IntEnergyReguExOperation / IntEnergyReguComp (demos_om/shape_opt/eVTOL): W_int + regularisation, dW/dCP against central
+    differences, dW/du and dW/dh unchanged."""
+    from goldfish_amd.operations.int_energy_exop import IntEnergyExOperation
+    from goldfish_amd.operations.int_energy_regu_exop import IntEnergyReguExOperation
+    from goldfish_amd.om_comps import IntEnergyReguComp, om
+    spec, th, nm = _problem()
+    rng = np.random.default_rng(8)
+    nm.update_uIGA(1e-3 * rng.standard_normal(nm.vec_iga_dof))
+    op, base = IntEnergyReguExOperation(nm, regu_para=1.0e6), IntEnergyExOperation(nm)
+    assert op.Wint() == base.Wint()                                   # initial shape: the term vanishes
+    cp2 = nm.get_init_CPIGA()[2].copy()
+    nm.update_CPIGA(cp2 + 0.02 * rng.standard_normal(cp2.size), 2)
+    assert op.Wint() > base.Wint() * (1 + 1e-6)
+    assert np.array_equal(op.dWintduIGA(), base.dWintduIGA()) and np.array_equal(op.dWintdh_th(), base.dWintdh_th())
+    for i, field in enumerate(nm.opt_field):
+        x0 = nm.cp_iga[field][nm._shopt_cols[i]].copy()
+        g, d = op.dWintdCPIGA(field), rng.standard_normal(x0.size)
+        eps = 1e-6
+        nm.update_CPIGA(x0 + eps * d, field); wp = op.Wint()
+        nm.update_CPIGA(x0 - eps * d, field); wm = op.Wint()
+        nm.update_CPIGA(x0, field)
+        assert abs((wp - wm) / (2 * eps) - g @ d) < 1e-6 * abs(g @ d), field
+    comp = IntEnergyReguComp(nonmatching_opt=nm, regu_para=1.0e6)
+    comp.init_parameters()
+    prob = om.Problem(model=comp)
+    prob.setup()
+    prob.run_model()
+    assert max(prob.check_partials(compact_print=False).values()) < 1e-5

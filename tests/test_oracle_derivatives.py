@@ -133,6 +133,24 @@ def test_stress_forms_vs_autograd(oracle_lib):
         assert _relerr(F["dIdh"] * wcp, gh.numpy()) < RTOL
 
 
+def test_shape_regularisation_vs_autograd(oracle_lib):
+    """Oracle's shape regularisation term (explicit contravariant metric, complex-step gradient) vs torch.autograd of the
+    pseudo-inverse statement of tIGAr's manifold gradient."""
+    spec = G.scordelis_lo_9patch(3, nels=[2, 1, 2, 1, 2, 1, 2, 1, 2])
+    A, O, T, c, U, ht = _setup(spec, seed=6)
+    rng = np.random.default_rng(3)
+    cp_now = c.detach().numpy()
+    for field in (2, 0):
+        cp0 = cp_now[:, field] + 0.05 * rng.standard_normal(A.total_cp)
+        coef = rng.uniform(0.5, 2.0, len(spec.patches))
+        F = O.shape_regu(field, cp0, coef)
+        V = T.shape_regu(c, field, cp0, coef)
+        gc, = torch.autograd.grad(V, c)
+        assert abs(F["value"] - V.item()) < 1e-12 * abs(V.item())
+        for f in range(3):
+            assert _relerr(F["dcp"][f], gc.numpy()[:, f]) < RTOL, (field, f)
+
+
 def test_penalty_point_hessians(oracle_lib):
     """complex-step Hessians of one mortar vertex vs torch autograd."""
     from oracle import kl_energy_torch as ke

@@ -42,7 +42,7 @@ def _point_basis(P, wflat, xi):
 class TorchModel:
     def __init__(self, spec, arrays):
         self.spec, self.A = spec, arrays
-        ids, Rb, N0, wq, pid = [], [], [], [], []
+        ids, Rb, N0, wq, pid, Nb12 = [], [], [], [], [], []
         for s, P in enumerate(spec.patches):
             w = P.cp_hom_flat()[:, 3]
             off = int(arrays.cp_off[s])
@@ -60,6 +60,7 @@ class TorchModel:
                             ids.append(i + off)
                             Rb.append(R)
                             N0.append(Nb[0])
+                            Nb12.append(Nb[1:3])
                             wq.append(0.25 * (a1 - a0) * (b1 - b0) * wu * wv)
                             pid.append(s)
         nbmax = max(len(i) for i in ids)
@@ -67,6 +68,7 @@ class TorchModel:
         self.ids = torch.tensor(np.array(ids))
         self.Rb = torch.tensor(np.array(Rb))
         self.N0 = torch.tensor(np.array(N0))
+        self.Nb12 = torch.tensor(np.array(Nb12))
         self.wq = torch.tensor(np.array(wq))
         self.pid = torch.tensor(np.array(pid))
         self.E = torch.tensor(arrays.young)[self.pid]
@@ -128,6 +130,17 @@ class TorchModel:
             val = torch.exp(rho * (sig - m_list[s])) if mode == 0 else (sig / m_list[s]) ** rho
             out[s] = out[s] + self.wq[g] * J[g] * val
         return torch.stack(out)
+
+    def shape_regu(self, c, field, cp0, coef):
+        """sum_s coef_s int |grad_s(P_f - P_f^0)|^2 dA with the surface gradient through the pseudo-inverse of DF (tIGAr
+        spline.grad on a manifold), demos_om/shape_opt/eVTOL/int_energy_regu_exop.py:30-38."""
+        Z = torch.einsum("gma,gak->gmk", self.Rb[:, 1:3], c[self.ids])             # (g, 2, 3): G1, G2
+        dc = (c[:, field] - torch.as_tensor(cp0))[self.ids]
+        D = torch.einsum("gma,ga->gm", self.Nb12, dc)                             # non-rational derivatives
+        DF = Z.transpose(1, 2)                                                    # (g, 3, 2)
+        grad = torch.einsum("gm,gmk->gk", D, torch.linalg.pinv(DF))               # D_,a (DF^+)_a,k
+        J = ke.area_jacobian(Z)
+        return (self.wq * torch.as_tensor(coef)[self.pid] * (grad * grad).sum(-1) * J).sum()
 
     def penalty_energy(self, c, U):
         W = torch.zeros((), dtype=torch.float64)
