@@ -677,7 +677,7 @@ template <int P> struct FunCfg { static constexpr int NB = (P + 1) * (P + 1), ST
 struct StressCfg { int mode, measure; double rho, sgn; const double* m_list; int field; const double* cp0; };   // KIND 2: field, cp0 (initial homogeneous coordinate), m_list = coefficient per patch
 
 template <int P, int KIND>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void kl_pointfun_kernel(DevModel M, int e_first, int e_count, StressCfg S,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KIND == 2 ? 1 : 2))) void kl_pointfun_kernel(DevModel M, int e_first, int e_count, StressCfg S,
                                                                                                  double* __restrict__ blk, size_t blk_stride) {
     constexpr int P1 = P + 1, NB = P1 * P1, NG = NB, ND = 3 * NB, NE = 64 / NG, TS = P1 * 3 * P1;
     const int tid = threadIdx.x;
@@ -721,10 +721,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void kl
             for (int k = 0; k < 6; ++k) { W[k] = 0.0; for (int i = 0; i < 3; ++i) { Ac[i][k] = 0.0; Ad[i][k] = 0.0; } }
             double U[3][P1];
             for (int d = 0; d < 3; ++d) for (int j = 0; j < P1; ++j) U[d][j] = s_tu[el][(gu * 3 + d) * P1 + j];
+            double D1 = 0.0, D2 = 0.0;                                  // KIND 2: non-rational derivatives of the coordinate difference
 #pragma unroll
             for (int jv = 0; jv < P1; ++jv) {
                 const double v0 = s_tv[el][(gv * 3 + 0) * P1 + jv], v1 = s_tv[el][(gv * 3 + 1) * P1 + jv], v2 = s_tv[el][(gv * 3 + 2) * P1 + jv];
-                double Sm[7][3], Sh = 0.0;
+                double Sm[7][3], Sh = 0.0, Sd0 = 0.0, Sd1 = 0.0;
                 for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) Sm[q][d] = 0.0;
 #pragma unroll
                 for (int ju = 0; ju < P1; ++ju) {
@@ -732,8 +733,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void kl
                     const double qv[7] = {s_c[el][a][0], s_c[el][a][1], s_c[el][a][2], s_d[el][a][0], s_d[el][a][1], s_d[el][a][2], s_w[el][a]};
                     for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) Sm[q][d] += U[d][ju] * qv[q];
                     Sh += U[0][ju] * s_h[el][a];
+                    if constexpr (KIND == 2) {
+                        const double dc = (S.field == 0 ? qv[0] : (S.field == 1 ? qv[1] : qv[2])) - s_c0[el][a];
+                        Sd0 += U[0][ju] * dc; Sd1 += U[1][ju] * dc;
+                    }
                 }
                 t += v0 * Sh;
+                if constexpr (KIND == 2) { D1 += v0 * Sd1; D2 += v1 * Sd0; }
 #pragma unroll
                 for (int q = 0; q < 7; ++q) {
                     double* A = q < 3 ? Ac[q] : (q < 6 ? Ad[q - 3] : W);
@@ -752,11 +758,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void kl
             double* fe = s_fe[el][gpi];
             if constexpr (KIND == 2) {
                 // D_,alpha: non-rational derivatives of the homogeneous coordinate difference (spline.grad(cpFuncs[f]) of the reference)
-                double D1 = 0.0, D2 = 0.0;
-                for (int jv = 0; jv < P1; ++jv) for (int ju = 0; ju < P1; ++ju) {
-                    const int a = ju + P1 * jv; const double dc = s_c[el][a][S.field] - s_c0[el][a];
-                    D1 += U[1][ju] * s_tv[el][(gv * 3 + 0) * P1 + jv] * dc; D2 += U[0][ju] * s_tv[el][(gv * 3 + 1) * P1 + jv] * dc;
-                }
                 double wv[3], nt[3];
                 for (int k = 0; k < 3; ++k) wv[k] = D1 * Z[3 + k] - D2 * Z[k];
                 cross3(Z, Z + 3, nt);
