@@ -271,7 +271,13 @@ class CPIGA2Xi(object):
 
     def solve_xi(self, xi_flat_init, rtol=1e-5, max_iter=200):
         """Root of the coupled system (scipy fsolve with the analytic Jacobian, :503-566)."""
-        return fsolve(self.residual, x0=np.asarray(xi_flat_init, float), fprime=lambda x: np.asarray(self.dRdxi(x, coo=False)))
+        x0 = np.asarray(xi_flat_init, float)
+        if np.abs(self.residual(x0)).max() < 1e-13:                       # already a root (MINPACK would only warn about "no progress")
+            return x0.copy()
+        xi, info, ier, msg = fsolve(self.residual, x0=x0, fprime=lambda x: np.asarray(self.dRdxi(x, coo=False)), full_output=True, xtol=1e-14)
+        if np.abs(self.residual(xi)).max() > 1e-8:
+            raise RuntimeError("CPIGA2Xi.solve_xi: no intersection found (%s)" % msg)
+        return xi
 
     # ---- derivatives -------------------------------------------------------------------------
     def dRdxi_sub(self, int_ind, xi_flat_sub, coo=True):

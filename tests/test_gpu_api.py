@@ -684,3 +684,17 @@ def test_regularised_energy_operation_and_comp():
     prob.setup()
     prob.run_model()
     assert max(prob.check_partials(compact_print=False).values()) < 1e-5
+
+
+def test_moving_intersection_optimisation_finds_the_symmetric_optimum():
+    """examples/tbeam_moving_intersection.py (set-up of demos_om/shape_opt_mint/T-beam): the web starts 0.4 off centre under a
+    load that is symmetric about the flange's centre line; with the intersection moving along (xi(CP), dR/dxi in the total
+    derivative) SLSQP brings it back to the centre, the optimum known by symmetry."""
+    import importlib.util
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec_ = importlib.util.spec_from_file_location("tbeam_mint", os.path.join(here, "examples", "tbeam_moving_intersection.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    out = mod.run(verbose=False)
+    assert abs(out["s1"]) < 2e-3, out["s1"]
+    assert out["w1"] < out["w0"]
