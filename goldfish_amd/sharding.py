@@ -279,3 +279,17 @@ class ShardedDeviceModel:
             out["dIdh"] = self._rows_to_global(own(F["dIdh"]), 1)
             out["dIdcp"] = np.stack([self._rows_to_global(own(F["dIdcp"][f]), 1) for f in range(3)])
         return out
+
+    def shape_regu(self, field, cp0_global, coef_global):
+        """Global shape regularisation term (gf_shape_regu): owned elements per rank, value and owned gradient rows summed."""
+        order = np.asarray(self.shard.order)
+        F = self.D.shape_regu(field, self.shard.to_local(np.asarray(cp0_global, float)), np.asarray(coef_global, float)[order])
+        n = self.n_owned_cp
+        out = dict(value=float(self._allreduce(np.array([F["value"]]))[0]))
+        dcp = []
+        for f in range(3):
+            w = np.array(F["dcp"][f], float)
+            w[n:] = 0.0
+            dcp.append(self._rows_to_global(w, 1))
+        out["dcp"] = np.stack(dcp)
+        return out

@@ -194,7 +194,8 @@ def _rank_worker(rank, world, port, q):
     res = dict(R=S.residual(), Ku=S.apply(_lib.MAT_K, xu), KTl=S.apply(_lib.MAT_K, lam, transpose=True),
                Cc=S.apply(_lib.MAT_DRDCP1, xc), CTl=S.apply(_lib.MAT_DRDCP1, lam, transpose=True),
                HTl=S.apply(_lib.MAT_DRDH, lam, transpose=True), F=S.functionals(apply_bcs=False), xu=xu, xc=xc, lam=lam,
-               S=S.stress_forms(1, 3.0, 1e6 * (1.0 + np.arange(len(spec.patches))), -1, 0, apply_bcs=False))
+               S=S.stress_forms(1, 3.0, 1e6 * (1.0 + np.arange(len(spec.patches))), -1, 0, apply_bcs=False),
+               G=S.shape_regu(2, 0.98 * np.concatenate([p.cp_hom_flat()[:, 2] for p in spec.patches]), 1.0 + np.arange(len(spec.patches))))
     if rank == 0:
         q.put(res)
     dist.barrier()
@@ -237,6 +238,8 @@ def test_two_rank_sharded_assembly_on_gpu(oracle_lib):
     assert _rel(Sd["I"], So["I"]) < 1e-11 and _rel(Sd["vmax"], So["vmax"]) < 1e-11
     assert _rel(Sd["dIdu"], So["dIdu"]) < 1e-10 and _rel(Sd["dIdh"], So["dIdh"]) < 1e-10
     assert _rel(Sd["dIdcp"][1], So["dIdcp"][1]) < 1e-10
+    Go = O.shape_regu(2, 0.98 * np.concatenate([p.cp_hom_flat()[:, 2] for p in spec.patches]), 1.0 + np.arange(len(spec.patches)))
+    assert abs(res["G"]["value"] - Go["value"]) < 1e-11 * abs(Go["value"]) and _rel(res["G"]["dcp"][0], Go["dcp"][0]) < 1e-10
 
 
 def test_ffd_chain_rule_through_the_gpu_path():
