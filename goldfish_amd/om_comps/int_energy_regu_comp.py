@@ -6,12 +6,7 @@ from ..operations.int_energy_regu_exop import IntEnergyReguExOperation
 
 
 class IntEnergyReguComp(IntEnergyComp):
+    OPTIONS = IntEnergyComp.OPTIONS + (('regu_para', 1.0e-1),)
 
-    def initialize(self):
-        super().initialize()
-        self.options.declare('regu_para', default=1.0e-1)
-
-    def init_parameters(self):
-        super().init_parameters()
-        self.regu_para = self.options['regu_para']
+    def _operation(self):
         self.wint_exop = IntEnergyReguExOperation(self.nonmatching_opt, self.regu_para)
