@@ -112,3 +112,27 @@ class FunctionalComp(DesignIO, om.ExplicitComponent):
                 partials[self._of, name] = self._dcp(field)
         if self.opt_thickness:
             partials[self._of, self.input_h_th_name] = self._dh()
+
+
+class LinearMapsComp(DesignIO, om.ExplicitComponent):
+    """outputs[k] = A_k inputs[k] - b_k for constant sparse A_k (one map per optimised field, or a single one).
+    Subclasses give OPTIONS and ``_build()`` -> [(input name, output name, A, initial input, b or None), ...]."""
+
+    def init_parameters(self):
+        self._read_options()
+        self._maps = [(i, o, A.tocoo(), x0, b) for (i, o, A, x0, b) in self._build()]
+
+    def setup(self):
+        for i, o, A, x0, b in self._maps:
+            self.add_input(i, shape=A.shape[1], val=x0)
+            self.add_output(o, shape=A.shape[0])
+            self.declare_partials(o, i, val=A.data, rows=A.row, cols=A.col)
+
+    def compute(self, inputs, outputs):
+        for i, o, A, x0, b in self._maps:
+            y = A * inputs[i]
+            outputs[o] = y if b is None else y - b
+
+    def compute_partials(self, inputs, partials):
+        for i, o, A, x0, b in self._maps:
+            partials[o, i] = A.toarray()

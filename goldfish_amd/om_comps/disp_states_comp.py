@@ -6,8 +6,13 @@ from ..operations.disp_imop import DispImOpeartion
 
 
 class StatesComp(DesignIO, om.ImplicitComponent):
-    """R(u; design) = 0 through an implicit operation ``self._imop`` (apply_nonlinear, solve_nonlinear, linearize,
-    apply_linear_fwd/rev, solve_linear_fwd/rev); ``_input_names()`` lists the inputs in the operation's order."""
+    """R(state; inputs) = 0 through an implicit operation ``self._imop`` (apply_linear_fwd/rev, solve_linear_fwd/rev, ...);
+    ``STATE_OPTION`` names the option holding the output's name, ``_input_names()`` lists the inputs in the operation's order."""
+    STATE_OPTION = 'output_u_name'
+
+    @property
+    def _state(self):
+        return getattr(self, self.STATE_OPTION)
 
     def _state_setup(self):
         self.add_output(self.output_u_name, shape=self.output_shape)
@@ -29,7 +34,7 @@ class StatesComp(DesignIO, om.ImplicitComponent):
         self.major_iter_ind += 1
 
     def _products(self, d_inputs, d_outputs, d_residuals, mode):
-        u = self.output_u_name
+        u = self._state
         args = (self._present(self._input_names(), d_inputs), d_outputs[u] if u in d_outputs else None, d_residuals[u] if u in d_residuals else None)
         if mode == 'fwd':
             self._imop.apply_linear_fwd(*args)
@@ -37,7 +42,7 @@ class StatesComp(DesignIO, om.ImplicitComponent):
             self._imop.apply_linear_rev(*args)
 
     def solve_linear(self, d_outputs, d_residuals, mode):
-        u = self.output_u_name
+        u = self._state
         if mode == 'fwd':
             self._imop.solve_linear_fwd(d_outputs[u], d_residuals[u])
         if mode == 'rev':
