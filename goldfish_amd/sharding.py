@@ -135,15 +135,20 @@ def allgather_owned_rows(shard, local_rows, dist, width=3, out=None):
         out[g0:g1] = local_rows[:g1 - g0]
         return out
     mx = max(b - a for a, b in rng)
-    send = torch.zeros(mx, dtype=torch.float64, device=local_rows.device)
-    send[:g1 - g0] = local_rows[:g1 - g0]
+    cache = shard.__dict__.setdefault("_exchange_buffers", {})            # staging buffers are allocated once per (width, device)
+    key = (width, str(local_rows.device))
+    if key not in cache:
+        cache[key] = (torch.zeros(mx, dtype=torch.float64, device=local_rows.device),
+                      torch.empty(shard.world * mx, dtype=torch.float64, device=local_rows.device))
+    send, recv_buf = cache[key]
+    send[:g1 - g0] = local_rows[:g1 - g0]                                  # the padding behind it stays zero
     if send.is_cuda:
         # local_rows is usually a view of the library's residual buffer, which the next assembly (on the library's own
         # stream) overwrites: wait for this one copy, not for the collective, so that the exchange overlaps the next step
         ev = torch.cuda.Event()
         ev.record()
         ev.synchronize()
-    recv = torch.empty(shard.world * mx, dtype=torch.float64, device=local_rows.device)
+    recv = recv_buf
     if dist.get_backend() == "nccl":
         dist.all_gather_into_tensor(recv, send)
     else:                                                       # gloo (tests, rehearsal): host tensors
