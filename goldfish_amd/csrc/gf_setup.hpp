@@ -204,6 +204,7 @@ inline void HostModel::build(const gf_model_desc* D) {
         }
     }
     zero.assign(ndof, 0);
+    if ((D->n_zero_dofs > 0 && !D->zero_dofs) || (D->n_point_loads > 0 && (!D->pl_dof || !D->pl_val))) throw std::runtime_error("gf_create: a count is positive but its array is NULL");
     for (int64_t k = 0; k < D->n_zero_dofs; ++k) {
         if (D->zero_dofs[k] < 0 || D->zero_dofs[k] >= ndof) throw std::runtime_error("gf_create: zero_dofs out of range");
         zero[D->zero_dofs[k]] = 1;
@@ -224,9 +225,10 @@ inline void HostModel::build(const gf_model_desc* D) {
     // ---- mortar points ------------------------------------------------------------
     ni = D->n_interfaces;
     const int NB = (degree + 1) * (degree + 1);
+    if (ni > 0 && (!D->if_patch || !D->if_off || !D->if_xi || !D->if_tau || !D->if_wt || !D->if_alpha)) throw std::runtime_error("gf_create: n_interfaces > 0 but an interface array is NULL");
     npts = ni > 0 ? D->if_off[ni] : 0;
     if_patch.assign(D->if_patch, D->if_patch + 2 * ni); if_alpha.assign(D->if_alpha, D->if_alpha + 2 * ni);
-    if_off.assign(D->if_off, D->if_off + ni + 1);
+    if (ni > 0) if_off.assign(D->if_off, D->if_off + ni + 1); else if_off.assign(1, 0);     // the interface arrays may be NULL when there is none
     pt_iface.resize(npts); pt_base.resize(4 * npts); pt_nu.assign(size_t(npts) * 2 * 3 * NB, 0.0); pt_nu2.assign(size_t(npts) * 2 * 3 * NB, 0.0);
     pt_tau.assign(D->if_tau, D->if_tau + 2 * npts); pt_wt.assign(D->if_wt, D->if_wt + npts);
     for (int i = 0; i < ni; ++i) {

@@ -701,3 +701,13 @@ def test_moving_intersection_optimisation_finds_the_symmetric_optimum():
     out = mod.run(verbose=False)
     assert abs(out["s1"]) < 2e-3, out["s1"]
     assert out["w1"] < out["w0"]
+
+
+def test_plain_c_consumer_of_the_c_abi(tmp_path):
+    """tests/c_abi/c_consumer.c: a C program (no Python, no torch) creates a model through gf_model_desc, assembles, checks the
+    load resultant and the symmetry of K through gf_apply, and the error convention."""
+    import subprocess
+    from tests.test_host_logic import _build_c_consumer
+    out = subprocess.run([_build_c_consumer(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "c consumer ok" in out.stdout

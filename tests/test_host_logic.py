@@ -575,3 +575,21 @@ def test_small_utils_with_reference_names():
     A = sps.csr_matrix(np.array([[4, 1, 0], [2, 3, 0], [0, 1, 5.]]))
     b = np.array([1, 2, 3.])
     assert np.allclose(A @ solve_Ax_b(A, b), b) and np.allclose(A.T @ solve_ATx_b(A, b), b)
+
+
+def _build_c_consumer(tmp_path):
+    import subprocess
+    from goldfish_amd import build
+    build.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "goldfish_amd")
+    exe = os.path.join(str(tmp_path), "c_consumer")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "c_abi", "c_consumer.c"),
+                           "-o", exe, "-L" + libdir, "-lgoldfish_hip", "-lm", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_c_abi_headers_compile_and_link_from_plain_c(tmp_path):
+    """include/*.h are C99-clean and libgoldfish_hip.so links into a plain-C program (tests/c_abi/c_consumer.c); it is run on
+    the GPU box by tests/test_gpu_api.py."""
+    assert os.path.exists(_build_c_consumer(tmp_path))
