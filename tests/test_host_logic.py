@@ -593,3 +593,37 @@ def test_c_abi_headers_compile_and_link_from_plain_c(tmp_path):
     """include/*.h are C99-clean and libgoldfish_hip.so links into a plain-C program (tests/c_abi/c_consumer.c); it is run on
     the GPU box by tests/test_gpu_api.py."""
     assert os.path.exists(_build_c_consumer(tmp_path))
+
+
+def _dump_model(A, path):
+    """Flat binary of a ModelArrays in the order tests/c_abi/setup_sanitize.cpp reads it."""
+    hd = np.array([A.n_patches, A.knots.size, A.total_cp, len(A.zero_dofs), len(A.pl_dof), A.n_interfaces, A.n_mortar_points, A.n_owned], dtype=np.int64)
+    with open(path, "wb") as f:
+        for arr, dt in ((hd, np.int64), (A.degree, np.int32), (A.ncp, np.int32), (A.knot_off, np.int64), (A.knots, np.float64), (A.cp_off, np.int64),
+                        (A.weights, np.float64), (A.young, np.float64), (A.poisson, np.float64), (A.body_force, np.float64), (A.zero_dofs, np.int64),
+                        (A.pl_dof, np.int64), (A.pl_val, np.float64), (A.if_patch, np.int32), (A.if_off, np.int64), (A.if_xi, np.float64),
+                        (A.if_tau, np.float64), (A.if_wt, np.float64), (A.if_alpha, np.float64), (A.load_proj, np.float64)):
+            np.ascontiguousarray(arr, dtype=dt).tofile(f)
+
+
+def test_host_setup_under_address_and_ub_sanitizers(tmp_path):
+    """gf_setup.hpp (the host half of gf_create: element / neighbour / mortar-vertex / owner tables) built from real models
+    under ASan + UBSan: T-beam, NURBS Scordelis-Lo, the 16-patch wing with the reference's interface data (T junctions, interior
+    curves), a p = 4 shell, a shard with ghost patches, and a single patch without interfaces."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(tmp_path), "setup_sanitize")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                           os.path.join(root, "tests", "c_abi", "setup_sanitize.cpp"), "-o", exe])
+    wing = G.wing_16patch_from_interface_data(np.load(os.path.join(root, "tests", "golden", "ref_wing_int_data.npz"), allow_pickle=True))
+    shell = G.synthetic_shell(3, 2, nel=4, p=3, jitter=1)
+    models = {"tbeam4": arrays_from_spec(G.tbeam_4patch(nels=((5, 6), (6, 7), (5, 7), (6, 8)))), "slr9": arrays_from_spec(G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2])),
+              "wing16": arrays_from_spec(wing), "shell_p4": arrays_from_spec(G.synthetic_shell(2, 2, nel=3, p=4, jitter=1)),
+              "shard": sharding.shard_arrays(sharding.shard_spec(shell, 1, 2)), "single": arrays_from_spec(G.scordelis_lo_single(4))}
+    for name, A in models.items():
+        path = os.path.join(str(tmp_path), name + ".bin")
+        _dump_model(A, path)
+        out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+        assert out.returncode == 0 and "built:" in out.stdout, (name, out.stderr[-2000:])
+        assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, (name, out.stderr[-2000:])
