@@ -59,7 +59,7 @@ __device__ __forceinline__ void mfma_hazard_gap(double (&t)[9]) {
 
 // P = 3: the tile is exactly full.  P = 2: 9 basis functions / 9 Gauss points use the same code with the lanes x >= 9 and the
 // Gauss-point slots >= 9 of the third group padded by zeros (a third of the tile, still far fewer instructions than the VALU path).
-template <int P>
+template <int P, bool WITHC = true>        // WITHC = false: Newton pass (no dR/dCP): the Hc row and its MFMAs are compiled out
 __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_first, int flags, double* __restrict__ blk) {
     static_assert(P == 2 || P == 3, "one 16 x 16 tile: p <= 3");
     using Cfg = ElemCfg<P>;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
         wave_lds_sync();                                   // all three lanes hold z, Z before the record overwrites the exchange slots
         if (act) {
             const double dsel[3] = {ic == 0 ? 1.0 : 0.0, ic == 1 ? 1.0 : 0.0, ic == 2 ? 1.0 : 0.0};
-            shell_point_cols(z, Z, t, Pt.E, Pt.nu_, ic, dsel, kk == 0, im);
+            shell_point_cols<WITHC>(z, Z, t, Pt.E, Pt.nu_, ic, dsel, kk == 0, im);
             if (kk == 0) {
                 for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
                 im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     wave_lds_sync();
     GF_STAMP(1, tstamp);
 
-    const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = (flags & GF_ASM_C_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
+    const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = WITHC && (flags & GF_ASM_C_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
     const bool has_bf = (Pt.f[0] != 0.0) || (Pt.f[1] != 0.0) || (Pt.f[2] != 0.0);
     const int xb = x < NB ? x : 0, ju = xb % P1, jv = xb / P1;
     const double bval = x < NB ? 1.0 : 0.0;                  // lanes beyond the basis functions contribute zero rows / columns
@@ -220,9 +220,12 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
             for (int s = 0; s < 6; ++s) {
                 const double g = e0 * im[IM_CEZ + s] + e1 * im[IM_CEZ + 6 + s] + e2 * im[IM_CEZ + 12 + s]
                                + b0 * im[IM_CBG + s] + b1 * im[IM_CBG + 6 + s] + b2 * im[IM_CBG + 12 + s] - xfac * im[oX[s]] + dij[s % 3] * jn[s / 3];
-                const double zz = pzr * im[IM_JZJ + s] + e0 * im[IM_JDNV + s] + e1 * im[IM_JDNV + 6 + s] + e2 * im[IM_JDNV + 12 + s]
-                                - (b0 * im[IM_JDMO + s] + b1 * im[IM_JDMO + 6 + s] + b2 * im[IM_JDMO + 12 + s]);
-                gR[s] = g; hR[s] = g + zz;
+                gR[s] = g;
+                if constexpr (WITHC) {
+                    const double zz = pzr * im[IM_JZJ + s] + e0 * im[IM_JDNV + s] + e1 * im[IM_JDNV + 6 + s] + e2 * im[IM_JDNV + 12 + s]
+                                    - (b0 * im[IM_JDMO + s] + b1 * im[IM_JDMO + 6 + s] + b2 * im[IM_JDMO + 12 + s]);
+                    hR[s] = g + zz;
+                }
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {                                       // curvature columns (c, jj)
@@ -232,11 +235,13 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
 #pragma unroll
                 for (int jj = 0; jj < 3; ++jj) {
                     const double g = im[IM_N + jj] * alpha - beta * im[IM_DN + 6 * jj + rt];
-                    gR[6 + 3 * c + jj] = g; hR[6 + 3 * c + jj] = g - gam * im[IM_NB + jj];
+                    gR[6 + 3 * c + jj] = g;
+                    if constexpr (WITHC) hR[6 + 3 * c + jj] = g - gam * im[IM_NB + jj];
                 }
             }
             GF_STAMP(4, tstamp);
-            dpp_source_fence(gR); dpp_source_fence(hR);
+            dpp_source_fence(gR);
+            if constexpr (WITHC) dpp_source_fence(hR);
         }
         GF_STAMP(5, tstamp);
         // -- residual and dR/dh prefactors of basis function x at this Gauss point

@@ -254,7 +254,10 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
         const int slot = h->ev_n % 64;
         HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
         if (P == 3 && h->strip) hipLaunchKernelGGL(kl_element_strip_kernel, dim3((unsigned)(c.s1 - c.s0)), dim3(64), 0, h->stream, h->M, h->d_strips, c.s0, flags, h->d_blk);
-        else if ((P == 3 || P == 2) && h->mfma) hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3)>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+        else if ((P == 3 || P == 2) && h->mfma) {
+            if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), true>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+            else hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), false>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+        }
         else if (P == 4 && h->mfma) hipLaunchKernelGGL(kl_element_mfma4_kernel, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
         else hipLaunchKernelGGL(kl_element_kernel<P>, dim3((unsigned)ne), dim3(Cfg::NT), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
         HIPCHK(hipEventRecord(h->ev1[slot], h->stream));

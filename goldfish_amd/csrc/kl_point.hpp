@@ -190,6 +190,8 @@ GF_HD inline void shell_point(const double* z, const double* Z, double t, double
 // MFMA element kernel, which run this code in lock-step) fill the whole record.  d[i] = delta(i, ic) selects components
 // arithmetically (no register-array indexing by ic).  The scalar part is computed by every caller (same instruction
 // stream on the GPU) and written by the caller with lead = true.  Same formulas as shell_point above.
+// ref = false (Newton pass: no dR/dCP): the reference-configuration derivatives (IM_JDNV, IM_JDMO) are not produced.
+template <bool REF = true>
 GF_HD inline void shell_point_cols(const double* z, const double* Z, double t, double E, double nu, int ic, const double* d, bool lead, double* im) {
     const double f3[3] = {1.0, 1.0, 2.0};
     double nt[3], n[3], Nt[3], N[3];
@@ -218,7 +220,7 @@ GF_HD inline void shell_point_cols(const double* z, const double* Z, double t, d
     double JZ[6];
     cross3(Z + 3, N, JZ); cross3(N, Z, JZ + 3);
     double dCe[3][3], dCk[3][3];
-    for (int q = 0; q < 3; ++q) { symmv(dC[q], eps, dCe[q]); symmv(dC[q], kap, dCk[q]); }
+    if constexpr (REF) for (int q = 0; q < 3; ++q) { symmv(dC[q], eps, dCe[q]); symmv(dC[q], kap, dCk[q]); }
     double M[3];
     for (int i = 0; i < 3; ++i) M[i] = mo[0] * z[6 + i] + mo[1] * z[9 + i] + 2.0 * mo[2] * z[12 + i];
     const double Mn = dot3(M, n), ij2 = ij * ij;
@@ -253,12 +255,14 @@ GF_HD inline void shell_point_cols(const double* z, const double* Z, double t, d
         for (int k = 0; k < 3; ++k) { pe += nv[k] * ez[k]; pb += mo[k] * bg[k]; }
         im[IM_PZ + c] = J * (pe - pb);
         im[IM_JZJ + c] = dot3(d, JZ + 3 * cc) / J;
-        const double a0 = cc == 0 ? 2 * G1c : 0.0, a1 = cc == 0 ? 0.0 : 2 * G2c, a2 = cc == 0 ? G2c : G1c;
-        double ce[3], cb2[3];
-        symmv(C, eZ, ce); symmv(C, bG, cb2);
-        for (int k = 0; k < 3; ++k) {
-            im[IM_JDNV + 6 * k + c] = J * t * (dCe[0][k] * a0 + dCe[1][k] * a1 + dCe[2][k] * a2 + ce[k]);
-            im[IM_JDMO + 6 * k + c] = J * t3 * (dCk[0][k] * a0 + dCk[1][k] * a1 + dCk[2][k] * a2 + cb2[k]);
+        if constexpr (REF) {
+            const double a0 = cc == 0 ? 2 * G1c : 0.0, a1 = cc == 0 ? 0.0 : 2 * G2c, a2 = cc == 0 ? G2c : G1c;
+            double ce[3], cb2[3];
+            symmv(C, eZ, ce); symmv(C, bG, cb2);
+            for (int k = 0; k < 3; ++k) {
+                im[IM_JDNV + 6 * k + c] = J * t * (dCe[0][k] * a0 + dCe[1][k] * a1 + dCe[2][k] * a2 + ce[k]);
+                im[IM_JDMO + 6 * k + c] = J * t3 * (dCk[0][k] * a0 + dCk[1][k] * a1 + dCk[2][k] * a2 + cb2[k]);
+            }
         }
         // Hessian of M . n, column c, rows r <= c (symmetric storage): H[r][c] = Bc[r] . (Q Bc[c]) -+ skew(v)
         double QB[3];
