@@ -26,7 +26,7 @@ struct RowLane {
         oJ0 = IM_JNV + (mr == 0 ? 0 : 2); oJ1 = IM_JNV + (mr == 1 ? 1 : 2);
         for (int s = 0; s < 6; ++s) oX[s] = tang ? IM_HMN + hmn_idx(r, s) : IM_DN + 6 * ir + s;
     }
-    __device__ __forceinline__ void expand(const double* im, double (&gR)[15], double (&hR)[15]) const {
+    template <bool WITHC> __device__ __forceinline__ void expand(const double* im, double (&gR)[15], double (&hR)[15]) const {
         const double gr = im[IM_G + rt], e0 = m0 * gr, e1 = m1 * gr, e2 = mt * im[oE2];
         const double fnr = f3c * im[IM_N + ir];
         const double b0 = mt * im[IM_BG + rt] + ck[0] * fnr, b1 = mt * im[IM_BG + 6 + rt] + ck[1] * fnr, b2 = mt * im[IM_BG + 12 + rt] + ck[2] * fnr;
@@ -36,9 +36,12 @@ struct RowLane {
         for (int s = 0; s < 6; ++s) {
             const double g = e0 * im[IM_CEZ + s] + e1 * im[IM_CEZ + 6 + s] + e2 * im[IM_CEZ + 12 + s]
                            + b0 * im[IM_CBG + s] + b1 * im[IM_CBG + 6 + s] + b2 * im[IM_CBG + 12 + s] - xfac * im[oX[s]] + dij[s % 3] * jn[s / 3];
-            const double zz = pzr * im[IM_JZJ + s] + e0 * im[IM_JDNV + s] + e1 * im[IM_JDNV + 6 + s] + e2 * im[IM_JDNV + 12 + s]
-                            - (b0 * im[IM_JDMO + s] + b1 * im[IM_JDMO + 6 + s] + b2 * im[IM_JDMO + 12 + s]);
-            gR[s] = g; hR[s] = g + zz;
+            gR[s] = g;
+            if constexpr (WITHC) {
+                const double zz = pzr * im[IM_JZJ + s] + e0 * im[IM_JDNV + s] + e1 * im[IM_JDNV + 6 + s] + e2 * im[IM_JDNV + 12 + s]
+                                - (b0 * im[IM_JDMO + s] + b1 * im[IM_JDMO + 6 + s] + b2 * im[IM_JDMO + 12 + s]);
+                hR[s] = g + zz;
+            }
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -48,12 +51,14 @@ struct RowLane {
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj) {
                 const double g = im[IM_N + jj] * alpha - beta * im[IM_DN + 6 * jj + rt];
-                gR[6 + 3 * c + jj] = g; hR[6 + 3 * c + jj] = g - gam * im[IM_NB + jj];
+                gR[6 + 3 * c + jj] = g;
+                if constexpr (WITHC) hR[6 + 3 * c + jj] = g - gam * im[IM_NB + jj];
             }
         }
     }
 };
 
+template <bool WITHC = true>               // WITHC = false: Newton pass (no dR/dCP)
 __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_first, int flags, double* __restrict__ blk) {
     using Cfg = ElemCfg<4>;
     constexpr int P = 4, P1 = 5, NB = 25, NG = 25, ND = 75, NGRP = 7, NT1 = NB - 16;       // NT1: basis functions in the second tile
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
     }
     wave_lds_sync();
 
-    const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = (flags & GF_ASM_C_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
+    const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = WITHC && (flags & GF_ASM_C_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
     const bool has_bf = (Pt.f[0] != 0.0) || (Pt.f[1] != 0.0) || (Pt.f[2] != 0.0);
     // basis functions of this lane: tile 0 -> x, tile 1 -> 16 + x (padding for x >= NT1)
     const int bf[2] = {x, x < NT1 ? 16 + x : 0};
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
             // -- row r of G and Hc
             double gR[15], hR[15];
             for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
-            if (doK || doC) { RL.expand(im, gR, hR); dpp_source_fence(gR); dpp_source_fence(hR); }
+            if (doK || doC) { RL.template expand<WITHC>(im, gR, hR); dpp_source_fence(gR); if constexpr (WITHC) dpp_source_fence(hR); }
             // -- residual (first pass only) and dR/dh prefactors of both a tiles
             const LoadGeom lg = load_geom(im, Pt.pd);
             const double ls = has_bf ? load_scalar(im, lg) : 0.0;

@@ -258,7 +258,10 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
             if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), true>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
             else hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), false>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
         }
-        else if (P == 4 && h->mfma) hipLaunchKernelGGL(kl_element_mfma4_kernel, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+        else if (P == 4 && h->mfma) {
+            if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL(kl_element_mfma4_kernel<true>, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+            else hipLaunchKernelGGL(kl_element_mfma4_kernel<false>, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+        }
         else hipLaunchKernelGGL(kl_element_kernel<P>, dim3((unsigned)ne), dim3(Cfg::NT), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
         HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
         h->ev_n++;
