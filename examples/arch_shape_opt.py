@@ -108,7 +108,8 @@ class ReducedShapeProblem:
         return self.A.T @ (self.D.T @ (self.wint.dWintdCPIGA(2) - g[0]))
 
     def crown_height(self):
-        return float(self.nm.splines[1].__class__((3, 3), self.nm.splines[1].knots, self._control(1)).eval((1.0, 0.5))[2])
+        P = self.nm.splines[1]
+        return float(type(P)((P.p, P.q), P.knots, self._control(1)).eval((1.0, 0.5))[2])
 
     def _control(self, s):
         P = self.nm.splines[s]
