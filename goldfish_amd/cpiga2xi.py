@@ -46,6 +46,35 @@ class IntersectionData:
             self.intersections_type = [["surf-surf"] for _ in range(self.num_intersections_all)]
 
 
+    # ---- the reference's intersection cache (PENGoLINS preprocessor.save_intersections_data / load_intersections_data,
+    # demos_om/thickness_opt/plate/plate_const_th_opt_wint.py:187-193): an .npz with the keys name1..name6 =
+    # num_intersections, mapping_list (n x 2), physical coordinates per intersection, parametric coordinates per intersection
+    # (2 x (npts x 2)), a length per intersection, mortar_nels
+    def physical_coords(self):
+        return [np.array([self.patches[a].eval(x) for x in c[0]]) for (a, b), c in zip(self.mapping_list, self.intersections_para_coords)]
+
+    def save_intersections_data(self, filename):
+        phys = self.physical_coords()
+        para = np.empty(len(self.mapping_list), dtype=object)
+        ph = np.empty(len(self.mapping_list), dtype=object)
+        for i, c in enumerate(self.intersections_para_coords):
+            para[i] = [np.asarray(c[0]), np.asarray(c[1])]
+            ph[i] = phys[i]
+        lengths = np.array([np.linalg.norm(np.diff(x, axis=0), axis=1).sum() for x in phys])
+        np.savez(filename, name1=self.num_intersections_all, name2=np.asarray(self.mapping_list, dtype=int), name3=ph, name4=para,
+                 name5=lengths, name6=np.asarray(self.mortar_nels, dtype=int))
+
+    @classmethod
+    def load_intersections_data(cls, filename, patches, **kw):
+        d = np.load(filename, allow_pickle=True)
+        mapping = [[int(a), int(b)] for a, b in d["name2"]]
+        para = [[np.asarray(d["name4"][i][0], float), np.asarray(d["name4"][i][1], float)] for i in range(len(mapping))]
+        out = cls(patches=patches, mapping_list=mapping, intersections_para_coords=para, mortar_nels=[int(x) for x in d["name6"]], **kw)
+        if int(d["name1"]) != out.num_intersections_all:
+            raise ValueError("load_intersections_data: name1 does not match the number of interfaces in name2")
+        return out
+
+
 class CPIGA2Xi(object):
 
     def __init__(self, preprocessor, opt_surf_inds, opt_field, num_edge_pts=None):

@@ -627,3 +627,28 @@ def test_host_setup_under_address_and_ub_sanitizers(tmp_path):
                              env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
         assert out.returncode == 0 and "built:" in out.stdout, (name, out.stderr[-2000:])
         assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, (name, out.stderr[-2000:])
+
+
+def test_intersection_cache_format_round_trip_and_reference_files(tmp_path):
+    """The reference's .npz intersection cache (keys name1..name6): IntersectionData reads the two files shipped with the
+    reference (plate: 5 interfaces, wing: 62) and writes / re-reads its own in the same format."""
+    from goldfish_amd.cpiga2xi import IntersectionData
+    root = os.path.dirname(os.path.abspath(__file__))
+    plate = IntersectionData.load_intersections_data(os.path.join(root, "golden", "ref_plate_int_data.npz"), G.plate_6patch().patches)
+    assert plate.num_intersections_all == 5 and list(plate.mortar_nels) == [17, 19, 19, 17, 16]
+    assert all(c[0].shape == (n + 1, 2) for c, n in zip(plate.intersections_para_coords, plate.mortar_nels))
+    # the strips of the plate meet along x = k/6: both pre-images of a vertex are the same physical point
+    for (a, b), c in zip(plate.mapping_list, plate.intersections_para_coords):
+        XA = np.array([plate.patches[a].eval(x) for x in c[0]])
+        XB = np.array([plate.patches[b].eval(x) for x in c[1]])
+        assert np.abs(XA - XB).max() < 1e-6
+    wing = np.load(os.path.join(root, "golden", "ref_wing_int_data.npz"), allow_pickle=True)
+    assert int(wing["name1"]) == 62 == len(wing["name2"])
+    path = os.path.join(str(tmp_path), "int_data.npz")
+    plate.save_intersections_data(path)
+    again = IntersectionData.load_intersections_data(path, plate.patches)
+    assert again.mapping_list == plate.mapping_list and list(again.mortar_nels) == list(plate.mortar_nels)
+    for c0, c1 in zip(plate.intersections_para_coords, again.intersections_para_coords):
+        assert np.array_equal(c0[0], c1[0]) and np.array_equal(c0[1], c1[1])
+    d = np.load(path, allow_pickle=True)
+    assert sorted(d.files) == ["name%d" % k for k in range(1, 7)] and d["name5"].shape == (5,) and np.all(d["name5"] > 0.99)
