@@ -68,9 +68,36 @@ class ReducedThicknessProblem:
         return self.vol.dvoldh_th()
 
 
-def run(p=3, maxiter=60, lower=4e-3, upper=5e-2, verbose=True):
-    spec = G.plate_6patch(p)
-    nm = NonMatchingOptFFD.from_spec(spec)
+def problem_from_reference_files():
+    """The same problem assembled the way the demo does it: the six surfaces from the reference's IGES file
+    (demos_csdl_alpha/thickness_opt/geometry/plate_geometry.igs) and the interfaces from its intersection cache
+    (plate_int_data.npz), both committed as data under tests/golden/."""
+    from goldfish_amd.cpiga2xi import IntersectionData
+    from goldfish_amd.nonmatching_opt import PointSource, SVKResidual
+    from goldfish_amd.utils.iges import read_iges_surfaces
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    patches = read_iges_surfaces(os.path.join(gold, "ref_plate_geometry.igs"))
+    s0 = patches[0]                                                        # clampedBC of the demo (:119-133)
+    s0.add_zero_dofs(0, s0.get_side_dofs(0, 0, 1))
+    for f in (1, 2):
+        s0.add_zero_dofs(f, s0.get_side_dofs(0, 0, 2))
+    data = IntersectionData.load_intersections_data(os.path.join(gold, "ref_plate_int_data.npz"), patches)
+    nm = NonMatchingOptFFD(patches, 68e9, 1.0e-2, 0.35)
+    nm.create_mortar_meshes(data.mortar_nels)
+    nm.mortar_meshes_setup(data.mapping_list, data.intersections_para_coords, 1.0e3)
+    nm.set_residuals([SVKResidual()] * len(patches))
+    loads = G.edge_traction_point_loads(patches, 5, 0, 1, (0.0, 0.0, -100.0))
+    nm.set_point_sources([PointSource(xi, f, v) for (_, xi, f, v) in loads], [s for (s, _, _, _) in loads])
+    return nm, 1.0e-2
+
+
+def run(p=3, maxiter=60, lower=4e-3, upper=5e-2, verbose=True, from_files=False):
+    if from_files:
+        nm, h_init = problem_from_reference_files()
+        spec = type("S", (), {"h_th": h_init})()
+    else:
+        spec = G.plate_6patch(p)
+        nm = NonMatchingOptFFD.from_spec(spec)
     prob = ReducedThicknessProblem(nm)
     h0 = np.full(nm.num_splines, spec.h_th)
     v0, w0 = prob.volume(h0), prob.objective(h0)

@@ -526,6 +526,9 @@ def test_plate_thickness_optimisation_end_to_end():
     assert out["w1"] < 0.8 * out["w0"]
     assert abs(out["v1"] - out["v0"]) < 1e-8 * out["v0"]
     assert np.all(np.diff(out["h"]) <= 1e-9) and out["h"][0] > 1.5 * out["h"][-1]       # thick at the clamp, thin at the loaded edge
+    # the same problem read from the reference's own files (IGES surfaces + .npz intersection cache): same optimum
+    out2 = mod.run(maxiter=40, verbose=False, from_files=True)
+    assert np.abs(out2["h"] - out["h"]).max() < 2e-5 and abs(out2["w1"] - out["w1"]) < 1e-4 * out["w1"]
 
 
 def test_incremental_assembly_and_functional_cache():
