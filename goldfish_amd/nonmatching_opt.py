@@ -413,9 +413,15 @@ class NonMatchingOpt:
     def stress_forms(self, mode, rho, m_list, surf, measure, apply_bcs=True, gradients=True):
         ml = np.ascontiguousarray(m_list, float)
         key = ("stress", int(mode), float(rho), ml.tobytes(), int(surf), int(measure), bool(apply_bcs))
-        if not gradients and (key + (True,)) in getattr(self, "_fun_cache", {}) and getattr(self, "_fun_state", None) == (getattr(self, "_state_version", 0), id(self.dev)):
-            return self._fun_cache[key + (True,)]
+        if not gradients:                                     # a values-only request is served by a cached full evaluation
+            full = self._cached_peek(key + (True,))
+            if full is not None:
+                return full
         return self._cached(key + (bool(gradients),), lambda: self.dev.stress_forms(mode, rho, ml, surf, measure, apply_bcs=apply_bcs, gradients=gradients))
+
+    def _cached_peek(self, key):
+        tag = (getattr(self, "_state_version", 0), id(self.dev))
+        return self._fun_cache.get(key) if getattr(self, "_fun_state", None) == tag else None
 
     # ------------------------------------------------------------------ direct solves with K
     linear_solver = os.environ.get("GF_LINEAR_SOLVER", "host")     # "host": scipy SuperLU per call; "device": rocSOLVER re-factorisation
