@@ -197,8 +197,8 @@ class NonMatchingOpt:
     def set_shopt_pin_CP(self, pin_surf_inds=[], pin_dir=[], pin_side=[], pin_dofs=None, pin_vals=None):
         """nonmatching_opt.py:303-364: design control points on the edge ``pin_side`` of direction ``pin_dir`` of the listed
         patches keep their initial values (linear equality constraint ``shopt_dcppindcpsurf``)."""
-        des = [np.asarray(d).ravel() if not isinstance(d, np.ndarray) else d
-               for d in (self.cpdes_iga_dofs if isinstance(self.cpdes_iga_dofs[0], np.ndarray) else [np.concatenate(l) for l in self.cpdes_iga_dofs])]
+        # design dofs per field: flat arrays after set_shopt_align_CP, per-patch lists before
+        des = [np.asarray(d if isinstance(d, np.ndarray) else np.concatenate(d)).astype(int).ravel() for d in self.cpdes_iga_dofs]
         if pin_dofs is None:
             assert len(pin_surf_inds) == len(self.opt_field) and len(pin_dir) == len(self.opt_field) and len(pin_side) == len(self.opt_field)
             self.pin_surf_inds, self.pin_dir, self.pin_side = pin_surf_inds, pin_dir, pin_side
