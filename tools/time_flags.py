@@ -8,7 +8,7 @@ th = G.random_thickness(spec)
 D = _lib.DeviceModel(arrays_from_spec(spec, th))
 D.set_thickness(np.concatenate(th)); D.set_u(G.smooth_displacement(spec, 0.5 * spec.h_th))
 for name, fl in (("R", _lib.ASM_R), ("R+K (Newton iteration)", _lib.ASM_R | _lib.ASM_K), ("K+dRdCP+dRdh (linearize)", _lib.ASM_K | _lib.ASM_DRDCP | _lib.ASM_DRDH),
-                 ("dRdCP only", _lib.ASM_DRDCP), ("dRdh only", _lib.ASM_DRDH), ("all", _lib.ASM_ALL)):
+                 ("dRdCP+dRdh (linearize after a Newton solve: K is current)", _lib.ASM_DRDCP | _lib.ASM_DRDH), ("dRdCP only", _lib.ASM_DRDCP), ("dRdh only", _lib.ASM_DRDH), ("all", _lib.ASM_ALL)):
     for _ in range(2): D.assemble(fl)
     D.sync(); t0 = time.perf_counter()
     for _ in range(4): D.assemble(fl)
