@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(64) void pen_dxi_kernel(DevModel M, DevPenalty Q, c
 // support window adds its blocks.  Fixed visit order, nothing shared: bitwise reproducible.
 // The kernel WRITES the rows (the gather of these control points adds the shell part afterwards).
 constexpr int PEN_MAXDEG = 64 * 5;
-template <int P, int PEN_SL, bool WITHC = true>     // WITHC = false (Newton pass): no dR/dCP blocks
+template <int P, int PEN_SL, bool WITHC = true, bool WITHK = true>     // WITHC = false (Newton pass): no dR/dCP blocks; WITHK = false (linearize after a Newton solve): no K blocks
 __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q, int flags, int maxdeg, const double* __restrict__ pbuf, double* __restrict__ R,
                                                         double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1, double* __restrict__ valC2) {
     constexpr int P1 = P + 1, NB = P1 * P1;
@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
     __shared__ double s_w[4][3][32];                    // [buffer][i][0..17 wK | 18..29 wC]
     // owned slots
     int sp[PEN_SL], si[PEN_SL], sj[PEN_SL];
-    double kk[PEN_SL][9], cc[WITHC ? PEN_SL : 1][9];
+    double kk[WITHK ? PEN_SL : 1][9], cc[WITHC ? PEN_SL : 1][9];
 #pragma unroll
     for (int sl = 0; sl < PEN_SL; ++sl) {
         const int k = tid + 64 * sl;
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
             const int lb = int(bcp - Pb.cp_off);
             sp[sl] = pb; si[sl] = lb % Pb.nu; sj[sl] = lb / Pb.nu;
         }
-        for (int q = 0; q < 9; ++q) { kk[sl][q] = 0.0; if constexpr (WITHC) cc[sl][q] = 0.0; }
+        for (int q = 0; q < 9; ++q) { if constexpr (WITHK) kk[sl][q] = 0.0; if constexpr (WITHC) cc[sl][q] = 0.0; }
     }
     double racc = 0.0;                                  // tid < 3: residual entry (a, tid)
     const int iK = tid < 54 ? tid / 18 : 0, cK = tid < 54 ? tid - 18 * iK : 0, iC = tid < 36 ? tid / 12 : 0, cC = tid < 36 ? tid - 12 * iC : 0;
@@ -1070,7 +1070,8 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
             const double* na = Q.pt_nu + ((size_t)v * 2 + s) * 3 * NB; const double* pb = pbuf + (size_t)v * PB_STRIDE;
             n3[u][0] = na[al]; n3[u][1] = na[NB + al]; n3[u][2] = na[2 * NB + al];
             if (mats) {                                  // residual-only: the Hessian slots of the vertex record are not even computed
-                { const double* h = pb + PB_HYY + (9 * s + iK) * 18 + cK; hk[u][0] = h[0]; hk[u][1] = h[3 * 18]; hk[u][2] = h[6 * 18]; }
+                if constexpr (WITHK) { const double* h = pb + PB_HYY + (9 * s + iK) * 18 + cK; hk[u][0] = h[0]; hk[u][1] = h[3 * 18]; hk[u][2] = h[6 * 18]; }
+                else { hk[u][0] = hk[u][1] = hk[u][2] = 0.0; }
                 if constexpr (WITHC) { const double* h = pb + PB_HYC + (9 * s + iC) * 12 + cC; hc[u][0] = h[0]; hc[u][1] = h[3 * 12]; hc[u][2] = h[6 * 12]; }
                 else { hc[u][0] = hc[u][1] = hc[u][2] = 0.0; }
             } else { for (int q = 0; q < 3; ++q) { hk[u][q] = 0.0; hc[u][q] = 0.0; } }
@@ -1092,7 +1093,7 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
         for (int u = 0; u < 2; ++u) {
             if (u < nu_) {
                 double (*w)[32] = s_w[2 * pair + u];
-                if (mats && tid < 54) w[iK][cK] = n3[u][0] * hk[u][0] + n3[u][1] * hk[u][1] + n3[u][2] * hk[u][2];
+                if constexpr (WITHK) { if (mats && tid < 54) w[iK][cK] = n3[u][0] * hk[u][0] + n3[u][1] * hk[u][1] + n3[u][2] * hk[u][2]; }
                 if constexpr (WITHC) { if (mats && tid < 36) w[iC][18 + cC] = n3[u][0] * hc[u][0] + n3[u][1] * hc[u][1] + n3[u][2] * hc[u][2]; }
                 if (tid < 3) racc += n3[u][0] * g3[u][0] + n3[u][1] * g3[u][1] + n3[u][2] * g3[u][2];
             }
@@ -1109,7 +1110,7 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
                     if (t < 0) continue;
                     const double b0 = bv[u][sl][0], b1 = bv[u][sl][1], b2 = bv[u][sl][2];
                     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-                        kk[sl][3 * i + j] += w[i][9 * t + j] * b0 + w[i][9 * t + 3 + j] * b1 + w[i][9 * t + 6 + j] * b2;
+                        if constexpr (WITHK) kk[sl][3 * i + j] += w[i][9 * t + j] * b0 + w[i][9 * t + 3 + j] * b1 + w[i][9 * t + 6 + j] * b2;
                         if constexpr (WITHC) cc[sl][3 * i + j] += w[i][18 + 6 * t + j] * b1 + w[i][18 + 6 * t + 3 + j] * b2;
                     }
                 }
@@ -1125,7 +1126,7 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
         const int k = tid + 64 * sl;
         for (int i = 0; i < 3; ++i) {                    // every entry of the rows is written (Dirichlet rows/columns are overwritten by the gather)
             for (int j = 0; j < 3; ++j) {
-                if (flags & GF_ASM_K_BIT) valK[9 * ptr_c + (long long)i * 3 * deg_c + 3 * k + j] = kk[sl][3 * i + j];
+                if constexpr (WITHK) { if (flags & GF_ASM_K_BIT) valK[9 * ptr_c + (long long)i * 3 * deg_c + 3 * k + j] = kk[sl][3 * i + j]; }
                 if constexpr (WITHC) { if (flags & GF_ASM_C_BIT) { double* dst = j == 0 ? valC0 : (j == 1 ? valC1 : valC2); dst[3 * ptr_c + (long long)i * deg_c + k] = cc[sl][3 * i + j]; } }
             }
         }

@@ -244,10 +244,13 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
         hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf, (flags & (GF_ASM_K | GF_ASM_DRDCP)) ? 0 : 1);
         const dim3 grid((unsigned)(((h->Q.nrow_groups + 7) / 8) * 8)), blk64(64);       // multiple of 8: XCD-contiguous group ranges
         const int sl = (h->pen_maxdeg + 63) / 64;         // neighbour slots per lane, register resident
-#define GF_PEN_LAUNCH(SL, WC) hipLaunchKernelGGL((pen_owner_kernel<P, SL, WC>), grid, blk64, 0, h->stream, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \
-                                                 h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])
-        if (flags & GF_ASM_DRDCP) { if (sl <= 2) GF_PEN_LAUNCH(2, true); else if (sl == 3) GF_PEN_LAUNCH(3, true); else GF_PEN_LAUNCH(5, true); }
-        else { if (sl <= 2) GF_PEN_LAUNCH(2, false); else if (sl == 3) GF_PEN_LAUNCH(3, false); else GF_PEN_LAUNCH(5, false); }      // Newton pass
+#define GF_PEN_LAUNCH(SL, WC, WK) hipLaunchKernelGGL((pen_owner_kernel<P, SL, WC, WK>), grid, blk64, 0, h->stream, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \
+                                                     h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])
+#define GF_PEN_SLOTS(WC, WK) do { if (sl <= 2) GF_PEN_LAUNCH(2, WC, WK); else if (sl == 3) GF_PEN_LAUNCH(3, WC, WK); else GF_PEN_LAUNCH(5, WC, WK); } while (0)
+        if (!(flags & GF_ASM_DRDCP)) GF_PEN_SLOTS(false, true);                 // Newton pass
+        else if (!(flags & GF_ASM_K)) GF_PEN_SLOTS(true, false);                // linearize right after a Newton solve (K is current)
+        else GF_PEN_SLOTS(true, true);
+#undef GF_PEN_SLOTS
 #undef GF_PEN_LAUNCH
     }
     for (const Chunk& c : h->chunks) {
