@@ -41,6 +41,8 @@ struct gf_handle {
     bool strip = false;                               // p = 3 MFMA path: accumulate along element strips (GF_STRIP=1; see gf_element_strip.hpp for the measured trade-off)
     const StripDesc* d_strips = nullptr; const int* d_strip_off = nullptr;
     bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
+    bool atomic_t = false;                            // GF_ATOMIC_T=1: transposed products of dR/dCP, dR/dh by FP64 atomics (order not fixed) instead of the fixed-order gather
+    const int *d_rev_s = nullptr, *d_rev_c = nullptr;
     bool gather1 = true;                              // one-wave gather (GF_GATHER1=0 selects the four-wave gather, which the strip path also uses)
     int pen_maxdeg = 0;                               // largest neighbour count of an interface control point
 
@@ -74,6 +76,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         h->H.build(desc);
         if (const char* s = getenv("GF_ELEMENT")) h->mfma = std::string(s) != "valu";
         if (const char* s = getenv("GF_STRIP")) h->strip = std::string(s) == "1";
+        if (const char* s = getenv("GF_ATOMIC_T")) h->atomic_t = std::string(s) == "1";
         h->gather1 = h->H.degree <= 3;                    // p = 4: 25 elements x 75-wide rows per control point are bandwidth bound either way (57.9 vs 57.6 ms per step)
         if (const char* s = getenv("GF_GATHER1")) h->gather1 = std::string(s) != "0";
         h->strip = h->strip && h->mfma && h->H.degree == 3;
@@ -89,6 +92,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         DevModel& M = h->M;
         M.patches = h->upload(H.patches); M.tab = h->upload(H.tab); M.ints = h->upload(H.ints);
         M.elem_patch = h->upload(H.elem_patch); M.cp_patch = h->upload(H.cp_patch); M.edesc = h->upload(H.elem_desc); M.cpdesc = h->upload(H.cp_desc); M.nb_meta = h->upload(H.nb_meta);
+        h->d_rev_s = h->upload(H.nb_rev_s); h->d_rev_c = h->upload(H.nb_rev_c);
         M.cp4 = h->d_cp4; M.u = h->d_u; M.h = h->d_h; M.zero = h->upload(H.zero);
         M.nb_ptr_s = h->upload(nbs); M.nb_s = h->upload(H.nb_s); M.nb_ptr_c = h->upload(nbc); M.nb_c = h->upload(H.nb_c);
         M.total_cp = H.total_cp; M.nelem = H.nelem;
@@ -400,6 +404,7 @@ int gf_apply_dev(gf_handle* h, int which, int transpose, const double* x, double
     // (not on a shard: ghost rows are not assembled there, so the local K is not symmetric)
     if (which == GF_MAT_K && (!transpose || h->H.n_owned == h->H.np)) hipLaunchKernelGGL(csr_apply_kernel<3>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
     else if (!transpose) hipLaunchKernelGGL(csr_apply_kernel<1>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
+    else if (bw == 1 && !h->atomic_t) hipLaunchKernelGGL(csr_apply_tdet_kernel, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, which == GF_MAT_DRDH ? h->d_rev_s : h->d_rev_c, h->d_val[which], x, y);
     else hipLaunchKernelGGL(csr_apply_t_kernel, dim3(grid), dim3(256), 0, h->stream, nrows, ptr, nb, bw, h->d_val[which], x, y);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("gf_apply: ") + hipGetErrorString(e));

@@ -117,6 +117,7 @@ struct HostModel {
     std::vector<int64_t> pl_dof; std::vector<double> pl_val;
     // neighbour lists (CP level): shell only / shell + coupling
     std::vector<int64_t> nb_ptr_s, nb_ptr_c; std::vector<int> nb_s, nb_c;
+    std::vector<int> nb_rev_s, nb_rev_c;   // per neighbour entry (a, k) with b = nb[k]: position of a in b's list (the relation is symmetric): fixed-order transposed products
     std::vector<unsigned short> nb_meta;   // per nb_c entry: bits 0-6 box slot of the neighbour (127: coupling-only column), 7-9 Dirichlet flags of its dofs, 10 self
     // mortar points
     std::vector<int> pt_iface;          // [npts]
@@ -328,6 +329,19 @@ inline void HostModel::build(const gf_model_desc* D) {
                 }
             }
         }
+    }
+    {   // reverse indices (lists are sorted ascending)
+        auto build_rev = [&](const std::vector<int64_t>& ptr, const std::vector<int>& nb, std::vector<int>& rev) {
+            rev.assign(nb.size(), 0);
+            for (int64_t a = 0; a < total_cp; ++a) for (int64_t k = ptr[a]; k < ptr[a + 1]; ++k) {
+                const int b = nb[k];
+                const int* lo = nb.data() + ptr[b]; const int* hi = nb.data() + ptr[b + 1];
+                const int* it = std::lower_bound(lo, hi, (int)a);
+                if (it == hi || *it != (int)a) throw std::runtime_error("gf_create: neighbour relation is not symmetric");
+                rev[k] = int(it - lo);
+            }
+        };
+        build_rev(nb_ptr_s, nb_s, nb_rev_s); build_rev(nb_ptr_c, nb_c, nb_rev_c);
     }
     cp_desc.assign(total_cp, CpDesc{});
     for (int s = 0; s < np; ++s) {

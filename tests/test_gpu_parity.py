@@ -184,6 +184,9 @@ def test_apply_linear(oracle_lib):
         z = z0.copy()
         D.apply(which, xt, z, transpose=True)
         assert _rel(z, z0 + Mx.T @ xt) < 1e-12
+        z2 = z0.copy()
+        D.apply(which, xt, z2, transpose=True)
+        assert np.array_equal(z, z2)                        # fixed-order transposed products: bitwise reproducible
     with pytest.raises(ValueError):
         D.apply(0, np.zeros(3), np.zeros(A.ndof))
     D.close()
