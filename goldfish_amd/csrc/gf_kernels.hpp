@@ -1175,23 +1175,36 @@ __global__ __launch_bounds__(256) void csr_apply_kernel(long long ncp, const lon
 // its entries through the symmetric neighbour relation -- entry (row (a, i), column b) sits at position rev of a's list, where
 // rev = position of b in a's list, precomputed -- and adds them in fixed order (lane partial sums over k, fixed shuffle tree).
 // Rows with x = 0 are skipped (the ghost rows of a shard are not assembled).  Bitwise reproducible reverse-mode products.
+template <int BW>
 __global__ __launch_bounds__(256) void csr_apply_tdet_kernel(long long ncp, const long long* __restrict__ nb_ptr, const int* __restrict__ nb, const int* __restrict__ rev,
                                                               const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y) {
     const long long b = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (b >= ncp) return;
     const long long ptr = nb_ptr[b], deg = nb_ptr[b + 1] - ptr;
-    double s = 0.0;
+    double s[BW];
+#pragma unroll
+    for (int j = 0; j < BW; ++j) s[j] = 0.0;
     for (long long k = lane; k < deg; k += 64) {
         const long long a = nb[ptr + k];
         const long long pa = nb_ptr[a], da = nb_ptr[a + 1] - pa;
-        const double* v = val + 3 * pa + rev[ptr + k];
+        const double* v = val + 3 * BW * pa + BW * rev[ptr + k];         // BW = 1: dR/dCP_f, dR/dh; BW = 3: K (on a shard, where the local K is not symmetric)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { const double xv = x[3 * a + i]; if (xv != 0.0) s += v[(long long)i * da] * xv; }
+        for (int i = 0; i < 3; ++i) {
+            const double xv = x[3 * a + i];
+            if (xv != 0.0) {
+#pragma unroll
+                for (int j = 0; j < BW; ++j) s[j] += v[(long long)i * BW * da + j] * xv;
+            }
+        }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) y[b] += s;
+    for (int j = 0; j < BW; ++j) {
+        double t = s[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if (lane == 0) y[BW * b + j] += t;
+    }
 }
 
 // y += A^T x: scatter with FP64 atomics (summation order not fixed); kept for K on a shard and as GF_ATOMIC_T=1

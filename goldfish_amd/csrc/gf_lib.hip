@@ -404,7 +404,8 @@ int gf_apply_dev(gf_handle* h, int which, int transpose, const double* x, double
     // (not on a shard: ghost rows are not assembled there, so the local K is not symmetric)
     if (which == GF_MAT_K && (!transpose || h->H.n_owned == h->H.np)) hipLaunchKernelGGL(csr_apply_kernel<3>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
     else if (!transpose) hipLaunchKernelGGL(csr_apply_kernel<1>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
-    else if (bw == 1 && !h->atomic_t) hipLaunchKernelGGL(csr_apply_tdet_kernel, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, which == GF_MAT_DRDH ? h->d_rev_s : h->d_rev_c, h->d_val[which], x, y);
+    else if (bw == 1 && !h->atomic_t) hipLaunchKernelGGL(csr_apply_tdet_kernel<1>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, which == GF_MAT_DRDH ? h->d_rev_s : h->d_rev_c, h->d_val[which], x, y);
+    else if (!h->atomic_t) hipLaunchKernelGGL(csr_apply_tdet_kernel<3>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_rev_c, h->d_val[which], x, y);
     else hipLaunchKernelGGL(csr_apply_t_kernel, dim3(grid), dim3(256), 0, h->stream, nrows, ptr, nb, bw, h->d_val[which], x, y);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("gf_apply: ") + hipGetErrorString(e));
