@@ -955,7 +955,9 @@ __global__ __launch_bounds__(64) void pen_point_kernel(DevModel M, DevPenalty Q,
             }
         }
     }
-    penalty_point(y, Y, Q.pt_tau + 2 * v, Q.if_alpha[2 * itf], Q.if_alpha[2 * itf + 1], Q.pt_wt[v], pbuf + (size_t)v * PB_STRIDE, grad_only != 0);
+    // grad_only: 0 = gradient + both Hessian blocks, 1 = gradient only, 2 = gradient + Hyy (Newton pass), 3 = gradient + HyC
+    penalty_point(y, Y, Q.pt_tau + 2 * v, Q.if_alpha[2 * itf], Q.if_alpha[2 * itf + 1], Q.pt_wt[v], pbuf + (size_t)v * PB_STRIDE, grad_only == 1,
+                  grad_only == 2 ? 1 : (grad_only == 3 ? 2 : 3));
 }
 
 // Moving intersections (reference nonmatching_opt.py:1042-1341 dRIGAdxi_sub): derivative of the penalty

@@ -245,7 +245,8 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
     // by what the overlap saves (profiles/r01_v8_*).
     const int pen = (H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP))) ? 1 : 0;
     if (pen) {
-        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf, (flags & (GF_ASM_K | GF_ASM_DRDCP)) ? 0 : 1);
+        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf,
+                           !(flags & (GF_ASM_K | GF_ASM_DRDCP)) ? 1 : (!(flags & GF_ASM_DRDCP) ? 2 : (!(flags & GF_ASM_K) ? 3 : 0)));
         const dim3 grid((unsigned)(((h->Q.nrow_groups + 7) / 8) * 8)), blk64(64);       // multiple of 8: XCD-contiguous group ranges
         const int sl = (h->pen_maxdeg + 63) / 64;         // neighbour slots per lane, register resident
 #define GF_PEN_LAUNCH(SL, WC, WK) hipLaunchKernelGGL((pen_owner_kernel<P, SL, WC, WK>), grid, blk64, 0, h->stream, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \

@@ -539,7 +539,8 @@ constexpr int PB_STRIDE = PB_SIZE + 2;   // + energy + pad
 // One mortar vertex: y[18] = (uA, gA1, gA2, uB, gB1, gB2), Y[12] = (GA1, GA2, GB1, GB2).
 // out: grad[18], Hyy[18][18], HyC[18][12] where HyC = Hyy[:, tangent cols] + HyY (the dR/dCP operator).
 // grad_only: energy and gradient only (residual-only assemblies, functionals); the Hessian slots are left untouched.
-GF_HD inline void penalty_point(const double* y, const double* Y, const double* tau, double ad, double ar, double dt, double* out, bool grad_only = false) {
+// want: bit 0 = store Hyy, bit 1 = store HyC (the Newton pass needs only Hyy, linearize right after it only HyC)
+GF_HD inline void penalty_point(const double* y, const double* Y, const double* tau, double ad, double ar, double dt, double* out, bool grad_only = false, int want = 3) {
     const int tan[12] = {3, 4, 5, 6, 7, 8, 12, 13, 14, 15, 16, 17};
     double s1, s2, S1, S2, g1[12], g2[12], G1[12], G2[12], L, Lr, at[3], At[3];
     double H1[12][12], H2[12][12];
@@ -567,10 +568,10 @@ GF_HD inline void penalty_point(const double* y, const double* Y, const double* 
             if (tr < 0 && tc < 0) { if (r % 9 == c % 9) v = (r == c) ? c0 * ad : -c0 * ad; }            // displacement block: +-alpha_d I
             else if (tr >= 0 && tc >= 0) v = c0 * ar * (g1[tr] * g1[tc] + e1 * H1[tr][tc] + g2[tr] * g2[tc] + e2 * H2[tr][tc]);
             row[c] = v;
-            Hyy[r * 18 + c] = v;
+            if (want & 1) Hyy[r * 18 + c] = v;
         }
         // HyC[r][c], c over Y slots (GA1,GA2,GB1,GB2) == tangent slots of y
-        for (int c = 0; c < 12; ++c) {
+        if (want & 2) for (int c = 0; c < 12; ++c) {
             const double c0Y = c < 6 ? dt * tau[c / 3] * At[c % 3] : 0.0;
             double v = row[tan[c]] + gl[r] * c0Y / c0;
             if (tr >= 0) v -= c0 * ar * (g1[tr] * G1[c] + g2[tr] * G2[c]);
