@@ -268,3 +268,21 @@ def test_four_wave_gather_is_bitwise_the_one_wave_gather(oracle_lib, monkeypatch
             D.close()
         for x, y in zip(*out):
             assert np.array_equal(x, y), case
+
+
+def test_atomic_transposed_products_still_match(oracle_lib, monkeypatch):
+    """GF_ATOMIC_T=1 keeps the FP64-atomic scatter for the transposed products (the fixed-order gather is the default)."""
+    from goldfish_amd import _lib
+    monkeypatch.setenv("GF_ATOMIC_T", "1")
+    A, h, u = _state(G.tbeam_2patch(6), seed=4)
+    D = _lib.DeviceModel(A)
+    D.set_thickness(h)
+    D.set_u(u)
+    D.assemble()
+    rng = np.random.default_rng(10)
+    for which in (2, 4):
+        Mx = D.csr(which)
+        xt, z = rng.standard_normal(Mx.shape[0]), np.zeros(Mx.shape[1])
+        D.apply(which, xt, z, transpose=True)
+        assert _rel(z, Mx.T @ xt) < 1e-12
+    D.close()
