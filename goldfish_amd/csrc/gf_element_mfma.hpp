@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
         GF_STAMP(5, tstamp);
         // -- residual and dR/dh prefactors of basis function x at this Gauss point
         {
-            const double ls = has_bf ? load_scalar(im, load_geom(im, Pt.pd)) : 0.0;
+            const double ls = has_bf ? load_scalar(im, Pt.pd) : 0.0;
             for (int i = 0; i < 3; ++i) {
                 double rz = 0.0;
                 for (int m = 0; m < 5; ++m) rz += phi[m] * im[IM_PZ + 3 * m + i];
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
                 const LoadGeom lg = load_geom(im, Pt.pd);
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {
-                    const double jz = load_dz_dot(im, lg, f, pb[0], pb[1]);
+                    const double jz = load_dz_dot(im, Pt.pd, lg, f, pb[0], pb[1]);
                     accB[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(R0, jz, accB[f], 0, 0, 0);
                 }
             }

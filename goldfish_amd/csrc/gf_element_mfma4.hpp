@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
             if (doK || doC) { RL.template expand<WITHC>(im, gR, hR); dpp_source_fence(gR); if constexpr (WITHC) dpp_source_fence(hR); }
             // -- residual (first pass only) and dR/dh prefactors of both a tiles
             const LoadGeom lg = load_geom(im, Pt.pd);
-            const double ls = has_bf ? load_scalar(im, lg) : 0.0;
+            const double ls = has_bf ? load_scalar(im, Pt.pd) : 0.0;
             if (tb == 0) {
 #pragma unroll
                 for (int ta = 0; ta < 2; ++ta)
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
                 if (has_bf) {                    // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b)
 #pragma unroll
                     for (int f = 0; f < 3; ++f) {
-                        const double jz = load_dz_dot(im, lg, f, pb[0], pb[1]);
+                        const double jz = load_dz_dot(im, Pt.pd, lg, f, pb[0], pb[1]);
 #pragma unroll
                         for (int i = 0; i < 3; ++i) {
                             accC[0][3 * i + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pt.f[i] * R0[0], jz, accC[0][3 * i + f], 0, 0, 0);

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, (P >= 4 ? 1 : ElemCfg<P>::NT / 64))
         if (do_rz) {
             double rz = 0.0;
             for (int m = 0; m < 5; ++m) rz += s_phi[ra][m] * im[IM_PZ + 3 * m + ri];
-            accR += wq * (rz - (has_bf ? load_scalar(im, load_geom(im, Pt.pd)) : 0.0) * Pt.f[ri] * s_phi[ra][5]);
+            accR += wq * (rz - (has_bf ? load_scalar(im, Pt.pd) : 0.0) * Pt.f[ri] * s_phi[ra][5]);
         }
         if (do_rh) {
             const double p1 = s_phi[ha][0], p2 = s_phi[ha][1];
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, (P >= 4 ? 1 : ElemCfg<P>::NT / 64))
         for (int k = 0; k < AG; ++k) { const int a = ag * AG + k < NB ? ag * AG + k : NB - 1; pa0[k] = s_phi[a][5]; for (int m = 0; m < 5; ++m) pa[k][m] = s_phi[a][m]; }
         const double n0b = s_n0[b];
         double jz[3] = {0.0, 0.0, 0.0};
-        if (has_bf) { const LoadGeom lg = load_geom(im, Pt.pd); for (int f = 0; f < 3; ++f) jz[f] = load_dz_dot(im, lg, f, pb[0], pb[1]); }
+        if (has_bf) { const LoadGeom lg = load_geom(im, Pt.pd); for (int f = 0; f < 3; ++f) jz[f] = load_dz_dot(im, Pt.pd, lg, f, pb[0], pb[1]); }
 #pragma unroll
         for (int t = 0; t < NTO; ++t) {
             const int o = ag + t * LPB;
