@@ -6,7 +6,8 @@ def per_kernel(path, counter):
     tot, n = collections.defaultdict(float), collections.defaultdict(set)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter: continue
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("gf::", "").split("<")[0]
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("gf::", "")
+        if not name.startswith(("kl_", "pen_")): name = name.split("<")[0]   # the gf kernels keep their template arguments: the full-pass and Newton-pass instances move different bytes
         tot[name] += float(r["Counter_Value"]) * 1024.0
         n[name].add(r["Dispatch_Id"])
     return {k: tot[k] / max(1, len(n[k])) for k in tot}, {k: len(n[k]) for k in tot}
@@ -16,7 +17,7 @@ kern = {}
 for k in sorted(set(f) | set(w)):
     kern[k] = {"FETCH_SIZE_bytes_raw_per_launch": f.get(k, 0.0), "WRITE_SIZE_bytes_raw_per_launch": w.get(k, 0.0),
                "hbm_side_bytes_corrected_per_launch": 2 * f.get(k, 0.0) + w.get(k, 0.0), "launches": nf.get(k, nw.get(k, 0))}
-el = [k for k in kern if k.startswith("kl_element")]
+el = sorted((k for k in kern if k.startswith("kl_element")), key=lambda k: -kern[k]["hbm_side_bytes_corrected_per_launch"])   # the full-pass instance first
 out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_*.csv), bench.py C4; averages per launch. "
                "Counters are KB at the L2<->fabric interface (Infinity-Cache hits included); corrected = 2*FETCH + WRITE "
                "(gfx950: FETCH_SIZE counts 64 B per 128-B request)." % tag,
