@@ -322,8 +322,7 @@ template <int P>
 __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_first, long long e_first, long long e_count, int flags,
                                                          const double* __restrict__ blk,
                                                          double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1,
-                                                         double* __restrict__ valC2, double* __restrict__ valH, double* __restrict__ R, int pen_add,
-                                                         const StripDesc* __restrict__ strips, const int* __restrict__ strip_off) {
+                                                         double* __restrict__ valC2, double* __restrict__ valH, double* __restrict__ R, int pen_add) {
     using Cfg = ElemCfg<P>;
     constexpr int P1 = Cfg::P1, NB = Cfg::NB, ND = Cfg::ND, WB = 2 * P + 1, NBOX = WB * WB;
     const long long a = a_first + blockIdx.x;
@@ -350,68 +349,6 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
     // of the group, so up to 4 x 6 loads per lane are in flight (the adds keep the fixed element order).
     constexpr int NPASS = (ND + 63) / 64, NPH = (3 * NB + 63) / 64, UNR = 4;
     const int neu = cd.neu, nev = cd.nev, ne = neu * nev;
-    if (strips != nullptr) {
-        // Strip records (gf_element_strip.hpp): every strip eu containing a holds, per dof row i, the sums over the strip's
-        // elements against the 28 neighbours (local u index 0..3 of the strip) x (row offset -3..3).  At most p + 1 strips;
-        // all their loads are issued before the fixed-order accumulation.
-        constexpr int RS = 200, MAXS = P1;
-        const double* rec[MAXS]; int iu0s[MAXS]; bool sok[MAXS];
-#pragma unroll
-        for (int q = 0; q < MAXS; ++q) {
-            const int eu = eu0 + q; sok[q] = q < neu && ne > 0;
-            const int euc = sok[q] ? eu : eu0;
-            const StripDesc sd = strips[strip_off[cd.patch] + (ne > 0 ? euc : 0)];
-            iu0s[q] = cd.bu[sok[q] ? q : 0];
-            rec[q] = blk + sd.out_off + (size_t)((ja * 4 + (ia - iu0s[q])) * 3) * RS;
-        }
-        if (wave < 3) {
-            const int i = wave;
-            double v[MAXS][3];
-#pragma unroll
-            for (int q = 0; q < MAXS; ++q)
-#pragma unroll
-                for (int ps = 0; ps < 3; ++ps) {
-                    const int c = lane + 64 * ps;
-                    const bool on = sok[q] && c < 168 && (c < 84 ? (flags & GF_ASM_K_BIT) != 0 : (flags & GF_ASM_C_BIT) != 0);
-                    v[q][ps] = on ? rec[q][i * RS + c] : 0.0;
-                }
-#pragma unroll
-            for (int q = 0; q < MAXS; ++q)
-#pragma unroll
-                for (int ps = 0; ps < 3; ++ps) {
-                    const int c = lane + 64 * ps;
-                    if (!sok[q] || c >= 168) continue;
-                    const int cc = c < 84 ? c : c - 84, slot = cc / 3, jf = cc - 3 * slot, jb = ja + slot / 4 - 3;
-                    if (jb < j0 || jb > j1) continue;                     // rows that never share an element with a: slot not written
-                    const int ks = (iu0s[q] + slot % 4 - i0) + (jb - j0) * wbox;
-                    if (c < 84) aK[i][ks][jf] += v[q][ps]; else aC[jf][i][ks] += v[q][ps];
-                }
-        } else {
-            double vh[MAXS][2], vr[MAXS];
-#pragma unroll
-            for (int q = 0; q < MAXS; ++q) {
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int w = lane + 64 * ps;
-                    vh[q][ps] = (sok[q] && w < 84 && (flags & GF_ASM_H_BIT)) ? rec[q][(w / 28) * RS + 168 + w % 28] : 0.0;
-                }
-                vr[q] = (sok[q] && lane < 3 && (flags & GF_ASM_R_BIT)) ? rec[q][lane * RS + 196] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < MAXS; ++q) {
-                if (!sok[q]) continue;
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int w = lane + 64 * ps;
-                    if (w >= 84) continue;
-                    const int i = w / 28, slot = w - 28 * i, jb = ja + slot / 4 - 3;
-                    if (jb < j0 || jb > j1) continue;
-                    aH[i][(iu0s[q] + slot % 4 - i0) + (jb - j0) * wbox] += vh[q][ps];
-                }
-                if (lane < 3) aR[lane] += vr[q];
-            }
-        }
-    } else
     for (int g0 = 0; g0 < ne; g0 += UNR) {
         const double* Bp[UNR]; int bu[UNR], bv[UNR], al[UNR]; bool ok[UNR];
 #pragma unroll
@@ -515,7 +452,12 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
 // bandwidth when few bytes are asked for (Newton pass R + K: 5.7 ms for 42 % of the bytes of the full pass); with one wave
 // per control point 2-3x as many control points are resident per CU: R + K pass 19.7 -> 16.9 ms, dR/dh-only 10.5 -> 7.1,
 // dR/dCP-only 21.7 -> 19.1, full pass 26.4 -> 25.9 ms at C4.  Same fixed element order per accumulator slot: bitwise the
-// same sums as the four-wave kernel (which stays for GF_GATHER1=0 and the strip path).
+// same sums as the four-wave kernel (which stays for GF_GATHER1=0).
+#ifndef GF_GATHER1_UNR
+#define GF_GATHER1_UNR 4
+#endif
+// With at most 88 registers a wave of this kernel then fits next to a wave of the MFMA element kernel (424 of the 512 registers of
+// a SIMD), which is what lets the gather of one chunk run under the element kernel of the next (gf_lib.hip, overlap).
 template <int P, bool WITHC>
 __global__ __launch_bounds__(64) void kl_gather1_kernel(DevModel M, long long a_first, long long e_first, long long e_count, int flags,
                                                         const double* __restrict__ blk, double* __restrict__ valK, double* __restrict__ valC0,
@@ -537,7 +479,7 @@ __global__ __launch_bounds__(64) void kl_gather1_kernel(DevModel M, long long a_
     for (int k = lane; k < 3 * NBOX; k += 64) (&aH[0][0])[k] = 0.0;
     if (lane < 3) aR[lane] = 0.0;
     __syncthreads();
-    constexpr int NPASS = (ND + 63) / 64, NPH = (3 * NB + 63) / 64, UNR = 4;
+    constexpr int NPASS = (ND + 63) / 64, NPH = (3 * NB + 63) / 64, UNR = GF_GATHER1_UNR;
     const int neu = cd.neu, nev = cd.nev, ne = neu * nev;
     const bool doC = WITHC && (flags & GF_ASM_C_BIT) != 0;
     const bool doK = (flags & GF_ASM_K_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0, doR = (flags & GF_ASM_R_BIT) != 0;
@@ -637,9 +579,8 @@ __global__ __launch_bounds__(64) void kl_gather1_kernel(DevModel M, long long a_
 // point sums the three residual entries of its <= (p+1)^2 element blocks in the same fixed order as kl_gather_kernel.
 template <int P>
 __global__ __launch_bounds__(256) void kl_rgather_kernel(DevModel M, long long a_first, long long a_end, long long e_first, long long e_count,
-                                                          const double* __restrict__ blk, double* __restrict__ R, int pen_add) {
-    using Cfg = ElemCfg<P>;
-    constexpr int P1 = P + 1;
+                                                          const double* __restrict__ blk, double* __restrict__ R, int pen_add, int blk_stride, int off_r) {
+    constexpr int P1 = P + 1;                               // blk_stride / off_r: element-block layout (ElemCfg) or the residual-only blocks of the walking kernel
     const long long a = a_first + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= a_end) return;
     const PatchDev& Pt = M.patches[M.cp_patch[a]];
@@ -650,7 +591,7 @@ __global__ __launch_bounds__(256) void kl_rgather_kernel(DevModel M, long long a
         const long long e = Pt.elem_off + eu + (long long)ev * Pt.nelu - e_first;
         if (e < 0 || e >= e_count) continue;
         const int al = (ia - (spu[eu] - P)) + (ja - (spv[ev] - P)) * P1;
-        const double* B = blk + (size_t)e * Cfg::BLK + Cfg::OFF_R + 3 * al;
+        const double* B = blk + (size_t)e * blk_stride + off_r + 3 * al;
         for (int i = 0; i < 3; ++i) acc[i] += B[i];
     }
     const bool padd = pen_add && M.pen_row[a];
@@ -1024,7 +965,9 @@ __global__ __launch_bounds__(64) void pen_dxi_kernel(DevModel M, DevPenalty Q, c
 // support window adds its blocks.  Fixed visit order, nothing shared: bitwise reproducible.
 // The kernel WRITES the rows (the gather of these control points adds the shell part afterwards).
 constexpr int PEN_MAXDEG = 64 * 5;
-template <int P, int PEN_SL, bool WITHC = true, bool WITHK = true>     // WITHC = false (Newton pass): no dR/dCP blocks; WITHK = false (linearize after a Newton solve): no K blocks
+// ADD = true (walking element kernel: the shell part is already in the CSR arrays, Dirichlet entries included): the blocks are
+// added to the box entries that are not Dirichlet-constrained, and the coupling-only entries are written (0 where constrained).
+template <int P, int PEN_SL, bool WITHC = true, bool WITHK = true, bool ADD = false>     // WITHC = false (Newton pass): no dR/dCP blocks; WITHK = false (linearize after a Newton solve): no K blocks
 __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q, int flags, int maxdeg, const double* __restrict__ pbuf, double* __restrict__ R,
                                                         double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1, double* __restrict__ valC2) {
     constexpr int P1 = P + 1, NB = P1 * P1;
@@ -1126,6 +1069,24 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
     for (int sl = 0; sl < PEN_SL; ++sl) {
         if (sl * 64 >= maxdeg || sp[sl] < 0) continue;
         const int k = tid + 64 * sl;
+        if constexpr (ADD) {
+            const unsigned meta = M.nb_meta[ptr_c + k];
+            const bool inbox = (meta & 127u) != 127u;
+            for (int i = 0; i < 3; ++i) {
+                const bool zrow = M.zero[3 * (long long)a + i] != 0;
+                for (int j = 0; j < 3; ++j) {
+                    if constexpr (WITHK) if (flags & GF_ASM_K_BIT) {
+                        double* dst = valK + 9 * ptr_c + (long long)i * 3 * deg_c + 3 * k + j;
+                        const bool bc = zrow || (meta & (128u << j));
+                        if (inbox) { if (!bc) *dst += kk[sl][3 * i + j]; } else *dst = bc ? 0.0 : kk[sl][3 * i + j];
+                    }
+                    if constexpr (WITHC) if (flags & GF_ASM_C_BIT) {
+                        double* dst = (j == 0 ? valC0 : (j == 1 ? valC1 : valC2)) + 3 * ptr_c + (long long)i * deg_c + k;
+                        if (inbox) { if (!zrow) *dst += cc[sl][3 * i + j]; } else *dst = zrow ? 0.0 : cc[sl][3 * i + j];
+                    }
+                }
+            }
+        } else
         for (int i = 0; i < 3; ++i) {                    // every entry of the rows is written (Dirichlet rows/columns are overwritten by the gather)
             for (int j = 0; j < 3; ++j) {
                 if constexpr (WITHK) { if (flags & GF_ASM_K_BIT) valK[9 * ptr_c + (long long)i * 3 * deg_c + 3 * k + j] = kk[sl][3 * i + j]; }

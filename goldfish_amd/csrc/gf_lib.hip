@@ -14,7 +14,7 @@ constexpr int GF_ASM_R_BIT = 1, GF_ASM_K_BIT = 2, GF_ASM_C_BIT = 4, GF_ASM_H_BIT
 #include "gf_kernels.hpp"
 #include "gf_element_mfma.hpp"
 #include "gf_element_mfma4.hpp"
-#include "gf_element_strip.hpp"
+#include "gf_element_walk.hpp"
 
 using namespace gf;
 
@@ -22,10 +22,14 @@ static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return 1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
-struct Chunk { int p0, p1; long long e0, e1, a0, a1; int s0 = 0, s1 = 0; };     // s0..s1: strips of the chunk
+struct Chunk { int p0, p1; long long e0, e1, a0, a1; };
 
 struct gf_handle {
     int device = 0; hipStream_t stream = nullptr;
+    // Overlap of the two halves of a pass (element-block path): the gather of chunk c runs on a second stream next to the
+    // element kernel of chunk c + 1 -- the element kernel holds one wave per SIMD (424 of its 512 registers) and is FP64 bound,
+    // the gather is bandwidth bound and its waves fit the remaining registers.  Two block buffers alternate.
+    hipStream_t stream_g = nullptr; double* d_blk2 = nullptr; std::vector<hipEvent_t> ev_e, ev_g; hipEvent_t ev_join = nullptr; bool overlap = false;
     HostModel H;
     std::vector<void*> allocs; long long bytes = 0;
     DevModel M{}; DevPenalty Q{};
@@ -38,12 +42,12 @@ struct gf_handle {
     std::vector<Chunk> chunks;
     std::vector<hipEvent_t> ev0, ev1; int ev_n = 0;   // element-kernel timing
     bool assembled[5] = {false, false, false, false, false};
-    bool strip = false;                               // p = 3 MFMA path: accumulate along element strips (GF_STRIP=1; see gf_element_strip.hpp for the measured trade-off)
-    const StripDesc* d_strips = nullptr; const int* d_strip_off = nullptr;
+    bool walk = false;                                // GF_WALK=1 (p = 2, 3, MFMA path): walk element strips and accumulate straight into the CSR arrays (gf_element_walk.hpp: a quarter of the device memory, half the traffic, currently slower)
+    const WalkItem* d_walk_items = nullptr; const RowDesc* d_row_desc = nullptr; const WalkPatch* d_walk_patch = nullptr;
     bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
     bool atomic_t = false;                            // GF_ATOMIC_T=1: transposed products of dR/dCP, dR/dh by FP64 atomics (order not fixed) instead of the fixed-order gather
     const int *d_rev_s = nullptr, *d_rev_c = nullptr;
-    bool gather1 = true;                              // one-wave gather (GF_GATHER1=0 selects the four-wave gather, which the strip path also uses)
+    bool gather1 = true;                              // one-wave gather (GF_GATHER1=0 selects the four-wave gather)
     int pen_maxdeg = 0;                               // largest neighbour count of an interface control point
 
     template <class T> T* dalloc(size_t n) {
@@ -75,12 +79,17 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         HIPCHK(hipStreamCreate(&h->stream));
         h->H.build(desc);
         if (const char* s = getenv("GF_ELEMENT")) h->mfma = std::string(s) != "valu";
-        if (const char* s = getenv("GF_STRIP")) h->strip = std::string(s) == "1";
         if (const char* s = getenv("GF_ATOMIC_T")) h->atomic_t = std::string(s) == "1";
         h->gather1 = h->H.degree <= 3;                    // p = 4: 25 elements x 75-wide rows per control point are bandwidth bound either way (57.9 vs 57.6 ms per step)
         if (const char* s = getenv("GF_GATHER1")) h->gather1 = std::string(s) != "0";
-        h->strip = h->strip && h->mfma && h->H.degree == 3;
         HostModel& H = h->H;
+        {
+            bool want = false;
+            if (const char* s = getenv("GF_WALK")) want = h->mfma && H.degree <= 3 && std::string(s) == "1";
+            int seg = 12;
+            if (const char* s = getenv("GF_WALK_SEG")) seg = std::max(1, atoi(s));
+            if (want) { H.build_walk(seg); h->walk = H.walk_ok; }
+        }
         std::vector<long long> nbs(H.nb_ptr_s.begin(), H.nb_ptr_s.end()), nbc(H.nb_ptr_c.begin(), H.nb_ptr_c.end());
         h->d_cp4 = h->dalloc<double>(4 * H.total_cp); h->d_u = h->dalloc<double>(H.ndof); h->d_h = h->dalloc<double>(H.total_cp); h->d_R = h->dalloc<double>(H.ndof);
         {   // weights into the 4th slot, rest zero until gf_set_cp
@@ -132,10 +141,22 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         M.pen_row = h->upload(pen_row);
         // element-block scratch, chunked over whole patches
         const int P = H.degree, NB = (P + 1) * (P + 1), ND = 3 * NB;
-        const long long blk_doubles = 2LL * ND * ND + (long long)ND * NB + ND;
+        const long long blk_doubles = h->walk ? (long long)ND : 2LL * ND * ND + (long long)ND * NB + ND;   // walking kernel: residual entries only
         double budget_gb = 40.0;
         if (const char* s = getenv("GF_SCRATCH_GB")) budget_gb = atof(s);
-        const long long max_elems = std::max<long long>(1, (long long)(budget_gb * 1e9 / (blk_doubles * 8.0)));
+        if (h->walk) budget_gb = 1e9;                     // no element blocks: one chunk
+        long long max_elems = std::max<long long>(1, (long long)(budget_gb * 1e9 / (blk_doubles * 8.0)));
+        {   // GF_OVERLAP=1: element kernel and gather overlapped over GF_CHUNKS chunks of whole patches (measured at C4: no gain,
+            // 25.6 vs 25.9 ms -- the element kernel slows down by what the gather hides, profiles/r02_overlap_*; off by default)
+            int nch = 8;
+            if (const char* s = getenv("GF_CHUNKS")) nch = std::max(1, atoi(s));
+            if (const char* s = getenv("GF_OVERLAP")) h->overlap = std::string(s) == "1" && !h->walk && H.n_owned >= 2 * nch;
+            if (h->overlap) {
+                long long tot = 0;
+                for (int s = 0; s < H.n_owned; ++s) tot += (long long)H.patches[s].nelu * H.patches[s].nelv;
+                max_elems = std::min(max_elems, (tot + nch - 1) / nch);
+            }
+        }
         long long biggest = 0;
         for (int s = 0; s < H.n_owned;) {
             Chunk c; c.p0 = s; c.e0 = H.patches[s].elem_off; c.a0 = H.patches[s].cp_off;
@@ -149,17 +170,20 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             h->chunks.push_back(c); biggest = std::max(biggest, ne);
         }
         long long scratch_doubles = biggest * blk_doubles;
-        if (h->strip) {                               // strip records instead of element blocks: offsets relative to the chunk's scratch base
-            scratch_doubles = 0;
-            for (Chunk& c : h->chunks) {
-                long long off = 0;
-                c.s0 = H.strip_off[c.p0]; c.s1 = H.strip_off[c.p1];
-                for (int s = c.s0; s < c.s1; ++s) { H.strips[s].out_off = off; off += (long long)H.strips[s].nv * 12 * STRIP_RS; }
-                scratch_doubles = std::max(scratch_doubles, off);
-            }
-            h->d_strips = h->upload(H.strips); h->d_strip_off = h->upload(H.strip_off);
+        if (h->walk) {
+            scratch_doubles = std::max<long long>(scratch_doubles, H.nelem * (long long)(11 * NB + 2));   // the functionals' element blocks (FunCfg::STRIDE) share the scratch
+            h->d_walk_items = h->upload(H.walk_items); h->d_row_desc = h->upload(H.row_desc);
+            h->d_walk_patch = h->upload(H.walk_patch);
         }
         h->d_blk = h->dalloc<double>((size_t)scratch_doubles);
+        h->overlap = h->overlap && h->chunks.size() >= 2;
+        if (h->overlap) {
+            h->d_blk2 = h->dalloc<double>((size_t)scratch_doubles);
+            HIPCHK(hipStreamCreate(&h->stream_g));
+            h->ev_e.resize(h->chunks.size()); h->ev_g.resize(h->chunks.size());
+            for (size_t k = 0; k < h->chunks.size(); ++k) { HIPCHK(hipEventCreateWithFlags(&h->ev_e[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_g[k], hipEventDisableTiming)); }
+            HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
         h->ev0.resize(64); h->ev1.resize(64);
         for (int k = 0; k < 64; ++k) { HIPCHK(hipEventCreate(&h->ev0[k])); HIPCHK(hipEventCreate(&h->ev1[k])); }
         HIPCHK(hipDeviceSynchronize());
@@ -178,6 +202,10 @@ void gf_destroy(gf_handle* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto e : h->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : h->ev1) if (e) (void)hipEventDestroy(e);
+    for (auto e : h->ev_e) if (e) (void)hipEventDestroy(e);
+    for (auto e : h->ev_g) if (e) (void)hipEventDestroy(e);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->stream_g) (void)hipStreamDestroy(h->stream_g);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -236,20 +264,17 @@ int gf_pattern(const gf_handle* h, int which, int64_t* rowptr, int32_t* col) {
 
 }  // extern "C"
 
-template <int P> static void run_assemble(gf_handle* h, int flags) {
-    using Cfg = ElemCfg<P>;
+// Penalty kernels of one pass.  ADD = false: pen_owner_kernel WRITES the rows of the interface control points and the gather adds the
+// shell part afterwards; ADD = true (walking element kernel): the shell part is in place and the blocks are added to it.
+template <int P, bool ADD> static int run_penalty(gf_handle* h, int flags) {
     const HostModel& H = h->H;
-    // Penalty rows first: pen_owner_kernel WRITES the rows of the interface control points, the gather adds the shell part to
-    // them (no read-modify-write pass over those rows afterwards).  Running the penalty kernels on a second stream was measured
-    // and dropped: next to the element kernel they cost it LDS occupancy (17.7 -> 22.8 ms), next to the gather both slow down
-    // by what the overlap saves (profiles/r01_v8_*).
     const int pen = (H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP))) ? 1 : 0;
     if (pen) {
         hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf,
                            !(flags & (GF_ASM_K | GF_ASM_DRDCP)) ? 1 : (!(flags & GF_ASM_DRDCP) ? 2 : (!(flags & GF_ASM_K) ? 3 : 0)));
         const dim3 grid((unsigned)(((h->Q.nrow_groups + 7) / 8) * 8)), blk64(64);       // multiple of 8: XCD-contiguous group ranges
         const int sl = (h->pen_maxdeg + 63) / 64;         // neighbour slots per lane, register resident
-#define GF_PEN_LAUNCH(SL, WC, WK) hipLaunchKernelGGL((pen_owner_kernel<P, SL, WC, WK>), grid, blk64, 0, h->stream, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \
+#define GF_PEN_LAUNCH(SL, WC, WK) hipLaunchKernelGGL((pen_owner_kernel<P, SL, WC, WK, ADD>), grid, blk64, 0, h->stream, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \
                                                      h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])
 #define GF_PEN_SLOTS(WC, WK) do { if (sl <= 2) GF_PEN_LAUNCH(2, WC, WK); else if (sl == 3) GF_PEN_LAUNCH(3, WC, WK); else GF_PEN_LAUNCH(5, WC, WK); } while (0)
         if (!(flags & GF_ASM_DRDCP)) GF_PEN_SLOTS(false, true);                 // Newton pass
@@ -258,40 +283,86 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
 #undef GF_PEN_SLOTS
 #undef GF_PEN_LAUNCH
     }
-    for (const Chunk& c : h->chunks) {
+    return pen;
+}
+
+static void finish_residual(gf_handle* h) {
+    const HostModel& H = h->H;
+    const long long npl = (long long)H.pl_dof.size();
+    if (npl > 0) hipLaunchKernelGGL(residual_finish_kernel, dim3((unsigned)((npl + 255) / 256)), dim3(256), 0, h->stream, (long long)H.ndof, h->M.zero, npl, h->d_pl_dof, h->d_pl_val, h->d_R);
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((H.ndof + 255) / 256)), dim3(256), 0, h->stream, (long long)H.ndof, h->M.zero, h->d_R);
+}
+
+// Walking element kernel (gf_element_walk.hpp): the classes of work items in ascending order, then the penalty blocks are added,
+// then the residual-only gather.  One timed "launch" of the dominant kernel = the class launches of one pass.
+template <int P> static void run_assemble_walk(gf_handle* h, int flags) {
+    constexpr int PW = P == 2 ? 2 : 3;
+    const HostModel& H = h->H;
+    const WalkOut O{h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_blk, h->d_walk_patch};
+    const int slot = h->ev_n % 64;
+    HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
+    for (size_t c = 0; c + 1 < H.walk_cls_off.size(); ++c) {
+        const int i0 = H.walk_cls_off[c], n = H.walk_cls_off[c + 1] - i0;
+        if (n <= 0) continue;
+        if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_walk_kernel<PW, true>), dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_walk_items, i0, flags, h->d_row_desc, O);
+        else hipLaunchKernelGGL((kl_element_walk_kernel<PW, false>), dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_walk_items, i0, flags, h->d_row_desc, O);
+    }
+    HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
+    h->ev_n++;
+    const int pen = run_penalty<P, true>(h, flags);
+    if (flags & GF_ASM_R) {
+        const Chunk& c = h->chunks[0];
         const long long ne = c.e1 - c.e0, na = c.a1 - c.a0;
+        hipLaunchKernelGGL(kl_rgather_kernel<P>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, h->d_blk, h->d_R, pen, 3 * (P + 1) * (P + 1), 0);
+        finish_residual(h);
+    }
+    HIPCHK(hipGetLastError());
+}
+
+template <int P> static void run_assemble(gf_handle* h, int flags) {
+    using Cfg = ElemCfg<P>;
+    const HostModel& H = h->H;
+    // Penalty rows first: pen_owner_kernel WRITES the rows of the interface control points, the gather adds the shell part to
+    // them (no read-modify-write pass over those rows afterwards).  Running the penalty kernels on a second stream was measured
+    // and dropped: next to the element kernel they cost it LDS occupancy (17.7 -> 22.8 ms), next to the gather both slow down
+    // by what the overlap saves (profiles/r01_v8_*).
+    if ((P == 2 || P == 3) && h->walk) { run_assemble_walk<P>(h, flags); return; }
+    const int pen = run_penalty<P, false>(h, flags);
+    for (size_t ci = 0; ci < h->chunks.size(); ++ci) {
+        const Chunk& c = h->chunks[ci];
+        const long long ne = c.e1 - c.e0, na = c.a1 - c.a0;
+        double* const blk = (h->overlap && (ci & 1)) ? h->d_blk2 : h->d_blk;
+        hipStream_t gs = h->overlap ? h->stream_g : h->stream;                 // stream of the gather
+        if (h->overlap && ci >= 2) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_g[ci - 2], 0));   // the block buffer is free again
         const int slot = h->ev_n % 64;
         HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
-        if (P == 3 && h->strip) hipLaunchKernelGGL(kl_element_strip_kernel, dim3((unsigned)(c.s1 - c.s0)), dim3(64), 0, h->stream, h->M, h->d_strips, c.s0, flags, h->d_blk);
-        else if ((P == 3 || P == 2) && h->mfma) {
-            if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), true>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
-            else hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), false>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+        if ((P == 3 || P == 2) && h->mfma) {
+            if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), true>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, blk);
+            else hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), false>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, blk);
         }
         else if (P == 4 && h->mfma) {
-            if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL(kl_element_mfma4_kernel<true>, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
-            else hipLaunchKernelGGL(kl_element_mfma4_kernel<false>, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+            if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL(kl_element_mfma4_kernel<true>, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, blk);
+            else hipLaunchKernelGGL(kl_element_mfma4_kernel<false>, dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, blk);
         }
-        else hipLaunchKernelGGL(kl_element_kernel<P>, dim3((unsigned)ne), dim3(Cfg::NT), 0, h->stream, h->M, (int)c.e0, flags, h->d_blk);
+        else hipLaunchKernelGGL(kl_element_kernel<P>, dim3((unsigned)ne), dim3(Cfg::NT), 0, h->stream, h->M, (int)c.e0, flags, blk);
         HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
         h->ev_n++;
-        if (flags == GF_ASM_R && !(P == 3 && h->strip))
-            hipLaunchKernelGGL(kl_rgather_kernel<P>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, h->d_blk, h->d_R, pen);
-        else if (!(flags & GF_ASM_DRDCP) && !(P == 3 && h->strip) && h->gather1)      // one wave per control point; without dR/dCP (Newton pass) the leaner instance
-            hipLaunchKernelGGL((kl_gather1_kernel<P, false>), dim3((unsigned)na), dim3(64), 0, h->stream, h->M, c.a0, c.e0, ne, flags, h->d_blk,
+        if (h->overlap) { HIPCHK(hipEventRecord(h->ev_e[ci], h->stream)); HIPCHK(hipStreamWaitEvent(gs, h->ev_e[ci], 0)); }
+        if (flags == GF_ASM_R)
+            hipLaunchKernelGGL(kl_rgather_kernel<P>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, gs, h->M, c.a0, c.a1, c.e0, ne, blk, h->d_R, pen, Cfg::BLK, Cfg::OFF_R);
+        else if (!(flags & GF_ASM_DRDCP) && h->gather1)      // one wave per control point; without dR/dCP (Newton pass) the leaner instance
+            hipLaunchKernelGGL((kl_gather1_kernel<P, false>), dim3((unsigned)na), dim3(64), 0, gs, h->M, c.a0, c.e0, ne, flags, blk,
                                h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R, pen);
-        else if (!(P == 3 && h->strip) && h->gather1)
-            hipLaunchKernelGGL((kl_gather1_kernel<P, true>), dim3((unsigned)na), dim3(64), 0, h->stream, h->M, c.a0, c.e0, ne, flags, h->d_blk,
+        else if (h->gather1)
+            hipLaunchKernelGGL((kl_gather1_kernel<P, true>), dim3((unsigned)na), dim3(64), 0, gs, h->M, c.a0, c.e0, ne, flags, blk,
                                h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R, pen);
         else
-        hipLaunchKernelGGL(kl_gather_kernel<P>, dim3((unsigned)na), dim3(256), 0, h->stream, h->M, c.a0, c.e0, ne, flags, h->d_blk,
-                           h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R, pen,
-                           (P == 3 && h->strip) ? h->d_strips : nullptr, h->d_strip_off);
+        hipLaunchKernelGGL(kl_gather_kernel<P>, dim3((unsigned)na), dim3(256), 0, gs, h->M, c.a0, c.e0, ne, flags, blk,
+                           h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R, pen);
+        if (h->overlap) HIPCHK(hipEventRecord(h->ev_g[ci], gs));
     }
-    if (flags & GF_ASM_R) {
-        const long long npl = (long long)H.pl_dof.size();
-        if (npl > 0) hipLaunchKernelGGL(residual_finish_kernel, dim3((unsigned)((npl + 255) / 256)), dim3(256), 0, h->stream, (long long)H.ndof, h->M.zero, npl, h->d_pl_dof, h->d_pl_val, h->d_R);
-        hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((H.ndof + 255) / 256)), dim3(256), 0, h->stream, (long long)H.ndof, h->M.zero, h->d_R);
-    }
+    if (h->overlap) { HIPCHK(hipEventRecord(h->ev_join, h->stream_g)); HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0)); }   // the pass ends on the main stream
+    if (flags & GF_ASM_R) finish_residual(h);
     HIPCHK(hipGetLastError());
 }
 
@@ -448,6 +519,8 @@ double gf_kernel_ms(gf_handle* h, int* n_launches) {
     h->ev_n = 0;
     return n > 0 ? tot / n : 0.0;
 }
+
+int gf_assembly_path(const gf_handle* h) { return !h ? -1 : (h->walk ? 2 : (h->mfma ? 0 : 3)); }
 
 int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, double* dCdu, double* dCdcp, int apply_bcs) {
     if (!h || !forces || !C) return fail("gf_compliance: null argument");

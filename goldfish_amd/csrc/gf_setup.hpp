@@ -38,8 +38,18 @@ struct ElemDesc { int patch, g0, nu, tabu, tabv, wu, wv, pad; };   // g0: global
 // cp_patch -> patch -> c2u/c2v -> span-table chain of dependent loads
 struct CpDesc { int patch, ia, ja, eu0, neu, ev0, nev, i0, j0, i1, j1, nelu; long long e00; int bu[5], bv[5]; };   // bu[k] = first CP index of element eu0 + k
 
-// one strip of elements (fixed u-span eu of a patch, all v-spans) of the strip-accumulating element kernel
-struct StripDesc { int patch, eu, e_first, nelv, nv, pad; long long out_off; };   // out_off: doubles from the chunk's scratch base
+// Walking element kernel (gf_element_walk.hpp): per-control-point row descriptor -- where the rows of a control point sit in
+// the CSR value arrays, its neighbour box, its element ranges and its Dirichlet flags, in one 64-byte record.
+//   entry of box slot s in a's coupled neighbour list = pre + s (the coupling-only neighbours of other patches sort in front
+//   of / behind the box; checked in HostModel::build, walk_ok); in the shell-only list the entry IS the slot.
+//   offK / offC / offH: position (in doubles, relative to the patch's first row: WalkPatch) of the first box entry of row (a, 0) in
+//   the K, dR/dCP_f and dR/dh value arrays; row (a, i) follows at + i * 3 deg_c, + i * deg_c, + i * deg_s.
+struct RowDesc { int offK, deg_c, offC, offH, deg_s, i0, j0, wbox, flags, lou, hiu, lov, hiv, pre, pad0, pad1; };   // flags: bits 0-2 Dirichlet dofs
+// per patch: where its rows start in the value arrays (doubles) and how many bytes they span (buffer-resource range of the kernel)
+struct WalkPatch { long long kbase, cbase, hbase; unsigned kbytes, cbytes, hbytes, pad; };
+// one work item of the walking kernel: the elements ev0 .. ev0 + nel - 1 of the strip eu of a patch; items of one class
+// (cls = (eu mod (p+1)) * 2 + (seg & 1)) share no control-point pair, classes are launched in ascending order
+struct WalkItem { int patch, eu, ev0, nel, seg, cls, iu0, pad; };
 
 struct PenRowItem { int a, code, lo, hi; };           // code = iface*2 + s
 // one (owned control point, mortar vertex) visit of the penalty row kernel: everything the kernel needs to address the
@@ -110,7 +120,11 @@ struct HostModel {
     std::vector<int> elem_patch;        // [nelem]
     std::vector<ElemDesc> elem_desc;    // [nelem]
     std::vector<CpDesc> cp_desc;        // [total_cp]
-    std::vector<StripDesc> strips; std::vector<int> strip_off;   // owned patches' strips (patch-major), first strip of every patch
+    std::vector<RowDesc> row_desc;      // [total_cp] (walking element kernel)
+    std::vector<WalkPatch> walk_patch;  // [np]
+    std::vector<WalkItem> walk_items; std::vector<int> walk_cls_off;   // items sorted by class; walk_cls_off[c] .. [c + 1]
+    bool walk_ok = false;               // the walking kernel's addressing assumptions hold for this model
+    void build_walk(int seg_len);
     std::vector<int> cp_patch;          // [total_cp]
     std::vector<double> weights;
     std::vector<unsigned char> zero;    // [ndof]
@@ -186,14 +200,6 @@ inline void HostModel::build(const gf_model_desc* D) {
     if (nelem >= (int64_t(1) << 31)) throw std::runtime_error("gf_create: too many elements");
     elem_patch.resize(nelem);
     for (int s = 0; s < np; ++s) std::fill(elem_patch.begin() + patches[s].elem_off, elem_patch.begin() + patches[s].elem_off + int64_t(patches[s].nelu) * patches[s].nelv, s);
-    strips.clear(); strip_off.assign(np + 1, 0);
-    for (int s = 0; s < np; ++s) {
-        strip_off[s] = (int)strips.size();
-        if (s >= n_owned) continue;
-        const PatchDev& P = patches[s];
-        for (int eu = 0; eu < P.nelu; ++eu) strips.push_back({s, eu, int(P.elem_off + eu), P.nelv, P.nv, 0, 0});
-    }
-    strip_off[np] = (int)strips.size();
     elem_desc.resize(nelem);
     for (int s = 0; s < np; ++s) {
         const PatchDev& P = patches[s];
@@ -406,6 +412,54 @@ inline void HostModel::build(const gf_model_desc* D) {
             ent_ptr.push_back((int64_t)pen_entries.size()); row_cp.push_back(a);
         }
     }
+}
+
+// Tables of the walking element kernel.  seg_len: target number of elements per work item along the walk direction (v).
+inline void HostModel::build_walk(int seg_len) {
+    walk_ok = degree >= 2 && degree <= 3;
+    row_desc.assign(total_cp, RowDesc{}); walk_patch.assign(np, WalkPatch{});
+    for (int s = 0; s < np && walk_ok; ++s) {
+        const PatchDev& P = patches[s];
+        const int *c2u = &ints[P.c2u], *c2v = &ints[P.c2v];
+        const int64_t a0 = P.cp_off, a1 = P.cp_off + int64_t(P.nu) * P.nv, pc0 = nb_ptr_c[a0], ps0 = nb_ptr_s[a0];
+        if ((nb_ptr_c[a1] - pc0) * 72 >= (int64_t(1) << 32) - 4096 || (nb_ptr_s[a1] - ps0) * 24 >= (int64_t(1) << 32) - 4096) { walk_ok = false; break; }   // 32-bit byte offsets inside a patch
+        walk_patch[s] = {9 * pc0, 3 * pc0, 3 * ps0, unsigned((nb_ptr_c[a1] - pc0) * 72), unsigned((nb_ptr_c[a1] - pc0) * 24), unsigned((nb_ptr_s[a1] - ps0) * 24), 0};
+        for (int j = 0; j < P.nv; ++j) for (int i = 0; i < P.nu; ++i) {
+            const int64_t a = P.cp_off + i + int64_t(j) * P.nu;
+            const CpDesc& c = cp_desc[a];
+            RowDesc& r = row_desc[a];
+            r.deg_c = int(nb_ptr_c[a + 1] - nb_ptr_c[a]); r.deg_s = int(nb_ptr_s[a + 1] - nb_ptr_s[a]);
+            r.i0 = c.i0; r.j0 = c.j0; r.wbox = c.i1 - c.i0 + 1;
+            r.flags = (zero[3 * a] ? 1 : 0) | (zero[3 * a + 1] ? 2 : 0) | (zero[3 * a + 2] ? 4 : 0);
+            r.lou = c2u[2 * i]; r.hiu = c2u[2 * i + 1]; r.lov = c2v[2 * j]; r.hiv = c2v[2 * j + 1];
+            int pre = 0;
+            for (int64_t k = nb_ptr_c[a]; k < nb_ptr_c[a + 1] && nb_c[k] < P.cp_off; ++k) ++pre;
+            r.pre = pre;
+            r.offK = int(9 * (nb_ptr_c[a] - pc0) + 3 * pre); r.offC = int(3 * (nb_ptr_c[a] - pc0) + pre); r.offH = int(3 * (nb_ptr_s[a] - ps0));
+            for (int64_t k = nb_ptr_c[a]; k < nb_ptr_c[a + 1]; ++k) {
+                const int slot = nb_meta[k] & 127;
+                if (slot != 127 && int(k - nb_ptr_c[a]) != pre + slot) walk_ok = false;
+            }
+            if (r.deg_s != r.wbox * (c.j1 - c.j0 + 1)) walk_ok = false;
+        }
+    }
+    walk_items.clear(); walk_cls_off.assign(2 * (degree + 1) + 1, 0);
+    if (!walk_ok) return;
+    const int P1 = degree + 1;
+    std::vector<WalkItem> items;
+    for (int s = 0; s < n_owned; ++s) {
+        const PatchDev& P = patches[s];
+        int nseg = std::max(1, (P.nelv + seg_len / 2) / std::max(seg_len, P1));
+        while (nseg > 1 && P.nelv / nseg < P1) --nseg;                 // every segment holds at least p + 1 elements
+        for (int eu = 0; eu < P.nelu; ++eu) for (int g = 0; g < nseg; ++g) {
+            const int e0 = int(int64_t(g) * P.nelv / nseg), e1 = int(int64_t(g + 1) * P.nelv / nseg);
+            items.push_back({s, eu, e0, e1 - e0, g, (eu % P1) * 2 + (g & 1), ints[P.spu + eu] - P.p, 0});
+        }
+    }
+    std::stable_sort(items.begin(), items.end(), [](const WalkItem& x, const WalkItem& y) { return x.cls < y.cls; });
+    walk_items = items;
+    for (const WalkItem& it : items) walk_cls_off[it.cls + 1]++;
+    for (size_t c = 0; c + 1 < walk_cls_off.size(); ++c) walk_cls_off[c + 1] += walk_cls_off[c];
 }
 
 }  // namespace gf

@@ -340,6 +340,8 @@ class NonMatchingOpt:
         u = np.asarray(u_array_iga, float).ravel()
         if u.size != self.vec_iga_dof:
             raise ValueError("update_uIGA: expected %d values, got %d" % (self.vec_iga_dof, u.size))
+        if self._dev is not None and np.array_equal(u, self.u_iga):
+            return                                  # unchanged input: what was assembled / evaluated for this state stays current
         self.u_iga = u.copy()
         self.dev.set_u(self.u_iga)
         self._touch()
@@ -352,6 +354,8 @@ class NonMatchingOpt:
         v = np.asarray(cp_array_iga, float).ravel()
         if v.size != cols.size:
             raise ValueError("update_CPIGA: expected %d values, got %d" % (cols.size, v.size))
+        if self._dev is not None and np.array_equal(self.cp_iga[field][cols], v):
+            return
         self.cp_iga[field][cols] = v
         self.dev.set_cp(field, self.cp_iga[field])
         self._touch()
@@ -361,6 +365,8 @@ class NonMatchingOpt:
         v = np.asarray(h_th_iga_array, float).ravel()
         if v.size != self.vec_scalar_iga_dof:
             raise ValueError("update_h_th_IGA: expected %d values, got %d" % (self.vec_scalar_iga_dof, v.size))
+        if self._dev is not None and np.array_equal(np.concatenate(self.h_th), v):
+            return
         self.h_th = [v[self.cp_off[s]:self.cp_off[s + 1]].copy() for s in range(self.num_splines)]
         self.dev.set_thickness(v)
         self._touch()
@@ -370,8 +376,11 @@ class NonMatchingOpt:
         v = np.asarray(h_th_array, float).ravel()
         if v.size != self.num_splines:
             raise ValueError("update_h_th: expected %d values, got %d" % (self.num_splines, v.size))
+        new = np.concatenate([np.full(s.ncp, v[i]) for i, s in enumerate(self.splines)])
+        if self._dev is not None and np.array_equal(np.concatenate(self.h_th), new):
+            return
         self.h_th = [np.full(s.ncp, v[i]) for i, s in enumerate(self.splines)]
-        self.dev.set_thickness(np.concatenate(self.h_th))
+        self.dev.set_thickness(new)
         self._touch()
 
     # ------------------------------------------------------------------ residual and Jacobians
@@ -601,6 +610,7 @@ class NonMatchingOpt:
         zero_mortar_funcs)."""
         if zero_mortar_funcs:
             self.update_uIGA(np.zeros(self.vec_iga_dof))
+        nrm = float("inf")
         for it in range(max_it):
             self._assemble(_lib.ASM_R | _lib.ASM_K)
             R = self.dev.residual()
@@ -611,6 +621,17 @@ class NonMatchingOpt:
                 break
             du = self.solve_K(-R)
             self.update_uIGA(self.u_iga + du)
+        else:
+            # max_it Newton steps taken: the residual of the last iterate decides; an unconverged state must not pass silently
+            # into linearize / solve_linear (the adjoint gradients would be wrong without any sign of it)
+            self._assemble(_lib.ASM_R)
+            nrm = np.linalg.norm(self.dev.residual())
+            ref_error = ref_error if ref_error else 1.0
+            if not nrm / ref_error < rtol:
+                import warnings
+                warnings.warn("solve_nonlinear_nonmatching_problem: not converged after %d iterations (relative residual %.3e >= rtol %.1e)"
+                              % (max_it, nrm / ref_error, rtol), RuntimeWarning)
+        self.newton_relative_residual = nrm / ref_error
         return None, self.u_iga
 
     # ------------------------------------------------------------------ convenience

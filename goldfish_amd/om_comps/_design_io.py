@@ -133,6 +133,4 @@ class LinearMapsComp(DesignIO, om.ExplicitComponent):
             y = A * inputs[i]
             outputs[o] = y if b is None else y - b
 
-    def compute_partials(self, inputs, partials):
-        for i, o, A, x0, b in self._maps:
-            partials[o, i] = A.toarray()
+    # no compute_partials: the partials are constant and declared (COO values in rows / cols order) in setup

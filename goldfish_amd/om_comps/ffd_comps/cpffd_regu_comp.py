@@ -34,6 +34,4 @@ class CPFFDReguComp(om.ExplicitComponent):
         for i, field in enumerate(self.opt_field):
             outputs[self.output_cpregu_name_list[i]] = self.derivs[i] * inputs[self.input_cpffd_name_list[i]]
 
-    def compute_partials(self, inputs, partials):
-        for i, field in enumerate(self.opt_field):
-            partials[self.output_cpregu_name_list[i], self.input_cpffd_name_list[i]] = self.derivs[i].toarray()
+    # the partials are constant and declared in setup (COO values in rows / cols order): no compute_partials

@@ -21,8 +21,7 @@ class _LinearMapComp(om.ExplicitComponent):
     def compute(self, inputs, outputs):
         outputs[self.out_name] = self.deriv * inputs[self.in_name]
 
-    def compute_partials(self, inputs, partials):
-        partials[self.out_name, self.in_name] = self.deriv.toarray()
+    # the partials are constant and declared in setup (COO values in rows / cols order): no compute_partials
 
 
 class HthFFD2FEComp(_LinearMapComp):

@@ -53,6 +53,45 @@ class _Component:
         self._partials.append((of, wrt, kw))
 
 
+class _Partials(dict):
+    """Sub-Jacobians as OpenMDAO keeps them: a pair declared with rows / cols holds its nnz values in that COO order (assigning
+    anything of another size raises, as OpenMDAO does: 'wrong size, expected nnz'), a dense pair holds (n_of, n_wrt) values;
+    declared ``val`` seeds the entry, so a component with constant declared partials needs no compute_partials."""
+
+    def __init__(self, comp, inputs, outputs):
+        super().__init__()
+        self._decl, self._shape = {}, {}
+        for of, wrt, kw in comp._partials:
+            ofs = list(outputs) if of == "*" else [of]
+            wrts = (list(inputs) + list(outputs)) if wrt == "*" else [wrt]
+            for o in ofs:
+                for w in wrts:
+                    self._decl[(o, w)] = kw
+                    self._shape[(o, w)] = (outputs[o].size, (inputs[w] if w in inputs else outputs[w]).size)
+                    if kw.get("val") is not None:
+                        self[(o, w)] = kw["val"]
+
+    def __setitem__(self, key, val):
+        kw = self._decl.get(key)
+        val = np.asarray(val, float)
+        if kw is not None and kw.get("rows") is not None:
+            nnz = len(kw["rows"])
+            if val.size != nnz and val.size != 1:
+                raise ValueError("partials%s: sub-jacobian declared with rows/cols has wrong size %d, expected nnz = %d" % (key, val.size, nnz))
+        elif key in self._shape and val.size not in (1, self._shape[key][0] * self._shape[key][1]):
+            raise ValueError("partials%s: wrong size %d for a dense (%d, %d) sub-jacobian" % ((key, val.size) + self._shape[key]))
+        dict.__setitem__(self, key, val)
+
+    def dense(self, of, wrt):
+        kw, val = self._decl.get((of, wrt)), self[(of, wrt)]
+        shape = self._shape.get((of, wrt))
+        if kw is not None and kw.get("rows") is not None:
+            J = np.zeros(shape)
+            np.add.at(J, (np.asarray(kw["rows"]), np.asarray(kw["cols"])), np.broadcast_to(val.ravel(), (len(kw["rows"]),)))
+            return J
+        return np.broadcast_to(val, shape) if (shape is not None and val.size == 1) else (val.reshape(shape) if shape is not None else val)
+
+
 class ImplicitComponent(_Component):
     pass
 
@@ -118,10 +157,12 @@ class Problem:
                     fd, an = fd[free_mask], an[free_mask]
                 res[(of, wrt)] = np.abs(fd - an).max() / max(np.abs(fd).max(), 1e-300)
         else:
-            partials = {}
+            partials = _Partials(m, self.inputs, self.outputs)
             m.compute(self.inputs, self.outputs)
-            m.compute_partials(self.inputs, partials)
-            for (of, wrt), Jm in partials.items():
+            if hasattr(m, "compute_partials"):
+                m.compute_partials(self.inputs, partials)
+            for (of, wrt) in list(partials):
+                Jm = partials.dense(of, wrt)
                 base = self.inputs[wrt].copy()
                 v = rng.standard_normal(base.shape)
                 if free_mask is not None and base.size == np.size(free_mask):      # gradients with Dirichlet rows zeroed (apply_bcs=True)

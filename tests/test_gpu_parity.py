@@ -56,6 +56,7 @@ def test_assembly_parity(oracle_lib, case):
     A, h, u = _state(spec)
     O = Oracle(A, thickness=h, u=u)
     D = _lib.DeviceModel(A)
+    assert D.assembly_path == 0                 # MFMA element kernel, one block per element, row-owner gather
     D.set_thickness(h)
     D.set_u(u)
     D.assemble(_lib.ASM_ALL)
@@ -81,34 +82,50 @@ def test_assembly_parity(oracle_lib, case):
     D.close()
 
 
+@pytest.mark.parametrize("seg", ["4", "7", "1000"])
+def test_walking_kernel_segment_lengths_and_block_path(oracle_lib, monkeypatch, seg):
+    """GF_WALK=1: the walking element kernel (gf_element_walk.hpp: accumulators kept along an element strip, sums added straight
+    into the CSR arrays in a fixed class order -- no element blocks, no gather) with work items of 4 / 7 elements / whole strips
+    (GF_WALK_SEG: different class structure, different first-touch pattern) against the oracle and against the default
+    element-block + gather path, for every flag subset; each variant is bitwise reproducible run to run."""
+    from goldfish_amd import _lib
+    from oracle.oracle_py import Oracle
+    for case in ("tbeam2_p2", "shell3x2_p3", "C3_wing16_refdata", "slr9_nurbs_p3_projected_load"):
+        A, h, u = _state(CASES[case](), seed=11)
+        O = Oracle(A, thickness=h, u=u)
+        vals, Ro = O.assemble(), O.residual()
+        out = {}
+        for walk in ("1", "0"):
+            monkeypatch.setenv("GF_WALK", walk)
+            monkeypatch.setenv("GF_WALK_SEG", seg)
+            D = _lib.DeviceModel(A)
+            assert D.assembly_path == (2 if walk == "1" else 0)
+            D.set_thickness(h)
+            D.set_u(u)
+            D.assemble(_lib.ASM_ALL)
+            out[walk] = [D.residual().copy()] + [D.values(w).copy() for w in range(5)]
+            assert _rel(out[walk][0], Ro) < RTOL
+            for w in range(5):
+                assert _rel(out[walk][1 + w], vals[w]) < RTOL, (case, walk, w)
+            D.assemble(_lib.ASM_ALL)                                # same bits again (stale partial sums never leak into a pass)
+            assert np.array_equal(out[walk][0], D.residual())
+            for w in range(5):
+                assert np.array_equal(out[walk][1 + w], D.values(w)), (case, walk, w)
+            for flags, which in ((_lib.ASM_R | _lib.ASM_K, (0,)), (_lib.ASM_DRDCP | _lib.ASM_DRDH, (1, 2, 3, 4)), (_lib.ASM_K | _lib.ASM_DRDH, (0, 4))):
+                D.assemble(flags)
+                for w in which:
+                    assert _rel(D.values(w), vals[w]) < RTOL, (case, walk, flags, w)
+            D.close()
+        for x, y in zip(out["1"], out["0"]):
+            assert _rel(x, y) < 1e-12
+
+
 def test_valu_element_kernel_still_matches(oracle_lib, monkeypatch):
     """The FP64-VALU element kernel (GF_ELEMENT=valu) stays a supported path for every degree."""
     from goldfish_amd import _lib
     from oracle.oracle_py import Oracle
     monkeypatch.setenv("GF_ELEMENT", "valu")
     for case in ("tbeam2_p2", "shell3x2_p3", "shell2x2_p4", "slr9_nurbs_p3_projected_load"):
-        A, h, u = _state(CASES[case]())
-        O = Oracle(A, thickness=h, u=u)
-        D = _lib.DeviceModel(A)
-        D.set_thickness(h)
-        D.set_u(u)
-        D.assemble(_lib.ASM_ALL)
-        assert _rel(D.residual(), O.residual()) < RTOL
-        vals = O.assemble()
-        for which in range(5):
-            assert _rel(D.values(which), vals[which]) < RTOL, (case, which)
-        D.close()
-
-
-def test_strip_accumulating_element_kernel(oracle_lib, monkeypatch):
-    """GF_STRIP=1: the element kernel that sums along element strips before writing (gf_element_strip.hpp) and the
-    strip branch of the gather give the same matrices, also when the scratch is chunked."""
-    from goldfish_amd import _lib
-    from oracle.oracle_py import Oracle
-    monkeypatch.setenv("GF_STRIP", "1")
-    for case, gb in (("shell3x2_p3", None), ("slr9_nurbs_p3", None), ("C3_wing16_refdata", "0.002")):
-        if gb is not None:
-            monkeypatch.setenv("GF_SCRATCH_GB", gb)
         A, h, u = _state(CASES[case]())
         O = Oracle(A, thickness=h, u=u)
         D = _lib.DeviceModel(A)
@@ -250,7 +267,7 @@ def test_create_rejects_bad_models():
 
 
 def test_four_wave_gather_is_bitwise_the_one_wave_gather(oracle_lib, monkeypatch):
-    """The one-wave gather (default) and the four-wave gather (GF_GATHER1=0; also what the strip path uses) add the element
+    """The one-wave gather (default) and the four-wave gather (GF_GATHER1=0) add the element
     blocks in the same fixed order: identical bits for every output, for p = 2, 3, 4."""
     from goldfish_amd import _lib
     for case in ("tbeam2_p2", "shell3x2_p3", "shell2x2_p4"):
