@@ -1,19 +1,20 @@
 """ctypes binding of libgoldfish_solver.so (include/goldfish_solver.h): direct solves with K that stay on the device.
 
-Replaces the per-call MUMPS factorisation of GOLDFISH/utils/opt_utils.py:156-209 (solve_Ax_b / solve_ATx_b) after the
-first solve: ordering + symbolic factorisation once on the host (SuperLU, symmetric mode), then numeric re-factorisation and
-triangular solves on the GPU (rocSOLVER csrrf) for every later Newton step and adjoint solve.  No CPU fallback: raises
-when the library or a GPU is missing."""
+Replaces the per-call MUMPS factorisation of GOLDFISH/utils/opt_utils.py:156-209 (solve_Ax_b / solve_ATx_b): the control
+points are renumbered once on the host (reverse Cuthill-McKee on the neighbour graph, whose pattern never changes during
+an optimisation), K's values are read in place from libgoldfish_hip's buffer, and factorisation (block-banded L D L^T,
+64 x 64 tiles on the FP64 matrix pipe), substitutions and iterative refinement run on the GPU -- hand-written HIP, no
+rocSOLVER / rocBLAS.  No CPU fallback: raises when the library or a GPU is missing."""
 import ctypes as C
 import os
 
 import numpy as np
 import scipy.sparse as sp
-import scipy.sparse.linalg as spla
+from scipy.sparse.csgraph import reverse_cuthill_mckee
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgoldfish_solver.so")
-EXPORTS = ["gfs_last_error", "gfs_create", "gfs_destroy", "gfs_refactor", "gfs_solve", "gfs_nnz_factors", "gfs_device_bytes"]
+EXPORTS = ["gfs_last_error", "gfs_create", "gfs_destroy", "gfs_refactor", "gfs_solve", "gfs_solve_dev", "gfs_info"]
 _L = None
 
 
@@ -23,74 +24,60 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libgoldfish_solver.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
         L = C.CDLL(LIB_PATH)
-        i32p, dp, vp = C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p
+        i32p, i64p, dp, vp = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_void_p
         L.gfs_last_error.restype = C.c_char_p
-        L.gfs_create.argtypes = [C.c_int, C.c_int64, C.c_int64, i32p, i32p, vp, C.c_int64, i32p, i32p, dp, i32p, i32p, C.POINTER(vp)]
+        L.gfs_create.argtypes = [C.c_int, C.c_int64, i64p, i32p, i32p, vp, C.POINTER(vp)]
         L.gfs_destroy.argtypes = [vp]
+        L.gfs_destroy.restype = None
         L.gfs_refactor.argtypes = [vp]
-        L.gfs_solve.argtypes = [vp, dp, dp]
-        L.gfs_nnz_factors.restype = C.c_int64
-        L.gfs_nnz_factors.argtypes = [vp]
-        L.gfs_device_bytes.restype = C.c_int64
-        L.gfs_device_bytes.argtypes = [vp]
+        L.gfs_solve.argtypes = [vp, dp, dp, C.c_int, dp]
+        L.gfs_solve_dev.argtypes = [vp, vp, vp, C.c_int, dp]
+        L.gfs_info.argtypes = [vp, dp]
         _L = L
     return _L
 
 
-def host_symbolic(K, seed=0):
-    """Ordering + symbolic factorisation on the host.  Returns (T, pivP, pivQ): the structural pattern of (L - I) + U as CSR
-    and the row / column orders of P K Q = L U in rocSOLVER's convention.
+def control_point_graph(rowptr, col):
+    """Control-point-level neighbour lists (nb_ptr, nb) from the dof-level pattern of K (gf_pattern(GF_MAT_K): row 3 a + i
+    lists the columns 3 b + j of a's neighbours b in ascending order)."""
+    rowptr, col = np.asarray(rowptr, np.int64), np.asarray(col, np.int64)
+    ncp = (rowptr.size - 1) // 3
+    starts, ends = rowptr[0:3 * ncp:3], rowptr[1:3 * ncp + 1:3]
+    deg = (ends - starts) // 3
+    nb_ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    idx = np.repeat(starts, deg) + 3 * (np.arange(nb_ptr[-1]) - np.repeat(nb_ptr[:-1], deg))
+    return nb_ptr, (col[idx] // 3).astype(np.int32)
 
-    scipy returns the SuperLU factors without the fill entries that happen to be numerically zero (and K has many exact zeros,
-    e.g. membrane-bending coupling of flat patches at u = 0), so the pattern is taken from the factors of a GENERIC symmetric
-    positive definite matrix with K's structure (random symmetric off-diagonals, dominant diagonal); the numeric factors of
-    the real K are then computed on the device (DeviceSolver calls refactor())."""
-    n = K.shape[0]
-    P = sp.csr_matrix(K)
-    rng = np.random.default_rng(seed)
-    G = sp.csr_matrix((rng.uniform(0.5, 1.5, P.nnz), P.indices, P.indptr), shape=(n, n))
-    G = G + G.T                                               # symmetric, no cancellations (all positive)
-    G.setdiag(0.0)
-    G = (G + sp.diags(np.asarray(abs(G).sum(1)).ravel() + 1.0)).tocsc()
-    lu = spla.splu(G, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
-    Lc, Uc = lu.L.tocoo(), lu.U.tocoo()
-    off = Lc.row != Lc.col                                   # drop L's unit diagonal structurally
-    T = sp.coo_matrix((np.concatenate([Lc.data[off], Uc.data]), (np.concatenate([Lc.row[off], Uc.row]), np.concatenate([Lc.col[off], Uc.col]))),
-                      shape=(n, n)).tocsr()
-    T.sort_indices()
-    # SuperLU: Pr K Pc = L U with Pr[perm_r[i], i] = 1 and Pc[i, perm_c[i]] = 1, i.e. row i of K becomes row perm_r[i] and
-    # column j becomes column perm_c[j]; rocSOLVER wants the source index of every permuted row / column: the inverses
-    pivP = np.argsort(lu.perm_r).astype(np.int32)
-    pivQ = np.argsort(lu.perm_c).astype(np.int32)
-    return T, pivP, pivQ
+
+def bandwidth_reducing_order(nb_ptr, nb):
+    """new_index[a] = position of control point a in the factorisation order (reverse Cuthill-McKee on the neighbour graph)."""
+    ncp = nb_ptr.size - 1
+    G = sp.csr_matrix((np.ones(nb.size, np.int8), nb, nb_ptr), shape=(ncp, ncp))
+    perm = reverse_cuthill_mckee(G, symmetric_mode=True)           # perm[new] = old
+    new_index = np.empty(ncp, np.int32)
+    new_index[perm] = np.arange(ncp, dtype=np.int32)
+    return new_index
 
 
 class DeviceSolver:
-    """K x = b (= K^T x = b) with the K of a goldfish_amd._lib.DeviceModel, factors resident in HBM."""
+    """K x = b (= K^T x = b: K is symmetric) with the K of a goldfish_amd._lib.DeviceModel; factors resident in HBM."""
 
-    def __init__(self, dev_model, _pivots=None):
+    def __init__(self, dev_model, max_refine=3):
         from . import _lib
-        self.D = dev_model
+        self.D, self.max_refine = dev_model, max_refine
         rowptr, col = dev_model.pattern(_lib.MAT_K)
-        vals = dev_model.values(_lib.MAT_K)
-        n = rowptr.size - 1
-        K = sp.csr_matrix((vals, col, rowptr), shape=(n, n))
-        T, pivP, pivQ = host_symbolic(K)
-        if _pivots is not None:
-            pivP, pivQ = _pivots(pivP, pivQ)
-        self.n, self.nnzT = n, T.nnz
-        ptrA, indA = rowptr.astype(np.int32), np.ascontiguousarray(col, np.int32)
-        ptrT, indT, valT = T.indptr.astype(np.int32), T.indices.astype(np.int32), np.ascontiguousarray(T.data, float)
-        i32p, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        self.nb_ptr, self.nb = control_point_graph(rowptr, col)
+        self.new_index = bandwidth_reducing_order(self.nb_ptr, self.nb)
+        self.n = 3 * (self.nb_ptr.size - 1)
         dK = _lib.lib().gf_device_ptr(dev_model.h, _lib.BUF_VAL_K)
         h = C.c_void_p()
-        rc = lib().gfs_create(int(dev_model.device), n, ptrA[-1], ptrA.ctypes.data_as(i32p), indA.ctypes.data_as(i32p), C.c_void_p(dK),
-                              T.nnz, ptrT.ctypes.data_as(i32p), indT.ctypes.data_as(i32p), valT.ctypes.data_as(dp),
-                              pivP.ctypes.data_as(i32p), pivQ.ctypes.data_as(i32p), C.byref(h))
+        rc = lib().gfs_create(int(dev_model.device), self.nb_ptr.size - 1, self.nb_ptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                              self.nb.ctypes.data_as(C.POINTER(C.c_int32)), self.new_index.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(dK), C.byref(h))
         if rc:
             raise RuntimeError(lib().gfs_last_error().decode())
         self.h = h
-        self.refactor()                                       # numeric factors of the current K, computed on the device
+        self.rel_residual = None
+        self.refactor()                                       # numeric factors of the current K
 
     def close(self):
         if getattr(self, "h", None):
@@ -100,7 +87,8 @@ class DeviceSolver:
     __del__ = close
 
     def refactor(self):
-        """Numeric re-factorisation with the values of K currently on the device (after a new assembly)."""
+        """Numeric factorisation of the values of K currently on the device (after a new assembly)."""
+        self.D.sync()                                         # the assembly runs on the model's stream, the solver on its own
         if lib().gfs_refactor(self.h):
             raise RuntimeError(lib().gfs_last_error().decode())
 
@@ -108,12 +96,19 @@ class DeviceSolver:
         b = np.ascontiguousarray(b, float)
         if b.size != self.n:
             raise ValueError("DeviceSolver.solve: expected %d values, got %d" % (self.n, b.size))
-        x = np.empty(self.n)
+        x, rr = np.empty(self.n), C.c_double(0.0)
         dp = C.POINTER(C.c_double)
-        if lib().gfs_solve(self.h, b.ctypes.data_as(dp), x.ctypes.data_as(dp)):
+        if lib().gfs_solve(self.h, b.ctypes.data_as(dp), x.ctypes.data_as(dp), int(self.max_refine), C.byref(rr)):
             raise RuntimeError(lib().gfs_last_error().decode())
+        self.rel_residual = rr.value
         return x
+
+    def info(self):
+        v = (C.c_double * 6)()
+        lib().gfs_info(self.h, v)
+        return {"half_bandwidth": int(v[0]), "block_columns": int(v[1]), "tiles_per_block_row": int(v[2]), "device_bytes": int(v[3]),
+                "factor_flops": float(v[4]), "small_pivot": bool(v[5])}
 
     @property
     def device_bytes(self):
-        return lib().gfs_device_bytes(self.h)
+        return self.info()["device_bytes"]

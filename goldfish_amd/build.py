@@ -33,10 +33,10 @@ def build(force=False, verbose=False):
     if force or needs_build(host, ["point_host_test.cpp", "kl_point.hpp"]):
         subprocess.check_call([_hipcc(), "-O2", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-x", "hip",
                                os.path.join(CSRC, "point_host_test.cpp"), "-o", host])
-    solver = os.path.join(HERE, "libgoldfish_solver.so")      # device re-factorisation + solves (rocSOLVER csrrf), include/goldfish_solver.h
+    solver = os.path.join(HERE, "libgoldfish_solver.so")      # block-banded L D L^T factorisation + solves on the device, include/goldfish_solver.h
     if force or needs_build(solver, ["gf_solver.hip", os.path.join("..", "..", "include", "goldfish_solver.h")]):
         subprocess.check_call([_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", os.path.join(CSRC, "gf_solver.hip"),
-                               "-o", solver, "-lrocsolver", "-lrocblas"])
+                               "-o", solver])
     return LIB
 
 

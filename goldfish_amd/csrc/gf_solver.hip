@@ -1,9 +1,17 @@
-// gf_solver.hip -- C ABI (include/goldfish_solver.h): device-resident re-factorisation and solves with K (rocSOLVER csrrf).
-// Build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC gf_solver.hip -o ../libgoldfish_solver.so -lrocsolver -lrocblas
+// gf_solver.hip -- C ABI (include/goldfish_solver.h): block-banded L D L^T factorisation of K and solves, on the device.
+// Build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC gf_solver.hip -o ../libgoldfish_solver.so      (no library dependency)
+//
+// Storage: control points renumbered by the caller's bandwidth-reducing order; n = 3 ncp dofs padded to nblk tiles of NB = 64
+// (identity on the padding); lower block band, tile (I, d) = block (I, I - d), d = 0 .. T, dense 64 x 64 row-major at
+// ((I (T + 1) + d) NB^2).  Right-looking factorisation over block columns k, three launches per k:
+//   diag_kernel     A_kk = L_kk D_k L_kk^T in LDS (one workgroup), and L_kk^-1 (unit lower) for the panel and the solves
+//   panel_kernel    W_ik = A_ik L_kk^-T,  L_ik = W_ik D_k^-1           (one workgroup per tile, 64^3 product on v_mfma_f64_16x16x4)
+//   update_kernel   A_ij -= W_ik L_jk^T   for k < j <= i <= k + T       (one workgroup per tile, same product)
+// Solves: block forward / backward substitution with the inverted diagonal tiles (one launch per block column), then
+// iterative refinement with the block-CSR K.  Reference: the MUMPS solves of GOLDFISH/utils/opt_utils.py:156-209.
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
-#include <chrono>
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -14,57 +22,343 @@
 static thread_local std::string g_serr;
 static int sfail(const std::string& m) { g_serr = m; return 1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
-#define RBCHK(x) do { rocblas_status s_ = (x); if (s_ != rocblas_status_success) throw std::runtime_error(std::string(#x) + ": rocblas status " + std::to_string((int)s_)); } while (0)
+
+namespace {
+
+constexpr int NB = 64, NB2 = NB * NB, LS = 66;        // tile edge; LDS row stride (66 doubles: the MFMA operand reads are bank-conflict free)
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ---- 64 x 64 tile product C (+)= A B^T on the FP64 matrix pipe.  A, B in LDS (row-major, stride LS).  Wave w of the four
+//      owns rows 16 w .. 16 w + 15 of C: four 16 x 16 accumulators (one per column block), 16 k-steps of 4.
+//      v_mfma_f64_16x16x4: A[i][k]: lane = i + 16 k,  B[k][j]: lane = j + 16 k,  D[i][j]: lane = j + 16 (i % 4), register i / 4.
+__device__ __forceinline__ void tile_abt(const double* __restrict__ sA, const double* __restrict__ sB, d4 (&acc)[4], int wave, int lane, double sign) {
+    const int l16 = lane & 15, kq = lane >> 4;
+    const double* pa = sA + (16 * wave + l16) * LS + kq;
+    const double* pb = sB + l16 * LS + kq;
+#pragma unroll 4
+    for (int k0 = 0; k0 < NB; k0 += 4) {
+        const double a = sign * pa[k0];
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) acc[nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[nj * 16 * LS + k0], acc[nj], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void load_tile(const double* __restrict__ g, double* __restrict__ s, int tid) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int idx = 2 * (tid + 256 * q), r = idx >> 6, c = idx & 63;
+        const double2 v = *reinterpret_cast<const double2*>(g + idx);
+        s[r * LS + c] = v.x; s[r * LS + c + 1] = v.y;
+    }
+}
+
+// K (block CSR of libgoldfish_hip, original numbering) -> lower block band in the factorisation order; identity on the padding
+__global__ void band_fill_kernel(long long ncp, const long long* __restrict__ nb_ptr, const int* __restrict__ nb, const int* __restrict__ newi,
+                                 const double* __restrict__ valK, double* __restrict__ band, int T, long long n, long long npad) {
+    const long long a = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (a < ncp) {
+        const long long ptr = nb_ptr[a], deg = nb_ptr[a + 1] - ptr;
+        const long long pa = newi[a];
+        for (long long k = lane; k < deg; k += 64) {
+            const long long pb = newi[nb[ptr + k]];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const long long r = 3 * pa + i, c = 3 * pb + j;
+                    if (r < c) continue;
+                    const long long I = r >> 6, d = I - (c >> 6);
+                    band[((size_t)I * (T + 1) + d) * NB2 + (r & 63) * NB + (c & 63)] = valK[9 * ptr + (long long)i * 3 * deg + 3 * k + j];
+                }
+        }
+    }
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < npad - n) { const long long r = n + t, I = r >> 6; band[((size_t)I * (T + 1)) * NB2 + (r & 63) * NB + (r & 63)] = 1.0; }
+}
+
+// diagonal tile of block column k: L D L^T (lower, no pivoting) and the inverse of the unit lower factor
+__global__ __launch_bounds__(256) void diag_kernel(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, int T, int k, double* __restrict__ stat) {
+    __shared__ double s[NB * (NB + 1)], v[NB * (NB + 1)];
+    constexpr int S1 = NB + 1;
+    const int tid = threadIdx.x;
+    double* A = band + ((size_t)k * (T + 1)) * NB2;
+    for (int q = tid; q < NB2; q += 256) s[(q >> 6) * S1 + (q & 63)] = A[q];
+    // thread (i, jg): rows i, columns 16 jg .. 16 jg + 15 of the trailing update
+    const int i = tid >> 2, jg = tid & 3;
+    for (int p = 0; p < NB; ++p) {
+        __syncthreads();
+        if (i > p) {
+            const double lip = s[i * S1 + p] / s[p * S1 + p];
+            const int j0 = max(16 * jg, p + 1), j1 = min(16 * jg + 15, i);
+            for (int j = j0; j <= j1; ++j) s[i * S1 + j] -= lip * s[j * S1 + p];
+        }
+    }
+    __syncthreads();
+    if (tid < NB) { dval[(size_t)k * NB + tid] = s[tid * S1 + tid]; }
+    __syncthreads();
+    // scale the columns: L[i][p] = a[i][p] / d_p (i > p); unit diagonal, zero above
+    for (int q = tid; q < NB2; q += 256) {
+        const int r = q >> 6, c = q & 63;
+        const double l = r > c ? s[r * S1 + c] / s[c * S1 + c] : (r == c ? 1.0 : 0.0);
+        v[r * S1 + c] = l;
+    }
+    __syncthreads();
+    for (int q = tid; q < NB2; q += 256) { const int r = q >> 6, c = q & 63; A[q] = r == c ? s[r * S1 + r] : (r > c ? v[r * S1 + c] : 0.0); }
+    // smallest / largest |d| of the tile (singularity report)
+    if (tid == 0) {
+        double mn = 1e300, mx = 0.0;
+        for (int p = 0; p < NB; ++p) { const double d = fabs(s[p * S1 + p]); mn = fmin(mn, d); mx = fmax(mx, d); }
+        stat[2 * k] = mn; stat[2 * k + 1] = mx;
+    }
+    __syncthreads();
+    // inverse of the unit lower factor: column c by the four lanes 4 c .. 4 c + 3 (same wave: LDS operations of a wave are in order),
+    // row by row; s is reused for the inverse
+    const int c = tid >> 2, q4 = tid & 3;
+    for (int r = 0; r < NB; ++r) {
+        double part = 0.0;
+        for (int m = c + q4; m < r; m += 4) part += v[r * S1 + m] * s[m * S1 + c];      // inv[m][c], m < r: written in earlier iterations
+        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+        if (q4 == 0) s[r * S1 + c] = r < c ? 0.0 : (r == c ? 1.0 : -part);
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the write is done before the next row reads it (same wave)
+    }
+    __syncthreads();
+    double* Li = linv + (size_t)k * NB2;
+    for (int q = tid; q < NB2; q += 256) Li[q] = s[(q >> 6) * S1 + (q & 63)];
+}
+
+// panel tile i = k + 1 + blockIdx.x: W = A_ik L_kk^-T (to wbuf), L_ik = W D_k^-1 (in place)
+__global__ __launch_bounds__(256) void panel_kernel(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, int T, int k) {
+    __shared__ __attribute__((aligned(16))) double sA[NB * LS], sB[NB * LS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = blockIdx.x;
+    double* A = band + ((size_t)(k + 1 + g) * (T + 1) + (g + 1)) * NB2;
+    load_tile(A, sA, tid); load_tile(linv + (size_t)k * NB2, sB, tid);
+    __syncthreads();
+    d4 acc[4] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+    tile_abt(sA, sB, acc, wave, lane, 1.0);
+    double* W = wbuf + (size_t)g * NB2;
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) {
+        const int c = 16 * nj + (lane & 15);
+        const double di = 1.0 / dval[(size_t)k * NB + c];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int r = 16 * wave + 4 * rg + (lane >> 4);
+            W[r * NB + c] = acc[nj][rg]; A[r * NB + c] = acc[nj][rg] * di;
+        }
+    }
+}
+
+// trailing tile (i, j), k < j <= i: A_ij -= W_ik L_jk^T
+__global__ __launch_bounds__(256) void update_kernel(double* __restrict__ band, const double* __restrict__ wbuf, int T, int k, int ni) {
+    __shared__ __attribute__((aligned(16))) double sA[NB * LS], sB[NB * LS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // linear index -> (gi >= gj) over the lower triangle of the ni x ni tile block
+    int gi = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((gi + 1) * (gi + 2) / 2 <= (int)blockIdx.x) ++gi;
+    while (gi * (gi + 1) / 2 > (int)blockIdx.x) --gi;
+    const int gj = blockIdx.x - gi * (gi + 1) / 2;
+    if (gi >= ni) return;
+    const int i = k + 1 + gi, j = k + 1 + gj;
+    load_tile(wbuf + (size_t)gi * NB2, sA, tid);
+    load_tile(band + ((size_t)j * (T + 1) + (gj + 1)) * NB2, sB, tid);
+    double* C = band + ((size_t)i * (T + 1) + (gi - gj)) * NB2;
+    d4 acc[4];
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) acc[nj][rg] = C[(16 * wave + 4 * rg + (lane >> 4)) * NB + 16 * nj + (lane & 15)];
+    __syncthreads();
+    tile_abt(sA, sB, acc, wave, lane, -1.0);
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) C[(16 * wave + 4 * rg + (lane >> 4)) * NB + 16 * nj + (lane & 15)] = acc[nj][rg];
+}
+
+// forward substitution, block column k: y_k = L_kk^-1 b_k (every workgroup; workgroup 0 keeps it), b_{k+g} -= L_{k+g,k} y_k (workgroup g >= 1)
+__global__ __launch_bounds__(256) void fwd_kernel(const double* __restrict__ band, const double* __restrict__ linv, double* __restrict__ b, double* __restrict__ y, int T, int k) {
+    __shared__ double sb[NB], sy[NB];
+    const int tid = threadIdx.x, r = tid >> 2, q4 = tid & 3, g = blockIdx.x;
+    if (tid < NB) sb[tid] = b[(size_t)k * NB + tid];
+    __syncthreads();
+    {
+        const double* L = linv + (size_t)k * NB2 + r * NB + 16 * q4;
+        double part = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) part += L[c] * sb[16 * q4 + c];
+        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+        if (q4 == 0) sy[r] = part;
+    }
+    __syncthreads();
+    if (g == 0) { if (tid < NB) y[(size_t)k * NB + tid] = sy[tid]; return; }
+    const double* L = band + ((size_t)(k + g) * (T + 1) + g) * NB2 + r * NB + 16 * q4;
+    double part = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) part += L[c] * sy[16 * q4 + c];
+    part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+    if (q4 == 0) b[(size_t)(k + g) * NB + r] -= part;
+}
+// backward substitution, block column k: x_k = L_kk^-T z_k, z_{k-g} -= L_{k,k-g}^T x_k (workgroup g >= 1)
+__global__ __launch_bounds__(256) void bwd_kernel(const double* __restrict__ band, const double* __restrict__ linv, double* __restrict__ z, double* __restrict__ x, int T, int k) {
+    __shared__ double sz[NB], sx[NB], sp[4][NB];
+    const int tid = threadIdx.x, c = tid & 63, rq = tid >> 6, g = blockIdx.x;
+    if (tid < NB) sz[tid] = z[(size_t)k * NB + tid];
+    __syncthreads();
+    {
+        const double* L = linv + (size_t)k * NB2 + (16 * rq) * NB + c;
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part += L[r * NB] * sz[16 * rq + r];
+        sp[rq][c] = part;
+    }
+    __syncthreads();
+    if (tid < NB) sx[tid] = sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+    __syncthreads();
+    if (g == 0) { if (tid < NB) x[(size_t)k * NB + tid] = sx[tid]; return; }
+    const double* L = band + ((size_t)k * (T + 1) + g) * NB2 + (16 * rq) * NB + c;
+    double part = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part += L[r * NB] * sx[16 * rq + r];
+    __syncthreads();
+    sp[rq][c] = part;
+    __syncthreads();
+    if (tid < NB) z[(size_t)(k - g) * NB + tid] -= sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+}
+
+__global__ void permute_in_kernel(long long ncp, const int* __restrict__ newi, const double* __restrict__ src, double* __restrict__ dst) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 3 * ncp) dst[3 * (long long)newi[t / 3] + t % 3] = src[t];
+}
+__global__ void permute_out_kernel(long long ncp, const int* __restrict__ newi, const double* __restrict__ src, double* __restrict__ dst, int add) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 3 * ncp) { const double v = src[3 * (long long)newi[t / 3] + t % 3]; dst[t] = add ? dst[t] + v : v; }
+}
+__global__ void scale_kernel(long long n, const double* __restrict__ d, const double* __restrict__ y, double* __restrict__ z) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) z[t] = y[t] / d[t];
+}
+// r = b - K x (block CSR, original numbering): one wave per control point, fixed reduction order
+__global__ __launch_bounds__(256) void residual_kernel(long long ncp, const long long* __restrict__ nb_ptr, const int* __restrict__ nb, const double* __restrict__ val,
+                                                       const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ r) {
+    const long long a = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (a >= ncp) return;
+    const long long ptr = nb_ptr[a], deg = nb_ptr[a + 1] - ptr;
+    const double* v = val + 9 * ptr;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (long long k = lane; k < deg; k += 64) {
+        const long long col = 3LL * nb[ptr + k];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double xv = x[col + j];
+            s0 += v[3 * k + j] * xv; s1 += v[3 * deg + 3 * k + j] * xv; s2 += v[6 * deg + 3 * k + j] * xv;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+    if (lane == 0) { r[3 * a] = b[3 * a] - s0; r[3 * a + 1] = b[3 * a + 1] - s1; r[3 * a + 2] = b[3 * a + 2] - s2; }
+}
+// sum of squares in fixed order: per-block partials, summed on the host
+__global__ __launch_bounds__(256) void sumsq_kernel(long long n, const double* __restrict__ v, double* __restrict__ part) {
+    __shared__ double s[256];
+    double acc = 0.0;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) acc += v[t] * v[t];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = s[0];
+}
+
+}  // namespace
 
 struct gfs_handle {
-    int device = 0; hipStream_t stream = nullptr; rocblas_handle rb = nullptr; rocsolver_rfinfo rf = nullptr;
-    rocblas_int n = 0, nnzA = 0, nnzT = 0;
-    rocblas_int *ptrA = nullptr, *indA = nullptr, *ptrT = nullptr, *indT = nullptr, *pivP = nullptr, *pivQ = nullptr;
-    double *valA = nullptr, *valT = nullptr, *B = nullptr;
-    std::vector<void*> allocs; long long bytes = 0;
-    template <class T> T* up(const T* src, size_t cnt) {
-        void* p = nullptr; HIPCHK(hipMalloc(&p, (cnt ? cnt : 1) * sizeof(T))); allocs.push_back(p); bytes += (long long)(cnt * sizeof(T));
-        if (src && cnt) HIPCHK(hipMemcpy(p, src, cnt * sizeof(T), hipMemcpyHostToDevice));
-        return (T*)p;
+    int device = 0; hipStream_t stream = nullptr;
+    long long ncp = 0, n = 0, npad = 0, nblk = 0; int T = 0; long long bw = 0;
+    long long* nb_ptr = nullptr; int* nb = nullptr; int* newi = nullptr; const double* valK = nullptr;
+    double *band = nullptr, *linv = nullptr, *dval = nullptr, *wbuf = nullptr, *stat = nullptr;
+    double *vb = nullptr, *vy = nullptr, *vz = nullptr, *vx = nullptr, *vr = nullptr, *vsol = nullptr, *vrhs = nullptr, *part = nullptr;
+    std::vector<void*> allocs; long long bytes = 0; bool factored = false, small_pivot = false;
+    template <class Tp> Tp* dalloc(size_t cnt) {
+        void* p = nullptr; const size_t nb_ = (cnt ? cnt : 1) * sizeof(Tp);
+        HIPCHK(hipMalloc(&p, nb_)); allocs.push_back(p); bytes += (long long)nb_; return (Tp*)p;
     }
+    template <class Tp> Tp* up(const Tp* src, size_t cnt) { Tp* p = dalloc<Tp>(cnt); if (cnt) HIPCHK(hipMemcpy(p, src, cnt * sizeof(Tp), hipMemcpyHostToDevice)); return p; }
 };
+
+static double norm2(gfs_handle* h, const double* v, long long n) {
+    const int nblk = 240;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, h->stream, n, v, h->part);
+    double p[240];
+    HIPCHK(hipMemcpyAsync(p, h->part, sizeof(p), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    long double s = 0; for (int k = 0; k < nblk; ++k) s += p[k];
+    return std::sqrt((double)s);
+}
+
+// x (original numbering, device) = (L D L^T)^-1 rhs (original numbering, device); add: x += instead
+static void substitute(gfs_handle* h, const double* rhs, double* x, int add) {
+    const unsigned g3 = (unsigned)((3 * h->ncp + 255) / 256), gp = (unsigned)((h->npad + 255) / 256);
+    HIPCHK(hipMemsetAsync(h->vb, 0, h->npad * sizeof(double), h->stream));
+    hipLaunchKernelGGL(permute_in_kernel, dim3(g3), dim3(256), 0, h->stream, h->ncp, h->newi, rhs, h->vb);
+    for (long long k = 0; k < h->nblk; ++k) {
+        const int ni = (int)std::min<long long>(h->T, h->nblk - 1 - k);
+        hipLaunchKernelGGL(fwd_kernel, dim3(ni + 1), dim3(256), 0, h->stream, h->band, h->linv, h->vb, h->vy, h->T, (int)k);
+    }
+    hipLaunchKernelGGL(scale_kernel, dim3(gp), dim3(256), 0, h->stream, h->npad, h->dval, h->vy, h->vz);
+    for (long long k = h->nblk - 1; k >= 0; --k) {
+        const int ni = (int)std::min<long long>(h->T, k);
+        hipLaunchKernelGGL(bwd_kernel, dim3(ni + 1), dim3(256), 0, h->stream, h->band, h->linv, h->vz, h->vx, h->T, (int)k);
+    }
+    hipLaunchKernelGGL(permute_out_kernel, dim3(g3), dim3(256), 0, h->stream, h->ncp, h->newi, h->vx, x, add);
+    HIPCHK(hipGetLastError());
+}
 
 extern "C" {
 
 const char* gfs_last_error(void) { return g_serr.c_str(); }
 
-int gfs_create(int device, int64_t n, int64_t nnzA, const int32_t* ptrA, const int32_t* indA, const double* d_valA,
-               int64_t nnzT, const int32_t* ptrT, const int32_t* indT, const double* valT,
-               const int32_t* pivP, const int32_t* pivQ, gfs_handle** out) {
-    if (!out || !ptrA || !indA || !d_valA || !ptrT || !indT || !valT || !pivP || !pivQ) return sfail("gfs_create: null argument");
+int gfs_create(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb, const int32_t* new_index, const double* d_valK, gfs_handle** out) {
+    if (!out || !nb_ptr || !nb || !new_index || !d_valK) return sfail("gfs_create: null argument");
     *out = nullptr;
-    if (n <= 0 || nnzA <= 0 || nnzT <= 0 || n >= (int64_t(1) << 31) || nnzA >= (int64_t(1) << 31) || nnzT >= (int64_t(1) << 31))
-        return sfail("gfs_create: sizes must be positive and fit 32-bit indices (rocSOLVER csrrf)");
+    if (ncp <= 0) return sfail("gfs_create: no control points");
     gfs_handle* h = nullptr;
     try {
         int ndev = 0;
-        if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) throw std::runtime_error("gfs_create: no such HIP device");
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("gfs_create: no HIP device visible (libgoldfish_solver has no CPU fallback)");
+        if (device < 0 || device >= ndev) throw std::runtime_error("gfs_create: device index out of range");
+        {   // new_index must be a permutation; the neighbour relation gives the bandwidth
+            std::vector<char> seen(ncp, 0);
+            for (int64_t a = 0; a < ncp; ++a) { const int32_t p = new_index[a]; if (p < 0 || p >= ncp || seen[p]) throw std::runtime_error("gfs_create: new_index is not a permutation"); seen[p] = 1; }
+        }
+        long long bwcp = 0;
+        for (int64_t a = 0; a < ncp; ++a) for (int64_t k = nb_ptr[a]; k < nb_ptr[a + 1]; ++k) {
+            if (nb[k] < 0 || nb[k] >= ncp) throw std::runtime_error("gfs_create: neighbour index out of range");
+            bwcp = std::max<long long>(bwcp, std::llabs((long long)new_index[a] - new_index[nb[k]]));
+        }
         h = new gfs_handle(); h->device = device;
         HIPCHK(hipSetDevice(device));
-        const bool verbose = getenv("GFS_VERBOSE") != nullptr;
-        auto t0 = std::chrono::steady_clock::now();
-        auto lap = [&](const char* what) { if (verbose) { auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[gfs_create] %s %.2f s\n", what, std::chrono::duration<double>(t1 - t0).count()); t0 = t1; } };
         HIPCHK(hipStreamCreate(&h->stream));
-        RBCHK(rocblas_create_handle(&h->rb));
-        lap("rocblas_create_handle");
-        RBCHK(rocblas_set_stream(h->rb, h->stream));
-        h->n = (rocblas_int)n; h->nnzA = (rocblas_int)nnzA; h->nnzT = (rocblas_int)nnzT;
-        h->ptrA = h->up(ptrA, n + 1); h->indA = h->up(indA, nnzA); h->valA = const_cast<double*>(d_valA);
-        h->ptrT = h->up(ptrT, n + 1); h->indT = h->up(indT, nnzT); h->valT = h->up(valT, nnzT);
-        h->pivP = h->up(pivP, n); h->pivQ = h->up(pivQ, n);
-        h->B = h->up<double>(nullptr, n);
-        lap("uploads");
-        RBCHK(rocsolver_create_rfinfo(&h->rf, h->rb));
-        lap("rocsolver_create_rfinfo");
-        RBCHK(rocsolver_dcsrrf_analysis(h->rb, h->n, 1, h->nnzA, h->ptrA, h->indA, h->valA, h->nnzT, h->ptrT, h->indT, h->valT, h->pivP, h->pivQ, h->B, h->n, h->rf));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        lap("rocsolver_dcsrrf_analysis");
-    } catch (const std::exception& ex) { if (h) gfs_destroy(h); return sfail(ex.what()); }
+        h->ncp = ncp; h->n = 3 * ncp; h->nblk = (h->n + NB - 1) / NB; h->npad = h->nblk * NB;
+        h->bw = 3 * bwcp + 2;
+        h->T = (int)std::min<long long>((h->bw + NB - 1) / NB, h->nblk - 1);        // a dof pair at distance <= bw lies at most ceil(bw / NB) block rows apart
+        const double gb = (double)h->nblk * (h->T + 2) * NB2 * 8.0 / 1e9;
+        size_t freeb = 0, totb = 0; HIPCHK(hipMemGetInfo(&freeb, &totb));
+        if (gb * 1e9 > 0.9 * (double)freeb)
+            throw std::runtime_error("gfs_create: the factor band needs " + std::to_string(gb) + " GB (" + std::to_string(h->n) + " dofs, half bandwidth " + std::to_string(h->bw) +
+                                     "), more than the free device memory");
+        std::vector<long long> ptr(nb_ptr, nb_ptr + ncp + 1);
+        h->nb_ptr = h->up(ptr.data(), ptr.size()); h->nb = h->up(nb, (size_t)nb_ptr[ncp]); h->newi = h->up(new_index, (size_t)ncp);
+        h->valK = d_valK;
+        h->band = h->dalloc<double>((size_t)h->nblk * (h->T + 1) * NB2);
+        h->linv = h->dalloc<double>((size_t)h->nblk * NB2);
+        h->dval = h->dalloc<double>((size_t)h->npad); h->stat = h->dalloc<double>((size_t)2 * h->nblk);
+        h->wbuf = h->dalloc<double>((size_t)std::max(h->T, 1) * NB2);
+        h->vb = h->dalloc<double>(h->npad); h->vy = h->dalloc<double>(h->npad); h->vz = h->dalloc<double>(h->npad); h->vx = h->dalloc<double>(h->npad);
+        h->vr = h->dalloc<double>(h->npad); h->vsol = h->dalloc<double>(h->npad); h->vrhs = h->dalloc<double>(h->npad); h->part = h->dalloc<double>(256);
+        HIPCHK(hipDeviceSynchronize());
+    } catch (const std::exception& ex) {
+        if (h) gfs_destroy(h);
+        return sfail(ex.what());
+    }
     *out = h;
     return 0;
 }
@@ -72,8 +366,7 @@ int gfs_create(int device, int64_t n, int64_t nnzA, const int32_t* ptrA, const i
 void gfs_destroy(gfs_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->rf) (void)rocsolver_destroy_rfinfo(h->rf);
-    if (h->rb) (void)rocblas_destroy_handle(h->rb);
+    (void)hipDeviceSynchronize();
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -83,26 +376,82 @@ int gfs_refactor(gfs_handle* h) {
     if (!h) return sfail("gfs_refactor: null handle");
     try {
         HIPCHK(hipSetDevice(h->device));
-        HIPCHK(hipDeviceSynchronize());                    // the assembly that produced the new values ran on another stream
-        RBCHK(rocsolver_dcsrrf_refactlu(h->rb, h->n, h->nnzA, h->ptrA, h->indA, h->valA, h->nnzT, h->ptrT, h->indT, h->valT, h->pivP, h->pivQ, h->rf));
+        h->factored = false;
+        HIPCHK(hipMemsetAsync(h->band, 0, (size_t)h->nblk * (h->T + 1) * NB2 * sizeof(double), h->stream));
+        hipLaunchKernelGGL(band_fill_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->newi, h->valK, h->band, h->T, h->n, h->npad);
+        for (long long k = 0; k < h->nblk; ++k) {
+            const int ni = (int)std::min<long long>(h->T, h->nblk - 1 - k);
+            hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, h->stream, h->band, h->linv, h->dval, h->T, (int)k, h->stat);
+            if (ni > 0) {
+                hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, h->stream, h->band, h->linv, h->dval, h->wbuf, h->T, (int)k);
+                hipLaunchKernelGGL(update_kernel, dim3((unsigned)(ni * (ni + 1) / 2)), dim3(256), 0, h->stream, h->band, h->wbuf, h->T, (int)k, ni);
+            }
+        }
+        HIPCHK(hipGetLastError());
+        std::vector<double> st(2 * h->nblk);
+        HIPCHK(hipMemcpyAsync(st.data(), h->stat, st.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        double mn = 1e300, mx = 0.0;
+        for (long long k = 0; k < h->nblk; ++k) { mn = std::min(mn, st[2 * k]); mx = std::max(mx, st[2 * k + 1]); }
+        if (!(mn == mn) || !(mx == mx) || !std::isfinite(mx) || mn == 0.0) throw std::runtime_error("gfs_refactor: zero or non-finite pivot (K is singular for this ordering without pivoting)");
+        h->small_pivot = mn < 1e-14 * mx;
+        h->factored = true;
     } catch (const std::exception& ex) { return sfail(ex.what()); }
     return 0;
 }
 
-int gfs_solve(gfs_handle* h, const double* b, double* x) {
+int gfs_solve_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual) {
+    if (!h || !d_b || !d_x) return sfail("gfs_solve: null argument");
+    if (!h->factored) return sfail("gfs_solve: no factorisation (call gfs_refactor)");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        const unsigned gcp = (unsigned)((h->ncp * 64 + 255) / 256);
+        substitute(h, d_b, h->vsol, 0);
+        const double nb_ = norm2(h, d_b, h->n);
+        double best = -1.0;
+        for (int itr = 0; itr <= max_refine; ++itr) {
+            hipLaunchKernelGGL(residual_kernel, dim3(gcp), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->valK, d_b, h->vsol, h->vr);
+            const double nr = norm2(h, h->vr, h->n);
+            if (best >= 0.0 && !(nr < 0.5 * best)) {            // the last correction did not help: keep the previous iterate
+                if (nr >= best) HIPCHK(hipMemcpyAsync(h->vsol, h->vrhs, h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream)); else best = nr;
+                break;
+            }
+            best = nr;
+            if (itr == max_refine || nr == 0.0) break;
+            HIPCHK(hipMemcpyAsync(h->vrhs, h->vsol, h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));     // previous iterate
+            substitute(h, h->vr, h->vsol, 1);
+        }
+        HIPCHK(hipMemcpyAsync(d_x, h->vsol, h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (rel_residual) *rel_residual = nb_ > 0.0 ? best / nb_ : best;
+    } catch (const std::exception& ex) { return sfail(ex.what()); }
+    return 0;
+}
+
+int gfs_solve(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual) {
     if (!h || !b || !x) return sfail("gfs_solve: null argument");
     try {
         HIPCHK(hipSetDevice(h->device));
-        HIPCHK(hipMemcpyAsync(h->B, b, (size_t)h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        RBCHK(rocsolver_dcsrrf_solve(h->rb, h->n, 1, h->nnzT, h->ptrT, h->indT, h->valT, h->pivP, h->pivQ, h->B, h->n, h->rf));
-        HIPCHK(hipMemcpyAsync(x, h->B, (size_t)h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        double *db = nullptr, *dx = nullptr;
+        HIPCHK(hipMalloc(&db, h->n * sizeof(double)));
+        if (hipMalloc(&dx, h->n * sizeof(double)) != hipSuccess) { (void)hipFree(db); throw std::runtime_error("gfs_solve: out of device memory"); }
+        int rc = 1;
+        if (hipMemcpy(db, b, h->n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess) {
+            rc = gfs_solve_dev(h, db, dx, max_refine, rel_residual);
+            if (!rc && hipMemcpy(x, dx, h->n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = sfail("gfs_solve: copy to the host failed");
+        } else rc = sfail("gfs_solve: copy to the device failed");
+        (void)hipFree(db); (void)hipFree(dx);
+        return rc;
     } catch (const std::exception& ex) { return sfail(ex.what()); }
-    return 0;
 }
 
-int64_t gfs_nnz_factors(gfs_handle* h) { return h ? h->nnzT : 0; }
-int64_t gfs_device_bytes(gfs_handle* h) { return h ? h->bytes : 0; }
+int gfs_info(gfs_handle* h, double info[6]) {
+    if (!h || !info) return sfail("gfs_info: null argument");
+    info[0] = (double)h->bw; info[1] = (double)h->nblk; info[2] = (double)(h->T + 1); info[3] = (double)h->bytes;
+    double fl = 0.0;
+    for (long long k = 0; k < h->nblk; ++k) { const double ni = (double)std::min<long long>(h->T, h->nblk - 1 - k); fl += 2.0 * NB * NB * NB * (ni + ni * (ni + 1) / 2) + 2.0 * NB * NB * NB / 3; }
+    info[4] = fl; info[5] = h->small_pivot ? 1.0 : 0.0;
+    return 0;
+}
 
 }  // extern "C"

@@ -433,13 +433,15 @@ class NonMatchingOpt:
         return self._fun_cache.get(key) if getattr(self, "_fun_state", None) == tag else None
 
     # ------------------------------------------------------------------ direct solves with K
-    linear_solver = os.environ.get("GF_LINEAR_SOLVER", "host")     # "host": scipy SuperLU per call; "device": rocSOLVER re-factorisation
+    linear_solver = os.environ.get("GF_LINEAR_SOLVER", "device")   # "device": block-banded L D L^T on the GPU (default); "host": scipy SuperLU on a copy of K
 
     def solve_K(self, rhs):
         """x = K^{-1} rhs (= K^{-T} rhs: K is symmetric) with the tangent currently assembled on the device.
-        ``linear_solver == "device"``: ordering and symbolic factorisation once on the host, then every call after a new
-        assembly is a numeric re-factorisation + triangular solves on the GPU (goldfish_amd/_solver.py); K's values are read
-        in place from the library's buffer.  Replaces GOLDFISH/utils/opt_utils.py:156-209 (MUMPS on a copy of K per call)."""
+        ``linear_solver == "device"`` (default): bandwidth-reducing ordering once on the host, then every call after a new
+        assembly is a block-banded L D L^T factorisation + substitutions + iterative refinement on the GPU
+        (goldfish_amd/_solver.py, csrc/gf_solver.hip); K's values are read in place from the library's buffer.
+        ``"host"``: scipy SuperLU on a host copy of K (what MUMPS does in the reference; kept as the cross-check of the tests).
+        Replaces GOLDFISH/utils/opt_utils.py:156-209 (MUMPS on a copy of K per call)."""
         rhs = np.asarray(rhs, float)
         ver = getattr(self, "_k_version", 0)
         if self.linear_solver == "device":
@@ -610,15 +612,17 @@ class NonMatchingOpt:
         zero_mortar_funcs)."""
         if zero_mortar_funcs:
             self.update_uIGA(np.zeros(self.vec_iga_dof))
-        nrm = float("inf")
+        nrm = prev = float("inf")
         for it in range(max_it):
             self._assemble(_lib.ASM_R | _lib.ASM_K)
             R = self.dev.residual()
-            nrm = np.linalg.norm(R)
+            prev, nrm = nrm, np.linalg.norm(R)
             if it == 0 and ref_error is None:
                 ref_error = nrm if nrm > 0 else 1.0
             if nrm / ref_error < rtol:
                 break
+            if nrm > 0.5 * prev and nrm / ref_error < 1e-7:
+                break                               # quadratic convergence has reached the round-off floor of the residual: rtol is below it
             du = self.solve_K(-R)
             self.update_uIGA(self.u_iga + du)
         else:

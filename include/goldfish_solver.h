@@ -1,11 +1,17 @@
 /* goldfish_solver.h -- C ABI of libgoldfish_solver.so: sparse direct solves with K on the device.
  *
  * Replaces GOLDFISH/utils/opt_utils.py:156-209 (solve_Ax_b / solve_ATx_b: a MUMPS factorisation of a copy of K on every
- * call, GOLDFISH/operations/disp_imop.py:130-142) for everything after the first solve: the sparsity pattern of K never
- * changes during an optimisation, so the symbolic work and the fill-reducing ordering are done ONCE on the host
- * (SuperLU through scipy, symmetric mode) and every later Newton step / adjoint solve is a numeric re-factorisation
- * (rocSOLVER csrrf_refactlu) plus triangular solves (csrrf_solve) on the GPU, reading K's values in place from
- * libgoldfish_hip's buffer (gf_device_ptr(h, GF_BUF_VAL_K)).  K is symmetric, so K^T x = b is the same solve.
+ * call, GOLDFISH/operations/disp_imop.py:38-44, 130-142).  K never leaves the device: its values are read in place from
+ * libgoldfish_hip's buffer (gf_device_ptr(h, GF_BUF_VAL_K)).
+ *
+ * Method (hand-written HIP, no library dependency): the control points are renumbered by a bandwidth-reducing ordering
+ * computed once on the host (reverse Cuthill-McKee on the neighbour graph; the pattern never changes during an
+ * optimisation), K is scattered into block-banded storage (64 x 64 tiles, lower triangle) and factorised as
+ * P K P^T = L D L^T, right-looking over block columns: diagonal tile (LDL^T + inverse of its unit-triangular factor, one
+ * workgroup), panel tiles L_ik = A_ik L_kk^-T D_k^-1 and trailing tiles A_ij -= (L_ik D_k) L_jk^T as 64^3 products on
+ * v_mfma_f64_16x16x4.  No pivoting (K is symmetric; a vanishing pivot is reported).  Solves are block forward / backward
+ * substitutions with the inverted diagonal tiles, followed by iterative refinement with the block-CSR K itself.
+ * K is symmetric, so K^T x = b is the same solve.
  * All functions return 0 on success; gfs_last_error() describes the last failure of the calling thread. */
 #ifndef GOLDFISH_SOLVER_H
 #define GOLDFISH_SOLVER_H
@@ -18,20 +24,23 @@ typedef struct gfs_handle gfs_handle;
 
 const char* gfs_last_error(void);
 
-/* n: matrix order.  ptrA/indA (host, CSR pattern of K, sorted) and d_valA (DEVICE pointer to K's values, borrowed and
- * re-read by every gfs_refactor).  ptrT/indT/valT (host): T = (L - I) + U of a factorisation P K Q = L U of the CURRENT K;
- * pivP/pivQ (host): row i of P K is row pivP[i] of K, column j of K Q is column pivQ[j] of K. */
-int gfs_create(int device, int64_t n, int64_t nnzA, const int32_t* ptrA, const int32_t* indA, const double* d_valA,
-               int64_t nnzT, const int32_t* ptrT, const int32_t* indT, const double* valT,
-               const int32_t* pivP, const int32_t* pivQ, gfs_handle** out);
+/* ncp control points, 3 dofs each (dof = 3 * cp + component).  nb_ptr / nb (host): control-point-level neighbour lists =
+ * the block pattern of K as gf_pattern(GF_MAT_K) returns it (K's values: per control point a the three dof rows, each
+ * [neighbour k][j], i.e. value of entry ((a, i), (nb[k], j)) at 9 * nb_ptr[a] + i * 3 * deg(a) + 3 * k + j).
+ * new_index (host, ncp): position of every control point in the factorisation order (a permutation).
+ * d_valK: DEVICE pointer to K's values, borrowed and re-read by every gfs_refactor. */
+int gfs_create(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb, const int32_t* new_index, const double* d_valK, gfs_handle** out);
 void gfs_destroy(gfs_handle* h);
-/* numeric re-factorisation with the values currently in d_valA (same pattern) */
+/* numeric factorisation of the values currently in d_valK */
 int gfs_refactor(gfs_handle* h);
-/* x = K^{-1} b (host pointers, n doubles each) with the current factors */
-int gfs_solve(gfs_handle* h, const double* b, double* x);
-/* fill-in and memory of the factors */
-int64_t gfs_nnz_factors(gfs_handle* h);
-int64_t gfs_device_bytes(gfs_handle* h);
+/* x = K^{-1} b with the current factors and up to max_refine steps of iterative refinement (stops when the residual no longer
+ * decreases); b, x: 3 * ncp doubles, host pointers (gfs_solve) or device pointers (gfs_solve_dev).
+ * rel_residual (may be NULL): |b - K x| / |b| of the returned solution (2-norm). */
+int gfs_solve(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual);
+int gfs_solve_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual);
+/* info[0] = half bandwidth (dofs), [1] = block columns, [2] = band tiles per block row, [3] = device bytes,
+ * [4] = flops of one factorisation, [5] = 1 if the last factorisation met a pivot below 1e-14 * max |diag|, else 0 */
+int gfs_info(gfs_handle* h, double info[6]);
 
 #ifdef __cplusplus
 }

@@ -67,11 +67,10 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_solver_library_exports_every_declared_symbol():
-    """libgoldfish_solver.so (device re-factorisation + solves) loads and exports what
-    include/goldfish_solver.h declares; the generic-pattern symbolic step keeps fill that is numerically zero for the
-    actual matrix (scipy drops such entries from SuperLU's factors)."""
+    """libgoldfish_solver.so (block-banded L D L^T factorisation + solves on the device) loads and exports
+    what include/goldfish_solver.h declares (no compute call without a GPU: gfs_create must fail cleanly); the host half --
+    control-point graph from the dof pattern, bandwidth-reducing order -- on a two-patch model."""
     import scipy.sparse as sp
-    import scipy.sparse.linalg as spla
     from goldfish_amd import _solver, build
     build.build()
     hdr = open(os.path.join(ROOT, "include", "goldfish_solver.h")).read()
@@ -81,26 +80,38 @@ def test_solver_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_solver.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    # arrow matrix whose first row/column is numerically zero except the diagonal: the fill it causes must stay in the pattern
-    n = 12
-    rows, cols = [0] * (n - 1) + list(range(1, n)), list(range(1, n)) + [0] * (n - 1)
-    K = sp.csr_matrix((np.concatenate([np.zeros(2 * (n - 1)), np.ones(n)]), (rows + list(range(n)), cols + list(range(n)))), shape=(n, n))
-    K.sum_duplicates()
-    T, pivP, pivQ = _solver.host_symbolic(K)
-    assert np.array_equal(pivP, pivQ) and sorted(pivP) == list(range(n))
-    G = sp.csr_matrix(([2.0 + 0.01 * k for k in range(K.nnz)], K.indices, K.indptr), shape=(n, n))
-    G = (G + G.T + 50 * sp.identity(n)).tocsc()                   # a matrix with the same structure and no zeros
-    Pm = sp.csr_matrix((np.ones(n), (np.arange(n), pivP)), shape=(n, n))
-    Qm = sp.csr_matrix((np.ones(n), (pivQ, np.arange(n))), shape=(n, n))
-    B = (Pm @ G @ Qm).toarray()                                  # row i of P G is row pivP[i] of G, column j of G Q is column pivQ[j]
-    Lm, Um = np.eye(n), B.copy()
-    for k in range(n):                                            # LU without pivoting of the permuted matrix: fill must lie inside T's pattern
-        for i in range(k + 1, n):
-            Lm[i, k] = Um[i, k] / Um[k, k]
-            Um[i] -= Lm[i, k] * Um[k]
-    fill = (np.abs(np.tril(Lm, -1)) + np.abs(np.triu(Um))) > 1e-14
-    stored = {(r, int(c)) for r in range(n) for c in T.indices[T.indptr[r]:T.indptr[r + 1]]}
-    assert {(int(r), int(c)) for r, c in zip(*np.nonzero(fill))} <= stored
+    # dof-level pattern of a small block matrix -> control-point lists; the order is a permutation that shrinks the bandwidth
+    rng = np.random.default_rng(0)
+    ncp = 60
+    pts = rng.uniform(0, 1, (ncp, 2))
+    adj = (np.abs(pts[:, None, :] - pts[None, :, :]).max(-1) < 0.22)
+    nb_lists = [np.flatnonzero(adj[a]) for a in range(ncp)]
+    rowptr, col = [0], []
+    for a in range(ncp):
+        for i in range(3):
+            col += [3 * b + j for b in nb_lists[a] for j in range(3)]
+            rowptr.append(len(col))
+    nb_ptr, nb = _solver.control_point_graph(np.array(rowptr), np.array(col))
+    assert np.array_equal(nb_ptr, np.concatenate([[0], np.cumsum([len(x) for x in nb_lists])]))
+    assert np.array_equal(nb, np.concatenate(nb_lists))
+    new = _solver.bandwidth_reducing_order(nb_ptr, nb)
+    assert sorted(new) == list(range(ncp))
+    bw_old = max(abs(a - b) for a in range(ncp) for b in nb_lists[a])
+    bw_new = max(abs(int(new[a]) - int(new[b])) for a in range(ncp) for b in nb_lists[a])
+    assert bw_new < bw_old
+    if _lib_has_no_gpu():
+        h = ctypes.c_void_p()
+        L.gfs_create.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                 ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        L.gfs_last_error.restype = ctypes.c_char_p
+        rc = L.gfs_create(0, ncp, nb_ptr.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), nb.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                          new.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.c_void_p(8), ctypes.byref(h))
+        assert rc != 0 and b"no HIP device" in L.gfs_last_error()
+
+
+def _lib_has_no_gpu():
+    from goldfish_amd import _lib
+    return _lib.lib().gf_device_count() == 0
 
 
 def test_partition_and_shards():
