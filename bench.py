@@ -30,29 +30,55 @@ ALG_BYTES_PER_GP = {2: 476.4, 3: 520.0, 4: 548.0}    # (K + 3 dR
 ALG_FLOP_PER_GP = {2: 2.6e4, 3: 6.3e4, 4: 1.4e5}     # FMA*2 count of the kernel's formulation, DESIGN.md section 4
 
 
+def usable_cores():
+    """Cores this process can really run on: the affinity mask, capped by the cgroup CPU quota (cpu.max / cfs_quota) of the box."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            q, per = parse(open(path).read())
+            if q != "max" and int(q) > 0:
+                n = max(1, min(n, int(round(int(q) / int(per)))))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(args, ncores):
-    """The CPU oracle (C, OpenMP over patches) on a bounded sample of the same workload:
-    `ncores` patches of the C4 generator, full assembly + residual, best of 2."""
+    """The CPU oracle (C, OpenMP over patches: the restatement of the reference's algorithm) on a bounded
+    sample of the same workload, on this box's host cores: one patch on one thread, and one patch per usable core on all of
+    them (`ncores` = the cores this process may run on); each 1 warm-up + best of 5 (3 for the single thread: ~4 s a run)."""
     from goldfish_amd import geometry as G
     from goldfish_amd.model import arrays_from_spec
     from oracle import oracle_py
     oracle_py.build()
-    npatch = max(1, min(ncores, 32))           # OpenMP parallelism of the oracle is over patches
-    oracle_py.lib().gfo_set_num_threads(npatch)
-    spec = G.synthetic_shell(npatch, 1, nel=args.nel, p=args.degree, jitter=2)
-    th = G.random_thickness(spec)
-    A = arrays_from_spec(spec, th)
-    O = oracle_py.Oracle(A, thickness=np.concatenate(th), u=G.smooth_displacement(spec, 0.5 * spec.h_th))
-    best = 1e30
-    for _ in range(2):
-        t0 = time.perf_counter()
-        O.residual()
-        O.assemble()
-        best = min(best, time.perf_counter() - t0)
-    return {"value": A.n_gauss_points / best, "unit": "GP-updates/s", "cores": npatch,
-            "kind": "port", "host_cores": ncores,
-            "sample": "%d patches (%d GPs) of the same generator, oracle/kl_oracle.c R+K+dRdCP+dRdh on %d OpenMP threads (one per patch), best of 2 (%.1f s)"
-            % (npatch, A.n_gauss_points, npatch, best)}
+
+    def run(npatch, nthreads, reps):
+        oracle_py.lib().gfo_set_num_threads(nthreads)
+        spec = G.synthetic_shell(npatch, 1, nel=args.nel, p=args.degree, jitter=2)
+        th = G.random_thickness(spec)
+        A = arrays_from_spec(spec, th)
+        O = oracle_py.Oracle(A, thickness=np.concatenate(th), u=G.smooth_displacement(spec, 0.5 * spec.h_th))
+        best = 1e30
+        for it in range(reps + 1):                 # first run = warm-up
+            t0 = time.perf_counter()
+            O.residual()
+            O.assemble()
+            if it > 0:
+                best = min(best, time.perf_counter() - t0)
+        return A.n_gauss_points / best, A.n_gauss_points, best
+
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    v1, gp1, t1 = run(1, 1, 3)
+    nall = max(1, min(ncores, 256))
+    # bounded sample: the all-core leg is skipped down to what ~5 s per repetition allows if the cores turn out to be oversubscribed
+    vn, gpn, tn = run(nall, nall, 5 if t1 * 6 < 30 else 2) if nall > 1 else (v1, gp1, t1)
+    return {"value": vn, "unit": "GP-updates/s", "cores": nall, "kind": "port", "host_cores": os.cpu_count(), "usable_cores": ncores,
+            "single_thread": {"value": v1, "cores": 1, "sample": "1 patch (%d GPs), best of 3 after 1 warm-up (%.1f s)" % (gp1, t1)},
+            "sample": "%d patches (%d GPs) of the same generator, oracle/kl_oracle.c R+K+dRdCP+dRdh on %d OpenMP threads (one patch per thread), "
+                      "best of 5 after 1 warm-up (%.1f s)" % (nall, gpn, nall, tn)}
 
 
 def main():
@@ -72,6 +98,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    from goldfish_amd import build
+    if rank == 0:
+        build.build()                          # hipcc (if anything is stale) runs before this process touches the GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
     # GF_BENCH_REHEARSE=1: all ranks on GPU 0 with the gloo backend -- exercises the N > 1 code path on a one-GPU box
@@ -88,16 +117,16 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from goldfish_amd import _lib, build, geometry as G, sharding
-    if rank == 0:
-        build.build()
+    from goldfish_amd import _lib, geometry as G, sharding
     if dist is not None:
         dist.barrier()
 
     spec = G.synthetic_shell(args.patches[0], args.patches[1], nel=args.nel, p=args.degree, jitter=2)
     th_g = G.random_thickness(spec)
     u_g = G.smooth_displacement(spec, 0.5 * spec.h_th)
-    shard = sharding.shard_spec(spec, rank, world)
+    part = sharding.partition_patches(spec, world)          # interface-graph partition balanced by Gauss points
+    pq = sharding.partition_quality(spec, part)
+    shard = sharding.shard_spec(spec, rank, world, part)
     A = sharding.shard_arrays(shard, th_g)
     D = _lib.DeviceModel(A, device=local_rank)
     D.set_thickness(shard.to_local(np.concatenate(th_g)))
@@ -113,10 +142,16 @@ def main():
     R_loc = torch.as_tensor(_Buf(_lib.lib().gf_device_ptr(D.h, _lib.BUF_R), A.ndof), device="cuda") if exchange else None
     R_glob = torch.zeros(3 * shard.total_cp_global, dtype=torch.float64, device="cuda") if exchange else None
 
+    # the library launches on its own stream: the exchange (torch's stream, RCCL) is ordered behind the assembly by an event,
+    # and the next assembly behind the exchange's read of the residual buffer -- no host synchronisation inside a step
+    lib_stream = torch.cuda.ExternalStream(D.stream_ptr) if exchange else None
+
     def step():
+        if exchange:
+            lib_stream.wait_stream(torch.cuda.current_stream())
         D.assemble(_lib.ASM_ALL, sync=False)
         if exchange:
-            D.sync()
+            torch.cuda.current_stream().wait_stream(lib_stream)
             sharding.allgather_owned_rows(shard, R_loc, dist, 3, out=R_glob)
 
     def fence():
@@ -136,9 +171,10 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kern_ms, kern_n = D.kernel_ms()
+    kern_ms_step = kern_ms * kern_n / max(args.steps, 1)      # element-kernel time per step (a step may launch it in chunks)
     if exchange:       # the exchanged global residual must equal the library's own copy of the owned rows
-        g0, g1 = shard.owned_global_range(3)
-        assert np.array_equal(R_glob[g0:g1].cpu().numpy(), D.residual()[:g1 - g0]) or world > 1
+        rows = shard.owned_rows_global(3)
+        assert np.array_equal(R_glob[torch.from_numpy(rows).cuda()].cpu().numpy(), D.residual()[:rows.size])
     # the HBM-bound phase of the path: apply_linear = block-CSR SpMV on the assembled K
     # (DispImOpeartion.apply_linear_fwd, disp_imop.py:58-72), device pointers, HIP events on torch's stream are
     # not used: the library's own stream is timed by wall clock around a synchronised batch
@@ -181,16 +217,17 @@ def main():
     if rank == 0:
         p = args.degree
         alg_bytes = ALG_BYTES_PER_GP[p] * n_gp_local
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = None
+        achieved = alg_bytes / (kern_ms_step * 1e-3) / 1e9 if kern_ms_step > 0 else 0.0
+        traffic = counter_flop = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
                 if tj.get("workload_gps") == n_gp_local:
                     traffic = tj.get("element_kernel_bytes_per_launch")
+                    counter_flop = tj.get("element_kernel_fp64_flop_issued_per_launch")
             except Exception:
-                traffic = None
+                traffic = counter_flop = None
         mfma = os.environ.get("GF_ELEMENT", "mfma") != "valu"
         kname = ("kl_element_mfma4_kernel" if p == 4 else "kl_element_mfma_kernel") if mfma else "kl_element_kernel"
         out = {
@@ -201,12 +238,15 @@ def main():
                                    "%d dofs, %d Gauss points, %d mortar points; R+K+dRdCP(3)+dRdh incl. penalty coupling"
                                    % ("C4" if (args.patches == [16, 16] and args.nel == 48 and p == 3) else "custom", args.patches[0], args.patches[1], p, args.nel, 3 * shard.total_cp_global, n_gp_total,
                                       sum(i.npts for i in spec.interfaces)),
-                       "parallelism": "patch-sharded x%d, owner-computes-rows, all-gather of the owned residual rows" % world},
+                       "parallelism": "patch-sharded x%d (interface-graph partition), owner-computes-rows, all-gather of the owned residual rows" % world,
+                       "partition": {"gauss_points_per_rank": pq["gauss_points"], "imbalance_max_over_mean": pq["imbalance"],
+                                     "cut_interfaces": pq["cut_interfaces"], "ghost_patches_per_rank": pq["ghost_patches"]}},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms, "launches_timed": kern_n},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms_step, "launches_timed": kern_n,
+                         "launches_per_step": kern_n / max(args.steps, 1)},
             "roofline_fp64": {"bound": "fp64 (v_mfma_f64 + FP64 VALU share one pipe)" if mfma else "fp64-valu", "kernel": kname,
-                              "achieved": ALG_FLOP_PER_GP[p] * n_gp_local / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
+                              "achieved": ALG_FLOP_PER_GP[p] * n_gp_local / (kern_ms_step * 1e-3) / 1e12 if kern_ms_step > 0 else 0.0,
                               "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "note": "the tangent / shape-Jacobian contraction is FP64 bound (SURVEY.md 8(d)); "
                                       "this is the binding roofline of the dominant kernel; flop count = the formulation's "
@@ -216,9 +256,12 @@ def main():
             "device_bytes": D.device_bytes,
         }
         out["roofline_fp64"]["frac"] = out["roofline_fp64"]["achieved"] / FP64_PEAK_TFLOPS
+        if counter_flop and kern_ms_step > 0:      # the same fraction with the flop count the SQ counters report for this kernel and workload (profiles/traffic.json)
+            out["roofline_fp64"]["counter_flop_per_launch"] = counter_flop
+            out["roofline_fp64"]["frac_counters"] = counter_flop / (kern_ms_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, os.cpu_count() or 1)
+                out["cpu_baseline"] = cpu_baseline(args, usable_cores())
             except Exception as ex:       # the oracle is only the reported baseline; never the product
                 out["cpu_baseline"] = {"error": str(ex)}
         print(json.dumps(out), flush=True)

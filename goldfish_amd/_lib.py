@@ -18,7 +18,7 @@ BUF_CP, BUF_U, BUF_H, BUF_R, BUF_VAL_K, BUF_VAL_C0, BUF_VAL_C1, BUF_VAL_C2, BUF_
 EXPORTS = ["gf_device_count", "gf_last_error", "gf_create", "gf_destroy", "gf_total_cp", "gf_num_dofs",
            "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes", "gf_set_cp",
            "gf_set_thickness", "gf_set_u", "gf_nnz", "gf_pattern", "gf_assemble", "gf_sync", "gf_get_residual",
-           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_shape_regu", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms", "gf_assembly_path"]
+           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_shape_regu", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms", "gf_assembly_path", "gf_stream"]
 
 
 def lib():
@@ -57,6 +57,8 @@ def lib():
         L.gf_device_ptr.argtypes = [vp, C.c_int]
         L.gf_apply_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.gf_assembly_path.argtypes = [vp]
+        L.gf_stream.restype = vp
+        L.gf_stream.argtypes = [vp]
         L.gf_kernel_ms.restype = C.c_double
         L.gf_kernel_ms.argtypes = [vp, C.POINTER(C.c_int)]
         _LIB = L
@@ -204,6 +206,11 @@ class DeviceModel:
         n = C.c_int(0)
         ms = lib().gf_kernel_ms(self.h, C.byref(n))
         return ms, n.value
+
+    @property
+    def stream_ptr(self):
+        """hipStream_t of the handle (torch.cuda.ExternalStream(D.stream_ptr) orders torch work against the library's without a host sync)."""
+        return lib().gf_stream(self.h)
 
     @property
     def assembly_path(self):

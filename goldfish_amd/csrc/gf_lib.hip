@@ -520,6 +520,8 @@ double gf_kernel_ms(gf_handle* h, int* n_launches) {
     return n > 0 ? tot / n : 0.0;
 }
 
+void* gf_stream(gf_handle* h) { return h ? (void*)h->stream : nullptr; }
+
 int gf_assembly_path(const gf_handle* h) { return !h ? -1 : (h->walk ? 2 : (h->mfma ? 0 : 3)); }
 
 int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, double* dCdu, double* dCdcp, int apply_bcs) {

@@ -133,6 +133,10 @@ int gf_apply_dev(gf_handle* h, int which, int transpose, const double* x_dev, do
  * last call, measured with HIP events on the handle's stream; resets the accumulator. */
 double gf_kernel_ms(gf_handle* h, int* n_launches);
 
+/* the HIP stream (hipStream_t) the handle launches on: lets a caller order its own streams / collectives against the
+ * library's work with events (torch.cuda.ExternalStream(ptr)) instead of gf_sync */
+void* gf_stream(gf_handle* h);
+
 /* which element path gf_assemble runs on this handle: 0 = MFMA element kernel, one block per element + row gather (default),
  * 2 = walking kernel that accumulates straight into the CSR arrays (GF_WALK=1, p = 2, 3), 3 = FP64-VALU element kernel + gather
  * (GF_ELEMENT=valu) */

@@ -35,8 +35,8 @@ def _worker(rank, world, port, q):
     # reverse-mode product with remote columns: y = sum_ranks (dR/dCP_0 owned rows)^T lambda_owned
     lam = np.sin(np.arange(3 * sh.total_cp_global) * 0.37)
     C0 = O.csr(1, O.assemble(K=False, dRdCP=(0,), dRdh=False)[1])
-    g0, g1 = sh.owned_global_range(3)
-    yl = C0[:g1 - g0].T @ lam[g0:g1]
+    rows = sh.owned_rows_global(3)
+    yl = C0[:rows.size].T @ lam[rows]
     yg = torch.zeros(sh.total_cp_global, dtype=torch.float64)
     yg.index_add_(0, torch.from_numpy(sh.local_cols_to_global()), torch.from_numpy(yl))
     dist.all_reduce(yg)
@@ -46,14 +46,19 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_residual_and_adjoint_product(oracle_lib):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_residual_and_adjoint_product(oracle_lib, world):
+    """world_size 2 and 4 (4: a 2 x 2 block partition whose owned patches are not contiguous in the global numbering)."""
     from goldfish_amd import geometry as G
     from goldfish_amd.model import arrays_from_spec
     from oracle.oracle_py import Oracle
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     Rg, yg = q.get(timeout=300)

@@ -115,20 +115,38 @@ def _lib_has_no_gpu():
 
 
 def test_partition_and_shards():
+    """Partition of the interface graph: every patch owned once, balanced Gauss points, ghosts = the patches
+    across cut interfaces; the owned rows of a rank (not contiguous in the global numbering in general) map back to the global vector."""
     spec = G.synthetic_shell(4, 3, nel=4, p=3, jitter=1)
     for world in (1, 2, 3, 4):
-        parts = sharding.partition_patches(spec, world)
-        assert parts[0][0] == 0 and parts[-1][1] == 12 and all(a < b for a, b in parts)
-        assert all(parts[r][1] == parts[r + 1][0] for r in range(world - 1))
-    sh = sharding.shard_spec(spec, 1, 2)
-    own = set(sh.order[:sh.n_owned])
-    for itf_g in spec.interfaces:
-        if (itf_g.a in own) != (itf_g.b in own):
-            assert {itf_g.a, itf_g.b} <= set(sh.order)
-    g0, g1 = sh.owned_global_range(3)
-    assert g1 - g0 == sh.owned_local_size(3)
-    v = np.arange(3 * sh.total_cp_global, dtype=float)
-    assert np.array_equal(sh.to_local(v, 3)[:g1 - g0], v[g0:g1])
+        part = sharding.partition_patches(spec, world)
+        assert part.shape == (12,) and sorted(set(part.tolist())) == list(range(world))
+        q = sharding.partition_quality(spec, part)
+        assert q["imbalance"] < 1.35 and sum(q["owned_patches"]) == 12
+    for rank in range(3):
+        sh = sharding.shard_spec(spec, rank, 3)
+        own = set(sh.order[:sh.n_owned])
+        assert own == set(sh.owned_by_rank[rank])
+        for itf_g in spec.interfaces:
+            if (itf_g.a in own) != (itf_g.b in own):
+                assert {itf_g.a, itf_g.b} <= set(sh.order)
+        rows = sh.owned_rows_global(3)
+        assert rows.size == sh.owned_local_size(3)
+        v = np.arange(3 * sh.total_cp_global, dtype=float)
+        assert np.array_equal(sh.to_local(v, 3)[:rows.size], v[rows])
+    allrows = np.sort(np.concatenate([sh.owned_rows_global(3, r) for r in range(3)]))
+    assert np.array_equal(allrows, np.arange(3 * sh.total_cp_global))
+
+
+def test_partition_of_the_c4_topology_at_eight_ranks():
+    """C4 (16 x 16 patches, 480 interfaces) over 8 ranks: the 4 x 2 arrangement of 4 x 8-patch blocks -- 64 cut interfaces
+    (a contiguous 1-D split cuts 112), Gauss points balanced to 1 %, half of the owned patches as ghosts on average."""
+    spec = G.synthetic_shell(16, 16, nel=48, p=3, jitter=2)
+    for world, cut in ((2, 16), (4, 32), (8, 64)):
+        q = sharding.partition_quality(spec, sharding.partition_patches(spec, world))
+        assert q["cut_interfaces"] <= cut and q["imbalance"] < 1.02, (world, q)
+        assert q["owned_patches"] == [256 // world] * world
+    assert q["ghost_fraction_mean"] <= 0.5 and q["ghost_fraction_max"] <= 0.65
 
 
 def test_no_gpu_means_loud_failure():

@@ -24,5 +24,25 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
        "workload_gps": gps, "kernels": kern,
        "element_kernel": el[0] if el else None,
        "element_kernel_bytes_per_launch": kern[el[0]]["hbm_side_bytes_corrected_per_launch"] if el else None}
+# FP64 work per launch as the SQ counters see it (tools/profile_round.sh, fourth pass): flop = 512 * MFMA_MOPS_F64 + 64 * (2 FMA + ADD + MUL + TRANS)
+# wave-level VALU instructions (all 64 lanes counted, active or not: issued work, what occupies the FP64 pipe)
+import os
+fp = "profiles/%s_pmc_fp64.csv" % tag
+if os.path.exists(fp):
+    acc, disp = collections.defaultdict(lambda: collections.defaultdict(float)), collections.defaultdict(set)
+    for r in csv.DictReader(open(fp)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("gf::", "")
+        if not name.startswith(("kl_", "pen_")): name = name.split("<")[0]
+        acc[name][r["Counter_Name"]] += float(r["Counter_Value"]); disp[name].add(r["Dispatch_Id"])
+    for k, c in acc.items():
+        n = max(1, len(disp[k]))
+        flop = (512.0 * c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) + 64.0 * (2.0 * c.get("SQ_INSTS_VALU_FMA_F64", 0.0) + c.get("SQ_INSTS_VALU_ADD_F64", 0.0)
+                + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0))) / n
+        kern.setdefault(k, {})["fp64_flop_issued_per_launch"] = flop
+        kern[k]["fp64_mfma_flop_per_launch"] = 512.0 * c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) / n
+        if c.get("SQ_BUSY_CYCLES", 0.0) > 0: kern[k]["mfma_busy_over_busy_cycles"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / c["SQ_BUSY_CYCLES"]
+        if c.get("SQ_WAVE_CYCLES", 0.0) > 0: kern[k]["mfma_busy_cycles_over_wave_cycles_x4"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * c["SQ_WAVE_CYCLES"])
+    out["fp64_note"] = "SQ counters (profiles/%s_pmc_fp64.csv): issued FP64 flop per launch = 512 * MFMA_MOPS_F64 + 64 * (2 FMA_F64 + ADD_F64 + MUL_F64 + TRANS_F64); SQ_WAVE_CYCLES counts quad-cycles" % tag
+    if el: out["element_kernel_fp64_flop_issued_per_launch"] = kern[el[0]].get("fp64_flop_issued_per_launch")
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps({k: round(v["hbm_side_bytes_corrected_per_launch"] / 1e9, 2) for k, v in kern.items()}))
