@@ -2,6 +2,7 @@
 fallback: a missing library or a missing GPU raises."""
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -18,7 +19,7 @@ BUF_CP, BUF_U, BUF_H, BUF_R, BUF_VAL_K, BUF_VAL_C0, BUF_VAL_C1, BUF_VAL_C2, BUF_
 EXPORTS = ["gf_device_count", "gf_last_error", "gf_create", "gf_destroy", "gf_total_cp", "gf_num_dofs",
            "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes", "gf_set_cp",
            "gf_set_thickness", "gf_set_u", "gf_nnz", "gf_pattern", "gf_assemble", "gf_sync", "gf_get_residual",
-           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_shape_regu", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms", "gf_assembly_path", "gf_stream"]
+           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_shape_regu", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms", "gf_assembly_path", "gf_stream", "gf_apply_many", "gf_get_functional_gradient", "gf_penalty_dxi_range"]
 
 
 def lib():
@@ -52,11 +53,14 @@ def lib():
         L.gf_compliance.argtypes = [vp, dp, i64, dp, dp, dp, C.c_int]
         L.gf_shape_regu.argtypes = [vp, C.c_int, dp, i64, dp, i64, dp, dp]
         L.gf_penalty_dxi.argtypes = [vp, dp, i64, C.POINTER(C.c_int32), i64]
+        L.gf_penalty_dxi_range.argtypes = [vp, i64, i64, dp, i64, C.POINTER(C.c_int32), i64]
         L.gf_stress_forms.argtypes = [vp, C.c_int, C.c_double, dp, i64, C.c_int, C.c_int, dp, dp, dp, dp, dp, C.c_int]
         L.gf_device_ptr.restype = vp
         L.gf_device_ptr.argtypes = [vp, C.c_int]
         L.gf_apply_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.gf_assembly_path.argtypes = [vp]
+        L.gf_get_functional_gradient.argtypes = [vp, C.c_int, dp, i64]
+        L.gf_apply_many.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(dp), C.POINTER(dp)]
         L.gf_stream.restype = vp
         L.gf_stream.argtypes = [vp]
         L.gf_kernel_ms.restype = C.c_double
@@ -72,6 +76,44 @@ def _dp(a):
 def _check(rc, exc=RuntimeError):
     if rc != 0:
         raise exc(lib().gf_last_error().decode())
+
+
+class _LazyFields(dict):
+    """dict of the results of a functional evaluation whose gradient fields are fetched from the device on first access."""
+
+    def __init__(self, dev, fields):
+        super().__init__()
+        self._dev, self._pending = dev, dict(fields)
+
+    def _fetch(self, key):
+        field, shape = self._pending.pop(key)
+        arr = np.zeros(shape)
+        _check(lib().gf_get_functional_gradient(self._dev.h, field, _dp(arr), arr.size))
+        dict.__setitem__(self, key, arr)
+
+    def __missing__(self, key):
+        if key in self._pending:
+            self._fetch(key)
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._pending
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        self.materialize()
+        return dict.keys(self)
+
+    def items(self):
+        self.materialize()
+        return dict.items(self)
+
+    def materialize(self):
+        for key in list(self._pending):
+            self._fetch(key)
 
 
 class DeviceModel:
@@ -91,6 +133,7 @@ class DeviceModel:
 
     def close(self):
         if getattr(self, "h", None):
+            self._materialize_lazy()              # results handed out stay valid after the handle is gone
             lib().gf_destroy(self.h)
             self.h = None
 
@@ -160,19 +203,51 @@ class DeviceModel:
         _check(lib().gf_apply(self.h, which, int(bool(transpose)), _dp(x), x.size, _dp(y), y.size), ValueError)
         return y
 
+    def apply_many(self, which, xs, ys, transpose=False):
+        """Several products with one copy in / out per vector (gf_apply_many): transpose=False: ys[0] += sum_m A_m xs[m];
+        transpose=True: ys[m] += A_m^T xs[0].  ys are contiguous float64 arrays updated in place."""
+        which = [int(w) for w in which]
+        xs = [np.ascontiguousarray(x, dtype=np.float64) for x in xs]
+        for y in ys:
+            if not (isinstance(y, np.ndarray) and y.dtype == np.float64 and y.flags.c_contiguous):
+                raise ValueError("apply_many: ys must be contiguous float64 ndarrays (updated in place)")
+        nrow = self.ndof
+        for m, w in enumerate(which):
+            ncol = self.ndof if w == MAT_K else self.total_cp
+            x, y = (xs[0], ys[m]) if transpose else (xs[m], ys[0])
+            if x.size != (nrow if transpose else ncol) or y.size != (ncol if transpose else nrow):
+                raise ValueError("apply_many: vector lengths do not match the matrix shape")
+        wa = (C.c_int * len(which))(*which)
+        xa = (C.POINTER(C.c_double) * len(xs))(*[_dp(x) for x in xs])
+        ya = (C.POINTER(C.c_double) * len(ys))(*[_dp(y) for y in ys])
+        _check(lib().gf_apply_many(self.h, int(bool(transpose)), len(which), wa, xa, ya), ValueError)
+        return ys
+
     def functionals(self, apply_bcs=True):
+        """W_int, volume, penalty energy and their gradient fields (gf_functionals).  The values come back at once; a gradient
+        field is copied from the device when it is first read (each is ndof or total_cp doubles over PCIe: a caller that wants
+        dW/du only does not pay for the other four), or all remaining ones before the gradient buffer is reused."""
+        self._materialize_lazy()
         out = np.zeros(3)
-        g = dict(dWdu=np.zeros(self.ndof), dWdcp=np.zeros((3, self.total_cp)), dWdh=np.zeros(self.total_cp),
-                 dVdcp=np.zeros((3, self.total_cp)), dVdh=np.zeros(self.total_cp))
-        _check(lib().gf_functionals(self.h, _dp(out), _dp(g["dWdu"]), _dp(g["dWdcp"]), _dp(g["dWdh"]),
-                                    _dp(g["dVdcp"]), _dp(g["dVdh"]), int(apply_bcs)))
+        null = C.POINTER(C.c_double)()
+        _check(lib().gf_functionals(self.h, _dp(out), null, null, null, null, null, int(apply_bcs)))
+        g = _LazyFields(self, {"dWdu": (0, (self.ndof,)), "dWdcp": (1, (3, self.total_cp)), "dWdh": (2, (self.total_cp,)),
+                               "dVdcp": (3, (3, self.total_cp)), "dVdh": (4, (self.total_cp,))})
         g.update(Wint=out[0], volume=out[1], Wpen=out[2])
+        self._lazy_fun = weakref.ref(g)           # only a result somebody still holds has to be completed before the buffer is reused
         return g
+
+    def _materialize_lazy(self):
+        ref = getattr(self, "_lazy_fun", None)
+        g = ref() if ref is not None else None
+        if g is not None:
+            g.materialize()
+        self._lazy_fun = None
 
     def compliance(self, forces, apply_bcs=True):
         f = np.ascontiguousarray(forces, dtype=np.float64).ravel()
         out, dCdu, dCdcp = np.zeros(1), np.zeros(self.ndof), np.zeros((3, self.total_cp))
-        _check(lib().gf_compliance(self.h, _dp(f), f.size, _dp(out), _dp(dCdu), _dp(dCdcp), int(apply_bcs)), ValueError)
+        self._materialize_lazy(); _check(lib().gf_compliance(self.h, _dp(f), f.size, _dp(out), _dp(dCdu), _dp(dCdcp), int(apply_bcs)), ValueError)
         return dict(C=out[0], dCdu=dCdu, dCdcp=dCdcp)
 
     def stress_forms(self, mode, rho, m_list, surf=1, measure=0, apply_bcs=True, gradients=True):
@@ -181,7 +256,7 @@ class DeviceModel:
         I, vmax = np.zeros(ml.size), np.zeros(ml.size)
         g = dict(dIdu=np.zeros(self.ndof), dIdcp=np.zeros((3, self.total_cp)), dIdh=np.zeros(self.total_cp)) if gradients else \
             dict(dIdu=None, dIdcp=None, dIdh=None)
-        _check(lib().gf_stress_forms(self.h, int(mode), float(rho), _dp(ml), ml.size, int(surf), int(measure), _dp(I), _dp(vmax),
+        self._materialize_lazy(); _check(lib().gf_stress_forms(self.h, int(mode), float(rho), _dp(ml), ml.size, int(surf), int(measure), _dp(I), _dp(vmax),
                                      _dp(g["dIdu"]), _dp(g["dIdcp"]), _dp(g["dIdh"]), int(apply_bcs)), ValueError)
         g.update(I=I, vmax=vmax)
         return g
@@ -191,15 +266,16 @@ class DeviceModel:
         cp0 = np.ascontiguousarray(cp0, dtype=np.float64).ravel()
         coef = np.ascontiguousarray(coef, dtype=np.float64).ravel()
         val, dcp = np.zeros(1), np.zeros((3, self.total_cp))
-        _check(lib().gf_shape_regu(self.h, int(field), _dp(cp0), cp0.size, _dp(coef), coef.size, _dp(val), _dp(dcp)), ValueError)
+        self._materialize_lazy(); _check(lib().gf_shape_regu(self.h, int(field), _dp(cp0), cp0.size, _dp(coef), coef.size, _dp(val), _dp(dcp)), ValueError)
         return dict(value=val[0], dcp=dcp)
 
-    def penalty_dxi(self, npts, degree):
-        """Per-vertex blocks of d(penalty residual)/d(xi, tau) and the support windows (gf_penalty_dxi)."""
+    def penalty_dxi(self, npts, degree, v_first=0):
+        """Per-vertex blocks of d(penalty residual)/d(xi, tau) and the support windows of the mortar vertices
+        v_first .. v_first + npts - 1 (gf_penalty_dxi_range; the whole model with the defaults of the callers)."""
         nb = (degree + 1) ** 2
         blocks = np.zeros((npts, 6, 2, nb, 3))
         win = np.zeros((npts, 2, 2), dtype=np.int32)
-        _check(lib().gf_penalty_dxi(self.h, _dp(blocks), blocks.size, win.ctypes.data_as(C.POINTER(C.c_int32)), win.size), ValueError)
+        _check(lib().gf_penalty_dxi_range(self.h, int(v_first), int(npts), _dp(blocks), blocks.size, win.ctypes.data_as(C.POINTER(C.c_int32)), win.size), ValueError)
         return blocks, win
 
     def kernel_ms(self):

@@ -859,6 +859,23 @@ __global__ __launch_bounds__(256) void kl_fgather_kernel(DevModel M, long long a
     }
     fun[6 * T + a] = acc[9]; fun[10 * T + a] = acc[10];
 }
+// Per-segment sums (and maxima) of per-element / per-vertex values, in fixed order: one workgroup per segment (the elements of a
+// patch, the vertices of an interface), strided partial sums per thread, fixed tree.  The few per-segment numbers are what crosses
+// to the host (gf_functionals, gf_compliance, gf_stress_forms, gf_shape_regu) instead of nelem-long arrays.
+__global__ __launch_bounds__(256) void seg_reduce_kernel(const long long* __restrict__ seg_off, const double* __restrict__ a, const double* __restrict__ b,
+                                                         double* __restrict__ sum_a, double* __restrict__ sum_b, double* __restrict__ max_b) {
+    __shared__ double sa[256], sb[256], sm[256];
+    const long long i0 = seg_off[blockIdx.x], i1 = seg_off[blockIdx.x + 1];
+    double xa = 0.0, xb = 0.0, xm = 0.0;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) { xa += a[i]; if (b) { xb += b[i]; xm = fmax(xm, b[i]); } }
+    sa[threadIdx.x] = xa; sb[threadIdx.x] = xb; sm[threadIdx.x] = xm;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { sa[threadIdx.x] += sa[threadIdx.x + off]; sb[threadIdx.x] += sb[threadIdx.x + off]; sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + off]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sum_a[blockIdx.x] = sa[0]; if (sum_b) sum_b[blockIdx.x] = sb[0]; if (max_b) max_b[blockIdx.x] = sm[0]; }
+}
 __global__ void pen_energy_kernel(long long npts, const double* __restrict__ pbuf, double* __restrict__ en) {
     const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (v < npts) en[v] = pbuf[(size_t)v * PB_STRIDE + PB_EN];
@@ -908,11 +925,11 @@ __global__ __launch_bounds__(64) void pen_point_kernel(DevModel M, DevPenalty Q,
 // pass of the vertex gradient in dual numbers, then the contraction with both sides' basis values:
 //   out[(v*6 + dir)][sd'][a][i] = sum_m nu_m,a^(sd') d(grad)[9 sd' + 3 m + i] + [sd' == sd] sum_m d(nu_m,a)/d(xi_d) grad[9 sd + 3 m + i]
 template <int P>
-__global__ __launch_bounds__(64) void pen_dxi_kernel(DevModel M, DevPenalty Q, const double* __restrict__ pt_nu2, double* __restrict__ out) {
+__global__ __launch_bounds__(64) void pen_dxi_kernel(DevModel M, DevPenalty Q, const double* __restrict__ pt_nu2, double* __restrict__ out, long long v_first, long long v_count) {
     constexpr int P1 = P + 1, NB = P1 * P1;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= Q.npts * 6) return;
-    const long long v = t / 6; const int dir = int(t - 6 * v), sdd = dir >> 1, d = dir & 1;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // (vertex of the range, direction)
+    if (t >= v_count * 6) return;
+    const long long v = v_first + t / 6; const int dir = int(t % 6), sdd = dir >> 1, d = dir & 1;
     const int itf = Q.pt_iface[v];
     Dual y[18], Y[12], tau[2], gr[18];
     for (int k = 0; k < 18; ++k) y[k] = {0.0, 0.0};

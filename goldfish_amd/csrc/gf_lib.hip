@@ -36,6 +36,10 @@ struct gf_handle {
     double *d_cp4 = nullptr, *d_u = nullptr, *d_h = nullptr, *d_R = nullptr, *d_blk = nullptr, *d_pbuf = nullptr;
     double* d_val[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double *d_x = nullptr, *d_y = nullptr;           // staging for host-pointer gf_apply / per-element partial sums
+    const long long *d_elem_off = nullptr, *d_if_off = nullptr; double* d_red = nullptr; long long nred = 0;   // per-patch / per-interface reductions on the device
+    double* d_dxi = nullptr; long long dxi_doubles = 0;   // gf_penalty_dxi: block buffer kept between calls
+    int fun_owner = -1;                              // which entry wrote d_fun last (0 = gf_functionals)
+    double* d_many = nullptr;                        // gf_apply_many: five more vectors of ndof doubles (allocated on first use)
     double* d_pt_nu2 = nullptr;                                        // second derivatives of the basis at the mortar vertices (gf_penalty_dxi)
     double *d_fun = nullptr, *d_pen_en = nullptr, *d_ve = nullptr;    // functional gradients [11*total_cp], penalty energies [npts]
     long long* d_pl_dof = nullptr; double* d_pl_val = nullptr;
@@ -119,6 +123,13 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         h->d_x = h->dalloc<double>(H.ndof); h->d_y = h->dalloc<double>(H.ndof);
         h->d_fun = h->dalloc<double>(11 * H.total_cp); h->d_pen_en = h->dalloc<double>(H.npts); h->d_ve = h->dalloc<double>(H.nelem);
         HIPCHK(hipMemset(h->d_fun, 0, 11 * H.total_cp * sizeof(double)));
+        {
+            std::vector<long long> eo(H.np + 1), io(H.if_off.begin(), H.if_off.end());
+            for (int s = 0; s < H.np; ++s) eo[s] = H.patches[s].elem_off;
+            eo[H.np] = H.nelem;
+            h->d_elem_off = h->upload(eo); h->d_if_off = h->upload(io);
+            h->nred = std::max<long long>(H.np, H.ni) + 1; h->d_red = h->dalloc<double>(3 * (size_t)h->nred);
+        }
         // penalty
         DevPenalty& Q = h->Q;
         std::vector<unsigned char> pen_row(H.total_cp, 0);
@@ -420,6 +431,16 @@ template <int P> static void run_stress(gf_handle* h, const StressCfg& S, int ap
     HIPCHK(hipGetLastError());
 }
 
+// per-patch sums of two per-element arrays (and the per-patch maximum of the second): a few numbers to the host instead of nelem-long arrays
+static void patch_sums(gf_handle* h, const double* a, const double* b, std::vector<double>& sa, std::vector<double>& sb, std::vector<double>* mb) {
+    const int np = h->H.np;
+    hipLaunchKernelGGL(seg_reduce_kernel, dim3(np), dim3(256), 0, h->stream, h->d_elem_off, a, b, h->d_red, b ? h->d_red + h->nred : nullptr, (b && mb) ? h->d_red + 2 * h->nred : nullptr);
+    sa.assign(np, 0.0); sb.assign(np, 0.0);
+    HIPCHK(hipMemcpyAsync(sa.data(), h->d_red, np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (b) HIPCHK(hipMemcpyAsync(sb.data(), h->d_red + h->nred, np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (b && mb) { mb->assign(np, 0.0); HIPCHK(hipMemcpyAsync(mb->data(), h->d_red + 2 * h->nred, np * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
+}
+
 extern "C" {
 
 int gf_assemble(gf_handle* h, int flags) {
@@ -500,6 +521,36 @@ int gf_apply(gf_handle* h, int which, int transpose, const double* x, int64_t nx
     return 0;
 }
 
+int gf_apply_many(gf_handle* h, int transpose, int nmat, const int* which, const double* const* xs, double* const* ys) {
+    if (!h || !which || !xs || !ys) return fail("gf_apply_many: null argument");
+    if (nmat < 1 || nmat > 5) return fail("gf_apply_many: 1 to 5 matrices");
+    for (int m = 0; m < nmat; ++m) {
+        if (which[m] < 0 || which[m] > 4) return fail("gf_apply_many: unknown matrix id");
+        if (!h->assembled[which[m]]) return fail("gf_apply_many: matrix has not been assembled");
+        if (!(transpose ? ys[m] : xs[m])) return fail("gf_apply_many: null vector");
+    }
+    if (!(transpose ? xs[0] : ys[0])) return fail("gf_apply_many: null vector");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        const long long nd = h->H.ndof, ncp = h->H.total_cp;
+        if (!h->d_many) h->d_many = h->dalloc<double>(5 * (size_t)nd);
+        auto len = [&](int w) { return w == GF_MAT_K ? nd : ncp; };
+        if (!transpose) {
+            HIPCHK(hipMemcpyAsync(h->d_y, ys[0], nd * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            for (int m = 0; m < nmat; ++m) HIPCHK(hipMemcpyAsync(h->d_many + (size_t)m * nd, xs[m], len(which[m]) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            for (int m = 0; m < nmat; ++m) if (gf_apply_dev(h, which[m], 0, h->d_many + (size_t)m * nd, h->d_y)) return 1;
+            HIPCHK(hipMemcpyAsync(ys[0], h->d_y, nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        } else {
+            HIPCHK(hipMemcpyAsync(h->d_x, xs[0], nd * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            for (int m = 0; m < nmat; ++m) HIPCHK(hipMemcpyAsync(h->d_many + (size_t)m * nd, ys[m], len(which[m]) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            for (int m = 0; m < nmat; ++m) if (gf_apply_dev(h, which[m], 1, h->d_x, h->d_many + (size_t)m * nd)) return 1;
+            for (int m = 0; m < nmat; ++m) HIPCHK(hipMemcpyAsync(ys[m], h->d_many + (size_t)m * nd, len(which[m]) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+    } catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
+}
+
 void* gf_device_ptr(gf_handle* h, int which) {
     if (!h) return nullptr;
     switch (which) {
@@ -524,12 +575,25 @@ void* gf_stream(gf_handle* h) { return h ? (void*)h->stream : nullptr; }
 
 int gf_assembly_path(const gf_handle* h) { return !h ? -1 : (h->walk ? 2 : (h->mfma ? 0 : 3)); }
 
+int gf_get_functional_gradient(gf_handle* h, int field, double* out, int64_t n) {
+    if (!h || !out) return fail("gf_get_functional_gradient: null argument");
+    if (field < 0 || field > 4) return fail("gf_get_functional_gradient: field must be 0..4");
+    if (h->fun_owner != 0) return fail("gf_get_functional_gradient: the gradient buffer does not hold the fields of a gf_functionals call");
+    const long long T = h->H.total_cp;
+    const long long off[5] = {0, 3 * T, 6 * T, 7 * T, 10 * T}, len[5] = {3 * T, 3 * T, T, 3 * T, T};
+    if (n != len[field]) return fail("gf_get_functional_gradient: wrong length");
+    try { HIPCHK(hipMemcpyAsync(out, h->d_fun + off[field], n * sizeof(double), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); }
+    catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
+}
+
 int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, double* dCdu, double* dCdcp, int apply_bcs) {
     if (!h || !forces || !C) return fail("gf_compliance: null argument");
     if (nf != 3 * (int64_t)h->H.np) return fail("gf_compliance: forces must hold 3 values per patch");
     try {
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipMemcpyAsync(h->d_y, forces, nf * sizeof(double), hipMemcpyHostToDevice, h->stream));   // d_y: >= 3*n_patches doubles
+        h->fun_owner = 1;
         switch (h->H.degree) {
             case 2: run_compliance<2>(h, apply_bcs); break;
             case 3: run_compliance<3>(h, apply_bcs); break;
@@ -537,13 +601,12 @@ int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, dou
             default: throw std::runtime_error("gf_compliance: unsupported degree");
         }
         const HostModel& H = h->H; const long long T = H.total_cp;
-        std::vector<double> ce(H.nelem);
-        HIPCHK(hipMemcpyAsync(ce.data(), h->d_x, H.nelem * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        std::vector<double> ce, unused;
+        patch_sums(h, h->d_x, nullptr, ce, unused, nullptr);
         if (dCdu) HIPCHK(hipMemcpyAsync(dCdu, h->d_fun, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         if (dCdcp) HIPCHK(hipMemcpyAsync(dCdcp, h->d_fun + 7 * T, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        const long long e_end = H.n_owned < H.np ? H.patches[H.n_owned].elem_off : H.nelem;
-        long double acc = 0; for (long long e = 0; e < e_end; ++e) acc += ce[e];
+        long double acc = 0; for (int s = 0; s < H.n_owned; ++s) acc += ce[s];      // owned patches only (fixed order)
         *C = (double)acc;
     } catch (const std::exception& ex) { return fail(ex.what()); }
     return 0;
@@ -559,18 +622,18 @@ int gf_shape_regu(gf_handle* h, int field, const double* cp0, int64_t ncp, const
         HIPCHK(hipMemcpyAsync(h->d_y, coef, nc * sizeof(double), hipMemcpyHostToDevice, h->stream));          // d_y, d_x: >= ndof doubles each
         HIPCHK(hipMemcpyAsync(h->d_y + H.np, cp0, ncp * sizeof(double), hipMemcpyHostToDevice, h->stream));
         StressCfg S{}; S.m_list = h->d_y; S.cp0 = h->d_y + H.np; S.field = field;
+        h->fun_owner = 3;
         switch (H.degree) {
             case 2: run_regu<2>(h, S); break;
             case 3: run_regu<3>(h, S); break;
             case 4: run_regu<4>(h, S); break;
             default: throw std::runtime_error("gf_shape_regu: unsupported degree");
         }
-        std::vector<double> ve(H.nelem);
-        HIPCHK(hipMemcpyAsync(ve.data(), h->d_x, H.nelem * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        std::vector<double> ve, unused;
+        patch_sums(h, h->d_x, nullptr, ve, unused, nullptr);
         if (dcp) HIPCHK(hipMemcpyAsync(dcp, h->d_fun + 3 * T, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        const long long e_end = H.n_owned < H.np ? H.patches[H.n_owned].elem_off : H.nelem;
-        long double acc = 0; for (long long e = 0; e < e_end; ++e) acc += ve[e];
+        long double acc = 0; for (int s = 0; s < H.n_owned; ++s) acc += ve[s];
         *value = (double)acc;
     } catch (const std::exception& ex) { return fail(ex.what()); }
     return 0;
@@ -586,6 +649,7 @@ int gf_stress_forms(gf_handle* h, int mode, double rho, const double* m_list, in
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipMemcpyAsync(h->d_y, m_list, nm * sizeof(double), hipMemcpyHostToDevice, h->stream));   // d_y: >= 3*n_patches doubles
         StressCfg S; S.mode = mode; S.measure = measure; S.rho = rho; S.sgn = (double)surf; S.m_list = h->d_y;
+        h->fun_owner = 2;
         switch (h->H.degree) {
             case 2: run_stress<2>(h, S, apply_bcs); break;
             case 3: run_stress<3>(h, S, apply_bcs); break;
@@ -593,56 +657,56 @@ int gf_stress_forms(gf_handle* h, int mode, double rho, const double* m_list, in
             default: throw std::runtime_error("gf_stress_forms: unsupported degree");
         }
         const HostModel& H = h->H; const long long T = H.total_cp;
-        std::vector<double> ie(H.nelem), se(H.nelem);
-        HIPCHK(hipMemcpyAsync(ie.data(), h->d_x, H.nelem * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(se.data(), h->d_ve, H.nelem * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        std::vector<double> ip, sp_, mp;
+        patch_sums(h, h->d_x, h->d_ve, ip, sp_, &mp);
         if (dIdu) HIPCHK(hipMemcpyAsync(dIdu, h->d_fun, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         if (dIdcp) HIPCHK(hipMemcpyAsync(dIdcp, h->d_fun + 3 * T, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         if (dIdh) HIPCHK(hipMemcpyAsync(dIdh, h->d_fun + 6 * T, T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         // fixed-order host sums per patch; the ghost patches of a shard are not evaluated here (their owner reports them): 0
         for (int s = 0; s < H.np; ++s) {
-            const long long e0 = H.patches[s].elem_off, e1 = s + 1 < H.np ? H.patches[s + 1].elem_off : H.nelem;
-            long double acc = 0; double mx = 0;
-            if (s < H.n_owned) for (long long e = e0; e < e1; ++e) { acc += ie[e]; mx = std::max(mx, se[e]); }
-            if (forms) forms[s] = (double)acc;
-            if (vmax) vmax[s] = mx;
+            if (forms) forms[s] = s < H.n_owned ? ip[s] : 0.0;
+            if (vmax) vmax[s] = s < H.n_owned ? mp[s] : 0.0;
         }
     } catch (const std::exception& ex) { return fail(ex.what()); }
     return 0;
 }
 
-int gf_penalty_dxi(gf_handle* h, double* blocks, int64_t n, int32_t* windows, int64_t nw) {
+int gf_penalty_dxi_range(gf_handle* h, int64_t v_first, int64_t v_count, double* blocks, int64_t n, int32_t* windows, int64_t nw) {
     if (!h || !blocks) return fail("gf_penalty_dxi: null argument");
     const HostModel& H = h->H;
     const int NB = (H.degree + 1) * (H.degree + 1);
-    const int64_t need = (int64_t)H.npts * 6 * 2 * NB * 3;
-    if (n != need) return fail("gf_penalty_dxi: blocks must hold npts * 6 * 2 * (p+1)^2 * 3 doubles");
-    if (windows && nw != 4 * (int64_t)H.npts) return fail("gf_penalty_dxi: windows must hold 4 ints per mortar vertex");
-    if (H.npts == 0) return 0;
+    if (v_first < 0 || v_count < 0 || v_first + v_count > (int64_t)H.npts) return fail("gf_penalty_dxi: vertex range outside the model's mortar vertices");
+    const int64_t need = v_count * 6 * 2 * NB * 3;
+    if (n != need) return fail("gf_penalty_dxi: blocks must hold (vertices) * 6 * 2 * (p+1)^2 * 3 doubles");
+    if (windows && nw != 4 * v_count) return fail("gf_penalty_dxi: windows must hold 4 ints per mortar vertex");
+    if (v_count == 0) return 0;
     try {
         HIPCHK(hipSetDevice(h->device));
         if (!h->d_pt_nu2) {                                  // uploaded on first use: only moving-intersection problems need it
             h->d_pt_nu2 = h->dalloc<double>(H.pt_nu2.size());
             HIPCHK(hipMemcpy(h->d_pt_nu2, H.pt_nu2.data(), H.pt_nu2.size() * sizeof(double), hipMemcpyHostToDevice));
         }
-        double* d_out = nullptr;
-        HIPCHK(hipMalloc(&d_out, need * sizeof(double)));
-        const long long nt = (long long)H.npts * 6;
+        if (h->dxi_doubles < need) { h->d_dxi = h->dalloc<double>((size_t)need); h->dxi_doubles = need; }   // kept between calls (no hipMalloc / hipFree per call)
+        double* d_out = h->d_dxi;
+        const long long nt = (long long)v_count * 6;
         switch (H.degree) {
-            case 2: hipLaunchKernelGGL(pen_dxi_kernel<2>, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pt_nu2, d_out); break;
-            case 3: hipLaunchKernelGGL(pen_dxi_kernel<3>, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pt_nu2, d_out); break;
-            case 4: hipLaunchKernelGGL(pen_dxi_kernel<4>, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pt_nu2, d_out); break;
-            default: (void)hipFree(d_out); throw std::runtime_error("gf_penalty_dxi: unsupported degree");
+            case 2: hipLaunchKernelGGL(pen_dxi_kernel<2>, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pt_nu2, d_out, (long long)v_first, (long long)v_count); break;
+            case 3: hipLaunchKernelGGL(pen_dxi_kernel<3>, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pt_nu2, d_out, (long long)v_first, (long long)v_count); break;
+            case 4: hipLaunchKernelGGL(pen_dxi_kernel<4>, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pt_nu2, d_out, (long long)v_first, (long long)v_count); break;
+            default: throw std::runtime_error("gf_penalty_dxi: unsupported degree");
         }
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(blocks, d_out, need * sizeof(double), hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        (void)hipFree(d_out);
         if (e != hipSuccess) throw std::runtime_error(std::string("gf_penalty_dxi: ") + hipGetErrorString(e));
-        if (windows) for (int64_t k = 0; k < 4 * (int64_t)H.npts; ++k) windows[k] = H.pt_base[k];
+        if (windows) for (int64_t k = 0; k < 4 * v_count; ++k) windows[k] = H.pt_base[4 * v_first + k];
     } catch (const std::exception& ex) { return fail(ex.what()); }
     return 0;
+}
+int gf_penalty_dxi(gf_handle* h, double* blocks, int64_t n, int32_t* windows, int64_t nw) {
+    if (!h) return fail("gf_penalty_dxi: null argument");
+    return gf_penalty_dxi_range(h, 0, (int64_t)h->H.npts, blocks, n, windows, nw);
 }
 
 #ifdef GF_STAMPS
@@ -658,6 +722,7 @@ int gf_functionals(gf_handle* h, double out[3], double* dWdu, double* dWdcp, dou
     if (!h || !out) return fail("gf_functionals: null argument");
     try {
         HIPCHK(hipSetDevice(h->device));
+        h->fun_owner = 0;
         switch (h->H.degree) {
             case 2: run_functionals<2>(h, apply_bcs); break;
             case 3: run_functionals<3>(h, apply_bcs); break;
@@ -665,10 +730,12 @@ int gf_functionals(gf_handle* h, double out[3], double* dWdu, double* dWdcp, dou
             default: throw std::runtime_error("gf_functionals: unsupported degree");
         }
         const HostModel& H = h->H; const long long T = H.total_cp;
-        std::vector<double> we(H.nelem), ve(H.nelem), pe(H.npts);
-        HIPCHK(hipMemcpyAsync(we.data(), h->d_x, H.nelem * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(ve.data(), h->d_y, H.nelem * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        if (H.npts > 0) HIPCHK(hipMemcpyAsync(pe.data(), h->d_pen_en, H.npts * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        std::vector<double> wp, vp, pi(H.ni, 0.0);
+        patch_sums(h, h->d_x, h->d_y, wp, vp, nullptr);
+        if (H.npts > 0) {       // per-interface sums of the vertex energies
+            hipLaunchKernelGGL(seg_reduce_kernel, dim3(H.ni), dim3(256), 0, h->stream, h->d_if_off, h->d_pen_en, (const double*)nullptr, h->d_red + 2 * h->nred, (double*)nullptr, (double*)nullptr);
+            HIPCHK(hipMemcpyAsync(pi.data(), h->d_red + 2 * h->nred, H.ni * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        }
         if (dWdu) HIPCHK(hipMemcpyAsync(dWdu, h->d_fun, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         if (dWdcp) HIPCHK(hipMemcpyAsync(dWdcp, h->d_fun + 3 * T, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         if (dWdh) HIPCHK(hipMemcpyAsync(dWdh, h->d_fun + 6 * T, T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -676,11 +743,10 @@ int gf_functionals(gf_handle* h, double out[3], double* dWdu, double* dWdcp, dou
         if (dVdh) HIPCHK(hipMemcpyAsync(dVdh, h->d_fun + 10 * T, T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         // fixed-order host sums of the per-element / per-vertex partials (owned elements only)
-        const long long e_end = H.n_owned < H.np ? H.patches[H.n_owned].elem_off : H.nelem;
         long double W = 0, V = 0, Wp = 0;
-        for (long long e = 0; e < e_end; ++e) { W += we[e]; V += ve[e]; }
+        for (int s = 0; s < H.n_owned; ++s) { W += wp[s]; V += vp[s]; }           // owned patches, fixed order
         // an interface cut by the partition is present on both ranks: its energy is counted by the owner of side A
-        for (long long v = 0; v < H.npts; ++v) if (H.if_patch[2 * H.pt_iface[v]] < H.n_owned) Wp += pe[v];
+        for (int i = 0; i < H.ni; ++i) if (H.if_patch[2 * i] < H.n_owned) Wp += pi[i];
         out[0] = (double)W; out[1] = (double)V; out[2] = (double)Wp;
     } catch (const std::exception& ex) { return fail(ex.what()); }
     return 0;

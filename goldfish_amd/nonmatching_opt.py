@@ -548,13 +548,12 @@ class NonMatchingOpt:
         A = self._arrays_cache
         p = self.splines[0].p
         P1, nb = p + 1, (p + 1) ** 2
-        blocks, win = dev.penalty_dxi(int(A.if_off[-1]), p)
         rows, cols, vals = [], [], []
         al = np.arange(nb)
         for i, g in enumerate(self.diff_int_inds):
             n = c2x.diff_int_num_pts[i]
             v0, base = int(A.if_off[g]), c2x.xi_flat_inds[i]
-            B, W = blocks[v0:v0 + n], win[v0:v0 + n]                                  # (n, 6, 2, nb, 3), (n, 2, 2)
+            B, W = dev.penalty_dxi(n, p, v_first=v0)                                   # the vertices of this moving interface only: (n, 6, 2, nb, 3), (n, 2, 2)
             dof = np.zeros((n, 2, nb, 3), dtype=np.int64)
             for sd, s in enumerate(self.mapping_list[g]):
                 cp = self.cp_off[s] + (W[:, sd, 0][:, None] + al % P1) + (W[:, sd, 1][:, None] + al // P1) * self.splines[s].n_u

@@ -1,7 +1,8 @@
 """DispImOpeartion -- implicit operation for the displacement states
 (reference: GOLDFISH/operations/disp_imop.py:3-142; the class name keeps the
 reference's spelling).  Same call signatures and in-place semantics; Jacobian
-products run on the GPU (csr_apply kernels), direct solves on the host."""
+products run on the GPU (csr_apply kernels, one gf_apply_many call per OM call), direct solves on the device
+(NonMatchingOpt.solve_K)."""
 import numpy as np
 
 from .. import _lib
@@ -52,39 +53,46 @@ class DispImOpeartion(object):
         return np.asarray(x, float) if self.var_thickness else np.repeat(np.asarray(x, float), nm.vec_scalar_iga_dof_list)
 
     def apply_linear_fwd(self, d_inputs_array_list=None, d_outputs_array=None, d_residuals_array=None):
-        """disp_imop.py:58-97: d_residuals += K du + sum_f dR/dCP_f dcp_f + dR/dh dh."""
+        """disp_imop.py:58-97: d_residuals += K du + sum_f dR/dCP_f dcp_f + dR/dh dh -- one device call (gf_apply_many)."""
         dev = self.nonmatching_opt.dev
         if d_residuals_array is not None:
-            acc = np.zeros(self.nonmatching_opt.vec_iga_dof)
+            which, xs = [], []
             if d_outputs_array is not None:
-                dev.apply(_lib.MAT_K, d_outputs_array, acc)
+                which.append(_lib.MAT_K); xs.append(d_outputs_array)
             if d_inputs_array_list is not None:
                 if self.opt_shape:
                     for i, field in enumerate(self.opt_field):
-                        dev.apply(_lib.MAT_DRDCP0 + field, self._cp_full(i, d_inputs_array_list[i]), acc)
+                        which.append(_lib.MAT_DRDCP0 + field); xs.append(self._cp_full(i, d_inputs_array_list[i]))
                 if self.opt_thickness:
-                    dev.apply(_lib.MAT_DRDH, self._h_full(d_inputs_array_list[len(self.opt_field)]), acc)
-            d_residuals_array[:] += acc
+                    which.append(_lib.MAT_DRDH); xs.append(self._h_full(d_inputs_array_list[len(self.opt_field)]))
+            if which:
+                acc = np.zeros(self.nonmatching_opt.vec_iga_dof)
+                dev.apply_many(which, xs, [acc])
+                d_residuals_array[:] += acc
         return d_residuals_array
 
     def apply_linear_rev(self, d_inputs_array_list=None, d_outputs_array=None, d_residuals_array=None):
-        """disp_imop.py:99-128: d_outputs += K^T d_res, d_inputs[f] += (dR/dCP_f)^T d_res, ..."""
+        """disp_imop.py:99-128: d_outputs += K^T d_res, d_inputs[f] += (dR/dCP_f)^T d_res, ... -- one device call."""
         nm, dev = self.nonmatching_opt, self.nonmatching_opt.dev
         if d_residuals_array is not None:
             dres = np.ascontiguousarray(d_residuals_array, float)
+            which, ys, sinks = [], [], []
             if d_outputs_array is not None:
-                acc = np.zeros(nm.vec_iga_dof)
-                dev.apply(_lib.MAT_K, dres, acc, transpose=True)
-                d_outputs_array[:] += acc
+                which.append(_lib.MAT_K); ys.append(np.zeros(nm.vec_iga_dof)); sinks.append(("u", None))
             if d_inputs_array_list is not None:
                 if self.opt_shape:
                     for i, field in enumerate(self.opt_field):
-                        acc = np.zeros(nm.vec_scalar_iga_dof)
-                        dev.apply(_lib.MAT_DRDCP0 + field, dres, acc, transpose=True)
-                        d_inputs_array_list[i][:] += acc[nm._shopt_cols[i]]
+                        which.append(_lib.MAT_DRDCP0 + field); ys.append(np.zeros(nm.vec_scalar_iga_dof)); sinks.append(("cp", i))
                 if self.opt_thickness:
-                    acc = np.zeros(nm.vec_scalar_iga_dof)
-                    dev.apply(_lib.MAT_DRDH, dres, acc, transpose=True)
+                    which.append(_lib.MAT_DRDH); ys.append(np.zeros(nm.vec_scalar_iga_dof)); sinks.append(("h", None))
+            if which:
+                dev.apply_many(which, [dres], ys, transpose=True)
+            for (kind, i), acc in zip(sinks, ys):
+                if kind == "u":
+                    d_outputs_array[:] += acc
+                elif kind == "cp":
+                    d_inputs_array_list[i][:] += acc[nm._shopt_cols[i]]
+                else:
                     if not self.var_thickness:
                         acc = np.add.reduceat(acc, nm.cp_off[:-1])
                     d_inputs_array_list[len(self.opt_field)][:] += acc

@@ -92,6 +92,11 @@ int gf_functionals(gf_handle* h, double out[3], double* dWdu, double* dWdcp, dou
 
 /* ComplianceExOperation.cpl/dcplduIGA/dcpldCPIGA (operations/compliance_exop.py:50-99): C = sum_s int forces[s] . u_hom dA
  * with forces = 3 values per patch; dCdu [ndof] (Dirichlet rows zeroed when apply_bcs), dCdcp 3 arrays of total_cp. */
+/* one gradient field of the LAST gf_functionals call, copied on request (call gf_functionals with NULL gradient pointers, then fetch
+ * what the caller actually uses: every field is a D2H copy of ndof or total_cp doubles): field 0 dWdu [ndof], 1 dWdcp [3 total_cp],
+ * 2 dWdh [total_cp], 3 dVdcp [3 total_cp], 4 dVdh [total_cp].  Fails if another functional entry (gf_compliance, gf_stress_forms,
+ * gf_shape_regu) has used the gradient buffer since. */
+int gf_get_functional_gradient(gf_handle* h, int field, double* out, int64_t n);
 int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, double* dCdu, double* dCdcp, int apply_bcs);
 
 /* MaxvMStressExOperation (operations/max_vmstress_exop.py): the per-patch aggregation forms
@@ -124,11 +129,20 @@ int gf_shape_regu(gf_handle* h, int field, const double* cp0, int64_t ncp, const
  * [npts][2][2]; the a-th support control point of a patch with nu control points in u is (iu0 + a % (p+1)) + (iv0 + a / (p+1)) * nu.
  * No Dirichlet treatment (the reference zeroes the rows afterwards, :1057-1062). */
 int gf_penalty_dxi(gf_handle* h, double* blocks, int64_t n, int32_t* windows, int64_t nw);
+/* the same for the mortar vertices v_first .. v_first + v_count - 1 only (blocks, windows sized for v_count vertices): the vertices
+ * of the interfaces that actually move, instead of every vertex of the model (0.64 GB of blocks at C4) */
+int gf_penalty_dxi_range(gf_handle* h, int64_t v_first, int64_t v_count, double* blocks, int64_t n, int32_t* windows, int64_t nw);
 
 /* borrowed device pointer to one of the GF_BUF_* buffers (for zero-copy users: bench, RCCL exchange) */
 void* gf_device_ptr(gf_handle* h, int which);
 /* y_dev += A x_dev on device pointers (no host copies, asynchronous) */
 int gf_apply_dev(gf_handle* h, int which, int transpose, const double* x_dev, double* y_dev);
+/* DispImOpeartion.apply_linear_fwd / _rev (disp_imop.py:58-128) in ONE call: nmat products with one copy in and one copy out
+ * per vector instead of gf_apply's three per product.
+ *   transpose = 0:  ys[0] (ndof, in/out) += sum_m A_which[m] xs[m]      (xs[m]: ndof values for K, total_cp otherwise)
+ *   transpose = 1:  ys[m] (in/out, ndof for K, total_cp otherwise) += A_which[m]^T xs[0]      (xs[0]: ndof values)
+ * Host pointers; 1 <= nmat <= 5, every matrix must have been assembled. */
+int gf_apply_many(gf_handle* h, int transpose, int nmat, const int* which, const double* const* xs, double* const* ys);
 /* average duration (ms) of the dominant kernel (shell element kernel) over the launches since the
  * last call, measured with HIP events on the handle's stream; resets the accumulator. */
 double gf_kernel_ms(gf_handle* h, int* n_launches);

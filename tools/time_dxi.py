@@ -13,3 +13,8 @@ D.penalty_dxi(npts, 3); D.sync()
 t0 = time.perf_counter()
 for _ in range(3): B, W = D.penalty_dxi(npts, 3)
 print("gf_penalty_dxi: %d mortar vertices, %.1f ms per call incl. the %.2f GB device-to-host copy of the blocks" % (npts, (time.perf_counter() - t0) / 3 * 1e3, B.nbytes / 1e9))
+nv = int(A.if_off[1] - A.if_off[0])
+D.penalty_dxi(nv, 3, v_first=int(A.if_off[7]))
+t0 = time.perf_counter()
+for _ in range(10): B, W = D.penalty_dxi(nv, 3, v_first=int(A.if_off[7]))
+print("gf_penalty_dxi_range: the %d vertices of one interface, %.3f ms per call (what dRIGAdxi asks for per moving interface)" % (nv, (time.perf_counter() - t0) / 10 * 1e3))

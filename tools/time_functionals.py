@@ -16,4 +16,10 @@ for name, fn in (("functionals", lambda: D.functionals()), ("compliance", lambda
     t0 = time.perf_counter()
     for _ in range(3): fn()
     D.sync()
-    print(name, "%.2f ms per call (incl. host copies of the gradients)" % ((time.perf_counter() - t0) / 3 * 1e3))
+    print(name, "%.2f ms per call" % ((time.perf_counter() - t0) / 3 * 1e3), flush=True)
+t0 = time.perf_counter()
+for _ in range(3): F = None; F = D.functionals(); F["dWdu"]
+print("functionals + dW/du fetched: %.2f ms per call" % ((time.perf_counter() - t0) / 3 * 1e3))
+t0 = time.perf_counter()
+for _ in range(3): F = None; F = D.functionals(); F.materialize()
+print("functionals + all five gradient fields fetched: %.2f ms per call" % ((time.perf_counter() - t0) / 3 * 1e3))
