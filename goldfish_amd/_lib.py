@@ -29,42 +29,30 @@ def lib():
             raise RuntimeError("libgoldfish_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                                "goldfish_amd has no CPU fallback")
         L = C.CDLL(LIB_PATH)
-        dp, vp, i64 = C.POINTER(C.c_double), C.c_void_p, C.c_int64
-        L.gf_device_count.restype = C.c_int
-        L.gf_last_error.restype = C.c_char_p
-        L.gf_create.argtypes = [C.POINTER(gf_model_desc), C.c_int, C.POINTER(vp)]
-        L.gf_destroy.argtypes = [vp]
-        L.gf_destroy.restype = None
+        dp, vp, i64, ci = C.POINTER(C.c_double), C.c_void_p, C.c_int64, C.c_int
+        i32p = C.POINTER(C.c_int32)
+        sig = {   # name: (argtypes, restype); restype None keeps ctypes' default int
+            "gf_device_count": (None, ci), "gf_last_error": (None, C.c_char_p), "gf_create": ([C.POINTER(gf_model_desc), ci, C.POINTER(vp)], None),
+            "gf_destroy": ([vp], "void"), "gf_set_cp": ([vp, ci, dp, i64], None), "gf_set_thickness": ([vp, dp, i64], None), "gf_set_u": ([vp, dp, i64], None),
+            "gf_nnz": ([vp, ci], i64), "gf_pattern": ([vp, ci, C.POINTER(C.c_int64), i32p], None), "gf_assemble": ([vp, ci], None), "gf_sync": ([vp], None),
+            "gf_get_residual": ([vp, dp, i64], None), "gf_get_values": ([vp, ci, dp, i64], None), "gf_apply": ([vp, ci, ci, dp, i64, dp, i64], None),
+            "gf_functionals": ([vp, dp, dp, dp, dp, dp, dp, ci], None), "gf_compliance": ([vp, dp, i64, dp, dp, dp, ci], None),
+            "gf_shape_regu": ([vp, ci, dp, i64, dp, i64, dp, dp], None), "gf_penalty_dxi": ([vp, dp, i64, i32p, i64], None),
+            "gf_penalty_dxi_range": ([vp, i64, i64, dp, i64, i32p, i64], None),
+            "gf_stress_forms": ([vp, ci, C.c_double, dp, i64, ci, ci, dp, dp, dp, dp, dp, ci], None), "gf_device_ptr": ([vp, ci], vp),
+            "gf_apply_dev": ([vp, ci, ci, vp, vp], None), "gf_kernel_ms": ([vp, C.POINTER(ci)], C.c_double), "gf_assembly_path": ([vp], None),
+            "gf_get_functional_gradient": ([vp, ci, dp, i64], None), "gf_apply_many": ([vp, ci, ci, C.POINTER(ci), C.POINTER(dp), C.POINTER(dp)], None),
+            "gf_stream": ([vp], vp)}
         for name in ("gf_total_cp", "gf_num_dofs", "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes"):
-            getattr(L, name).restype = i64
-            getattr(L, name).argtypes = [vp]
-        L.gf_set_cp.argtypes = [vp, C.c_int, dp, i64]
-        L.gf_set_thickness.argtypes = [vp, dp, i64]
-        L.gf_set_u.argtypes = [vp, dp, i64]
-        L.gf_nnz.restype = i64
-        L.gf_nnz.argtypes = [vp, C.c_int]
-        L.gf_pattern.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
-        L.gf_assemble.argtypes = [vp, C.c_int]
-        L.gf_sync.argtypes = [vp]
-        L.gf_get_residual.argtypes = [vp, dp, i64]
-        L.gf_get_values.argtypes = [vp, C.c_int, dp, i64]
-        L.gf_apply.argtypes = [vp, C.c_int, C.c_int, dp, i64, dp, i64]
-        L.gf_functionals.argtypes = [vp, dp, dp, dp, dp, dp, dp, C.c_int]
-        L.gf_compliance.argtypes = [vp, dp, i64, dp, dp, dp, C.c_int]
-        L.gf_shape_regu.argtypes = [vp, C.c_int, dp, i64, dp, i64, dp, dp]
-        L.gf_penalty_dxi.argtypes = [vp, dp, i64, C.POINTER(C.c_int32), i64]
-        L.gf_penalty_dxi_range.argtypes = [vp, i64, i64, dp, i64, C.POINTER(C.c_int32), i64]
-        L.gf_stress_forms.argtypes = [vp, C.c_int, C.c_double, dp, i64, C.c_int, C.c_int, dp, dp, dp, dp, dp, C.c_int]
-        L.gf_device_ptr.restype = vp
-        L.gf_device_ptr.argtypes = [vp, C.c_int]
-        L.gf_apply_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp]
-        L.gf_assembly_path.argtypes = [vp]
-        L.gf_get_functional_gradient.argtypes = [vp, C.c_int, dp, i64]
-        L.gf_apply_many.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(dp), C.POINTER(dp)]
-        L.gf_stream.restype = vp
-        L.gf_stream.argtypes = [vp]
-        L.gf_kernel_ms.restype = C.c_double
-        L.gf_kernel_ms.argtypes = [vp, C.POINTER(C.c_int)]
+            sig[name] = ([vp], i64)
+        for name, (argtypes, restype) in sig.items():
+            if not hasattr(L, name):
+                continue                  # an older library loaded through GF_LIB for an A/B run binds only the entry points it has
+            fn = getattr(L, name)
+            if argtypes is not None:
+                fn.argtypes = argtypes
+            if restype is not None:
+                fn.restype = None if restype == "void" else restype
         _LIB = L
     return _LIB
 

@@ -171,8 +171,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
             for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
             if (doK || doC) { RL.template expand<WITHC>(im, gR, hR); dpp_source_fence(gR); if constexpr (WITHC) dpp_source_fence(hR); }
             // -- residual (first pass only) and dR/dh prefactors of both a tiles
-            const LoadGeom lg = load_geom(im, Pt.pd);
-            const double ls = has_bf ? load_scalar(im, Pt.pd) : 0.0;
+            const double ls = (has_bf && tb == 0) ? load_scalar(im, Pt.pd) : 0.0;
             if (tb == 0) {
 #pragma unroll
                 for (int ta = 0; ta < 2; ++ta)
@@ -227,6 +226,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
                     }
                 });
                 if (has_bf) {                    // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b)
+                    const LoadGeom lg = load_geom(im, Pt.pd);        // behind the uniform branch: a model without distributed loads does not pay for it
 #pragma unroll
                     for (int f = 0; f < 3; ++f) {
                         const double jz = load_dz_dot(im, Pt.pd, lg, f, pb[0], pb[1]);

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -157,6 +158,8 @@ inline void HostModel::build(const gf_model_desc* D) {
     owned_cp = D->cp_off[n_owned];
     if (total_cp >= (int64_t(1) << 31) / 3) throw std::runtime_error("gf_create: too many control points for 32-bit column ids");
     patches.resize(np); cp_patch.resize(total_cp);
+    const char* env_b32 = std::getenv("GF_BASIS_FP32");
+    const bool basis_fp32 = env_b32 && std::string(env_b32) == "1";
     weights.assign(D->weights, D->weights + total_cp);
     nelem = 0; ngp = 0;
     for (int s = 0; s < np; ++s) {
@@ -181,7 +184,9 @@ inline void HostModel::build(const gf_model_desc* D) {
             for (int e = 0; e < nel; ++e) for (int g = 0; g < ng; ++g) {
                 const double a = U[sp[e]], b = U[sp[e] + 1], xi = 0.5 * (a + b) + 0.5 * (b - a) * gx[g];
                 double ders[3][MAXP + 1]; basis_ders(sp[e], xi, p, U, ders);
-                for (int k = 0; k < 3; ++k) for (int j = 0; j <= p; ++j) tab[t0 + ((size_t(e) * ng + g) * 3 + k) * (p + 1) + j] = ders[k][j];
+                // GF_BASIS_FP32=1 (measurement of BASELINE.json's "mixed FP64/FP32 basis eval" mode, tools/mixed_precision.py): the 1-D basis
+                // values and derivatives as an FP32 evaluation would deliver them, everything downstream in FP64
+                for (int k = 0; k < 3; ++k) for (int j = 0; j <= p; ++j) tab[t0 + ((size_t(e) * ng + g) * 3 + k) * (p + 1) + j] = basis_fp32 ? (double)(float)ders[k][j] : ders[k][j];
                 tab[w0 + e * ng + g] = 0.5 * (b - a) * gw[g];
             }
             const int s0 = (int)ints.size(); ints.insert(ints.end(), sp.begin(), sp.end());
@@ -198,6 +203,7 @@ inline void HostModel::build(const gf_model_desc* D) {
         if (s < n_owned) ngp += int64_t(P.nelu) * P.nelv * (P.p + 1) * (P.q + 1);
     }
     if (nelem >= (int64_t(1) << 31)) throw std::runtime_error("gf_create: too many elements");
+    (void)basis_fp32;
     elem_patch.resize(nelem);
     for (int s = 0; s < np; ++s) std::fill(elem_patch.begin() + patches[s].elem_off, elem_patch.begin() + patches[s].elem_off + int64_t(patches[s].nelu) * patches[s].nelv, s);
     elem_desc.resize(nelem);

@@ -126,12 +126,14 @@ def test_c4_rigid_body_and_reproducibility(c4):
     assert np.array_equal(R0, D.residual()) and np.array_equal(K0, D.values(_lib.MAT_K))
 
 
-def test_c5_family_p4_properties():
-    """p = 4 (BASELINE.json configs[4] family: synthetic fuselage, MFMA 2x2-tile element kernel) at a size the oracle does
-    not run in seconds (32 patches, 0.3 M dofs): K x and (dR/dCP) x against residual differences, symmetry of K, and
-    bitwise agreement of two assemblies."""
+@pytest.mark.parametrize("size", ["32 patches", "C5 share of one GPU"])
+def test_c5_family_p4_properties(size):
+    """p = 4 (BASELINE.json configs[4]: synthetic fuselage, MFMA 2x2-tile element kernel) at sizes the oracle does not run in
+    seconds -- 32 patches (0.3 M dofs) and one GPU's share of C5 at 8 GPUs (128 patches of 53 spans a side, 1.04 M dofs,
+    7.35 M Gauss points; the element blocks take two scratch chunks): K x and (dR/dCP) x against residual differences,
+    symmetry of K, and bitwise agreement of two assemblies."""
     from goldfish_amd import _lib
-    spec = G.synthetic_fuselage(8, 4, nel=24, p=4, jitter=2)
+    spec = G.synthetic_fuselage(8, 4, nel=24, p=4, jitter=2) if size == "32 patches" else G.synthetic_fuselage(16, 8, nel=53, p=4, jitter=2)
     th = G.random_thickness(spec)
     A = arrays_from_spec(spec, th)
     D = _lib.DeviceModel(A)
@@ -139,10 +141,13 @@ def test_c5_family_p4_properties():
     D.set_thickness(h)
     D.set_u(u)
     D.assemble(_lib.ASM_ALL)
+    if size != "32 patches":
+        assert len(spec.patches) == 128 and D.n_gauss_points > 7.0e6
     vals = [D.values(w).copy() for w in range(5)]
     R0 = D.residual().copy()
     D.assemble(_lib.ASM_ALL)
     assert np.array_equal(R0, D.residual()) and all(np.array_equal(vals[w], D.values(w)) for w in range(5))
+    del vals
     rng = np.random.default_rng(1)
     free = np.ones(A.ndof, bool)
     free[A.zero_dofs] = False
