@@ -14,6 +14,7 @@ constexpr int GF_ASM_R_BIT = 1, GF_ASM_K_BIT = 2, GF_ASM_C_BIT = 4, GF_ASM_H_BIT
 #include "gf_kernels.hpp"
 #include "gf_element_mfma.hpp"
 #include "gf_element_mfma4.hpp"
+#include "gf_element_mfma2.hpp"
 #include "gf_element_walk.hpp"
 
 using namespace gf;
@@ -48,6 +49,7 @@ struct gf_handle {
     bool assembled[5] = {false, false, false, false, false};
     bool walk = false;                                // GF_WALK=1 (p = 2, 3, MFMA path): walk element strips and accumulate straight into the CSR arrays (gf_element_walk.hpp: a quarter of the device memory, half the traffic, currently slower)
     const WalkItem* d_walk_items = nullptr; const RowDesc* d_row_desc = nullptr; const WalkPatch* d_walk_patch = nullptr;
+    bool two_wave = true;                             // p = 2, 3 full pass: two waves per element, two resident per SIMD (gf_element_mfma2.hpp; GF_TWOWAVE=0: one wave)
     bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
     bool atomic_t = false;                            // GF_ATOMIC_T=1: transposed products of dR/dCP, dR/dh by FP64 atomics (order not fixed) instead of the fixed-order gather
     const int *d_rev_s = nullptr, *d_rev_c = nullptr;
@@ -84,6 +86,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         h->H.build(desc);
         if (const char* s = getenv("GF_ELEMENT")) h->mfma = std::string(s) != "valu";
         if (const char* s = getenv("GF_ATOMIC_T")) h->atomic_t = std::string(s) == "1";
+        if (const char* s = getenv("GF_TWOWAVE")) h->two_wave = std::string(s) != "0";
         h->gather1 = h->H.degree <= 3;                    // p = 4: 25 elements x 75-wide rows per control point are bandwidth bound either way (57.9 vs 57.6 ms per step)
         if (const char* s = getenv("GF_GATHER1")) h->gather1 = std::string(s) != "0";
         HostModel& H = h->H;
@@ -348,7 +351,8 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
         const int slot = h->ev_n % 64;
         HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
         if ((P == 3 || P == 2) && h->mfma) {
-            if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), true>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, blk);
+            if ((flags & GF_ASM_DRDCP) && h->two_wave) hipLaunchKernelGGL((kl_element_mfma2_kernel<(P == 2 ? 2 : 3)>), dim3((unsigned)ne), dim3(128), 0, h->stream, h->M, (int)c.e0, flags, blk);
+            else if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), true>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, blk);
             else hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), false>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, blk);
         }
         else if (P == 4 && h->mfma) {
