@@ -483,9 +483,10 @@ def test_max_vm_stress_operation_and_comp(method):
 
 
 def test_moving_intersection_residual_derivative(oracle_lib):
-    """N3: NonMatchingOpt.dRIGAdxi (gf_penalty_dxi -> pen_dxi_kernel, dual-number pass per mortar vertex) against central
-    differences of the ORACLE's residual with the interface rebuilt at perturbed parametric coordinates, and against the
-    reference-style forward-difference check dRIGAdxi_FD of the device path."""
+    """N3: NonMatchingOpt.dRIGAdxi (gf_penalty_dxi -> pen_dxi_kernel, dual-number pass per mortar vertex) against the analytic
+    mixed derivative of the interface energy (autograd through the rational basis at the vertices and the tangent stencil,
+    tests/torch_model.py: penalty_residual_dxi) to 1e-9, against central differences of the ORACLE's residual with the interface
+    rebuilt at perturbed parametric coordinates, and against the reference-style forward-difference check dRIGAdxi_FD."""
     from goldfish_amd.model import Interface
     from oracle.oracle_py import Oracle
     spec, th, nm = _problem()
@@ -503,6 +504,12 @@ def test_moving_intersection_residual_derivative(oracle_lib):
     xi0 = nm.cpiga2xi.xi_flat_global.copy()
     J = nm.dRIGAdxi().toarray()
     assert J.shape == (nm.vec_iga_dof, 4 * n) and np.abs(J[nm.zero_dofs]).max() == 0.0
+    # analytic: d/dxi of dE/dU of the interface energy
+    from tests.torch_model import penalty_residual_dxi
+    A0 = nm._arrays()
+    Jt = penalty_residual_dxi(nm.splines, nm.cp_off, nm.mapping_list[0][0], nm.mapping_list[0][1], A0.weights, np.stack(nm.cp_iga, 1), nm.u_iga,
+                              xa, xb, (A0.if_alpha[0], A0.if_alpha[1]), A0.if_wt, nm.zero_dofs)
+    assert np.abs(Jt - J).max() < 1e-9 * np.abs(J).max(), np.abs(Jt - J).max() / np.abs(J).max()
 
     def oracle_residual(xi):
         itf = Interface(nm.mapping_list[0][0], nm.mapping_list[0][1], xi[:2 * n].reshape(-1, 2), xi[2 * n:].reshape(-1, 2))

@@ -159,3 +159,72 @@ class TorchModel:
         if self.mp:
             W = W + self.penalty_energy(c, U)
         return W
+
+
+# ---- analytic d(penalty residual)/d(xi) of one interface by autograd (moving intersections) ----------------------
+def _bspline_torch(span, xi, p, U):
+    """Values and first derivatives (torch, differentiable in xi) of the p + 1 B-spline functions that are non-zero on the span:
+    Cox-de Boor triangle for degrees 0 .. p, derivative from degree p - 1 (The NURBS Book, eq. 2.7)."""
+    N = [[None] * (p + 1) for _ in range(p + 1)]          # N[d][j]: function span - d + j of degree d
+    N[0][0] = torch.ones((), dtype=torch.float64)
+    for d in range(1, p + 1):
+        for j in range(d + 1):
+            i = span - d + j
+            v = torch.zeros((), dtype=torch.float64)
+            if j > 0 and U[i + d] > U[i]:
+                v = v + (xi - U[i]) / (U[i + d] - U[i]) * N[d - 1][j - 1]
+            if j < d and U[i + d + 1] > U[i + 1]:
+                v = v + (U[i + d + 1] - xi) / (U[i + d + 1] - U[i + 1]) * N[d - 1][j]
+            N[d][j] = v
+    val = torch.stack(N[p])
+    der = []
+    for j in range(p + 1):
+        i = span - p + j
+        v = torch.zeros((), dtype=torch.float64)
+        if j > 0 and U[i + p] > U[i]:
+            v = v + p / (U[i + p] - U[i]) * N[p - 1][j - 1]
+        if j < p and U[i + p + 1] > U[i + 1]:
+            v = v - p / (U[i + p + 1] - U[i + 1]) * N[p - 1][j]
+        der.append(v)
+    return val, torch.stack(der)
+
+
+def penalty_residual_dxi(patches, cp_off, pa, pb, weights, c, U, xi_a, xi_b, alpha, wt, zero_dofs):
+    """J[:, k] = d(penalty residual)/d(xi_flat[k]) for ONE interface between patches pa, pb, xi_flat = [xi_A (n x 2) | xi_B (n x 2)]:
+    the interface energy as a torch function of (U, xi) -- rational basis values and first derivatives at the vertices, the curve
+    tangent tau = G xi_A (second-order differences, model.Interface), Herrema's vertex energy (oracle/kl_energy_torch.py) with
+    frozen parameters alpha and vertex weights wt -- differentiated once in U and once in xi by autograd.  Dirichlet rows zeroed."""
+    n = xi_a.shape[0]
+    xi = torch.tensor(np.concatenate([xi_a.ravel(), xi_b.ravel()]), dtype=torch.float64, requires_grad=True)
+    Ut = torch.tensor(U.reshape(-1, 3), dtype=torch.float64, requires_grad=True)
+    ct = torch.tensor(c, dtype=torch.float64)
+    G = torch.tensor(np.gradient(np.eye(n), 1.0 / (n - 1), axis=0, edge_order=2 if n > 2 else 1), dtype=torch.float64)
+    XA, XB = xi[:2 * n].reshape(n, 2), xi[2 * n:].reshape(n, 2)
+    tau = G @ XA
+    E = torch.zeros((), dtype=torch.float64)
+    for v in range(n):
+        side = []
+        for s, X in ((pa, XA), (pb, XB)):
+            P = patches[s]
+            su = find_span(P.n_u, P.p, P.knots[0], float(X[v, 0]))
+            sv = find_span(P.n_v, P.q, P.knots[1], float(X[v, 1]))
+            nu, du = _bspline_torch(su, X[v, 0], P.p, P.knots[0])
+            nv, dv = _bspline_torch(sv, X[v, 1], P.q, P.knots[1])
+            ids = np.array([cp_off[s] + P.flat(su - P.p + ju, sv - P.q + jv) for jv in range(P.q + 1) for ju in range(P.p + 1)])
+            w = torch.tensor(weights[ids], dtype=torch.float64)
+            N0 = (nv[:, None] * nu[None, :]).reshape(-1)
+            N1 = (nv[:, None] * du[None, :]).reshape(-1)
+            N2 = (dv[:, None] * nu[None, :]).reshape(-1)
+            W0, W1, W2 = (N0 * w).sum(), (N1 * w).sum(), (N2 * w).sum()
+            R = N0 / W0
+            R1, R2 = (N1 - R * W1) / W0, (N2 - R * W2) / W0
+            Rg = torch.stack([R1, R2])
+            side.append((R @ Ut[ids], Rg @ (ct[ids] + Ut[ids]), Rg @ ct[ids]))
+        (uA, gA, GA), (uB, gB, GB) = side
+        E = E + ke.penalty_energy_point(uA, gA, uB, gB, GA, GB, tau[v], alpha[0], alpha[1], wt[v])
+    gxi = torch.autograd.grad(E, xi, create_graph=True)[0]
+    J = np.zeros((Ut.numel(), 4 * n))
+    for k in range(4 * n):
+        J[:, k] = torch.autograd.grad(gxi[k], Ut, retain_graph=True)[0].reshape(-1).numpy()
+    J[np.asarray(zero_dofs, dtype=np.int64)] = 0.0
+    return J
