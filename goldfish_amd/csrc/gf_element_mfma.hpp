@@ -69,6 +69,11 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     if (e >= M.nelem) return;
     const ElemDesc ed = M.edesc[e];
     const PatchDev& Pt = M.patches[ed.patch];
+    // patch constants (E, nu, f[3], pd[3]: contiguous in PatchDev) staged in LDS: read from memory inside the Gauss-point loop they
+    // are vector loads behind a vmcnt wait each (the compiler cannot move them across stores), held in registers they cost 16 VGPRs
+    __shared__ double s_pc[8];
+    if (threadIdx.x < 8) s_pc[threadIdx.x] = (&Pt.E)[threadIdx.x];
+    const double* const pf = s_pc + 2; const double* const ppd = s_pc + 5;
 
     __shared__ __attribute__((aligned(16))) double s_g[4 * 3 * 16];  // control-point staging (phases 0-1), residual reduction at the end
     double (*s_c)[3] = reinterpret_cast<double (*)[3]>(s_g);
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
         wave_lds_sync();                                   // all three lanes hold z, Z before the record overwrites the exchange slots
         if (act) {
             const double dsel[3] = {ic == 0 ? 1.0 : 0.0, ic == 1 ? 1.0 : 0.0, ic == 2 ? 1.0 : 0.0};
-            shell_point_cols<WITHC>(z, Z, t, Pt.E, Pt.nu_, ic, dsel, kk == 0, im);
+            shell_point_cols<WITHC>(z, Z, t, s_pc[0], s_pc[1], ic, dsel, kk == 0, im);
             if (kk == 0) {
                 for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
                 im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     GF_STAMP(1, tstamp);
 
     const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = WITHC && (flags & GF_ASM_C_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
-    const bool has_bf = (Pt.f[0] != 0.0) || (Pt.f[1] != 0.0) || (Pt.f[2] != 0.0);
+    const bool has_bf = (pf[0] != 0.0) || (pf[1] != 0.0) || (pf[2] != 0.0);
     const int xb = x < NB ? x : 0, ju = xb % P1, jv = xb / P1;
     const double bval = x < NB ? 1.0 : 0.0;                  // lanes beyond the basis functions contribute zero rows / columns
 
@@ -246,11 +251,11 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
         GF_STAMP(5, tstamp);
         // -- residual and dR/dh prefactors of basis function x at this Gauss point
         {
-            const double ls = has_bf ? load_scalar(im, Pt.pd) : 0.0;
+            const double ls = has_bf ? load_scalar(im, ppd) : 0.0;
             for (int i = 0; i < 3; ++i) {
                 double rz = 0.0;
                 for (int m = 0; m < 5; ++m) rz += phi[m] * im[IM_PZ + 3 * m + i];
-                accR[i] += wq * (rz - ls * Pt.f[i] * R0);
+                accR[i] += wq * (rz - ls * pf[i] * R0);
             }
         }
         double pb[5];
@@ -292,10 +297,10 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
                 for (int q = 0; q < 9; ++q) accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], t[q], accC[q], 0, 0, 0);
             });
             if (has_bf) {                    // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b): one tile per f, the factor -f_i is applied once at the end
-                const LoadGeom lg = load_geom(im, Pt.pd);
+                const LoadGeom lg = load_geom(im, ppd);
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {
-                    const double jz = load_dz_dot(im, Pt.pd, lg, f, pb[0], pb[1]);
+                    const double jz = load_dz_dot(im, ppd, lg, f, pb[0], pb[1]);
                     accB[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(R0, jz, accB[f], 0, 0, 0);
                 }
             }
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int f = 0; f < 3; ++f) accC[3 * i + f] -= Pt.f[i] * accB[f];
+            for (int f = 0; f < 3; ++f) accC[3 * i + f] -= pf[i] * accB[f];
     }
 
     // ---- residual: sum the four Gauss-point groups

@@ -110,6 +110,11 @@ __global__ __launch_bounds__(128, 2) void kl_element_mfma2_kernel(DevModel M, in
     if (e >= M.nelem) return;
     const ElemDesc ed = M.edesc[e];
     const PatchDev& Pt = M.patches[ed.patch];
+    // patch constants (E, nu, f[3], pd[3]: contiguous in PatchDev) staged in LDS: read from memory inside the Gauss-point loop they
+    // are vector loads behind a vmcnt wait each (the compiler cannot move them across stores), held in registers they cost 16 VGPRs
+    __shared__ double s_pc[8];
+    if (threadIdx.x < 8) s_pc[threadIdx.x] = (&Pt.E)[threadIdx.x];
+    const double* const pf = s_pc + 2; const double* const ppd = s_pc + 5;
 
     __shared__ __attribute__((aligned(16))) double s_g[4 * 3 * 16];
     double (*s_c)[3] = reinterpret_cast<double (*)[3]>(s_g);
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(128, 2) void kl_element_mfma2_kernel(DevModel M, in
         wave_lds_sync();
         if (act) {
             const double dsel[3] = {ic == 0 ? 1.0 : 0.0, ic == 1 ? 1.0 : 0.0, ic == 2 ? 1.0 : 0.0};
-            shell_point_cols<true>(z, Z, th, Pt.E, Pt.nu_, ic, dsel, kk == 0, im);
+            shell_point_cols<true>(z, Z, th, s_pc[0], s_pc[1], ic, dsel, kk == 0, im);
             if (kk == 0) {
                 for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
                 im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
@@ -232,8 +237,8 @@ __global__ __launch_bounds__(128, 2) void kl_element_mfma2_kernel(DevModel M, in
         __syncthreads();                                   // all six lanes hold z, Z before the record overwrites the exchange slots
         if (act) {
             const double dsel[3] = {ic == 0 ? 1.0 : 0.0, ic == 1 ? 1.0 : 0.0, ic == 2 ? 1.0 : 0.0};
-            if (cc == 0) shell_point_col<true, 0>(z, Z, th, Pt.E, Pt.nu_, ic, dsel, part == 0, im);
-            else shell_point_col<true, 1>(z, Z, th, Pt.E, Pt.nu_, ic, dsel, false, im);
+            if (cc == 0) shell_point_col<true, 0>(z, Z, th, s_pc[0], s_pc[1], ic, dsel, part == 0, im);
+            else shell_point_col<true, 1>(z, Z, th, s_pc[0], s_pc[1], ic, dsel, false, im);
             if (part == 0) {
                 for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
                 im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(128, 2) void kl_element_mfma2_kernel(DevModel M, in
     int oX[6];
     for (int s = 0; s < 6; ++s) oX[s] = tang ? IM_HMN + hmn_idx(r, s) : IM_DN + 6 * ir + s;
 
-    const bool has_bf = (Pt.f[0] != 0.0) || (Pt.f[1] != 0.0) || (Pt.f[2] != 0.0);
+    const bool has_bf = (pf[0] != 0.0) || (pf[1] != 0.0) || (pf[2] != 0.0);
     const int xb = x < NB ? x : 0, ju = xb % P1, jv = xb / P1;
     const double bval = x < NB ? 1.0 : 0.0;
     double* const out = blk + (size_t)blockIdx.x * Cfg::BLK;
@@ -321,11 +326,11 @@ __global__ __launch_bounds__(128, 2) void kl_element_mfma2_kernel(DevModel M, in
             for (int s = 0; s < 15; ++s) gR[s] = 0.0;
             if (doK) expand(im, gR, std::false_type{});
             {
-                const double ls = has_bf ? load_scalar(im, Pt.pd) : 0.0;
+                const double ls = has_bf ? load_scalar(im, ppd) : 0.0;
                 for (int i = 0; i < 3; ++i) {
                     double rz = 0.0;
                     for (int m = 0; m < 5; ++m) rz += phi[m] * im[IM_PZ + 3 * m + i];
-                    accR[i] += wq * (rz - ls * Pt.f[i] * R0);
+                    accR[i] += wq * (rz - ls * pf[i] * R0);
                 }
             }
             double pb[5];
@@ -403,10 +408,10 @@ __global__ __launch_bounds__(128, 2) void kl_element_mfma2_kernel(DevModel M, in
                 for (int q = 0; q < 9; ++q) accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], t[q], accC[q], 0, 0, 0);
             });
             if (has_bf) {
-                const LoadGeom lg = load_geom(im, Pt.pd);
+                const LoadGeom lg = load_geom(im, ppd);
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {
-                    const double jz = load_dz_dot(im, Pt.pd, lg, f, pb[0], pb[1]);
+                    const double jz = load_dz_dot(im, ppd, lg, f, pb[0], pb[1]);
                     accB[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(R0, jz, accB[f], 0, 0, 0);
                 }
             }
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(128, 2) void kl_element_mfma2_kernel(DevModel M, in
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int f = 0; f < 3; ++f) accC[3 * i + f] -= Pt.f[i] * accB[f];
+                for (int f = 0; f < 3; ++f) accC[3 * i + f] -= pf[i] * accB[f];
         }
         const int b = x;
 #pragma unroll

@@ -67,6 +67,11 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
     if (e >= M.nelem) return;
     const ElemDesc ed = M.edesc[e];
     const PatchDev& Pt = M.patches[ed.patch];
+    // patch constants (E, nu, f[3], pd[3]: contiguous in PatchDev) staged in LDS: read from memory inside the Gauss-point loop they
+    // are vector loads behind a vmcnt wait each (the compiler cannot move them across stores), held in registers they cost 16 VGPRs
+    __shared__ double s_pc[8];
+    if (threadIdx.x < 8) s_pc[threadIdx.x] = (&Pt.E)[threadIdx.x];
+    const double* const pf = s_pc + 2; const double* const ppd = s_pc + 5;
 
     __shared__ __attribute__((aligned(16))) double s_g[8 * NB];      // control-point staging (phases 0-1), then the residual reduction (2 x 2 x NB x 3 <= 8 NB... see below)
     double (*s_c)[3] = reinterpret_cast<double (*)[3]>(s_g);
@@ -125,14 +130,14 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
             for (int m = 0; m < 5; ++m) z[3 * m + i] = R[m + 1];
         }
         double* im = s_im[tid];
-        shell_point(z, Z, t, Pt.E, Pt.nu_, im);
+        shell_point(z, Z, t, s_pc[0], s_pc[1], im);
         for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
         im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
     }
     wave_lds_sync();
 
     const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = WITHC && (flags & GF_ASM_C_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
-    const bool has_bf = (Pt.f[0] != 0.0) || (Pt.f[1] != 0.0) || (Pt.f[2] != 0.0);
+    const bool has_bf = (pf[0] != 0.0) || (pf[1] != 0.0) || (pf[2] != 0.0);
     // basis functions of this lane: tile 0 -> x, tile 1 -> 16 + x (padding for x >= NT1)
     const int bf[2] = {x, x < NT1 ? 16 + x : 0};
     const double bval[2] = {1.0, x < NT1 ? 1.0 : 0.0};
@@ -171,14 +176,14 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
             for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
             if (doK || doC) { RL.template expand<WITHC>(im, gR, hR); dpp_source_fence(gR); if constexpr (WITHC) dpp_source_fence(hR); }
             // -- residual (first pass only) and dR/dh prefactors of both a tiles
-            const double ls = (has_bf && tb == 0) ? load_scalar(im, Pt.pd) : 0.0;
+            const double ls = (has_bf && tb == 0) ? load_scalar(im, ppd) : 0.0;
             if (tb == 0) {
 #pragma unroll
                 for (int ta = 0; ta < 2; ++ta)
                     for (int i = 0; i < 3; ++i) {
                         double rz = 0.0;
                         for (int m = 0; m < 5; ++m) rz += phi[ta][m] * im[IM_PZ + 3 * m + i];
-                        accR[ta][i] += wq * (rz - ls * Pt.f[i] * R0[ta]);
+                        accR[ta][i] += wq * (rz - ls * pf[i] * R0[ta]);
                     }
             }
             double pb[5];
@@ -226,14 +231,14 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
                     }
                 });
                 if (has_bf) {                    // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b)
-                    const LoadGeom lg = load_geom(im, Pt.pd);        // behind the uniform branch: a model without distributed loads does not pay for it
+                    const LoadGeom lg = load_geom(im, ppd);        // behind the uniform branch: a model without distributed loads does not pay for it
 #pragma unroll
                     for (int f = 0; f < 3; ++f) {
-                        const double jz = load_dz_dot(im, Pt.pd, lg, f, pb[0], pb[1]);
+                        const double jz = load_dz_dot(im, ppd, lg, f, pb[0], pb[1]);
 #pragma unroll
                         for (int i = 0; i < 3; ++i) {
-                            accC[0][3 * i + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pt.f[i] * R0[0], jz, accC[0][3 * i + f], 0, 0, 0);
-                            accC[1][3 * i + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pt.f[i] * R0[1], jz, accC[1][3 * i + f], 0, 0, 0);
+                            accC[0][3 * i + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pf[i] * R0[0], jz, accC[0][3 * i + f], 0, 0, 0);
+                            accC[1][3 * i + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pf[i] * R0[1], jz, accC[1][3 * i + f], 0, 0, 0);
                         }
                     }
                 }

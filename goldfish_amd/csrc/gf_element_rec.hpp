@@ -1,49 +1,36 @@
-// gf_element_walk.hpp -- MFMA element kernel (p = 2, 3) that walks a strip of elements and accumulates straight into the CSR
-// value arrays: no element blocks, no gather.
+// gf_element_rec.hpp -- MFMA element kernel (p = 2, 3) that walks a strip of elements, keeps the accumulators across elements and
+// STORES every control-point pair once per work item, when its lower row leaves the window: "row records" instead of element blocks.
 //
-// kl_element_mfma_kernel writes one 43 KB block per element and the gather reads every block back (26 GB each way per C4
-// step, 5.3x the algorithmic bytes; the gather is a quarter of the step).  Here one wave walks the elements ev = ev0 .. of a
-// strip (fixed u-span eu) and KEEPS the MFMA accumulators across elements.  A control-point pair (A, B) lives in the
-// accumulator slot addressed by the rows' indices modulo 4:
-//     operand lane x  <->  basis function (u index x / 4, v slot x % 4),  v slot s holds the control-point row with row % 4 = s,
-//     D[a][b]: lane (x, kk), register rr  <->  A = (iu0 + rr, row of slot kk),  B = (iu0 + x / 4, row of slot x % 4),
-// so moving to the next element changes WHICH basis function a lane evaluates (a different entry of the 1-D v table), never
-// where a pair's partial sum sits: no shifts, no moves.  When the window leaves a row, the pairs that have it as their lower
-// row (28 of 64 lanes, all registers) are complete for this strip: their sums are added to the CSR entries and the slots are
-// zeroed for the row that enters.  A pair receives contributions from up to p + 1 strips and (when a strip is cut into
-// segments) two segments: the work items are launched in classes (eu mod (p + 1), segment parity); items of one class share
-// no pair, classes run in ascending order, the first class touching an entry stores, later ones add to what is there --
-// a fixed summation order, no atomics, bitwise reproducible.  vmcnt counts loads and stores together, in order: a load issued
-// behind the flush stores would wait for every one of them, so the kernel never issues one there -- the next element's inputs
-// are fetched before the group loop into a few registers and parked in LDS (rows in a ring of 8: the window of the next element
-// never collides with the rows the flush still needs), and all reads of a flush precede its first store.  Dirichlet rows / columns are overwritten at every flush; the
-// penalty rows are added afterwards (pen_owner_kernel<.., ADD = true>).  The residual still goes through a 3 (p+1)^2-double
-// block per element and kl_rgather_kernel.
-// Traffic per C4 step: ~11 GB of partial sums written + ~6 GB read back, instead of 26 GB written + 29 GB read + 6 GB written.
+// kl_element_mfma_kernel writes one 43 KB block per element (18 tiles of 16 x 16 plus the mirrored K tiles) and the gather reads every
+// block back: a pair of control points is stored up to (p+1)^2 times.  Walking along v with the slot addressing of
+// kl_element_walk_kernel (a pair lives in the accumulator slot given by its rows' indices modulo 4; see gf_element_walk.hpp) the
+// (p+1) elements of a strip that contribute to a pair are summed in registers, so a pair is stored once per strip it lies in
+// ((p+1) times instead of (p+1)^2): 16 KB per element instead of 43 KB.  Unlike kl_element_walk_kernel nothing is read back and
+// nothing depends on launch order: the flush is a burst of plain stores (no read-modify-write round trip, no classes, one launch),
+// and kl_gather_rec_kernel sums the <= p + 1 strips (x <= 2 segments) of every pair in a fixed order: bitwise reproducible.
+//
+// Record of row rho of a work item (RecCfg<WITHC>::SZ = 112 NT doubles, NT tiles): the pairs (A, B) whose lower row is rho,
+//     area 1  [rr][tile q][c], c < 16:        A = (iu0 + rr, rho),       B = (iu0 + c / 4, the row >= rho with row % 4 = c % 4)
+//     area 2  [rr][rk][tile q][jub], rk < 3:  A = (iu0 + rr, rho + 1 + rk),  B = (iu0 + jub, rho)
+// so that what the gather of one control point needs from a record is contiguous (a control point reads [rr = its u index] of both
+// areas).  Tiles: K (i <= j) 0..5, dR/dh 6..8, dR/dCP (i, f) 9..17.  Record index = item * rec_rows + (rho - first row of the item).
 // Reference path: the same integrals as kl_element_mfma_kernel (GOLDFISH/nonmatching_opt.py:941-1015 via PENGoLINS assembly).
 #pragma once
-#include "gf_element_mfma.hpp"
+#include "gf_element_walk.hpp"
 
 namespace gf {
 
-struct WalkOut { double* valK; double* valC0; double* valC1; double* valC2; double* valH; double* rblk; const WalkPatch* wpatch; };
+template <bool WITHC> struct RecCfg { static constexpr int NT = WITHC ? 18 : 9, A2 = 64 * NT, SZ = 112 * NT, QK = 0, QH = 6, QC = 9; };
 
-// The value arrays are addressed through buffer resources that span ONE patch (base in SGPRs, 32-bit byte offset per lane):
-// half the address registers and arithmetic of flat 64-bit pointers, and an offset beyond the range reads as zero -- a pair
-// that starts in this class, or a Dirichlet entry, "reads" its old value from there: no branch, no zero page.
-typedef unsigned gf_u2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t walk_rsrc(double* base, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000); }
-__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0)); }
-__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned off, double v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gf_u2, v), r, (int)off, 0, 0); }
-constexpr unsigned WALK_OOR = 0xFFFFE000u;     // byte offset beyond every patch range (HostModel::build_walk keeps the ranges below 2^32 - 4096)
+struct RecOut { double* rec; double* rblk; int rec_rows; };
 
 template <int P, bool WITHC = true>
-__global__ __launch_bounds__(64) void kl_element_walk_kernel(DevModel M, const WalkItem* __restrict__ items, int item_first, int flags,
-                                                              const RowDesc* __restrict__ rowdesc, WalkOut O) {
+__global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const WalkItem* __restrict__ items, int flags, RecOut O) {
     static_assert(P == 2 || P == 3, "one 16 x 16 tile: p <= 3");
+    using RC = RecCfg<WITHC>;
     constexpr int P1 = P + 1, NB = P1 * P1, NG = NB, ND = 3 * NB, NGRP = (NG + 3) / 4, TS = P1 * 3 * P1;
     const int tid = threadIdx.x, x = tid & 15, kk = tid >> 4;
-    const WalkItem it = items[item_first + blockIdx.x];
+    const WalkItem it = items[blockIdx.x];
     const PatchDev& Pt = M.patches[it.patch];
     // patch constants (E, nu, f[3], pd[3]: contiguous in PatchDev) staged in LDS: read from memory inside the Gauss-point loop they
     // are vector loads behind a vmcnt wait each (the compiler cannot move them across stores), held in registers they cost 16 VGPRs
@@ -59,7 +46,6 @@ __global__ __launch_bounds__(64) void kl_element_walk_kernel(DevModel M, const W
     __shared__ double s_tu[TS], s_tv[2][TS], s_wgu[P1], s_wgv[2][P1];            // v tables double buffered (the next element's are parked while this one's are in use)
     __shared__ __attribute__((aligned(16))) double s_im[NG][IM_SIZE];
     __shared__ __attribute__((aligned(16))) double s_raw[8][4][8];               // control points of the windows, ring over the row index: c_x, c_y, c_z, w, u_x, u_y, u_z, h
-    __shared__ __attribute__((aligned(16))) int s_rd[8][4][16];                  // their row descriptors
 
     // ---- lane constants of the row expansion (see kl_element_mfma_kernel)
     const bool tang = x < 6;
@@ -85,145 +71,69 @@ __global__ __launch_bounds__(64) void kl_element_walk_kernel(DevModel M, const W
     for (int q = 0; q < 3; ++q) accH[q] = gf_d4{0, 0, 0, 0};
 
     // ---- input fetch of one element: 16 bytes per lane of the window's control points (lane = 4 * local index + quarter:
-    //      c_xy | c_zw | u_xy | u_z, h) and of their row descriptors, the v table and v weights; parked in LDS by park()
+    //      c_xy | c_zw | u_xy | u_z, h), the v table and v weights; requested behind phase 1, parked in LDS behind the group loop
     const int pa_cp = tid >> 2, pa_q = tid & 3, pa_ju = pa_cp % P1, pa_jv = pa_cp / P1;
-    struct Fetch { double2 cp; int4 rd; double tv, wv; };
-    auto fetch = [&](const ElemDesc& ed) {
-        Fetch F; F.cp = double2{0.0, 0.0}; F.rd = int4{0, 0, 0, 0}; F.tv = 0.0; F.wv = 0.0;
+    struct Fetch { double2 cp; double tv, wv; };
+    // (everything is addressed from the patch record and the element row: no per-element descriptor, no dependent load)
+    auto fetch = [&](int ev, int iv0f) {
+        Fetch F; F.cp = double2{0.0, 0.0}; F.tv = 0.0; F.wv = 0.0;
         if (pa_cp < NB) {
-            const long long g = ed.g0 + pa_ju + (long long)pa_jv * ed.nu;
+            const long long g = Pt.cp_off + (it.iu0 + pa_ju) + (long long)(iv0f + pa_jv) * Pt.nu;
             if (pa_q < 2) F.cp = reinterpret_cast<const double2*>(M.cp4 + 4 * g)[pa_q];
             else if (pa_q == 2) { F.cp.x = M.u[3 * g]; F.cp.y = M.u[3 * g + 1]; }
             else { F.cp.x = M.u[3 * g + 2]; F.cp.y = M.h[g]; }
-            F.rd = reinterpret_cast<const int4*>(rowdesc + g)[pa_q];
         }
-        if (tid < TS) F.tv = M.tab[ed.tabv + tid];
-        if (tid < P1) F.wv = M.tab[ed.wv + tid];
+        if (tid < TS) F.tv = M.tab[Pt.tabv + ev * TS + tid];
+        if (tid < P1) F.wv = M.tab[Pt.wv + ev * P1 + tid];
         return F;
     };
     auto park = [&](const Fetch& F, int iv0f, int buf) {
-        if (pa_cp < NB) {
-            const int rs = (iv0f + pa_jv) & 7;
-            *reinterpret_cast<double2*>(&s_raw[rs][pa_ju][2 * pa_q]) = F.cp;
-            *reinterpret_cast<int4*>(&s_rd[rs][pa_ju][4 * pa_q]) = F.rd;
-        }
+        if (pa_cp < NB) *reinterpret_cast<double2*>(&s_raw[(iv0f + pa_jv) & 7][pa_ju][2 * pa_q]) = F.cp;
         if (tid < TS) s_tv[buf][tid] = F.tv;
         if (tid < P1) s_wgv[buf][tid] = F.wv;
     };
+    const int iv_first = M.ints[Pt.spv + it.ev0] - P;
     {   // prologue: u table and weights of the strip, inputs of the first element
-        const long long e0 = Pt.elem_off + it.eu + (long long)it.ev0 * Pt.nelu;
-        const ElemDesc ed = M.edesc[e0];
-        if (tid < TS) s_tu[tid] = M.tab[ed.tabu + tid];
-        if (tid < P1) s_wgu[tid] = M.tab[ed.wu + tid];
-        const Fetch F = fetch(ed);
-        park(F, M.ints[Pt.spv + it.ev0] - P, 0);
+        if (tid < TS) s_tu[tid] = M.tab[Pt.tabu + it.eu * TS + tid];
+        if (tid < P1) s_wgu[tid] = M.tab[Pt.wu + it.eu * P1 + tid];
+        const Fetch F = fetch(it.ev0, iv_first);
+        park(F, iv_first, 0);
     }
 
-    const int ev_end = it.ev0 + it.nel;
-    const bool seg_even = (it.seg & 1) == 0;
-    const WalkPatch wp = O.wpatch[it.patch];
-    const __amdgpu_buffer_rsrc_t rK = walk_rsrc(O.valK + wp.kbase, wp.kbytes), rC0 = walk_rsrc(O.valC0 + wp.cbase, wp.cbytes),
-                                 rC1 = walk_rsrc(O.valC1 + wp.cbase, wp.cbytes), rC2 = walk_rsrc(O.valC2 + wp.cbase, wp.cbytes), rH = walk_rsrc(O.valH + wp.hbase, wp.hbytes);
-    // ---- flush of the pairs whose lower row leaves the window (first row iv0f, next element's first row iv0nf): they are
-    //      complete for this item.  PART 0: K and dR/dh, at the end of the element; PART 1: dR/dCP, behind phase 1 of the NEXT
-    //      element (its inputs are in LDS already, so no load is issued in between and the stores of part 0 have drained) --
-    //      two halves so that all reads of a half (every one precedes its first store) fit the register file.
-    auto flush = [&](auto PART_, int iv0f, int iv0nf) {
-        constexpr int PART = decltype(PART_)::value;
-#ifndef GF_WALK_HPART
-#define GF_WALK_HPART 0                    // dR/dh rides with K (measured: fewer spills than with the dR/dCP half)
-#endif
-        const bool fK = PART == 0 && doK, fH = PART == GF_WALK_HPART && doH, fC = PART == 1 && doC;
+    // ---- flush: the pairs whose lower row leaves the window (first row iv0f, next element's first row iv0nf) are complete for
+    //      this item; every lane holds pairs of exactly one lower row rho and stores its registers into that row's record.
+    const __amdgpu_buffer_rsrc_t rR = walk_rsrc(O.rec + (size_t)blockIdx.x * O.rec_rows * RC::SZ, (unsigned)(O.rec_rows * RC::SZ * 8));
+    auto flush = [&](int iv0f, int iv0nf) {
         const int rowa = iv0f + ((kk - iv0f) & 3), rowb = iv0f + ((sb - iv0f) & 3);       // control-point rows of this lane's slots
         const bool live = (rowa - iv0f) < P1 && (rowb - iv0f) < P1 && jub < P1;
-        // any Dirichlet dof among the window's control points (wave-uniform): only then the flush carries the constraint logic
-        const bool anybc = __builtin_amdgcn_ballot_w64(((rowb - iv0f) < P1 && jub < P1) ? s_rd[rowb & 7][jubc][8] != 0 : false) != 0;
-        if (live && (rowa < iv0nf || rowb < iv0nf) && (fK || fC || fH)) {
-            const int* dB = s_rd[rowb & 7][jub];
-            const int Bu = it.iu0 + jub;
-            const int offKB = dB[0], degB = dB[1], i0B = dB[5], j0B = dB[6], wbB = dB[7], zB = dB[8], louB = dB[9], hiuB = dB[10], lovB = dB[11], hivB = dB[12];
-            // first touch along the walk direction: a pair seen by two segments is started by the even one
-            const int lovA = s_rd[rowa & 7][0][11], hivA = s_rd[rowa & 7][0][12];
-            const int t0 = lovA > lovB ? lovA : lovB, t1 = hivA < hivB ? hivA : hivB;
-            const bool vfirst = (t0 >= it.ev0 && t1 < ev_end) || seg_even;
-            constexpr int IJ_I[6] = {0, 0, 0, 1, 1, 2}, IJ_J[6] = {0, 1, 2, 1, 2, 2};
-            unsigned kA[P1], kB[P1], cA[P1], hA[P1], sK[P1], sC[P1], sH[P1], zA[P1], gate[P1];
+        const int rho = rowa < rowb ? rowa : rowb;
+        if (live && rho < iv0nf) {
+            const int s = rho & 3;
+            const bool own = kk == s;                                 // A's row is the lower one: area 1, else area 2 (A's row = rho + 1 + rk)
+            const int rk = ((kk - s) & 3) - 1;
+            const unsigned sr = 8u * (own ? RC::NT * 16 : 3 * RC::NT * 4), sq = 8u * (own ? 16 : 4);
+            unsigned off = 8u * (unsigned)((rho - iv_first) * RC::SZ + (own ? x : RC::A2 + rk * RC::NT * 4 + jub));
 #pragma unroll
-            for (int rr = 0; rr < P1; ++rr) {
-                const int* dA = s_rd[rowa & 7][rr];
-                const int Au = it.iu0 + rr;
-                const int offKA = dA[0], dgA = dA[1], offCA = dA[2], offHA = dA[3], dgsA = dA[4], i0A = dA[5], j0A = dA[6], wbA = dA[7], louA = dA[9], hiuA = dA[10];
-                zA[rr] = dA[8];
-                const int s0 = louA > louB ? louA : louB, s1 = hiuA < hiuB ? hiuA : hiuB;
-                const bool first = vfirst && ((it.eu % P1 == 0) || (it.eu == s0 && s0 / P1 == s1 / P1));
-                gate[rr] = first ? WALK_OOR : 0u;                              // offset | gate: out of range, reads 0
-                const int slotAB = (Bu - i0A) + (rowb - j0A) * wbA, slotBA = (Au - i0B) + (rowa - j0B) * wbB;
-                kA[rr] = 8u * (offKA + 3 * slotAB); kB[rr] = 8u * (offKB + 3 * slotBA); cA[rr] = 8u * (offCA + slotAB); hA[rr] = 8u * (offHA + slotAB);
-                sK[rr] = 24u * dgA; sC[rr] = 8u * dgA; sH[rr] = 8u * dgsA;
-            }
-            const unsigned sKB = 24u * degB;
-            // -- pass 1: every read of this half (what the earlier classes left) before its first store -- vmcnt is in order, a
-            //    load behind a store would wait for it.  Unconditional loads: nothing for the compiler to predicate.
-            double tK[P1][6], tC[P1][9], tH[P1][3];
+            for (int rr = 0; rr < P1; ++rr, off += sr) {
+                if (doK) {
 #pragma unroll
-            for (int rr = 0; rr < P1; ++rr) {
-                if (fK) {
-#pragma unroll
-                    for (int ij = 0; ij < 6; ++ij) {
-                        const int i = IJ_I[ij], j = IJ_J[ij];
-                        unsigned off = (kA[rr] + i * sK[rr] + 8 * j) | gate[rr];
-                        if (anybc) off = (((zA[rr] >> i) & 1) || ((zB >> j) & 1)) ? WALK_OOR : off;
-                        tK[rr][ij] = buf_ld(rK, off);
-                    }
+                    for (int q = 0; q < 6; ++q) buf_st(rR, off + (RC::QK + q) * sq, accK[q][rr]);
                 }
-                if constexpr (WITHC) if (fC) {
+                if (doH) {
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) {
-                        const int i = q / 3, f = q % 3;
-                        unsigned off = (cA[rr] + i * sC[rr]) | gate[rr];
-                        if (anybc) off = ((zA[rr] >> i) & 1) ? WALK_OOR : off;
-                        tC[rr][q] = buf_ld(f == 0 ? rC0 : (f == 1 ? rC1 : rC2), off);
-                    }
+                    for (int q = 0; q < 3; ++q) buf_st(rR, off + (RC::QH + q) * sq, accH[q][rr]);
                 }
-                if (fH) {
+                if constexpr (WITHC) if (doC) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) tH[rr][i] = buf_ld(rH, (hA[rr] + i * sH[rr]) | gate[rr]);
+                    for (int q = 0; q < 9; ++q) buf_st(rR, off + (RC::QC + q) * sq, accC[q][rr]);
                 }
             }
-            // -- pass 2: sums and stores, then the slots start from zero for the rows that enter
-#pragma unroll
-            for (int rr = 0; rr < P1; ++rr) {
-                const bool diag = (rr == jub) && (kk == sb);
-                if (fK) {
-#pragma unroll
-                    for (int ij = 0; ij < 6; ++ij) {
-                        const int i = IJ_I[ij], j = IJ_J[ij];
-                        double v = tK[rr][ij] + accK[ij][rr];
-                        if (anybc) { if (((zA[rr] >> i) & 1) || ((zB >> j) & 1)) v = (diag && i == j) ? 1.0 : 0.0; }
-                        buf_st(rK, kA[rr] + i * sK[rr] + 8 * j, v);
-                        if (i < j) buf_st(rK, kB[rr] + j * sKB + 8 * i, v);          // K is symmetric: entry (B, j), (A, i)
-                    }
-                }
-                if constexpr (WITHC) if (fC) {
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) {
-                        double v = tC[rr][q] + accC[q][rr];
-                        if (anybc) { if ((zA[rr] >> (q / 3)) & 1) v = 0.0; }
-                        buf_st(q % 3 == 0 ? rC0 : (q % 3 == 1 ? rC1 : rC2), cA[rr] + (q / 3) * sC[rr], v);
-                    }
-                }
-                if (fH) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) buf_st(rH, hA[rr] + i * sH[rr], tH[rr][i] + accH[i][rr]);
-                }
-            }
-            if constexpr (PART == 0) for (int q = 0; q < 6; ++q) accK[q] = gf_d4{0, 0, 0, 0};
-            if constexpr (PART == 1) for (int q = 0; q < 9; ++q) accC[q] = gf_d4{0, 0, 0, 0};
-            if constexpr (PART == GF_WALK_HPART) for (int q = 0; q < 3; ++q) accH[q] = gf_d4{0, 0, 0, 0};
+            for (int q = 0; q < 6; ++q) accK[q] = gf_d4{0, 0, 0, 0};
+            for (int q = 0; q < 9; ++q) accC[q] = gf_d4{0, 0, 0, 0};
+            for (int q = 0; q < 3; ++q) accH[q] = gf_d4{0, 0, 0, 0};
         }
     };
 
-    int prev_iv0 = 0, prev_iv0n = 0;
     unsigned long long tstamp = 0; (void)tstamp;
 #ifdef GF_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -301,14 +211,11 @@ __global__ __launch_bounds__(64) void kl_element_walk_kernel(DevModel M, const W
         wave_lds_sync();
 
         GF_STAMP(1, tstamp);
-        // ---- second half of the previous element's flush (dR/dCP): the stores of its first half have drained meanwhile
-        if constexpr (WITHC) { if (t > 0) flush(std::integral_constant<int, 1>{}, prev_iv0, prev_iv0n); }
-
         // ---- the next element's inputs are requested now (they land during the group loop) and parked in LDS behind it:
-        //      no load is ever issued behind the flush stores
+        //      vmcnt counts loads and stores in order, so a load right behind the flush stores would wait for all of them
         GF_STAMP(2, tstamp);
-        Fetch Fn; Fn.cp = double2{0.0, 0.0}; Fn.rd = int4{0, 0, 0, 0}; Fn.tv = 0.0; Fn.wv = 0.0;
-        if (more) Fn = fetch(M.edesc[e + Pt.nelu]);
+        Fetch Fn; Fn.cp = double2{0.0, 0.0}; Fn.tv = 0.0; Fn.wv = 0.0;
+        if (more) Fn = fetch(ev + 1, iv0n);
         GF_STAMP(3, tstamp);
 
         // this lane's basis function in the current element: u index jub, v index = (slot - first row) mod 4
@@ -442,15 +349,139 @@ __global__ __launch_bounds__(64) void kl_element_walk_kernel(DevModel M, const W
         }
 
         GF_STAMP(5, tstamp);
-        // ---- flush, first half (K, dR/dh); the dR/dCP half follows behind phase 1 of the next element
-        flush(std::integral_constant<int, 0>{}, iv0, iv0n);
-        prev_iv0 = iv0; prev_iv0n = iv0n;
+        // ---- store the pairs whose lower row leaves the window
+        flush(iv0, iv0n);
         GF_STAMP(6, tstamp);
     }
 #ifdef GF_STAMPS
     if ((blockIdx.x & 7) == 0 && tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[k], stamp_acc[k]);
 #endif
-    if constexpr (WITHC) flush(std::integral_constant<int, 1>{}, prev_iv0, prev_iv0n);      // (with WITHC = false there is no second half)
+}
+
+
+// Record gather: ONE wave per control point a = (ia, ja) sums, strip by strip and segment by segment (a fixed order), what the row
+// records hold for its three dof rows, then writes the rows (gather_write_rows: Dirichlet entries, coupling-only columns, penalty
+// rows).  From a work item (strip iu0 .. iu0 + p, segment g) with rr_a = ia - iu0:
+//   G1  record ja,      area 1 [rr_a][q][c]:            a as A, neighbours b = (iu0 + c / 4, ja + ((c - ja) & 3)): all tiles, contiguous
+//   G3  record ja-1-rk, area 2 [rr_a][rk][q][jub]:      a as A, b = (iu0 + jub, ja - 1 - rk): all tiles, contiguous per rk
+//   G2  record ja,      area 2 [rr][rk][q'][rr_a]:      a as B, b = (iu0 + rr, ja + 1 + rk): K^(i > j) = tile (j, i) of the pair (b, a)
+//   G4  record ja-d,    area 1 [rr][q'][4 rr_a + ja%4]: a as B, b = (iu0 + rr, ja - d)
+// A pair is present in an item only if one of the item's elements holds both rows; everything else in a record row is never
+// written and never read.
+template <int P, bool WITHC>
+__global__ __launch_bounds__(64) void kl_gather_rec_kernel(DevModel M, long long a_first, long long a_end, int flags, const double* __restrict__ rec, int rec_rows,
+                                                           const RecPatch* __restrict__ rpatch, double* __restrict__ valK, double* __restrict__ valC0,
+                                                           double* __restrict__ valC1, double* __restrict__ valC2, double* __restrict__ valH, int pen_add) {
+    using RC = RecCfg<WITHC>;
+    constexpr int P1 = P + 1, WB = 2 * P + 1, NBOX = WB * WB, NT = RC::NT, SZ = RC::SZ, A2 = RC::A2;
+    // workgroup w runs on XCD w % 8: every XCD takes a contiguous range of control points, so that the record lines shared by
+    // neighbouring control points are fetched into one L2
+    const long long chunk = (a_end - a_first + 7) / 8;
+    const long long a = a_first + (long long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((long long)(blockIdx.x >> 3) >= chunk || a >= a_end) return;
+    const CpDesc& cd = M.cpdesc[a];
+    const int ia = cd.ia, ja = cd.ja, i0 = cd.i0, j0 = cd.j0, wbox = cd.i1 - cd.i0 + 1;
+    const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c, ptr_s = M.nb_ptr_s[a], deg_s = M.nb_ptr_s[a + 1] - ptr_s;
+    const int lane = threadIdx.x;
+    __shared__ double acc[21 * NBOX];                   // aK [3][NBOX][3] | aH [3][NBOX] | aC [3 f][3 i][NBOX]
+    __shared__ unsigned short s_meta[GATHER_MAXMETA];
+    __shared__ int s_lov[8], s_hiv[8], s_tb[18], s_ts[18], s_mb[3];
+    const PatchDev& Pt = M.patches[cd.patch];
+    const RecPatch rp = rpatch[cd.patch];
+    for (int k = lane; k < (int)deg_c && k < GATHER_MAXMETA; k += 64) s_meta[k] = M.nb_meta[ptr_c + k];
+    for (int k = lane; k < 21 * NBOX; k += 64) acc[k] = 0.0;
+    if (lane < 7) {                                     // element rows of the control-point rows ja - 3 .. ja + 3
+        const int jb = ja - 3 + lane; const bool in = jb >= 0 && jb < Pt.nv;
+        s_lov[lane] = in ? M.ints[Pt.c2v + 2 * jb] : (1 << 30); s_hiv[lane] = in ? M.ints[Pt.c2v + 2 * jb + 1] : -1;
+    }
+    if (lane < 18) {                                    // accumulator address of tile q: base + slot * stride
+        constexpr int QI[6] = {0, 0, 0, 1, 1, 2}, QJ[6] = {0, 1, 2, 1, 2, 2};
+        int qi = 0, qj = 0;
+        for (int q = 0; q < 6; ++q) if (q == lane) { qi = QI[q]; qj = QJ[q]; }
+        if (lane < 6) { s_tb[lane] = qi * NBOX * 3 + qj; s_ts[lane] = 3; }
+        else if (lane < 9) { s_tb[lane] = 9 * NBOX + (lane - 6) * NBOX; s_ts[lane] = 1; }
+        else { const int i = (lane - 9) / 3, f = (lane - 9) % 3; s_tb[lane] = 12 * NBOX + (f * 3 + i) * NBOX; s_ts[lane] = 1; }
+        if (lane == 1 || lane == 2 || lane == 4) s_mb[lane == 4 ? 2 : lane - 1] = qj * NBOX * 3 + qi;       // mirrored entry (i > j) of the tiles (0,1), (0,2), (1,2)
+    }
+    __syncthreads();
+    const bool doC = WITHC && (flags & GF_ASM_C_BIT) != 0, doK = (flags & GF_ASM_K_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
+    const int lov_a = s_lov[3], hiv_a = s_hiv[3];
+    const int g_lo = M.ints[rp.seg_of + lov_a], g_hi = M.ints[rp.seg_of + hiv_a], ng = g_hi - g_lo + 1, nit = cd.neu * ng;
+    constexpr int N1 = NT * 16, NP1 = (N1 + 63) / 64, N3 = 3 * NT * 4, NP3 = (N3 + 63) / 64, NV = NP1 + NP3 + 2;
+    // ---- per-lane task table (independent of strip and segment): accumulator address for iu0 = i0, its stride in iu0 (1 or 3), the
+    //      row offset d whose presence decides, the offset in the record (relative to the row record of ja) and its stride in rr_a.
+    //      task v < NP1: G1, < NP1 + NP3: G3, then G2, G4.  tk = address | stride3 << 15 | d << 16 | valid << 20
+    int tk[NV], to[NV];
+#pragma unroll
+    for (int ps = 0; ps < NP1; ++ps) {
+        const int t = lane + 64 * ps, q = (t >> 4) < NT ? (t >> 4) : 0, c = t & 15, jub = c >> 2, dv = (c - ja) & 3;
+        const bool en = q < 6 ? doK : (q < 9 ? doH : doC);
+        const bool ok = t < N1 && en && jub < P1 && dv < P1;
+        tk[ps] = ((s_tb[q] + (jub + (ja + dv - j0) * wbox) * s_ts[q]) & 0x7fff) | (s_ts[q] == 3 ? 1 << 15 : 0) | ((3 + dv) << 16) | (ok ? 1 << 20 : 0);
+        to[ps] = t;                                                   // + rr_a * NT * 16
+    }
+#pragma unroll
+    for (int ps = 0; ps < NP3; ++ps) {
+        const int t = lane + 64 * ps, rk = t / (NT * 4) < 3 ? t / (NT * 4) : 0, r = t - (t / (NT * 4)) * NT * 4, q = r >> 2, jub = r & 3;
+        const bool en = q < 6 ? doK : (q < 9 ? doH : doC);
+        const bool ok = t < N3 && en && jub < P1 && rk + 1 < P1;
+        tk[NP1 + ps] = ((s_tb[q] + (jub + (ja - 1 - rk - j0) * wbox) * s_ts[q]) & 0x7fff) | (s_ts[q] == 3 ? 1 << 15 : 0) | ((2 - rk) << 16) | (ok ? 1 << 20 : 0);
+        to[NP1 + ps] = (-1 - rk) * SZ + A2 + rk * NT * 4 + r;          // + rr_a * 3 * NT * 4
+    }
+    {   // G2: 3 tiles x 3 rk x 4 rr (a as B, rows above)
+        const int m = lane / 12 < 3 ? lane / 12 : 0, r = lane - 12 * (lane / 12), rk = r >> 2, rr = r & 3, qm = m == 2 ? 4 : m + 1;
+        const bool ok = lane < 36 && doK && rr < P1 && rk + 1 < P1;
+        tk[NP1 + NP3] = ((s_mb[m] + (rr + (ja + 1 + rk - j0) * wbox) * 3) & 0x7fff) | (1 << 15) | ((4 + rk) << 16) | (ok ? 1 << 20 : 0);
+        to[NP1 + NP3] = A2 + ((rr * 3 + rk) * NT + qm) * 4;           // + rr_a
+    }
+    {   // G4: 3 tiles x 4 d x 4 rr (a as B, own row and rows below)
+        const int m = (lane >> 4) < 3 ? (lane >> 4) : 0, r = lane & 15, d = r >> 2, rr = r & 3, qm = m == 2 ? 4 : m + 1;
+        const bool ok = lane < 48 && doK && rr < P1 && d < P1;
+        tk[NP1 + NP3 + 1] = ((s_mb[m] + (rr + (ja - d - j0) * wbox) * 3) & 0x7fff) | (1 << 15) | ((3 - d) << 16) | (ok ? 1 << 20 : 0);
+        to[NP1 + NP3 + 1] = -d * SZ + (rr * NT + qm) * 16 + (ja & 3); // + 4 * rr_a
+    }
+    // ---- the work items that hold pairs of a: strips k (ascending), segments g (ascending); the loads of item n + 1 are in flight
+    //      while item n is summed (one wave: its LDS operations execute in order; the targets of one instruction are distinct)
+    struct Item { double v[NV]; int iu0; unsigned pm; };
+    auto load_item = [&](int n) {
+        Item I;
+        const int k = n / ng, g = g_lo + (n - k * ng), eu = cd.eu0 + k;
+        I.iu0 = cd.bu[k] - i0;                           // >= 0: the strip starts inside the box
+        const int rra = ia - cd.bu[k];
+        const int E0 = M.ints[rp.ev0_of + g], E1 = M.ints[rp.ev0_of + g + 1], ivf = M.ints[Pt.spv + E0] - P;
+        // rows ja and ja - 3 + d share an element of this item: bit d
+        const int dd = lane < 7 ? lane : 0;
+        const int lo = lov_a > s_lov[dd] ? lov_a : s_lov[dd], hi = hiv_a < s_hiv[dd] ? hiv_a : s_hiv[dd];
+        I.pm = (unsigned)__builtin_amdgcn_ballot_w64(lane < 7 && lo <= hi && lo < E1 && hi >= E0);
+        const double* Rja = rec + ((size_t)(rp.item_off + eu * rp.nseg + g) * rec_rows + (ja - ivf)) * SZ;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int mul = v < NP1 ? NT * 16 : (v < NP1 + NP3 ? 3 * NT * 4 : (v == NP1 + NP3 ? 1 : 4));
+            const bool ok = ((tk[v] >> 20) & 1) && ((I.pm >> ((tk[v] >> 16) & 7)) & 1);
+            I.v[v] = ok ? Rja[to[v] + rra * mul] : 0.0;
+        }
+        return I;
+    };
+    auto add_item = [&](const Item& I) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bool ok = ((tk[v] >> 20) & 1) && ((I.pm >> ((tk[v] >> 16) & 7)) & 1);
+            if (ok) acc[(tk[v] & 0x7fff) + I.iu0 * ((tk[v] >> 15) & 1 ? 3 : 1)] += I.v[v];
+        }
+    };
+    if (nit > 0) {
+        Item cur = load_item(0);
+        for (int n = 0; n < nit; ++n) {
+            Item nxt = cur;
+            if (n + 1 < nit) nxt = load_item(n + 1);
+            add_item(cur);
+            cur = nxt;
+        }
+    }
+    __syncthreads();
+    const bool padd = pen_add && M.pen_row[a];
+    gather_write_rows<NBOX, WITHC>(M, a, lane, doK, doC, doH, padd, ptr_c, deg_c, ptr_s, deg_s, s_meta, acc, acc + 12 * NBOX, acc + 9 * NBOX,
+                                   valK, valC0, valC1, valC2, valH);
 }
 
 }  // namespace gf

@@ -447,6 +447,57 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
     if ((flags & GF_ASM_R_BIT) && tid < 3) R[3 * a + tid] = aR[tid] + (padd ? R[3 * a + tid] : 0.0);
 }
 
+// Write phase of the one-wave gathers: the three dof rows of control point a from the box accumulators in LDS (aK [3][NBOX][3],
+// aC [3 f][3 i][NBOX], aH [3][NBOX]); Dirichlet rows / columns, the coupling-only columns and the penalty rows written before
+// (pen_owner_kernel) are handled here.
+constexpr int GATHER_MAXMETA = 320;
+template <int NBOX, bool WITHC>
+__device__ __forceinline__ void gather_write_rows(const DevModel& M, long long a, int lane, bool doK, bool doC, bool doH, bool padd,
+                                                  long long ptr_c, long long deg_c, long long ptr_s, long long deg_s, const unsigned short* s_meta,
+                                                  const double* aK, const double* aC, const double* aH,
+                                                  double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1, double* __restrict__ valC2, double* __restrict__ valH) {
+    constexpr int MAXMETA = GATHER_MAXMETA;
+    if (doK) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const bool zrow = M.zero[3 * a + i] != 0;
+            double* dst = valK + 9 * ptr_c + (long long)i * 3 * deg_c;
+            for (int c = lane; c < 3 * (int)deg_c; c += 64) {
+                const int k = c / 3, j = c - 3 * k;
+                const unsigned meta = k < MAXMETA ? s_meta[k] : M.nb_meta[ptr_c + k];
+                const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
+                double v = 0.0;
+                if (zrow || (meta & (128u << j))) v = ((meta & 1024u) && i == j) ? 1.0 : 0.0;
+                else { if (ks >= 0) v = aK[(i * NBOX + ks) * 3 + j]; if (padd) v += dst[c]; }
+                dst[c] = v;
+            }
+        }
+    }
+    if constexpr (WITHC) if (doC) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const bool zrow = M.zero[3 * a + i] != 0;
+            for (int k = lane; k < (int)deg_c; k += 64) {
+                const unsigned meta = k < MAXMETA ? s_meta[k] : M.nb_meta[ptr_c + k];
+                const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    double* dst = (f == 0 ? valC0 : (f == 1 ? valC1 : valC2)) + 3 * ptr_c + (long long)i * deg_c + k;
+                    double v = 0.0;
+                    if (!zrow) { if (ks >= 0) v = aC[(f * 3 + i) * NBOX + ks]; if (padd) v += *dst; }
+                    *dst = v;
+                }
+            }
+        }
+    }
+    if (doH) {
+        for (int k = lane; k < (int)deg_s; k += 64) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) valH[3 * ptr_s + (long long)i * deg_s + k] = aH[i * NBOX + k];
+        }
+    }
+}
+
 // One-wave gather: ONE wave per control point takes the three dof rows itself (WITHC: 24 row loads in flight per group of
 // four elements, otherwise 12).  The four-wave gather above is bound by the latency chain of a workgroup rather than by
 // bandwidth when few bytes are asked for (Newton pass R + K: 5.7 ms for 42 % of the bytes of the full pass); with one wave
@@ -472,7 +523,7 @@ __global__ __launch_bounds__(64) void kl_gather1_kernel(DevModel M, long long a_
     const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c, ptr_s = M.nb_ptr_s[a], deg_s = M.nb_ptr_s[a + 1] - ptr_s;
     const int lane = threadIdx.x;
     __shared__ double aK[3][NBOX][3], aC[WITHC ? 3 : 1][3][NBOX], aH[3][NBOX], aR[3];
-    constexpr int MAXMETA = 320;
+    constexpr int MAXMETA = GATHER_MAXMETA;
     __shared__ unsigned short s_meta[MAXMETA];
     for (int k = lane; k < (int)deg_c && k < MAXMETA; k += 64) s_meta[k] = M.nb_meta[ptr_c + k];
     for (int k = lane; k < 9 * NBOX; k += 64) { (&aK[0][0][0])[k] = 0.0; if constexpr (WITHC) (&aC[0][0][0])[k] = 0.0; }
@@ -533,45 +584,8 @@ __global__ __launch_bounds__(64) void kl_gather1_kernel(DevModel M, long long a_
     }
     __syncthreads();
     const bool padd = pen_add && M.pen_row[a];
-    if (doK) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const bool zrow = M.zero[3 * a + i] != 0;
-            double* dst = valK + 9 * ptr_c + (long long)i * 3 * deg_c;
-            for (int c = lane; c < 3 * (int)deg_c; c += 64) {
-                const int k = c / 3, j = c - 3 * k;
-                const unsigned meta = k < MAXMETA ? s_meta[k] : M.nb_meta[ptr_c + k];
-                const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
-                double v = 0.0;
-                if (zrow || (meta & (128u << j))) v = ((meta & 1024u) && i == j) ? 1.0 : 0.0;
-                else { if (ks >= 0) v = aK[i][ks][j]; if (padd) v += dst[c]; }
-                dst[c] = v;
-            }
-        }
-    }
-    if constexpr (WITHC) if (doC) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const bool zrow = M.zero[3 * a + i] != 0;
-            for (int k = lane; k < (int)deg_c; k += 64) {
-                const unsigned meta = k < MAXMETA ? s_meta[k] : M.nb_meta[ptr_c + k];
-                const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
-#pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    double* dst = (f == 0 ? valC0 : (f == 1 ? valC1 : valC2)) + 3 * ptr_c + (long long)i * deg_c + k;
-                    double v = 0.0;
-                    if (!zrow) { if (ks >= 0) v = aC[f][i][ks]; if (padd) v += *dst; }
-                    *dst = v;
-                }
-            }
-        }
-    }
-    if (doH) {
-        for (int k = lane; k < (int)deg_s; k += 64) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) valH[3 * ptr_s + (long long)i * deg_s + k] = aH[i][k];
-        }
-    }
+    gather_write_rows<NBOX, WITHC>(M, a, lane, doK, doC, doH, padd, ptr_c, deg_c, ptr_s, deg_s, s_meta, &aK[0][0][0], &aC[0][0][0], &aH[0][0],
+                                   valK, valC0, valC1, valC2, valH);
     if (doR && lane < 3) R[3 * a + lane] = aR[lane] + (padd ? R[3 * a + lane] : 0.0);
 }
 

@@ -16,6 +16,7 @@ constexpr int GF_ASM_R_BIT = 1, GF_ASM_K_BIT = 2, GF_ASM_C_BIT = 4, GF_ASM_H_BIT
 #include "gf_element_mfma4.hpp"
 #include "gf_element_mfma2.hpp"
 #include "gf_element_walk.hpp"
+#include "gf_element_rec.hpp"
 
 using namespace gf;
 
@@ -49,6 +50,8 @@ struct gf_handle {
     bool assembled[5] = {false, false, false, false, false};
     bool walk = false;                                // GF_WALK=1 (p = 2, 3, MFMA path): walk element strips and accumulate straight into the CSR arrays (gf_element_walk.hpp: a quarter of the device memory, half the traffic, currently slower)
     const WalkItem* d_walk_items = nullptr; const RowDesc* d_row_desc = nullptr; const WalkPatch* d_walk_patch = nullptr;
+    bool rec = false;                                 // GF_WALK=2 (p = 2, 3, MFMA path): walking kernel that stores row records + kl_gather_rec_kernel (gf_element_rec.hpp)
+    const WalkItem* d_rec_items = nullptr; const RecPatch* d_rec_patch = nullptr; double* d_rec = nullptr; long long rec_doubles = 0;
     bool two_wave = true;                             // p = 2, 3 full pass: two waves per element, two resident per SIMD (gf_element_mfma2.hpp; GF_TWOWAVE=0: one wave)
     bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
     bool atomic_t = false;                            // GF_ATOMIC_T=1: transposed products of dR/dCP, dR/dh by FP64 atomics (order not fixed) instead of the fixed-order gather
@@ -92,10 +95,12 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         HostModel& H = h->H;
         {
             bool want = false;
-            if (const char* s = getenv("GF_WALK")) want = h->mfma && H.degree <= 3 && std::string(s) == "1";
-            int seg = 12;
+            bool want_rec = false;
+            if (const char* s = getenv("GF_WALK")) { want = h->mfma && H.degree <= 3 && std::string(s) == "1"; want_rec = h->mfma && H.degree <= 3 && std::string(s) == "2"; }
+            int seg = want_rec ? 24 : 12;
             if (const char* s = getenv("GF_WALK_SEG")) seg = std::max(1, atoi(s));
             if (want) { H.build_walk(seg); h->walk = H.walk_ok; }
+            if (want_rec) { H.build_rec(seg); h->rec = true; }
         }
         std::vector<long long> nbs(H.nb_ptr_s.begin(), H.nb_ptr_s.end()), nbc(H.nb_ptr_c.begin(), H.nb_ptr_c.end());
         h->d_cp4 = h->dalloc<double>(4 * H.total_cp); h->d_u = h->dalloc<double>(H.ndof); h->d_h = h->dalloc<double>(H.total_cp); h->d_R = h->dalloc<double>(H.ndof);
@@ -155,16 +160,16 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         M.pen_row = h->upload(pen_row);
         // element-block scratch, chunked over whole patches
         const int P = H.degree, NB = (P + 1) * (P + 1), ND = 3 * NB;
-        const long long blk_doubles = h->walk ? (long long)ND : 2LL * ND * ND + (long long)ND * NB + ND;   // walking kernel: residual entries only
+        const long long blk_doubles = (h->walk || h->rec) ? (long long)ND : 2LL * ND * ND + (long long)ND * NB + ND;   // walking kernels: residual entries only
         double budget_gb = 40.0;
         if (const char* s = getenv("GF_SCRATCH_GB")) budget_gb = atof(s);
-        if (h->walk) budget_gb = 1e9;                     // no element blocks: one chunk
+        if (h->walk || h->rec) budget_gb = 1e9;           // no element blocks: one chunk
         long long max_elems = std::max<long long>(1, (long long)(budget_gb * 1e9 / (blk_doubles * 8.0)));
         {   // GF_OVERLAP=1: element kernel and gather overlapped over GF_CHUNKS chunks of whole patches (measured at C4: no gain,
             // 25.6 vs 25.9 ms -- the element kernel slows down by what the gather hides, profiles/r02_overlap_*; off by default)
             int nch = 8;
             if (const char* s = getenv("GF_CHUNKS")) nch = std::max(1, atoi(s));
-            if (const char* s = getenv("GF_OVERLAP")) h->overlap = std::string(s) == "1" && !h->walk && H.n_owned >= 2 * nch;
+            if (const char* s = getenv("GF_OVERLAP")) h->overlap = std::string(s) == "1" && !h->walk && !h->rec && H.n_owned >= 2 * nch;
             if (h->overlap) {
                 long long tot = 0;
                 for (int s = 0; s < H.n_owned; ++s) tot += (long long)H.patches[s].nelu * H.patches[s].nelv;
@@ -188,6 +193,12 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             scratch_doubles = std::max<long long>(scratch_doubles, H.nelem * (long long)(11 * NB + 2));   // the functionals' element blocks (FunCfg::STRIDE) share the scratch
             h->d_walk_items = h->upload(H.walk_items); h->d_row_desc = h->upload(H.row_desc);
             h->d_walk_patch = h->upload(H.walk_patch);
+        }
+        if (h->rec) {
+            scratch_doubles = std::max<long long>(scratch_doubles, H.nelem * (long long)(11 * NB + 2));
+            h->d_rec_items = h->upload(H.rec_items); h->d_rec_patch = h->upload(H.rec_patch);
+            h->rec_doubles = (long long)H.rec_items.size() * H.rec_rows * RecCfg<true>::SZ;
+            h->d_rec = h->dalloc<double>((size_t)h->rec_doubles);
         }
         h->d_blk = h->dalloc<double>((size_t)scratch_doubles);
         h->overlap = h->overlap && h->chunks.size() >= 2;
@@ -333,6 +344,34 @@ template <int P> static void run_assemble_walk(gf_handle* h, int flags) {
     HIPCHK(hipGetLastError());
 }
 
+// Row-record path (gf_element_rec.hpp): penalty rows first (written), one launch of the walking kernel over all work items, then the
+// record gather adds the shell part per control point.
+template <int P> static void run_assemble_rec(gf_handle* h, int flags) {
+    constexpr int PW = P == 2 ? 2 : 3;
+    const HostModel& H = h->H;
+    const int pen = run_penalty<P, false>(h, flags);
+    const RecOut O{h->d_rec, h->d_blk, H.rec_rows};
+    const int slot = h->ev_n % 64, n = (int)H.rec_items.size();
+    HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
+    if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_rec_kernel<PW, true>), dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_rec_items, flags, O);
+    else hipLaunchKernelGGL((kl_element_rec_kernel<PW, false>), dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_rec_items, flags, O);
+    HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
+    h->ev_n++;
+    const Chunk& c = h->chunks[0];
+    const long long ne = c.e1 - c.e0, na = c.a1 - c.a0;
+    if (flags & ~GF_ASM_R) {
+        if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_gather_rec_kernel<PW, true>), dim3((unsigned)(((na + 7) / 8) * 8)), dim3(64), 0, h->stream, h->M, c.a0, c.a1, flags, h->d_rec, H.rec_rows, h->d_rec_patch,
+                                                     h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], pen);
+        else hipLaunchKernelGGL((kl_gather_rec_kernel<PW, false>), dim3((unsigned)(((na + 7) / 8) * 8)), dim3(64), 0, h->stream, h->M, c.a0, c.a1, flags, h->d_rec, H.rec_rows, h->d_rec_patch,
+                                h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], pen);
+    }
+    if (flags & GF_ASM_R) {
+        hipLaunchKernelGGL(kl_rgather_kernel<P>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, h->d_blk, h->d_R, pen, 3 * (P + 1) * (P + 1), 0);
+        finish_residual(h);
+    }
+    HIPCHK(hipGetLastError());
+}
+
 template <int P> static void run_assemble(gf_handle* h, int flags) {
     using Cfg = ElemCfg<P>;
     const HostModel& H = h->H;
@@ -341,6 +380,7 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
     // and dropped: next to the element kernel they cost it LDS occupancy (17.7 -> 22.8 ms), next to the gather both slow down
     // by what the overlap saves (profiles/r01_v8_*).
     if ((P == 2 || P == 3) && h->walk) { run_assemble_walk<P>(h, flags); return; }
+    if ((P == 2 || P == 3) && h->rec) { run_assemble_rec<P>(h, flags); return; }
     const int pen = run_penalty<P, false>(h, flags);
     for (size_t ci = 0; ci < h->chunks.size(); ++ci) {
         const Chunk& c = h->chunks[ci];
@@ -577,7 +617,7 @@ double gf_kernel_ms(gf_handle* h, int* n_launches) {
 
 void* gf_stream(gf_handle* h) { return h ? (void*)h->stream : nullptr; }
 
-int gf_assembly_path(const gf_handle* h) { return !h ? -1 : (h->walk ? 2 : (h->mfma ? 0 : 3)); }
+int gf_assembly_path(const gf_handle* h) { return !h ? -1 : (h->walk ? 2 : (h->rec ? 4 : (h->mfma ? 0 : 3))); }
 
 int gf_get_functional_gradient(gf_handle* h, int field, double* out, int64_t n) {
     if (!h || !out) return fail("gf_get_functional_gradient: null argument");

@@ -51,6 +51,9 @@ struct WalkPatch { long long kbase, cbase, hbase; unsigned kbytes, cbytes, hbyte
 // one work item of the walking kernel: the elements ev0 .. ev0 + nel - 1 of the strip eu of a patch; items of one class
 // (cls = (eu mod (p+1)) * 2 + (seg & 1)) share no control-point pair, classes are launched in ascending order
 struct WalkItem { int patch, eu, ev0, nel, seg, cls, iu0, pad; };
+// row-record path (gf_element_rec.hpp), per patch: first work item (items in the order strip-major, segment), segments per strip, and
+// (offsets into ints[]) the segment of every element row / the first element row of every segment (nseg + 1 entries)
+struct RecPatch { int item_off, nseg, seg_of, ev0_of; };
 
 struct PenRowItem { int a, code, lo, hi; };           // code = iface*2 + s
 // one (owned control point, mortar vertex) visit of the penalty row kernel: everything the kernel needs to address the
@@ -126,6 +129,8 @@ struct HostModel {
     std::vector<WalkItem> walk_items; std::vector<int> walk_cls_off;   // items sorted by class; walk_cls_off[c] .. [c + 1]
     bool walk_ok = false;               // the walking kernel's addressing assumptions hold for this model
     void build_walk(int seg_len);
+    std::vector<WalkItem> rec_items; std::vector<RecPatch> rec_patch; int rec_rows = 0;   // row-record path (GF_WALK=2)
+    void build_rec(int seg_len);
     std::vector<int> cp_patch;          // [total_cp]
     std::vector<double> weights;
     std::vector<unsigned char> zero;    // [ndof]
@@ -466,6 +471,30 @@ inline void HostModel::build_walk(int seg_len) {
     walk_items = items;
     for (const WalkItem& it : items) walk_cls_off[it.cls + 1]++;
     for (size_t c = 0; c + 1 < walk_cls_off.size(); ++c) walk_cls_off[c + 1] += walk_cls_off[c];
+}
+
+// Tables of the row-record path: work items in natural order (patch, strip, segment) -- nothing depends on launch order --, per
+// patch the segment of every element row, and the number of record rows an item can touch.  Called before the tables are uploaded.
+inline void HostModel::build_rec(int seg_len) {
+    if (degree < 2 || degree > 3) throw std::runtime_error("build_rec: p = 2, 3 only");
+    const int P1 = degree + 1;
+    rec_items.clear(); rec_patch.assign(np, RecPatch{0, 0, 0, 0}); rec_rows = 0;
+    for (int s = 0; s < n_owned; ++s) {
+        const PatchDev& P = patches[s];
+        int nseg = std::max(1, (P.nelv + seg_len / 2) / std::max(seg_len, P1));
+        while (nseg > 1 && P.nelv / nseg < P1) --nseg;                 // every segment holds at least p + 1 elements: a pair lies in at most two
+        RecPatch& R = rec_patch[s];
+        R.item_off = (int)rec_items.size(); R.nseg = nseg;
+        R.seg_of = (int)ints.size(); ints.resize(ints.size() + P.nelv);
+        R.ev0_of = (int)ints.size(); ints.resize(ints.size() + nseg + 1);
+        for (int g = 0; g <= nseg; ++g) ints[R.ev0_of + g] = int(int64_t(g) * P.nelv / nseg);
+        for (int g = 0; g < nseg; ++g) for (int ev = ints[R.ev0_of + g]; ev < ints[R.ev0_of + g + 1]; ++ev) ints[R.seg_of + ev] = g;
+        for (int eu = 0; eu < P.nelu; ++eu) for (int g = 0; g < nseg; ++g) {
+            const int e0 = ints[R.ev0_of + g], e1 = ints[R.ev0_of + g + 1];
+            rec_items.push_back({s, eu, e0, e1 - e0, g, 0, ints[P.spu + eu] - P.p, 0});
+            rec_rows = std::max(rec_rows, (ints[P.spv + e1 - 1] + 1) - (ints[P.spv + e0] - P.q));     // rows first .. last of the item's windows
+        }
+    }
 }
 
 }  // namespace gf

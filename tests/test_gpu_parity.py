@@ -120,6 +120,44 @@ def test_walking_kernel_segment_lengths_and_block_path(oracle_lib, monkeypatch, 
             assert _rel(x, y) < 1e-12
 
 
+@pytest.mark.parametrize("seg", ["4", "7", "1000"])
+def test_row_record_path_segment_lengths_and_block_path(oracle_lib, monkeypatch, seg):
+    """GF_WALK=2: the walking element kernel that stores row records (gf_element_rec.hpp: a control-point pair is stored once per
+    strip and segment, when its lower row leaves the window) + the record gather, with work items of 4 / 7 elements / whole strips
+    (a pair then lies in two / one segment), against the oracle and the element-block + gather path, for every flag subset;
+    bitwise reproducible run to run (fixed strip and segment order per entry)."""
+    from goldfish_amd import _lib
+    from oracle.oracle_py import Oracle
+    for case in ("tbeam2_p2", "shell3x2_p3", "C3_wing16_refdata", "slr9_nurbs_p3_projected_load"):
+        A, h, u = _state(CASES[case](), seed=11)
+        O = Oracle(A, thickness=h, u=u)
+        vals, Ro = O.assemble(), O.residual()
+        out = {}
+        for walk in ("2", "0"):
+            monkeypatch.setenv("GF_WALK", walk)
+            monkeypatch.setenv("GF_WALK_SEG", seg)
+            D = _lib.DeviceModel(A)
+            assert D.assembly_path == (4 if walk == "2" else 0)
+            D.set_thickness(h)
+            D.set_u(u)
+            D.assemble(_lib.ASM_ALL)
+            out[walk] = [D.residual().copy()] + [D.values(w).copy() for w in range(5)]
+            assert _rel(out[walk][0], Ro) < RTOL
+            for w in range(5):
+                assert _rel(out[walk][1 + w], vals[w]) < RTOL, (case, walk, w)
+            D.assemble(_lib.ASM_ALL)
+            assert np.array_equal(out[walk][0], D.residual())
+            for w in range(5):
+                assert np.array_equal(out[walk][1 + w], D.values(w)), (case, walk, w)
+            for flags, which in ((_lib.ASM_R | _lib.ASM_K, (0,)), (_lib.ASM_DRDCP | _lib.ASM_DRDH, (1, 2, 3, 4)), (_lib.ASM_K | _lib.ASM_DRDH, (0, 4))):
+                D.assemble(flags)
+                for w in which:
+                    assert _rel(D.values(w), vals[w]) < RTOL, (case, walk, flags, w)
+            D.close()
+        for x, y in zip(out["2"], out["0"]):
+            assert _rel(x, y) < 1e-12
+
+
 def test_valu_element_kernel_still_matches(oracle_lib, monkeypatch):
     """The FP64-VALU element kernel (GF_ELEMENT=valu) stays a supported path for every degree."""
     from goldfish_amd import _lib
