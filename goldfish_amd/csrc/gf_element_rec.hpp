@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
 // written and never read.
 template <int P, bool WITHC>
 __global__ __launch_bounds__(64) void kl_gather_rec_kernel(DevModel M, long long a_first, long long a_end, int flags, const double* __restrict__ rec, int rec_rows,
-                                                           const RecPatch* __restrict__ rpatch, double* __restrict__ valK, double* __restrict__ valC0,
+                                                           const RecCp* __restrict__ reccp, double* __restrict__ valK, double* __restrict__ valC0,
                                                            double* __restrict__ valC1, double* __restrict__ valC2, double* __restrict__ valH, int pen_add) {
     using RC = RecCfg<WITHC>;
     constexpr int P1 = P + 1, WB = 2 * P + 1, NBOX = WB * WB, NT = RC::NT, SZ = RC::SZ, A2 = RC::A2;
@@ -385,28 +385,23 @@ __global__ __launch_bounds__(64) void kl_gather_rec_kernel(DevModel M, long long
     const int lane = threadIdx.x;
     __shared__ double acc[21 * NBOX];                   // aK [3][NBOX][3] | aH [3][NBOX] | aC [3 f][3 i][NBOX]
     __shared__ unsigned short s_meta[GATHER_MAXMETA];
-    __shared__ int s_lov[8], s_hiv[8], s_tb[18], s_ts[18], s_mb[3];
-    const PatchDev& Pt = M.patches[cd.patch];
-    const RecPatch rp = rpatch[cd.patch];
-    for (int k = lane; k < (int)deg_c && k < GATHER_MAXMETA; k += 64) s_meta[k] = M.nb_meta[ptr_c + k];
+    const RecCp rc = reccp[a];                          // the work items of a (wave-uniform: scalar loads)
+    const bool pen_row_a = M.pen_row[a] != 0;           // requested now, used by the write phase
+    // One wave per workgroup: LDS operations execute in order, no barrier anywhere; nothing below waits for memory before the
+    // record loads are issued (the neighbour metadata of the write phase is requested behind them).
     for (int k = lane; k < 21 * NBOX; k += 64) acc[k] = 0.0;
-    if (lane < 7) {                                     // element rows of the control-point rows ja - 3 .. ja + 3
-        const int jb = ja - 3 + lane; const bool in = jb >= 0 && jb < Pt.nv;
-        s_lov[lane] = in ? M.ints[Pt.c2v + 2 * jb] : (1 << 30); s_hiv[lane] = in ? M.ints[Pt.c2v + 2 * jb + 1] : -1;
-    }
-    if (lane < 18) {                                    // accumulator address of tile q: base + slot * stride
-        constexpr int QI[6] = {0, 0, 0, 1, 1, 2}, QJ[6] = {0, 1, 2, 1, 2, 2};
-        int qi = 0, qj = 0;
-        for (int q = 0; q < 6; ++q) if (q == lane) { qi = QI[q]; qj = QJ[q]; }
-        if (lane < 6) { s_tb[lane] = qi * NBOX * 3 + qj; s_ts[lane] = 3; }
-        else if (lane < 9) { s_tb[lane] = 9 * NBOX + (lane - 6) * NBOX; s_ts[lane] = 1; }
-        else { const int i = (lane - 9) / 3, f = (lane - 9) % 3; s_tb[lane] = 12 * NBOX + (f * 3 + i) * NBOX; s_ts[lane] = 1; }
-        if (lane == 1 || lane == 2 || lane == 4) s_mb[lane == 4 ? 2 : lane - 1] = qj * NBOX * 3 + qi;       // mirrored entry (i > j) of the tiles (0,1), (0,2), (1,2)
-    }
-    __syncthreads();
+    // accumulator address of tile q: base + box slot * stride;  mirrored entry (i > j) of the tiles (0,1), (0,2), (1,2)
+    auto tile_base = [&](int q) {
+        const int qi = q < 3 ? 0 : (q < 5 ? 1 : 2), qj = q < 3 ? q : (q < 5 ? q - 2 : 2);
+        return q < 6 ? qi * NBOX * 3 + qj : (q < 9 ? 9 * NBOX + (q - 6) * NBOX : 12 * NBOX + (((q - 9) % 3) * 3 + (q - 9) / 3) * NBOX);
+    };
+    auto mirror_base = [&](int m) { const int qi = m == 2 ? 1 : 0, qj = m == 0 ? 1 : 2; return qj * NBOX * 3 + qi; };
     const bool doC = WITHC && (flags & GF_ASM_C_BIT) != 0, doK = (flags & GF_ASM_K_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
-    const int lov_a = s_lov[3], hiv_a = s_hiv[3];
-    const int g_lo = M.ints[rp.seg_of + lov_a], g_hi = M.ints[rp.seg_of + hiv_a], ng = g_hi - g_lo + 1, nit = cd.neu * ng;
+#ifdef GF_REC_NOITEMS
+    const int nit = 0;
+#else
+    const int nit = rc.nit;
+#endif
     constexpr int N1 = NT * 16, NP1 = (N1 + 63) / 64, N3 = 3 * NT * 4, NP3 = (N3 + 63) / 64, NV = NP1 + NP3 + 2;
     // ---- per-lane task table (independent of strip and segment): accumulator address for iu0 = i0, its stride in iu0 (1 or 3), the
     //      row offset d whose presence decides, the offset in the record (relative to the row record of ja) and its stride in rr_a.
@@ -417,7 +412,7 @@ __global__ __launch_bounds__(64) void kl_gather_rec_kernel(DevModel M, long long
         const int t = lane + 64 * ps, q = (t >> 4) < NT ? (t >> 4) : 0, c = t & 15, jub = c >> 2, dv = (c - ja) & 3;
         const bool en = q < 6 ? doK : (q < 9 ? doH : doC);
         const bool ok = t < N1 && en && jub < P1 && dv < P1;
-        tk[ps] = ((s_tb[q] + (jub + (ja + dv - j0) * wbox) * s_ts[q]) & 0x7fff) | (s_ts[q] == 3 ? 1 << 15 : 0) | ((3 + dv) << 16) | (ok ? 1 << 20 : 0);
+        tk[ps] = ((tile_base(q) + (jub + (ja + dv - j0) * wbox) * (q < 6 ? 3 : 1)) & 0x7fff) | (q < 6 ? 1 << 15 : 0) | ((3 + dv) << 16) | (ok ? 1 << 20 : 0);
         to[ps] = t;                                                   // + rr_a * NT * 16
     }
 #pragma unroll
@@ -425,19 +420,19 @@ __global__ __launch_bounds__(64) void kl_gather_rec_kernel(DevModel M, long long
         const int t = lane + 64 * ps, rk = t / (NT * 4) < 3 ? t / (NT * 4) : 0, r = t - (t / (NT * 4)) * NT * 4, q = r >> 2, jub = r & 3;
         const bool en = q < 6 ? doK : (q < 9 ? doH : doC);
         const bool ok = t < N3 && en && jub < P1 && rk + 1 < P1;
-        tk[NP1 + ps] = ((s_tb[q] + (jub + (ja - 1 - rk - j0) * wbox) * s_ts[q]) & 0x7fff) | (s_ts[q] == 3 ? 1 << 15 : 0) | ((2 - rk) << 16) | (ok ? 1 << 20 : 0);
+        tk[NP1 + ps] = ((tile_base(q) + (jub + (ja - 1 - rk - j0) * wbox) * (q < 6 ? 3 : 1)) & 0x7fff) | (q < 6 ? 1 << 15 : 0) | ((2 - rk) << 16) | (ok ? 1 << 20 : 0);
         to[NP1 + ps] = (-1 - rk) * SZ + A2 + rk * NT * 4 + r;          // + rr_a * 3 * NT * 4
     }
     {   // G2: 3 tiles x 3 rk x 4 rr (a as B, rows above)
         const int m = lane / 12 < 3 ? lane / 12 : 0, r = lane - 12 * (lane / 12), rk = r >> 2, rr = r & 3, qm = m == 2 ? 4 : m + 1;
         const bool ok = lane < 36 && doK && rr < P1 && rk + 1 < P1;
-        tk[NP1 + NP3] = ((s_mb[m] + (rr + (ja + 1 + rk - j0) * wbox) * 3) & 0x7fff) | (1 << 15) | ((4 + rk) << 16) | (ok ? 1 << 20 : 0);
+        tk[NP1 + NP3] = ((mirror_base(m) + (rr + (ja + 1 + rk - j0) * wbox) * 3) & 0x7fff) | (1 << 15) | ((4 + rk) << 16) | (ok ? 1 << 20 : 0);
         to[NP1 + NP3] = A2 + ((rr * 3 + rk) * NT + qm) * 4;           // + rr_a
     }
     {   // G4: 3 tiles x 4 d x 4 rr (a as B, own row and rows below)
         const int m = (lane >> 4) < 3 ? (lane >> 4) : 0, r = lane & 15, d = r >> 2, rr = r & 3, qm = m == 2 ? 4 : m + 1;
         const bool ok = lane < 48 && doK && rr < P1 && d < P1;
-        tk[NP1 + NP3 + 1] = ((s_mb[m] + (rr + (ja - d - j0) * wbox) * 3) & 0x7fff) | (1 << 15) | ((3 - d) << 16) | (ok ? 1 << 20 : 0);
+        tk[NP1 + NP3 + 1] = ((mirror_base(m) + (rr + (ja - d - j0) * wbox) * 3) & 0x7fff) | (1 << 15) | ((3 - d) << 16) | (ok ? 1 << 20 : 0);
         to[NP1 + NP3 + 1] = -d * SZ + (rr * NT + qm) * 16 + (ja & 3); // + 4 * rr_a
     }
     // ---- the work items that hold pairs of a: strips k (ascending), segments g (ascending); the loads of item n + 1 are in flight
@@ -445,15 +440,12 @@ __global__ __launch_bounds__(64) void kl_gather_rec_kernel(DevModel M, long long
     struct Item { double v[NV]; int iu0; unsigned pm; };
     auto load_item = [&](int n) {
         Item I;
-        const int k = n / ng, g = g_lo + (n - k * ng), eu = cd.eu0 + k;
-        I.iu0 = cd.bu[k] - i0;                           // >= 0: the strip starts inside the box
-        const int rra = ia - cd.bu[k];
-        const int E0 = M.ints[rp.ev0_of + g], E1 = M.ints[rp.ev0_of + g + 1], ivf = M.ints[Pt.spv + E0] - P;
-        // rows ja and ja - 3 + d share an element of this item: bit d
-        const int dd = lane < 7 ? lane : 0;
-        const int lo = lov_a > s_lov[dd] ? lov_a : s_lov[dd], hi = hiv_a < s_hiv[dd] ? hiv_a : s_hiv[dd];
-        I.pm = (unsigned)__builtin_amdgcn_ballot_w64(lane < 7 && lo <= hi && lo < E1 && hi >= E0);
-        const double* Rja = rec + ((size_t)(rp.item_off + eu * rp.nseg + g) * rec_rows + (ja - ivf)) * SZ;
+        int row = rc.it[0].row; unsigned info = rc.it[0].info;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) if (q == n) { row = rc.it[q].row; info = rc.it[q].info; }       // register-resident table: no dynamic indexing
+        I.iu0 = int(info & 255u); I.pm = info >> 16;
+        const int rra = int((info >> 8) & 255u);
+        const double* Rja = rec + (size_t)row * SZ;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int mul = v < NP1 ? NT * 16 : (v < NP1 + NP3 ? 3 * NT * 4 : (v == NP1 + NP3 ? 1 : 4));
@@ -466,21 +458,37 @@ __global__ __launch_bounds__(64) void kl_gather_rec_kernel(DevModel M, long long
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const bool ok = ((tk[v] >> 20) & 1) && ((I.pm >> ((tk[v] >> 16) & 7)) & 1);
-            if (ok) acc[(tk[v] & 0x7fff) + I.iu0 * ((tk[v] >> 15) & 1 ? 3 : 1)] += I.v[v];
+            // ds_add_f64: one LDS instruction, no returned value to wait for (distinct targets within an instruction, program order between them)
+            if (ok) (void)__hip_atomic_fetch_add(&acc[(tk[v] & 0x7fff) + I.iu0 * ((tk[v] >> 15) & 1 ? 3 : 1)], I.v[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
-    if (nit > 0) {
-        Item cur = load_item(0);
-        for (int n = 0; n < nit; ++n) {
-            Item nxt = cur;
-            if (n + 1 < nit) nxt = load_item(n + 1);
-            add_item(cur);
-            cur = nxt;
+#ifndef GF_REC_BATCH
+#define GF_REC_BATCH 2
+#endif
+    constexpr int NBT = GF_REC_BATCH;                   // work items whose loads are in flight together
+    Item B[NBT];
+#pragma unroll
+    for (int q = 0; q < NBT; ++q) if (q < nit) B[q] = load_item(q);
+    // neighbour metadata of the write phase: requested behind the first record loads, parked in LDS before the rows are written
+    constexpr int NM = (GATHER_MAXMETA + 63) / 64;
+    unsigned short mt[NM];
+#pragma unroll
+    for (int q = 0; q < NM; ++q) { const int k = lane + 64 * q; mt[q] = k < (int)deg_c ? M.nb_meta[ptr_c + k] : (unsigned short)0; }
+    for (int n0 = 0; n0 < nit; n0 += NBT) {
+#pragma unroll
+        for (int q = 0; q < NBT; ++q) {
+            if (n0 + q < nit) add_item(B[q]);
+            if (n0 + NBT + q < nit) B[q] = load_item(n0 + NBT + q);
         }
     }
-    __syncthreads();
-    const bool padd = pen_add && M.pen_row[a];
-    gather_write_rows<NBOX, WITHC>(M, a, lane, doK, doC, doH, padd, ptr_c, deg_c, ptr_s, deg_s, s_meta, acc, acc + 12 * NBOX, acc + 9 * NBOX,
+#pragma unroll
+    for (int q = 0; q < NM; ++q) { const int k = lane + 64 * q; if (k < GATHER_MAXMETA) s_meta[k] = mt[q]; }
+    wave_lds_sync();
+    const bool padd = pen_add && pen_row_a;
+#ifdef GF_REC_NOWRITE
+    if (acc[lane] == 123.456)
+#endif
+    gather_write_rows<NBOX, WITHC>(M, a, lane, doK, doC, doH, padd, (unsigned)rc.flags, ptr_c, deg_c, ptr_s, deg_s, s_meta, acc, acc + 12 * NBOX, acc + 9 * NBOX,
                                    valK, valC0, valC1, valC2, valH);
 }
 

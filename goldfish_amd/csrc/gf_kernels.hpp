@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
             double* dst = valK + 9 * ptr_c + (long long)i * 3 * deg_c;
             for (int c = lane; c < 3 * (int)deg_c; c += 64) {
                 const int k = c / 3, j = c - 3 * k;
-                const unsigned meta = k < MAXMETA ? s_meta[k] : M.nb_meta[ptr_c + k];
+                const unsigned meta = s_meta[k];
                 const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
                 double v = 0.0;
                 if (zrow || (meta & (128u << j))) v = ((meta & 1024u) && i == j) ? 1.0 : 0.0;
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
             }
         }
         for (int k = lane; k < (int)deg_c; k += 64) {
-            const unsigned meta = k < MAXMETA ? s_meta[k] : M.nb_meta[ptr_c + k];
+            const unsigned meta = s_meta[k];
             const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
             if (flags & GF_ASM_C_BIT) {
 #pragma unroll
@@ -450,9 +450,12 @@ __global__ __launch_bounds__(256) void kl_gather_kernel(DevModel M, long long a_
 // Write phase of the one-wave gathers: the three dof rows of control point a from the box accumulators in LDS (aK [3][NBOX][3],
 // aC [3 f][3 i][NBOX], aH [3][NBOX]); Dirichlet rows / columns, the coupling-only columns and the penalty rows written before
 // (pen_owner_kernel) are handled here.
+// Every neighbour list fits the LDS copy of its metadata (gf_create checks deg <= GATHER_MAXMETA).  A fallback to the global array
+// (k < MAXMETA ? s_meta[k] : M.nb_meta[..]) compiles to a FLAT load: it counts in vmcnt, and vmcnt is in order -- every iteration of
+// the write loops then waits for the previous iteration's store to complete (the write phase ran at 2 TB/s because of it).
 constexpr int GATHER_MAXMETA = 320;
 template <int NBOX, bool WITHC>
-__device__ __forceinline__ void gather_write_rows(const DevModel& M, long long a, int lane, bool doK, bool doC, bool doH, bool padd,
+__device__ __forceinline__ void gather_write_rows(const DevModel& M, long long a, int lane, bool doK, bool doC, bool doH, bool padd, unsigned zmask,
                                                   long long ptr_c, long long deg_c, long long ptr_s, long long deg_s, const unsigned short* s_meta,
                                                   const double* aK, const double* aC, const double* aH,
                                                   double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1, double* __restrict__ valC2, double* __restrict__ valH) {
@@ -460,11 +463,11 @@ __device__ __forceinline__ void gather_write_rows(const DevModel& M, long long a
     if (doK) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const bool zrow = M.zero[3 * a + i] != 0;
+            const bool zrow = (zmask >> i) & 1u;
             double* dst = valK + 9 * ptr_c + (long long)i * 3 * deg_c;
             for (int c = lane; c < 3 * (int)deg_c; c += 64) {
                 const int k = c / 3, j = c - 3 * k;
-                const unsigned meta = k < MAXMETA ? s_meta[k] : M.nb_meta[ptr_c + k];
+                const unsigned meta = s_meta[k];
                 const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
                 double v = 0.0;
                 if (zrow || (meta & (128u << j))) v = ((meta & 1024u) && i == j) ? 1.0 : 0.0;
@@ -476,9 +479,9 @@ __device__ __forceinline__ void gather_write_rows(const DevModel& M, long long a
     if constexpr (WITHC) if (doC) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const bool zrow = M.zero[3 * a + i] != 0;
+            const bool zrow = (zmask >> i) & 1u;
             for (int k = lane; k < (int)deg_c; k += 64) {
-                const unsigned meta = k < MAXMETA ? s_meta[k] : M.nb_meta[ptr_c + k];
+                const unsigned meta = s_meta[k];
                 const int ks = (meta & 127) == 127 ? -1 : int(meta & 127);
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {
@@ -522,6 +525,8 @@ __global__ __launch_bounds__(64) void kl_gather1_kernel(DevModel M, long long a_
     const int ia = cd.ia, ja = cd.ja, i0 = cd.i0, j0 = cd.j0, wbox = cd.i1 - cd.i0 + 1;
     const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c, ptr_s = M.nb_ptr_s[a], deg_s = M.nb_ptr_s[a + 1] - ptr_s;
     const int lane = threadIdx.x;
+    const unsigned zmask = (M.zero[3 * a] ? 1u : 0u) | (M.zero[3 * a + 1] ? 2u : 0u) | (M.zero[3 * a + 2] ? 4u : 0u);   // requested now, used by the write phase
+    const bool pen_row_a = M.pen_row[a] != 0;
     __shared__ double aK[3][NBOX][3], aC[WITHC ? 3 : 1][3][NBOX], aH[3][NBOX], aR[3];
     constexpr int MAXMETA = GATHER_MAXMETA;
     __shared__ unsigned short s_meta[MAXMETA];
@@ -583,8 +588,8 @@ __global__ __launch_bounds__(64) void kl_gather1_kernel(DevModel M, long long a_
         }
     }
     __syncthreads();
-    const bool padd = pen_add && M.pen_row[a];
-    gather_write_rows<NBOX, WITHC>(M, a, lane, doK, doC, doH, padd, ptr_c, deg_c, ptr_s, deg_s, s_meta, &aK[0][0][0], &aC[0][0][0], &aH[0][0],
+    const bool padd = pen_add && pen_row_a;
+    gather_write_rows<NBOX, WITHC>(M, a, lane, doK, doC, doH, padd, zmask, ptr_c, deg_c, ptr_s, deg_s, s_meta, &aK[0][0][0], &aC[0][0][0], &aH[0][0],
                                    valK, valC0, valC1, valC2, valH);
     if (doR && lane < 3) R[3 * a + lane] = aR[lane] + (padd ? R[3 * a + lane] : 0.0);
 }

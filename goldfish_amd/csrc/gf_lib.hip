@@ -51,7 +51,7 @@ struct gf_handle {
     bool walk = false;                                // GF_WALK=1 (p = 2, 3, MFMA path): walk element strips and accumulate straight into the CSR arrays (gf_element_walk.hpp: a quarter of the device memory, half the traffic, currently slower)
     const WalkItem* d_walk_items = nullptr; const RowDesc* d_row_desc = nullptr; const WalkPatch* d_walk_patch = nullptr;
     bool rec = false;                                 // GF_WALK=2 (p = 2, 3, MFMA path): walking kernel that stores row records + kl_gather_rec_kernel (gf_element_rec.hpp)
-    const WalkItem* d_rec_items = nullptr; const RecPatch* d_rec_patch = nullptr; double* d_rec = nullptr; long long rec_doubles = 0;
+    const WalkItem* d_rec_items = nullptr; const RecCp* d_rec_cp = nullptr; double* d_rec = nullptr; long long rec_doubles = 0;
     bool two_wave = true;                             // p = 2, 3 full pass: two waves per element, two resident per SIMD (gf_element_mfma2.hpp; GF_TWOWAVE=0: one wave)
     bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
     bool atomic_t = false;                            // GF_ATOMIC_T=1: transposed products of dR/dCP, dR/dh by FP64 atomics (order not fixed) instead of the fixed-order gather
@@ -158,6 +158,8 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
                     throw std::runtime_error("gf_create: a control point couples to more than " + std::to_string(PEN_MAXDEG) + " neighbours (PEN_MAXDEG)");
         }
         M.pen_row = h->upload(pen_row);
+        for (long long a = 0; a < H.total_cp; ++a)
+            if (H.nb_ptr_c[a + 1] - H.nb_ptr_c[a] > GATHER_MAXMETA) throw std::runtime_error("gf_create: a control point has more than " + std::to_string(GATHER_MAXMETA) + " neighbours (GATHER_MAXMETA)");
         // element-block scratch, chunked over whole patches
         const int P = H.degree, NB = (P + 1) * (P + 1), ND = 3 * NB;
         const long long blk_doubles = (h->walk || h->rec) ? (long long)ND : 2LL * ND * ND + (long long)ND * NB + ND;   // walking kernels: residual entries only
@@ -196,7 +198,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         }
         if (h->rec) {
             scratch_doubles = std::max<long long>(scratch_doubles, H.nelem * (long long)(11 * NB + 2));
-            h->d_rec_items = h->upload(H.rec_items); h->d_rec_patch = h->upload(H.rec_patch);
+            h->d_rec_items = h->upload(H.rec_items); h->d_rec_cp = h->upload(H.rec_cp);
             h->rec_doubles = (long long)H.rec_items.size() * H.rec_rows * RecCfg<true>::SZ;
             h->d_rec = h->dalloc<double>((size_t)h->rec_doubles);
         }
@@ -360,9 +362,9 @@ template <int P> static void run_assemble_rec(gf_handle* h, int flags) {
     const Chunk& c = h->chunks[0];
     const long long ne = c.e1 - c.e0, na = c.a1 - c.a0;
     if (flags & ~GF_ASM_R) {
-        if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_gather_rec_kernel<PW, true>), dim3((unsigned)(((na + 7) / 8) * 8)), dim3(64), 0, h->stream, h->M, c.a0, c.a1, flags, h->d_rec, H.rec_rows, h->d_rec_patch,
+        if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_gather_rec_kernel<PW, true>), dim3((unsigned)(((na + 7) / 8) * 8)), dim3(64), 0, h->stream, h->M, c.a0, c.a1, flags, h->d_rec, H.rec_rows, h->d_rec_cp,
                                                      h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], pen);
-        else hipLaunchKernelGGL((kl_gather_rec_kernel<PW, false>), dim3((unsigned)(((na + 7) / 8) * 8)), dim3(64), 0, h->stream, h->M, c.a0, c.a1, flags, h->d_rec, H.rec_rows, h->d_rec_patch,
+        else hipLaunchKernelGGL((kl_gather_rec_kernel<PW, false>), dim3((unsigned)(((na + 7) / 8) * 8)), dim3(64), 0, h->stream, h->M, c.a0, c.a1, flags, h->d_rec, H.rec_rows, h->d_rec_cp,
                                 h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], pen);
     }
     if (flags & GF_ASM_R) {

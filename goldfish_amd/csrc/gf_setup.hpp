@@ -54,6 +54,11 @@ struct WalkItem { int patch, eu, ev0, nel, seg, cls, iu0, pad; };
 // row-record path (gf_element_rec.hpp), per patch: first work item (items in the order strip-major, segment), segments per strip, and
 // (offsets into ints[]) the segment of every element row / the first element row of every segment (nseg + 1 entries)
 struct RecPatch { int item_off, nseg, seg_of, ev0_of; };
+// per control point: the work items that hold pairs of it, in summation order (strips ascending, segments ascending) -- one load
+// instead of the chain cp_desc -> c2v -> segment tables -> span table.  row = item * rec_rows + (ja - first row of the item): the
+// row record of ja in that item; info = (iu0 - i0) | (ia - iu0) << 8 | pm << 16, pm bit d: the rows ja and ja - 3 + d share an element
+// of the item (only then the pair (ja, ja - 3 + d) is present in its records)
+struct RecCp { int nit, flags; struct { int row; unsigned info; } it[8]; };   // flags: bits 0-2 Dirichlet dofs of the control point
 
 struct PenRowItem { int a, code, lo, hi; };           // code = iface*2 + s
 // one (owned control point, mortar vertex) visit of the penalty row kernel: everything the kernel needs to address the
@@ -129,7 +134,7 @@ struct HostModel {
     std::vector<WalkItem> walk_items; std::vector<int> walk_cls_off;   // items sorted by class; walk_cls_off[c] .. [c + 1]
     bool walk_ok = false;               // the walking kernel's addressing assumptions hold for this model
     void build_walk(int seg_len);
-    std::vector<WalkItem> rec_items; std::vector<RecPatch> rec_patch; int rec_rows = 0;   // row-record path (GF_WALK=2)
+    std::vector<WalkItem> rec_items; std::vector<RecPatch> rec_patch; std::vector<RecCp> rec_cp; int rec_rows = 0;   // row-record path (GF_WALK=2)
     void build_rec(int seg_len);
     std::vector<int> cp_patch;          // [total_cp]
     std::vector<double> weights;
@@ -493,6 +498,35 @@ inline void HostModel::build_rec(int seg_len) {
             const int e0 = ints[R.ev0_of + g], e1 = ints[R.ev0_of + g + 1];
             rec_items.push_back({s, eu, e0, e1 - e0, g, 0, ints[P.spu + eu] - P.p, 0});
             rec_rows = std::max(rec_rows, (ints[P.spv + e1 - 1] + 1) - (ints[P.spv + e0] - P.q));     // rows first .. last of the item's windows
+        }
+    }
+    rec_cp.assign(total_cp, RecCp{});
+    for (int s = 0; s < n_owned; ++s) {
+        const PatchDev& P = patches[s];
+        const RecPatch& R = rec_patch[s];
+        const int* c2v = &ints[P.c2v];
+        for (int64_t a = P.cp_off; a < P.cp_off + int64_t(P.nu) * P.nv; ++a) {
+            const CpDesc& c = cp_desc[a];
+            RecCp& rc = rec_cp[a];
+            rc.flags = (zero[3 * a] ? 1 : 0) | (zero[3 * a + 1] ? 2 : 0) | (zero[3 * a + 2] ? 4 : 0);
+            const int lov_a = c2v[2 * c.ja], hiv_a = c2v[2 * c.ja + 1];
+            if (lov_a > hiv_a) continue;
+            const int g_lo = ints[R.seg_of + lov_a], g_hi = ints[R.seg_of + hiv_a];
+            if (c.neu * (g_hi - g_lo + 1) > 8) throw std::runtime_error("build_rec: a control point lies in more than 8 work items");
+            for (int k = 0; k < c.neu; ++k) for (int g = g_lo; g <= g_hi; ++g) {
+                const int E0 = ints[R.ev0_of + g], E1 = ints[R.ev0_of + g + 1], ivf = ints[P.spv + E0] - P.q;
+                unsigned pm = 0;
+                for (int d = 0; d < 7; ++d) {
+                    const int jb = c.ja - 3 + d;
+                    if (jb < 0 || jb >= P.nv) continue;
+                    const int lo = std::max(lov_a, c2v[2 * jb]), hi = std::min(hiv_a, c2v[2 * jb + 1]);
+                    if (lo <= hi && lo < E1 && hi >= E0) pm |= 1u << d;
+                }
+                const int item = R.item_off + (c.eu0 + k) * R.nseg + g;
+                rc.it[rc.nit].row = item * rec_rows + (c.ja - ivf);
+                rc.it[rc.nit].info = unsigned(c.bu[k] - c.i0) | unsigned(c.ia - c.bu[k]) << 8 | pm << 16;
+                ++rc.nit;
+            }
         }
     }
 }
