@@ -81,6 +81,12 @@ def cpu_baseline(args, ncores):
                       "best of 5 after 1 warm-up (%.1f s)" % (nall, gpn, nall, tn)}
 
 
+def kname_of(D, p):
+    """Name of the dominant kernel of the path the handle runs (gf_assembly_path)."""
+    return {4: "kl_element_rec_kernel", 2: "kl_element_walk_kernel", 3: "kl_element_kernel"}.get(
+        D.assembly_path, "kl_element_mfma4_kernel" if p == 4 else ("kl_element_mfma2_kernel" if os.environ.get("GF_TWOWAVE", "1") != "0" else "kl_element_mfma_kernel"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,18 +224,19 @@ def main():
         p = args.degree
         alg_bytes = ALG_BYTES_PER_GP[p] * n_gp_local
         achieved = alg_bytes / (kern_ms_step * 1e-3) / 1e9 if kern_ms_step > 0 else 0.0
-        traffic = counter_flop = None
+        traffic = counter_flop = step_traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                if tj.get("workload_gps") == n_gp_local:
+                if tj.get("workload_gps") == n_gp_local and str(tj.get("element_kernel", "")).startswith(kname_of(D, args.degree)):
                     traffic = tj.get("element_kernel_bytes_per_launch")
                     counter_flop = tj.get("element_kernel_fp64_flop_issued_per_launch")
+                    step_traffic = tj.get("full_pass_bytes_per_step")
             except Exception:
-                traffic = counter_flop = None
+                traffic = counter_flop = step_traffic = None
         mfma = os.environ.get("GF_ELEMENT", "mfma") != "valu"
-        kname = ("kl_element_mfma4_kernel" if p == 4 else "kl_element_mfma_kernel") if mfma else "kl_element_kernel"
+        kname = kname_of(D, p)
         out = {
             "metric": "element-Gauss-point updates/sec (assembly+adjoint)", "value": value, "unit": "GP-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -244,7 +251,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms_step, "launches_timed": kern_n,
-                         "launches_per_step": kern_n / max(args.steps, 1)},
+                         "launches_per_step": kern_n / max(args.steps, 1), "step_traffic_all_kernels": step_traffic},
             "roofline_fp64": {"bound": "fp64 (v_mfma_f64 + FP64 VALU share one pipe)" if mfma else "fp64-valu", "kernel": kname,
                               "achieved": ALG_FLOP_PER_GP[p] * n_gp_local / (kern_ms_step * 1e-3) / 1e12 if kern_ms_step > 0 else 0.0,
                               "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

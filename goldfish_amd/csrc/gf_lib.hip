@@ -50,7 +50,7 @@ struct gf_handle {
     bool assembled[5] = {false, false, false, false, false};
     bool walk = false;                                // GF_WALK=1 (p = 2, 3, MFMA path): walk element strips and accumulate straight into the CSR arrays (gf_element_walk.hpp: a quarter of the device memory, half the traffic, currently slower)
     const WalkItem* d_walk_items = nullptr; const RowDesc* d_row_desc = nullptr; const WalkPatch* d_walk_patch = nullptr;
-    bool rec = false;                                 // GF_WALK=2 (p = 2, 3, MFMA path): walking kernel that stores row records + kl_gather_rec_kernel (gf_element_rec.hpp)
+    bool rec = false;                                 // p = 2, 3, MFMA path, default (GF_WALK unset or 2): walking kernel that stores row records + kl_gather_rec_kernel (gf_element_rec.hpp)
     const WalkItem* d_rec_items = nullptr; const RecCp* d_rec_cp = nullptr; double* d_rec = nullptr; long long rec_doubles = 0;
     bool two_wave = true;                             // p = 2, 3 full pass: two waves per element, two resident per SIMD (gf_element_mfma2.hpp; GF_TWOWAVE=0: one wave)
     bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
@@ -94,10 +94,12 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         if (const char* s = getenv("GF_GATHER1")) h->gather1 = std::string(s) != "0";
         HostModel& H = h->H;
         {
-            bool want = false;
-            bool want_rec = false;
-            if (const char* s = getenv("GF_WALK")) { want = h->mfma && H.degree <= 3 && std::string(s) == "1"; want_rec = h->mfma && H.degree <= 3 && std::string(s) == "2"; }
-            int seg = want_rec ? 24 : 12;
+            // p = 2, 3 on the matrix pipe: row records + record gather (gf_element_rec.hpp) by default; GF_WALK=0: one block per element +
+            // row gather, GF_WALK=1: walking kernel that adds straight into the CSR arrays (gf_element_walk.hpp)
+            const bool can = h->mfma && H.degree <= 3;
+            bool want = false, want_rec = can;
+            if (const char* s = getenv("GF_WALK")) { want = can && std::string(s) == "1"; want_rec = can && std::string(s) == "2"; }
+            int seg = want ? 12 : 24;
             if (const char* s = getenv("GF_WALK_SEG")) seg = std::max(1, atoi(s));
             if (want) { H.build_walk(seg); h->walk = H.walk_ok; }
             if (want_rec) { H.build_rec(seg); h->rec = true; }

@@ -56,7 +56,7 @@ def test_assembly_parity(oracle_lib, case):
     A, h, u = _state(spec)
     O = Oracle(A, thickness=h, u=u)
     D = _lib.DeviceModel(A)
-    assert D.assembly_path == 0                 # MFMA element kernel, one block per element, row-owner gather
+    assert D.assembly_path == (0 if int(A.degree[0]) == 4 else 4)     # p = 2, 3: walking MFMA kernel + row records + record gather; p = 4: one block per element + row gather
     D.set_thickness(h)
     D.set_u(u)
     D.assemble(_lib.ASM_ALL)
@@ -122,7 +122,7 @@ def test_walking_kernel_segment_lengths_and_block_path(oracle_lib, monkeypatch, 
 
 @pytest.mark.parametrize("seg", ["4", "7", "1000"])
 def test_row_record_path_segment_lengths_and_block_path(oracle_lib, monkeypatch, seg):
-    """GF_WALK=2: the walking element kernel that stores row records (gf_element_rec.hpp: a control-point pair is stored once per
+    """Default path for p = 2, 3: the walking element kernel that stores row records (gf_element_rec.hpp: a control-point pair is stored once per
     strip and segment, when its lower row leaves the window) + the record gather, with work items of 4 / 7 elements / whole strips
     (a pair then lies in two / one segment), against the oracle and the element-block + gather path, for every flag subset;
     bitwise reproducible run to run (fixed strip and segment order per entry)."""
@@ -134,7 +134,8 @@ def test_row_record_path_segment_lengths_and_block_path(oracle_lib, monkeypatch,
         vals, Ro = O.assemble(), O.residual()
         out = {}
         for walk in ("2", "0"):
-            monkeypatch.setenv("GF_WALK", walk)
+            if walk == "2": monkeypatch.delenv("GF_WALK", raising=False)          # the default path
+            else: monkeypatch.setenv("GF_WALK", walk)
             monkeypatch.setenv("GF_WALK_SEG", seg)
             D = _lib.DeviceModel(A)
             assert D.assembly_path == (4 if walk == "2" else 0)

@@ -658,7 +658,9 @@ def test_host_setup_under_address_and_ub_sanitizers(tmp_path):
             assert out.returncode == 0 and "built:" in out.stdout, (name, out.stderr[-2000:])
             assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, (name, out.stderr[-2000:])
             # the walking kernel's addressing (p <= 3): dry run of every (item, element, pair) visit against the CSR pattern
-            assert ("walk: not applicable" in out.stdout) if name == "shell_p4" else ("dry run ok" in out.stdout), (name, out.stdout)
+            assert ("walk: not applicable" in out.stdout) if name == "shell_p4" else ("walk:" in out.stdout and "items, dry run ok" in out.stdout), (name, out.stdout)
+            # the row-record path (default for p <= 3): the element kernel's stores against the record gather's reads, position by position
+            assert ("rec:" not in out.stdout) if name == "shell_p4" else ("rows per item, dry run ok" in out.stdout), (name, out.stdout)
 
 
 def test_intersection_cache_format_round_trip_and_reference_files(tmp_path):

@@ -24,6 +24,14 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
        "workload_gps": gps, "kernels": kern,
        "element_kernel": el[0] if el else None,
        "element_kernel_bytes_per_launch": kern[el[0]]["hbm_side_bytes_corrected_per_launch"] if el else None}
+# all kernels of one full pass (R + K + dR/dCP + dR/dh): the instances the full pass launches (element / gather kernels with the dR/dCP
+# blocks, penalty kernels of the full pass, residual gather and clean-up), one launch each per step
+def in_full_pass(k):
+    if k.startswith(("kl_element", "kl_gather")): return "true" in k or k.startswith(("kl_element_mfma2", "kl_element_kernel")) or "<" not in k
+    if k.startswith("pen_owner"): return k.replace(" ", "").split("<")[1].startswith(("3,2,true,true", "2,2,true,true", "4,"))
+    return k.startswith(("pen_point", "kl_rgather", "zero_rows", "residual_finish"))
+out["full_pass_kernels"] = sorted(k for k in kern if in_full_pass(k))
+out["full_pass_bytes_per_step"] = sum(kern[k]["hbm_side_bytes_corrected_per_launch"] for k in kern if in_full_pass(k))
 # FP64 work per launch as the SQ counters see it (tools/profile_round.sh, fourth pass): flop = 512 * MFMA_MOPS_F64 + 64 * (2 FMA + ADD + MUL + TRANS)
 # wave-level VALU instructions (all 64 lanes counted, active or not: issued work, what occupies the FP64 pipe)
 import os
