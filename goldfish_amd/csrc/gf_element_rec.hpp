@@ -369,16 +369,18 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
 // A pair is present in an item only if one of the item's elements holds both rows; everything else in a record row is never
 // written and never read.
 template <int P, bool WITHC>
-__global__ __launch_bounds__(64) void kl_gather_rec_kernel(DevModel M, long long a_first, long long a_end, int flags, const double* __restrict__ rec, int rec_rows,
+__global__ __launch_bounds__(64) void kl_gather_rec_kernel(DevModel M, long long a_first, long long a_end, const int* __restrict__ cp_list, int flags, const double* __restrict__ rec, int rec_rows,
                                                            const RecCp* __restrict__ reccp, double* __restrict__ valK, double* __restrict__ valC0,
                                                            double* __restrict__ valC1, double* __restrict__ valC2, double* __restrict__ valH, int pen_add) {
     using RC = RecCfg<WITHC>;
     constexpr int P1 = P + 1, WB = 2 * P + 1, NBOX = WB * WB, NT = RC::NT, SZ = RC::SZ, A2 = RC::A2;
     // workgroup w runs on XCD w % 8: every XCD takes a contiguous range of control points, so that the record lines shared by
     // neighbouring control points are fetched into one L2
+    // cp_list: the control points to gather (ascending), entries a_first .. a_end - 1 of it; nullptr: the control points a_first .. a_end - 1
     const long long chunk = (a_end - a_first + 7) / 8;
-    const long long a = a_first + (long long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if ((long long)(blockIdx.x >> 3) >= chunk || a >= a_end) return;
+    const long long idx = a_first + (long long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((long long)(blockIdx.x >> 3) >= chunk || idx >= a_end) return;
+    const long long a = cp_list ? (long long)cp_list[idx] : idx;
     const CpDesc& cd = M.cpdesc[a];
     const int ia = cd.ia, ja = cd.ja, i0 = cd.i0, j0 = cd.j0, wbox = cd.i1 - cd.i0 + 1;
     const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c, ptr_s = M.nb_ptr_s[a], deg_s = M.nb_ptr_s[a + 1] - ptr_s;

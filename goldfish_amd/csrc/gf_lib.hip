@@ -52,6 +52,10 @@ struct gf_handle {
     const WalkItem* d_walk_items = nullptr; const RowDesc* d_row_desc = nullptr; const WalkPatch* d_walk_patch = nullptr;
     bool rec = false;                                 // p = 2, 3, MFMA path, default (GF_WALK unset or 2): walking kernel that stores row records + kl_gather_rec_kernel (gf_element_rec.hpp)
     const WalkItem* d_rec_items = nullptr; const RecCp* d_rec_cp = nullptr; double* d_rec = nullptr; long long rec_doubles = 0;
+    // Row-record path: the penalty kernels (latency / issue bound, 1.2 TB/s) run on a second stream NEXT TO the record gather of the
+    // control points without penalty rows (bandwidth bound); the gather of the interface control points follows both.
+    hipStream_t stream_p = nullptr; hipEvent_t ev_elem = nullptr, ev_pen = nullptr; bool pen_overlap = false;
+    const int *d_cp_plain = nullptr, *d_cp_pen = nullptr; long long n_cp_plain = 0, n_cp_pen = 0;
     bool two_wave = true;                             // p = 2, 3 full pass: two waves per element, two resident per SIMD (gf_element_mfma2.hpp; GF_TWOWAVE=0: one wave)
     bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
     bool atomic_t = false;                            // GF_ATOMIC_T=1: transposed products of dR/dCP, dR/dh by FP64 atomics (order not fixed) instead of the fixed-order gather
@@ -160,6 +164,24 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
                     throw std::runtime_error("gf_create: a control point couples to more than " + std::to_string(PEN_MAXDEG) + " neighbours (PEN_MAXDEG)");
         }
         M.pen_row = h->upload(pen_row);
+        if (h->rec) {
+            std::vector<int> plain, withpen;
+            for (long long a = 0; a < H.owned_cp; ++a) (pen_row[a] ? withpen : plain).push_back((int)a);
+            h->d_cp_plain = h->upload(plain); h->d_cp_pen = h->upload(withpen); h->n_cp_plain = (long long)plain.size(); h->n_cp_pen = (long long)withpen.size();
+            // measured at C4 (tools/timeline.sh): next to the gather (HBM saturated) pen_owner_kernel does a quarter of its work in the
+            // time it needs for all of it alone (5.3 ms overlapped + alone vs 2.7 ms), pen_point_kernel 3.8 instead of 0.7 ms, with or
+            // without stream priority: 23.6 vs 23.4 ms per step.  Off unless GF_PEN_OVERLAP=1.
+            h->pen_overlap = false;
+            if (const char* s = getenv("GF_PEN_OVERLAP")) h->pen_overlap = H.npts > 0 && std::string(s) == "1";
+            if (h->pen_overlap) {
+                // higher priority: the gather's half million workgroups would otherwise keep every slot and the penalty kernels would
+                // only trickle in behind them (measured: pen_point stretched from 0.7 to 3.8 ms, pen_owner started after the gather)
+                int lo = 0, hi = 0;
+                HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                HIPCHK(hipStreamCreateWithPriority(&h->stream_p, hipStreamDefault, hi));
+                HIPCHK(hipEventCreateWithFlags(&h->ev_elem, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_pen, hipEventDisableTiming));
+            }
+        }
         for (long long a = 0; a < H.total_cp; ++a)
             if (H.nb_ptr_c[a + 1] - H.nb_ptr_c[a] > GATHER_MAXMETA) throw std::runtime_error("gf_create: a control point has more than " + std::to_string(GATHER_MAXMETA) + " neighbours (GATHER_MAXMETA)");
         // element-block scratch, chunked over whole patches
@@ -235,6 +257,9 @@ void gf_destroy(gf_handle* h) {
     for (auto e : h->ev_g) if (e) (void)hipEventDestroy(e);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream_g) (void)hipStreamDestroy(h->stream_g);
+    if (h->stream_p) (void)hipStreamDestroy(h->stream_p);
+    if (h->ev_elem) (void)hipEventDestroy(h->ev_elem);
+    if (h->ev_pen) (void)hipEventDestroy(h->ev_pen);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -295,15 +320,18 @@ int gf_pattern(const gf_handle* h, int which, int64_t* rowptr, int32_t* col) {
 
 // Penalty kernels of one pass.  ADD = false: pen_owner_kernel WRITES the rows of the interface control points and the gather adds the
 // shell part afterwards; ADD = true (walking element kernel): the shell part is in place and the blocks are added to it.
-template <int P, bool ADD> static int run_penalty(gf_handle* h, int flags) {
+// parts: 1 = vertex records (pen_point_kernel), 2 = rows (pen_owner_kernel), 3 = both
+template <int P, bool ADD> static int run_penalty(gf_handle* h, int flags, hipStream_t st = nullptr, int parts = 3) {
+    if (!st) st = h->stream;
     const HostModel& H = h->H;
     const int pen = (H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP))) ? 1 : 0;
-    if (pen) {
-        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf,
+    if (pen && (parts & 1))
+        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, st, h->M, h->Q, h->d_pbuf,
                            !(flags & (GF_ASM_K | GF_ASM_DRDCP)) ? 1 : (!(flags & GF_ASM_DRDCP) ? 2 : (!(flags & GF_ASM_K) ? 3 : 0)));
+    if (pen && (parts & 2)) {
         const dim3 grid((unsigned)(((h->Q.nrow_groups + 7) / 8) * 8)), blk64(64);       // multiple of 8: XCD-contiguous group ranges
         const int sl = (h->pen_maxdeg + 63) / 64;         // neighbour slots per lane, register resident
-#define GF_PEN_LAUNCH(SL, WC, WK) hipLaunchKernelGGL((pen_owner_kernel<P, SL, WC, WK, ADD>), grid, blk64, 0, h->stream, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \
+#define GF_PEN_LAUNCH(SL, WC, WK) hipLaunchKernelGGL((pen_owner_kernel<P, SL, WC, WK, ADD>), grid, blk64, 0, st, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \
                                                      h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])
 #define GF_PEN_SLOTS(WC, WK) do { if (sl <= 2) GF_PEN_LAUNCH(2, WC, WK); else if (sl == 3) GF_PEN_LAUNCH(3, WC, WK); else GF_PEN_LAUNCH(5, WC, WK); } while (0)
         if (!(flags & GF_ASM_DRDCP)) GF_PEN_SLOTS(false, true);                 // Newton pass
@@ -353,7 +381,12 @@ template <int P> static void run_assemble_walk(gf_handle* h, int flags) {
 template <int P> static void run_assemble_rec(gf_handle* h, int flags) {
     constexpr int PW = P == 2 ? 2 : 3;
     const HostModel& H = h->H;
-    const int pen = run_penalty<P, false>(h, flags);
+    const bool mats = (flags & ~GF_ASM_R) != 0;
+    const bool want_pen = H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP));
+    const bool split = h->pen_overlap && mats && want_pen;      // penalty kernels next to the gather of the control points without penalty rows
+    int pen = 0;
+    if (!split) pen = run_penalty<P, false>(h, flags);
+    else run_penalty<P, false>(h, flags, h->stream, 1);           // vertex records first: a latency-bound kernel that crawls next to the gather
     const RecOut O{h->d_rec, h->d_blk, H.rec_rows};
     const int slot = h->ev_n % 64, n = (int)H.rec_items.size();
     HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
@@ -363,12 +396,23 @@ template <int P> static void run_assemble_rec(gf_handle* h, int flags) {
     h->ev_n++;
     const Chunk& c = h->chunks[0];
     const long long ne = c.e1 - c.e0, na = c.a1 - c.a0;
-    if (flags & ~GF_ASM_R) {
-        if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_gather_rec_kernel<PW, true>), dim3((unsigned)(((na + 7) / 8) * 8)), dim3(64), 0, h->stream, h->M, c.a0, c.a1, flags, h->d_rec, H.rec_rows, h->d_rec_cp,
-                                                     h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], pen);
-        else hipLaunchKernelGGL((kl_gather_rec_kernel<PW, false>), dim3((unsigned)(((na + 7) / 8) * 8)), dim3(64), 0, h->stream, h->M, c.a0, c.a1, flags, h->d_rec, H.rec_rows, h->d_rec_cp,
-                                h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], pen);
-    }
+    auto gather = [&](const int* list, long long cnt, long long a0, long long a1, int pen_add) {
+        if (cnt <= 0) return;
+        const dim3 grid((unsigned)(((cnt + 7) / 8) * 8));
+        if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_gather_rec_kernel<PW, true>), grid, dim3(64), 0, h->stream, h->M, a0, a1, list, flags, h->d_rec, H.rec_rows, h->d_rec_cp,
+                                                     h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], pen_add);
+        else hipLaunchKernelGGL((kl_gather_rec_kernel<PW, false>), grid, dim3(64), 0, h->stream, h->M, a0, a1, list, flags, h->d_rec, H.rec_rows, h->d_rec_cp,
+                                h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], pen_add);
+    };
+    if (split) {
+        HIPCHK(hipEventRecord(h->ev_elem, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->stream_p, h->ev_elem, 0));            // not next to the element kernel (it holds every SIMD's registers)
+        pen = run_penalty<P, false>(h, flags, h->stream_p, 2);
+        HIPCHK(hipEventRecord(h->ev_pen, h->stream_p));
+        gather(h->d_cp_plain, h->n_cp_plain, 0, h->n_cp_plain, 0);
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_pen, 0));               // the pass continues (and ends) on the main stream
+        gather(h->d_cp_pen, h->n_cp_pen, 0, h->n_cp_pen, pen);
+    } else if (mats) gather(nullptr, na, c.a0, c.a1, pen);
     if (flags & GF_ASM_R) {
         hipLaunchKernelGGL(kl_rgather_kernel<P>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, h->d_blk, h->d_R, pen, 3 * (P + 1) * (P + 1), 0);
         finish_residual(h);
