@@ -1017,7 +1017,10 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
     const int a = Q.row_cp[gidx];
     const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c;
     const bool mats = (flags & (GF_ASM_K_BIT | GF_ASM_C_BIT)) != 0;
-    __shared__ double s_w[4][3][32];                    // [buffer][i][0..17 wK | 18..29 wC]
+    // [buffer][i][side t][0..8 wK (m, j) | 9 pad | 10..15 wC (m', j)]: 128-byte groups read back as 16-byte pairs (-6 %).  Measured and
+    // dropped: requesting the next pair's vertex data before the current pair is contracted (229 instead of 162 registers, two waves
+    // per SIMD instead of three: 724 instead of 621 us on the 8 x 8-patch slice) -- the loop lives on occupancy.
+    __shared__ __attribute__((aligned(16))) double s_w[4][3][2][16];
     // owned slots
     int sp[PEN_SL], si[PEN_SL], sj[PEN_SL];
     double kk[WITHK ? PEN_SL : 1][9], cc[WITHC ? PEN_SL : 1][9];
@@ -1073,9 +1076,9 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (u < nu_) {
-                double (*w)[32] = s_w[2 * pair + u];
-                if constexpr (WITHK) { if (mats && tid < 54) w[iK][cK] = n3[u][0] * hk[u][0] + n3[u][1] * hk[u][1] + n3[u][2] * hk[u][2]; }
-                if constexpr (WITHC) { if (mats && tid < 36) w[iC][18 + cC] = n3[u][0] * hc[u][0] + n3[u][1] * hc[u][1] + n3[u][2] * hc[u][2]; }
+                double (*w)[2][16] = s_w[2 * pair + u];
+                if constexpr (WITHK) { if (mats && tid < 54) w[iK][cK / 9][cK % 9] = n3[u][0] * hk[u][0] + n3[u][1] * hk[u][1] + n3[u][2] * hk[u][2]; }
+                if constexpr (WITHC) { if (mats && tid < 36) w[iC][cC / 6][10 + cC % 6] = n3[u][0] * hc[u][0] + n3[u][1] * hc[u][1] + n3[u][2] * hc[u][2]; }
                 if (tid < 3) racc += n3[u][0] * g3[u][0] + n3[u][1] * g3[u][1] + n3[u][2] * g3[u][2];
             }
         }
@@ -1084,15 +1087,23 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (u >= nu_) continue;
-                const double (*w)[32] = s_w[2 * pair + u];
+                const double (*w)[2][16] = s_w[2 * pair + u];
 #pragma unroll
                 for (int sl = 0; sl < PEN_SL; ++sl) {
                     const int t = tt[u][sl];
                     if (t < 0) continue;
                     const double b0 = bv[u][sl][0], b1 = bv[u][sl][1], b2 = bv[u][sl][2];
-                    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-                        if constexpr (WITHK) kk[sl][3 * i + j] += w[i][9 * t + j] * b0 + w[i][9 * t + 3 + j] * b1 + w[i][9 * t + 6 + j] * b2;
-                        if constexpr (WITHC) cc[sl][3 * i + j] += w[i][18 + 6 * t + j] * b1 + w[i][18 + 6 * t + 3 + j] * b2;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        double wl[16];
+                        const double2* wp = reinterpret_cast<const double2*>(w[i][t]);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { if ((q < 5 && WITHK) || (q >= 5 && WITHC)) { const double2 v2 = wp[q]; wl[2 * q] = v2.x; wl[2 * q + 1] = v2.y; } else { wl[2 * q] = 0.0; wl[2 * q + 1] = 0.0; } }
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            if constexpr (WITHK) kk[sl][3 * i + j] += wl[j] * b0 + wl[3 + j] * b1 + wl[6 + j] * b2;
+                            if constexpr (WITHC) cc[sl][3 * i + j] += wl[10 + j] * b1 + wl[13 + j] * b2;
+                        }
                     }
                 }
             }
