@@ -103,7 +103,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             const bool can = h->mfma && H.degree <= 3;
             bool want = false, want_rec = can;
             if (const char* s = getenv("GF_WALK")) { want = can && std::string(s) == "1"; want_rec = can && std::string(s) == "2"; }
-            int seg = want ? 12 : 24;
+            int seg = want ? 12 : 0;                          // row records: whole strips unless the model is small (HostModel::build_rec)
             if (const char* s = getenv("GF_WALK_SEG")) seg = std::max(1, atoi(s));
             if (want) { H.build_walk(seg); h->walk = H.walk_ok; }
             if (want_rec) { H.build_rec(seg); h->rec = true; }

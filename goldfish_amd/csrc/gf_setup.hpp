@@ -484,9 +484,14 @@ inline void HostModel::build_rec(int seg_len) {
     if (degree < 2 || degree > 3) throw std::runtime_error("build_rec: p = 2, 3 only");
     const int P1 = degree + 1;
     rec_items.clear(); rec_patch.assign(np, RecPatch{0, 0, 0, 0}); rec_rows = 0;
+    // seg_len <= 0: whole strips (no partial sums at segment ends: 11 % fewer record bytes than 24-element items) unless the model is
+    // too small to fill the device that way -- then the strips are cut until there are a few items per SIMD
+    int64_t nstrips = 0;
+    for (int s = 0; s < n_owned; ++s) nstrips += patches[s].nelu;
+    const int cut = seg_len > 0 ? 1 : int(std::min<int64_t>(64, (4 * 1024 + nstrips - 1) / std::max<int64_t>(nstrips, 1)));
     for (int s = 0; s < n_owned; ++s) {
         const PatchDev& P = patches[s];
-        int nseg = std::max(1, (P.nelv + seg_len / 2) / std::max(seg_len, P1));
+        int nseg = seg_len > 0 ? std::max(1, (P.nelv + seg_len / 2) / std::max(seg_len, P1)) : cut;
         while (nseg > 1 && P.nelv / nseg < P1) --nseg;                 // every segment holds at least p + 1 elements: a pair lies in at most two
         RecPatch& R = rec_patch[s];
         R.item_off = (int)rec_items.size(); R.nseg = nseg;

@@ -652,7 +652,7 @@ def test_host_setup_under_address_and_ub_sanitizers(tmp_path):
     for name, A in models.items():
         path = os.path.join(str(tmp_path), name + ".bin")
         _dump_model(A, path)
-        for seg in ("4", "7", "1000"):       # segment length of the walking kernel's work items (1000: whole strips)
+        for seg in ("4", "7", "1000", "0"):  # segment length of the walking kernels' work items (1000: whole strips; 0: the row-record path's own choice)
             out = subprocess.run([exe, path, seg], capture_output=True, text=True, timeout=300,
                                  env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
             assert out.returncode == 0 and "built:" in out.stdout, (name, out.stderr[-2000:])
