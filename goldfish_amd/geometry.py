@@ -268,6 +268,18 @@ def synthetic_fuselage(nx=32, ny=32, nel=53, p=4, jitter=2, seed=SEED, mortar_mu
                        "synthetic_fuselage_%dx%d_p%d" % (nx, ny, p))
 
 
+def with_double_knots(spec, every=2):
+    """Inserts every ``every``-th interior knot of every patch a second time (both directions): C^(p-2) lines inside the patches -- still
+    C1 for p = 3 --, i.e. consecutive elements whose control-point windows are two rows / columns apart.  The surfaces, and with them the
+    interface data, are unchanged."""
+    for patch in spec.patches:
+        for d in (0, 1):
+            U = np.asarray(patch.knots[d]); p = patch.p if d == 0 else patch.q
+            interior = np.unique(U[p + 1:-p - 1])
+            patch.refine(d, [float(x) for x in interior[::every]])
+    return spec
+
+
 def random_thickness(spec, seed=SEED, lo=0.8, hi=1.2):
     """Per-control-point thickness h ~ U(lo,hi)*h_th."""
     rng = np.random.default_rng(seed + 1)

@@ -38,6 +38,7 @@ CASES = {
     "C5_fuselage3x2_p4": lambda: G.synthetic_fuselage(3, 2, nel=6, p=4, jitter=1),
     # load per unit projected area along a general direction (gf_model_desc.load_proj; the arch demo's source term)
     "slr9_nurbs_p3_projected_load": lambda: _with_projected_load(G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2])),
+    "shell2x2_p3_double_knots": lambda: G.with_double_knots(G.synthetic_shell(2, 2, nel=6, p=3, jitter=1)),
     "slr9_p2_projected_load": lambda: _with_projected_load(G.scordelis_lo_9patch(4, p=2)),
     "shell2x2_p4_projected_load": lambda: _with_projected_load(G.synthetic_shell(2, 2, nel=4, p=4, jitter=1)),
 }
@@ -128,7 +129,7 @@ def test_row_record_path_segment_lengths_and_block_path(oracle_lib, monkeypatch,
     bitwise reproducible run to run (fixed strip and segment order per entry)."""
     from goldfish_amd import _lib
     from oracle.oracle_py import Oracle
-    for case in ("tbeam2_p2", "shell3x2_p3", "C3_wing16_refdata", "slr9_nurbs_p3_projected_load"):
+    for case in ("tbeam2_p2", "shell3x2_p3", "C3_wing16_refdata", "slr9_nurbs_p3_projected_load", "shell2x2_p3_double_knots"):
         A, h, u = _state(CASES[case](), seed=11)
         O = Oracle(A, thickness=h, u=u)
         vals, Ro = O.assemble(), O.residual()

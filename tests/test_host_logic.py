@@ -648,7 +648,8 @@ def test_host_setup_under_address_and_ub_sanitizers(tmp_path):
     shell = G.synthetic_shell(3, 2, nel=4, p=3, jitter=1)
     models = {"tbeam4": arrays_from_spec(G.tbeam_4patch(nels=((5, 6), (6, 7), (5, 7), (6, 8)))), "slr9": arrays_from_spec(G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2])),
               "wing16": arrays_from_spec(wing), "shell_p4": arrays_from_spec(G.synthetic_shell(2, 2, nel=3, p=4, jitter=1)),
-              "shard": sharding.shard_arrays(sharding.shard_spec(shell, 1, 2)), "single": arrays_from_spec(G.scordelis_lo_single(4))}
+              "shard": sharding.shard_arrays(sharding.shard_spec(shell, 1, 2)), "single": arrays_from_spec(G.scordelis_lo_single(4)),
+              "double_knots": arrays_from_spec(G.with_double_knots(G.synthetic_shell(2, 2, nel=6, p=3, jitter=1)))}   # windows that move two rows at a time
     for name, A in models.items():
         path = os.path.join(str(tmp_path), name + ".bin")
         _dump_model(A, path)
