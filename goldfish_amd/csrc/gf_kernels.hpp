@@ -905,6 +905,7 @@ struct DevPenalty {
     const int* pt_iface; const int* pt_base; const double* pt_nu; const double* pt_tau; const double* pt_wt;
     const int* if_patch; const double* if_alpha;
     const PenEntry* entries; const long long* ent_ptr; const int* row_cp;
+    const unsigned short* slots;     // p <= 3: per visit and side the 16 window positions' indices in the row's neighbour list (pen_row16_kernel)
     long long npts, nrow_groups;
 };
 

@@ -17,6 +17,7 @@ constexpr int GF_ASM_R_BIT = 1, GF_ASM_K_BIT = 2, GF_ASM_C_BIT = 4, GF_ASM_H_BIT
 #include "gf_element_mfma2.hpp"
 #include "gf_element_walk.hpp"
 #include "gf_element_rec.hpp"
+#include "gf_penalty_row16.hpp"
 
 using namespace gf;
 
@@ -62,6 +63,7 @@ struct gf_handle {
     const int *d_rev_s = nullptr, *d_rev_c = nullptr;
     bool gather1 = true;                              // one-wave gather (GF_GATHER1=0 selects the four-wave gather)
     int pen_maxdeg = 0;                               // largest neighbour count of an interface control point
+    bool pen_row16 = true;                            // p = 2, 3: pen_row16_kernel (one 16-lane row per visit; GF_PEN_ROW16=0: pen_owner_kernel)
 
     template <class T> T* dalloc(size_t n) {
         void* p = nullptr; const size_t nb = (n > 0 ? n : 1) * sizeof(T);
@@ -153,6 +155,8 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             Q.pt_iface = h->upload(H.pt_iface); Q.pt_base = h->upload(H.pt_base); Q.pt_nu = h->upload(H.pt_nu);
             Q.pt_tau = h->upload(H.pt_tau); Q.pt_wt = h->upload(H.pt_wt); Q.if_patch = h->upload(H.if_patch); Q.if_alpha = h->upload(H.if_alpha);
             Q.entries = h->upload(H.pen_entries); Q.ent_ptr = h->upload(ep); Q.row_cp = h->upload(H.row_cp);
+            Q.slots = H.degree <= 3 ? h->upload(H.pen_slots) : nullptr;
+            if (const char* s = getenv("GF_PEN_ROW16")) h->pen_row16 = std::string(s) != "0";
             Q.nrow_groups = (long long)rp.size() - 1;
             for (long long g = 0; g + 1 < (long long)rp.size(); ++g) if (rp[g + 1] > rp[g]) pen_row[H.row_items[rp[g]].a] = 1;
             h->d_pbuf = h->dalloc<double>((size_t)H.npts * PB_STRIDE);
@@ -330,6 +334,17 @@ template <int P, bool ADD> static int run_penalty(gf_handle* h, int flags, hipSt
                            !(flags & (GF_ASM_K | GF_ASM_DRDCP)) ? 1 : (!(flags & GF_ASM_DRDCP) ? 2 : (!(flags & GF_ASM_K) ? 3 : 0)));
     if (pen && (parts & 2)) {
         const dim3 grid((unsigned)(((h->Q.nrow_groups + 7) / 8) * 8)), blk64(64);       // multiple of 8: XCD-contiguous group ranges
+        if constexpr (P <= 3 && !ADD) {
+            if (h->pen_row16 && h->Q.slots) {
+                const size_t lds = (size_t)h->pen_maxdeg * 18 * sizeof(double);
+#define GF_PEN16(WC, WK) hipLaunchKernelGGL((pen_row16_kernel<P, WC, WK>), grid, blk64, lds, st, h->M, h->Q, flags, h->d_pbuf, h->d_R, h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])
+                if (!(flags & GF_ASM_DRDCP)) GF_PEN16(false, true);
+                else if (!(flags & GF_ASM_K)) GF_PEN16(true, false);
+                else GF_PEN16(true, true);
+#undef GF_PEN16
+                return pen;
+            }
+        }
         const int sl = (h->pen_maxdeg + 63) / 64;         // neighbour slots per lane, register resident
 #define GF_PEN_LAUNCH(SL, WC, WK) hipLaunchKernelGGL((pen_owner_kernel<P, SL, WC, WK, ADD>), grid, blk64, 0, st, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \
                                                      h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])

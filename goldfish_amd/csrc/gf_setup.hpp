@@ -154,6 +154,7 @@ struct HostModel {
     // deterministic owner lists
     std::vector<PenRowItem> row_items; std::vector<int64_t> row_ptr;      // groups by CP a
     std::vector<PenEntry> pen_entries; std::vector<int64_t> ent_ptr; std::vector<int> row_cp;   // per group: its visits in fixed order
+    std::vector<unsigned short> pen_slots;   // p <= 3: [visit][side][16] index of the window's control points in the row's coupled neighbour list
 
     void build(const gf_model_desc* D);
 };
@@ -409,7 +410,7 @@ inline void HostModel::build(const gf_model_desc* D) {
         std::stable_sort(rows.begin(), rows.end(), [](const PenRowItem& x, const PenRowItem& y) { return x.a < y.a; });
         row_items = rows; row_ptr.clear(); row_ptr.push_back(0);
         for (size_t k = 1; k <= rows.size(); ++k) if (k == rows.size() || rows[k].a != rows[k - 1].a) row_ptr.push_back((int64_t)k);
-        pen_entries.clear(); ent_ptr.assign(1, 0); row_cp.clear();
+        pen_entries.clear(); pen_slots.clear(); ent_ptr.assign(1, 0); row_cp.clear();
         for (size_t g = 0; g + 1 < row_ptr.size(); ++g) {
             const int a = rows[row_ptr[g]].a;
             for (int64_t it = row_ptr[g]; it < row_ptr[g + 1]; ++it) {
@@ -423,6 +424,23 @@ inline void HostModel::build(const gf_model_desc* D) {
                     for (int k = 0; k < 4; ++k) if (pt_base[4 * v + k] < 0 || pt_base[4 * v + k] > 32767) throw std::runtime_error("gf_create: patch too large for the packed mortar windows");
                     pen_entries.push_back({v, (sd << 8) | (di + dj * (P.p + 1)), pt_base[4 * v] | (pt_base[4 * v + 1] << 16), pt_base[4 * v + 2] | (pt_base[4 * v + 3] << 16),
                                            if_patch[2 * itf], if_patch[2 * itf + 1], 0, 0});
+                    if (degree <= 3) {                               // where the window's control points sit in a's coupled neighbour list (sorted by id)
+                        const int p1 = degree + 1;
+                        const int* nb0 = nb_c.data() + nb_ptr_c[a]; const int* nb1 = nb_c.data() + nb_ptr_c[a + 1];
+                        for (int t = 0; t < 2; ++t) {
+                            const PatchDev& Pt = patches[if_patch[2 * itf + t]];
+                            for (int c = 0; c < 16; ++c) {
+                                unsigned short k = 0xFFFF;
+                                if (c < p1 * p1) {
+                                    const int64_t b = Pt.cp_off + (pt_base[4 * v + 2 * t] + c % p1) + int64_t(pt_base[4 * v + 2 * t + 1] + c / p1) * Pt.nu;
+                                    const int* it2 = std::lower_bound(nb0, nb1, (int)b);
+                                    if (it2 == nb1 || *it2 != (int)b) throw std::runtime_error("gf_create: a mortar vertex couples control points that are not neighbours");
+                                    k = (unsigned short)(it2 - nb0);
+                                }
+                                pen_slots.push_back(k);
+                            }
+                        }
+                    }
                 }
             }
             ent_ptr.push_back((int64_t)pen_entries.size()); row_cp.push_back(a);
