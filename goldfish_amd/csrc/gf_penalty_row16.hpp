@@ -10,6 +10,8 @@
 // visits' data is requested before the current four are contracted.  ~65 instead of ~190 instructions per visit.
 // Summation order per entry: every 16-lane row walks its quarter of the visit list in order; where several rows hit one address in
 // the same instruction the LDS unit serialises the lanes in a fixed order -- run-to-run reproducible (tests compare bitwise).
+// Measured and dropped: a second batch of data in flight (513 / 444 vs 487 / 426 us on the 8 x 8-patch slice before / after the bank fix); one
+// launch per class of neighbour counts (<= 64, <= 88, rest: more waves per CU for the narrow rows, but three tails: 463 vs 426 us).
 // The kernel WRITES the rows (the gather adds the shell part), like pen_owner_kernel<.., ADD = false>.
 // Reference path: nonmatching_opt.py:745-752, 789-801, 861-887 (penalty residual and its blocks of dR/du, dR/dCP).
 #pragma once
