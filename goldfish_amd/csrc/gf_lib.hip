@@ -18,6 +18,7 @@ constexpr int GF_ASM_R_BIT = 1, GF_ASM_K_BIT = 2, GF_ASM_C_BIT = 4, GF_ASM_H_BIT
 #include "gf_element_walk.hpp"
 #include "gf_element_rec.hpp"
 #include "gf_penalty_row16.hpp"
+#include "gf_penalty_point16.hpp"
 
 using namespace gf;
 
@@ -64,6 +65,7 @@ struct gf_handle {
     bool gather1 = true;                              // one-wave gather (GF_GATHER1=0 selects the four-wave gather)
     int pen_maxdeg = 0;                               // largest neighbour count of an interface control point
     bool pen_row16 = true;                            // p = 2, 3: pen_row16_kernel (one 16-lane row per visit; GF_PEN_ROW16=0: pen_owner_kernel)
+    bool pen_point16 = false;                         // GF_PEN_POINT16=1, p = 2, 3: pen_point16_kernel (16 lanes per mortar vertex, coalesced record writes); parity-tested, not yet faster than pen_point_kernel (196 vs 155 us on the 8 x 8-patch slice: 272 registers, one wave per SIMD)
 
     template <class T> T* dalloc(size_t n) {
         void* p = nullptr; const size_t nb = (n > 0 ? n : 1) * sizeof(T);
@@ -157,6 +159,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             Q.entries = h->upload(H.pen_entries); Q.ent_ptr = h->upload(ep); Q.row_cp = h->upload(H.row_cp);
             Q.slots = H.degree <= 3 ? h->upload(H.pen_slots) : nullptr;
             if (const char* s = getenv("GF_PEN_ROW16")) h->pen_row16 = std::string(s) != "0";
+            if (const char* s = getenv("GF_PEN_POINT16")) h->pen_point16 = std::string(s) == "1";
             Q.nrow_groups = (long long)rp.size() - 1;
             for (long long g = 0; g + 1 < (long long)rp.size(); ++g) if (rp[g + 1] > rp[g]) pen_row[H.row_items[rp[g]].a] = 1;
             h->d_pbuf = h->dalloc<double>((size_t)H.npts * PB_STRIDE);
@@ -329,9 +332,14 @@ template <int P, bool ADD> static int run_penalty(gf_handle* h, int flags, hipSt
     if (!st) st = h->stream;
     const HostModel& H = h->H;
     const int pen = (H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP))) ? 1 : 0;
-    if (pen && (parts & 1))
-        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, st, h->M, h->Q, h->d_pbuf,
-                           !(flags & (GF_ASM_K | GF_ASM_DRDCP)) ? 1 : (!(flags & GF_ASM_DRDCP) ? 2 : (!(flags & GF_ASM_K) ? 3 : 0)));
+    if (pen && (parts & 1)) {
+        const int mode = !(flags & (GF_ASM_K | GF_ASM_DRDCP)) ? 1 : (!(flags & GF_ASM_DRDCP) ? 2 : (!(flags & GF_ASM_K) ? 3 : 0));
+        bool done = false;
+        if constexpr (P <= 3) {
+            if (h->pen_point16) { hipLaunchKernelGGL(pen_point16_kernel<P>, dim3((unsigned)((H.npts + 3) / 4)), dim3(64), 0, st, h->M, h->Q, h->d_pbuf, mode); done = true; }
+        }
+        if (!done) hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, st, h->M, h->Q, h->d_pbuf, mode);
+    }
     if (pen && (parts & 2)) {
         const dim3 grid((unsigned)(((h->Q.nrow_groups + 7) / 8) * 8)), blk64(64);       // multiple of 8: XCD-contiguous group ranges
         if constexpr (P <= 3 && !ADD) {

@@ -160,6 +160,39 @@ def test_row_record_path_segment_lengths_and_block_path(oracle_lib, monkeypatch,
             assert _rel(x, y) < 1e-12
 
 
+def test_penalty_kernel_variants(oracle_lib, monkeypatch):
+    """The penalty kernels come in two generations: pen_row16_kernel (default for p = 2, 3: one 16-lane row per visit, LDS accumulators)
+    vs pen_owner_kernel (GF_PEN_ROW16=0; p = 4 always), and pen_point_kernel (default) vs pen_point16_kernel (GF_PEN_POINT16=1: 16 lanes
+    per mortar vertex).  Every combination against the oracle; each is bitwise reproducible run to run."""
+    from goldfish_amd import _lib
+    from oracle.oracle_py import Oracle
+    for case in ("tbeam2_p2", "C3_wing16_refdata", "slr9_nurbs_p3_projected_load"):
+        A, h, u = _state(CASES[case](), seed=5)
+        O = Oracle(A, thickness=h, u=u)
+        vals, Ro = O.assemble(), O.residual()
+        for row16, point16 in (("0", "0"), ("1", "1"), ("0", "1")):
+            monkeypatch.setenv("GF_PEN_ROW16", row16)
+            monkeypatch.setenv("GF_PEN_POINT16", point16)
+            D = _lib.DeviceModel(A)
+            D.set_thickness(h)
+            D.set_u(u)
+            D.assemble(_lib.ASM_ALL)
+            first = [D.residual().copy()] + [D.values(w).copy() for w in range(5)]
+            assert _rel(first[0], Ro) < RTOL
+            for w in range(5):
+                assert _rel(first[1 + w], vals[w]) < RTOL, (case, row16, point16, w)
+            D.assemble(_lib.ASM_ALL)
+            assert np.array_equal(first[0], D.residual())
+            for w in range(5):
+                assert np.array_equal(first[1 + w], D.values(w)), (case, row16, point16, w)
+            for flags, which in ((_lib.ASM_R | _lib.ASM_K, (0,)), (_lib.ASM_DRDCP | _lib.ASM_DRDH, (1, 2, 3, 4)), (_lib.ASM_R, ())):
+                D.assemble(flags)
+                assert _rel(D.residual(), Ro) < RTOL or not (flags & _lib.ASM_R)
+                for w in which:
+                    assert _rel(D.values(w), vals[w]) < RTOL, (case, row16, point16, flags, w)
+            D.close()
+
+
 def test_valu_element_kernel_still_matches(oracle_lib, monkeypatch):
     """The FP64-VALU element kernel (GF_ELEMENT=valu) stays a supported path for every degree."""
     from goldfish_amd import _lib
