@@ -29,6 +29,7 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
 def in_full_pass(k):
     if k.startswith(("kl_element", "kl_gather")): return "true" in k or k.startswith(("kl_element_mfma2", "kl_element_kernel")) or "<" not in k
     if k.startswith("pen_owner"): return k.replace(" ", "").split("<")[1].startswith(("3,2,true,true", "2,2,true,true", "4,"))
+    if k.startswith("pen_row16"): return k.replace(" ", "").endswith("true,true>")
     return k.startswith(("pen_point", "kl_rgather", "zero_rows", "residual_finish"))
 out["full_pass_kernels"] = sorted(k for k in kern if in_full_pass(k))
 out["full_pass_bytes_per_step"] = sum(kern[k]["hbm_side_bytes_corrected_per_launch"] for k in kern if in_full_pass(k))
