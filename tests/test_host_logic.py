@@ -687,3 +687,27 @@ def test_intersection_cache_format_round_trip_and_reference_files(tmp_path):
         assert np.array_equal(c0[0], c1[0]) and np.array_equal(c0[1], c1[1])
     d = np.load(path, allow_pickle=True)
     assert sorted(d.files) == ["name%d" % k for k in range(1, 7)] and d["name5"].shape == (5,) and np.all(d["name5"] > 0.99)
+
+
+def test_no_valu_write_in_front_of_a_dpp_read():
+    """The v_fmac_f64_dpp of the element and penalty kernels are inline assembly: LLVM's hazard recogniser does not see them, and a copy or
+    spill reload placed between the kernels' `s_nop 1` fence and a DPP read would read stale lanes silently.  tools/check_dpp_hazard.py
+    disassembles the built code object and checks every DPP read (and every MFMA operand produced by one) for a VALU write of its source
+    within two wait states; the checker itself is tested on synthetic code."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec_ = importlib.util.spec_from_file_location("check_dpp_hazard", os.path.join(root, "tools", "check_dpp_hazard.py"))
+    chk = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(chk)
+    head = "0000000000001000 <kern>:\n"
+    dpp = "\tv_fmac_f64_dpp v[4:5], v[166:167], v[114:115] row_newbcast:0 row_mask:0xf bank_mask:0xf // 0\n"
+    assert chk.scan(head + "\tv_mul_f64 v[166:167], v[2:3], v[8:9] // 0\n" + dpp)[2]                                  # written one slot earlier
+    assert chk.scan(head + "\tv_mul_f64 v[166:167], v[2:3], v[8:9] // 0\n\tv_mov_b32_e32 v1, v2 // 0\n" + dpp)[2]     # one instruction between: one wait state
+    assert not chk.scan(head + "\tv_mul_f64 v[166:167], v[2:3], v[8:9] // 0\n\ts_nop 1 // 0\n" + dpp)[2]              # the kernels' fence
+    assert not chk.scan(head + "\tv_mul_f64 v[160:161], v[2:3], v[8:9] // 0\n" + dpp)[2]                                 # another register
+    assert chk.scan(head + dpp + "\tv_mfma_f64_16x16x4_f64 a[0:7], v[4:5], v[6:7], a[0:7] // 0\n")[2]                    # DPP result straight into an MFMA
+    from goldfish_amd import build
+    build.build()
+    n, kernels, bad = chk.scan(chk.disassemble(build.LIB))
+    assert n > 1000 and any("kl_element_rec_kernel" in k for k in kernels) and any("pen_row16_kernel" in k for k in kernels), (n, kernels)
+    assert not bad, bad[:5]
