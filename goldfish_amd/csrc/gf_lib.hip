@@ -65,7 +65,7 @@ struct gf_handle {
     bool gather1 = true;                              // one-wave gather (GF_GATHER1=0 selects the four-wave gather)
     int pen_maxdeg = 0;                               // largest neighbour count of an interface control point
     bool pen_row16 = true;                            // p = 2, 3: pen_row16_kernel (one 16-lane row per visit; GF_PEN_ROW16=0: pen_owner_kernel)
-    bool pen_point16 = false;                         // GF_PEN_POINT16=1, p = 2, 3: pen_point16_kernel (16 lanes per mortar vertex, coalesced record writes); parity-tested, not yet faster than pen_point_kernel (196 vs 155 us on the 8 x 8-patch slice: 272 registers, one wave per SIMD)
+    bool pen_point16 = true;                          // p = 2, 3: pen_point16_kernel (16 lanes per mortar vertex, coalesced record writes; GF_PEN_POINT16=0: pen_point_kernel)
 
     template <class T> T* dalloc(size_t n) {
         void* p = nullptr; const size_t nb = (n > 0 ? n : 1) * sizeof(T);
@@ -159,7 +159,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             Q.entries = h->upload(H.pen_entries); Q.ent_ptr = h->upload(ep); Q.row_cp = h->upload(H.row_cp);
             Q.slots = H.degree <= 3 ? h->upload(H.pen_slots) : nullptr;
             if (const char* s = getenv("GF_PEN_ROW16")) h->pen_row16 = std::string(s) != "0";
-            if (const char* s = getenv("GF_PEN_POINT16")) h->pen_point16 = std::string(s) == "1";
+            if (const char* s = getenv("GF_PEN_POINT16")) h->pen_point16 = std::string(s) != "0";
             Q.nrow_groups = (long long)rp.size() - 1;
             for (long long g = 0; g + 1 < (long long)rp.size(); ++g) if (rp[g + 1] > rp[g]) pen_row[H.row_items[rp[g]].a] = 1;
             h->d_pbuf = h->dalloc<double>((size_t)H.npts * PB_STRIDE);
@@ -503,7 +503,9 @@ template <int P> static void run_functionals(gf_handle* h, int apply_bcs) {
     }
     const HostModel& H = h->H;
     if (H.npts > 0) {
-        hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf, 1);
+        bool done = false;
+        if constexpr (P <= 3) { if (h->pen_point16) { hipLaunchKernelGGL(pen_point16_kernel<P>, dim3((unsigned)((H.npts + 3) / 4)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf, 1); done = true; } }
+        if (!done) hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf, 1);
         hipLaunchKernelGGL(pen_energy_kernel, dim3((unsigned)((H.npts + 255) / 256)), dim3(256), 0, h->stream, (long long)H.npts, h->d_pbuf, h->d_pen_en);
     }
     HIPCHK(hipGetLastError());

@@ -5,18 +5,16 @@
 // 16-lane row takes the vertex (four vertices per wave):
 //   A  kinematics: lane c sums control point c of side A, then of side B, into its 30 partial sums of y (u, g1, g2 per side) and
 //      Y (G1, G2 per side); the row adds them up through LDS;
-//   B  six lanes of the row compute the SMALL per-vertex quantities of penalty_point (lane 0: normals and tangent with their derivatives,
-//      gradients g1, g2, cross-product tables; lanes 1-4: the cores Q B, v of the four Hessians of M . n; lane 5: the reference
-//      configuration) into a table of 315 doubles in LDS;
+//   B  the row computes the SMALL per-vertex quantities of penalty_point by role (lanes 0-5: one tangent-slot column each of the normal /
+//      tangent derivatives, gradients g1, g2 and cross-product tables; lanes 6-9: the cores Q B, v of the four Hessians of M . n; lanes
+//      10-15: the columns of the reference configuration) into a table of 315 doubles in LDS;
 //   C1 the 12 x 12 tangent block W = c0 ar (g1 g1^T + e1 H1 + g2 g2^T + e2 H2) block by block (AA, AB = BA^T, BB: the same closed form for
 //      every lane of a pass, one 3-term dot product per Hessian term) into LDS;
 //   C2 every entry of the record is a lookup in W plus rank-one terms: lane c writes the entries c, c + 16, ... -- consecutive lanes on
 //      consecutive addresses.
 // Same formulas as penalty_point (kl_point.hpp: s_terms, hess_M_dot_n, hess_M_dot_t), entry by entry; same record layout.
-// Status: opt-in (GF_PEN_POINT16=1).  Equal results (parity suite), but 196 us against pen_point_kernel's 155 us on the 8 x 8-patch slice:
-// lane 0's share of phase B holds ~250 registers (one wave per SIMD again); splitting it further (normals / tangent / tables by column)
-// is the open item.
-// Reference path: nonmatching_opt.py:745-752 (penalty energy of PENGoLINS, Herrema 2019) via its first and second variations.
+// Default for p = 2, 3 (GF_PEN_POINT16=0: pen_point_kernel).  8 x 8-patch slice: 97 us against pen_point_kernel's 155 us; the first version,
+// with the current configuration's table on one lane (~250 registers, one wave per SIMD), took 196 us.
 #pragma once
 #include "gf_element_mfma.hpp"
 
@@ -42,65 +40,86 @@ __device__ inline void hess_core(const double* g1, const double* g2, const doubl
 }
 __device__ inline void store_dn(double* T, const double Dn[3][6]) { for (int i = 0; i < 3; ++i) for (int c = 0; c < 6; ++c) T[6 * i + c] = Dn[i][c]; }
 
-// phase B: the per-vertex table, spread over six lanes of the vertex's row (role = lane in the row; the others idle)
+// phase B: the per-vertex table, spread over the 16 lanes of the vertex's row.  role 0..5: column c = role of the current configuration
+// (d/d(g1, g2)_c of the normals and the tangent, everything that is indexed by one tangent slot of a side); role 6..9: the cores of the
+// four Hessians of M . n; role 10..15: column role - 10 of the reference configuration (values and gradients only).  Every lane
+// recomputes the normals and the tangent it needs (a few dozen flops) instead of holding whole derivative arrays.
+__device__ __forceinline__ void unit_normal(const double* g1, const double* g2, double* n, double& j) {
+    double t[3]; cross3(g1, g2, t); j = sqrt(dot3(t, t));
+    for (int k = 0; k < 3; ++k) n[k] = t[k] / j;
+}
+// column c of Dn = (I - n n^T) / j * B and the B column itself
+__device__ __forceinline__ void dn_column(const double* g1, const double* g2, const double* n, double j, int c, double* bc, double* dn) {
+    double e[3] = {0, 0, 0}; e[c % 3] = 1.0;
+    if (c < 3) cross3(e, g2, bc); else cross3(g1, e, bc);
+    const double nc = dot3(n, bc);
+    for (int i = 0; i < 3; ++i) dn[i] = (bc[i] - n[i] * nc) / j;
+}
+// one tangent-slot column of a configuration (gA = (g1, g2) of side A, gB of side B): the entries c and 6 + c of the gradients of
+// s1 = nA . nB and s2 = at . (nA x nB); with T != nullptr also the column's part of the tables and (c == 0) the scalars
+__device__ inline void config_column(const double* gA, const double* gB, const double* tau, int c, double* T, double& g1a, double& g1b, double& g2a, double& g2b,
+                                     double& s1, double& s2, double& L, double* at) {
+    double nA[3], nB[3], jA, jB, tt[3];
+    unit_normal(gA, gA + 3, nA, jA); unit_normal(gB, gB + 3, nB, jB);
+    for (int k = 0; k < 3; ++k) tt[k] = tau[0] * gA[k] + tau[1] * gA[3 + k];
+    L = sqrt(dot3(tt, tt));
+    for (int k = 0; k < 3; ++k) at[k] = tt[k] / L;
+    double cAB[3], cBt[3], ctA[3];
+    cross3(nA, nB, cAB); cross3(nB, at, cBt); cross3(at, nA, ctA);
+    s1 = dot3(nA, nB); s2 = dot3(at, cAB);
+    double bcA[3], bcB[3], dnA[3], dnB[3], dt[3];
+    dn_column(gA, gA + 3, nA, jA, c, bcA, dnA);
+    dn_column(gB, gB + 3, nB, jB, c, bcB, dnB);
+    for (int i = 0; i < 3; ++i) dt[i] = tau[c / 3] * ((i == c % 3 ? 1.0 : 0.0) - at[i] * at[c % 3]) / L;
+    g1a = dot3(dnA, nB); g1b = dot3(dnB, nA);
+    g2a = dot3(dt, cAB) + dot3(dnA, cBt); g2b = dot3(dnB, ctA);
+    if (!T) return;
+    for (int k = 0; k < 3; ++k) { T[PT_BCA + 3 * c + k] = bcA[k]; T[PT_BCB + 3 * c + k] = bcB[k]; }
+    double t0[3], t1[3], t2[3];
+    cross3(nB, dnA, t0); cross3(nA, dnB, t1); cross3(at, dnB, t2);
+    for (int i = 0; i < 3; ++i) {
+        T[PT_DNA + 6 * i + c] = dnA[i]; T[PT_DNB + 6 * i + c] = dnB[i]; T[PT_DT + 6 * i + c] = dt[i];
+        T[PT_SBA + 6 * i + c] = t0[i]; T[PT_SAB + 6 * i + c] = t1[i]; T[PT_STB + 6 * i + c] = t2[i];
+    }
+    if (c == 0) {   // hess_M_dot_t with M = cAB: Ht[r][c] = tau[r / 3] tau[c / 3] Qt[r % 3][c % 3]
+        const double Ma = dot3(cAB, at), iL2 = 1.0 / (L * L);
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
+            T[PT_QT + 3 * a + b] = -(cAB[a] * at[b] + at[a] * cAB[b] + Ma * ((a == b ? 1.0 : 0.0) - 3.0 * at[a] * at[b])) * iL2;
+    }
+}
 __device__ inline void penalty_tables(int role, const double* y, const double* Y, const double* tau, double ad, double ar, double dt, double* T) {
     const double* gA = y + 3; const double* gB = y + 12;
-    if (role == 0) {
-        double nA[3], nB[3], jA, jB, DnA[3][6], DnB[3][6], Dt[3][6], at[3], L;
-        normal_derivs(gA, gA + 3, nA, jA, DnA);
-        normal_derivs(gB, gB + 3, nB, jB, DnB);
-        tangent_derivs(gA, gA + 3, tau, at, L, Dt);
-        double cAB[3], cBt[3], ctA[3];
-        cross3(nA, nB, cAB); cross3(nB, at, cBt); cross3(at, nA, ctA);
-        T[PT_SC] = dot3(nA, nB); T[PT_SC + 1] = dot3(at, cAB);                  // s1, s2 (turned into e1, e2 by the combine step)
-        for (int c = 0; c < 6; ++c) {
-            T[PT_G1 + c] = DnA[0][c] * nB[0] + DnA[1][c] * nB[1] + DnA[2][c] * nB[2];
-            T[PT_G1 + 6 + c] = DnB[0][c] * nA[0] + DnB[1][c] * nA[1] + DnB[2][c] * nA[2];
-            T[PT_G2 + c] = Dt[0][c] * cAB[0] + Dt[1][c] * cAB[1] + Dt[2][c] * cAB[2] + DnA[0][c] * cBt[0] + DnA[1][c] * cBt[1] + DnA[2][c] * cBt[2];
-            T[PT_G2 + 6 + c] = DnB[0][c] * ctA[0] + DnB[1][c] * ctA[1] + DnB[2][c] * ctA[2];
-        }
-        for (int c = 0; c < 6; ++c) {                                 // B columns of both sides
-            double e[3] = {0, 0, 0}, col[3]; e[c % 3] = 1.0;
-            if (c < 3) cross3(e, gA + 3, col); else cross3(gA, e, col);
-            for (int k = 0; k < 3; ++k) T[PT_BCA + 3 * c + k] = col[k];
-            if (c < 3) cross3(e, gB + 3, col); else cross3(gB, e, col);
-            for (int k = 0; k < 3; ++k) T[PT_BCB + 3 * c + k] = col[k];
-        }
-        {   // hess_M_dot_t with M = cAB: Ht[r][c] = tau[r / 3] tau[c / 3] Qt[r % 3][c % 3]
-            const double Ma = dot3(cAB, at), iL2 = 1.0 / (L * L);
-            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
-                T[PT_QT + 3 * a + b] = -(cAB[a] * at[b] + at[a] * cAB[b] + Ma * ((a == b ? 1.0 : 0.0) - 3.0 * at[a] * at[b])) * iL2;
-        }
-        store_dn(T + PT_DNA, DnA); store_dn(T + PT_DNB, DnB); store_dn(T + PT_DT, Dt);
-        for (int c = 0; c < 6; ++c) {
-            double colA[3] = {DnA[0][c], DnA[1][c], DnA[2][c]}, colB[3] = {DnB[0][c], DnB[1][c], DnB[2][c]}, t0[3], t1[3], t2[3];
-            cross3(nB, colA, t0); cross3(nA, colB, t1); cross3(at, colB, t2);
-            for (int i = 0; i < 3; ++i) { T[PT_SBA + 6 * i + c] = t0[i]; T[PT_SAB + 6 * i + c] = t1[i]; T[PT_STB + 6 * i + c] = t2[i]; }
-        }
-        T[PT_SC + 5] = dt; T[PT_SC + 6] = tau[0]; T[PT_SC + 7] = tau[1];
-    } else if (role <= 4) {                                           // the four Hessians of M . n: (gA, nB), (gB, nA), (gA, nB x at), (gB, at x nA)
-        double nA[3], nB[3], t3[3], jA, jB;
-        cross3(gA, gA + 3, t3); jA = sqrt(dot3(t3, t3)); for (int k = 0; k < 3; ++k) nA[k] = t3[k] / jA;
-        cross3(gB, gB + 3, t3); jB = sqrt(dot3(t3, t3)); for (int k = 0; k < 3; ++k) nB[k] = t3[k] / jB;
+    if (role < 6) {
+        double g1a, g1b, g2a, g2b, s1, s2, L, at[3];
+        config_column(gA, gB, tau, role, T, g1a, g1b, g2a, g2b, s1, s2, L, at);
+        T[PT_G1 + role] = g1a; T[PT_G1 + 6 + role] = g1b; T[PT_G2 + role] = g2a; T[PT_G2 + 6 + role] = g2b;
+        if (role == 0) { T[PT_SC] = s1; T[PT_SC + 1] = s2; T[PT_SC + 5] = dt; T[PT_SC + 6] = tau[0]; T[PT_SC + 7] = tau[1]; }   // s1, s2: turned into e1, e2 by the combine step
+    } else if (role < 10) {                                           // the four Hessians of M . n: (gA, nB), (gB, nA), (gA, nB x at), (gB, at x nA)
+        const int hq = role - 6;
+        double nA[3], nB[3], jA, jB;
+        unit_normal(gA, gA + 3, nA, jA); unit_normal(gB, gB + 3, nB, jB);
         double Mv[3];
-        if (role == 1) for (int k = 0; k < 3; ++k) Mv[k] = nB[k];
-        else if (role == 2) for (int k = 0; k < 3; ++k) Mv[k] = nA[k];
+        if (hq == 0) for (int k = 0; k < 3; ++k) Mv[k] = nB[k];
+        else if (hq == 1) for (int k = 0; k < 3; ++k) Mv[k] = nA[k];
         else {
             double tt[3], at[3];
             for (int k = 0; k < 3; ++k) tt[k] = tau[0] * gA[k] + tau[1] * gA[3 + k];
             const double L = sqrt(dot3(tt, tt));
             for (int k = 0; k < 3; ++k) at[k] = tt[k] / L;
-            if (role == 3) cross3(nB, at, Mv); else cross3(at, nA, Mv);
+            if (hq == 2) cross3(nB, at, Mv); else cross3(at, nA, Mv);
         }
-        const bool sideA = role == 1 || role == 3;
-        hess_core(sideA ? gA : gB, (sideA ? gA : gB) + 3, sideA ? nA : nB, sideA ? jA : jB, Mv, T + PT_QB + 18 * (role - 1), T + PT_V + 3 * (role - 1));
-    } else if (role == 5) {                                           // reference configuration: values and gradients only
-        double S1, S2, G1[12], G2[12], Lr, At[3];
-        s_terms(Y, Y + 6, tau, S1, S2, G1, G2, nullptr, nullptr, Lr, At);
-        for (int k = 0; k < 12; ++k) { T[PT_GR1 + k] = G1[k]; T[PT_GR2 + k] = G2[k]; }
-        T[PT_SC + 8] = At[0]; T[PT_SC + 9] = At[1]; T[PT_SC + 10] = At[2];
-        T[PT_SC + 2] = dt * Lr;                                       // c0
-        T[PT_SC + 3] = S1; T[PT_SC + 4] = S2;                          // (replaced by c0 ar, c0 ad in the combine step)
+        const bool sideA = hq == 0 || hq == 2;
+        hess_core(sideA ? gA : gB, (sideA ? gA : gB) + 3, sideA ? nA : nB, sideA ? jA : jB, Mv, T + PT_QB + 18 * hq, T + PT_V + 3 * hq);
+    } else {                                                          // reference configuration: values and gradients only
+        const int c = role - 10;
+        double g1a, g1b, g2a, g2b, S1, S2, Lr, At[3];
+        config_column(Y, Y + 6, tau, c, nullptr, g1a, g1b, g2a, g2b, S1, S2, Lr, At);
+        T[PT_GR1 + c] = g1a; T[PT_GR1 + 6 + c] = g1b; T[PT_GR2 + c] = g2a; T[PT_GR2 + 6 + c] = g2b;
+        if (c == 0) {
+            T[PT_SC + 8] = At[0]; T[PT_SC + 9] = At[1]; T[PT_SC + 10] = At[2];
+            T[PT_SC + 2] = dt * Lr;                                   // c0
+            T[PT_SC + 3] = S1; T[PT_SC + 4] = S2;                      // (replaced by c0 ar, c0 ad in the combine step)
+        }
     }
 }
 // combine step (one lane, behind the six): e1, e2, the scaled constants, the gradient of the energy, the energy
@@ -197,10 +216,10 @@ __global__ __launch_bounds__(64) void pen_point16_kernel(DevModel M, DevPenalty 
         s_y[g][k] = s;
     }
     wave_lds_sync();
-    // ---- B: the small quantities (six lanes per vertex), then the combine step
+    // ---- B: the small quantities (all 16 lanes of the row, by role), then the combine step
     double* T = s_buf[g]; double* W = s_buf[g] + PT_SIZE;
     const double ad = Q.if_alpha[2 * itf], ar = Q.if_alpha[2 * itf + 1];
-    if (c < 6) penalty_tables(c, s_y[g], s_y[g] + 18, Q.pt_tau + 2 * v, ad, ar, Q.pt_wt[v], T);
+    penalty_tables(c, s_y[g], s_y[g] + 18, Q.pt_tau + 2 * v, ad, ar, Q.pt_wt[v], T);
     wave_lds_sync();
     if (c == 0) penalty_combine(s_y[g], ad, ar, T);
     wave_lds_sync();

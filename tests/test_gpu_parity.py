@@ -162,8 +162,8 @@ def test_row_record_path_segment_lengths_and_block_path(oracle_lib, monkeypatch,
 
 def test_penalty_kernel_variants(oracle_lib, monkeypatch):
     """The penalty kernels come in two generations: pen_row16_kernel (default for p = 2, 3: one 16-lane row per visit, LDS accumulators)
-    vs pen_owner_kernel (GF_PEN_ROW16=0; p = 4 always), and pen_point_kernel (default) vs pen_point16_kernel (GF_PEN_POINT16=1: 16 lanes
-    per mortar vertex).  Every combination against the oracle; each is bitwise reproducible run to run."""
+    vs pen_owner_kernel (GF_PEN_ROW16=0; p = 4 always), and pen_point16_kernel (default for p = 2, 3: 16 lanes per mortar vertex) vs
+    pen_point_kernel (GF_PEN_POINT16=0; p = 4 always).  Every combination against the oracle; each is bitwise reproducible run to run."""
     from goldfish_amd import _lib
     from oracle.oracle_py import Oracle
     for case in ("tbeam2_p2", "C3_wing16_refdata", "slr9_nurbs_p3_projected_load"):
