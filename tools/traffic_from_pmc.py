@@ -30,7 +30,7 @@ def in_full_pass(k):
     if k.startswith(("kl_element", "kl_gather")): return "true" in k or k.startswith(("kl_element_mfma2", "kl_element_kernel")) or "<" not in k
     if k.startswith("pen_owner"): return k.replace(" ", "").split("<")[1].startswith(("3,2,true,true", "2,2,true,true", "4,"))
     if k.startswith("pen_row16"): return k.replace(" ", "").endswith("true,true>")
-    return k.startswith(("pen_point", "kl_rgather", "zero_rows", "residual_finish"))
+    return k.startswith(("pen_point", "kl_rgather", "zero_rows", "residual_finish"))      # pen_point_kernel / pen_point16_kernel: one launch per pass
 out["full_pass_kernels"] = sorted(k for k in kern if in_full_pass(k))
 out["full_pass_bytes_per_step"] = sum(kern[k]["hbm_side_bytes_corrected_per_launch"] for k in kern if in_full_pass(k))
 # FP64 work per launch as the SQ counters see it (tools/profile_round.sh, fourth pass): flop = 512 * MFMA_MOPS_F64 + 64 * (2 FMA + ADD + MUL + TRANS)
