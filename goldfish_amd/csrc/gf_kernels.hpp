@@ -56,8 +56,10 @@ __device__ __forceinline__ void rationalize6(const double* Nb, const double* W, 
     R[5] = (Nb[5] - R[1] * W[2] - R[2] * W[1] - R[0] * W[5]) * iW;
 }
 
-#ifdef GF_STAMPS
+#if defined(GF_STAMPS) || defined(GF_STAMPS_PEN)
 __device__ unsigned long long g_stamps[8];
+#endif
+#ifdef GF_STAMPS
 #define GF_STAMP(slot, t0) do { const unsigned long long t1_ = clock64(); stamp_acc[slot] += t1_ - (t0); (t0) = t1_; } while (0)
 #else
 #define GF_STAMP(slot, t0) do { } while (0)

@@ -826,7 +826,7 @@ int gf_penalty_dxi(gf_handle* h, double* blocks, int64_t n, int32_t* windows, in
     return gf_penalty_dxi_range(h, 0, (int64_t)h->H.npts, blocks, n, windows, nw);
 }
 
-#ifdef GF_STAMPS
+#if defined(GF_STAMPS) || defined(GF_STAMPS_PEN)
 // diagnostic build only: cycle sums per kernel section (lane 0 of every wave), then reset
 int gf_debug_stamps(unsigned long long out[8]) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;

@@ -10,7 +10,14 @@
 // visits' data is requested before the current four are contracted.  ~65 instead of ~190 instructions per visit.
 // Summation order per entry: every 16-lane row walks its quarter of the visit list in order; where several rows hit one address in
 // the same instruction the LDS unit serialises the lanes in a fixed order -- run-to-run reproducible (tests compare bitwise).
-// Measured and dropped: a second batch of data in flight (513 / 444 vs 487 / 426 us on the 8 x 8-patch slice before / after the bank fix); one
+// Where the time goes (clock64 stamps, 8 x 8-patch slice, 24 visits per row on average): prologue 5.6 k, visit loop 31 k (5.2 k per batch of
+// four visits, with two waves per SIMD), epilogue 6.1 k cycles per wave.  Measured without effect on that: run-length accumulation in
+// registers (ds_add_f64 only when a lane's slot changes), a loop without the `cur = nxt` copy at its back edge (the compiler waits for the
+// freshly requested registers there: s_waitcnt vmcnt(1) + 30 moves) with unconditional loads masked at use (exact vmcnt counts, the next
+// batch really in flight), fewer masks: 426-441 us each -- neither the LDS unit nor the load latency nor the VALU count is the limit;
+// the 37 vector loads per lane and batch (8-byte, four vertex records per instruction) through the texture addresser are the suspect
+// (a record layout with the three Hessian rows of a w value contiguous would need 26).
+// Measured and dropped earlier: a second batch of data in flight (513 / 444 vs 487 / 426 us on the 8 x 8-patch slice before / after the bank fix); one
 // launch per class of neighbour counts (<= 64, <= 88, rest: more waves per CU for the narrow rows, but three tails: 463 vs 426 us).
 // The kernel WRITES the rows (the gather adds the shell part), like pen_owner_kernel<.., ADD = false>.
 // Reference path: nonmatching_opt.py:745-752, 789-801, 861-887 (penalty residual and its blocks of dR/du, dR/dCP).
