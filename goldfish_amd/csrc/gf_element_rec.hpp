@@ -452,7 +452,10 @@ __global__ __launch_bounds__(64) void kl_gather_rec_kernel(DevModel M, long long
         for (int v = 0; v < NV; ++v) {
             const int mul = v < NP1 ? NT * 16 : (v < NP1 + NP3 ? 3 * NT * 4 : (v == NP1 + NP3 ? 1 : 4));
             const bool ok = ((tk[v] >> 20) & 1) && ((I.pm >> ((tk[v] >> 16) & 7)) & 1);
-            I.v[v] = ok ? Rja[to[v] + rra * mul] : 0.0;
+            // unconditional load (an absent pair reads the head of the row record; its value is never added): a predicated load is a branch, and
+            // behind branches the waitcnt insertion stops counting -- every ds_add_f64 then waited for ALL loads in flight (vmcnt(0)),
+            // the next item's included
+            I.v[v] = Rja[ok ? to[v] + rra * mul : 0];
         }
         return I;
     };
