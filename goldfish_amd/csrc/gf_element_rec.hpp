@@ -20,6 +20,7 @@
 
 namespace gf {
 
+constexpr int REC_MAX_NEL = 255;      // elements per work item (HostModel::build_rec cuts longer strips)
 template <bool WITHC> struct RecCfg { static constexpr int NT = WITHC ? 18 : 9, A2 = 64 * NT, SZ = 112 * NT, QK = 0, QH = 6, QC = 9; };
 
 struct RecOut { double* rec; double* rblk; int rec_rows; };
@@ -30,8 +31,18 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
     using RC = RecCfg<WITHC>;
     constexpr int P1 = P + 1, NB = P1 * P1, NG = NB, ND = 3 * NB, NGRP = (NG + 3) / 4, TS = P1 * 3 * P1;
     const int tid = threadIdx.x, x = tid & 15, kk = tid >> 4;
-    const WalkItem it = items[blockIdx.x];
+    // The work item and the patch fields the element loop needs are wave-uniform but arrive through vector loads (the compiler does not prove
+    // the addresses uniform); read inside the loop each of them is a load behind s_waitcnt vmcnt(0) -- and vmcnt also covers the 72 record
+    // stores of the previous element.  They are read ONCE here into scalar registers, the items' span indices go to LDS.
+    auto uni = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+    auto uni64 = [&](long long x) { return (long long)(((unsigned long long)(unsigned)uni((int)((unsigned long long)x >> 32)) << 32) | (unsigned)uni((int)(unsigned long long)x)); };
+    WalkItem it = items[blockIdx.x];
+    it.patch = uni(it.patch); it.eu = uni(it.eu); it.ev0 = uni(it.ev0); it.nel = uni(it.nel); it.iu0 = uni(it.iu0);
     const PatchDev& Pt = M.patches[it.patch];
+    const int p_nu = uni(Pt.nu), p_nelu = uni(Pt.nelu), p_tabu = uni(Pt.tabu), p_tabv = uni(Pt.tabv), p_wu = uni(Pt.wu), p_wv = uni(Pt.wv), p_spv = uni(Pt.spv);
+    const long long p_cp_off = uni64(Pt.cp_off), p_elem_off = uni64(Pt.elem_off);
+    __shared__ int s_iv[REC_MAX_NEL + 1];               // first control-point row of every element of the item (+ one behind)
+    for (int k = threadIdx.x; k <= it.nel && k <= REC_MAX_NEL; k += 64) s_iv[k] = M.ints[p_spv + it.ev0 + (k < it.nel ? k : it.nel - 1)] - P + (k < it.nel ? 0 : 4);
     // patch constants (E, nu, f[3], pd[3]: contiguous in PatchDev) staged in LDS: read from memory inside the Gauss-point loop they
     // are vector loads behind a vmcnt wait each (the compiler cannot move them across stores), held in registers they cost 16 VGPRs
     __shared__ double s_pc[8];
@@ -78,13 +89,13 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
     auto fetch = [&](int ev, int iv0f) {
         Fetch F; F.cp = double2{0.0, 0.0}; F.tv = 0.0; F.wv = 0.0;
         if (pa_cp < NB) {
-            const long long g = Pt.cp_off + (it.iu0 + pa_ju) + (long long)(iv0f + pa_jv) * Pt.nu;
+            const long long g = p_cp_off + (it.iu0 + pa_ju) + (long long)(iv0f + pa_jv) * p_nu;
             if (pa_q < 2) F.cp = reinterpret_cast<const double2*>(M.cp4 + 4 * g)[pa_q];
             else if (pa_q == 2) { F.cp.x = M.u[3 * g]; F.cp.y = M.u[3 * g + 1]; }
             else { F.cp.x = M.u[3 * g + 2]; F.cp.y = M.h[g]; }
         }
-        if (tid < TS) F.tv = M.tab[Pt.tabv + ev * TS + tid];
-        if (tid < P1) F.wv = M.tab[Pt.wv + ev * P1 + tid];
+        if (tid < TS) F.tv = M.tab[p_tabv + ev * TS + tid];
+        if (tid < P1) F.wv = M.tab[p_wv + ev * P1 + tid];
         return F;
     };
     auto park = [&](const Fetch& F, int iv0f, int buf) {
@@ -92,10 +103,10 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
         if (tid < TS) s_tv[buf][tid] = F.tv;
         if (tid < P1) s_wgv[buf][tid] = F.wv;
     };
-    const int iv_first = M.ints[Pt.spv + it.ev0] - P;
+    const int iv_first = s_iv[0];
     {   // prologue: u table and weights of the strip, inputs of the first element
-        if (tid < TS) s_tu[tid] = M.tab[Pt.tabu + it.eu * TS + tid];
-        if (tid < P1) s_wgu[tid] = M.tab[Pt.wu + it.eu * P1 + tid];
+        if (tid < TS) s_tu[tid] = M.tab[p_tabu + it.eu * TS + tid];
+        if (tid < P1) s_wgu[tid] = M.tab[p_wu + it.eu * P1 + tid];
         const Fetch F = fetch(it.ev0, iv_first);
         park(F, iv_first, 0);
     }
@@ -141,10 +152,10 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
 #endif
     for (int t = 0; t < it.nel; ++t) {
         const int ev = it.ev0 + t, buf = t & 1;
-        const long long e = Pt.elem_off + it.eu + (long long)ev * Pt.nelu;
-        const int iv0 = M.ints[Pt.spv + ev] - P;
+        const long long e = p_elem_off + it.eu + (long long)ev * p_nelu;
+        const int iv0 = s_iv[t];
         const bool more = t + 1 < it.nel;
-        const int iv0n = more ? M.ints[Pt.spv + ev + 1] - P : iv0 + 4;      // after the last element of the item every row leaves
+        const int iv0n = s_iv[t + 1];                                       // after the last element of the item every row leaves (iv0 + 4)
         // ---- phase 0: this element's control points from the ring
         wave_lds_sync();
         if (tid < NB) {

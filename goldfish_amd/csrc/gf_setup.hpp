@@ -510,6 +510,7 @@ inline void HostModel::build_rec(int seg_len) {
     for (int s = 0; s < n_owned; ++s) {
         const PatchDev& P = patches[s];
         int nseg = seg_len > 0 ? std::max(1, (P.nelv + seg_len / 2) / std::max(seg_len, P1)) : cut;
+        nseg = std::max(nseg, (P.nelv + 254) / 255);                   // the kernel keeps an item's span indices in LDS: <= 255 elements per item
         while (nseg > 1 && P.nelv / nseg < P1) --nseg;                 // every segment holds at least p + 1 elements: a pair lies in at most two
         RecPatch& R = rec_patch[s];
         R.item_off = (int)rec_items.size(); R.nseg = nseg;
