@@ -91,7 +91,6 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
     }
     for (int k = tid; k < P1 * 3 * P1; k += 64) { s_tu[k] = M.tab[ed.tabu + k]; s_tv[k] = M.tab[ed.tabv + k]; }
     if (tid < P1) { s_wg[tid] = M.tab[ed.wu + tid]; s_wg[P1 + tid] = M.tab[ed.wv + tid]; }
-    RowLane RL; RL.init(x);
     wave_lds_sync();
 
     // ---- phase 1: one lane per Gauss point (sum-factorised control-point sums, quotient rule, pointwise record)
@@ -174,7 +173,15 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
             // -- row r of G and Hc
             double gR[15], hR[15];
             for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
-            if (doK || doC) { RL.template expand<WITHC>(im, gR, hR); dpp_source_fence(gR); if constexpr (WITHC) dpp_source_fence(hR); }
+            if (doK || doC) {
+                // The lane constants of the row expansion (13 offsets, 10 masks) are re-derived from the lane index here instead of being
+                // kept across the group loop: kept, a dozen of them were spilled and came back through scratch loads, each behind an
+                // s_waitcnt vmcnt(0), nine times per group (the asm keeps the derivation inside the loop).
+                int xl = x;
+                asm volatile("" : "+v"(xl));
+                RowLane RLg; RLg.init(xl);
+                RLg.template expand<WITHC>(im, gR, hR); dpp_source_fence(gR); if constexpr (WITHC) dpp_source_fence(hR);
+            }
             // -- residual (first pass only) and dR/dh prefactors of both a tiles
             const double ls = (has_bf && tb == 0) ? load_scalar(im, ppd) : 0.0;
             if (tb == 0) {
