@@ -16,7 +16,8 @@
 // freshly requested registers there: s_waitcnt vmcnt(1) + 30 moves) with unconditional loads masked at use (exact vmcnt counts, the next
 // batch really in flight), fewer masks: 426-441 us each -- neither the LDS unit nor the load latency nor the VALU count is the limit;
 // the 37 vector loads per lane and batch (8-byte, four vertex records per instruction) through the texture addresser are the suspect
-// (a record layout with the three Hessian rows of a w value contiguous would need 26).
+// (a record layout with the three Hessian rows of a w value contiguous would need 26; dropping 9 of the 37 loads in a timing experiment
+// gave 384 instead of 426 us, so that layout is worth about 7 %).
 // Measured and dropped earlier: a second batch of data in flight (513 / 444 vs 487 / 426 us on the 8 x 8-patch slice before / after the bank fix); one
 // launch per class of neighbour counts (<= 64, <= 88, rest: more waves per CU for the narrow rows, but three tails: 463 vs 426 us).
 // The kernel WRITES the rows (the gather adds the shell part), like pen_owner_kernel<.., ADD = false>.
