@@ -79,7 +79,11 @@ def build(rise0=3.0, nel_u=(5, 6, 5, 6), nel_v=(2, 3, 2, 3), p=3, mortar_nel=8, 
 
 class ReducedShapeProblem:
 
-    def __init__(self, nm, newton_rtol=1e-10):
+    def __init__(self, nm, newton_rtol=1e-3):
+        # rtol = the reference's default (DispStatesComp.init_parameters, nonlinear_solver_rtol=1e-3).  With E h / |f| = 1e10 the response is
+        # linear to 1e-9 and the residual has an evaluation floor of ~4e-5 |R_0| (strain = difference of two metrics of size 6, times E h):
+        # the first Newton step from u = 0 -- where the strain is exactly zero -- IS the accurate state, further steps only add the
+        # floor's noise to it (profiles/r03_newton_history.txt).
         self.nm = nm
         self.disp, self.wint = DispImOpeartion(nm), IntEnergyExOperation(nm)
         self.D = nm.shopt_dcpsurf_fedcpffd.tocsr()                       # surface control points <- FFD control points

@@ -25,7 +25,7 @@ from goldfish_amd.operations.int_energy_exop import IntEnergyExOperation  # noqa
 
 class SlidingWebProblem:
 
-    def __init__(self, num_el=4, newton_rtol=1e-11):
+    def __init__(self, num_el=4, newton_rtol=1e-8):
         spec = G.tbeam_2patch(num_el, load=(0.0, 0.0, -1.0), tip_load=0.0)
         spec.body_force = [[0.0, 0.0, -1.0], [0.0, 0.0, 0.0]]               # the flange carries the load: symmetric about x = 0
         self.nm = nm = NonMatchingOptFFD.from_spec(spec)

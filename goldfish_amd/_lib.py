@@ -3,6 +3,7 @@ fallback: a missing library or a missing GPU raises."""
 import ctypes as C
 import os
 import weakref
+from collections.abc import Mapping
 
 import numpy as np
 
@@ -66,42 +67,46 @@ def _check(rc, exc=RuntimeError):
         raise exc(lib().gf_last_error().decode())
 
 
-class _LazyFields(dict):
-    """dict of the results of a functional evaluation whose gradient fields are fetched from the device on first access."""
+class _LazyFields(Mapping):
+    """Results of a functional evaluation; the gradient fields are fetched from the device on first access (a read-only
+    mapping: iteration, len, keys / values / items and dict(...) see every field, fetched or not)."""
 
-    def __init__(self, dev, fields):
-        super().__init__()
-        self._dev, self._pending = dev, dict(fields)
+    def __init__(self, dev, fields, values=()):
+        self._dev, self._pending, self._data = dev, dict(fields), dict(values)
 
     def _fetch(self, key):
-        field, shape = self._pending.pop(key)
+        field, shape = self._pending[key]
         arr = np.zeros(shape)
         _check(lib().gf_get_functional_gradient(self._dev.h, field, _dp(arr), arr.size))
-        dict.__setitem__(self, key, arr)
+        self._data[key] = arr
+        del self._pending[key]                   # only after a successful fetch
 
-    def __missing__(self, key):
+    def __getitem__(self, key):
         if key in self._pending:
             self._fetch(key)
-            return dict.__getitem__(self, key)
-        raise KeyError(key)
+        return self._data[key]
+
+    def __setitem__(self, key, value):
+        self._pending.pop(key, None)
+        self._data[key] = value
+
+    def __iter__(self):
+        yield from self._data
+        yield from self._pending
+
+    def __len__(self):
+        return len(self._data) + len(self._pending)
 
     def __contains__(self, key):
-        return dict.__contains__(self, key) or key in self._pending
-
-    def get(self, key, default=None):
-        return self[key] if key in self else default
-
-    def keys(self):
-        self.materialize()
-        return dict.keys(self)
-
-    def items(self):
-        self.materialize()
-        return dict.items(self)
+        return key in self._data or key in self._pending
 
     def materialize(self):
         for key in list(self._pending):
             self._fetch(key)
+        return self._data
+
+    def copy(self):
+        return dict(self.materialize())
 
 
 class DeviceModel:
@@ -220,8 +225,8 @@ class DeviceModel:
         null = C.POINTER(C.c_double)()
         _check(lib().gf_functionals(self.h, _dp(out), null, null, null, null, null, int(apply_bcs)))
         g = _LazyFields(self, {"dWdu": (0, (self.ndof,)), "dWdcp": (1, (3, self.total_cp)), "dWdh": (2, (self.total_cp,)),
-                               "dVdcp": (3, (3, self.total_cp)), "dVdh": (4, (self.total_cp,))})
-        g.update(Wint=out[0], volume=out[1], Wpen=out[2])
+                               "dVdcp": (3, (3, self.total_cp)), "dVdh": (4, (self.total_cp,))},
+                        dict(Wint=out[0], volume=out[1], Wpen=out[2]))
         self._lazy_fun = weakref.ref(g)           # only a result somebody still holds has to be completed before the buffer is reused
         return g
 

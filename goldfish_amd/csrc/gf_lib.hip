@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -804,7 +805,14 @@ int gf_penalty_dxi_range(gf_handle* h, int64_t v_first, int64_t v_count, double*
             h->d_pt_nu2 = h->dalloc<double>(H.pt_nu2.size());
             HIPCHK(hipMemcpy(h->d_pt_nu2, H.pt_nu2.data(), H.pt_nu2.size() * sizeof(double), hipMemcpyHostToDevice));
         }
-        if (h->dxi_doubles < need) { h->d_dxi = h->dalloc<double>((size_t)need); h->dxi_doubles = need; }   // kept between calls (no hipMalloc / hipFree per call)
+        if (h->dxi_doubles < need) {                           // kept between calls (no hipMalloc / hipFree per call); a larger range replaces the buffer
+            if (h->d_dxi) {
+                HIPCHK(hipStreamSynchronize(h->stream));
+                h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), (void*)h->d_dxi), h->allocs.end());
+                (void)hipFree(h->d_dxi); h->bytes -= h->dxi_doubles * (long long)sizeof(double); h->d_dxi = nullptr; h->dxi_doubles = 0;
+            }
+            h->d_dxi = h->dalloc<double>((size_t)need); h->dxi_doubles = need;
+        }
         double* d_out = h->d_dxi;
         const long long nt = (long long)v_count * 6;
         switch (H.degree) {

@@ -110,18 +110,18 @@ class NonMatchingOpt:
             else:
                 self.interfaces.append(Interface(a, b, ca, cb))
         self.num_intersections = len(self.interfaces)
-        self._dev = None
+        self._drop_device()
 
     def set_residuals(self, residuals, residuals_deriv=None):
         """nonmatching_opt.py:433-452 (the derivative forms are built inside the kernels)."""
         assert len(residuals) == self.num_splines
         self.residuals = list(residuals)
-        self._dev = None
+        self._drop_device()
 
     def set_point_sources(self, point_sources=[], point_source_inds=[]):
         self.point_sources = list(point_sources)
         self.point_source_inds = list(point_source_inds)
-        self._dev = None
+        self._drop_device()
 
     # ------------------------------------------------------------------ design variables
     def set_shopt_surf_inds(self, opt_field, shopt_surf_inds):
@@ -435,28 +435,60 @@ class NonMatchingOpt:
     # ------------------------------------------------------------------ direct solves with K
     linear_solver = os.environ.get("GF_LINEAR_SOLVER", "device")   # "device": block-banded L D L^T on the GPU (default); "host": scipy SuperLU on a copy of K
 
-    def solve_K(self, rhs):
-        """x = K^{-1} rhs (= K^{-T} rhs: K is symmetric) with the tangent currently assembled on the device.
-        ``linear_solver == "device"`` (default): bandwidth-reducing ordering once on the host, then every call after a new
-        assembly is a block-banded L D L^T factorisation + substitutions + iterative refinement on the GPU
-        (goldfish_amd/_solver.py, csrc/gf_solver.hip); K's values are read in place from the library's buffer.
-        ``"host"``: scipy SuperLU on a host copy of K (what MUMPS does in the reference; kept as the cross-check of the tests).
-        Replaces GOLDFISH/utils/opt_utils.py:156-209 (MUMPS on a copy of K per call)."""
-        rhs = np.asarray(rhs, float)
-        ver = getattr(self, "_k_version", 0)
-        if self.linear_solver == "device":
-            from . import _solver
-            if getattr(self, "_dsolver", None) is None:
-                self._dsolver = _solver.DeviceSolver(self.dev)
-                self._dsolver_version = ver
-            elif self._dsolver_version != ver:
-                self._dsolver.refactor()
-                self._dsolver_version = ver
-            return self._dsolver.solve(rhs)
+    linear_solve_rtol = 1e-6      # |b - K x| / |b| above which a device solve is rejected (unpivoted L D L^T on an indefinite / near-singular tangent)
+
+    def _drop_device(self):
+        """The device model is stale (coupling, loads or intersections changed): close it together with everything that
+        borrows its buffers (the factorisation reads K in place) or was computed for it."""
+        ds = getattr(self, "_dsolver", None)
+        if ds is not None:
+            ds.close()
+        if self._dev is not None:
+            self._dev.close()
+        self._dev = self._dsolver = self._hlu = None
+        self._touch()
+
+    def _host_solve(self, rhs, ver):
         from scipy.sparse.linalg import splu
         if getattr(self, "_hlu", None) is None or self._hlu_version != ver:
             self._hlu, self._hlu_version = splu(self.dev.csr(_lib.MAT_K).tocsc()), ver
         return self._hlu.solve(rhs)
+
+    def solve_K(self, rhs):
+        """x = K^{-1} rhs (= K^{-T} rhs: K is symmetric) with the tangent currently assembled on the device.
+        ``linear_solver == "device"`` (default): bandwidth-reducing ordering once on the host, then every call after a new
+        assembly is a block-banded L D L^T factorisation + substitutions + iterative refinement on the GPU
+        (goldfish_amd/_solver.py, csrc/gf_solver.hip); K's values are read in place from the library's buffer.  The
+        factorisation does not pivot across tiles: every solve is checked (relative residual after refinement, finite
+        values) and one that fails -- or a band that does not fit the device, or a zero pivot -- falls back, with a warning,
+        to the host path for this K.
+        ``"host"``: scipy SuperLU on a host copy of K (what MUMPS does in the reference; kept as the cross-check of the tests).
+        Replaces GOLDFISH/utils/opt_utils.py:156-209 (MUMPS on a copy of K per call)."""
+        rhs = np.asarray(rhs, float)
+        ver = getattr(self, "_k_version", 0)
+        if self.linear_solver == "device" and getattr(self, "_dsolver_failed_version", None) != ver:
+            from . import _solver
+            why = None
+            try:
+                if getattr(self, "_dsolver", None) is None or self._dsolver.D is not self.dev:
+                    self._dsolver = _solver.DeviceSolver(self.dev)
+                    self._dsolver_version = ver
+                elif self._dsolver_version != ver:
+                    self._dsolver.refactor()
+                    self._dsolver_version = ver
+                x = self._dsolver.solve(rhs)
+                rr = self._dsolver.rel_residual
+                self.linear_solve_relative_residual = rr
+                if np.all(np.isfinite(x)) and rr <= self.linear_solve_rtol:
+                    return x
+                why = "relative residual %.3e > %.1e after refinement" % (rr, self.linear_solve_rtol)
+            except RuntimeError as e:
+                why = str(e)
+                self._dsolver = None
+            import warnings
+            warnings.warn("solve_K: device L D L^T rejected for this tangent (%s); falling back to the host sparse LU" % why, RuntimeWarning)
+            self._dsolver_failed_version = ver
+        return self._host_solve(rhs, ver)
 
     def RIGA(self):
         """Non-matching residual in IGA dofs, Dirichlet rows zeroed (nonmatching_opt.py:941-948)."""
@@ -535,10 +567,7 @@ class NonMatchingOpt:
             sub = self.xi_flat[c2x.xi_flat_inds[i]:c2x.xi_flat_inds[i + 1]]
             a, b = self.mapping_list[g]
             self.interfaces[g] = Interface(a, b, sub[:2 * n].reshape(-1, 2), sub[2 * n:].reshape(-1, 2))
-        if self._dev is not None:
-            self._dev.close()
-        self._dev = None
-        self._dsolver = self._hlu = None                       # factorisations belong to the old coupling pattern
+        self._drop_device()                                    # factorisations belong to the old coupling pattern
 
     def dRIGAdxi(self):
         """d RIGA / d xi_flat (nonmatching_opt.py:1042-1088), ndof x xi_size, Dirichlet rows zeroed: the device returns the
@@ -602,47 +631,72 @@ class NonMatchingOpt:
         self._assemble(_lib.ASM_R | _lib.ASM_K)
         du = self.solve_K(-self.dev.residual())
         self.update_uIGA(self.u_iga + du)
-        return self.u_iga
+        return self.u_iga.copy()
+
+    newton_step_rtol = 1e-9          # |du| / |u| below which a residual stuck at its round-off floor counts as a converged state
+    newton_raise_unconverged = False  # True: an unconverged Newton solve raises instead of warning
 
     def solve_nonlinear_nonmatching_problem(self, solver="direct", ref_error=None, rtol=1e-3, max_it=30,
                                             zero_mortar_funcs=True, iga_dofs=True, POINT_SOURCE=True):
         """Newton iteration on R(u) = 0 (PENGoLINS; used by DispImOpeartion.solve_nonlinear,
-        GOLDFISH/operations/disp_imop.py:38-44: max_it=30, rtol=1e-3, start from zero when
-        zero_mortar_funcs)."""
+        GOLDFISH/operations/disp_imop.py:38-44: max_it=30, rtol=1e-3 relative to the first residual, start from zero when
+        zero_mortar_funcs).  Plain Newton as in the reference, with two safeguards it does not have:
+
+        * backtracking: after the first step (the linear solution, whose residual legitimately exceeds |R_0| for a
+          geometrically nonlinear shell) a step that does not reduce |R| is halved, at most four times;
+        * honesty about the end of the iteration: ``newton_converged`` is True when |R| / ref < rtol, or when the Newton
+          correction has become negligible (|du| <= newton_step_rtol |u|) -- the residual of a thin, stiffly coupled shell
+          has an evaluation floor of about eps E h |A| (strain = difference of metrics) that a tight rtol cannot pass.
+          Every solve that ends otherwise warns (RuntimeWarning) or raises (``newton_raise_unconverged``);
+          ``newton_history`` keeps (|R| / ref, |du| / |u|, step length) per iteration."""
         if zero_mortar_funcs:
             self.update_uIGA(np.zeros(self.vec_iga_dof))
-        nrm, hist, converged = float("inf"), [], False
-        for it in range(max_it):
-            self._assemble(_lib.ASM_R | _lib.ASM_K)
-            R = self.dev.residual()
-            nrm = np.linalg.norm(R)
-            if it == 0 and ref_error is None:
-                ref_error = nrm if nrm > 0 else 1.0
+        self._assemble(_lib.ASM_R | _lib.ASM_K)
+        R = self.dev.residual()
+        nrm = float(np.linalg.norm(R))
+        if ref_error is None:
+            ref_error = nrm if nrm > 0 else 1.0
+        hist, self.newton_history = [nrm], []
+        converged, by_step, stagnated, it = nrm / ref_error < rtol, False, False, 0
+        while not converged and it < max_it:
+            u0 = self.u_iga.copy()
+            du = self.solve_K(-R)
+            lam = 1.0
+            while True:
+                self.update_uIGA(u0 + lam * du)
+                self._assemble(_lib.ASM_R | _lib.ASM_K)
+                Rn = self.dev.residual()
+                nn = float(np.linalg.norm(Rn))
+                near_floor = min(hist) < 0.1 * max(hist) and nn < 10.0 * min(hist)   # jitter at the evaluation floor is not a failed step
+                if (np.isfinite(nn) and (it == 0 or nn <= hist[-1] or near_floor)) or lam <= 1.0 / 16.0:
+                    break
+                lam *= 0.5
+            rel_step = float(np.linalg.norm(du)) / max(float(np.linalg.norm(self.u_iga)), 1e-300)    # the full correction: a shortened step says nothing
+            R, nrm = Rn, nn
+            hist.append(nrm)
+            it += 1
+            self.newton_history.append((nrm / ref_error, rel_step, lam))
+            if not np.isfinite(nrm):
+                break
             if nrm / ref_error < rtol:
                 converged = True
+            elif rel_step <= self.newton_step_rtol and nrm < hist[0]:
+                converged = by_step = True
+            elif (len(hist) >= 5 and min(hist[:-3]) < 0.1 * max(hist[:-3]) and max(hist[-3:]) < hist[0]
+                  and min(hist[-3:]) > 0.5 * min(hist[:-3])):
+                stagnated = True                      # after a real contraction, three iterations that did not halve the best residual: the evaluation floor
                 break
-            # the residual has a round-off floor of about cond(K) eps |R_0| (thin, stiffly coupled shells: 1e-5 is common); once the
-            # iterates only jitter at it -- no halving over three iterations -- further steps change nothing
-            if len(hist) >= 3 and nrm > 0.5 * min(hist[-3:]):
-                break
-            hist.append(nrm)
-            du = self.solve_K(-R)
-            self.update_uIGA(self.u_iga + du)
-        else:
-            self._assemble(_lib.ASM_R)
-            nrm = np.linalg.norm(self.dev.residual())
-            converged = nrm / (ref_error or 1.0) < rtol
-        ref_error = ref_error if ref_error else 1.0
-        if not converged and not getattr(self, "_newton_warned", False):
-            # an unconverged state must not pass silently into linearize / solve_linear; said once per problem (newton_relative_residual
-            # holds the level of every solve)
-            import warnings
-            self._newton_warned = True
-            warnings.warn("solve_nonlinear_nonmatching_problem: stopped after %d iterations at relative residual %.3e >= rtol %.1e "
-                          "(round-off floor of the residual or max_it; later solves of this problem report through newton_relative_residual only)"
-                          % (it + 1, nrm / ref_error, rtol), RuntimeWarning)
         self.newton_relative_residual = nrm / ref_error
-        return None, self.u_iga
+        self.newton_converged, self.newton_converged_by_step, self.newton_stagnated, self.newton_iterations = converged, by_step, stagnated, it
+        if not converged:
+            msg = ("solve_nonlinear_nonmatching_problem: not converged after %d iterations%s: relative residual %.3e >= rtol %.1e, last "
+                   "relative Newton correction %.3e" % (it, " (residual stagnates: round-off floor of its evaluation)" if stagnated else "",
+                                                       nrm / ref_error, rtol, self.newton_history[-1][1] if self.newton_history else float("nan")))
+            if self.newton_raise_unconverged:
+                raise RuntimeError(msg)
+            import warnings
+            warnings.warn(msg, RuntimeWarning)
+        return None, self.u_iga.copy()
 
     # ------------------------------------------------------------------ convenience
     @classmethod

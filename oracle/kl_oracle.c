@@ -77,6 +77,8 @@ typedef struct gfo_model {
     int ni; iface_t* ifs;
     /* CP-level neighbour lists: shell only (dRdh) and shell+coupling (K, dRdCP) */
     int64_t *nb_ptr_s, *nb_ptr_c; int32_t *nb_s, *nb_c;
+    /* optional quadrature rule of the shell terms given on the unit square (gfo_set_quadrature); nq = 0: (p+1) x (q+1) Gauss points per span */
+    int nq; double *qx, *qy, *qw;
 } gfo_model;
 
 /* ------------------------------------------------------------------ basics */
@@ -279,7 +281,19 @@ void gfo_destroy(gfo_model* M) {
     for (int s = 0; s < M->np; ++s) { patch_t* P = &M->P[s]; free(P->ku); free(P->kv); free(P->spanu); free(P->spanv); free(P->bu); free(P->bv); free(P->wu); free(P->wv); }
     for (int i = 0; i < M->ni; ++i) { iface_t* F = &M->ifs[i]; free(F->iu0); free(F->iv0); free(F->R); free(F->tau); free(F->wt); }
     free(M->P); free(M->ifs); free(M->cp); free(M->u); free(M->h); free(M->w); free(M->zero); free(M->pl_dof); free(M->pl_val);
-    free(M->nb_ptr_s); free(M->nb_ptr_c); free(M->nb_s); free(M->nb_c); free(M);
+    free(M->nb_ptr_s); free(M->nb_ptr_c); free(M->nb_s); free(M->nb_c); free(M->qx); free(M->qy); free(M->qw); free(M);
+}
+
+/* Quadrature rule of the shell integrals as n points (x, y, weight) on the unit square, mapped to every non-empty knot span
+ * (n = 0: back to the tensor Gauss rule).  Used by tests/test_quadrature_gap.py to integrate with the rule FEniCS applies in the
+ * reference -- two triangles per span, collapsed Gauss-Jacobi of degree quad_deg (GOLDFISH/tests/test_tbeam.py:31 quad_deg = 3p,
+ * test_slr.py:37 2p, demos_om/thickness_opt/plate/plate_const_th_opt_wint.py:139-144 4p) -- and so bound the distance between the
+ * tensor-Gauss assembly of this oracle / the HIP kernels and what the reference integrates.  Penalty terms (vertex quadrature) do not change. */
+void gfo_set_quadrature(gfo_model* M, int n, const double* x, const double* y, const double* w) {
+    free(M->qx); free(M->qy); free(M->qw); M->qx = M->qy = M->qw = NULL; M->nq = 0;
+    if (n <= 0) return;
+    M->qx = (double*)malloc(sizeof(double) * n); M->qy = (double*)malloc(sizeof(double) * n); M->qw = (double*)malloc(sizeof(double) * n);
+    memcpy(M->qx, x, sizeof(double) * n); memcpy(M->qy, y, sizeof(double) * n); memcpy(M->qw, w, sizeof(double) * n); M->nq = n;
 }
 
 int64_t gfo_total_cp(const gfo_model* M) { return M->total_cp; }
@@ -382,13 +396,23 @@ static void shell_element(const gfo_model* M, const patch_t* P, int eu, int ev, 
     var1_t* Vd = (var1_t*)malloc(sizeof(var1_t) * nd); var1_t* Vr = (var1_t*)malloc(sizeof(var1_t) * nd);
     const double E = P->E, nu = P->nu_, f3[3] = {1, 1, 2};
 
-    for (int gv = 0; gv < P->ngv; ++gv) for (int gu = 0; gu < P->ngu; ++gu) {
-        const double* tu = P->bu + (size_t)((eu * P->ngu + gu) * 3) * (p + 1); const double* tv = P->bv + (size_t)((ev * P->ngv + gv) * 3) * (q + 1);
-        const double wq = P->wu[eu * P->ngu + gu] * P->wv[ev * P->ngv + gv];
+    const int ngp = M->nq > 0 ? M->nq : P->ngu * P->ngv;
+    for (int gp = 0; gp < ngp; ++gp) {
+        const double *tu, *tv; double wq, du_[3][MAXP + 1], dv_[3][MAXP + 1];
+        if (M->nq > 0) {                                   /* rule given on the unit square: evaluate the 1-D bases at the mapped point */
+            const double a0 = P->ku[P->spanu[eu]], a1 = P->ku[P->spanu[eu] + 1], b0 = P->kv[P->spanv[ev]], b1 = P->kv[P->spanv[ev] + 1];
+            basis_ders(P->spanu[eu], a0 + (a1 - a0) * M->qx[gp], p, P->ku, du_); basis_ders(P->spanv[ev], b0 + (b1 - b0) * M->qy[gp], q, P->kv, dv_);
+            tu = &du_[0][0]; tv = &dv_[0][0]; wq = M->qw[gp] * (a1 - a0) * (b1 - b0);
+        } else {
+            const int gu = gp % P->ngu, gv = gp / P->ngu;
+            tu = P->bu + (size_t)((eu * P->ngu + gu) * 3) * (p + 1); tv = P->bv + (size_t)((ev * P->ngv + gv) * 3) * (q + 1);
+            wq = P->wu[eu * P->ngu + gu] * P->wv[ev * P->ngv + gv];
+        }
+        const int su_ = M->nq > 0 ? MAXP + 1 : p + 1, sv_ = M->nq > 0 ? MAXP + 1 : q + 1;      /* row stride of the 1-D tables */
         double Nb[6][MAXNB], Rb[6][MAXNB];
         for (int jv = 0; jv <= q; ++jv) for (int ju = 0; ju <= p; ++ju) {
             int a = ju + jv * (p + 1);
-            double u0 = tu[ju], u1 = tu[(p + 1) + ju], u2 = tu[2 * (p + 1) + ju], v0 = tv[jv], v1 = tv[(q + 1) + jv], v2 = tv[2 * (q + 1) + jv];
+            double u0 = tu[ju], u1 = tu[su_ + ju], u2 = tu[2 * su_ + ju], v0 = tv[jv], v1 = tv[sv_ + jv], v2 = tv[2 * sv_ + jv];
             Nb[0][a] = u0 * v0; Nb[1][a] = u1 * v0; Nb[2][a] = u0 * v1; Nb[3][a] = u2 * v0; Nb[4][a] = u0 * v2; Nb[5][a] = u1 * v1;
         }
         rationalize(nb, Nb, wl, Rb);

@@ -51,6 +51,7 @@ def lib():
         L.gfo_compliance.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp, C.c_int]
         L.gfo_stress_forms.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, C.c_double, C.c_int] + [dp] * 7 + [C.c_int]
         L.gfo_shape_regu.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp]
+        L.gfo_set_quadrature.argtypes = [C.c_void_p, C.c_int, dp, dp, dp]
         L.gfo_num_threads.restype = C.c_int
         L.gfo_set_num_threads.argtypes = [C.c_int]
         _LIB = L
@@ -59,6 +60,34 @@ def lib():
 
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def two_triangle_rule(quad_deg, scheme="fiat"):
+    """(x, y, w) on the unit square of the rule FEniCS applies to one knot span in the reference (SURVEY.md App. A.1,
+    [ext-recall]: tIGAr's extraction mesh has 2 triangles per span -- dolfin's default "right" diagonal, (0,0)-(1,1) -- and
+    FFC integrates a form of estimated/declared degree ``quad_deg`` with FIAT's default scheme: for degree > 6 the collapsed
+    Gauss-Jacobi rule with m = (quad_deg + 2) // 2 points per direction (Gauss-Legendre x Gauss-Jacobi(1, 0), exact to degree
+    2m - 1 on the triangle), for degree 6 the symmetric 12-point rule of Dunavant).  ``scheme="collapsed"`` forces the
+    collapsed rule for every degree.  quad_deg in the reference: 3p (tests/test_tbeam.py:31), 2p (tests/test_slr.py:37),
+    4p (demos_om/thickness_opt/plate/plate_const_th_opt_wint.py:139-144)."""
+    from scipy.special import roots_jacobi
+    if scheme == "fiat" and quad_deg == 6:
+        a1, a2, (b1, b2, b3) = 0.249286745170910, 0.063089014491502, (0.053145049844817, 0.310352451033784, 0.636502499121399)
+        pts = [(a1, a1), (1 - 2 * a1, a1), (a1, 1 - 2 * a1), (a2, a2), (1 - 2 * a2, a2), (a2, 1 - 2 * a2),
+               (b1, b2), (b2, b1), (b1, b3), (b3, b1), (b2, b3), (b3, b2)]
+        wts = [0.116786275726379] * 3 + [0.050844906370207] * 3 + [0.082851075618374] * 6
+        X, Wt = np.array(pts), 0.5 * np.array(wts)
+    else:
+        m = (quad_deg + 2) // 2
+        s, ws = roots_jacobi(m, 0.0, 0.0)
+        t, wt = roots_jacobi(m, 1.0, 0.0)
+        S, T = np.meshgrid(s, t, indexing="ij")
+        X = np.stack([0.25 * (1 + S) * (1 - T), 0.5 * (1 + T)], -1).reshape(-1, 2)          # reference triangle (0,0), (1,0), (0,1)
+        Wt = (ws[:, None] * wt[None, :] / 8.0).ravel()
+    lo = np.stack([X[:, 0] + X[:, 1], X[:, 1]], 1)               # (0,0), (1,0), (1,1): (x, y) -> (x + y, y)
+    up = np.stack([X[:, 0], X[:, 0] + X[:, 1]], 1)               # (0,0), (0,1), (1,1) mirrored: (x, y) -> (x, x + y)
+    P = np.concatenate([lo, up])
+    return np.ascontiguousarray(P[:, 0]), np.ascontiguousarray(P[:, 1]), np.concatenate([Wt, Wt])
 
 
 class Oracle:
@@ -98,6 +127,14 @@ class Oracle:
         v = np.ascontiguousarray(v, float)
         assert v.size == self.ndof
         lib().gfo_set_u(self.h, _dp(v))
+
+    def set_quadrature(self, rule=None):
+        """rule = (x, y, w) on the unit square for the shell integrals (two_triangle_rule(...)); None: tensor Gauss."""
+        if rule is None:
+            lib().gfo_set_quadrature(self.h, 0, None, None, None)
+        else:
+            x, y, w = (np.ascontiguousarray(v, float) for v in rule)
+            lib().gfo_set_quadrature(self.h, x.size, _dp(x), _dp(y), _dp(w))
 
     def pattern(self, which):
         if which not in self._pat:

@@ -123,7 +123,7 @@ def test_scordelis_lo_on_gpu():
             a = P.flat(su - 3 + ju, sv - 3 + jv)
             num += Nu[ju] * Nv[jv] * u[3 * (off + a) + 1]
             W += Nu[ju] * Nv[jv] * P.cp_hom_flat()[a, 3]
-    assert abs(abs(num / W) - 0.3006) / 0.3006 < 5e-3
+    assert abs(abs(num / W) - 0.3006) / 0.3006 < 5e-4
 
 
 def test_newton_solve_converges():
@@ -638,13 +638,12 @@ def test_arch_shape_optimisation_known_answer(p):
     spec_.loader.exec_module(mod)
     out = mod.run(verbose=False, p=p)                       # finer p = 3 mesh: 5.47787
     assert abs(out["h0"] - 3.0) < 1e-12
-    # every product on the path is fixed-order (no atomics), so the optimisation is reproducible on one path: p = 3, 4 give 5.4782 / 5.4783.
-    # The strain energy is very flat in the rise, and the state solve has a round-off floor (relative residual ~5e-5 of the small
-    # external load): on the coarse p = 2 mesh SLSQP stops anywhere in 5.467 .. 5.478 (block path 5.4784, row-record path 5.4673)
-    # at energies that agree to 2.4e-4 -- so p = 2 is anchored on the energy and on a 0.3 % window of the rise.
-    assert abs(out["h1"] - 5.4779) < (1.5e-2 if p == 2 else 5e-3), out["h1"]
-    if p == 2:
-        assert abs(out["w1"] / 1.2127e-8 - 1.0) < 1e-3, out["w1"]
+    # every product on the path is fixed-order (no atomics), so the optimisation is reproducible on one path.  Round 2 iterated the
+    # state to rtol 1e-10, below the residual's evaluation floor (4e-5 |R_0|: each extra Newton step added that noise to u), and the
+    # p = 2 optimum then depended on the assembly path (5.4673 vs 5.4784); with the reference's rtol 1e-3 the state is the clean
+    # first Newton step and every degree lands inside the 5e-3 window.
+    assert abs(out["h1"] - 5.4779) < 5e-3, out["h1"]
+    assert out["problem"].nm.newton_converged
     assert out["w1"] < 0.8 * out["w0"]
     if p != 3:
         return

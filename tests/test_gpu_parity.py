@@ -35,6 +35,9 @@ CASES = {
     "C2_tbeam4_10kdof": lambda: G.tbeam_4patch(),
     "C3_wing16_refdata": lambda: G.wing_16patch_from_interface_data(
         np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_wing_int_data.npz"), allow_pickle=True)),
+    # C3 at the size BASELINE.json names: the reference's 16-patch / 62-interface wing topology with 42 .. 46 spans per patch side (~101 k dofs, ~0.47 M Gauss points)
+    "C3_wing16_100kdof": lambda: G.wing_16patch_from_interface_data(
+        np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_wing_int_data.npz"), allow_pickle=True), nel=44),
     "C5_fuselage3x2_p4": lambda: G.synthetic_fuselage(3, 2, nel=6, p=4, jitter=1),
     # load per unit projected area along a general direction (gf_model_desc.load_proj; the arch demo's source term)
     "slr9_nurbs_p3_projected_load": lambda: _with_projected_load(G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2])),

@@ -1,0 +1,197 @@
+"""Host logic of NonMatchingOpt.solve_nonlinear_nonmatching_problem and solve_K on stand-in residuals (no GPU): plain Newton through a
+non-monotone start (1, 50, 5, 0.6 must not be mistaken for a floor), backtracking, the evaluation floor of the residual,
+honest warnings, and the fallback of a rejected device solve.  Reference behaviour: GOLDFISH/operations/disp_imop.py:38-44
+(max_it 30, rtol 1e-3 relative to the first residual)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from goldfish_amd import _lib
+from goldfish_amd.nonmatching_opt import NonMatchingOpt
+
+
+class _FakeDev:
+    def __init__(self, nm):
+        self.nm = nm
+
+    def residual(self):
+        return self.nm.fun(self.nm.u_iga)
+
+
+class FakeNM(NonMatchingOpt):
+    """R(u) and its Jacobian given as Python callables; everything device-side replaced."""
+
+    def __init__(self, fun, jac, n, u0=None):
+        self.fun, self.jac, self.vec_iga_dof = fun, jac, n
+        self.u_iga = np.zeros(n) if u0 is None else np.asarray(u0, float)
+        self._dev = _FakeDev(self)
+        self.n_assemblies = 0
+
+    dev = property(lambda self: self._dev)
+
+    def update_uIGA(self, u):
+        self.u_iga = np.asarray(u, float).copy()
+
+    def _assemble(self, flags):
+        self.n_assemblies += 1
+
+    def solve_K(self, rhs):
+        return np.linalg.solve(self.jac(self.u_iga), rhs)
+
+
+def test_non_monotone_start_is_not_a_floor():
+    """A stiffening bar: the linear first step overshoots (residual rises well above |R_0|), plain Newton then converges
+    quadratically -- the round-2 exit (no halving over three residuals that include |R_0|) stopped this at iteration 4."""
+    k, f = 1.0e4, 1.0
+    nm = FakeNM(lambda u: u + k * u ** 3 - f, lambda u: np.diag(1.0 + 3.0 * k * u ** 2), 1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _, u = nm.solve_nonlinear_nonmatching_problem(rtol=1e-12, max_it=30)
+    hist = [h[0] for h in nm.newton_history]
+    assert hist[0] > 100.0 and nm.newton_converged and not nm.newton_stagnated
+    assert abs(u[0] + k * u[0] ** 3 - f) < 1e-11
+    assert all(h[2] == 1.0 for h in nm.newton_history)           # monotone after the first step: never backtracked
+    assert u is not nm.u_iga                                     # a copy: editing it cannot alias the cached state
+
+
+def test_backtracking_rescues_a_diverging_newton():
+    nm = FakeNM(lambda u: np.arctan(u), lambda u: np.diag(1.0 / (1.0 + u ** 2)), 1, u0=[3.0])
+    _, u = nm.solve_nonlinear_nonmatching_problem(rtol=1e-12, max_it=30, zero_mortar_funcs=False)
+    assert nm.newton_converged and abs(u[0]) < 1e-10
+    assert min(h[2] for h in nm.newton_history) < 1.0              # some step was shortened (plain Newton diverges from 3)
+
+
+def test_evaluation_floor_warns_every_time_and_can_raise():
+    rng = np.random.default_rng(0)
+    A = np.diag([1.0, 1.0e3, 1.0e6])
+
+    def fun(u):                                                   # linear residual + evaluation noise of relative size 1e-7
+        return A @ u - np.ones(3) + 1e-7 * rng.standard_normal(3)
+    nm = FakeNM(fun, lambda u: A, 3)
+    for _ in range(2):                                            # every unconverged solve warns, not only the first
+        with pytest.warns(RuntimeWarning, match="stagnates"):
+            nm.solve_nonlinear_nonmatching_problem(rtol=1e-14, max_it=30)
+        assert not nm.newton_converged and nm.newton_stagnated and nm.newton_iterations < 10
+        assert nm.newton_relative_residual < 1e-5
+    nm.newton_raise_unconverged = True
+    with pytest.raises(RuntimeError, match="not converged"):
+        nm.solve_nonlinear_nonmatching_problem(rtol=1e-14, max_it=30)
+    # the same floor with an achievable tolerance: converged, silent
+    nm.newton_raise_unconverged = False
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        nm.solve_nonlinear_nonmatching_problem(rtol=1e-5, max_it=30)
+    assert nm.newton_converged
+
+
+def test_negligible_correction_counts_as_converged():
+    """Residual noise that a tight rtol cannot pass, but a Newton correction far below newton_step_rtol |u|: converged by step."""
+    rng = np.random.default_rng(1)
+    nm = FakeNM(lambda u: u - 1.0 + 1e-12 * rng.standard_normal(2), lambda u: np.eye(2), 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        nm.solve_nonlinear_nonmatching_problem(rtol=1e-15, max_it=30)
+    assert nm.newton_converged and nm.newton_converged_by_step
+
+
+def test_max_it_without_convergence_warns():
+    nm = FakeNM(lambda u: u ** 2 + 1.0, lambda u: np.diag(2.0 * u + 1e-3), 1, u0=[1.0])       # no root
+    with pytest.warns(RuntimeWarning, match="not converged after 5 iterations"):
+        nm.solve_nonlinear_nonmatching_problem(rtol=1e-8, max_it=5, zero_mortar_funcs=False)
+    assert not nm.newton_converged
+
+
+class _FakeSolver:
+    def __init__(self, D, x, rr):
+        self.D, self.x, self.rel_residual, self.closed = D, x, rr, False
+
+    def solve(self, b):
+        return self.x(b)
+
+    def refactor(self):
+        pass
+
+    def close(self):
+        self.closed = True
+
+
+def test_rejected_device_solve_falls_back_to_the_host(monkeypatch):
+    """solve_K returned the device solution unchecked.  A solve whose refined residual stays above
+    linear_solve_rtol (indefinite tangent under unpivoted L D L^T) or that is not finite goes to the host path, once per K."""
+    import scipy.sparse as sp
+    K = sp.csr_matrix(np.array([[2.0, 1.0], [1.0, -3.0]]))
+
+    class Dev:
+        def csr(self, which):
+            assert which == _lib.MAT_K
+            return K
+    nm = NonMatchingOpt.__new__(NonMatchingOpt)
+    nm._dev, nm._k_version = Dev(), 7
+    monkeypatch.setattr(NonMatchingOpt, "dev", property(lambda self: self._dev))
+    monkeypatch.setattr(NonMatchingOpt, "linear_solver", "device")
+    b = np.array([1.0, 2.0])
+    nm._dsolver, nm._dsolver_version = _FakeSolver(nm._dev, lambda r: np.array([np.nan, 0.0]), 0.0), 7
+    with pytest.warns(RuntimeWarning, match="falling back"):
+        x = nm.solve_K(b)
+    assert np.allclose(K @ x, b)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                            # same K: straight to the host factors, no second warning
+        assert np.allclose(K @ nm.solve_K(2 * b), 2 * b)
+    nm._k_version = 8                                             # new tangent: the device gets its chance again
+    nm._dsolver = _FakeSolver(nm._dev, lambda r: np.linalg.solve(K.toarray(), r), 1e-13)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert np.allclose(K @ nm.solve_K(b), b)
+    nm._dsolver = _FakeSolver(nm._dev, lambda r: np.zeros(2), 0.5)
+    nm._k_version = 9
+    with pytest.warns(RuntimeWarning, match="relative residual"):
+        assert np.allclose(K @ nm.solve_K(b), b)
+
+
+def test_dropping_the_device_model_drops_its_factorisations():
+    """mortar_meshes_setup / set_residuals / set_point_sources left a DeviceSolver bound to the old model."""
+    nm = NonMatchingOpt.__new__(NonMatchingOpt)
+    closed = []
+
+    class Dev:
+        def close(self):
+            closed.append("dev")
+    ds = _FakeSolver(None, None, 0.0)
+    nm._dev, nm._dsolver, nm._hlu = Dev(), ds, object()
+    nm.num_splines = 1
+    nm.set_residuals([object()])
+    assert nm._dev is None and nm._dsolver is None and nm._hlu is None and ds.closed and closed == ["dev"]
+
+
+def test_lazy_fields_is_a_complete_mapping():
+    """dict(g), iteration and len dropped the gradient fields not yet fetched; a failed fetch lost its key."""
+    fetched = []
+
+    class L:
+        @staticmethod
+        def gf_get_functional_gradient(h, field, ptr, n):
+            fetched.append(field)
+            return 0 if field != 9 else 1
+
+        @staticmethod
+        def gf_last_error():
+            return b"boom"
+
+    class Dev:
+        h = None
+    g = _lib._LazyFields(Dev(), {"a": (0, (2,)), "b": (1, (3,)), "bad": (9, (1,))}, dict(W=1.0))
+    old = _lib.lib
+    _lib.lib = lambda: L
+    try:
+        assert len(g) == 4 and set(g) == {"W", "a", "b", "bad"} and "a" in g and g.get("zz") is None
+        assert g["a"].shape == (2,) and fetched == [0]
+        with pytest.raises(RuntimeError):
+            g["bad"]
+        assert "bad" in g                                         # still pending after the failed fetch
+        del g._pending["bad"]
+        d = dict(g)
+        assert set(d) == {"W", "a", "b"} and d["b"].shape == (3,) and fetched == [0, 9, 1]
+        assert set(g.copy()) == {"W", "a", "b"}
+    finally:
+        _lib.lib = old
