@@ -83,8 +83,7 @@ def cpu_baseline(args, ncores):
 
 def kname_of(D, p):
     """Name of the dominant kernel of the path the handle runs (gf_assembly_path)."""
-    return {4: "kl_element_rec_kernel", 2: "kl_element_walk_kernel", 3: "kl_element_kernel"}.get(
-        D.assembly_path, "kl_element_mfma4_kernel" if p == 4 else ("kl_element_mfma2_kernel" if os.environ.get("GF_TWOWAVE", "1") != "0" else "kl_element_mfma_kernel"))
+    return {4: "kl_element_rec_kernel", 3: "kl_element_kernel"}.get(D.assembly_path, "kl_element_mfma4_kernel" if p == 4 else "kl_element_mfma_kernel")
 
 
 def main():

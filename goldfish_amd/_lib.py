@@ -283,7 +283,7 @@ class DeviceModel:
 
     @property
     def assembly_path(self):
-        """0 MFMA element kernel + gather (default), 2 walking kernel (GF_WALK=1, CSR-direct), 3 VALU element kernel + gather (GF_ELEMENT=valu)."""
+        """4 walking MFMA kernel + row records + record gather (default for p = 2, 3), 0 MFMA element-block kernel + gather (p = 4; GF_ASSEMBLY=block), 3 VALU element kernel + gather (GF_ELEMENT=valu)."""
         return lib().gf_assembly_path(self.h)
 
     @property

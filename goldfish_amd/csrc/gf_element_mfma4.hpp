@@ -7,56 +7,9 @@
 // a tiles.  The row expansion is repeated per pass (15 % of the kernel).  Phase 1 is one lane per Gauss point (25 x 3 lanes
 // would not fit a wave; phase 1 is 6 % here).  One wave per element, 40.5 KB LDS -> four elements per CU.
 #pragma once
-#include "gf_element_mfma.hpp"
+#include "gf_gauss_loop.hpp"
 
 namespace gf {
-
-// lane constants + expansion of row r = x of G = Pzz and Hc = Pzz + PzZ (same closed forms as in kl_element_mfma_kernel)
-struct RowLane {
-    int r, ir, kr, rt, oE2, oJ0, oJ1, oX[6];
-    double mt, m0, m1, f3c, ck[3], dij[3];
-    __device__ __forceinline__ void init(int x) {
-        const bool tang = x < 6;
-        r = x < 15 ? x : 14; const int mr = r / 3; ir = r - 3 * mr;
-        kr = mr >= 2 ? mr - 2 : 0; rt = tang ? r : 0;
-        mt = tang ? 1.0 : 0.0; m0 = (mr == 0) ? 1.0 : 0.0; m1 = (mr == 1) ? 1.0 : 0.0;
-        f3c = tang ? 0.0 : ((kr == 2) ? 2.0 : 1.0);
-        for (int k = 0; k < 3; ++k) { ck[k] = (!tang && kr == k) ? 1.0 : 0.0; dij[k] = (tang && ir == k) ? 1.0 : 0.0; }
-        oE2 = IM_G + (tang ? 3 * (1 - mr) + ir : 0);
-        oJ0 = IM_JNV + (mr == 0 ? 0 : 2); oJ1 = IM_JNV + (mr == 1 ? 1 : 2);
-        for (int s = 0; s < 6; ++s) oX[s] = tang ? IM_HMN + hmn_idx(r, s) : IM_DN + 6 * ir + s;
-    }
-    template <bool WITHC> __device__ __forceinline__ void expand(const double* im, double (&gR)[15], double (&hR)[15]) const {
-        const double gr = im[IM_G + rt], e0 = m0 * gr, e1 = m1 * gr, e2 = mt * im[oE2];
-        const double fnr = f3c * im[IM_N + ir];
-        const double b0 = mt * im[IM_BG + rt] + ck[0] * fnr, b1 = mt * im[IM_BG + 6 + rt] + ck[1] * fnr, b2 = mt * im[IM_BG + 12 + rt] + ck[2] * fnr;
-        const double pzr = im[IM_PZ + r], xfac = mt + (1.0 - mt) * im[IM_JMOF + kr];
-        const double jn[2] = {im[oJ0], im[oJ1]};
-#pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            const double g = e0 * im[IM_CEZ + s] + e1 * im[IM_CEZ + 6 + s] + e2 * im[IM_CEZ + 12 + s]
-                           + b0 * im[IM_CBG + s] + b1 * im[IM_CBG + 6 + s] + b2 * im[IM_CBG + 12 + s] - xfac * im[oX[s]] + dij[s % 3] * jn[s / 3];
-            gR[s] = g;
-            if constexpr (WITHC) {
-                const double zz = pzr * im[IM_JZJ + s] + e0 * im[IM_JDNV + s] + e1 * im[IM_JDNV + 6 + s] + e2 * im[IM_JDNV + 12 + s]
-                                - (b0 * im[IM_JDMO + s] + b1 * im[IM_JDMO + 6 + s] + b2 * im[IM_JDMO + 12 + s]);
-                hR[s] = g + zz;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double fc = (c == 2) ? 2.0 : 1.0;
-            const double gam = fc * (b0 * im[IM_CT3 + sym3(0, c)] + b1 * im[IM_CT3 + sym3(1, c)] + b2 * im[IM_CT3 + sym3(2, c)]);
-            const double alpha = mt * (fc * im[IM_CBG + 6 * c + rt]) + (1.0 - mt) * gam, beta = mt * im[IM_JMOF + c];
-#pragma unroll
-            for (int jj = 0; jj < 3; ++jj) {
-                const double g = im[IM_N + jj] * alpha - beta * im[IM_DN + 6 * jj + rt];
-                gR[6 + 3 * c + jj] = g;
-                if constexpr (WITHC) hR[6 + 3 * c + jj] = g - gam * im[IM_NB + jj];
-            }
-        }
-    }
-};
 
 template <bool WITHC = true>               // WITHC = false: Newton pass (no dR/dCP)
 __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_first, int flags, double* __restrict__ blk) {

@@ -2,12 +2,13 @@
 // STORES every control-point pair once per work item, when its lower row leaves the window: "row records" instead of element blocks.
 //
 // kl_element_mfma_kernel writes one 43 KB block per element (18 tiles of 16 x 16 plus the mirrored K tiles) and the gather reads every
-// block back: a pair of control points is stored up to (p+1)^2 times.  Walking along v with the slot addressing of
-// kl_element_walk_kernel (a pair lives in the accumulator slot given by its rows' indices modulo 4; see gf_element_walk.hpp) the
-// (p+1) elements of a strip that contribute to a pair are summed in registers, so a pair is stored once per strip it lies in
-// ((p+1) times instead of (p+1)^2): 16 KB per element instead of 43 KB.  Unlike kl_element_walk_kernel nothing is read back and
-// nothing depends on launch order: the flush is a burst of plain stores (no read-modify-write round trip, no classes, one launch),
-// and kl_gather_rec_kernel sums the <= p + 1 strips (x <= 2 segments) of every pair in a fixed order: bitwise reproducible.
+// block back: a pair of control points is stored up to (p+1)^2 times.  Walking along v, a pair of control points lives in the
+// accumulator slot given by its rows' indices modulo 4 (operand lane x <-> basis function (u index x / 4, v slot x % 4)): moving on
+// changes which entry of the 1-D v table a lane evaluates, never where a sum sits, so the (p+1) elements of a strip that contribute
+// to a pair are summed in registers and a pair is stored once per strip it lies in ((p+1) times instead of (p+1)^2): 16 KB per
+// element instead of 43 KB.  Nothing is read back and nothing depends on launch order: the flush is a burst of plain stores (a
+// variant that added the sums straight into the CSR arrays -- read-modify-write, launch classes -- was measured slower in round 2 and
+// is gone), and kl_gather_rec_kernel sums the <= p + 1 strips (x <= 2 segments) of every pair in a fixed order: bitwise reproducible.
 //
 // Record of row rho of a work item (RecCfg<WITHC>::SZ = 112 NT doubles, NT tiles): the pairs (A, B) whose lower row is rho,
 //     area 1  [rr][tile q][c], c < 16:        A = (iu0 + rr, rho),       B = (iu0 + c / 4, the row >= rho with row % 4 = c % 4)
@@ -16,7 +17,7 @@
 // areas).  Tiles: K (i <= j) 0..5, dR/dh 6..8, dR/dCP (i, f) 9..17.  Record index = item * rec_rows + (rho - first row of the item).
 // Reference path: the same integrals as kl_element_mfma_kernel (GOLDFISH/nonmatching_opt.py:941-1015 via PENGoLINS assembly).
 #pragma once
-#include "gf_element_walk.hpp"
+#include "gf_gauss_loop.hpp"
 
 namespace gf {
 
@@ -58,18 +59,7 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
     __shared__ __attribute__((aligned(16))) double s_im[NG][IM_SIZE];
     __shared__ __attribute__((aligned(16))) double s_raw[8][4][8];               // control points of the windows, ring over the row index: c_x, c_y, c_z, w, u_x, u_y, u_z, h
 
-    // ---- lane constants of the row expansion (see kl_element_mfma_kernel)
-    const bool tang = x < 6;
-    const int r = x < 15 ? x : 14, mr = r / 3, ir = r - 3 * mr;
-    const int kr = mr >= 2 ? mr - 2 : 0, rt = tang ? r : 0;
-    const double mt = tang ? 1.0 : 0.0, m0 = (mr == 0) ? 1.0 : 0.0, m1 = (mr == 1) ? 1.0 : 0.0;
-    const double f3c = tang ? 0.0 : ((kr == 2) ? 2.0 : 1.0);
-    const double ck[3] = {(!tang && kr == 0) ? 1.0 : 0.0, (!tang && kr == 1) ? 1.0 : 0.0, (!tang && kr == 2) ? 1.0 : 0.0};
-    const double dij[3] = {(tang && ir == 0) ? 1.0 : 0.0, (tang && ir == 1) ? 1.0 : 0.0, (tang && ir == 2) ? 1.0 : 0.0};
-    const int oE2 = IM_G + (tang ? 3 * (1 - mr) + ir : 0);
-    const int oJ0 = IM_JNV + (mr == 0 ? 0 : 2), oJ1 = IM_JNV + (mr == 1 ? 1 : 2);
-    int oX[6];
-    for (int s = 0; s < 6; ++s) oX[s] = tang ? IM_HMN + hmn_idx(r, s) : IM_DN + 6 * ir + s;
+    const RowLane L(x);                                  // lane constants of the row expansion
 
     const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = WITHC && (flags & GF_ASM_C_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
     const bool has_bf = (pf[0] != 0.0) || (pf[1] != 0.0) || (pf[2] != 0.0);
@@ -113,7 +103,7 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
 
     // ---- flush: the pairs whose lower row leaves the window (first row iv0f, next element's first row iv0nf) are complete for
     //      this item; every lane holds pairs of exactly one lower row rho and stores its registers into that row's record.
-    const __amdgpu_buffer_rsrc_t rR = walk_rsrc(O.rec + (size_t)blockIdx.x * O.rec_rows * RC::SZ, (unsigned)(O.rec_rows * RC::SZ * 8));
+    const __amdgpu_buffer_rsrc_t rR = buf_rsrc(O.rec + (size_t)blockIdx.x * O.rec_rows * RC::SZ, (unsigned)(O.rec_rows * RC::SZ * 8));
     auto flush = [&](int iv0f, int iv0nf) {
         const int rowa = iv0f + ((kk - iv0f) & 3), rowb = iv0f + ((sb - iv0f) & 3);       // control-point rows of this lane's slots
         const bool live = (rowa - iv0f) < P1 && (rowb - iv0f) < P1 && jub < P1;
@@ -168,58 +158,8 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
         const double* const tv = s_tv[buf];
         GF_STAMP(0, tstamp);
 
-        // ---- phase 1: three lanes per Gauss point (gp = x, part ic = kk < 3): kinematics + pointwise closed forms
-        {
-            const int gp = x < NG ? x : NG - 1, ic = kk < 3 ? kk : 0, gu = gp % P1, gv = gp / P1;
-            const bool act = kk < 3 && x < NG;
-            double* im = s_im[gp];
-            double W[6], th = 0.0;
-            if (act) {
-                double Ac[6], Ad[6];
-                for (int k = 0; k < 6; ++k) { W[k] = 0.0; Ac[k] = 0.0; Ad[k] = 0.0; }
-                double U[3][P1];
-                for (int d = 0; d < 3; ++d) for (int j = 0; j < P1; ++j) U[d][j] = s_tu[(gu * 3 + d) * P1 + j];
-#pragma unroll
-                for (int jv = 0; jv < P1; ++jv) {
-                    const double v0 = tv[(gv * 3 + 0) * P1 + jv], v1 = tv[(gv * 3 + 1) * P1 + jv], v2 = tv[(gv * 3 + 2) * P1 + jv];
-                    double S[3][3], Sh = 0.0;
-                    for (int q = 0; q < 3; ++q) for (int d = 0; d < 3; ++d) S[q][d] = 0.0;
-#pragma unroll
-                    for (int ju = 0; ju < P1; ++ju) {
-                        const int a = ju + P1 * jv;
-                        const double qv[3] = {s_c[a][ic], s_d[a][ic], s_w[a]};
-                        for (int q = 0; q < 3; ++q) for (int d = 0; d < 3; ++d) S[q][d] += U[d][ju] * qv[q];
-                        Sh += U[0][ju] * s_h[a];
-                    }
-                    th += v0 * Sh;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        double* A = q == 0 ? Ac : (q == 1 ? Ad : W);
-                        A[0] += v0 * S[q][0]; A[1] += v0 * S[q][1]; A[2] += v1 * S[q][0];
-                        A[3] += v0 * S[q][2]; A[4] += v2 * S[q][0]; A[5] += v1 * S[q][1];
-                    }
-                }
-                W[0] = 1.0 / W[0];
-                double R[6];
-                rationalize6(Ac, W, R);
-                for (int mm = 0; mm < 5; ++mm) im[3 * mm + ic] = R[mm + 1];
-                rationalize6(Ad, W, R);
-                for (int mm = 0; mm < 5; ++mm) im[15 + 3 * mm + ic] = R[mm + 1];
-            }
-            wave_lds_sync();
-            double z[15], Z[15];
-            if (act) for (int k = 0; k < 15; ++k) { Z[k] = im[k]; z[k] = im[15 + k]; }
-            wave_lds_sync();                                   // all three lanes hold z, Z before the record overwrites the exchange slots
-            if (act) {
-                const double dsel[3] = {ic == 0 ? 1.0 : 0.0, ic == 1 ? 1.0 : 0.0, ic == 2 ? 1.0 : 0.0};
-                shell_point_cols<WITHC>(z, Z, th, s_pc[0], s_pc[1], ic, dsel, kk == 0, im);
-                if (kk == 0) {
-                    for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
-                    im[IM_WQ] = s_wgu[gu] * s_wgv[buf][gv];
-                }
-            }
-        }
-        wave_lds_sync();
+        // ---- phase 1: three lanes per Gauss point: kinematics + pointwise closed forms -> s_im
+        point_phase<P, WITHC>(x, kk, s_tu, tv, s_c, s_d, s_w, s_h, s_pc, s_wgu, s_wgv[buf], s_im);
 
         GF_STAMP(1, tstamp);
         // ---- the next element's inputs are requested now (they land during the group loop) and parked in LDS behind it:
@@ -241,104 +181,7 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
             const int gp = 4 * grp + kk, gpc = gp < NG ? gp : NG - 1, gu = gpc % P1, gv = gpc / P1;   // Gauss point of this lane's group
             const double* im = s_im[gpc];
             const double wq = gp < NG ? im[IM_WQ] : 0.0;        // padded Gauss-point slots contribute nothing
-            double phi[5], R0, n0;
-            {
-                const double u0 = s_tu[(gu * 3 + 0) * P1 + jubc], u1 = s_tu[(gu * 3 + 1) * P1 + jubc], u2 = s_tu[(gu * 3 + 2) * P1 + jubc];
-                const double v0 = tv[(gv * 3 + 0) * P1 + jvc], v1 = tv[(gv * 3 + 1) * P1 + jvc], v2 = tv[(gv * 3 + 2) * P1 + jvc];
-                const double Nb[6] = {u0 * v0, u1 * v0, u0 * v1, u2 * v0, u0 * v2, u1 * v1};
-                double R[6];
-                rationalize6(Nb, im + IM_W, R);
-                for (int k = 0; k < 5; ++k) phi[k] = bval * R[k + 1];
-                R0 = bval * R[0]; n0 = bval * Nb[0];
-            }
-            // -- row r of G and Hc at this Gauss point
-            double gR[15], hR[15];
-            for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
-            if (doK || doC) {
-                const double gr = im[IM_G + rt], e0 = m0 * gr, e1 = m1 * gr, e2 = mt * im[oE2];
-                const double fnr = f3c * im[IM_N + ir];
-                const double b0 = mt * im[IM_BG + rt] + ck[0] * fnr, b1 = mt * im[IM_BG + 6 + rt] + ck[1] * fnr, b2 = mt * im[IM_BG + 12 + rt] + ck[2] * fnr;
-                const double pzr = im[IM_PZ + r], xfac = mt + (1.0 - mt) * im[IM_JMOF + kr];
-                const double jn[2] = {im[oJ0], im[oJ1]};
-#pragma unroll
-                for (int s = 0; s < 6; ++s) {
-                    const double g = e0 * im[IM_CEZ + s] + e1 * im[IM_CEZ + 6 + s] + e2 * im[IM_CEZ + 12 + s]
-                                   + b0 * im[IM_CBG + s] + b1 * im[IM_CBG + 6 + s] + b2 * im[IM_CBG + 12 + s] - xfac * im[oX[s]] + dij[s % 3] * jn[s / 3];
-                    gR[s] = g;
-                    if constexpr (WITHC) {
-                        const double zz = pzr * im[IM_JZJ + s] + e0 * im[IM_JDNV + s] + e1 * im[IM_JDNV + 6 + s] + e2 * im[IM_JDNV + 12 + s]
-                                        - (b0 * im[IM_JDMO + s] + b1 * im[IM_JDMO + 6 + s] + b2 * im[IM_JDMO + 12 + s]);
-                        hR[s] = g + zz;
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {                                       // curvature columns (c, jj)
-                    const double fc = (c == 2) ? 2.0 : 1.0;
-                    const double gam = fc * (b0 * im[IM_CT3 + sym3(0, c)] + b1 * im[IM_CT3 + sym3(1, c)] + b2 * im[IM_CT3 + sym3(2, c)]);
-                    const double alpha = mt * (fc * im[IM_CBG + 6 * c + rt]) + (1.0 - mt) * gam, beta = mt * im[IM_JMOF + c];
-#pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) {
-                        const double g = im[IM_N + jj] * alpha - beta * im[IM_DN + 6 * jj + rt];
-                        gR[6 + 3 * c + jj] = g;
-                        if constexpr (WITHC) hR[6 + 3 * c + jj] = g - gam * im[IM_NB + jj];
-                    }
-                }
-                dpp_source_fence(gR);
-                if constexpr (WITHC) dpp_source_fence(hR);
-            }
-            // -- residual and dR/dh prefactors of this lane's basis function at this Gauss point
-            {
-                const double ls = has_bf ? load_scalar(im, ppd) : 0.0;
-                for (int i = 0; i < 3; ++i) {
-                    double rz = 0.0;
-                    for (int m = 0; m < 5; ++m) rz += phi[m] * im[IM_PZ + 3 * m + i];
-                    accR[i] += wq * (rz - ls * pf[i] * R0);
-                }
-            }
-            double pb[5];
-            for (int m = 0; m < 5; ++m) pb[m] = wq * phi[m];
-            if (doH) {
-                double nn = 0.0;
-                for (int k = 0; k < 3; ++k) nn += phi[2 + k] * im[IM_JCK4 + k] * (k == 2 ? 2.0 : 1.0);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const double g1i = im[IM_G + i], g2i = im[IM_G + 3 + i];
-                    double rh = phi[0] * (im[IM_JCE] * g1i + im[IM_JCE + 2] * g2i) + phi[1] * (im[IM_JCE + 1] * g2i + im[IM_JCE + 2] * g1i);
-                    for (int k = 0; k < 3; ++k) rh -= im[IM_JCK4 + k] * (phi[0] * im[IM_BG + 6 * k + i] + phi[1] * im[IM_BG + 6 * k + 3 + i]);
-                    rh -= im[IM_N + i] * nn;
-                    accH[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wq * rh, n0, accH[i], 0, 0, 0);
-                }
-            }
-            // -- contraction: one MFMA per (component, m); the B operand T_b is formed from the expanded row on the fly
-            constexpr int QI[6] = {0, 0, 0, 1, 1, 2}, QJ[6] = {0, 1, 2, 1, 2, 2};
-            if (doK) {
-                static_for<5>([&](auto m_) {
-                    constexpr int m = decltype(m_)::value;
-                    double tq[6];
-                    static_for<6>([&](auto q_) { constexpr int q = decltype(q_)::value; tq[q] = row_dot<3 * m + QI[q], QJ[q]>(gR, pb); });
-                    mfma_hazard_gap(tq);
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) accK[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], tq[q], accK[q], 0, 0, 0);
-                });
-            }
-            if (doC) {
-                static_for<5>([&](auto m_) {
-                    constexpr int m = decltype(m_)::value;
-                    double tq[9];
-                    static_for<9>([&](auto q_) { constexpr int q = decltype(q_)::value; tq[q] = row_dot<3 * m + q / 3, q % 3>(hR, pb); });
-                    mfma_hazard_gap(tq);
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], tq[q], accC[q], 0, 0, 0);
-                });
-                if (has_bf) {                    // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b): one tile per f, the factor -f_i is applied behind the loop
-                    const LoadGeom lg = load_geom(im, ppd);
-#pragma unroll
-                    for (int f = 0; f < 3; ++f) {
-                        const double jz = load_dz_dot(im, ppd, lg, f, pb[0], pb[1]);
-                        accB[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(R0, jz, accB[f], 0, 0, 0);
-                    }
-                }
-            }
+            gauss_group<P, WITHC>(L, im, wq, s_tu, tv, gu, gv, jubc, jvc, bval, doK, doC, doH, has_bf, pf, ppd, accK, accC, accH, accB, accR);
         }
         if (has_bf && doC) {
 #pragma unroll

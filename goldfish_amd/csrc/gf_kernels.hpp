@@ -1004,9 +1004,7 @@ __global__ __launch_bounds__(64) void pen_dxi_kernel(DevModel M, DevPenalty Q, c
 // support window adds its blocks.  Fixed visit order, nothing shared: bitwise reproducible.
 // The kernel WRITES the rows (the gather of these control points adds the shell part afterwards).
 constexpr int PEN_MAXDEG = 64 * 5;
-// ADD = true (walking element kernel: the shell part is already in the CSR arrays, Dirichlet entries included): the blocks are
-// added to the box entries that are not Dirichlet-constrained, and the coupling-only entries are written (0 where constrained).
-template <int P, int PEN_SL, bool WITHC = true, bool WITHK = true, bool ADD = false>     // WITHC = false (Newton pass): no dR/dCP blocks; WITHK = false (linearize after a Newton solve): no K blocks
+template <int P, int PEN_SL, bool WITHC = true, bool WITHK = true>     // WITHC = false (Newton pass): no dR/dCP blocks; WITHK = false (linearize after a Newton solve): no K blocks
 __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q, int flags, int maxdeg, const double* __restrict__ pbuf, double* __restrict__ R,
                                                         double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1, double* __restrict__ valC2) {
     constexpr int P1 = P + 1, NB = P1 * P1;
@@ -1119,24 +1117,6 @@ __global__ __launch_bounds__(64) void pen_owner_kernel(DevModel M, DevPenalty Q,
     for (int sl = 0; sl < PEN_SL; ++sl) {
         if (sl * 64 >= maxdeg || sp[sl] < 0) continue;
         const int k = tid + 64 * sl;
-        if constexpr (ADD) {
-            const unsigned meta = M.nb_meta[ptr_c + k];
-            const bool inbox = (meta & 127u) != 127u;
-            for (int i = 0; i < 3; ++i) {
-                const bool zrow = M.zero[3 * (long long)a + i] != 0;
-                for (int j = 0; j < 3; ++j) {
-                    if constexpr (WITHK) if (flags & GF_ASM_K_BIT) {
-                        double* dst = valK + 9 * ptr_c + (long long)i * 3 * deg_c + 3 * k + j;
-                        const bool bc = zrow || (meta & (128u << j));
-                        if (inbox) { if (!bc) *dst += kk[sl][3 * i + j]; } else *dst = bc ? 0.0 : kk[sl][3 * i + j];
-                    }
-                    if constexpr (WITHC) if (flags & GF_ASM_C_BIT) {
-                        double* dst = (j == 0 ? valC0 : (j == 1 ? valC1 : valC2)) + 3 * ptr_c + (long long)i * deg_c + k;
-                        if (inbox) { if (!zrow) *dst += cc[sl][3 * i + j]; } else *dst = zrow ? 0.0 : cc[sl][3 * i + j];
-                    }
-                }
-            }
-        } else
         for (int i = 0; i < 3; ++i) {                    // every entry of the rows is written (Dirichlet rows/columns are overwritten by the gather)
             for (int j = 0; j < 3; ++j) {
                 if constexpr (WITHK) { if (flags & GF_ASM_K_BIT) valK[9 * ptr_c + (long long)i * 3 * deg_c + 3 * k + j] = kk[sl][3 * i + j]; }
@@ -1218,20 +1198,6 @@ __global__ __launch_bounds__(256) void csr_apply_tdet_kernel(long long ncp, cons
         for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
         if (lane == 0) y[BW * b + j] += t;
     }
-}
-
-// y += A^T x: scatter with FP64 atomics (summation order not fixed); kept for K on a shard and as GF_ATOMIC_T=1
-__global__ __launch_bounds__(256) void csr_apply_t_kernel(long long nrows, const long long* nb_ptr, const int* nb, int bw, const double* __restrict__ val,
-                                                           const double* __restrict__ x, double* __restrict__ y) {
-    const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (row >= nrows) return;
-    const double xr = x[row];
-    if (xr == 0.0) return;
-    const long long a = row / 3; const int i = int(row - 3 * a);
-    const long long ptr = nb_ptr[a], deg = nb_ptr[a + 1] - ptr, n = deg * bw;
-    const double* v = val + 3 * bw * ptr + (long long)i * n;
-    for (long long c = lane; c < n; c += 64) { const long long col = (long long)nb[ptr + c / bw] * bw + c % bw; atomicAdd(&y[col], v[c] * xr); }
 }
 
 }  // namespace gf

@@ -15,8 +15,6 @@ constexpr int GF_ASM_R_BIT = 1, GF_ASM_K_BIT = 2, GF_ASM_C_BIT = 4, GF_ASM_H_BIT
 #include "gf_kernels.hpp"
 #include "gf_element_mfma.hpp"
 #include "gf_element_mfma4.hpp"
-#include "gf_element_mfma2.hpp"
-#include "gf_element_walk.hpp"
 #include "gf_element_rec.hpp"
 #include "gf_penalty_row16.hpp"
 #include "gf_penalty_point16.hpp"
@@ -31,10 +29,6 @@ struct Chunk { int p0, p1; long long e0, e1, a0, a1; };
 
 struct gf_handle {
     int device = 0; hipStream_t stream = nullptr;
-    // Overlap of the two halves of a pass (element-block path): the gather of chunk c runs on a second stream next to the
-    // element kernel of chunk c + 1 -- the element kernel holds one wave per SIMD (424 of its 512 registers) and is FP64 bound,
-    // the gather is bandwidth bound and its waves fit the remaining registers.  Two block buffers alternate.
-    hipStream_t stream_g = nullptr; double* d_blk2 = nullptr; std::vector<hipEvent_t> ev_e, ev_g; hipEvent_t ev_join = nullptr; bool overlap = false;
     HostModel H;
     std::vector<void*> allocs; long long bytes = 0;
     DevModel M{}; DevPenalty Q{};
@@ -51,22 +45,13 @@ struct gf_handle {
     std::vector<Chunk> chunks;
     std::vector<hipEvent_t> ev0, ev1; int ev_n = 0;   // element-kernel timing
     bool assembled[5] = {false, false, false, false, false};
-    bool walk = false;                                // GF_WALK=1 (p = 2, 3, MFMA path): walk element strips and accumulate straight into the CSR arrays (gf_element_walk.hpp: a quarter of the device memory, half the traffic, currently slower)
-    const WalkItem* d_walk_items = nullptr; const RowDesc* d_row_desc = nullptr; const WalkPatch* d_walk_patch = nullptr;
-    bool rec = false;                                 // p = 2, 3, MFMA path, default (GF_WALK unset or 2): walking kernel that stores row records + kl_gather_rec_kernel (gf_element_rec.hpp)
+    bool rec = false;                                 // p = 2, 3, MFMA path, default: walking kernel that stores row records + kl_gather_rec_kernel (gf_element_rec.hpp); GF_ASSEMBLY=block: one block per element + row gather
     const WalkItem* d_rec_items = nullptr; const RecCp* d_rec_cp = nullptr; double* d_rec = nullptr; long long rec_doubles = 0;
-    // Row-record path: the penalty kernels (latency / issue bound, 1.2 TB/s) run on a second stream NEXT TO the record gather of the
-    // control points without penalty rows (bandwidth bound); the gather of the interface control points follows both.
-    hipStream_t stream_p = nullptr; hipEvent_t ev_elem = nullptr, ev_pen = nullptr; bool pen_overlap = false;
-    const int *d_cp_plain = nullptr, *d_cp_pen = nullptr; long long n_cp_plain = 0, n_cp_pen = 0;
-    bool two_wave = true;                             // p = 2, 3 full pass: two waves per element, two resident per SIMD (gf_element_mfma2.hpp; GF_TWOWAVE=0: one wave)
     bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
-    bool atomic_t = false;                            // GF_ATOMIC_T=1: transposed products of dR/dCP, dR/dh by FP64 atomics (order not fixed) instead of the fixed-order gather
     const int *d_rev_s = nullptr, *d_rev_c = nullptr;
-    bool gather1 = true;                              // one-wave gather (GF_GATHER1=0 selects the four-wave gather)
+    bool gather1 = true;                              // element-block path: one-wave gather for p <= 3, four-wave gather for p = 4
     int pen_maxdeg = 0;                               // largest neighbour count of an interface control point
-    bool pen_row16 = true;                            // p = 2, 3: pen_row16_kernel (one 16-lane row per visit; GF_PEN_ROW16=0: pen_owner_kernel)
-    bool pen_point16 = true;                          // p = 2, 3: pen_point16_kernel (16 lanes per mortar vertex, coalesced record writes; GF_PEN_POINT16=0: pen_point_kernel)
+    bool pen16 = true;                                // p = 2, 3: pen_point16_kernel + pen_row16_kernel (16 lanes per mortar vertex / per visit); p = 4 and GF_PENALTY=owner: pen_point_kernel + pen_owner_kernel
 
     template <class T> T* dalloc(size_t n) {
         void* p = nullptr; const size_t nb = (n > 0 ? n : 1) * sizeof(T);
@@ -97,20 +82,15 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         HIPCHK(hipStreamCreate(&h->stream));
         h->H.build(desc);
         if (const char* s = getenv("GF_ELEMENT")) h->mfma = std::string(s) != "valu";
-        if (const char* s = getenv("GF_ATOMIC_T")) h->atomic_t = std::string(s) == "1";
-        if (const char* s = getenv("GF_TWOWAVE")) h->two_wave = std::string(s) != "0";
         h->gather1 = h->H.degree <= 3;                    // p = 4: 25 elements x 75-wide rows per control point are bandwidth bound either way (57.9 vs 57.6 ms per step)
-        if (const char* s = getenv("GF_GATHER1")) h->gather1 = std::string(s) != "0";
         HostModel& H = h->H;
         {
-            // p = 2, 3 on the matrix pipe: row records + record gather (gf_element_rec.hpp) by default; GF_WALK=0: one block per element +
-            // row gather, GF_WALK=1: walking kernel that adds straight into the CSR arrays (gf_element_walk.hpp)
-            const bool can = h->mfma && H.degree <= 3;
-            bool want = false, want_rec = can;
-            if (const char* s = getenv("GF_WALK")) { want = can && std::string(s) == "1"; want_rec = can && std::string(s) == "2"; }
-            int seg = want ? 12 : 0;                          // row records: whole strips unless the model is small (HostModel::build_rec)
-            if (const char* s = getenv("GF_WALK_SEG")) seg = std::max(1, atoi(s));
-            if (want) { H.build_walk(seg); h->walk = H.walk_ok; }
+            // p = 2, 3 on the matrix pipe: row records + record gather (gf_element_rec.hpp) by default; GF_ASSEMBLY=block: one block per
+            // element + row gather (the cross-check path of the tests)
+            bool want_rec = h->mfma && H.degree <= 3;
+            if (const char* s = getenv("GF_ASSEMBLY")) want_rec = want_rec && std::string(s) != "block";
+            int seg = 0;                                      // whole strips unless the model is small (HostModel::build_rec); GF_REC_SEG: elements per work item
+            if (const char* s = getenv("GF_REC_SEG")) seg = std::max(1, atoi(s));
             if (want_rec) { H.build_rec(seg); h->rec = true; }
         }
         std::vector<long long> nbs(H.nb_ptr_s.begin(), H.nb_ptr_s.end()), nbc(H.nb_ptr_c.begin(), H.nb_ptr_c.end());
@@ -159,8 +139,8 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             Q.pt_tau = h->upload(H.pt_tau); Q.pt_wt = h->upload(H.pt_wt); Q.if_patch = h->upload(H.if_patch); Q.if_alpha = h->upload(H.if_alpha);
             Q.entries = h->upload(H.pen_entries); Q.ent_ptr = h->upload(ep); Q.row_cp = h->upload(H.row_cp);
             Q.slots = H.degree <= 3 ? h->upload(H.pen_slots) : nullptr;
-            if (const char* s = getenv("GF_PEN_ROW16")) h->pen_row16 = std::string(s) != "0";
-            if (const char* s = getenv("GF_PEN_POINT16")) h->pen_point16 = std::string(s) != "0";
+            h->pen16 = H.degree <= 3;
+            if (const char* s = getenv("GF_PENALTY")) h->pen16 = h->pen16 && std::string(s) != "owner";
             Q.nrow_groups = (long long)rp.size() - 1;
             for (long long g = 0; g + 1 < (long long)rp.size(); ++g) if (rp[g + 1] > rp[g]) pen_row[H.row_items[rp[g]].a] = 1;
             h->d_pbuf = h->dalloc<double>((size_t)H.npts * PB_STRIDE);
@@ -172,44 +152,15 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
                     throw std::runtime_error("gf_create: a control point couples to more than " + std::to_string(PEN_MAXDEG) + " neighbours (PEN_MAXDEG)");
         }
         M.pen_row = h->upload(pen_row);
-        if (h->rec) {
-            std::vector<int> plain, withpen;
-            for (long long a = 0; a < H.owned_cp; ++a) (pen_row[a] ? withpen : plain).push_back((int)a);
-            h->d_cp_plain = h->upload(plain); h->d_cp_pen = h->upload(withpen); h->n_cp_plain = (long long)plain.size(); h->n_cp_pen = (long long)withpen.size();
-            // measured at C4 (tools/timeline.sh): next to the gather (HBM saturated) pen_owner_kernel does a quarter of its work in the
-            // time it needs for all of it alone (5.3 ms overlapped + alone vs 2.7 ms), pen_point_kernel 3.8 instead of 0.7 ms, with or
-            // without stream priority: 23.6 vs 23.4 ms per step.  Off unless GF_PEN_OVERLAP=1.
-            h->pen_overlap = false;
-            if (const char* s = getenv("GF_PEN_OVERLAP")) h->pen_overlap = H.npts > 0 && std::string(s) == "1";
-            if (h->pen_overlap) {
-                // higher priority: the gather's half million workgroups would otherwise keep every slot and the penalty kernels would
-                // only trickle in behind them (measured: pen_point stretched from 0.7 to 3.8 ms, pen_owner started after the gather)
-                int lo = 0, hi = 0;
-                HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-                HIPCHK(hipStreamCreateWithPriority(&h->stream_p, hipStreamDefault, hi));
-                HIPCHK(hipEventCreateWithFlags(&h->ev_elem, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_pen, hipEventDisableTiming));
-            }
-        }
         for (long long a = 0; a < H.total_cp; ++a)
             if (H.nb_ptr_c[a + 1] - H.nb_ptr_c[a] > GATHER_MAXMETA) throw std::runtime_error("gf_create: a control point has more than " + std::to_string(GATHER_MAXMETA) + " neighbours (GATHER_MAXMETA)");
         // element-block scratch, chunked over whole patches
         const int P = H.degree, NB = (P + 1) * (P + 1), ND = 3 * NB;
-        const long long blk_doubles = (h->walk || h->rec) ? (long long)ND : 2LL * ND * ND + (long long)ND * NB + ND;   // walking kernels: residual entries only
+        const long long blk_doubles = h->rec ? (long long)ND : 2LL * ND * ND + (long long)ND * NB + ND;   // row-record path: residual entries only
         double budget_gb = 40.0;
         if (const char* s = getenv("GF_SCRATCH_GB")) budget_gb = atof(s);
-        if (h->walk || h->rec) budget_gb = 1e9;           // no element blocks: one chunk
-        long long max_elems = std::max<long long>(1, (long long)(budget_gb * 1e9 / (blk_doubles * 8.0)));
-        {   // GF_OVERLAP=1: element kernel and gather overlapped over GF_CHUNKS chunks of whole patches (measured at C4: no gain,
-            // 25.6 vs 25.9 ms -- the element kernel slows down by what the gather hides, profiles/r02_overlap_*; off by default)
-            int nch = 8;
-            if (const char* s = getenv("GF_CHUNKS")) nch = std::max(1, atoi(s));
-            if (const char* s = getenv("GF_OVERLAP")) h->overlap = std::string(s) == "1" && !h->walk && !h->rec && H.n_owned >= 2 * nch;
-            if (h->overlap) {
-                long long tot = 0;
-                for (int s = 0; s < H.n_owned; ++s) tot += (long long)H.patches[s].nelu * H.patches[s].nelv;
-                max_elems = std::min(max_elems, (tot + nch - 1) / nch);
-            }
-        }
+        if (h->rec) budget_gb = 1e9;                      // no element blocks: one chunk
+        const long long max_elems = std::max<long long>(1, (long long)(budget_gb * 1e9 / (blk_doubles * 8.0)));
         long long biggest = 0;
         for (int s = 0; s < H.n_owned;) {
             Chunk c; c.p0 = s; c.e0 = H.patches[s].elem_off; c.a0 = H.patches[s].cp_off;
@@ -223,26 +174,13 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             h->chunks.push_back(c); biggest = std::max(biggest, ne);
         }
         long long scratch_doubles = biggest * blk_doubles;
-        if (h->walk) {
-            scratch_doubles = std::max<long long>(scratch_doubles, H.nelem * (long long)(11 * NB + 2));   // the functionals' element blocks (FunCfg::STRIDE) share the scratch
-            h->d_walk_items = h->upload(H.walk_items); h->d_row_desc = h->upload(H.row_desc);
-            h->d_walk_patch = h->upload(H.walk_patch);
-        }
         if (h->rec) {
-            scratch_doubles = std::max<long long>(scratch_doubles, H.nelem * (long long)(11 * NB + 2));
+            scratch_doubles = std::max<long long>(scratch_doubles, H.nelem * (long long)(11 * NB + 2));   // the functionals' element blocks (FunCfg::STRIDE) share the scratch
             h->d_rec_items = h->upload(H.rec_items); h->d_rec_cp = h->upload(H.rec_cp);
             h->rec_doubles = (long long)H.rec_items.size() * H.rec_rows * RecCfg<true>::SZ;
             h->d_rec = h->dalloc<double>((size_t)h->rec_doubles);
         }
         h->d_blk = h->dalloc<double>((size_t)scratch_doubles);
-        h->overlap = h->overlap && h->chunks.size() >= 2;
-        if (h->overlap) {
-            h->d_blk2 = h->dalloc<double>((size_t)scratch_doubles);
-            HIPCHK(hipStreamCreate(&h->stream_g));
-            h->ev_e.resize(h->chunks.size()); h->ev_g.resize(h->chunks.size());
-            for (size_t k = 0; k < h->chunks.size(); ++k) { HIPCHK(hipEventCreateWithFlags(&h->ev_e[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_g[k], hipEventDisableTiming)); }
-            HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        }
         h->ev0.resize(64); h->ev1.resize(64);
         for (int k = 0; k < 64; ++k) { HIPCHK(hipEventCreate(&h->ev0[k])); HIPCHK(hipEventCreate(&h->ev1[k])); }
         HIPCHK(hipDeviceSynchronize());
@@ -261,13 +199,6 @@ void gf_destroy(gf_handle* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto e : h->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : h->ev1) if (e) (void)hipEventDestroy(e);
-    for (auto e : h->ev_e) if (e) (void)hipEventDestroy(e);
-    for (auto e : h->ev_g) if (e) (void)hipEventDestroy(e);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->stream_g) (void)hipStreamDestroy(h->stream_g);
-    if (h->stream_p) (void)hipStreamDestroy(h->stream_p);
-    if (h->ev_elem) (void)hipEventDestroy(h->ev_elem);
-    if (h->ev_pen) (void)hipEventDestroy(h->ev_pen);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -326,25 +257,24 @@ int gf_pattern(const gf_handle* h, int which, int64_t* rowptr, int32_t* col) {
 
 }  // extern "C"
 
-// Penalty kernels of one pass.  ADD = false: pen_owner_kernel WRITES the rows of the interface control points and the gather adds the
-// shell part afterwards; ADD = true (walking element kernel): the shell part is in place and the blocks are added to it.
-// parts: 1 = vertex records (pen_point_kernel), 2 = rows (pen_owner_kernel), 3 = both
-template <int P, bool ADD> static int run_penalty(gf_handle* h, int flags, hipStream_t st = nullptr, int parts = 3) {
-    if (!st) st = h->stream;
+// Penalty kernels of one pass: the vertex records, then the rows of the interface control points are WRITTEN (the gather adds the
+// shell part afterwards).
+template <int P> static int run_penalty(gf_handle* h, int flags) {
+    hipStream_t st = h->stream;
     const HostModel& H = h->H;
     const int pen = (H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP))) ? 1 : 0;
-    if (pen && (parts & 1)) {
+    if (pen) {
         const int mode = !(flags & (GF_ASM_K | GF_ASM_DRDCP)) ? 1 : (!(flags & GF_ASM_DRDCP) ? 2 : (!(flags & GF_ASM_K) ? 3 : 0));
         bool done = false;
         if constexpr (P <= 3) {
-            if (h->pen_point16) { hipLaunchKernelGGL(pen_point16_kernel<P>, dim3((unsigned)((H.npts + 3) / 4)), dim3(64), 0, st, h->M, h->Q, h->d_pbuf, mode); done = true; }
+            if (h->pen16) { hipLaunchKernelGGL(pen_point16_kernel<P>, dim3((unsigned)((H.npts + 3) / 4)), dim3(64), 0, st, h->M, h->Q, h->d_pbuf, mode); done = true; }
         }
         if (!done) hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, st, h->M, h->Q, h->d_pbuf, mode);
     }
-    if (pen && (parts & 2)) {
+    if (pen) {
         const dim3 grid((unsigned)(((h->Q.nrow_groups + 7) / 8) * 8)), blk64(64);       // multiple of 8: XCD-contiguous group ranges
-        if constexpr (P <= 3 && !ADD) {
-            if (h->pen_row16 && h->Q.slots) {
+        if constexpr (P <= 3) {
+            if (h->pen16 && h->Q.slots) {
                 const size_t lds = (size_t)h->pen_maxdeg * 18 * sizeof(double);
 #define GF_PEN16(WC, WK) hipLaunchKernelGGL((pen_row16_kernel<P, WC, WK>), grid, blk64, lds, st, h->M, h->Q, flags, h->d_pbuf, h->d_R, h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])
                 if (!(flags & GF_ASM_DRDCP)) GF_PEN16(false, true);
@@ -355,7 +285,7 @@ template <int P, bool ADD> static int run_penalty(gf_handle* h, int flags, hipSt
             }
         }
         const int sl = (h->pen_maxdeg + 63) / 64;         // neighbour slots per lane, register resident
-#define GF_PEN_LAUNCH(SL, WC, WK) hipLaunchKernelGGL((pen_owner_kernel<P, SL, WC, WK, ADD>), grid, blk64, 0, st, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \
+#define GF_PEN_LAUNCH(SL, WC, WK) hipLaunchKernelGGL((pen_owner_kernel<P, SL, WC, WK>), grid, blk64, 0, st, h->M, h->Q, flags, h->pen_maxdeg, h->d_pbuf, h->d_R, \
                                                      h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])
 #define GF_PEN_SLOTS(WC, WK) do { if (sl <= 2) GF_PEN_LAUNCH(2, WC, WK); else if (sl == 3) GF_PEN_LAUNCH(3, WC, WK); else GF_PEN_LAUNCH(5, WC, WK); } while (0)
         if (!(flags & GF_ASM_DRDCP)) GF_PEN_SLOTS(false, true);                 // Newton pass
@@ -374,43 +304,13 @@ static void finish_residual(gf_handle* h) {
     hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((H.ndof + 255) / 256)), dim3(256), 0, h->stream, (long long)H.ndof, h->M.zero, h->d_R);
 }
 
-// Walking element kernel (gf_element_walk.hpp): the classes of work items in ascending order, then the penalty blocks are added,
-// then the residual-only gather.  One timed "launch" of the dominant kernel = the class launches of one pass.
-template <int P> static void run_assemble_walk(gf_handle* h, int flags) {
-    constexpr int PW = P == 2 ? 2 : 3;
-    const HostModel& H = h->H;
-    const WalkOut O{h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_blk, h->d_walk_patch};
-    const int slot = h->ev_n % 64;
-    HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
-    for (size_t c = 0; c + 1 < H.walk_cls_off.size(); ++c) {
-        const int i0 = H.walk_cls_off[c], n = H.walk_cls_off[c + 1] - i0;
-        if (n <= 0) continue;
-        if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_walk_kernel<PW, true>), dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_walk_items, i0, flags, h->d_row_desc, O);
-        else hipLaunchKernelGGL((kl_element_walk_kernel<PW, false>), dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_walk_items, i0, flags, h->d_row_desc, O);
-    }
-    HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
-    h->ev_n++;
-    const int pen = run_penalty<P, true>(h, flags);
-    if (flags & GF_ASM_R) {
-        const Chunk& c = h->chunks[0];
-        const long long ne = c.e1 - c.e0, na = c.a1 - c.a0;
-        hipLaunchKernelGGL(kl_rgather_kernel<P>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, h->d_blk, h->d_R, pen, 3 * (P + 1) * (P + 1), 0);
-        finish_residual(h);
-    }
-    HIPCHK(hipGetLastError());
-}
-
 // Row-record path (gf_element_rec.hpp): penalty rows first (written), one launch of the walking kernel over all work items, then the
 // record gather adds the shell part per control point.
 template <int P> static void run_assemble_rec(gf_handle* h, int flags) {
     constexpr int PW = P == 2 ? 2 : 3;
     const HostModel& H = h->H;
     const bool mats = (flags & ~GF_ASM_R) != 0;
-    const bool want_pen = H.npts > 0 && (flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP));
-    const bool split = h->pen_overlap && mats && want_pen;      // penalty kernels next to the gather of the control points without penalty rows
-    int pen = 0;
-    if (!split) pen = run_penalty<P, false>(h, flags);
-    else run_penalty<P, false>(h, flags, h->stream, 1);           // vertex records first: a latency-bound kernel that crawls next to the gather
+    const int pen = run_penalty<P>(h, flags);
     const RecOut O{h->d_rec, h->d_blk, H.rec_rows};
     const int slot = h->ev_n % 64, n = (int)H.rec_items.size();
     HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
@@ -428,15 +328,7 @@ template <int P> static void run_assemble_rec(gf_handle* h, int flags) {
         else hipLaunchKernelGGL((kl_gather_rec_kernel<PW, false>), grid, dim3(64), 0, h->stream, h->M, a0, a1, list, flags, h->d_rec, H.rec_rows, h->d_rec_cp,
                                 h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], pen_add);
     };
-    if (split) {
-        HIPCHK(hipEventRecord(h->ev_elem, h->stream));
-        HIPCHK(hipStreamWaitEvent(h->stream_p, h->ev_elem, 0));            // not next to the element kernel (it holds every SIMD's registers)
-        pen = run_penalty<P, false>(h, flags, h->stream_p, 2);
-        HIPCHK(hipEventRecord(h->ev_pen, h->stream_p));
-        gather(h->d_cp_plain, h->n_cp_plain, 0, h->n_cp_plain, 0);
-        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_pen, 0));               // the pass continues (and ends) on the main stream
-        gather(h->d_cp_pen, h->n_cp_pen, 0, h->n_cp_pen, pen);
-    } else if (mats) gather(nullptr, na, c.a0, c.a1, pen);
+    if (mats) gather(nullptr, na, c.a0, c.a1, pen);
     if (flags & GF_ASM_R) {
         hipLaunchKernelGGL(kl_rgather_kernel<P>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, h->d_blk, h->d_R, pen, 3 * (P + 1) * (P + 1), 0);
         finish_residual(h);
@@ -451,20 +343,17 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
     // them (no read-modify-write pass over those rows afterwards).  Running the penalty kernels on a second stream was measured
     // and dropped: next to the element kernel they cost it LDS occupancy (17.7 -> 22.8 ms), next to the gather both slow down
     // by what the overlap saves (profiles/r01_v8_*).
-    if ((P == 2 || P == 3) && h->walk) { run_assemble_walk<P>(h, flags); return; }
     if ((P == 2 || P == 3) && h->rec) { run_assemble_rec<P>(h, flags); return; }
-    const int pen = run_penalty<P, false>(h, flags);
+    const int pen = run_penalty<P>(h, flags);
     for (size_t ci = 0; ci < h->chunks.size(); ++ci) {
         const Chunk& c = h->chunks[ci];
         const long long ne = c.e1 - c.e0, na = c.a1 - c.a0;
-        double* const blk = (h->overlap && (ci & 1)) ? h->d_blk2 : h->d_blk;
-        hipStream_t gs = h->overlap ? h->stream_g : h->stream;                 // stream of the gather
-        if (h->overlap && ci >= 2) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_g[ci - 2], 0));   // the block buffer is free again
+        double* const blk = h->d_blk;
+        hipStream_t gs = h->stream;
         const int slot = h->ev_n % 64;
         HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
         if ((P == 3 || P == 2) && h->mfma) {
-            if ((flags & GF_ASM_DRDCP) && h->two_wave) hipLaunchKernelGGL((kl_element_mfma2_kernel<(P == 2 ? 2 : 3)>), dim3((unsigned)ne), dim3(128), 0, h->stream, h->M, (int)c.e0, flags, blk);
-            else if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), true>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, blk);
+            if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), true>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, blk);
             else hipLaunchKernelGGL((kl_element_mfma_kernel<(P == 2 ? 2 : 3), false>), dim3((unsigned)ne), dim3(64), 0, h->stream, h->M, (int)c.e0, flags, blk);
         }
         else if (P == 4 && h->mfma) {
@@ -474,7 +363,6 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
         else hipLaunchKernelGGL(kl_element_kernel<P>, dim3((unsigned)ne), dim3(Cfg::NT), 0, h->stream, h->M, (int)c.e0, flags, blk);
         HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
         h->ev_n++;
-        if (h->overlap) { HIPCHK(hipEventRecord(h->ev_e[ci], h->stream)); HIPCHK(hipStreamWaitEvent(gs, h->ev_e[ci], 0)); }
         if (flags == GF_ASM_R)
             hipLaunchKernelGGL(kl_rgather_kernel<P>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, gs, h->M, c.a0, c.a1, c.e0, ne, blk, h->d_R, pen, Cfg::BLK, Cfg::OFF_R);
         else if (!(flags & GF_ASM_DRDCP) && h->gather1)      // one wave per control point; without dR/dCP (Newton pass) the leaner instance
@@ -486,9 +374,7 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
         else
         hipLaunchKernelGGL(kl_gather_kernel<P>, dim3((unsigned)na), dim3(256), 0, gs, h->M, c.a0, c.e0, ne, flags, blk,
                            h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R, pen);
-        if (h->overlap) HIPCHK(hipEventRecord(h->ev_g[ci], gs));
     }
-    if (h->overlap) { HIPCHK(hipEventRecord(h->ev_join, h->stream_g)); HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0)); }   // the pass ends on the main stream
     if (flags & GF_ASM_R) finish_residual(h);
     HIPCHK(hipGetLastError());
 }
@@ -505,7 +391,7 @@ template <int P> static void run_functionals(gf_handle* h, int apply_bcs) {
     const HostModel& H = h->H;
     if (H.npts > 0) {
         bool done = false;
-        if constexpr (P <= 3) { if (h->pen_point16) { hipLaunchKernelGGL(pen_point16_kernel<P>, dim3((unsigned)((H.npts + 3) / 4)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf, 1); done = true; } }
+        if constexpr (P <= 3) { if (h->pen16) { hipLaunchKernelGGL(pen_point16_kernel<P>, dim3((unsigned)((H.npts + 3) / 4)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf, 1); done = true; } }
         if (!done) hipLaunchKernelGGL(pen_point_kernel<P>, dim3((unsigned)((H.npts + 63) / 64)), dim3(64), 0, h->stream, h->M, h->Q, h->d_pbuf, 1);
         hipLaunchKernelGGL(pen_energy_kernel, dim3((unsigned)((H.npts + 255) / 256)), dim3(256), 0, h->stream, (long long)H.npts, h->d_pbuf, h->d_pen_en);
     }
@@ -608,16 +494,15 @@ int gf_apply_dev(gf_handle* h, int which, int transpose, const double* x, double
     if (which < 0 || which > 4) return fail("gf_apply: unknown matrix id");
     if (!h->assembled[which]) return fail("gf_apply: matrix has not been assembled");
     const long long* ptr = which == GF_MAT_DRDH ? h->M.nb_ptr_s : h->M.nb_ptr_c; const int* nb = which == GF_MAT_DRDH ? h->M.nb_s : h->M.nb_c;
-    const int bw = which == GF_MAT_K ? 3 : 1; const long long nrows = h->H.ndof, ncp = h->H.total_cp;
-    const unsigned grid = (unsigned)((nrows * 64 + 255) / 256), grid_cp = (unsigned)((ncp * 64 + 255) / 256);
+    const int bw = which == GF_MAT_K ? 3 : 1; const long long ncp = h->H.total_cp;
+    const unsigned grid_cp = (unsigned)((ncp * 64 + 255) / 256);
     // K is symmetric including its Dirichlet treatment (rows+cols zeroed, unit diagonal): K^T x = K x, so the
     // transposed product uses the atomic-free row kernel as well (bitwise reproducible adjoint products with K)
     // (not on a shard: ghost rows are not assembled there, so the local K is not symmetric)
     if (which == GF_MAT_K && (!transpose || h->H.n_owned == h->H.np)) hipLaunchKernelGGL(csr_apply_kernel<3>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
     else if (!transpose) hipLaunchKernelGGL(csr_apply_kernel<1>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
-    else if (bw == 1 && !h->atomic_t) hipLaunchKernelGGL(csr_apply_tdet_kernel<1>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, which == GF_MAT_DRDH ? h->d_rev_s : h->d_rev_c, h->d_val[which], x, y);
-    else if (!h->atomic_t) hipLaunchKernelGGL(csr_apply_tdet_kernel<3>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_rev_c, h->d_val[which], x, y);
-    else hipLaunchKernelGGL(csr_apply_t_kernel, dim3(grid), dim3(256), 0, h->stream, nrows, ptr, nb, bw, h->d_val[which], x, y);
+    else if (bw == 1) hipLaunchKernelGGL(csr_apply_tdet_kernel<1>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, which == GF_MAT_DRDH ? h->d_rev_s : h->d_rev_c, h->d_val[which], x, y);
+    else hipLaunchKernelGGL(csr_apply_tdet_kernel<3>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_rev_c, h->d_val[which], x, y);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(std::string("gf_apply: ") + hipGetErrorString(e));
     return 0;
@@ -691,7 +576,7 @@ double gf_kernel_ms(gf_handle* h, int* n_launches) {
 
 void* gf_stream(gf_handle* h) { return h ? (void*)h->stream : nullptr; }
 
-int gf_assembly_path(const gf_handle* h) { return !h ? -1 : (h->walk ? 2 : (h->rec ? 4 : (h->mfma ? 0 : 3))); }
+int gf_assembly_path(const gf_handle* h) { return !h ? -1 : (h->rec ? 4 : (h->mfma ? 0 : 3)); }
 
 int gf_get_functional_gradient(gf_handle* h, int field, double* out, int64_t n) {
     if (!h || !out) return fail("gf_get_functional_gradient: null argument");

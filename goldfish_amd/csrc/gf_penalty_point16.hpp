@@ -16,7 +16,7 @@
 // Default for p = 2, 3 (GF_PEN_POINT16=0: pen_point_kernel).  8 x 8-patch slice: 97 us against pen_point_kernel's 155 us; the first version,
 // with the current configuration's table on one lane (~250 registers, one wave per SIMD), took 196 us.
 #pragma once
-#include "gf_element_mfma.hpp"
+#include "gf_gauss_loop.hpp"
 
 namespace gf {
 

@@ -23,7 +23,7 @@
 // The kernel WRITES the rows (the gather adds the shell part), like pen_owner_kernel<.., ADD = false>.
 // Reference path: nonmatching_opt.py:745-752, 789-801, 861-887 (penalty residual and its blocks of dR/du, dR/dCP).
 #pragma once
-#include "gf_element_mfma.hpp"
+#include "gf_gauss_loop.hpp"
 
 namespace gf {
 

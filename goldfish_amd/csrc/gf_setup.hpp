@@ -39,17 +39,7 @@ struct ElemDesc { int patch, g0, nu, tabu, tabv, wu, wv, pad; };   // g0: global
 // cp_patch -> patch -> c2u/c2v -> span-table chain of dependent loads
 struct CpDesc { int patch, ia, ja, eu0, neu, ev0, nev, i0, j0, i1, j1, nelu; long long e00; int bu[5], bv[5]; };   // bu[k] = first CP index of element eu0 + k
 
-// Walking element kernel (gf_element_walk.hpp): per-control-point row descriptor -- where the rows of a control point sit in
-// the CSR value arrays, its neighbour box, its element ranges and its Dirichlet flags, in one 64-byte record.
-//   entry of box slot s in a's coupled neighbour list = pre + s (the coupling-only neighbours of other patches sort in front
-//   of / behind the box; checked in HostModel::build, walk_ok); in the shell-only list the entry IS the slot.
-//   offK / offC / offH: position (in doubles, relative to the patch's first row: WalkPatch) of the first box entry of row (a, 0) in
-//   the K, dR/dCP_f and dR/dh value arrays; row (a, i) follows at + i * 3 deg_c, + i * deg_c, + i * deg_s.
-struct RowDesc { int offK, deg_c, offC, offH, deg_s, i0, j0, wbox, flags, lou, hiu, lov, hiv, pre, pad0, pad1; };   // flags: bits 0-2 Dirichlet dofs
-// per patch: where its rows start in the value arrays (doubles) and how many bytes they span (buffer-resource range of the kernel)
-struct WalkPatch { long long kbase, cbase, hbase; unsigned kbytes, cbytes, hbytes, pad; };
-// one work item of the walking kernel: the elements ev0 .. ev0 + nel - 1 of the strip eu of a patch; items of one class
-// (cls = (eu mod (p+1)) * 2 + (seg & 1)) share no control-point pair, classes are launched in ascending order
+// one work item of the walking kernel (gf_element_rec.hpp): the elements ev0 .. ev0 + nel - 1 of the strip eu of a patch
 struct WalkItem { int patch, eu, ev0, nel, seg, cls, iu0, pad; };
 // row-record path (gf_element_rec.hpp), per patch: first work item (items in the order strip-major, segment), segments per strip, and
 // (offsets into ints[]) the segment of every element row / the first element row of every segment (nseg + 1 entries)
@@ -129,12 +119,7 @@ struct HostModel {
     std::vector<int> elem_patch;        // [nelem]
     std::vector<ElemDesc> elem_desc;    // [nelem]
     std::vector<CpDesc> cp_desc;        // [total_cp]
-    std::vector<RowDesc> row_desc;      // [total_cp] (walking element kernel)
-    std::vector<WalkPatch> walk_patch;  // [np]
-    std::vector<WalkItem> walk_items; std::vector<int> walk_cls_off;   // items sorted by class; walk_cls_off[c] .. [c + 1]
-    bool walk_ok = false;               // the walking kernel's addressing assumptions hold for this model
-    void build_walk(int seg_len);
-    std::vector<WalkItem> rec_items; std::vector<RecPatch> rec_patch; std::vector<RecCp> rec_cp; int rec_rows = 0;   // row-record path (GF_WALK=2)
+    std::vector<WalkItem> rec_items; std::vector<RecPatch> rec_patch; std::vector<RecCp> rec_cp; int rec_rows = 0;   // row-record path
     void build_rec(int seg_len);
     std::vector<int> cp_patch;          // [total_cp]
     std::vector<double> weights;
@@ -169,8 +154,6 @@ inline void HostModel::build(const gf_model_desc* D) {
     owned_cp = D->cp_off[n_owned];
     if (total_cp >= (int64_t(1) << 31) / 3) throw std::runtime_error("gf_create: too many control points for 32-bit column ids");
     patches.resize(np); cp_patch.resize(total_cp);
-    const char* env_b32 = std::getenv("GF_BASIS_FP32");
-    const bool basis_fp32 = env_b32 && std::string(env_b32) == "1";
     weights.assign(D->weights, D->weights + total_cp);
     nelem = 0; ngp = 0;
     for (int s = 0; s < np; ++s) {
@@ -195,9 +178,7 @@ inline void HostModel::build(const gf_model_desc* D) {
             for (int e = 0; e < nel; ++e) for (int g = 0; g < ng; ++g) {
                 const double a = U[sp[e]], b = U[sp[e] + 1], xi = 0.5 * (a + b) + 0.5 * (b - a) * gx[g];
                 double ders[3][MAXP + 1]; basis_ders(sp[e], xi, p, U, ders);
-                // GF_BASIS_FP32=1 (measurement of BASELINE.json's "mixed FP64/FP32 basis eval" mode, tools/mixed_precision.py): the 1-D basis
-                // values and derivatives as an FP32 evaluation would deliver them, everything downstream in FP64
-                for (int k = 0; k < 3; ++k) for (int j = 0; j <= p; ++j) tab[t0 + ((size_t(e) * ng + g) * 3 + k) * (p + 1) + j] = basis_fp32 ? (double)(float)ders[k][j] : ders[k][j];
+                for (int k = 0; k < 3; ++k) for (int j = 0; j <= p; ++j) tab[t0 + ((size_t(e) * ng + g) * 3 + k) * (p + 1) + j] = ders[k][j];
                 tab[w0 + e * ng + g] = 0.5 * (b - a) * gw[g];
             }
             const int s0 = (int)ints.size(); ints.insert(ints.end(), sp.begin(), sp.end());
@@ -446,54 +427,6 @@ inline void HostModel::build(const gf_model_desc* D) {
             ent_ptr.push_back((int64_t)pen_entries.size()); row_cp.push_back(a);
         }
     }
-}
-
-// Tables of the walking element kernel.  seg_len: target number of elements per work item along the walk direction (v).
-inline void HostModel::build_walk(int seg_len) {
-    walk_ok = degree >= 2 && degree <= 3;
-    row_desc.assign(total_cp, RowDesc{}); walk_patch.assign(np, WalkPatch{});
-    for (int s = 0; s < np && walk_ok; ++s) {
-        const PatchDev& P = patches[s];
-        const int *c2u = &ints[P.c2u], *c2v = &ints[P.c2v];
-        const int64_t a0 = P.cp_off, a1 = P.cp_off + int64_t(P.nu) * P.nv, pc0 = nb_ptr_c[a0], ps0 = nb_ptr_s[a0];
-        if ((nb_ptr_c[a1] - pc0) * 72 >= (int64_t(1) << 32) - 4096 || (nb_ptr_s[a1] - ps0) * 24 >= (int64_t(1) << 32) - 4096) { walk_ok = false; break; }   // 32-bit byte offsets inside a patch
-        walk_patch[s] = {9 * pc0, 3 * pc0, 3 * ps0, unsigned((nb_ptr_c[a1] - pc0) * 72), unsigned((nb_ptr_c[a1] - pc0) * 24), unsigned((nb_ptr_s[a1] - ps0) * 24), 0};
-        for (int j = 0; j < P.nv; ++j) for (int i = 0; i < P.nu; ++i) {
-            const int64_t a = P.cp_off + i + int64_t(j) * P.nu;
-            const CpDesc& c = cp_desc[a];
-            RowDesc& r = row_desc[a];
-            r.deg_c = int(nb_ptr_c[a + 1] - nb_ptr_c[a]); r.deg_s = int(nb_ptr_s[a + 1] - nb_ptr_s[a]);
-            r.i0 = c.i0; r.j0 = c.j0; r.wbox = c.i1 - c.i0 + 1;
-            r.flags = (zero[3 * a] ? 1 : 0) | (zero[3 * a + 1] ? 2 : 0) | (zero[3 * a + 2] ? 4 : 0);
-            r.lou = c2u[2 * i]; r.hiu = c2u[2 * i + 1]; r.lov = c2v[2 * j]; r.hiv = c2v[2 * j + 1];
-            int pre = 0;
-            for (int64_t k = nb_ptr_c[a]; k < nb_ptr_c[a + 1] && nb_c[k] < P.cp_off; ++k) ++pre;
-            r.pre = pre;
-            r.offK = int(9 * (nb_ptr_c[a] - pc0) + 3 * pre); r.offC = int(3 * (nb_ptr_c[a] - pc0) + pre); r.offH = int(3 * (nb_ptr_s[a] - ps0));
-            for (int64_t k = nb_ptr_c[a]; k < nb_ptr_c[a + 1]; ++k) {
-                const int slot = nb_meta[k] & 127;
-                if (slot != 127 && int(k - nb_ptr_c[a]) != pre + slot) walk_ok = false;
-            }
-            if (r.deg_s != r.wbox * (c.j1 - c.j0 + 1)) walk_ok = false;
-        }
-    }
-    walk_items.clear(); walk_cls_off.assign(2 * (degree + 1) + 1, 0);
-    if (!walk_ok) return;
-    const int P1 = degree + 1;
-    std::vector<WalkItem> items;
-    for (int s = 0; s < n_owned; ++s) {
-        const PatchDev& P = patches[s];
-        int nseg = std::max(1, (P.nelv + seg_len / 2) / std::max(seg_len, P1));
-        while (nseg > 1 && P.nelv / nseg < P1) --nseg;                 // every segment holds at least p + 1 elements
-        for (int eu = 0; eu < P.nelu; ++eu) for (int g = 0; g < nseg; ++g) {
-            const int e0 = int(int64_t(g) * P.nelv / nseg), e1 = int(int64_t(g + 1) * P.nelv / nseg);
-            items.push_back({s, eu, e0, e1 - e0, g, (eu % P1) * 2 + (g & 1), ints[P.spu + eu] - P.p, 0});
-        }
-    }
-    std::stable_sort(items.begin(), items.end(), [](const WalkItem& x, const WalkItem& y) { return x.cls < y.cls; });
-    walk_items = items;
-    for (const WalkItem& it : items) walk_cls_off[it.cls + 1]++;
-    for (size_t c = 0; c + 1 < walk_cls_off.size(); ++c) walk_cls_off[c + 1] += walk_cls_off[c];
 }
 
 // Tables of the row-record path: work items in natural order (patch, strip, segment) -- nothing depends on launch order --, per

@@ -39,44 +39,7 @@ int main(int argc, char** argv) {
     try {
         gf::HostModel H;
         H.build(&d);
-        // tables of the walking element kernel + a dry run of its addressing: every box entry of every owned row must be
-        // visited by its classes in ascending order, started exactly once (the first visit) and never twice within a class
         const int seg = argc > 2 ? atoi(argv[2]) : 5;
-        H.build_walk(seg);
-        if (H.walk_ok) {
-            const int P = H.degree, P1 = P + 1;
-            std::vector<int> lastcls(H.nb_c.size(), -1), nfirst(H.nb_c.size(), 0), nvis(H.nb_c.size(), 0);
-            for (const gf::WalkItem& it : H.walk_items) {
-                const gf::PatchDev& Pt = H.patches[it.patch];
-                for (int t = 0; t < it.nel; ++t) {
-                    const int ev = it.ev0 + t, iv0 = H.ints[Pt.spv + ev] - P;
-                    const int iv0n = t + 1 < it.nel ? H.ints[Pt.spv + ev + 1] - P : iv0 + 4;
-                    for (int ja = 0; ja < P1; ++ja) for (int ia = 0; ia < P1; ++ia) for (int jb = 0; jb < P1; ++jb) for (int ib = 0; ib < P1; ++ib) {
-                        const int rowa = iv0 + ja, rowb = iv0 + jb;
-                        if (!(rowa < iv0n || rowb < iv0n)) continue;             // the pair stays in the window
-                        const int64_t A = Pt.cp_off + (it.iu0 + ia) + int64_t(rowa) * Pt.nu, B = Pt.cp_off + (it.iu0 + ib) + int64_t(rowb) * Pt.nu;
-                        const gf::RowDesc &dA = H.row_desc[A], &dB = H.row_desc[B];
-                        const int t0 = std::max(dA.lov, dB.lov), t1 = std::min(dA.hiv, dB.hiv), s0 = std::max(dA.lou, dB.lou), s1 = std::min(dA.hiu, dB.hiu);
-                        const bool vfirst = (t0 >= it.ev0 && t1 < it.ev0 + it.nel) || (it.seg & 1) == 0;
-                        const bool first = vfirst && ((it.eu % P1 == 0) || (it.eu == s0 && s0 / P1 == s1 / P1));
-                        const int slot = (it.iu0 + ib - dA.i0) + (rowb - dA.j0) * dA.wbox;
-                        const gf::WalkPatch& wp = H.walk_patch[it.patch];
-                        // position of entry (row (A, 0), column B) in the dR/dCP and dR/dh value arrays -> index into the neighbour lists
-                        const int64_t k = wp.cbase + dA.offC + slot - 2 * H.nb_ptr_c[A], ks = wp.hbase + dA.offH + slot - 2 * H.nb_ptr_s[A];
-                        if (k < H.nb_ptr_c[A] || k >= H.nb_ptr_c[A + 1] || H.nb_c[k] != B) { fprintf(stderr, "walk: wrong entry\n"); return 5; }
-                        if (ks < H.nb_ptr_s[A] || ks >= H.nb_ptr_s[A + 1] || H.nb_s[ks] != B) { fprintf(stderr, "walk: wrong shell entry\n"); return 5; }
-                        if (wp.kbase + dA.offK + 3 * slot != 9 * H.nb_ptr_c[A] + 3 * (k - H.nb_ptr_c[A])) { fprintf(stderr, "walk: wrong K entry\n"); return 5; }
-                        if (8 * (uint64_t)(dA.offK + 3 * slot + 6 * dA.deg_c + 3) > wp.kbytes) { fprintf(stderr, "walk: K offset beyond the patch range\n"); return 5; }
-                        if (lastcls[k] >= it.cls) { fprintf(stderr, "walk: class order violated\n"); return 5; }
-                        if (first != (lastcls[k] < 0)) { fprintf(stderr, "walk: first-touch flag wrong\n"); return 5; }
-                        lastcls[k] = it.cls; nfirst[k] += first; nvis[k]++;
-                    }
-                }
-            }
-            for (int64_t a = 0; a < H.owned_cp; ++a) for (int64_t k = H.nb_ptr_c[a]; k < H.nb_ptr_c[a + 1]; ++k)
-                if (((H.nb_meta[k] & 127) != 127) != (nvis[k] > 0) || ((H.nb_meta[k] & 127) != 127 && nfirst[k] != 1)) { fprintf(stderr, "walk: entry coverage wrong\n"); return 5; }
-            printf("walk: %zu items, dry run ok\n", H.walk_items.size());
-        } else printf("walk: not applicable\n");
         // tables of the row-record path + a dry run of its addressing: the element kernel's stores (which pair lands at which position of
         // which row record) against the gather's reads (every position a control point reads must have been written, by exactly the
         // pair the gather attributes to it; every written position is read exactly once as "a as A")

@@ -87,44 +87,6 @@ def test_assembly_parity(oracle_lib, case):
 
 
 @pytest.mark.parametrize("seg", ["4", "7", "1000"])
-def test_walking_kernel_segment_lengths_and_block_path(oracle_lib, monkeypatch, seg):
-    """GF_WALK=1: the walking element kernel (gf_element_walk.hpp: accumulators kept along an element strip, sums added straight
-    into the CSR arrays in a fixed class order -- no element blocks, no gather) with work items of 4 / 7 elements / whole strips
-    (GF_WALK_SEG: different class structure, different first-touch pattern) against the oracle and against the default
-    element-block + gather path, for every flag subset; each variant is bitwise reproducible run to run."""
-    from goldfish_amd import _lib
-    from oracle.oracle_py import Oracle
-    for case in ("tbeam2_p2", "shell3x2_p3", "C3_wing16_refdata", "slr9_nurbs_p3_projected_load"):
-        A, h, u = _state(CASES[case](), seed=11)
-        O = Oracle(A, thickness=h, u=u)
-        vals, Ro = O.assemble(), O.residual()
-        out = {}
-        for walk in ("1", "0"):
-            monkeypatch.setenv("GF_WALK", walk)
-            monkeypatch.setenv("GF_WALK_SEG", seg)
-            D = _lib.DeviceModel(A)
-            assert D.assembly_path == (2 if walk == "1" else 0)
-            D.set_thickness(h)
-            D.set_u(u)
-            D.assemble(_lib.ASM_ALL)
-            out[walk] = [D.residual().copy()] + [D.values(w).copy() for w in range(5)]
-            assert _rel(out[walk][0], Ro) < RTOL
-            for w in range(5):
-                assert _rel(out[walk][1 + w], vals[w]) < RTOL, (case, walk, w)
-            D.assemble(_lib.ASM_ALL)                                # same bits again (stale partial sums never leak into a pass)
-            assert np.array_equal(out[walk][0], D.residual())
-            for w in range(5):
-                assert np.array_equal(out[walk][1 + w], D.values(w)), (case, walk, w)
-            for flags, which in ((_lib.ASM_R | _lib.ASM_K, (0,)), (_lib.ASM_DRDCP | _lib.ASM_DRDH, (1, 2, 3, 4)), (_lib.ASM_K | _lib.ASM_DRDH, (0, 4))):
-                D.assemble(flags)
-                for w in which:
-                    assert _rel(D.values(w), vals[w]) < RTOL, (case, walk, flags, w)
-            D.close()
-        for x, y in zip(out["1"], out["0"]):
-            assert _rel(x, y) < 1e-12
-
-
-@pytest.mark.parametrize("seg", ["4", "7", "1000"])
 def test_row_record_path_segment_lengths_and_block_path(oracle_lib, monkeypatch, seg):
     """Default path for p = 2, 3: the walking element kernel that stores row records (gf_element_rec.hpp: a control-point pair is stored once per
     strip and segment, when its lower row leaves the window) + the record gather, with work items of 4 / 7 elements / whole strips
@@ -138,9 +100,9 @@ def test_row_record_path_segment_lengths_and_block_path(oracle_lib, monkeypatch,
         vals, Ro = O.assemble(), O.residual()
         out = {}
         for walk in ("2", "0"):
-            if walk == "2": monkeypatch.delenv("GF_WALK", raising=False)          # the default path
-            else: monkeypatch.setenv("GF_WALK", walk)
-            monkeypatch.setenv("GF_WALK_SEG", seg)
+            if walk == "2": monkeypatch.delenv("GF_ASSEMBLY", raising=False)      # the default path
+            else: monkeypatch.setenv("GF_ASSEMBLY", "block")                    # one block per element + row gather: the cross-check path
+            monkeypatch.setenv("GF_REC_SEG", seg)
             D = _lib.DeviceModel(A)
             assert D.assembly_path == (4 if walk == "2" else 0)
             D.set_thickness(h)
@@ -164,18 +126,18 @@ def test_row_record_path_segment_lengths_and_block_path(oracle_lib, monkeypatch,
 
 
 def test_penalty_kernel_variants(oracle_lib, monkeypatch):
-    """The penalty kernels come in two generations: pen_row16_kernel (default for p = 2, 3: one 16-lane row per visit, LDS accumulators)
-    vs pen_owner_kernel (GF_PEN_ROW16=0; p = 4 always), and pen_point16_kernel (default for p = 2, 3: 16 lanes per mortar vertex) vs
-    pen_point_kernel (GF_PEN_POINT16=0; p = 4 always).  Every combination against the oracle; each is bitwise reproducible run to run."""
+    """Two penalty kernel pairs: pen_point16_kernel + pen_row16_kernel (default for p = 2, 3: 16 lanes per mortar vertex / one 16-lane row per
+    visit, LDS accumulators) and pen_point_kernel + pen_owner_kernel (p = 4; GF_PENALTY=owner for p = 2, 3: the cross-check).  Both against
+    the oracle; each is bitwise reproducible run to run."""
     from goldfish_amd import _lib
     from oracle.oracle_py import Oracle
     for case in ("tbeam2_p2", "C3_wing16_refdata", "slr9_nurbs_p3_projected_load"):
         A, h, u = _state(CASES[case](), seed=5)
         O = Oracle(A, thickness=h, u=u)
         vals, Ro = O.assemble(), O.residual()
-        for row16, point16 in (("0", "0"), ("1", "1"), ("0", "1")):
-            monkeypatch.setenv("GF_PEN_ROW16", row16)
-            monkeypatch.setenv("GF_PEN_POINT16", point16)
+        for row16, point16 in (("0", "0"), ("1", "1")):
+            if row16 == "0": monkeypatch.setenv("GF_PENALTY", "owner")
+            else: monkeypatch.delenv("GF_PENALTY", raising=False)
             D = _lib.DeviceModel(A)
             D.set_thickness(h)
             D.set_u(u)
@@ -298,21 +260,25 @@ def test_error_behaviour():
 
 
 def test_chunked_scratch_gives_identical_results(oracle_lib, monkeypatch):
-    """GF_SCRATCH_GB small enough to force one chunk per patch: same bits as the single-chunk run."""
+    """Element-block path (p = 4; GF_ASSEMBLY=block for p = 3): GF_SCRATCH_GB small enough to force one chunk per patch gives the same bits
+    as the single-chunk run."""
     from goldfish_amd import _lib
-    spec = G.synthetic_shell(3, 2, nel=5, p=3, jitter=1)
-    A, h, u = _state(spec, seed=5)
-    out = []
-    for gb in ("40", "0.0015"):
-        monkeypatch.setenv("GF_SCRATCH_GB", gb)
-        D = _lib.DeviceModel(A)
-        D.set_thickness(h)
-        D.set_u(u)
-        D.assemble()
-        out.append([D.residual()] + [D.values(w) for w in range(5)])
-        D.close()
-    for x, y in zip(*out):
-        assert np.array_equal(x, y)
+    monkeypatch.setenv("GF_ASSEMBLY", "block")
+    for p in (3, 4):
+        spec = G.synthetic_shell(3, 2, nel=5, p=p, jitter=1)
+        A, h, u = _state(spec, seed=5)
+        out = []
+        for gb in ("40", "0.0015" if p == 3 else "0.004"):
+            monkeypatch.setenv("GF_SCRATCH_GB", gb)
+            D = _lib.DeviceModel(A)
+            assert D.assembly_path == 0
+            D.set_thickness(h)
+            D.set_u(u)
+            D.assemble()
+            out.append([D.residual()] + [D.values(w) for w in range(5)])
+            D.close()
+        for x, y in zip(*out):
+            assert np.array_equal(x, y)
 
 
 def test_single_patch_without_interfaces(oracle_lib):
@@ -340,42 +306,3 @@ def test_create_rejects_bad_models():
     spec = ProblemSpec([p1, p2], [], 1.0, 0.3, 0.1, [[0, 0, 0]] * 2)
     with pytest.raises(RuntimeError, match="degree"):
         _lib.DeviceModel(arrays_from_spec(spec))
-
-
-def test_four_wave_gather_is_bitwise_the_one_wave_gather(oracle_lib, monkeypatch):
-    """The one-wave gather (default) and the four-wave gather (GF_GATHER1=0) add the element
-    blocks in the same fixed order: identical bits for every output, for p = 2, 3, 4."""
-    from goldfish_amd import _lib
-    for case in ("tbeam2_p2", "shell3x2_p3", "shell2x2_p4"):
-        A, h, u = _state(CASES[case]())
-        out = []
-        for env in ("1", "0"):
-            monkeypatch.setenv("GF_GATHER1", env)
-            D = _lib.DeviceModel(A)
-            D.set_thickness(h)
-            D.set_u(u)
-            D.assemble(_lib.ASM_ALL)
-            out.append([D.residual().copy()] + [D.values(w).copy() for w in range(5)])
-            D.assemble(_lib.ASM_R | _lib.ASM_K)                      # the Newton pass uses the leaner instance
-            out[-1] += [D.residual().copy(), D.values(0).copy()]
-            D.close()
-        for x, y in zip(*out):
-            assert np.array_equal(x, y), case
-
-
-def test_atomic_transposed_products_still_match(oracle_lib, monkeypatch):
-    """GF_ATOMIC_T=1 keeps the FP64-atomic scatter for the transposed products (the fixed-order gather is the default)."""
-    from goldfish_amd import _lib
-    monkeypatch.setenv("GF_ATOMIC_T", "1")
-    A, h, u = _state(G.tbeam_2patch(6), seed=4)
-    D = _lib.DeviceModel(A)
-    D.set_thickness(h)
-    D.set_u(u)
-    D.assemble()
-    rng = np.random.default_rng(10)
-    for which in (2, 4):
-        Mx = D.csr(which)
-        xt, z = rng.standard_normal(Mx.shape[0]), np.zeros(Mx.shape[1])
-        D.apply(which, xt, z, transpose=True)
-        assert _rel(z, Mx.T @ xt) < 1e-12
-    D.close()

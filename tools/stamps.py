@@ -14,14 +14,14 @@ L = _lib.lib(); out = (C.c_ulonglong * 8)()
 D.assemble(); L.gf_debug_stamps(out)
 D.assemble(); L.gf_debug_stamps(out)
 mfma = os.environ.get("GF_ELEMENT", "mfma") != "valu"
-walk = D.assembly_path in (2, 4)
-nw = (D.n_elements / 8.0) if walk else (1 if mfma else 2) * ((D.n_elements + 31) // 32)      # 1 in 32 elements sampled (walking kernel: 1 in 8 items; per element)
-names = (["phase0 load", "phase1 pointwise", "lane constants", "basis at GP", "row expansion", "row write + sync", "rz/rh + H MFMA", "T + MFMA contraction (+last: phase 3 excluded)"] if mfma else
-         ["phase0 load", "phase1 pointwise(+barrier wait)", "descriptors", "S1 expansion", "barrier1", "S2 T-formation", "barrier2", "S3 contraction"])
-if D.assembly_path == 4:
+rec = D.assembly_path == 4
+nw = (D.n_elements / 8.0) if rec else (1 if mfma else 2) * ((D.n_elements + 31) // 32)      # 1 in 32 elements sampled (row-record kernel: 1 in 8 items; per element)
+if rec:
     names = ["ring -> staging", "phase1 pointwise", "-", "fetch issue (next element)", "group loop (expansion, T, MFMA)", "park + residual", "record stores", "-"]
-elif walk:
-    names = ["ring -> staging", "phase1 pointwise", "flush half 2 (dR/dCP of the previous element)", "fetch issue (next element)", "group loop (expansion, T, MFMA)", "park + residual", "flush half 1 (K, dR/dh)", "-"]
+elif mfma:
+    names = ["phase0 load", "phase1 pointwise", "-", "-", "group loop (expansion, T, MFMA)", "-", "-", "-"]
+else:
+    names = ["phase0 load", "phase1 pointwise(+barrier wait)", "descriptors", "S1 expansion", "barrier1", "S2 T-formation", "barrier2", "S3 contraction"]
 tot = sum(out)
 for n, v in zip(names, out):
     print("%-34s %10.0f cycles/wave  %5.1f%%" % (n, v / nw, 100.0 * v / tot))
