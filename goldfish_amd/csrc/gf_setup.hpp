@@ -195,7 +195,6 @@ inline void HostModel::build(const gf_model_desc* D) {
         if (s < n_owned) ngp += int64_t(P.nelu) * P.nelv * (P.p + 1) * (P.q + 1);
     }
     if (nelem >= (int64_t(1) << 31)) throw std::runtime_error("gf_create: too many elements");
-    (void)basis_fp32;
     elem_patch.resize(nelem);
     for (int s = 0; s < np; ++s) std::fill(elem_patch.begin() + patches[s].elem_off, elem_patch.begin() + patches[s].elem_off + int64_t(patches[s].nelu) * patches[s].nelv, s);
     elem_desc.resize(nelem);
