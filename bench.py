@@ -5,12 +5,15 @@ One "step" = one pass of the hot path over the synthetic multi-patch shell: resi
 tangent K, dR/dCP (3 fields) and dR/dh (everything DispImOpeartion.apply_nonlinear +
 linearize produce, GOLDFISH/operations/disp_imop.py:33-56), penalty coupling included,
 with control points, thickness and displacements already resident in HBM.
-metric = element-Gauss-point updates per second (BASELINE.json); the workload is C4
-(16x16 bicubic NURBS patches, ~2.0M dofs, ~9.4M Gauss points), the
-largest configuration that fits one GPU; for N > 1 the same model is patch-sharded
-(strong scaling) and every step ends with the RCCL all-reduce of the global residual.
+metric = element-Gauss-point updates per second (BASELINE.json); the default workload is C4
+(16x16 bicubic NURBS patches, ~2.0M dofs, ~9.4M Gauss points), the configuration
+BASELINE.json's metric is quoted on at one GPU; for N > 1 the same model is patch-sharded
+(strong scaling) and every step ends with the RCCL all-gather of the owned residual rows.
+C5 (32x32 quartic patches of the fuselage skin, ~10M dofs, 71.9M Gauss points) is
+`--geometry fuselage --patches 32 32 --nel 53 --degree 4` (whether it fits one GPU: DESIGN.md section 4, measured), one GPU's
+share of it `--geometry fuselage --patches 16 8 --nel 53 --degree 4`.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--patches NX NY] [--nel E] [--degree P]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--geometry shell|fuselage] [--patches NX NY] [--nel E] [--degree P]
 N > 1:  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -56,7 +59,7 @@ def cpu_baseline(args, ncores):
 
     def run(npatch, nthreads, reps):
         oracle_py.lib().gfo_set_num_threads(nthreads)
-        spec = G.synthetic_shell(npatch, 1, nel=args.nel, p=args.degree, jitter=2)
+        spec = make_spec(args, npatch, 1)
         th = G.random_thickness(spec)
         A = arrays_from_spec(spec, th)
         O = oracle_py.Oracle(A, thickness=np.concatenate(th), u=G.smooth_displacement(spec, 0.5 * spec.h_th))
@@ -81,6 +84,19 @@ def cpu_baseline(args, ncores):
                       "best of 5 after 1 warm-up (%.1f s)" % (nall, gpn, nall, tn)}
 
 
+def make_spec(args, nx, ny):
+    """The synthetic generator of the workload: the doubly curved shell of C4 or the cylindrical fuselage skin of C5."""
+    from goldfish_amd import geometry as G
+    if args.geometry == "fuselage":
+        return G.synthetic_fuselage(nx, ny, nel=args.nel, p=args.degree, jitter=2)
+    return G.synthetic_shell(nx, ny, nel=args.nel, p=args.degree, jitter=2)
+
+
+def workload_name(args):
+    key = (args.geometry, tuple(args.patches), args.nel, args.degree)
+    return {("shell", (16, 16), 48, 3): "C4", ("fuselage", (32, 32), 53, 4): "C5", ("fuselage", (16, 8), 53, 4): "one GPU's share (1/8) of C5"}.get(key, "custom")
+
+
 def kname_of(D, p):
     """Name of the dominant kernel of the path the handle runs (gf_assembly_path)."""
     return {4: "kl_element_rec_kernel", 3: "kl_element_kernel"}.get(D.assembly_path, "kl_element_mfma4_kernel" if p == 4 else "kl_element_mfma_kernel")
@@ -91,6 +107,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--geometry", choices=["shell", "fuselage"], default="shell")
     ap.add_argument("--patches", type=int, nargs=2, default=[16, 16])
     ap.add_argument("--nel", type=int, default=48)
     ap.add_argument("--degree", type=int, default=3)
@@ -126,7 +143,7 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    spec = G.synthetic_shell(args.patches[0], args.patches[1], nel=args.nel, p=args.degree, jitter=2)
+    spec = make_spec(args, args.patches[0], args.patches[1])
     th_g = G.random_thickness(spec)
     u_g = G.smooth_displacement(spec, 0.5 * spec.h_th)
     part = sharding.partition_patches(spec, world)          # interface-graph partition balanced by Gauss points
@@ -224,8 +241,8 @@ def main():
         alg_bytes = ALG_BYTES_PER_GP[p] * n_gp_local
         achieved = alg_bytes / (kern_ms_step * 1e-3) / 1e9 if kern_ms_step > 0 else 0.0
         traffic = counter_flop = step_traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
+        import glob
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic*.json"))):     # PMC-derived bytes / flop of the profiled workloads (tools/traffic_from_pmc.py)
             try:
                 tj = json.load(open(tf))
                 if tj.get("workload_gps") == n_gp_local and str(tj.get("element_kernel", "")).startswith(kname_of(D, args.degree)):
@@ -233,16 +250,17 @@ def main():
                     counter_flop = tj.get("element_kernel_fp64_flop_issued_per_launch")
                     step_traffic = tj.get("full_pass_bytes_per_step")
             except Exception:
-                traffic = counter_flop = step_traffic = None
+                pass
         mfma = os.environ.get("GF_ELEMENT", "mfma") != "valu"
         kname = kname_of(D, p)
         out = {
             "metric": "element-Gauss-point updates/sec (assembly+adjoint)", "value": value, "unit": "GP-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s synthetic %dx%d-patch curved NURBS shell, p=%d, %d spans/side +-2 (non-matching), "
+            "config": {"workload": "%s synthetic %dx%d-patch %s, p=%d, %d spans/side +-2 (non-matching), "
                                    "%d dofs, %d Gauss points, %d mortar points; R+K+dRdCP(3)+dRdh incl. penalty coupling"
-                                   % ("C4" if (args.patches == [16, 16] and args.nel == 48 and p == 3) else "custom", args.patches[0], args.patches[1], p, args.nel, 3 * shard.total_cp_global, n_gp_total,
+                                   % (workload_name(args), args.patches[0], args.patches[1], "curved NURBS shell" if args.geometry == "shell" else "cylindrical fuselage skin",
+                                      p, args.nel, 3 * shard.total_cp_global, n_gp_total,
                                       sum(i.npts for i in spec.interfaces)),
                        "parallelism": "patch-sharded x%d (interface-graph partition), owner-computes-rows, all-gather of the owned residual rows" % world,
                        "partition": {"gauss_points_per_rank": pq["gauss_points"], "imbalance_max_over_mean": pq["imbalance"],

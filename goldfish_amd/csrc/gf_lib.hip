@@ -91,7 +91,8 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             if (const char* s = getenv("GF_ASSEMBLY")) want_rec = want_rec && std::string(s) != "block";
             int seg = 0;                                      // whole strips unless the model is small (HostModel::build_rec); GF_REC_SEG: elements per work item
             if (const char* s = getenv("GF_REC_SEG")) seg = std::max(1, atoi(s));
-            if (want_rec) { H.build_rec(seg); h->rec = true; }
+            H.tick("penalty owner lists, visit records");
+            if (want_rec) { H.build_rec(seg); h->rec = true; H.tick("row-record tables"); }
         }
         std::vector<long long> nbs(H.nb_ptr_s.begin(), H.nb_ptr_s.end()), nbc(H.nb_ptr_c.begin(), H.nb_ptr_c.end());
         h->d_cp4 = h->dalloc<double>(4 * H.total_cp); h->d_u = h->dalloc<double>(H.ndof); h->d_h = h->dalloc<double>(H.total_cp); h->d_R = h->dalloc<double>(H.ndof);
@@ -184,6 +185,12 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         h->ev0.resize(64); h->ev1.resize(64);
         for (int k = 0; k < 64; ++k) { HIPCHK(hipEventCreate(&h->ev0[k])); HIPCHK(hipEventCreate(&h->ev1[k])); }
         HIPCHK(hipDeviceSynchronize());
+        H.tick("device allocations, uploads, memsets");
+        if (const char* s = getenv("GF_SETUP_TIMING")) if (std::string(s) == "1") {
+            double tot = 0; for (const auto& t : H.timing) tot += t.second;
+            fprintf(stderr, "gf_create: %.1f ms (%lld control points, %lld elements, %lld mortar vertices)\n", tot, (long long)H.total_cp, (long long)H.nelem, (long long)H.npts);
+            for (const auto& t : H.timing) fprintf(stderr, "  %9.1f ms  %s\n", t.second, t.first.c_str());
+        }
     } catch (const std::exception& ex) {
         if (h) gf_destroy(h);
         return fail(ex.what());

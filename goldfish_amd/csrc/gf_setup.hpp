@@ -9,6 +9,7 @@
 // mortar vertices, and the FE<->IGA extraction does not exist.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -125,6 +126,13 @@ struct HostModel {
     std::vector<double> weights;
     std::vector<unsigned char> zero;    // [ndof]
     std::vector<int64_t> pl_dof; std::vector<double> pl_val;
+    // set-up phases and their wall time in ms (printed by gf_create when GF_SETUP_TIMING=1)
+    std::vector<std::pair<std::string, double>> timing;
+    std::chrono::steady_clock::time_point t_last = std::chrono::steady_clock::now();
+    void tick(const char* what) {
+        const auto t = std::chrono::steady_clock::now();
+        timing.push_back({what, std::chrono::duration<double, std::milli>(t - t_last).count()}); t_last = t;
+    }
     // neighbour lists (CP level): shell only / shell + coupling
     std::vector<int64_t> nb_ptr_s, nb_ptr_c; std::vector<int> nb_s, nb_c;
     std::vector<int> nb_rev_s, nb_rev_c;   // per neighbour entry (a, k) with b = nb[k]: position of a in b's list (the relation is symmetric): fixed-order transposed products
@@ -145,6 +153,7 @@ struct HostModel {
 };
 
 inline void HostModel::build(const gf_model_desc* D) {
+    t_last = std::chrono::steady_clock::now();
     np = D->n_patches;
     if (np <= 0) throw std::runtime_error("gf_create: model has no patches");
     degree = D->degree[0];
@@ -226,6 +235,7 @@ inline void HostModel::build(const gf_model_desc* D) {
         }
     }
 
+    tick("patch tables, elements, Dirichlet, point loads");
     // ---- mortar points ------------------------------------------------------------
     ni = D->n_interfaces;
     const int NB = (degree + 1) * (degree + 1);
@@ -286,6 +296,7 @@ inline void HostModel::build(const gf_model_desc* D) {
             for (int a : touched) { ranges[2 * i + sd].push_back({a, lo[a], hi[a]}); lo[a] = hi[a] = -1; }
         }
     }
+    tick("mortar vertices: spans, basis values, control-point ranges");
     // coupling partners per CP and the block / row owner lists
     // two control points couple iff some mortar vertex has both in its support windows (the ranges are
     // only bounding ranges when an intersection curve is not monotone in the control net)
@@ -361,6 +372,7 @@ inline void HostModel::build(const gf_model_desc* D) {
             for (int k = 0; k < 5; ++k) { c.bu[k] = k < c.neu ? spu[eu0 + k] - P.p : 0; c.bv[k] = k < c.nev ? spv[ev0 + k] - P.q : 0; }
         }
     }
+    tick("neighbour lists (shell, coupling), reverse indices, control-point descriptors");
     // per-entry metadata of the coupling lists: what the gather's write phase would otherwise derive from dependent loads
     nb_meta.assign(nb_c.size(), 0);
     for (int s = 0; s < np; ++s) {
@@ -383,6 +395,7 @@ inline void HostModel::build(const gf_model_desc* D) {
             }
         }
     }
+    tick("per-entry metadata of the coupling lists");
     // owner lists: (interface, side, vertex range) items grouped by owned control point
     {
         std::vector<PenRowItem> rows;

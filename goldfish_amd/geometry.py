@@ -27,6 +27,8 @@ class ProblemSpec:
     penalty_coefficient: float = 1.0e3
     name: str = ""
     load_proj: list = None                 # per patch (3,): non-zero = load per unit projected area (gf_model_desc.load_proj)
+    pressure: list = None                  # per patch: follower pressure (gf_model_desc.pressure)
+    edge_traction: list = None             # [(patch, direction, side, (fx, fy, fz)), ...]: dead force per unit length of the edge xi_direction = side
 
 
 def tbeam_2patch(num_el=10, p=3, load=(0.0, 0.0, 1.0), tip_load=-10.0):

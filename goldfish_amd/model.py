@@ -73,6 +73,8 @@ class gf_model_desc(C.Structure):
         ("if_wt", C.POINTER(C.c_double)), ("if_alpha", C.POINTER(C.c_double)),
         ("n_owned_patches", C.c_int32),
         ("load_proj", C.POINTER(C.c_double)),
+        ("pressure", C.POINTER(C.c_double)),
+        ("edge_traction", C.POINTER(C.c_double)),
     ]
 
 
@@ -84,7 +86,7 @@ class ModelArrays:
     """Owns the NumPy buffers behind a ``gf_model_desc`` (keeps them alive)."""
 
     def __init__(self, patches, E, nu, body_force=None, interfaces=(), alphas=(),
-                 point_loads=(), n_owned=0, load_proj=None):
+                 point_loads=(), n_owned=0, load_proj=None, pressure=None, edge_traction=None):
         n = len(patches)
         self.n_patches = n
         self.n_owned = int(n_owned) if n_owned else n
@@ -109,6 +111,13 @@ class ModelArrays:
         self.body_force = np.ascontiguousarray(bf).ravel()
         lp = np.zeros((n, 3)) if load_proj is None else np.asarray(load_proj, float).reshape(n, 3)
         self.load_proj = np.ascontiguousarray(lp).ravel()
+        # follower pressure per patch; dead edge tractions [(patch, direction, side, (fx, fy, fz)), ...] -> [n][2 * direction + side][3]
+        self.pressure = np.zeros(n) if pressure is None else np.ascontiguousarray(np.broadcast_to(np.asarray(pressure, float), (n,)))
+        et = np.zeros((n, 4, 3))
+        for s_, d_, side_, f_ in (edge_traction or ()):
+            et[int(s_), 2 * int(d_) + int(side_)] += np.asarray(f_, float)
+        self.edge_traction = np.ascontiguousarray(et).ravel()
+        self.symmetric_K = not np.any(self.pressure != 0.0)              # the load stiffness of a follower pressure is not symmetric
         zd = []
         for s, p in enumerate(patches):
             zd += [3 * int(self.cp_off[s]) + d for d in sorted(p.zero_dofs)]
@@ -148,6 +157,8 @@ class ModelArrays:
         d.if_wt, d.if_alpha = _ptr(self.if_wt, C.c_double), _ptr(self.if_alpha, C.c_double)
         d.n_owned_patches = self.n_owned
         d.load_proj = _ptr(self.load_proj, C.c_double)
+        d.pressure = _ptr(self.pressure, C.c_double)
+        d.edge_traction = _ptr(self.edge_traction, C.c_double)
         return d
 
 
@@ -184,4 +195,5 @@ def arrays_from_spec(spec, thickness=None):
               for itf in spec.interfaces]
     cp_off = np.concatenate([[0], np.cumsum([p.ncp for p in spec.patches])])
     pls = point_load_entries(spec.patches, cp_off, spec.point_loads)
-    return ModelArrays(spec.patches, E, nu, spec.body_force, spec.interfaces, alphas, pls, load_proj=getattr(spec, "load_proj", None))
+    return ModelArrays(spec.patches, E, nu, spec.body_force, spec.interfaces, alphas, pls, load_proj=getattr(spec, "load_proj", None),
+                       pressure=getattr(spec, "pressure", None), edge_traction=getattr(spec, "edge_traction", None))

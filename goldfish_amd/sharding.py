@@ -153,7 +153,10 @@ def shard_spec(spec, rank, world, part=None):
     local = ProblemSpec([spec.patches[g] for g in order], itfs, spec.E, spec.nu, spec.h_th,
                         [spec.body_force[g] for g in order], pls, spec.penalty_coefficient,
                         "%s[rank %d/%d]" % (spec.name, rank, world),
-                        None if getattr(spec, "load_proj", None) is None else [spec.load_proj[g] for g in order])
+                        None if getattr(spec, "load_proj", None) is None else [spec.load_proj[g] for g in order],
+                        pressure=None if getattr(spec, "pressure", None) is None else [spec.pressure[g] for g in order],
+                        edge_traction=None if getattr(spec, "edge_traction", None) is None else
+                        [(g2l[s], d, side, f) for (s, d, side, f) in spec.edge_traction if s in g2l])
     cpg = np.concatenate([[0], np.cumsum([p.ncp for p in spec.patches])]).astype(np.int64)
     cpl = np.concatenate([[0], np.cumsum([p.ncp for p in local.patches])]).astype(np.int64)
     return Shard(rank, world, local, len(own), order, cpg, cpl, [[int(g) for g in np.flatnonzero(part == r)] for r in range(world)])

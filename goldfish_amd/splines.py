@@ -253,7 +253,7 @@ class NURBSPatch:
                 Bm[r, sp - p:sp + 1] = basis_ders(sp, x, p, kn, 0)[0]
             return Bm
         Bu, Bv = bmat(self.knots[0], self.p, self.n_u, us), bmat(self.knots[1], self.q, self.n_v, vs)
-        Aw = np.einsum("ri,sj,ijc->rsc", Bu, Bv, self.control)
+        Aw = np.einsum("sj,rjc->rsc", Bv, np.tensordot(Bu, self.control, (1, 0)), optimize=True)     # two small products, not one five-index contraction
         return Aw[:, :, :3] / Aw[:, :, 3:4]
 
     def mean_element_size(self):

@@ -68,6 +68,13 @@ typedef struct gf_model_desc {
                                   i.e. f cos(beta) per unit surface area with cos(beta) = d . A2 -- the "snow" load of
                                   demos_om/shape_opt/arch/arch_shape_opt_wint.py:294-301 (d = e_z); geometry dependent:
                                   it enters dR/dCP                                                         */
+    const double*  pressure;   /* NULL or [n_patches]: follower pressure p, dWext = p sqrt(det a / det A) a2 . z dA = p (x_,1 x x_,2) . z dxi on the
+                                  DEFORMED configuration (demos_om/shape_opt/tube/tube_shape_opt_wint.py:303-324): enters R, K (the load
+                                  stiffness, not symmetric element by element) and dR/dCP                         */
+    const double*  edge_traction; /* NULL or [12*n_patches]: dead force per unit reference length on the patch edge xi_d = side, entry
+                                  [3*(2*d + side) + k]; dWext = f . z |dX/dt| dt along the edge (``inner(f*bdry, z)*spline.ds``,
+                                  demos_om/thickness_opt/plate/plate_const_th_opt_wint.py:235-250): enters R and, through the edge
+                                  length measure, dR/dCP                                                           */
 } gf_model_desc;
 
 /* which-matrix selectors shared by product and oracle */

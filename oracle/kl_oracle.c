@@ -55,6 +55,7 @@ typedef struct {
     double *wu, *wv;         /* [nel][ng] Gauss weight * span length/2 */
     int64_t cp_off;
     double E, nu_, f[3], pd[3];   /* pd != 0: load per unit projected area (gf_model_desc.load_proj) */
+    double press, et[4][3];       /* follower pressure; dead edge tractions, edge 2 d + side (gf_model_desc.pressure / edge_traction) */
 } patch_t;
 
 typedef struct {
@@ -234,6 +235,8 @@ gfo_model* gfo_create(const gf_model_desc* D) {
         P->kv = (double*)malloc(sizeof(double) * (o2 - o1)); memcpy(P->kv, D->knots + o1, sizeof(double) * (o2 - o1));
         P->cp_off = D->cp_off[s]; P->E = D->young[s]; P->nu_ = D->poisson[s];
         for (int k = 0; k < 3; ++k) { P->f[k] = D->body_force ? D->body_force[3 * s + k] : 0.0; P->pd[k] = D->load_proj ? D->load_proj[3 * s + k] : 0.0; }
+        P->press = D->pressure ? D->pressure[s] : 0.0;
+        for (int e = 0; e < 4; ++e) for (int k = 0; k < 3; ++k) P->et[e][k] = D->edge_traction ? D->edge_traction[12 * s + 3 * e + k] : 0.0;
         patch_tables(P);
     }
     M->cp = (double*)calloc(M->ndof, sizeof(double)); M->u = (double*)calloc(M->ndof, sizeof(double));
@@ -445,7 +448,8 @@ static void shell_element(const gfo_model* M, const patch_t* P, int eu, int ev, 
             double de[3] = {0.5 * Vd[r].dm[0], 0.5 * Vd[r].dm[1], 0.5 * Vd[r].dm[2]};
             double dk[3] = {-Vd[r].db[0], -Vd[r].db[1], -Vd[r].db[2]};
             rint[r] = dot3(nv, de) + dot3(mo, dk);
-            Re[r] += wq * (J * rint[r] - sload * P->f[r % 3] * Rb[0][r / 3]);
+            /* follower pressure p sqrt(det a / det A) a2 . z dA = p (g1 x g2) . z dxi (tube_shape_opt_wint.py:303-324): no J */
+            Re[r] += wq * (J * rint[r] - sload * P->f[r % 3] * Rb[0][r / 3] - P->press * nt[r % 3] * Rb[0][r / 3]);
         }
         if (want_fun) {
             for (int s = 0; s < nd; ++s) {
@@ -492,9 +496,11 @@ static void shell_element(const gfo_model* M, const patch_t* P, int eu, int ev, 
                 double ddk[3];
                 for (int k = 0; k < 3; ++k) ddk[k] = -f3[k] * (Rb[3 + k][a] * Vd[s].dn[ir] + Rb[3 + k][b] * Vd[r].dn[js] + dot3(g[2 + k], ddn));
                 double krs = th * dot3(der, Cde) + t3 * dot3(dkr, Cdk) + dot3(nv, dde) + dot3(mo, ddk);
-                Ke[r * nd + s] += wq * J * krs;
+                /* load stiffness of the follower pressure: d(g1 x g2)/dU_s = d(g1 x g2)/dc_s (the deformed tangents see c + U) */
+                const double pk = -P->press * Rb[0][a] * Vd[s].dnt[ir];
+                Ke[r * nd + s] += wq * (J * krs + pk);
                 double phi21 = dJ * rint[r] + J * (dot3(dnv, der) + dot3(dmo, dkr)) - dsl * P->f[ir] * Rb[0][a];
-                Ce[r * nd + s] += wq * (J * krs + phi21);
+                Ce[r * nd + s] += wq * (J * krs + pk + phi21);
             }
         }
     }
@@ -612,6 +618,51 @@ static void penalty_all(const gfo_model* M, int want_mats, out_t* O, double* Wpe
     }
 }
 
+/* ------------------------------------------------------------------ edge tractions
+ * dWext = f . z |dX/dt| dt on the patch edge xi_d = side (t = the other parameter), p + 1 Gauss points per edge span:
+ * R_(a,i) -= w f_i R_a |X_t|,  dR_(a,i)/dc_(b,k) -= w f_i R_a (X_t,k / |X_t|) R_b,t  (the measure depends on the geometry; no K term) */
+static void edge_loads(const gfo_model* M, out_t* O, int want_mats) {
+    for (int s = 0; s < M->np; ++s) {
+        const patch_t* P = &M->P[s];
+        for (int e = 0; e < 4; ++e) {
+            const double* f = P->et[e];
+            if (f[0] == 0 && f[1] == 0 && f[2] == 0) continue;
+            const int d = e / 2, side = e % 2, td = 1 - d;                       /* t runs along direction td */
+            const int pt = td ? P->q : P->p, pd_ = d ? P->q : P->p, nelt = td ? P->nelv : P->nelu, ng = td ? P->ngv : P->ngu;
+            const double* kd = d ? P->kv : P->ku; const int nd_ = d ? P->nv : P->nu;
+            const double xfix = side ? kd[nd_] : kd[pd_];
+            const int sd = find_span(nd_, pd_, kd, xfix);
+            double dd[3][MAXP + 1]; basis_ders(sd, xfix, pd_, kd, dd);
+            const int* spt = td ? P->spanv : P->spanu; const double* tabt = td ? P->bv : P->bu; const double* wt = td ? P->wv : P->wu;
+            const int nb = (P->p + 1) * (P->q + 1);
+            for (int et = 0; et < nelt; ++et) for (int g = 0; g < ng; ++g) {
+                const double* tt = tabt + (size_t)((et * ng + g) * 3) * (pt + 1);
+                const double wq = wt[et * ng + g];
+                double Nb[6][MAXNB], Rb[6][MAXNB], wl[MAXNB], c[MAXNB][3]; int64_t gid[MAXNB];
+                const int iu0 = (d == 0 ? sd : spt[et]) - P->p, iv0 = (d == 1 ? sd : spt[et]) - P->q;
+                for (int jv = 0; jv <= P->q; ++jv) for (int ju = 0; ju <= P->p; ++ju) {
+                    const int a = ju + jv * (P->p + 1);
+                    const double u0 = d == 0 ? dd[0][ju] : tt[ju], u1 = d == 0 ? dd[1][ju] : tt[(pt + 1) + ju], u2 = d == 0 ? dd[2][ju] : tt[2 * (pt + 1) + ju];
+                    const double v0 = d == 1 ? dd[0][jv] : tt[jv], v1 = d == 1 ? dd[1][jv] : tt[(pt + 1) + jv], v2 = d == 1 ? dd[2][jv] : tt[2 * (pt + 1) + jv];
+                    Nb[0][a] = u0 * v0; Nb[1][a] = u1 * v0; Nb[2][a] = u0 * v1; Nb[3][a] = u2 * v0; Nb[4][a] = u0 * v2; Nb[5][a] = u1 * v1;
+                    const int64_t gg = P->cp_off + (iu0 + ju) + (int64_t)(iv0 + jv) * P->nu; gid[a] = gg; wl[a] = M->w[gg];
+                    for (int k = 0; k < 3; ++k) c[a][k] = M->cp[3 * gg + k];
+                }
+                rationalize(nb, Nb, wl, Rb);
+                const double* Rt = Rb[1 + td];                                  /* derivative along the edge */
+                double Xt[3] = {0, 0, 0};
+                for (int a = 0; a < nb; ++a) for (int k = 0; k < 3; ++k) Xt[k] += Rt[a] * c[a][k];
+                const double len = sqrt(dot3(Xt, Xt));
+                for (int a = 0; a < nb; ++a) for (int i = 0; i < 3; ++i) {
+                    if (O->R) O->R[3 * gid[a] + i] -= wq * f[i] * Rb[0][a] * len;
+                    if (want_mats) for (int b = 0; b < nb; ++b) for (int k = 0; k < 3; ++k)
+                        if (O->C[k] && Rb[0][a] != 0.0 && Rt[b] != 0.0) O->C[k][pos_C(M, gid[a], i, gid[b])] -= wq * f[i] * Rb[0][a] * Xt[k] / len * Rt[b];
+                }
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ drivers */
 static void run_shell(const gfo_model* M, int want_mats, int want_fun, out_t* O) {
     /* patches own disjoint shell rows/entries -> parallel over patches is race-free */
@@ -627,7 +678,7 @@ static void run_shell(const gfo_model* M, int want_mats, int want_fun, out_t* O)
 
 void gfo_residual(const gfo_model* M, double* R) {
     out_t O; memset(&O, 0, sizeof(O)); memset(R, 0, sizeof(double) * M->ndof); O.R = R;
-    run_shell(M, 0, 0, &O); penalty_all(M, 0, &O, NULL);
+    run_shell(M, 0, 0, &O); penalty_all(M, 0, &O, NULL); edge_loads(M, &O, 0);
     for (int64_t k = 0; k < M->npl; ++k) R[M->pl_dof[k]] -= M->pl_val[k];
     for (int64_t r = 0; r < M->ndof; ++r) if (M->zero[r]) R[r] = 0;
 }
@@ -638,7 +689,7 @@ void gfo_assemble(const gfo_model* M, double* K, double* C0, double* C1, double*
     if (K) memset(K, 0, sizeof(double) * gfo_nnz(M, GF_MAT_K));
     for (int f = 0; f < 3; ++f) if (O.C[f]) memset(O.C[f], 0, sizeof(double) * gfo_nnz(M, GF_MAT_DRDCP0));
     if (H) memset(H, 0, sizeof(double) * gfo_nnz(M, GF_MAT_DRDH));
-    run_shell(M, 1, 0, &O); penalty_all(M, 1, &O, NULL);
+    run_shell(M, 1, 0, &O); penalty_all(M, 1, &O, NULL); edge_loads(M, &O, 1);
     /* Dirichlet: K rows+cols zero, diag 1; dRdCP rows zero; dRdh untouched (nonmatching_opt.py:1012-1014) */
     for (int64_t a = 0; a < M->total_cp; ++a) {
         int64_t deg = M->nb_ptr_c[a + 1] - M->nb_ptr_c[a];
@@ -662,11 +713,11 @@ void gfo_functionals(const gfo_model* M, double out[3], double* dWdu, double* dW
     O.dWdcp[0] = dWdcp0; O.dWdcp[1] = dWdcp1; O.dWdcp[2] = dWdcp2; O.dWdh = dWdh; O.dVdcp[0] = dVdcp0; O.dVdcp[1] = dVdcp1; O.dVdcp[2] = dVdcp2; O.dVdh = dVdh;
     for (int f = 0; f < 3; ++f) { if (O.dWdcp[f]) memset(O.dWdcp[f], 0, sizeof(double) * M->total_cp); if (O.dVdcp[f]) memset(O.dVdcp[f], 0, sizeof(double) * M->total_cp); }
     if (dWdh) memset(dWdh, 0, sizeof(double) * M->total_cp); if (dVdh) memset(dVdh, 0, sizeof(double) * M->total_cp);
-    /* body force must not enter dWint/du: temporarily zero it */
-    gfo_model* MM = (gfo_model*)M; double (*fs)[3] = (double (*)[3])malloc(sizeof(double[3]) * M->np);
-    for (int s = 0; s < M->np; ++s) for (int k = 0; k < 3; ++k) { fs[s][k] = MM->P[s].f[k]; MM->P[s].f[k] = 0; }
+    /* the loads must not enter dWint/du: temporarily zero them */
+    gfo_model* MM = (gfo_model*)M; double (*fs)[4] = (double (*)[4])malloc(sizeof(double[4]) * M->np);
+    for (int s = 0; s < M->np; ++s) { for (int k = 0; k < 3; ++k) { fs[s][k] = MM->P[s].f[k]; MM->P[s].f[k] = 0; } fs[s][3] = MM->P[s].press; MM->P[s].press = 0; }
     run_shell(M, 0, 1, &O);
-    for (int s = 0; s < M->np; ++s) for (int k = 0; k < 3; ++k) MM->P[s].f[k] = fs[s][k];
+    for (int s = 0; s < M->np; ++s) { for (int k = 0; k < 3; ++k) MM->P[s].f[k] = fs[s][k]; MM->P[s].press = fs[s][3]; }
     free(fs);
     double Wpen = 0; out_t O2; memset(&O2, 0, sizeof(O2)); penalty_all(M, 0, &O2, &Wpen);
     out[0] = O.Wint; out[1] = O.Vol; out[2] = Wpen;

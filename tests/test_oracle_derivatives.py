@@ -34,17 +34,24 @@ def _relerr(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-@pytest.mark.parametrize("name", ["slr9", "tbeam", "slr9_projected_load"])
+@pytest.mark.parametrize("name", ["slr9", "tbeam", "slr9_projected_load", "slr9_pressure_edge_traction", "tbeam_pressure_edge_traction"])
 def test_oracle_vs_autograd(oracle_lib, name):
     spec = G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2]) if name.startswith("slr9") else G.tbeam_2patch(4)
     if name == "slr9_projected_load":                 # load per unit projected area along a general direction (arch demo: e_z)
         spec.load_proj = [[0.3, -0.2, 1.0]] * len(spec.patches)
+    if name.endswith("pressure_edge_traction"):       # follower pressure (tube demo) on every second patch + dead edge tractions (plate demo)
+        n = len(spec.patches)
+        spec.pressure = [(-1.0e4 if s % 2 == 0 else 0.0) * (1 + s) for s in range(n)]
+        spec.edge_traction = [(n - 1, 0, 1, (30.0, -20.0, -100.0)), (0, 1, 0, (0.0, 50.0, 10.0)), (n - 1, 1, 1, (5.0, 0.0, 7.0))]
     A, O, T, c, U, ht = _setup(spec)
     free = np.ones(A.ndof, bool)
     free[A.zero_dofs] = False
 
     def grad_total(U_, c_, h_):
-        return torch.autograd.grad(T.total(c_, U_, h_), U_, create_graph=True)[0].reshape(-1)
+        g = torch.autograd.grad(T.total(c_, U_, h_), U_, create_graph=True)[0]
+        V = torch.zeros_like(U_, requires_grad=True)          # loads without an energy: the residual is the coefficient of the virtual displacement
+        ge = torch.autograd.grad(T.extra_virtual_work(c_, U_, V), V, create_graph=True, allow_unused=True)[0]
+        return (g - ge).reshape(-1) if ge is not None else g.reshape(-1)
 
     def grad_shell(U_, h_):
         return torch.autograd.grad(T.shell_energy(c, U_, h_), U_, create_graph=True)[0].reshape(-1)

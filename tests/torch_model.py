@@ -76,6 +76,27 @@ class TorchModel:
         self.f = torch.tensor(arrays.body_force.reshape(-1, 3))[self.pid]
         self.pd = torch.tensor(arrays.load_proj.reshape(-1, 3))[self.pid]
         self.proj = (self.pd.abs().sum(-1) > 0).to(torch.float64)
+        self.press = torch.tensor(arrays.pressure)[self.pid]
+        # Gauss points of the loaded patch edges (gf_model_desc.edge_traction): ids, rational basis, weight, force, direction along the edge
+        self.edges = []
+        et = arrays.edge_traction.reshape(-1, 4, 3)
+        for s, P in enumerate(spec.patches):
+            w = P.cp_hom_flat()[:, 3]
+            off = int(arrays.cp_off[s])
+            for e in range(4):
+                if not np.any(et[s, e]):
+                    continue
+                d, side, td = e // 2, e % 2, 1 - e // 2
+                deg = (P.p, P.q)[td]
+                kn = np.unique(P.knots[td])
+                gx, gw = _gauss(deg + 1)
+                fixed = P.knots[d][0] if side == 0 else P.knots[d][-1]
+                for a0, a1 in zip(kn[:-1], kn[1:]):
+                    for x, wg in zip(gx, gw):
+                        xi = [0.0, 0.0]
+                        xi[d], xi[td] = fixed, 0.5 * (a0 + a1) + 0.5 * (a1 - a0) * x
+                        i, Nb, R = _point_basis(P, w, xi)
+                        self.edges.append((torch.tensor(i + off), torch.tensor(R[0]), torch.tensor(R[1 + td]), 0.5 * (a1 - a0) * wg, torch.tensor(et[s, e])))
         # mortar points
         self.mp = []
         for k, itf in enumerate(spec.interfaces):
@@ -104,6 +125,18 @@ class TorchModel:
             s = self.proj * (self.pd * Nt).sum(-1) + (1 - self.proj) * ke.area_jacobian(Z)
             W = W - (self.wq * s * (self.f * uphys).sum(-1)).sum()
         return W
+
+    def extra_virtual_work(self, c, U, V):
+        """Virtual work of the loads that are not the gradient of a stored energy, linear in the virtual displacement coefficients V:
+        follower pressure p (x_,1 x x_,2) . z dxi on the deformed configuration (tube demo) + dead edge tractions f . z |X_,t| dt."""
+        dl = (c + U)[self.ids]
+        z = torch.einsum("gma,gak->gmk", self.Rb[:, 1:3], dl)
+        zt = torch.einsum("ga,gak->gk", self.Rb[:, 0], V[self.ids])
+        vw = (self.wq * self.press * (torch.linalg.cross(z[:, 0, :], z[:, 1, :]) * zt).sum(-1)).sum()
+        for ids, R0, Rt, w, f in self.edges:
+            Xt = (Rt[:, None] * c[ids]).sum(0)
+            vw = vw + w * (f * (R0[:, None] * V[ids]).sum(0)).sum() * torch.sqrt((Xt * Xt).sum())
+        return vw
 
     def volume(self, c, h):
         Z = torch.einsum("gma,gak->gmk", self.Rb[:, 1:], c[self.ids])

@@ -2,6 +2,7 @@
 gfx950 correction: FETCH_SIZE counts 64 B per 128-B request -> bytes = 2*FETCH + WRITE, MI355X_MICROARCH.md HBM section)."""
 import csv, json, sys, collections
 tag, gps = sys.argv[1], int(sys.argv[2])
+outfile = sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json"       # usage: traffic_from_pmc.py <tag> <Gauss points of the profiled workload> [output]
 def per_kernel(path, counter):
     tot, n = collections.defaultdict(float), collections.defaultdict(set)
     for r in csv.DictReader(open(path)):
@@ -18,9 +19,9 @@ for k in sorted(set(f) | set(w)):
     kern[k] = {"FETCH_SIZE_bytes_raw_per_launch": f.get(k, 0.0), "WRITE_SIZE_bytes_raw_per_launch": w.get(k, 0.0),
                "hbm_side_bytes_corrected_per_launch": 2 * f.get(k, 0.0) + w.get(k, 0.0), "launches": nf.get(k, nw.get(k, 0))}
 el = sorted((k for k in kern if k.startswith("kl_element")), key=lambda k: -kern[k]["hbm_side_bytes_corrected_per_launch"])   # the full-pass instance first
-out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_*.csv), bench.py C4; averages per launch. "
+out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_*.csv), bench.py (workload of %d Gauss points); averages per launch. "
                "Counters are KB at the L2<->fabric interface (Infinity-Cache hits included); corrected = 2*FETCH + WRITE "
-               "(gfx950: FETCH_SIZE counts 64 B per 128-B request)." % tag,
+               "(gfx950: FETCH_SIZE counts 64 B per 128-B request)." % (tag, gps),
        "workload_gps": gps, "kernels": kern,
        "element_kernel": el[0] if el else None,
        "element_kernel_bytes_per_launch": kern[el[0]]["hbm_side_bytes_corrected_per_launch"] if el else None}
@@ -53,5 +54,5 @@ if os.path.exists(fp):
         if c.get("SQ_WAVE_CYCLES", 0.0) > 0: kern[k]["mfma_busy_cycles_over_wave_cycles_x4"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * c["SQ_WAVE_CYCLES"])
     out["fp64_note"] = "SQ counters (profiles/%s_pmc_fp64.csv): issued FP64 flop per launch = 512 * MFMA_MOPS_F64 + 64 * (2 FMA_F64 + ADD_F64 + MUL_F64 + TRANS_F64); SQ_WAVE_CYCLES counts quad-cycles" % tag
     if el: out["element_kernel_fp64_flop_issued_per_launch"] = kern[el[0]].get("fp64_flop_issued_per_launch")
-json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+json.dump(out, open(outfile, "w"), indent=1)
 print(json.dumps({k: round(v["hbm_side_bytes_corrected_per_launch"] / 1e9, 2) for k, v in kern.items()}))
