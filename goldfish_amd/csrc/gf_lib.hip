@@ -18,6 +18,7 @@ constexpr int GF_ASM_R_BIT = 1, GF_ASM_K_BIT = 2, GF_ASM_C_BIT = 4, GF_ASM_H_BIT
 #include "gf_element_rec.hpp"
 #include "gf_penalty_row16.hpp"
 #include "gf_penalty_point16.hpp"
+#include "gf_extra_loads.hpp"
 
 using namespace gf;
 
@@ -49,6 +50,7 @@ struct gf_handle {
     const WalkItem* d_rec_items = nullptr; const RecCp* d_rec_cp = nullptr; double* d_rec = nullptr; long long rec_doubles = 0;
     bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
     const int *d_rev_s = nullptr, *d_rev_c = nullptr;
+    const int* d_load_cps = nullptr;                  // control points of the follower pressure / edge tractions (gf_extra_loads.hpp)
     bool gather1 = true;                              // element-block path: one-wave gather for p <= 3, four-wave gather for p = 4
     int pen_maxdeg = 0;                               // largest neighbour count of an interface control point
     bool pen16 = true;                                // p = 2, 3: pen_point16_kernel + pen_row16_kernel (16 lanes per mortar vertex / per visit); p = 4 and GF_PENALTY=owner: pen_point_kernel + pen_owner_kernel
@@ -106,6 +108,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         M.patches = h->upload(H.patches); M.tab = h->upload(H.tab); M.ints = h->upload(H.ints);
         M.elem_patch = h->upload(H.elem_patch); M.cp_patch = h->upload(H.cp_patch); M.edesc = h->upload(H.elem_desc); M.cpdesc = h->upload(H.cp_desc); M.nb_meta = h->upload(H.nb_meta);
         h->d_rev_s = h->upload(H.nb_rev_s); h->d_rev_c = h->upload(H.nb_rev_c);
+        h->d_load_cps = h->upload(H.load_cps);
         M.cp4 = h->d_cp4; M.u = h->d_u; M.h = h->d_h; M.zero = h->upload(H.zero);
         M.nb_ptr_s = h->upload(nbs); M.nb_s = h->upload(H.nb_s); M.nb_ptr_c = h->upload(nbc); M.nb_c = h->upload(H.nb_c);
         M.total_cp = H.total_cp; M.nelem = H.nelem;
@@ -304,6 +307,13 @@ template <int P> static int run_penalty(gf_handle* h, int flags) {
     return pen;
 }
 
+// follower pressure and dead edge tractions: added to the rows the gather has written (and to the gathered residual)
+template <int P> static void run_extra_loads(gf_handle* h, int flags) {
+    const int n = (int)h->H.load_cps.size();
+    if (n == 0 || !(flags & (GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP))) return;
+    hipLaunchKernelGGL(kl_extra_loads_kernel<P>, dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_load_cps, n, flags, h->d_R, h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3]);
+}
+
 static void finish_residual(gf_handle* h) {
     const HostModel& H = h->H;
     const long long npl = (long long)H.pl_dof.size();
@@ -336,10 +346,9 @@ template <int P> static void run_assemble_rec(gf_handle* h, int flags) {
                                 h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], pen_add);
     };
     if (mats) gather(nullptr, na, c.a0, c.a1, pen);
-    if (flags & GF_ASM_R) {
-        hipLaunchKernelGGL(kl_rgather_kernel<P>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, h->d_blk, h->d_R, pen, 3 * (P + 1) * (P + 1), 0);
-        finish_residual(h);
-    }
+    if (flags & GF_ASM_R) hipLaunchKernelGGL(kl_rgather_kernel<P>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, h->d_blk, h->d_R, pen, 3 * (P + 1) * (P + 1), 0);
+    run_extra_loads<P>(h, flags);
+    if (flags & GF_ASM_R) finish_residual(h);
     HIPCHK(hipGetLastError());
 }
 
@@ -382,6 +391,7 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
         hipLaunchKernelGGL(kl_gather_kernel<P>, dim3((unsigned)na), dim3(256), 0, gs, h->M, c.a0, c.e0, ne, flags, blk,
                            h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], h->d_R, pen);
     }
+    run_extra_loads<P>(h, flags);
     if (flags & GF_ASM_R) finish_residual(h);
     HIPCHK(hipGetLastError());
 }
@@ -506,7 +516,7 @@ int gf_apply_dev(gf_handle* h, int which, int transpose, const double* x, double
     // K is symmetric including its Dirichlet treatment (rows+cols zeroed, unit diagonal): K^T x = K x, so the
     // transposed product uses the atomic-free row kernel as well (bitwise reproducible adjoint products with K)
     // (not on a shard: ghost rows are not assembled there, so the local K is not symmetric)
-    if (which == GF_MAT_K && (!transpose || h->H.n_owned == h->H.np)) hipLaunchKernelGGL(csr_apply_kernel<3>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
+    if (which == GF_MAT_K && (!transpose || (h->H.n_owned == h->H.np && h->H.symmetric_K))) hipLaunchKernelGGL(csr_apply_kernel<3>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
     else if (!transpose) hipLaunchKernelGGL(csr_apply_kernel<1>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_val[which], x, y);
     else if (bw == 1) hipLaunchKernelGGL(csr_apply_tdet_kernel<1>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, which == GF_MAT_DRDH ? h->d_rev_s : h->d_rev_c, h->d_val[which], x, y);
     else hipLaunchKernelGGL(csr_apply_tdet_kernel<3>, dim3(grid_cp), dim3(256), 0, h->stream, ncp, ptr, nb, h->d_rev_c, h->d_val[which], x, y);

@@ -31,6 +31,7 @@ struct PatchDev {            // POD mirrored on the device
     int c2u, c2v;            // offsets into ints[] : [n][2] first/last element touching CP index
     long long cp_off, elem_off;
     double E, nu_, f[3], pd[3];   // pd != 0: load per unit projected area (gf_model_desc.load_proj)
+    double press, et[12];         // follower pressure; dead edge tractions [2 d + side][3] (gf_model_desc.pressure / edge_traction; gf_extra_loads.hpp)
 };
 
 // per-element descriptor: one load instead of the elem_patch -> patch -> span-table chain of dependent scalar loads
@@ -126,6 +127,8 @@ struct HostModel {
     std::vector<double> weights;
     std::vector<unsigned char> zero;    // [ndof]
     std::vector<int64_t> pl_dof; std::vector<double> pl_val;
+    bool symmetric_K = true;            // false: a follower pressure adds its (non-symmetric) load stiffness to K
+    std::vector<int> load_cps;          // owned control points that carry a follower pressure or an edge traction (kl_extra_loads_kernel)
     // set-up phases and their wall time in ms (printed by gf_create when GF_SETUP_TIMING=1)
     std::vector<std::pair<std::string, double>> timing;
     std::chrono::steady_clock::time_point t_last = std::chrono::steady_clock::now();
@@ -173,6 +176,9 @@ inline void HostModel::build(const gf_model_desc* D) {
         P.cp_off = D->cp_off[s]; P.E = D->young[s]; P.nu_ = D->poisson[s];
         if (D->cp_off[s + 1] - D->cp_off[s] != int64_t(P.nu) * P.nv) throw std::runtime_error("gf_create: cp_off inconsistent with ncp");
         for (int k = 0; k < 3; ++k) { P.f[k] = D->body_force ? D->body_force[3 * s + k] : 0.0; P.pd[k] = D->load_proj ? D->load_proj[3 * s + k] : 0.0; }
+        P.press = D->pressure ? D->pressure[s] : 0.0;
+        for (int k = 0; k < 12; ++k) P.et[k] = D->edge_traction ? D->edge_traction[12 * s + k] : 0.0;
+        if (P.press != 0.0) symmetric_K = false;
         for (int64_t a = P.cp_off; a < D->cp_off[s + 1]; ++a) cp_patch[a] = s;
         for (int d = 0; d < 2; ++d) {
             const int p = d ? P.q : P.p, n = d ? P.nv : P.nu;
@@ -394,6 +400,23 @@ inline void HostModel::build(const gf_model_desc* D) {
                 nb_meta[k] = (unsigned short)(slot | (zero[3 * b] ? 128 : 0) | (zero[3 * b + 1] ? 256 : 0) | (zero[3 * b + 2] ? 512 : 0) | (b == a ? 1024 : 0));
             }
         }
+    }
+    // control points of the loads that run behind the gather (gf_extra_loads.hpp): every control point of a pressurised patch, the
+    // edge row of a loaded edge
+    {
+        std::vector<unsigned char> mark(owned_cp > 0 ? owned_cp : 1, 0);
+        for (int s = 0; s < n_owned; ++s) {
+            const PatchDev& P = patches[s];
+            if (P.press != 0.0) for (int64_t a = P.cp_off; a < P.cp_off + int64_t(P.nu) * P.nv; ++a) mark[a] = 1;
+            for (int e = 0; e < 4; ++e) {
+                if (P.et[3 * e] == 0.0 && P.et[3 * e + 1] == 0.0 && P.et[3 * e + 2] == 0.0) continue;
+                const int d = e >> 1, side = e & 1;
+                if (d == 0) { const int i = side ? P.nu - 1 : 0; for (int j = 0; j < P.nv; ++j) mark[P.cp_off + i + int64_t(j) * P.nu] = 1; }
+                else { const int j = side ? P.nv - 1 : 0; for (int i = 0; i < P.nu; ++i) mark[P.cp_off + i + int64_t(j) * P.nu] = 1; }
+            }
+        }
+        load_cps.clear();
+        for (int64_t a = 0; a < owned_cp; ++a) if (mark[a]) load_cps.push_back((int)a);
     }
     tick("per-entry metadata of the coupling lists");
     // owner lists: (interface, side, vertex range) items grouped by owned control point

@@ -119,8 +119,9 @@ def edge_traction_point_loads(patches, s, direction, side, force, ngauss=None):
     """Dead edge traction ``inner(force, rationalize(v)) * ds`` on the edge ``xi_direction = side`` of patch ``s``
     (force per unit physical length) as consistent nodal forces: Gauss points along the edge, each a point load
     (patch, xi, field, value) of ProblemSpec.point_loads with value = force_i |dX/dt| w_gp / W(xi) (the 1/W turns the
-    non-rational test function of a point load into the rational one).  Valid while the geometry is fixed (thickness
-    optimisation, analysis); a shape-dependent edge load is not on the device path."""
+    non-rational test function of a point load into the rational one).  Valid while the geometry is fixed; the device path
+    carries the same load as ``ProblemSpec.edge_traction`` (gf_model_desc.edge_traction), including its dR/dCP term -- this
+    function is the independent statement the tests compare it with."""
     P = patches[s]
     t_dir = 1 - direction                                   # the parameter that runs along the edge
     kn = np.unique(P.knots[t_dir])
@@ -162,10 +163,10 @@ def plate_6patch(p=3):
     mn = [17, 19, 19, 17, 16]
     itfs = [Interface.from_endpoints(k, k + 1, [[1.0, 0.0], [1.0, 1.0]], [[0.0, 0.0], [0.0, 1.0]], mn[k]) for k in range(5)]
     # the reference loads the xi_0 = 1 edge of the last patch with -100 per unit length (inner(f1 * bdry1, v) * ds,
-    # plate_const_th_opt_wint.py:235-250): a dead load on a fixed geometry, i.e. consistent nodal forces
+    # plate_const_th_opt_wint.py:235-250): gf_model_desc.edge_traction (the edge length measure makes it shape dependent: it
+    # enters dR/dCP on the device; edge_traction_point_loads is the same load as fixed nodal forces, kept as the cross-check)
     bf = [[0.0, 0.0, 0.0]] * 6
-    pls = edge_traction_point_loads(patches, 5, 0, 1, (0.0, 0.0, -100.0))
-    return ProblemSpec(patches, itfs, 68e9, 0.35, 1.0e-2, bf, pls, 1.0e3, "plate_6patch")
+    return ProblemSpec(patches, itfs, 68e9, 0.35, 1.0e-2, bf, [], 1.0e3, "plate_6patch", edge_traction=[(5, 0, 1, (0.0, 0.0, -100.0))])
 
 
 def wing_16patch_from_interface_data(int_data, nel=10, p=3, seed=SEED):

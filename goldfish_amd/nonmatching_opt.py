@@ -25,11 +25,15 @@ from .model import Interface, ModelArrays, penalty_parameters, point_load_entrie
 @dataclass
 class SVKResidual:
     """Declarative stand-in for ``SVK_residual(spline, u, v, E, nu, h, dWext)`` with
-    ``dWext = inner(f, rationalize(v)) * dx`` (GOLDFISH/tests/test_dRdt.py:100-110).  ``projected`` = a direction d makes
+    ``dWext = inner(f, rationalize(v)) * dx`` (GOLDFISH/tests/test_dRdt.py:100-110) plus the two other source terms the reference's
+    demos use (follower ``pressure``, ``edge_tractions``; both shape dependent: they enter dR/dCP on the device, the pressure also K).  ``projected`` = a direction d makes
     the load act per unit projected area, ``f cos(beta)`` with ``cos(beta) = d . A2`` -- the source term of
     demos_om/shape_opt/arch/arch_shape_opt_wint.py:294-301 (``force = -load * inner(e_z, A2) e_z``)."""
     body_force: tuple = (0.0, 0.0, 0.0)
     projected: tuple = (0.0, 0.0, 0.0)
+    pressure: float = 0.0          # follower pressure: dWext = p sqrt(det a / det A) a2 . z dA (demos_om/shape_opt/tube/tube_shape_opt_wint.py:303-324)
+    edge_tractions: tuple = ()     # ((direction, side, (fx, fy, fz)), ...): dead force per unit length on the edge xi_direction = side,
+                                   # dWext = f . z ds (demos_om/thickness_opt/plate/plate_const_th_opt_wint.py:235-250)
 
 
 @dataclass
@@ -319,7 +323,9 @@ class NonMatchingOpt:
                                      [(s, ps.xi, ps.field, ps.value) for ps, s in zip(self.point_sources, self.point_source_inds)])
         bf = [list(r.body_force) for r in self.residuals]
         lp = [list(getattr(r, "projected", (0.0, 0.0, 0.0))) for r in self.residuals]
-        return ModelArrays(self.splines, self.E, self.nu, bf, self.interfaces, alphas, pls, load_proj=lp)
+        pr = [float(getattr(r, "pressure", 0.0)) for r in self.residuals]
+        et = [(s, d, side, tuple(f)) for s, r in enumerate(self.residuals) for (d, side, f) in getattr(r, "edge_tractions", ())]
+        return ModelArrays(self.splines, self.E, self.nu, bf, self.interfaces, alphas, pls, load_proj=lp, pressure=pr, edge_traction=et)
 
     @property
     def dev(self):
@@ -448,14 +454,22 @@ class NonMatchingOpt:
         self._dev = self._dsolver = self._hlu = None
         self._touch()
 
-    def _host_solve(self, rhs, ver):
+    def _host_solve(self, rhs, ver, transpose=False):
         from scipy.sparse.linalg import splu
         if getattr(self, "_hlu", None) is None or self._hlu_version != ver:
             self._hlu, self._hlu_version = splu(self.dev.csr(_lib.MAT_K).tocsc()), ver
-        return self._hlu.solve(rhs)
+        return self._hlu.solve(rhs, trans="T" if transpose else "N")
 
-    def solve_K(self, rhs):
-        """x = K^{-1} rhs (= K^{-T} rhs: K is symmetric) with the tangent currently assembled on the device.
+    @property
+    def symmetric_K(self):
+        """False when a follower pressure contributes its load stiffness (then K^T differs from K and the symmetric device
+        factorisation does not apply: solves run on the host path)."""
+        self.dev
+        return bool(getattr(getattr(self, "_arrays_cache", None), "symmetric_K", True))
+
+    def solve_K(self, rhs, transpose=False):
+        """x = K^{-1} rhs, or K^{-T} rhs with ``transpose`` (the same thing unless a follower pressure makes K non-symmetric), with the
+        tangent currently assembled on the device.
         ``linear_solver == "device"`` (default): bandwidth-reducing ordering once on the host, then every call after a new
         assembly is a block-banded L D L^T factorisation + substitutions + iterative refinement on the GPU
         (goldfish_amd/_solver.py, csrc/gf_solver.hip); K's values are read in place from the library's buffer.  The
@@ -466,6 +480,8 @@ class NonMatchingOpt:
         Replaces GOLDFISH/utils/opt_utils.py:156-209 (MUMPS on a copy of K per call)."""
         rhs = np.asarray(rhs, float)
         ver = getattr(self, "_k_version", 0)
+        if not self.symmetric_K:
+            return self._host_solve(rhs, ver, transpose)
         if self.linear_solver == "device" and getattr(self, "_dsolver_failed_version", None) != ver:
             from . import _solver
             why = None
@@ -710,7 +726,11 @@ class NonMatchingOpt:
             pb.mortar_meshes_setup([[i.a, i.b] for i in spec.interfaces], [[i.xi_a, i.xi_b] for i in spec.interfaces],
                                    spec.penalty_coefficient)
         lp = spec.load_proj if getattr(spec, "load_proj", None) is not None else [(0.0, 0.0, 0.0)] * len(spec.patches)
-        pb.set_residuals([SVKResidual(tuple(f), tuple(d)) for f, d in zip(spec.body_force, lp)])
+        pr = spec.pressure if getattr(spec, "pressure", None) is not None else [0.0] * len(spec.patches)
+        ets = [[] for _ in spec.patches]
+        for (s, d, side, f) in (getattr(spec, "edge_traction", None) or ()):
+            ets[s].append((d, side, tuple(f)))
+        pb.set_residuals([SVKResidual(tuple(f), tuple(d), float(p), tuple(e)) for f, d, p, e in zip(spec.body_force, lp, pr, ets)])
         if spec.point_loads:
             pb.set_point_sources([PointSource(xi, f, v) for (_, xi, f, v) in spec.point_loads],
                                  [s for (s, _, _, _) in spec.point_loads])

@@ -105,6 +105,7 @@ class DispImOpeartion(object):
         return d_outputs_array
 
     def solve_linear_rev(self, d_outputs_array, d_residuals_array):
-        """disp_imop.py:137-142: d_residuals = K^{-T} d_outputs (K is symmetric including its Dirichlet treatment)."""
-        d_residuals_array[:] = self.nonmatching_opt.solve_K(d_outputs_array)
+        """disp_imop.py:137-142: d_residuals = K^{-T} d_outputs (K is symmetric including its Dirichlet treatment unless a follower
+        pressure contributes its load stiffness)."""
+        d_residuals_array[:] = self.nonmatching_opt.solve_K(d_outputs_array, transpose=True)
         return d_residuals_array

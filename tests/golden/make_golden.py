@@ -32,8 +32,17 @@ def plate_from_reference_data():
     return spec
 
 
+def with_pressure_and_edge_tractions(spec):
+    """Follower pressure (tube demo) on every second patch + dead edge tractions (plate demo) on three edges."""
+    n = len(spec.patches)
+    spec.pressure = [(-1.0e4 if s % 2 == 0 else 0.0) * (1 + s) for s in range(n)]
+    spec.edge_traction = [(n - 1, 0, 1, (30.0, -20.0, -100.0)), (0, 1, 0, (0.0, 50.0, 10.0)), (n - 1, 1, 1, (5.0, 0.0, 7.0))]
+    return spec
+
+
 CASES = {"tbeam2": lambda: G.tbeam_2patch(4), "plate6_refdata": plate_from_reference_data,
-         "tbeam2_p2": lambda: G.tbeam_2patch(4, p=2), "shell2x2_p4": lambda: G.synthetic_shell(2, 2, nel=3, p=4, jitter=1)}
+         "tbeam2_p2": lambda: G.tbeam_2patch(4, p=2), "shell2x2_p4": lambda: G.synthetic_shell(2, 2, nel=3, p=4, jitter=1),
+         "tbeam2_pressure_edge": lambda: with_pressure_and_edge_tractions(G.tbeam_2patch(4))}
 
 
 def state(spec, seed=11):

@@ -44,7 +44,17 @@ CASES = {
     "shell2x2_p3_double_knots": lambda: G.with_double_knots(G.synthetic_shell(2, 2, nel=6, p=3, jitter=1)),
     "slr9_p2_projected_load": lambda: _with_projected_load(G.scordelis_lo_9patch(4, p=2)),
     "shell2x2_p4_projected_load": lambda: _with_projected_load(G.synthetic_shell(2, 2, nel=4, p=4, jitter=1)),
+    # follower pressure (tube demo: R, non-symmetric load stiffness, dR/dCP) + dead edge tractions (plate demo: R, dR/dCP): gf_extra_loads.hpp
+    "slr9_nurbs_p3_pressure_edge": lambda: _with_pressure_edge(G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2])),
+    "tbeam2_p2_pressure_edge": lambda: _with_pressure_edge(G.tbeam_2patch(4, p=2)),
+    "shell2x2_p4_pressure_edge": lambda: _with_pressure_edge(G.synthetic_shell(2, 2, nel=4, p=4, jitter=1)),
+    "shell3x2_p3_double_knots_pressure_edge": lambda: _with_pressure_edge(G.with_double_knots(G.synthetic_shell(3, 2, nel=6, p=3, jitter=1))),
 }
+
+
+def _with_pressure_edge(spec):
+    from tests.golden.make_golden import with_pressure_and_edge_tractions
+    return with_pressure_and_edge_tractions(spec)
 
 
 def _with_projected_load(spec):
