@@ -2,8 +2,11 @@
 // Build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC gf_solver.hip -o ../libgoldfish_solver.so      (no library dependency)
 //
 // Storage: control points renumbered by the caller's bandwidth-reducing order; n = 3 ncp dofs padded to nblk tiles of NB = 64
-// (identity on the padding); lower block band, tile (I, d) = block (I, I - d), d = 0 .. T, dense 64 x 64 row-major at
-// ((I (T + 1) + d) NB^2).  Right-looking factorisation over block columns k, three launches per k:
+// (identity on the padding); lower block SKYLINE: block row I keeps the tiles (I, I - d), d = 0 .. Tr[I], from its first coupled
+// block column on (envelope made monotone, so that the rows that reach a block column are contiguous), dense 64 x 64 row-major at
+// (rowoff[I] + d) NB^2.  The penalty coupling reaches 2 (p + 1) control-point rows across an interface but only p rows inside a
+// patch: the skyline holds about half the tiles of the uniform band of round 2 and the factorisation does a third of its work.
+// Right-looking factorisation over block columns k, three launches per k:
 //   diag_kernel     A_kk = L_kk D_k L_kk^T in LDS (one workgroup), and L_kk^-1 (unit lower) for the panel and the solves
 //   panel_kernel    W_ik = A_ik L_kk^-T,  L_ik = W_ik D_k^-1           (one workgroup per tile, 64^3 product on v_mfma_f64_16x16x4)
 //   update_kernel   A_ij -= W_ik L_jk^T   for k < j <= i <= k + T       (one workgroup per tile, same product)
@@ -53,7 +56,7 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ g, double* 
 
 // K (block CSR of libgoldfish_hip, original numbering) -> lower block band in the factorisation order; identity on the padding
 __global__ void band_fill_kernel(long long ncp, const long long* __restrict__ nb_ptr, const int* __restrict__ nb, const int* __restrict__ newi,
-                                 const double* __restrict__ valK, double* __restrict__ band, int T, long long n, long long npad) {
+                                 const double* __restrict__ valK, double* __restrict__ band, const long long* __restrict__ rowoff, long long n, long long npad) {
     const long long a = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (a < ncp) {
@@ -68,20 +71,20 @@ __global__ void band_fill_kernel(long long ncp, const long long* __restrict__ nb
                     const long long r = 3 * pa + i, c = 3 * pb + j;
                     if (r < c) continue;
                     const long long I = r >> 6, d = I - (c >> 6);
-                    band[((size_t)I * (T + 1) + d) * NB2 + (r & 63) * NB + (c & 63)] = valK[9 * ptr + (long long)i * 3 * deg + 3 * k + j];
+                    band[(size_t)(rowoff[I] + d) * NB2 + (r & 63) * NB + (c & 63)] = valK[9 * ptr + (long long)i * 3 * deg + 3 * k + j];
                 }
         }
     }
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < npad - n) { const long long r = n + t, I = r >> 6; band[((size_t)I * (T + 1)) * NB2 + (r & 63) * NB + (r & 63)] = 1.0; }
+    if (t < npad - n) { const long long r = n + t, I = r >> 6; band[(size_t)rowoff[I] * NB2 + (r & 63) * NB + (r & 63)] = 1.0; }
 }
 
 // diagonal tile of block column k: L D L^T (lower, no pivoting) and the inverse of the unit lower factor
-__global__ __launch_bounds__(256) void diag_kernel(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, int T, int k, double* __restrict__ stat) {
+__global__ __launch_bounds__(256) void diag_kernel(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
     __shared__ double s[NB * (NB + 1)], v[NB * (NB + 1)];
     constexpr int S1 = NB + 1;
     const int tid = threadIdx.x;
-    double* A = band + ((size_t)k * (T + 1)) * NB2;
+    double* A = band + (size_t)rowoff[k] * NB2;
     for (int q = tid; q < NB2; q += 256) s[(q >> 6) * S1 + (q & 63)] = A[q];
     // thread (i, jg): rows i, columns 16 jg .. 16 jg + 15 of the trailing update
     const int i = tid >> 2, jg = tid & 3;
@@ -127,10 +130,10 @@ __global__ __launch_bounds__(256) void diag_kernel(double* __restrict__ band, do
 }
 
 // panel tile i = k + 1 + blockIdx.x: W = A_ik L_kk^-T (to wbuf), L_ik = W D_k^-1 (in place)
-__global__ __launch_bounds__(256) void panel_kernel(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, int T, int k) {
+__global__ __launch_bounds__(256) void panel_kernel(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k) {
     __shared__ __attribute__((aligned(16))) double sA[NB * LS], sB[NB * LS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = blockIdx.x;
-    double* A = band + ((size_t)(k + 1 + g) * (T + 1) + (g + 1)) * NB2;
+    double* A = band + (size_t)(rowoff[k + 1 + g] + (g + 1)) * NB2;
     load_tile(A, sA, tid); load_tile(linv + (size_t)k * NB2, sB, tid);
     __syncthreads();
     d4 acc[4] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void panel_kernel(double* __restrict__ band, c
 }
 
 // trailing tile (i, j), k < j <= i: A_ij -= W_ik L_jk^T
-__global__ __launch_bounds__(256) void update_kernel(double* __restrict__ band, const double* __restrict__ wbuf, int T, int k, int ni) {
+__global__ __launch_bounds__(256) void update_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, int ni) {
     __shared__ __attribute__((aligned(16))) double sA[NB * LS], sB[NB * LS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // linear index -> (gi >= gj) over the lower triangle of the ni x ni tile block
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(256) void update_kernel(double* __restrict__ band, 
     if (gi >= ni) return;
     const int i = k + 1 + gi, j = k + 1 + gj;
     load_tile(wbuf + (size_t)gi * NB2, sA, tid);
-    load_tile(band + ((size_t)j * (T + 1) + (gj + 1)) * NB2, sB, tid);
-    double* C = band + ((size_t)i * (T + 1) + (gi - gj)) * NB2;
+    load_tile(band + (size_t)(rowoff[j] + (gj + 1)) * NB2, sB, tid);
+    double* C = band + (size_t)(rowoff[i] + (gi - gj)) * NB2;
     d4 acc[4];
 #pragma unroll
     for (int nj = 0; nj < 4; ++nj)
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void update_kernel(double* __restrict__ band, 
 }
 
 // forward substitution, block column k: y_k = L_kk^-1 b_k (every workgroup; workgroup 0 keeps it), b_{k+g} -= L_{k+g,k} y_k (workgroup g >= 1)
-__global__ __launch_bounds__(256) void fwd_kernel(const double* __restrict__ band, const double* __restrict__ linv, double* __restrict__ b, double* __restrict__ y, int T, int k) {
+__global__ __launch_bounds__(256) void fwd_kernel(const double* __restrict__ band, const double* __restrict__ linv, double* __restrict__ b, double* __restrict__ y, const long long* __restrict__ rowoff, int k) {
     __shared__ double sb[NB], sy[NB];
     const int tid = threadIdx.x, r = tid >> 2, q4 = tid & 3, g = blockIdx.x;
     if (tid < NB) sb[tid] = b[(size_t)k * NB + tid];
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(const double* __restrict__ ban
     }
     __syncthreads();
     if (g == 0) { if (tid < NB) y[(size_t)k * NB + tid] = sy[tid]; return; }
-    const double* L = band + ((size_t)(k + g) * (T + 1) + g) * NB2 + r * NB + 16 * q4;
+    const double* L = band + (size_t)(rowoff[k + g] + g) * NB2 + r * NB + 16 * q4;
     double part = 0.0;
 #pragma unroll
     for (int c = 0; c < 16; ++c) part += L[c] * sy[16 * q4 + c];
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(const double* __restrict__ ban
     if (q4 == 0) b[(size_t)(k + g) * NB + r] -= part;
 }
 // backward substitution, block column k: x_k = L_kk^-T z_k, z_{k-g} -= L_{k,k-g}^T x_k (workgroup g >= 1)
-__global__ __launch_bounds__(256) void bwd_kernel(const double* __restrict__ band, const double* __restrict__ linv, double* __restrict__ z, double* __restrict__ x, int T, int k) {
+__global__ __launch_bounds__(256) void bwd_kernel(const double* __restrict__ band, const double* __restrict__ linv, double* __restrict__ z, double* __restrict__ x, const long long* __restrict__ rowoff, int k) {
     __shared__ double sz[NB], sx[NB], sp[4][NB];
     const int tid = threadIdx.x, c = tid & 63, rq = tid >> 6, g = blockIdx.x;
     if (tid < NB) sz[tid] = z[(size_t)k * NB + tid];
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const double* __restrict__ ban
     if (tid < NB) sx[tid] = sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
     __syncthreads();
     if (g == 0) { if (tid < NB) x[(size_t)k * NB + tid] = sx[tid]; return; }
-    const double* L = band + ((size_t)k * (T + 1) + g) * NB2 + (16 * rq) * NB + c;
+    const double* L = band + (size_t)(rowoff[k] + g) * NB2 + (16 * rq) * NB + c;
     double part = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) part += L[r * NB] * sx[16 * rq + r];
@@ -272,11 +275,14 @@ __global__ __launch_bounds__(256) void sumsq_kernel(long long n, const double* _
 
 struct gfs_handle {
     int device = 0; hipStream_t stream = nullptr;
-    long long ncp = 0, n = 0, npad = 0, nblk = 0; int T = 0; long long bw = 0;
+    long long ncp = 0, n = 0, npad = 0, nblk = 0; int T = 0; long long bw = 0;       // T: largest number of tiles left of the diagonal in a block row
+    std::vector<int> Tr, nik;                    // per block row: tiles left of the diagonal; per block column: block rows below that reach it
+    long long* rowoff = nullptr; long long ntiles = 0;
     long long* nb_ptr = nullptr; int* nb = nullptr; int* newi = nullptr; const double* valK = nullptr;
     double *band = nullptr, *linv = nullptr, *dval = nullptr, *wbuf = nullptr, *stat = nullptr;
     double *vb = nullptr, *vy = nullptr, *vz = nullptr, *vx = nullptr, *vr = nullptr, *vsol = nullptr, *vrhs = nullptr, *part = nullptr;
     std::vector<void*> allocs; long long bytes = 0; bool factored = false, small_pivot = false;
+    long long nnz9 = 0; double normK = 0.0, backward_error = 0.0;     // Frobenius norm of the factored K; backward error of the last solve
     template <class Tp> Tp* dalloc(size_t cnt) {
         void* p = nullptr; const size_t nb_ = (cnt ? cnt : 1) * sizeof(Tp);
         HIPCHK(hipMalloc(&p, nb_)); allocs.push_back(p); bytes += (long long)nb_; return (Tp*)p;
@@ -300,13 +306,11 @@ static void substitute(gfs_handle* h, const double* rhs, double* x, int add) {
     HIPCHK(hipMemsetAsync(h->vb, 0, h->npad * sizeof(double), h->stream));
     hipLaunchKernelGGL(permute_in_kernel, dim3(g3), dim3(256), 0, h->stream, h->ncp, h->newi, rhs, h->vb);
     for (long long k = 0; k < h->nblk; ++k) {
-        const int ni = (int)std::min<long long>(h->T, h->nblk - 1 - k);
-        hipLaunchKernelGGL(fwd_kernel, dim3(ni + 1), dim3(256), 0, h->stream, h->band, h->linv, h->vb, h->vy, h->T, (int)k);
+        hipLaunchKernelGGL(fwd_kernel, dim3(h->nik[k] + 1), dim3(256), 0, h->stream, h->band, h->linv, h->vb, h->vy, h->rowoff, (int)k);
     }
     hipLaunchKernelGGL(scale_kernel, dim3(gp), dim3(256), 0, h->stream, h->npad, h->dval, h->vy, h->vz);
     for (long long k = h->nblk - 1; k >= 0; --k) {
-        const int ni = (int)std::min<long long>(h->T, k);
-        hipLaunchKernelGGL(bwd_kernel, dim3(ni + 1), dim3(256), 0, h->stream, h->band, h->linv, h->vz, h->vx, h->T, (int)k);
+        hipLaunchKernelGGL(bwd_kernel, dim3(h->Tr[k] + 1), dim3(256), 0, h->stream, h->band, h->linv, h->vz, h->vx, h->rowoff, (int)k);
     }
     hipLaunchKernelGGL(permute_out_kernel, dim3(g3), dim3(256), 0, h->stream, h->ncp, h->newi, h->vx, x, add);
     HIPCHK(hipGetLastError());
@@ -339,19 +343,38 @@ int gfs_create(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb
         HIPCHK(hipStreamCreate(&h->stream));
         h->ncp = ncp; h->n = 3 * ncp; h->nblk = (h->n + NB - 1) / NB; h->npad = h->nblk * NB;
         h->bw = 3 * bwcp + 2;
-        h->T = (int)std::min<long long>((h->bw + NB - 1) / NB, h->nblk - 1);        // a dof pair at distance <= bw lies at most ceil(bw / NB) block rows apart
-        const double gb = (double)h->nblk * (h->T + 2) * NB2 * 8.0 / 1e9;
-        size_t freeb = 0, totb = 0; HIPCHK(hipMemGetInfo(&freeb, &totb));
-        if (gb * 1e9 > 0.9 * (double)freeb)
-            throw std::runtime_error("gfs_create: the factor band needs " + std::to_string(gb) + " GB (" + std::to_string(h->n) + " dofs, half bandwidth " + std::to_string(h->bw) +
-                                     "), more than the free device memory");
+        {   // envelope: first coupled block column of every block row, made monotone (the rows that reach block column k are then k + 1 .. k + nik[k])
+            std::vector<long long> f(h->nblk);
+            for (long long I = 0; I < h->nblk; ++I) f[I] = I;
+            for (int64_t a = 0; a < ncp; ++a) {
+                long long mn = new_index[a];
+                for (int64_t k = nb_ptr[a]; k < nb_ptr[a + 1]; ++k) mn = std::min<long long>(mn, new_index[nb[k]]);
+                const long long cb = (3 * mn) >> 6;
+                for (int i = 0; i < 3; ++i) { const long long I = (3 * (long long)new_index[a] + i) >> 6; f[I] = std::min(f[I], cb); }
+            }
+            for (long long I = h->nblk - 2; I >= 0; --I) f[I] = std::min(f[I], f[I + 1]);
+            h->Tr.resize(h->nblk); h->nik.assign(h->nblk, 0);
+            std::vector<long long> off(h->nblk + 1, 0);
+            h->T = 0;
+            for (long long I = 0; I < h->nblk; ++I) { h->Tr[I] = (int)(I - f[I]); h->T = std::max(h->T, h->Tr[I]); off[I + 1] = off[I] + h->Tr[I] + 1; }
+            h->ntiles = off[h->nblk];
+            long long r = 0;
+            for (long long k = 0; k < h->nblk; ++k) { r = std::max(r, k); while (r + 1 < h->nblk && f[r + 1] <= k) ++r; h->nik[k] = (int)(r - k); }
+            h->rowoff = nullptr;
+            const double gbs = ((double)h->ntiles + h->nblk + h->T + 1) * NB2 * 8.0 / 1e9;
+            size_t freeb = 0, totb = 0; HIPCHK(hipMemGetInfo(&freeb, &totb));
+            if (gbs * 1e9 > 0.92 * (double)freeb)
+                throw std::runtime_error("gfs_create: the factor skyline needs " + std::to_string(gbs) + " GB (" + std::to_string(h->n) + " dofs, half bandwidth " + std::to_string(h->bw) +
+                                         "), more than the free device memory");
+            h->rowoff = h->up(off.data(), off.size());
+        }
         std::vector<long long> ptr(nb_ptr, nb_ptr + ncp + 1);
         h->nb_ptr = h->up(ptr.data(), ptr.size()); h->nb = h->up(nb, (size_t)nb_ptr[ncp]); h->newi = h->up(new_index, (size_t)ncp);
-        h->valK = d_valK;
-        h->band = h->dalloc<double>((size_t)h->nblk * (h->T + 1) * NB2);
+        h->valK = d_valK; h->nnz9 = 9 * (long long)nb_ptr[ncp];
+        h->band = h->dalloc<double>((size_t)h->ntiles * NB2);
         h->linv = h->dalloc<double>((size_t)h->nblk * NB2);
         h->dval = h->dalloc<double>((size_t)h->npad); h->stat = h->dalloc<double>((size_t)2 * h->nblk);
-        h->wbuf = h->dalloc<double>((size_t)std::max(h->T, 1) * NB2);
+        h->wbuf = h->dalloc<double>((size_t)std::max(h->T, 1) * NB2);       // W tiles of one panel: at most T rows reach a block column
         h->vb = h->dalloc<double>(h->npad); h->vy = h->dalloc<double>(h->npad); h->vz = h->dalloc<double>(h->npad); h->vx = h->dalloc<double>(h->npad);
         h->vr = h->dalloc<double>(h->npad); h->vsol = h->dalloc<double>(h->npad); h->vrhs = h->dalloc<double>(h->npad); h->part = h->dalloc<double>(256);
         HIPCHK(hipDeviceSynchronize());
@@ -377,14 +400,14 @@ int gfs_refactor(gfs_handle* h) {
     try {
         HIPCHK(hipSetDevice(h->device));
         h->factored = false;
-        HIPCHK(hipMemsetAsync(h->band, 0, (size_t)h->nblk * (h->T + 1) * NB2 * sizeof(double), h->stream));
-        hipLaunchKernelGGL(band_fill_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->newi, h->valK, h->band, h->T, h->n, h->npad);
+        HIPCHK(hipMemsetAsync(h->band, 0, (size_t)h->ntiles * NB2 * sizeof(double), h->stream));
+        hipLaunchKernelGGL(band_fill_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->newi, h->valK, h->band, h->rowoff, h->n, h->npad);
         for (long long k = 0; k < h->nblk; ++k) {
-            const int ni = (int)std::min<long long>(h->T, h->nblk - 1 - k);
-            hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, h->stream, h->band, h->linv, h->dval, h->T, (int)k, h->stat);
+            const int ni = h->nik[k];
+            hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, h->stream, h->band, h->linv, h->dval, h->rowoff, (int)k, h->stat);
             if (ni > 0) {
-                hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, h->stream, h->band, h->linv, h->dval, h->wbuf, h->T, (int)k);
-                hipLaunchKernelGGL(update_kernel, dim3((unsigned)(ni * (ni + 1) / 2)), dim3(256), 0, h->stream, h->band, h->wbuf, h->T, (int)k, ni);
+                hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, h->stream, h->band, h->linv, h->dval, h->wbuf, h->rowoff, (int)k);
+                hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, h->stream, h->band, h->wbuf, h->rowoff, (int)k, ni);
             }
         }
         HIPCHK(hipGetLastError());
@@ -395,6 +418,7 @@ int gfs_refactor(gfs_handle* h) {
         for (long long k = 0; k < h->nblk; ++k) { mn = std::min(mn, st[2 * k]); mx = std::max(mx, st[2 * k + 1]); }
         if (!(mn == mn) || !(mx == mx) || !std::isfinite(mx) || mn == 0.0) throw std::runtime_error("gfs_refactor: zero or non-finite pivot (K is singular for this ordering without pivoting)");
         h->small_pivot = mn < 1e-14 * mx;
+        h->normK = norm2(h, h->valK, h->nnz9);
         h->factored = true;
     } catch (const std::exception& ex) { return sfail(ex.what()); }
     return 0;
@@ -424,6 +448,10 @@ int gfs_solve_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine,
         HIPCHK(hipMemcpyAsync(d_x, h->vsol, h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         if (rel_residual) *rel_residual = nb_ > 0.0 ? best / nb_ : best;
+        // normwise backward error |b - K x| / (|K|_F |x| + |b|): the measure a backward-stable solve keeps at round-off level whatever
+        // the conditioning (|b - K x| / |b| alone has a floor of eps cond(K))
+        const double nx = norm2(h, d_x, h->n), den = h->normK * nx + nb_;
+        h->backward_error = den > 0.0 ? best / den : best;
     } catch (const std::exception& ex) { return sfail(ex.what()); }
     return 0;
 }
@@ -445,12 +473,12 @@ int gfs_solve(gfs_handle* h, const double* b, double* x, int max_refine, double*
     } catch (const std::exception& ex) { return sfail(ex.what()); }
 }
 
-int gfs_info(gfs_handle* h, double info[6]) {
+int gfs_info(gfs_handle* h, double info[8]) {
     if (!h || !info) return sfail("gfs_info: null argument");
     info[0] = (double)h->bw; info[1] = (double)h->nblk; info[2] = (double)(h->T + 1); info[3] = (double)h->bytes;
     double fl = 0.0;
-    for (long long k = 0; k < h->nblk; ++k) { const double ni = (double)std::min<long long>(h->T, h->nblk - 1 - k); fl += 2.0 * NB * NB * NB * (ni + ni * (ni + 1) / 2) + 2.0 * NB * NB * NB / 3; }
-    info[4] = fl; info[5] = h->small_pivot ? 1.0 : 0.0;
+    for (long long k = 0; k < h->nblk; ++k) { const double ni = (double)h->nik[k]; fl += 2.0 * NB * NB * NB * (ni + ni * (ni + 1) / 2) + 2.0 * NB * NB * NB / 3; }
+    info[4] = fl; info[5] = h->small_pivot ? 1.0 : 0.0; info[6] = h->backward_error; info[7] = h->normK;
     return 0;
 }
 

@@ -115,6 +115,36 @@ def scordelis_lo_9patch(num_el=6, p=3, nels=None):
     return ProblemSpec(patches, itfs, 4.32e8, 0.0, 0.25, [[0.0, -90.0, 0.0]] * 9, [], 1.0e3, "slr_9patch")
 
 
+def pressurised_tube(nels=((5, 2), (6, 3), (4, 2), (7, 3)), p=3, radius=1.0, length=0.5, E=1.0e12, h_th=0.01, pressure=1.0, shape=None):
+    """Tube under internal follower pressure -- the load case of the reference's demos_om/shape_opt/tube/tube_shape_opt_wint.py
+    (E = 1e12, nu = 0, h = 0.01, ``pressure`` acting along sqrt(det a / det A) a2, :258-262, 303-324): the closed ring as four
+    non-matching NURBS sectors of 90 degrees coupled by the penalty method, u_z = 0 (plane strain with nu = 0), the three
+    in-plane rigid-body modes removed by u_y = 0 on the generators at 0 and 180 degrees and u_x = 0 on the generator at 90
+    degrees (compatible with every doubly symmetric solution).  With u along the arc and v along the axis the normal
+    x_,1 x x_,2 points outwards: ``pressure`` > 0 is an internal pressure.  Known answer for the circle (uniform expansion
+    u_r; the curvature change B - b of the KL shell is u_r in covariant components, hence the h^2 term):
+        linearised about u = 0:  u_r = p r^2 / (E h (1 + h^2 / (12 r^2)) - p r),
+        geometrically exact membrane part:  E h eps = p r,  r' = r sqrt(1 + 2 p r / (E h)).
+    ``shape(theta)``: optional radius factor for a non-circular start (shape optimisation example)."""
+    patches = []
+    for k, ne in enumerate(nels):
+        a0, a1 = np.radians(90.0 * k), np.radians(90.0 * (k + 1))
+        s = NURBSPatch.cylinder_sector(radius, a0, a1, 0.0, length, ne[0], ne[1], p)
+        if shape is not None:                                 # scale every control point radially (homogeneous coordinates keep the weight)
+            c = s.control
+            f = shape(np.arctan2(c[:, :, 1], c[:, :, 0]))
+            c[:, :, 0] *= f
+            c[:, :, 1] *= f
+        for a in range(s.ncp):
+            s.add_zero_dofs(2, [a])
+        patches.append(s)
+    patches[0].add_zero_dofs(1, patches[0].get_side_dofs(0, 0, 1))      # generator at 0 degrees stays on y = 0
+    patches[2].add_zero_dofs(1, patches[2].get_side_dofs(0, 0, 1))      # generator at 180 degrees stays on y = 0
+    patches[1].add_zero_dofs(0, patches[1].get_side_dofs(0, 0, 1))      # generator at 90 degrees stays on x = 0
+    itfs = [Interface.from_endpoints(k, (k + 1) % 4, [[1.0, 0.0], [1.0, 1.0]], [[0.0, 0.0], [0.0, 1.0]], 3 * (nels[k][1] + nels[(k + 1) % 4][1])) for k in range(4)]
+    return ProblemSpec(patches, itfs, E, 0.0, h_th, [[0.0, 0.0, 0.0]] * 4, [], 1.0e3, "pressurised_tube", pressure=[pressure] * 4)
+
+
 def edge_traction_point_loads(patches, s, direction, side, force, ngauss=None):
     """Dead edge traction ``inner(force, rationalize(v)) * ds`` on the edge ``xi_direction = side`` of patch ``s``
     (force per unit physical length) as consistent nodal forces: Gauss points along the edge, each a point load

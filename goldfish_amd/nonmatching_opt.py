@@ -441,7 +441,8 @@ class NonMatchingOpt:
     # ------------------------------------------------------------------ direct solves with K
     linear_solver = os.environ.get("GF_LINEAR_SOLVER", "device")   # "device": block-banded L D L^T on the GPU (default); "host": scipy SuperLU on a copy of K
 
-    linear_solve_rtol = 1e-6      # |b - K x| / |b| above which a device solve is rejected (unpivoted L D L^T on an indefinite / near-singular tangent)
+    linear_solve_rtol = 1e-10     # normwise backward error |b - K x| / (|K|_F |x| + |b|) above which a device solve is rejected (unpivoted L D L^T on an
+                                  # indefinite / near-singular tangent); |b - K x| / |b| itself has a floor of eps cond(K) for any solver
 
     def _drop_device(self):
         """The device model is stale (coupling, loads or intersections changed): close it together with everything that
@@ -473,7 +474,7 @@ class NonMatchingOpt:
         ``linear_solver == "device"`` (default): bandwidth-reducing ordering once on the host, then every call after a new
         assembly is a block-banded L D L^T factorisation + substitutions + iterative refinement on the GPU
         (goldfish_amd/_solver.py, csrc/gf_solver.hip); K's values are read in place from the library's buffer.  The
-        factorisation does not pivot across tiles: every solve is checked (relative residual after refinement, finite
+        factorisation does not pivot across tiles: every solve is checked (normwise backward error after refinement, finite
         values) and one that fails -- or a band that does not fit the device, or a zero pivot -- falls back, with a warning,
         to the host path for this K.
         ``"host"``: scipy SuperLU on a host copy of K (what MUMPS does in the reference; kept as the cross-check of the tests).
@@ -487,17 +488,18 @@ class NonMatchingOpt:
             why = None
             try:
                 if getattr(self, "_dsolver", None) is None or self._dsolver.D is not self.dev:
-                    self._dsolver = _solver.DeviceSolver(self.dev)
+                    w = np.concatenate([sp_.cp_hom_flat()[:, 3] for sp_ in self.splines])
+                    self._dsolver = _solver.DeviceSolver(self.dev, coords=np.stack([self.cp_iga[f] / w for f in range(3)], 1))
                     self._dsolver_version = ver
                 elif self._dsolver_version != ver:
                     self._dsolver.refactor()
                     self._dsolver_version = ver
                 x = self._dsolver.solve(rhs)
-                rr = self._dsolver.rel_residual
-                self.linear_solve_relative_residual = rr
-                if np.all(np.isfinite(x)) and rr <= self.linear_solve_rtol:
+                rr, be = self._dsolver.rel_residual, self._dsolver.backward_error
+                self.linear_solve_relative_residual, self.linear_solve_backward_error = rr, be
+                if np.all(np.isfinite(x)) and be <= self.linear_solve_rtol:
                     return x
-                why = "relative residual %.3e > %.1e after refinement" % (rr, self.linear_solve_rtol)
+                why = "backward error %.3e > %.1e after refinement (relative residual %.3e)" % (be, self.linear_solve_rtol, rr)
             except RuntimeError as e:
                 why = str(e)
                 self._dsolver = None

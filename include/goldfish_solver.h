@@ -39,8 +39,10 @@ int gfs_refactor(gfs_handle* h);
 int gfs_solve(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual);
 int gfs_solve_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual);
 /* info[0] = half bandwidth (dofs), [1] = block columns, [2] = band tiles per block row, [3] = device bytes,
- * [4] = flops of one factorisation, [5] = 1 if the last factorisation met a pivot below 1e-14 * max |diag|, else 0 */
-int gfs_info(gfs_handle* h, double info[6]);
+ * [4] = flops of one factorisation, [5] = 1 if the last factorisation met a pivot below 1e-14 * max |diag|, else 0,
+ * [6] = normwise backward error |b - K x| / (|K|_F |x| + |b|) of the last solve (what a backward-stable solve keeps at round-off
+ * level whatever cond(K); |b - K x| / |b| alone has a floor of eps cond(K)), [7] = |K|_F of the factored matrix */
+int gfs_info(gfs_handle* h, double info[8]);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,8 @@ cases = [("C2 tbeam4", G.tbeam_4patch()), ("C3 wing 16 patches (reference interf
          ("shell 6x6 patches nel=24", G.synthetic_shell(6, 6, nel=24, p=3, jitter=2)), ("C3-size shell 4x4 patches nel=44", G.synthetic_shell(4, 4, nel=44, p=3, jitter=2))]
 if os.environ.get("GF_SOLVER_BIG"):
     cases.append(("shell 8x8 patches nel=48 (1/4 of C4)", G.synthetic_shell(8, 8, nel=48, p=3, jitter=2)))
+if os.environ.get("GF_SOLVER_C4"):
+    cases = [("C4: shell 16x16 patches nel=48", G.synthetic_shell(16, 16, nel=48, p=3, jitter=2))]
 host = os.environ.get("GF_SOLVER_HOST", "1") == "1"
 for name, spec in cases:
     A = arrays_from_spec(spec)
@@ -22,10 +24,11 @@ for name, spec in cases:
     t = time.perf_counter(); S = _solver.DeviceSolver(D); t_first = time.perf_counter() - t
     info = S.info()
     t = time.perf_counter(); S.refactor(); t_f = time.perf_counter() - t
-    t = time.perf_counter(); x = S.solve(b); t_s = time.perf_counter() - t; rr = S.rel_residual
-    t = time.perf_counter(); lam = S.solve(g); t_a = time.perf_counter() - t; ra = S.rel_residual
-    line = ("%s: %d dofs, half bandwidth %d, band %.2f GB; device: ordering + first factorisation %.3f s, re-factorisation %.4f s (%.1f TFLOP/s), Newton solve %.4f s "
-            "(residual %.1e), adjoint solve %.4f s (residual %.1e)" % (name, A.ndof, info["half_bandwidth"], info["device_bytes"] / 1e9, t_first, t_f, info["factor_flops"] / t_f / 1e12, t_s, rr, t_a, ra))
+    t = time.perf_counter(); x = S.solve(b); t_s = time.perf_counter() - t; rr, be = S.rel_residual, S.backward_error
+    t = time.perf_counter(); lam = S.solve(g); t_a = time.perf_counter() - t; ra, bea = S.rel_residual, S.backward_error
+    line = ("%s: %d dofs, half bandwidth %d, skyline %.2f GB; device: ordering + first factorisation %.3f s, re-factorisation %.4f s (%.1f TFLOP/s), Newton solve %.4f s "
+            "(residual %.1e, backward error %.1e), adjoint solve %.4f s (residual %.1e, backward error %.1e)"
+            % (name, A.ndof, info["half_bandwidth"], info["device_bytes"] / 1e9, t_first, t_f, info["factor_flops"] / t_f / 1e12, t_s, rr, be, t_a, ra, bea))
     if host and A.ndof < 150000:
         K = D.csr(_lib.MAT_K).tocsc()
         t = time.perf_counter(); lu = spla.splu(K, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True)); t_h = time.perf_counter() - t
