@@ -177,18 +177,26 @@ def test_energy_and_volume_comp_partials(var_thickness):
         assert max(errs.values()) < 1e-6, (Comp.__name__, errs)
 
 
-def _rank_worker(rank, world, port, q):
+def _rank_worker(rank, world, port, q, backend="gloo"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = rank if backend == "nccl" else 0               # nccl (= RCCL): one GPU per rank; gloo: every rank on GPU 0
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from goldfish_amd import _lib, sharding
     spec = G.synthetic_shell(3, 2, nel=4, p=3, jitter=1)
     th, u = G.random_thickness(spec), G.smooth_displacement(spec, 0.5 * spec.h_th)
-    S = sharding.ShardedDeviceModel(spec, dist, rank, world, device=0, thickness_global=th)
+    S = sharding.ShardedDeviceModel(spec, dist, rank, world, device=dev, thickness_global=th)
     S.set_thickness(np.concatenate(th))
     S.set_u(u)
     S.assemble()
+    if backend == "nccl":                                 # bench.py's exchange: device-resident all-gather of the owned residual rows
+        Rg = sharding.allgather_owned_rows(S.shard, torch.from_numpy(S.D.residual()).cuda(), dist, 3)
+        assert np.array_equal(Rg.cpu().numpy(), S.residual())
     rng = np.random.default_rng(11)                       # same seed on every rank: replicated inputs
     xu, xc, lam = rng.standard_normal(S.ndof), rng.standard_normal(S.total_cp), rng.standard_normal(S.ndof)
     res = dict(R=S.residual(), Ku=S.apply(_lib.MAT_K, xu), KTl=S.apply(_lib.MAT_K, lam, transpose=True),
@@ -203,23 +211,42 @@ def _rank_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_assembly_on_gpu(oracle_lib):
-    """Two processes (gloo; both on the single GPU of the box) own half of the patches each."""
+def _run_ranks(world, backend):
     import torch.multiprocessing as mp
-    from oracle.oracle_py import Oracle
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    ctx = mp.get_context("spawn")
+    ctx = mp.get_context("spawn")                         # fresh interpreters: the children initialise their own GPUs
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=600)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
+    return res
+
+
+def test_rccl_sharded_assembly_when_several_gpus_are_visible(oracle_lib):
+    """The N > 1 path over RCCL (backend "nccl"): min(device_count, 4) ranks, one GPU each -- residual, products, functionals and
+    the device-resident all-gather of bench.py against the unsharded oracle.  Skips on a one-GPU box (the gloo test below covers
+    the same code with both ranks on GPU 0); on a multi-GPU lease it is the first thing that exercises RCCL."""
+    import torch
+    n = torch.cuda.device_count()                         # does not initialise the GPU in this process
+    if n < 2:
+        pytest.skip("one GPU visible: RCCL needs at least two")
+    _check_sharded_results(_run_ranks(min(n, 4), "nccl"))
+
+
+def test_two_rank_sharded_assembly_on_gpu(oracle_lib):
+    """Two processes (gloo; both on the single GPU of the box) own half of the patches each."""
+    _check_sharded_results(_run_ranks(2, "gloo"))
+
+
+def _check_sharded_results(res):
+    from oracle.oracle_py import Oracle
     spec = G.synthetic_shell(3, 2, nel=4, p=3, jitter=1)
     th = G.random_thickness(spec)
     O = Oracle(arrays_from_spec(spec, th), thickness=np.concatenate(th), u=G.smooth_displacement(spec, 0.5 * spec.h_th))
