@@ -23,7 +23,7 @@ class ComplianceComp(FunctionalComp):
         return self.c_exop.cpl()
 
     def _du(self):
-        return self.c_exop.dcplduIGA(apply_bcs=False)
+        return self.c_exop.dcplduIGA(apply_bcs=True)          # compliance_comp.py:130 of the reference
 
     def _dcp(self, field):
         return self.c_exop.dcpldCPIGA(field)

@@ -94,7 +94,11 @@ class HthMapComp(_LinearMapComp):
         self.in_name = self.input_h_th_name_design = self.options['input_h_th_name_design']
         self.out_name = self.output_h_th_name_full = self.options['output_h_th_name_full']
         self.num_splines = nm.num_splines
-        sizes = [int(n) for n in nm.vec_scalar_iga_dof_list]      # one thickness value per control point of each patch
+        # thickness dofs per patch as set_thickness_opt laid them out (reference: nonmatching_opt.h_th_sizes, hth_map_comp.py:48-56): one
+        # per patch for a constant thickness (the "FE dofs" of a patch's thickness function collapse to its single value here, so the map is
+        # the identity and its output is what DispStatesComp / IntEnergyComp / VolumeComp take as ``thickness``), one per control point
+        # for a variable thickness
+        sizes = [int(n) for n in getattr(nm, "h_th_sizes", nm.vec_scalar_iga_dof_list)]
         self.init = self.init_val = np.array([float(np.mean(h)) for h in nm.h_th])
         rows = np.arange(sum(sizes))
         cols = np.repeat(np.arange(self.num_splines), sizes)

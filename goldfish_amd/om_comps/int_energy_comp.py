@@ -16,7 +16,10 @@ class IntEnergyComp(FunctionalComp):
         return self.wint_exop.Wint()
 
     def _du(self):
-        return self.wint_exop.dWintduIGA(apply_bcs=False)
+        # Dirichlet rows zeroed, as the reference does (int_energy_comp.py:94, apply_bcs=True): the constrained displacements are not
+        # free variables, and dR/dh keeps its untreated Dirichlet rows (nonmatching_opt.py:1012-1014) -- a reaction-sized entry here
+        # would reach the total derivative through them (tests/test_gpu_api.py: ThicknessOptGroup totals)
+        return self.wint_exop.dWintduIGA(apply_bcs=True)
 
     def _dcp(self, field):
         return self.wint_exop.dWintdCPIGA(field)

@@ -709,3 +709,144 @@ def test_no_valu_write_in_front_of_a_dpp_read():
     n, kernels, bad = chk.scan(chk.disassemble(build.LIB))
     assert n > 1000 and any("kl_element_rec_kernel" in k for k in kernels) and any("pen_row16_kernel" in k for k in kernels), (n, kernels)
     assert not bad, bad[:5]
+
+
+def test_om_shim_groups_totals_and_strictness():
+    """The protocol stand-in behaves like OpenMDAO where a component could pass here and fail there (openmdao itself is
+    not installable in the build image): Group + connect + compute_totals (explicit and implicit components, reverse mode) against
+    finite differences, undeclared sub-Jacobians, wrong sizes, bad connections, and an apply_linear that assigns instead of accumulating."""
+    from goldfish_amd import om_shim as om
+
+    class Sq(om.ExplicitComponent):                       # y = A x^2 (sparse declared partials)
+        def setup(self):
+            self.add_input("x", shape=3)
+            self.add_output("y", shape=2)
+            self.A = np.array([[1.0, 2.0, 0.0], [0.0, -1.0, 3.0]])
+            r, c = np.nonzero(self.A)
+            self.declare_partials("y", "x", rows=r, cols=c)
+
+        def compute(self, inputs, outputs):
+            outputs["y"] = self.A @ inputs["x"] ** 2
+
+        def compute_partials(self, inputs, partials):
+            r, c = np.nonzero(self.A)
+            partials["y", "x"] = (self.A * (2 * inputs["x"])[None, :])[r, c]
+
+    class Imp(om.ImplicitComponent):                      # R(y; p) = K y + y^3 - B p = 0
+        accumulate = True
+
+        def setup(self):
+            self.add_input("p", shape=2)
+            self.add_output("s", shape=2)
+            self.K, self.B = np.array([[3.0, 1.0], [1.0, 2.0]]), np.array([[1.0, 0.5], [0.0, 2.0]])
+            self.declare_partials("s", "s")
+            self.declare_partials("s", "p")
+
+        def apply_nonlinear(self, inputs, outputs, residuals):
+            residuals["s"] = self.K @ outputs["s"] + outputs["s"] ** 3 - self.B @ inputs["p"]
+
+        def solve_nonlinear(self, inputs, outputs):
+            y = np.zeros(2)
+            for _ in range(50):
+                r = self.K @ y + y ** 3 - self.B @ inputs["p"]
+                y = y - np.linalg.solve(self.K + np.diag(3 * y ** 2), r)
+            outputs["s"] = y
+
+        def linearize(self, inputs, outputs, partials):
+            self.J = self.K + np.diag(3 * outputs["s"] ** 2)
+
+        def apply_linear(self, inputs, outputs, d_inputs, d_outputs, d_residuals, mode):
+            if mode == "fwd":
+                add = np.zeros(2)
+                if "s" in d_outputs:
+                    add += self.J @ d_outputs["s"]
+                if "p" in d_inputs:
+                    add -= self.B @ d_inputs["p"]
+                d_residuals["s"] = (d_residuals["s"] + add) if self.accumulate else add
+            else:
+                if "s" in d_outputs:
+                    d_outputs["s"] = d_outputs["s"] + self.J.T @ d_residuals["s"]
+                if "p" in d_inputs:
+                    d_inputs["p"] = d_inputs["p"] - self.B.T @ d_residuals["s"]
+
+        def solve_linear(self, d_outputs, d_residuals, mode):
+            if mode == "fwd":
+                d_outputs["s"] = np.linalg.solve(self.J, d_residuals["s"])
+            else:
+                d_residuals["s"] = np.linalg.solve(self.J.T, d_outputs["s"])
+
+    class Obj(om.ExplicitComponent):                      # f = sum(s^2) + c . x
+        def setup(self):
+            self.add_input("s", shape=2)
+            self.add_input("x", shape=3)
+            self.add_output("f")
+            self.declare_partials("f", "s")
+            self.declare_partials("f", "x", val=np.array([[0.5, -1.0, 2.0]]))
+
+        def compute(self, inputs, outputs):
+            outputs["f"] = np.sum(inputs["s"] ** 2) + np.array([0.5, -1.0, 2.0]) @ inputs["x"]
+
+        def compute_partials(self, inputs, partials):
+            partials["f", "s"] = 2 * inputs["s"]
+
+    def build():
+        g = om.Group()
+        ivc = om.IndepVarComp()
+        ivc.add_output("x", shape=3, val=[0.3, -0.7, 1.1])
+        g.add_subsystem("ivc", ivc)
+        g.add_subsystem("sq", Sq())
+        g.add_subsystem("imp", Imp())
+        g.add_subsystem("obj", Obj())
+        g.connect("ivc.x", "sq.x")
+        g.connect("sq.y", "imp.p")
+        g.connect("imp.s", "obj.s")
+        g.connect("ivc.x", "obj.x")
+        return g
+
+    prob = om.Problem(model=build())
+    prob.setup()
+    prob.run_model()
+    tot = prob.compute_totals(of=["obj.f", "imp.s"], wrt=["ivc.x"])
+    x0 = prob.get_val("ivc.x").copy()
+
+    def f_of(x):
+        prob.set_val("ivc.x", x)
+        prob.run_model()
+        return np.concatenate([prob.get_val("obj.f").ravel(), prob.get_val("imp.s").ravel()])
+    J = np.zeros((3, 3))
+    for k in range(3):
+        e = np.zeros(3)
+        e[k] = 1e-6
+        J[:, k] = (f_of(x0 + e) - f_of(x0 - e)) / 2e-6
+    assert np.abs(tot[("obj.f", "ivc.x")] - J[0:1]).max() < 1e-8 and np.abs(tot[("imp.s", "ivc.x")] - J[1:3]).max() < 1e-8
+
+    # the implicit component alone: accumulate / transpose / solve_linear consistency are part of check_partials
+    p1 = om.Problem(model=Imp())
+    p1.setup()
+    p1["p"] = [0.4, -0.2]
+    p1.run_model()
+    assert max(p1.check_partials(compact_print=False).values()) < 1e-7
+    bad = Imp()
+    bad.accumulate = False                                # assigns d_residuals instead of accumulating: OpenMDAO would give wrong totals
+    p2 = om.Problem(model=bad)
+    p2.setup()
+    p2.run_model()
+    with pytest.raises(AssertionError, match="apply_linear|rel err"):
+        errs = p2.check_partials(compact_print=False)
+        assert max(errs.values()) < 1e-7, "rel err"
+    # undeclared sub-Jacobian, wrong nnz, wrong variable size
+    p3 = om.Problem(model=Sq())
+    p3.setup()
+    P = om._Partials(p3.model, p3.inputs, p3.outputs)
+    with pytest.raises(KeyError):
+        P["y", "z"] = 1.0
+    with pytest.raises(ValueError, match="nnz"):
+        P["y", "x"] = np.ones(5)
+    with pytest.raises(ValueError):
+        p3["x"] = np.ones(4)
+    # connections: unknown names, mismatched shapes, wrong direction
+    for src, tgt, exc in (("sq.nope", "imp.p", NameError), ("ivc.x", "imp.p", ValueError), ("imp.s", "sq.x", ValueError)):
+        g = build()
+        g.connect(src, tgt) if exc is not ValueError or src != "imp.s" else g._conns.append((src, tgt))
+        with pytest.raises(exc):
+            om.Problem(model=g).setup()
