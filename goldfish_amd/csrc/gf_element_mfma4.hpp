@@ -33,6 +33,11 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
     __shared__ double s_tu[P1 * 3 * P1], s_tv[P1 * 3 * P1], s_wg[2 * P1];
     __shared__ __attribute__((aligned(16))) double s_im[NG][IM_SIZE];
 
+    unsigned long long tstamp = 0; (void)tstamp;
+#ifdef GF_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    tstamp = clock64();
+#endif
     // ---- phase 0
     if (tid < NB) {
         const long long g = ed.g0 + (tid % P1) + (long long)(tid / P1) * ed.nu;
@@ -45,6 +50,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
     for (int k = tid; k < P1 * 3 * P1; k += 64) { s_tu[k] = M.tab[ed.tabu + k]; s_tv[k] = M.tab[ed.tabv + k]; }
     if (tid < P1) { s_wg[tid] = M.tab[ed.wu + tid]; s_wg[P1 + tid] = M.tab[ed.wv + tid]; }
     wave_lds_sync();
+    GF_STAMP(0, tstamp);
 
     // ---- phase 1: one lane per Gauss point (sum-factorised control-point sums, quotient rule, pointwise record)
     if (tid < NG) {
@@ -87,6 +93,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
         im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
     }
     wave_lds_sync();
+    GF_STAMP(1, tstamp);
 
     const bool doK = (flags & GF_ASM_K_BIT) != 0, doC = WITHC && (flags & GF_ASM_C_BIT) != 0, doH = (flags & GF_ASM_H_BIT) != 0;
     const bool has_bf = (pf[0] != 0.0) || (pf[1] != 0.0) || (pf[2] != 0.0);
@@ -123,6 +130,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
                 for (int k = 0; k < 5; ++k) phi[tl][k] = bval[tl] * R[k + 1];
                 R0[tl] = bval[tl] * R[0]; n0[tl] = bval[tl] * Nb[0];
             }
+            GF_STAMP(2, tstamp);
             // -- row r of G and Hc
             double gR[15], hR[15];
             for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
@@ -135,6 +143,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
                 RowLane RLg; RLg.init(xl);
                 RLg.template expand<WITHC>(im, gR, hR); dpp_source_fence(gR); if constexpr (WITHC) dpp_source_fence(hR);
             }
+            GF_STAMP(3, tstamp);
             // -- residual (first pass only) and dR/dh prefactors of both a tiles
             const double ls = (has_bf && tb == 0) ? load_scalar(im, ppd) : 0.0;
             if (tb == 0) {
@@ -164,6 +173,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
                     }
                 }
             }
+            GF_STAMP(4, tstamp);
             // -- contraction: T_b of this pass's b tile feeds both a tiles
             if (doK) {
                 static_for<5>([&](auto m_) {
@@ -178,6 +188,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
                     }
                 });
             }
+            GF_STAMP(5, tstamp);
             if (doC) {
                 static_for<5>([&](auto m_) {
                     constexpr int m = decltype(m_)::value;
@@ -203,6 +214,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
                     }
                 }
             }
+            GF_STAMP(6, tstamp);
         }
         // ---- write the (a tiles, b tile tb) part of the element block: register rr of lane (x, kk) is (a, b) = (16 ta + kk + 4 rr, 16 tb + x)
         const int b = 16 * tb + x;
@@ -231,7 +243,11 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
                     }
                 }
         }
+        GF_STAMP(7, tstamp);              // the block stores of this pass
     }
+#ifdef GF_STAMPS
+    if ((blockIdx.x & 31) == 0 && tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[k], stamp_acc[k]);
+#endif
     // ---- residual: sum the four Gauss-point slots of a group (two steps through the staging area: 2 x 32 x 3 doubles)
     wave_lds_sync();
     if (kk >= 2) for (int ta = 0; ta < 2; ++ta) for (int i = 0; i < 3; ++i) s_g[(((kk - 2) * 2 + ta) * 16 + x) * 3 + i] = accR[ta][i];

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["GF_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "goldfish_amd", "libgoldfish_hip_stamps.so")
 from goldfish_amd import _lib, geometry as G
 from goldfish_amd.model import arrays_from_spec
-spec = G.synthetic_shell(8, 8, nel=48, p=3, jitter=2)
+P = int(os.environ.get("GF_P", "3"))
+spec = G.synthetic_shell(8, 8, nel=48, p=3, jitter=2) if P != 4 else G.synthetic_fuselage(8, 4, nel=53, p=4, jitter=2)
 th = G.random_thickness(spec)
 A = arrays_from_spec(spec, th)
 D = _lib.DeviceModel(A)
@@ -16,7 +17,9 @@ D.assemble(); L.gf_debug_stamps(out)
 mfma = os.environ.get("GF_ELEMENT", "mfma") != "valu"
 rec = D.assembly_path == 4
 nw = (D.n_elements / 8.0) if rec else (1 if mfma else 2) * ((D.n_elements + 31) // 32)      # 1 in 32 elements sampled (row-record kernel: 1 in 8 items; per element)
-if rec:
+if P == 4 and mfma:
+    names = ["phase0 load", "phase1 pointwise (one lane per Gauss point)", "basis of both tiles at the Gauss point", "row expansion (per pass)", "rz / rh + dR/dh MFMAs", "K: T formation + MFMAs", "dR/dCP: T formation + MFMAs", "element-block stores"]
+elif rec:
     names = ["ring -> staging", "phase1 pointwise", "-", "fetch issue (next element)", "group loop (expansion, T, MFMA)", "park + residual", "record stores", "-"]
 elif mfma:
     names = ["phase0 load", "phase1 pointwise", "-", "-", "group loop (expansion, T, MFMA)", "-", "-", "-"]
