@@ -126,14 +126,17 @@ def test_c4_rigid_body_and_reproducibility(c4):
     assert np.array_equal(R0, D.residual()) and np.array_equal(K0, D.values(_lib.MAT_K))
 
 
-@pytest.mark.parametrize("size", ["32 patches", "C5 share of one GPU"])
+@pytest.mark.parametrize("size", ["32 patches", "C5 share of one GPU", "C5 (1024 patches) on one GPU"])
 def test_c5_family_p4_properties(size):
     """p = 4 (BASELINE.json configs[4]: synthetic fuselage, MFMA 2x2-tile element kernel) at sizes the oracle does not run in
     seconds -- 32 patches (0.3 M dofs) and one GPU's share of C5 at 8 GPUs (128 patches of 53 spans a side, 1.04 M dofs,
     7.35 M Gauss points; the element blocks take two scratch chunks): K x and (dR/dCP) x against residual differences,
-    symmetry of K, and bitwise agreement of two assemblies."""
+    symmetry of K, and bitwise agreement of two assemblies.  The full C5 (1024 patches, 10.0 M dofs, 72 M Gauss points, 100 GB of
+    device memory, eight scratch chunks) runs the same checks with the matrices compared through products instead of 45 GB of host copies."""
     from goldfish_amd import _lib
-    spec = G.synthetic_fuselage(8, 4, nel=24, p=4, jitter=2) if size == "32 patches" else G.synthetic_fuselage(16, 8, nel=53, p=4, jitter=2)
+    full = size.startswith("C5 (1024")
+    spec = (G.synthetic_fuselage(8, 4, nel=24, p=4, jitter=2) if size == "32 patches" else
+            G.synthetic_fuselage(32, 32, nel=53, p=4, jitter=2) if full else G.synthetic_fuselage(16, 8, nel=53, p=4, jitter=2))
     th = G.random_thickness(spec)
     A = arrays_from_spec(spec, th)
     D = _lib.DeviceModel(A)
@@ -141,14 +144,29 @@ def test_c5_family_p4_properties(size):
     D.set_thickness(h)
     D.set_u(u)
     D.assemble(_lib.ASM_ALL)
-    if size != "32 patches":
+    if full:
+        assert len(spec.patches) == 1024 and A.ndof == 9997272 and D.n_gauss_points == 72037200
+    elif size != "32 patches":
         assert len(spec.patches) == 128 and D.n_gauss_points > 7.0e6
-    vals = [D.values(w).copy() for w in range(5)]
-    R0 = D.residual().copy()
-    D.assemble(_lib.ASM_ALL)
-    assert np.array_equal(R0, D.residual()) and all(np.array_equal(vals[w], D.values(w)) for w in range(5))
-    del vals
     rng = np.random.default_rng(1)
+    R0 = D.residual().copy()
+    if full:                                                      # the matrices through one product each instead of host copies
+        xs = [rng.standard_normal(A.ndof)] + [rng.standard_normal(A.total_cp) for _ in range(4)]
+        prod = []
+        for rep in range(2):
+            if rep:
+                D.assemble(_lib.ASM_ALL)
+            ys = [np.zeros(A.ndof) for _ in range(5)]
+            for w in range(5):
+                D.apply(w, xs[w], ys[w])
+            prod.append(ys)
+        assert np.array_equal(R0, D.residual()) and all(np.array_equal(a, b) for a, b in zip(*prod))
+        del prod
+    else:
+        vals = [D.values(w).copy() for w in range(5)]
+        D.assemble(_lib.ASM_ALL)
+        assert np.array_equal(R0, D.residual()) and all(np.array_equal(vals[w], D.values(w)) for w in range(5))
+        del vals
     free = np.ones(A.ndof, bool)
     free[A.zero_dofs] = False
     x1, x2 = rng.standard_normal(A.ndof) * free, rng.standard_normal(A.ndof) * free
@@ -167,11 +185,11 @@ def test_c5_family_p4_properties(size):
         return (out[0] - out[1]) / (2 * eps)
 
     fd = R_at(D.set_u, u, x1, 1e-4 * np.abs(u).max())
-    assert _rel(fd[free], y1[free]) < 1e-6
+    assert _rel(fd[free], y1[free]) < (1e-5 if full else 1e-6)    # max-norm over 10 M entries of a difference quotient: 2.6e-6 at full C5
     c1 = A.cp_hom[1].copy()
     dc = rng.standard_normal(A.total_cp)
     yc = np.zeros(A.ndof)
     D.apply(_lib.MAT_DRDCP1, dc, yc)
     fd = R_at(lambda v: D.set_cp(1, v), c1, dc, 1e-6 * spec.h_th)
-    assert _rel(fd[free], yc[free]) < 1e-5
+    assert _rel(fd[free], yc[free]) < (5e-5 if full else 1e-5)
     D.close()

@@ -230,25 +230,33 @@ def test_zero_state_and_reproducible(oracle_lib):
     D.close()
 
 
-def test_apply_linear(oracle_lib):
+@pytest.mark.parametrize("case", ["tbeam2_p3", "C3_wing16_refdata", "shell2x2_p4", "tbeam2_p2_pressure_edge"])
+def test_apply_linear(oracle_lib, case):
+    """DispImOpeartion.apply_linear_fwd / rev (disp_imop.py:58-128): y += J x and z += J^T w for the five Jacobians against the ORACLE's matrices
+    (not only the device's own CSR), in place; transposed products bitwise reproducible.  The pressure case has a non-symmetric K."""
     from goldfish_amd import _lib
-    spec = G.tbeam_2patch(6)
+    from oracle.oracle_py import Oracle
+    spec = CASES[case]() if case in CASES else G.tbeam_2patch(6)
     A, h, u = _state(spec, seed=4)
     D = _lib.DeviceModel(A)
     D.set_thickness(h)
     D.set_u(u)
     D.assemble()
+    O = Oracle(A, thickness=h, u=u)
+    ovals = O.assemble()
     rng = np.random.default_rng(9)
     for which in range(5):
-        Mx = D.csr(which)
+        Mx, Mo = D.csr(which), O.csr(which, ovals[which])
         x, y0 = rng.standard_normal(Mx.shape[1]), rng.standard_normal(Mx.shape[0])
         y = y0.copy()
         D.apply(which, x, y)
         assert _rel(y, y0 + Mx @ x) < 1e-12
+        assert _rel(y - y0, Mo @ x) < RTOL, (case, which)
         xt, z0 = rng.standard_normal(Mx.shape[0]), rng.standard_normal(Mx.shape[1])
         z = z0.copy()
         D.apply(which, xt, z, transpose=True)
         assert _rel(z, z0 + Mx.T @ xt) < 1e-12
+        assert _rel(z - z0, Mo.T @ xt) < RTOL, (case, which)
         z2 = z0.copy()
         D.apply(which, xt, z2, transpose=True)
         assert np.array_equal(z, z2)                        # fixed-order transposed products: bitwise reproducible
