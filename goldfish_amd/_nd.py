@@ -1,0 +1,188 @@
+"""Nested-dissection ordering and the symbolic phase of the multifrontal factorisation of K (host side, NumPy).
+
+The device solver's skyline (goldfish_amd/csrc/gf_solver.hip) costs n x bandwidth of memory and n x bandwidth^2 of work; for a shell --
+a 2-D manifold of control points -- nested dissection brings that to O(n log n) and O(n^1.5): the control points are split recursively
+by coordinate bisection (the physical control points are at hand), the separator of a split is the set of control points of one half
+that are coupled to the other half (three control-point rows thick inside a patch, the penalty's 2 (p + 1) rows across an interface),
+and every tree node becomes a dense FRONT: the control points it eliminates followed by its boundary (the not yet eliminated control
+points its subtree couples to, all of them on ancestor separators).  The numeric phase (gf_solver.hip, ``gfs_create_nd``) factors the
+fronts in post-order on the 64 x 64 FP64-MFMA tile kernels of the skyline solver and passes Schur complements up (extend-add).
+
+Replaces, for large models, the MUMPS ordering / analysis phase behind GOLDFISH/utils/opt_utils.py:156-209 (solve_Ax_b / solve_ATx_b).
+"""
+import numpy as np
+
+
+class Symbolic:
+    """Fronts in post-order.  Per front t: ``elim[elim_off[t]:elim_off[t+1]]`` the control points it eliminates (in elimination order),
+    ``bnd[bnd_off[t]:bnd_off[t+1]]`` its boundary control points (ascending elimination order), ``parent[t]`` (-1: root).
+    ``order[cp]`` = position of a control point in the global elimination order, ``front_of[cp]`` = the front that eliminates it."""
+
+    def __init__(self, elim, elim_off, bnd, bnd_off, parent, order, front_of):
+        self.elim, self.elim_off, self.bnd, self.bnd_off = elim, elim_off, bnd, bnd_off
+        self.parent, self.order, self.front_of = parent, order, front_of
+        self.nfronts = parent.size
+
+    def front_dofs(self, nb=64):
+        """Per front: eliminated dofs padded to tiles, boundary dofs padded to tiles, block counts."""
+        ne = 3 * np.diff(self.elim_off)
+        nbd = 3 * np.diff(self.bnd_off)
+        nblk_e = (ne + nb - 1) // nb
+        nblk_b = (nbd + nb - 1) // nb
+        return ne, nbd, nblk_e.astype(np.int64), nblk_b.astype(np.int64)
+
+    def stats(self, nb=64):
+        ne, nbd, be, bb = self.front_dofs(nb)
+        bt = be + bb
+        tiles = bt * (bt + 1) // 2
+        # partial factorisation of a dense front: sum over eliminated block columns k of (rows below) + (rows below)(rows below + 1) / 2 tile products
+        flops = 0.0
+        for e, t in zip(be, bt):
+            k = np.arange(e)
+            r = t - 1 - k
+            flops += 2.0 * nb ** 3 * float(np.sum(r + r * (r + 1) / 2.0) + e / 3.0)
+        return dict(fronts=int(self.nfronts), tiles=int(tiles.sum()), bytes=int(tiles.sum()) * nb * nb * 8, flops=flops,
+                    largest_front_dofs=int((nb * bt).max()), eliminated_block_columns=int(be.sum()))
+
+
+def nested_dissection(nb_ptr, nb, coords, leaf=192):
+    """Recursive coordinate bisection of the control-point graph (nb_ptr, nb: neighbour lists incl. the control point itself) with
+    vertex separators; ``leaf``: regions of at most that many control points are not split further.  Level-synchronous: every pass
+    splits all regions of the current level with array operations over the edge list."""
+    ncp = nb_ptr.size - 1
+    X = np.asarray(coords, float).reshape(ncp, -1)
+    rows = np.repeat(np.arange(ncp, dtype=np.int64), np.diff(nb_ptr))
+    cols = np.asarray(nb, np.int64)
+    keep = rows != cols
+    rows, cols = rows[keep], cols[keep]
+    region = np.zeros(ncp, np.int64)              # tree node (heap numbering: children of r are 2 r + 1, 2 r + 2) a control point currently lies in
+    done = np.zeros(ncp, bool)                    # True: the control point has its final tree node (a separator or a leaf)
+    node_of = np.full(ncp, -1, np.int64)
+    while True:
+        act = np.flatnonzero(~done)
+        if act.size == 0:
+            break
+        reg = region[act]
+        order = np.argsort(reg, kind="stable")
+        act, reg = act[order], reg[order]
+        uniq, start, count = np.unique(reg, return_index=True, return_counts=True)
+        small = count <= leaf
+        # regions small enough become leaves
+        seg_small = np.repeat(small, count)
+        node_of[act[seg_small]] = reg[seg_small]
+        done[act[seg_small]] = True
+        if small.all():
+            break
+        act, reg = act[~seg_small], reg[~seg_small]
+        uniq, start, count = uniq[~small], None, count[~small]
+        start = np.concatenate([[0], np.cumsum(count)[:-1]])
+        # longest axis of every region, median split along it
+        seg = np.repeat(np.arange(uniq.size), count)
+        ext = np.stack([np.maximum.reduceat(X[act, d], start) - np.minimum.reduceat(X[act, d], start) for d in range(X.shape[1])], 1)
+        axis = ext.argmax(1)
+        val = X[act, axis[seg]]
+        o2 = np.lexsort((val, seg))
+        act, seg = act[o2], seg[o2]
+        rank = np.arange(act.size) - start[seg]
+        side = (rank >= (count[seg] + 1) // 2)                         # False: first half (A), True: second half (B)
+        side_of = np.zeros(ncp, np.int8)
+        side_of[act] = side.astype(np.int8) + 1                        # 1: A, 2: B, 0: not in a region that is being split
+        # separator: control points of A coupled to a control point of B of the same region
+        m = (side_of[rows] == 1) & (side_of[cols] == 2) & (region[rows] == region[cols]) & ~done[rows] & ~done[cols]
+        sep = np.zeros(ncp, bool)
+        sep[rows[m]] = True
+        is_sep = sep[act]
+        node_of[act[is_sep]] = uniq[seg[is_sep]]
+        done[act[is_sep]] = True
+        rest = ~is_sep
+        region[act[rest]] = 2 * uniq[seg[rest]] + 1 + side[rest]
+    # post-order of the tree nodes that own control points; heap numbering gives parents by (r - 1) // 2
+    nodes = np.unique(node_of)
+    present = set(int(r) for r in nodes)
+
+    def parent_of(r):
+        r = (r - 1) // 2
+        while r >= 0 and r not in present:
+            r = (r - 1) // 2 if r > 0 else -1
+        return r
+    children = {int(r): [] for r in nodes}
+    roots = []
+    for r in nodes:
+        p = parent_of(int(r)) if r > 0 else -1
+        (children[p] if p >= 0 else roots).append(int(r))
+    post, stack = [], [(r, False) for r in reversed(roots)]
+    while stack:
+        r, seen = stack.pop()
+        if seen:
+            post.append(r)
+        else:
+            stack.append((r, True))
+            for c in reversed(children[r]):
+                stack.append((c, False))
+    index = {r: i for i, r in enumerate(post)}
+    front_of = np.array([index[int(r)] for r in nodes])[np.searchsorted(nodes, node_of)].astype(np.int64)
+    nf = len(post)
+    parent = np.array([index[p] if (p := (parent_of(r) if r > 0 else -1)) >= 0 else -1 for r in post], np.int64)
+    # elimination order: fronts in post-order, inside a front along the first principal coordinate (locality only)
+    key = np.lexsort((X[:, 0], front_of))
+    order = np.empty(ncp, np.int64)
+    order[key] = np.arange(ncp)
+    elim = key.astype(np.int64)
+    elim_off = np.concatenate([[0], np.cumsum(np.bincount(front_of, minlength=nf))]).astype(np.int64)
+    # boundaries, bottom-up: bnd(t) = (neighbours of elim(t) + boundaries of the children) not eliminated in the subtree of t
+    hi = elim_off[1:].copy()                      # post-order: the subtree of t ends with t itself -> everything with order >= elim_off[t + 1] is outside
+    bnds = [None] * nf
+    kids = [[] for _ in range(nf)]
+    for t in range(nf):
+        if parent[t] >= 0:
+            kids[parent[t]].append(t)
+    nb_ptr = np.asarray(nb_ptr, np.int64)
+    nbl = np.asarray(nb, np.int64)
+    for t in range(nf):
+        e = elim[elim_off[t]:elim_off[t + 1]]
+        idx = np.concatenate([np.arange(nb_ptr[a], nb_ptr[a + 1]) for a in e]) if e.size else np.zeros(0, np.int64)
+        cand = [nbl[idx]] + [bnds[c] for c in kids[t]]
+        cand = np.unique(np.concatenate(cand)) if cand else np.zeros(0, np.int64)
+        cand = cand[order[cand] >= hi[t]]
+        bnds[t] = cand[np.argsort(order[cand], kind="stable")]
+    bnd_off = np.concatenate([[0], np.cumsum([b.size for b in bnds])]).astype(np.int64)
+    bnd = np.concatenate(bnds).astype(np.int64) if nf else np.zeros(0, np.int64)
+    return Symbolic(elim, elim_off, bnd, bnd_off, parent, order, front_of)
+
+
+def multifrontal_reference_solve(sym, K, b):
+    """Dense NumPy statement of the numeric phase (tests only: tiny models): factor the fronts in post-order, extend-add the Schur
+    complements, forward / backward substitution -- what gf_solver.hip does on tiles.  K: scipy CSR over dofs (3 per control point)."""
+    K = K.tocsr()
+    nf = sym.nfronts
+    fr = []
+    upd = [None] * nf
+    for t in range(nf):
+        e, bd = sym.elim[sym.elim_off[t]:sym.elim_off[t + 1]], sym.bnd[sym.bnd_off[t]:sym.bnd_off[t + 1]]
+        dof = np.concatenate([3 * e[:, None] + np.arange(3), 3 * bd[:, None] + np.arange(3)]).ravel() if e.size + bd.size else np.zeros(0, np.int64)
+        ne = 3 * e.size
+        F = np.zeros((dof.size, dof.size))
+        Ke = K[dof[:ne]][:, dof].toarray()
+        F[:ne, :] = Ke
+        F[:, :ne] = Ke.T
+        pos = {int(d): i for i, d in enumerate(dof)}
+        for c in range(nf):
+            if sym.parent[c] == t and upd[c] is not None:
+                cd, S = upd[c]
+                ii = np.array([pos[int(d)] for d in cd], np.int64)
+                F[np.ix_(ii, ii)] += S
+        A11, A21 = F[:ne, :ne], F[ne:, :ne]
+        X = np.linalg.solve(A11, A21.T)
+        upd[t] = (dof[ne:], F[ne:, ne:] - A21 @ X)
+        fr.append((dof, ne, A11, A21))
+    y = np.asarray(b, float).copy()
+    z = np.zeros_like(y)
+    for t in range(nf):                                         # forward
+        dof, ne, A11, A21 = fr[t]
+        z[dof[:ne]] = np.linalg.solve(A11, y[dof[:ne]])
+        y[dof[ne:]] -= A21 @ z[dof[:ne]]
+    x = np.zeros_like(y)
+    for t in reversed(range(nf)):                               # backward
+        dof, ne, A11, A21 = fr[t]
+        x[dof[:ne]] = z[dof[:ne]] - np.linalg.solve(A11, A21.T @ x[dof[ne:]])
+    return x

@@ -14,7 +14,7 @@ from scipy.sparse.csgraph import reverse_cuthill_mckee
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgoldfish_solver.so")
-EXPORTS = ["gfs_last_error", "gfs_create", "gfs_destroy", "gfs_refactor", "gfs_solve", "gfs_solve_dev", "gfs_info"]
+EXPORTS = ["gfs_last_error", "gfs_create", "gfs_create_nd", "gfs_destroy", "gfs_refactor", "gfs_solve", "gfs_solve_dev", "gfs_info"]
 _L = None
 
 
@@ -27,6 +27,7 @@ def lib():
         i32p, i64p, dp, vp = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_void_p
         L.gfs_last_error.restype = C.c_char_p
         L.gfs_create.argtypes = [C.c_int, C.c_int64, i64p, i32p, i32p, vp, C.POINTER(vp)]
+        L.gfs_create_nd.argtypes = [C.c_int, C.c_int64, i64p, i32p, vp, C.c_int64] + [i64p] * 8 + [C.POINTER(vp)]
         L.gfs_destroy.argtypes = [vp]
         L.gfs_destroy.restype = None
         L.gfs_refactor.argtypes = [vp]
@@ -83,21 +84,58 @@ def bandwidth_reducing_order(nb_ptr, nb, coords=None):
     return best
 
 
-class DeviceSolver:
-    """K x = b (= K^T x = b: K is symmetric) with the K of a goldfish_amd._lib.DeviceModel; factors resident in HBM."""
+def parent_positions(sym):
+    """For every boundary control point of every front: its position in the parent front's numbering (the parent's eliminated control
+    points first, then the parent's boundary) -- the index map of the extend-add (gfs_create_nd: ``pmap``)."""
+    pmap = np.zeros(sym.bnd.size, np.int64)
+    ne = np.diff(sym.elim_off)
+    for t in range(sym.nfronts):
+        p = sym.parent[t]
+        b = sym.bnd[sym.bnd_off[t]:sym.bnd_off[t + 1]]
+        if p < 0 or b.size == 0:
+            continue
+        ob = sym.order[b]
+        inside = sym.front_of[b] == p
+        pb = sym.bnd[sym.bnd_off[p]:sym.bnd_off[p + 1]]
+        pos = np.where(inside, ob - sym.elim_off[p], ne[p] + np.searchsorted(sym.order[pb], ob))
+        pmap[sym.bnd_off[t]:sym.bnd_off[t + 1]] = pos
+    return pmap
 
-    def __init__(self, dev_model, max_refine=3, coords=None):
-        """coords: (ncp, 3) physical control points (optional): lets the ordering consider plane sweeps next to RCM."""
+
+ND_MIN_CP = int(os.environ.get("GF_SOLVER_ND_MIN_CP", "40000"))     # models with more control points factor by nested dissection (when coordinates are given)
+
+
+class DeviceSolver:
+    """K x = b (= K^T x = b: K is symmetric) with the K of a goldfish_amd._lib.DeviceModel; factors resident in HBM.
+    ``method``: "skyline" (block skyline after RCM: small and medium models), "nd" (nested-dissection multifrontal: goldfish_amd/_nd.py +
+    gfs_create_nd; needs the control points' coordinates), "auto": nd above ND_MIN_CP control points."""
+
+    def __init__(self, dev_model, max_refine=3, coords=None, method="auto", leaf=256):
         from . import _lib
         self.D, self.max_refine = dev_model, max_refine
         rowptr, col = dev_model.pattern(_lib.MAT_K)
         self.nb_ptr, self.nb = control_point_graph(rowptr, col)
-        self.new_index = bandwidth_reducing_order(self.nb_ptr, self.nb, coords)
-        self.n = 3 * (self.nb_ptr.size - 1)
+        del rowptr, col
+        ncp = self.nb_ptr.size - 1
+        self.n = 3 * ncp
+        if method == "auto":
+            method = "nd" if (coords is not None and ncp >= ND_MIN_CP) else "skyline"
+        self.method = method
         dK = _lib.lib().gf_device_ptr(dev_model.h, _lib.BUF_VAL_K)
         h = C.c_void_p()
-        rc = lib().gfs_create(int(dev_model.device), self.nb_ptr.size - 1, self.nb_ptr.ctypes.data_as(C.POINTER(C.c_int64)),
-                              self.nb.ctypes.data_as(C.POINTER(C.c_int32)), self.new_index.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(dK), C.byref(h))
+        i64 = lambda a: np.ascontiguousarray(a, np.int64).ctypes.data_as(C.POINTER(C.c_int64))
+        if method == "nd":
+            from . import _nd
+            if coords is None:
+                raise ValueError("DeviceSolver(method='nd') needs the control points' coordinates")
+            self.sym = sym = _nd.nested_dissection(self.nb_ptr, self.nb, coords, leaf=leaf)
+            keep = [np.ascontiguousarray(a, np.int64) for a in (sym.elim, sym.elim_off, sym.bnd, sym.bnd_off, sym.parent, sym.order, sym.front_of, parent_positions(sym))]
+            rc = lib().gfs_create_nd(int(dev_model.device), ncp, self.nb_ptr.ctypes.data_as(C.POINTER(C.c_int64)), self.nb.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     C.c_void_p(dK), sym.nfronts, *[i64(a) for a in keep], C.byref(h))
+        else:
+            self.new_index = bandwidth_reducing_order(self.nb_ptr, self.nb, coords)
+            rc = lib().gfs_create(int(dev_model.device), ncp, self.nb_ptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                                  self.nb.ctypes.data_as(C.POINTER(C.c_int32)), self.new_index.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(dK), C.byref(h))
         if rc:
             raise RuntimeError(lib().gfs_last_error().decode())
         self.h = h

@@ -271,6 +271,121 @@ __global__ __launch_bounds__(256) void sumsq_kernel(long long n, const double* _
     if (threadIdx.x == 0) part[blockIdx.x] = s[0];
 }
 
+
+// ================================================================================================================================
+// Nested-dissection multifrontal mode (goldfish_amd/_nd.py gives the fronts): every front is a dense symmetric matrix in the same lower
+// tile layout as a skyline with a full envelope -- tile (I, J) at (tri[I] + I - J) NB^2, tri[I] = I (I + 1) / 2 -- so diag_kernel /
+// panel_kernel / update_kernel / fwd_kernel / bwd_kernel run on it unchanged (band = the front's base, rowoff = tri).  A front
+// eliminates its first nblk_e block columns; the trailing tiles then hold its Schur complement, which is added into the parent front.
+struct Front { long long tile_off, kbase, elim_off, bnd_off; int nblk_e, nblk_t, ne_cp, nb_cp, ne_pad, parent, pad0, pad1; };
+
+__device__ __forceinline__ int nd_dofpos(const Front& F, int p, int i) { return p < F.ne_cp ? 3 * p + i : F.ne_pad + 3 * (p - F.ne_cp) + i; }
+__device__ __forceinline__ size_t nd_entry(const Front& F, const long long* __restrict__ tri, int R, int C) {      // R >= C
+    const int I = R >> 6, J = C >> 6;
+    return (size_t)(F.tile_off + tri[I] + (I - J)) * NB2 + (size_t)(R & 63) * NB + (C & 63);
+}
+// position of control point c in front t: its place among the eliminated ones, or behind them in the boundary list (sorted by elimination order)
+__device__ __forceinline__ int nd_pos(const Front& F, int t, int c, const int* __restrict__ front_of, const long long* __restrict__ order, const int* __restrict__ bnd) {
+    if (front_of[c] == t) return (int)(order[c] - F.elim_off);
+    const long long oc = order[c];
+    int lo = 0, hi = F.nb_cp - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (order[bnd[F.bnd_off + mid]] < oc) lo = mid + 1; else hi = mid; }
+    return F.ne_cp + lo;
+}
+// K (block CSR, original numbering) -> fronts: the block (a, b) belongs to the front that eliminates the earlier of the two, and is stored
+// there when a's position is not in front of b's (lower triangle); one wave per control point a
+__global__ void nd_scatter_kernel(long long ncp, const long long* __restrict__ nb_ptr, const int* __restrict__ nb, const double* __restrict__ valK,
+                                  const Front* __restrict__ fronts, const int* __restrict__ front_of, const long long* __restrict__ order, const int* __restrict__ bnd,
+                                  const long long* __restrict__ tri, double* __restrict__ arena) {
+    const long long a = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (a >= ncp) return;
+    const long long ptr = nb_ptr[a], deg = nb_ptr[a + 1] - ptr;
+    const long long oa = order[a];
+    for (long long k = lane; k < deg; k += 64) {
+        const int b = nb[ptr + k];
+        const int t = order[b] < oa ? front_of[b] : front_of[a];
+        const Front F = fronts[t];
+        const int pa = nd_pos(F, t, (int)a, front_of, order, bnd), pb = nd_pos(F, t, b, front_of, order, bnd);
+        if (pa < pb) continue;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int R = nd_dofpos(F, pa, i), C = nd_dofpos(F, pb, j);
+                if (R < C) continue;
+                arena[nd_entry(F, tri, R, C)] = valK[9 * ptr + (long long)i * 3 * deg + 3 * k + j];
+            }
+    }
+}
+// identity on the padding of the eliminated part of every front (one workgroup per front)
+__global__ void nd_pad_kernel(const Front* __restrict__ fronts, const long long* __restrict__ tri, double* __restrict__ arena) {
+    const Front F = fronts[blockIdx.x];
+    for (int r = 3 * F.ne_cp + threadIdx.x; r < F.ne_pad; r += blockDim.x) arena[nd_entry(F, tri, r, r)] = 1.0;
+}
+// Schur complement of child c (its trailing tiles) added into its parent: one workgroup per lower tile of the child's boundary block
+__global__ __launch_bounds__(256) void nd_extend_add_kernel(const Front* __restrict__ fronts, int c, const int* __restrict__ pmap, const long long* __restrict__ tri, double* __restrict__ arena) {
+    const Front Fc = fronts[c]; const Front Fp = fronts[Fc.parent];
+    int gi = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((gi + 1) * (gi + 2) / 2 <= (int)blockIdx.x) ++gi;
+    while (gi * (gi + 1) / 2 > (int)blockIdx.x) --gi;
+    const int gj = blockIdx.x - gi * (gi + 1) / 2;
+    const int I = Fc.nblk_e + gi, J = Fc.nblk_e + gj;
+    const double* src = arena + (size_t)(Fc.tile_off + tri[I] + (I - J)) * NB2;
+    const int nbd = 3 * Fc.nb_cp;
+    for (int q = threadIdx.x; q < NB2; q += 256) {
+        const int rr = q >> 6, cc = q & 63;
+        const int rl = 64 * gi + rr, cl = 64 * gj + cc;              // boundary dof indices of the child
+        if (rl >= nbd || cl >= nbd || rl < cl) continue;
+        const int pr = pmap[Fc.bnd_off + rl / 3], pc = pmap[Fc.bnd_off + cl / 3];
+        const int R = nd_dofpos(Fp, pr, rl % 3), C = nd_dofpos(Fp, pc, cl % 3);       // the map is monotone: R >= C
+        arena[nd_entry(Fp, tri, R, C)] += src[q];
+    }
+}
+// front-local right-hand side: the eliminated dofs from the global vector (original numbering), zeros on the padding and the boundary part
+__global__ void nd_gather_rhs_kernel(Front F, const int* __restrict__ elim, const double* __restrict__ b, double* __restrict__ w) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 64 * F.nblk_t) return;
+    w[t] = t < 3 * F.ne_cp ? b[3 * (long long)elim[F.elim_off + t / 3] + t % 3] : 0.0;
+}
+// after the forward substitution of a front: y of the eliminated dofs to the global y, the boundary updates added to the global right-hand side
+__global__ void nd_scatter_fwd_kernel(Front F, const int* __restrict__ elim, const int* __restrict__ bnd, const double* __restrict__ wy, const double* __restrict__ wb,
+                                      double* __restrict__ y, double* __restrict__ b) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 3 * F.ne_cp) y[3 * (long long)elim[F.elim_off + t / 3] + t % 3] = wy[t];
+    if (t < 3 * F.nb_cp) b[3 * (long long)bnd[F.bnd_off + t / 3] + t % 3] += wb[F.ne_pad + t];
+}
+// before the backward substitution of a front: z = D^-1 y on the eliminated dofs, x of the boundary dofs (ancestors: already known)
+__global__ void nd_gather_bwd_kernel(Front F, const int* __restrict__ elim, const int* __restrict__ bnd, const double* __restrict__ y, const double* __restrict__ x,
+                                     const double* __restrict__ dval, double* __restrict__ wz, double* __restrict__ wx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 64 * F.nblk_t) return;
+    if (t < F.ne_pad) { wz[t] = t < 3 * F.ne_cp ? y[3 * (long long)elim[F.elim_off + t / 3] + t % 3] / dval[F.kbase * NB + t] : 0.0; wx[t] = 0.0; }
+    else { const int q = t - F.ne_pad; wx[t] = q < 3 * F.nb_cp ? x[3 * (long long)bnd[F.bnd_off + q / 3] + q % 3] : 0.0; wz[t] = 0.0; }
+}
+// z_J -= sum over the boundary block rows I of L_IJ^T x_I  (workgroup J < nblk_e)
+__global__ __launch_bounds__(256) void nd_bwd_bnd_kernel(const double* __restrict__ band, const long long* __restrict__ tri, int nblk_e, int nblk_t,
+                                                         const double* __restrict__ wx, double* __restrict__ wz) {
+    __shared__ double sx[NB], sp[4][NB];
+    const int tid = threadIdx.x, c = tid & 63, rq = tid >> 6, J = blockIdx.x;
+    double acc = 0.0;
+    for (int I = nblk_e; I < nblk_t; ++I) {
+        __syncthreads();
+        if (tid < NB) sx[tid] = wx[(size_t)I * NB + tid];
+        __syncthreads();
+        const double* L = band + (size_t)(tri[I] + (I - J)) * NB2 + (16 * rq) * NB + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += L[r * NB] * sx[16 * rq + r];
+    }
+    sp[rq][c] = acc;
+    __syncthreads();
+    if (tid < NB) wz[(size_t)J * NB + tid] -= sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+}
+__global__ void nd_scatter_bwd_kernel(Front F, const int* __restrict__ elim, const double* __restrict__ wx, double* __restrict__ x, int add) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 3 * F.ne_cp) { double* dst = x + 3 * (long long)elim[F.elim_off + t / 3] + t % 3; *dst = add ? *dst + wx[t] : wx[t]; }
+}
+
 }  // namespace
 
 struct gfs_handle {
@@ -283,6 +398,11 @@ struct gfs_handle {
     double *vb = nullptr, *vy = nullptr, *vz = nullptr, *vx = nullptr, *vr = nullptr, *vsol = nullptr, *vrhs = nullptr, *part = nullptr;
     std::vector<void*> allocs; long long bytes = 0; bool factored = false, small_pivot = false;
     long long nnz9 = 0; double normK = 0.0, backward_error = 0.0;     // Frobenius norm of the factored K; backward error of the last solve
+    // nested-dissection multifrontal mode
+    bool nd = false; std::vector<Front> fronts; std::vector<std::vector<int>> kids; Front* d_fronts = nullptr;
+    int *d_elim = nullptr, *d_bnd = nullptr, *d_pmap = nullptr, *d_front_of = nullptr; long long* d_order = nullptr; long long* d_tri = nullptr;
+    long long nbe_tot = 0; int max_blk = 0; double nd_flops = 0.0;
+    double *fw_b = nullptr, *fw_y = nullptr, *fw_z = nullptr, *fw_x = nullptr, *gy = nullptr, *gb = nullptr, *gx = nullptr;
     template <class Tp> Tp* dalloc(size_t cnt) {
         void* p = nullptr; const size_t nb_ = (cnt ? cnt : 1) * sizeof(Tp);
         HIPCHK(hipMalloc(&p, nb_)); allocs.push_back(p); bytes += (long long)nb_; return (Tp*)p;
@@ -301,7 +421,40 @@ static double norm2(gfs_handle* h, const double* v, long long n) {
 }
 
 // x (original numbering, device) = (L D L^T)^-1 rhs (original numbering, device); add: x += instead
+__global__ void nd_out_kernel(long long n, const double* __restrict__ src, double* __restrict__ dst, int add) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = add ? dst[t] + src[t] : src[t];
+}
+// multifrontal substitutions: fronts in post-order (forward), in reverse (backward); vectors in the original numbering
+static void substitute_nd(gfs_handle* h, const double* rhs, double* x, int add) {
+    HIPCHK(hipMemcpyAsync(h->gb, rhs, h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    const int nf = (int)h->fronts.size();
+    for (int t = 0; t < nf; ++t) {
+        const Front& F = h->fronts[t];
+        const double* band = h->band + (size_t)F.tile_off * NB2;
+        const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
+        hipLaunchKernelGGL(nd_gather_rhs_kernel, dim3(gl), dim3(256), 0, h->stream, F, h->d_elim, h->gb, h->fw_b);
+        for (int k = 0; k < F.nblk_e; ++k)
+            hipLaunchKernelGGL(fwd_kernel, dim3(F.nblk_t - k), dim3(256), 0, h->stream, band, h->linv + (size_t)F.kbase * NB2, h->fw_b, h->fw_y, h->d_tri, k);
+        hipLaunchKernelGGL(nd_scatter_fwd_kernel, dim3(gl), dim3(256), 0, h->stream, F, h->d_elim, h->d_bnd, h->fw_y, h->fw_b, h->gy, h->gb);
+    }
+    for (int t = nf - 1; t >= 0; --t) {
+        const Front& F = h->fronts[t];
+        const double* band = h->band + (size_t)F.tile_off * NB2;
+        const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
+        hipLaunchKernelGGL(nd_gather_bwd_kernel, dim3(gl), dim3(256), 0, h->stream, F, h->d_elim, h->d_bnd, h->gy, h->gx, h->dval, h->fw_z, h->fw_x);
+        if (F.nblk_t > F.nblk_e && F.nblk_e > 0)
+            hipLaunchKernelGGL(nd_bwd_bnd_kernel, dim3(F.nblk_e), dim3(256), 0, h->stream, band, h->d_tri, F.nblk_e, F.nblk_t, h->fw_x, h->fw_z);
+        for (int k = F.nblk_e - 1; k >= 0; --k)
+            hipLaunchKernelGGL(bwd_kernel, dim3(k + 1), dim3(256), 0, h->stream, band, h->linv + (size_t)F.kbase * NB2, h->fw_z, h->fw_x, h->d_tri, k);
+        hipLaunchKernelGGL(nd_scatter_bwd_kernel, dim3(gl), dim3(256), 0, h->stream, F, h->d_elim, h->fw_x, h->gx, 0);
+    }
+    hipLaunchKernelGGL(nd_out_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, h->gx, x, add);
+    HIPCHK(hipGetLastError());
+}
+
 static void substitute(gfs_handle* h, const double* rhs, double* x, int add) {
+    if (h->nd) { substitute_nd(h, rhs, x, add); return; }
     const unsigned g3 = (unsigned)((3 * h->ncp + 255) / 256), gp = (unsigned)((h->npad + 255) / 256);
     HIPCHK(hipMemsetAsync(h->vb, 0, h->npad * sizeof(double), h->stream));
     hipLaunchKernelGGL(permute_in_kernel, dim3(g3), dim3(256), 0, h->stream, h->ncp, h->newi, rhs, h->vb);
@@ -386,6 +539,91 @@ int gfs_create(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb
     return 0;
 }
 
+// Nested-dissection multifrontal mode: the fronts come from the host's symbolic phase (goldfish_amd/_nd.py); all arrays are host pointers.
+//   elim [ncp], elim_off [nfronts + 1]: control points eliminated by every front (post-order); bnd, bnd_off: boundary control points per front (ascending
+//   elimination order); parent [nfronts] (-1: root); order [ncp]: position in the elimination order; front_of [ncp]; pmap [size of bnd]: position of every
+//   boundary control point of a front in its PARENT's numbering (eliminated control points first, then the parent's boundary).
+int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb, const double* d_valK, int64_t nfronts, const int64_t* elim, const int64_t* elim_off,
+                  const int64_t* bnd, const int64_t* bnd_off, const int64_t* parent, const int64_t* order, const int64_t* front_of, const int64_t* pmap, gfs_handle** out) {
+    if (!out || !nb_ptr || !nb || !d_valK || !elim || !elim_off || !bnd_off || !parent || !order || !front_of) return sfail("gfs_create_nd: null argument");
+    *out = nullptr;
+    if (ncp <= 0 || nfronts <= 0) return sfail("gfs_create_nd: empty model");
+    gfs_handle* h = nullptr;
+    try {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("gfs_create_nd: no HIP device visible (libgoldfish_solver has no CPU fallback)");
+        if (device < 0 || device >= ndev) throw std::runtime_error("gfs_create_nd: device index out of range");
+        if (elim_off[nfronts] != ncp) throw std::runtime_error("gfs_create_nd: the fronts do not eliminate every control point exactly once");
+        {
+            std::vector<char> seen(ncp, 0);
+            for (int64_t q = 0; q < ncp; ++q) {
+                const int64_t a = elim[q];
+                if (a < 0 || a >= ncp || seen[a] || order[a] != q) throw std::runtime_error("gfs_create_nd: elim / order are not a consistent permutation");
+                seen[a] = 1;
+            }
+        }
+        h = new gfs_handle(); h->device = device; h->nd = true;
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreate(&h->stream));
+        h->ncp = ncp; h->n = 3 * ncp; h->npad = h->n; h->nblk = 0; h->bw = 0;
+        h->fronts.resize(nfronts); h->kids.assign(nfronts, {});
+        long long tiles = 0, kb = 0; int maxb = 0; double fl = 0.0;
+        for (int64_t t = 0; t < nfronts; ++t) {
+            Front& F = h->fronts[t];
+            F.elim_off = elim_off[t]; F.bnd_off = bnd_off[t];
+            F.ne_cp = (int)(elim_off[t + 1] - elim_off[t]); F.nb_cp = (int)(bnd_off[t + 1] - bnd_off[t]);
+            if (F.ne_cp <= 0) throw std::runtime_error("gfs_create_nd: a front eliminates nothing");
+            F.nblk_e = (3 * F.ne_cp + NB - 1) / NB; F.ne_pad = F.nblk_e * NB;
+            F.nblk_t = F.nblk_e + (3 * F.nb_cp + NB - 1) / NB;
+            F.parent = (int)parent[t]; F.pad0 = F.pad1 = 0;
+            if (F.parent >= 0) { if (F.parent <= t || F.parent >= nfronts) throw std::runtime_error("gfs_create_nd: the fronts are not in post-order"); h->kids[F.parent].push_back((int)t); }
+            else if (F.nb_cp != 0) throw std::runtime_error("gfs_create_nd: a root front has a boundary");
+            F.tile_off = tiles; F.kbase = kb;
+            tiles += (long long)F.nblk_t * (F.nblk_t + 1) / 2; kb += F.nblk_e; maxb = std::max(maxb, F.nblk_t);
+            for (int k = 0; k < F.nblk_e; ++k) { const double r = F.nblk_t - 1 - k; fl += 2.0 * NB * NB * NB * (r + r * (r + 1) / 2) + 2.0 * NB * NB * NB / 3; }
+        }
+        h->ntiles = tiles; h->nbe_tot = kb; h->max_blk = maxb; h->nd_flops = fl; h->T = maxb;
+        const double gbs = ((double)tiles + kb + maxb) * NB2 * 8.0 / 1e9;
+        size_t freeb = 0, totb = 0; HIPCHK(hipMemGetInfo(&freeb, &totb));
+        if (gbs * 1e9 > 0.92 * (double)freeb) throw std::runtime_error("gfs_create_nd: the fronts need " + std::to_string(gbs) + " GB, more than the free device memory");
+        std::vector<long long> ptr(nb_ptr, nb_ptr + ncp + 1), tri(maxb + 1), ord(order, order + ncp);
+        for (int I = 0; I <= maxb; ++I) tri[I] = (long long)I * (I + 1) / 2;
+        std::vector<int> e32(elim, elim + ncp), fo32(front_of, front_of + ncp), b32, pm32;
+        const int64_t nbnd = bnd_off[nfronts];
+        if (nbnd > 0) { if (!bnd || !pmap) throw std::runtime_error("gfs_create_nd: bnd / pmap missing"); b32.assign(bnd, bnd + nbnd); pm32.assign(pmap, pmap + nbnd); }
+        for (int64_t t = 0; t < nfronts; ++t) {               // the map into the parent must be strictly increasing and inside the parent
+            const Front& F = h->fronts[t];
+            if (F.parent < 0) continue;
+            const Front& P = h->fronts[F.parent];
+            for (int q = 0; q < F.nb_cp; ++q) {
+                const int v = pm32[F.bnd_off + q];
+                if (v < 0 || v >= P.ne_cp + P.nb_cp || (q > 0 && v <= pm32[F.bnd_off + q - 1])) throw std::runtime_error("gfs_create_nd: boundary map into the parent front is not monotone");
+            }
+        }
+        h->nb_ptr = h->up(ptr.data(), ptr.size()); h->nb = h->up(nb, (size_t)nb_ptr[ncp]);
+        h->d_tri = h->up(tri.data(), tri.size()); h->d_order = h->up(ord.data(), ord.size());
+        h->d_elim = h->up(e32.data(), e32.size()); h->d_front_of = h->up(fo32.data(), fo32.size());
+        h->d_bnd = h->up(b32.data(), b32.size()); h->d_pmap = h->up(pm32.data(), pm32.size());
+        h->d_fronts = h->up(h->fronts.data(), h->fronts.size());
+        h->valK = d_valK; h->nnz9 = 9 * (long long)nb_ptr[ncp];
+        h->band = h->dalloc<double>((size_t)tiles * NB2);
+        h->linv = h->dalloc<double>((size_t)kb * NB2);
+        h->dval = h->dalloc<double>((size_t)kb * NB); h->stat = h->dalloc<double>((size_t)2 * kb);
+        h->wbuf = h->dalloc<double>((size_t)std::max(maxb, 1) * NB2);
+        const size_t fl_ = (size_t)maxb * NB;
+        h->fw_b = h->dalloc<double>(fl_); h->fw_y = h->dalloc<double>(fl_); h->fw_z = h->dalloc<double>(fl_); h->fw_x = h->dalloc<double>(fl_);
+        h->gy = h->dalloc<double>(h->n); h->gb = h->dalloc<double>(h->n); h->gx = h->dalloc<double>(h->n);
+        h->vr = h->dalloc<double>(h->n); h->vsol = h->dalloc<double>(h->n); h->vrhs = h->dalloc<double>(h->n); h->part = h->dalloc<double>(256);
+        HIPCHK(hipMemsetAsync(h->gy, 0, h->n * sizeof(double), h->stream)); HIPCHK(hipMemsetAsync(h->gx, 0, h->n * sizeof(double), h->stream));
+        HIPCHK(hipDeviceSynchronize());
+    } catch (const std::exception& ex) {
+        if (h) gfs_destroy(h);
+        return sfail(ex.what());
+    }
+    *out = h;
+    return 0;
+}
+
 void gfs_destroy(gfs_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
@@ -401,6 +639,28 @@ int gfs_refactor(gfs_handle* h) {
         HIPCHK(hipSetDevice(h->device));
         h->factored = false;
         HIPCHK(hipMemsetAsync(h->band, 0, (size_t)h->ntiles * NB2 * sizeof(double), h->stream));
+        if (h->nd) {
+            hipLaunchKernelGGL(nd_scatter_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->valK, h->d_fronts, h->d_front_of, h->d_order,
+                               h->d_bnd, h->d_tri, h->band);
+            const int nf = (int)h->fronts.size();
+            hipLaunchKernelGGL(nd_pad_kernel, dim3(nf), dim3(64), 0, h->stream, h->d_fronts, h->d_tri, h->band);
+            for (int t = 0; t < nf; ++t) {
+                const Front& F = h->fronts[t];
+                for (int c : h->kids[t]) {
+                    const long long nbb = h->fronts[c].nblk_t - h->fronts[c].nblk_e;
+                    if (nbb > 0) hipLaunchKernelGGL(nd_extend_add_kernel, dim3((unsigned)(nbb * (nbb + 1) / 2)), dim3(256), 0, h->stream, h->d_fronts, c, h->d_pmap, h->d_tri, h->band);
+                }
+                double* band = h->band + (size_t)F.tile_off * NB2;
+                for (int k = 0; k < F.nblk_e; ++k) {
+                    const int ni = F.nblk_t - 1 - k;
+                    hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, h->stream, band, h->linv + (size_t)F.kbase * NB2, h->dval + (size_t)F.kbase * NB, h->d_tri, k, h->stat + 2 * F.kbase);
+                    if (ni > 0) {
+                        hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, h->stream, band, h->linv + (size_t)F.kbase * NB2, h->dval + (size_t)F.kbase * NB, h->wbuf, h->d_tri, k);
+                        hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, h->stream, band, h->wbuf, h->d_tri, k, ni);
+                    }
+                }
+            }
+        } else {
         hipLaunchKernelGGL(band_fill_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->newi, h->valK, h->band, h->rowoff, h->n, h->npad);
         for (long long k = 0; k < h->nblk; ++k) {
             const int ni = h->nik[k];
@@ -410,12 +670,14 @@ int gfs_refactor(gfs_handle* h) {
                 hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, h->stream, h->band, h->wbuf, h->rowoff, (int)k, ni);
             }
         }
+        }
         HIPCHK(hipGetLastError());
-        std::vector<double> st(2 * h->nblk);
+        const long long ncol = h->nd ? h->nbe_tot : h->nblk;
+        std::vector<double> st(2 * ncol);
         HIPCHK(hipMemcpyAsync(st.data(), h->stat, st.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         double mn = 1e300, mx = 0.0;
-        for (long long k = 0; k < h->nblk; ++k) { mn = std::min(mn, st[2 * k]); mx = std::max(mx, st[2 * k + 1]); }
+        for (long long k = 0; k < ncol; ++k) { mn = std::min(mn, st[2 * k]); mx = std::max(mx, st[2 * k + 1]); }
         if (!(mn == mn) || !(mx == mx) || !std::isfinite(mx) || mn == 0.0) throw std::runtime_error("gfs_refactor: zero or non-finite pivot (K is singular for this ordering without pivoting)");
         h->small_pivot = mn < 1e-14 * mx;
         h->normK = norm2(h, h->valK, h->nnz9);
@@ -476,8 +738,8 @@ int gfs_solve(gfs_handle* h, const double* b, double* x, int max_refine, double*
 int gfs_info(gfs_handle* h, double info[8]) {
     if (!h || !info) return sfail("gfs_info: null argument");
     info[0] = (double)h->bw; info[1] = (double)h->nblk; info[2] = (double)(h->T + 1); info[3] = (double)h->bytes;
-    double fl = 0.0;
-    for (long long k = 0; k < h->nblk; ++k) { const double ni = (double)h->nik[k]; fl += 2.0 * NB * NB * NB * (ni + ni * (ni + 1) / 2) + 2.0 * NB * NB * NB / 3; }
+    double fl = h->nd ? h->nd_flops : 0.0;
+    for (long long k = 0; !h->nd && k < h->nblk; ++k) { const double ni = (double)h->nik[k]; fl += 2.0 * NB * NB * NB * (ni + ni * (ni + 1) / 2) + 2.0 * NB * NB * NB / 3; }
     info[4] = fl; info[5] = h->small_pivot ? 1.0 : 0.0; info[6] = h->backward_error; info[7] = h->normK;
     return 0;
 }

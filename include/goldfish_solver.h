@@ -30,6 +30,14 @@ const char* gfs_last_error(void);
  * new_index (host, ncp): position of every control point in the factorisation order (a permutation).
  * d_valK: DEVICE pointer to K's values, borrowed and re-read by every gfs_refactor. */
 int gfs_create(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb, const int32_t* new_index, const double* d_valK, gfs_handle** out);
+/* Nested-dissection multifrontal factorisation instead of the skyline (large models: memory O(n log n) and work O(n^1.5) for a shell instead of
+ * n x bandwidth and n x bandwidth^2).  The fronts come from the caller's symbolic phase (goldfish_amd/_nd.py: recursive coordinate bisection with
+ * vertex separators), all host arrays: elim [ncp] / elim_off [nfronts + 1] = control points eliminated per front, fronts in post-order; bnd / bnd_off =
+ * boundary control points per front in ascending elimination order; parent [nfronts] (-1 = root); order [ncp] = elimination position of a control
+ * point; front_of [ncp]; pmap [bnd_off[nfronts]] = position of each boundary control point in the PARENT front's numbering (eliminated first).
+ * gfs_refactor / gfs_solve / gfs_solve_dev / gfs_info / gfs_destroy work on the handle as for the skyline. */
+int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb, const double* d_valK, int64_t nfronts, const int64_t* elim, const int64_t* elim_off,
+                  const int64_t* bnd, const int64_t* bnd_off, const int64_t* parent, const int64_t* order, const int64_t* front_of, const int64_t* pmap, gfs_handle** out);
 void gfs_destroy(gfs_handle* h);
 /* numeric factorisation of the values currently in d_valK */
 int gfs_refactor(gfs_handle* h);

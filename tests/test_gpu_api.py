@@ -365,7 +365,7 @@ def test_adjoint_total_derivatives_vs_finite_differences():
     assert abs(fd_cp - tot_cp @ dcp) < 1e-5 * max(abs(fd_cp), 1e-12)
 
 
-def _solver_case(spec, uamp):
+def _solver_case(spec, uamp, method="skyline", leaf=256):
     """K of a deformed state, a right-hand side, the device solution and the host (SuperLU) solution refined with the same K."""
     import scipy.sparse.linalg as spla
     from goldfish_amd import _lib, _solver
@@ -376,7 +376,8 @@ def _solver_case(spec, uamp):
     D.assemble(_lib.ASM_R | _lib.ASM_K)
     K = D.csr(_lib.MAT_K).tocsc()
     b = -D.residual()
-    S = _solver.DeviceSolver(D)
+    S = _solver.DeviceSolver(D, coords=np.stack([A.cp_hom[f] / A.weights for f in range(3)], 1), method=method, leaf=leaf)
+    assert S.method == method
     x = S.solve(b)
     lu = spla.splu(K)
     xh = lu.solve(b)
@@ -414,6 +415,20 @@ def test_device_linear_solver_against_superlu():
         # own solutions are to each other when only the elimination order changes (the conditioning of K sets that distance)
         assert res < 10 * res_host + 1e-13 and r2 < 1e-9 and rr < 10 * res + 1e-13
         assert err < max(tol, 20 * self_err), (ndof, err, self_err)
+
+
+def test_device_linear_solver_nested_dissection_against_superlu():
+    """The nested-dissection multifrontal mode (goldfish_amd/_nd.py: recursive coordinate bisection, vertex separators, fronts;
+    gfs_create_nd: dense fronts on the skyline solver's tile kernels, extend-add, post-order substitutions) on the same systems as the
+    skyline test, with leaves small enough for trees of depth 3 .. 7: same acceptance as the skyline -- residuals at the round-off floor of K,
+    solutions as close to SuperLU's as two SuperLU orderings are to each other; re-factorisation after a state change."""
+    for spec, leaf in ((G.tbeam_2patch(6), 24), (G.tbeam_4patch(), 96), (G.synthetic_shell(6, 6, nel=24, p=3, jitter=2), 256),
+                       (G.wing_16patch_from_interface_data(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_wing_int_data.npz"), allow_pickle=True)), 64)):
+        err, res, rr, r2, info, ndof, res_host, self_err = _solver_case(spec, 0.5, method="nd", leaf=leaf)
+        print("nested dissection: %d dofs, %.3f GB, err vs SuperLU %.2e (SuperLU vs SuperLU %.2e), residual %.2e (reported %.2e; SuperLU + refinement %.2e), after refactor %.2e"
+              % (ndof, info["device_bytes"] / 1e9, err, self_err, res, rr, res_host, r2))
+        assert res < 10 * res_host + 1e-13 and r2 < 1e-9 and rr < 10 * res + 1e-13
+        assert err < max(1e-9, 20 * self_err), (ndof, err, self_err)
 
 
 def test_device_solver_is_the_default_newton_and_adjoint_path():

@@ -21,12 +21,13 @@ for name, spec in cases:
     D.set_thickness(np.full(A.total_cp, spec.h_th)); D.set_u(G.smooth_displacement(spec, 0.5 * spec.h_th))
     D.assemble(_lib.ASM_R | _lib.ASM_K); D.sync()
     b = -D.residual(); g = np.random.default_rng(0).standard_normal(A.ndof)
-    t = time.perf_counter(); S = _solver.DeviceSolver(D); t_first = time.perf_counter() - t
+    X = np.stack([A.cp_hom[f] / A.weights for f in range(3)], 1)
+    t = time.perf_counter(); S = _solver.DeviceSolver(D, coords=X, method=os.environ.get("GF_SOLVER_METHOD", "auto")); t_first = time.perf_counter() - t
     info = S.info()
     t = time.perf_counter(); S.refactor(); t_f = time.perf_counter() - t
     t = time.perf_counter(); x = S.solve(b); t_s = time.perf_counter() - t; rr, be = S.rel_residual, S.backward_error
     t = time.perf_counter(); lam = S.solve(g); t_a = time.perf_counter() - t; ra, bea = S.rel_residual, S.backward_error
-    line = ("%s: %d dofs, half bandwidth %d, skyline %.2f GB; device: ordering + first factorisation %.3f s, re-factorisation %.4f s (%.1f TFLOP/s), Newton solve %.4f s "
+    line = (("%s [" + S.method + "]") + ": %d dofs, half bandwidth %d, factor storage %.2f GB; device: ordering + first factorisation %.3f s, re-factorisation %.4f s (%.1f TFLOP/s), Newton solve %.4f s "
             "(residual %.1e, backward error %.1e), adjoint solve %.4f s (residual %.1e, backward error %.1e)"
             % (name, A.ndof, info["half_bandwidth"], info["device_bytes"] / 1e9, t_first, t_f, info["factor_flops"] / t_f / 1e12, t_s, rr, be, t_a, ra, bea))
     if host and A.ndof < 150000:
