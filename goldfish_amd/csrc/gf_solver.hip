@@ -348,12 +348,18 @@ __global__ void nd_gather_rhs_kernel(Front F, const int* __restrict__ elim, cons
     if (t >= 64 * F.nblk_t) return;
     w[t] = t < 3 * F.ne_cp ? b[3 * (long long)elim[F.elim_off + t / 3] + t % 3] : 0.0;
 }
-// after the forward substitution of a front: y of the eliminated dofs to the global y, the boundary updates added to the global right-hand side
-__global__ void nd_scatter_fwd_kernel(Front F, const int* __restrict__ elim, const int* __restrict__ bnd, const double* __restrict__ wy, const double* __restrict__ wb,
-                                      double* __restrict__ y, double* __restrict__ b) {
+// the boundary updates a child left behind (fbnd, per front: 3 doubles per boundary control point) pulled into the parent's local vector: the
+// parent adds its children one after the other (fixed order, no two writers: bitwise reproducible, and sibling subtrees may run concurrently)
+__global__ void nd_pull_child_kernel(Front Fc, Front Fp, const int* __restrict__ pmap, const double* __restrict__ fbnd, double* __restrict__ w) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 3 * Fc.nb_cp) w[nd_dofpos(Fp, pmap[Fc.bnd_off + t / 3], t % 3)] += fbnd[3 * Fc.bnd_off + t];
+}
+// after the forward substitution of a front: y of the eliminated dofs to the global y, the updated boundary part to the front's own buffer
+__global__ void nd_scatter_fwd_kernel(Front F, const int* __restrict__ elim, const double* __restrict__ wy, const double* __restrict__ wb,
+                                      double* __restrict__ y, double* __restrict__ fbnd) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 3 * F.ne_cp) y[3 * (long long)elim[F.elim_off + t / 3] + t % 3] = wy[t];
-    if (t < 3 * F.nb_cp) b[3 * (long long)bnd[F.bnd_off + t / 3] + t % 3] += wb[F.ne_pad + t];
+    if (t < 3 * F.nb_cp) fbnd[3 * F.bnd_off + t] = wb[F.ne_pad + t];
 }
 // before the backward substitution of a front: z = D^-1 y on the eliminated dofs, x of the boundary dofs (ancestors: already known)
 __global__ void nd_gather_bwd_kernel(Front F, const int* __restrict__ elim, const int* __restrict__ bnd, const double* __restrict__ y, const double* __restrict__ x,
@@ -381,6 +387,92 @@ __global__ __launch_bounds__(256) void nd_bwd_bnd_kernel(const double* __restric
     __syncthreads();
     if (tid < NB) wz[(size_t)J * NB + tid] -= sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
 }
+// ---- whole-front substitutions for the small fronts (most block columns of a model sit in fronts of a few dozen blocks: one launch per block column
+//      makes a solve launch bound).  One workgroup per front, the front-local vector in LDS, the tiles streamed once; all fronts of one tree height in
+//      one launch (they are independent), heights in ascending (forward) / descending (backward) order on one stream.
+__global__ __launch_bounds__(256) void nd_fwd_front_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const int* __restrict__ kid_off, const int* __restrict__ kid,
+                                                           const long long* __restrict__ tri, const double* __restrict__ arena, const double* __restrict__ linv, const int* __restrict__ elim,
+                                                           const int* __restrict__ pmap, const double* __restrict__ gb, double* __restrict__ gy, double* __restrict__ fbnd) {
+    extern __shared__ double sw[];                                  // [64 nblk_t] front-local right-hand side, then sy [64]
+    const int t = list[blockIdx.x], tid = threadIdx.x;
+    const Front F = fronts[t];
+    const int nloc = 64 * F.nblk_t;
+    double* sy = sw + nloc;
+    for (int q = tid; q < nloc; q += 256) sw[q] = q < 3 * F.ne_cp ? gb[3 * (long long)elim[F.elim_off + q / 3] + q % 3] : 0.0;
+    __syncthreads();
+    for (int ci = kid_off[t]; ci < kid_off[t + 1]; ++ci) {           // children one after the other: fixed order
+        const Front Fc = fronts[kid[ci]];
+        for (int q = tid; q < 3 * Fc.nb_cp; q += 256) sw[nd_dofpos(F, pmap[Fc.bnd_off + q / 3], q % 3)] += fbnd[3 * Fc.bnd_off + q];
+        __syncthreads();
+    }
+    const double* band = arena + (size_t)F.tile_off * NB2;
+    const int r = tid >> 2, q4 = tid & 3;
+    for (int k = 0; k < F.nblk_e; ++k) {
+        {
+            const double* L = linv + (size_t)(F.kbase + k) * NB2 + r * NB + 16 * q4;
+            double part = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) part += L[c] * sw[64 * k + 16 * q4 + c];
+            part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+            if (q4 == 0) sy[r] = part;
+        }
+        __syncthreads();
+        for (int I = k + 1; I < F.nblk_t; ++I) {
+            const double* L = band + (size_t)(tri[I] + (I - k)) * NB2 + r * NB + 16 * q4;
+            double part = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) part += L[c] * sy[16 * q4 + c];
+            part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+            if (q4 == 0) sw[64 * I + r] -= part;
+        }
+        if (tid < NB) { const int q = 64 * k + tid; if (q < 3 * F.ne_cp) gy[3 * (long long)elim[F.elim_off + q / 3] + q % 3] = sy[tid]; }
+        __syncthreads();
+    }
+    for (int q = tid; q < 3 * F.nb_cp; q += 256) fbnd[3 * F.bnd_off + q] = sw[F.ne_pad + q];
+}
+__global__ __launch_bounds__(256) void nd_bwd_front_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ tri, const double* __restrict__ arena,
+                                                           const double* __restrict__ linv, const double* __restrict__ dval, const int* __restrict__ elim, const int* __restrict__ bnd,
+                                                           const double* __restrict__ gy, double* __restrict__ gx) {
+    extern __shared__ double sw[];                                  // [64 nblk_t]: z on the eliminated blocks (becomes x), x on the boundary blocks; then sp [4][64]
+    const int t = list[blockIdx.x], tid = threadIdx.x;
+    const Front F = fronts[t];
+    const int nloc = 64 * F.nblk_t;
+    double (*sp)[NB] = reinterpret_cast<double (*)[NB]>(sw + nloc);
+    for (int q = tid; q < nloc; q += 256) {
+        double v = 0.0;
+        if (q < F.ne_pad) { if (q < 3 * F.ne_cp) v = gy[3 * (long long)elim[F.elim_off + q / 3] + q % 3] / dval[F.kbase * NB + q]; }
+        else { const int qb = q - F.ne_pad; if (qb < 3 * F.nb_cp) v = gx[3 * (long long)bnd[F.bnd_off + qb / 3] + qb % 3]; }
+        sw[q] = v;
+    }
+    __syncthreads();
+    const double* band = arena + (size_t)F.tile_off * NB2;
+    const int c = tid & 63, rq = tid >> 6;
+    // z_J -= sum over the rows I below (boundary rows, then the eliminated rows already solved) of L_IJ^T x_I, J descending; then x_J = L_JJ^-T z_J
+    for (int J = F.nblk_e - 1; J >= 0; --J) {
+        double acc = 0.0;
+        for (int I = J + 1; I < F.nblk_t; ++I) {
+            const double* L = band + (size_t)(tri[I] + (I - J)) * NB2 + (16 * rq) * NB + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc += L[r * NB] * sw[64 * I + 16 * rq + r];
+        }
+        sp[rq][c] = acc;
+        __syncthreads();
+        if (tid < NB) sw[64 * J + tid] -= sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+        __syncthreads();
+        {
+            const double* L = linv + (size_t)(F.kbase + J) * NB2 + (16 * rq) * NB + c;
+            double part = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part += L[r * NB] * sw[64 * J + 16 * rq + r];
+            __syncthreads();
+            sp[rq][c] = part;
+        }
+        __syncthreads();
+        if (tid < NB) sw[64 * J + tid] = sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+        __syncthreads();
+    }
+    for (int q = tid; q < 3 * F.ne_cp; q += 256) gx[3 * (long long)elim[F.elim_off + q / 3] + q % 3] = sw[q];
+}
 __global__ void nd_scatter_bwd_kernel(Front F, const int* __restrict__ elim, const double* __restrict__ wx, double* __restrict__ x, int add) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 3 * F.ne_cp) { double* dst = x + 3 * (long long)elim[F.elim_off + t / 3] + t % 3; *dst = add ? *dst + wx[t] : wx[t]; }
@@ -402,7 +494,20 @@ struct gfs_handle {
     bool nd = false; std::vector<Front> fronts; std::vector<std::vector<int>> kids; Front* d_fronts = nullptr;
     int *d_elim = nullptr, *d_bnd = nullptr, *d_pmap = nullptr, *d_front_of = nullptr; long long* d_order = nullptr; long long* d_tri = nullptr;
     long long nbe_tot = 0; int max_blk = 0; double nd_flops = 0.0;
-    double *fw_b = nullptr, *fw_y = nullptr, *fw_z = nullptr, *fw_x = nullptr, *gy = nullptr, *gb = nullptr, *gx = nullptr;
+    double *gy = nullptr, *gb = nullptr, *gx = nullptr, *fbnd = nullptr;
+    // independent subtrees run on their own streams (their fronts are small: a single stream leaves the device idle); the fronts above
+    // them ("top") follow on the main stream.  Per stream: W tiles of a panel, front-local vectors
+    static constexpr int NS = 8;
+    hipStream_t st[NS] = {}; hipEvent_t ev[NS] = {}, ev_main = nullptr;
+    double *s_wbuf[NS + 1] = {}, *s_b[NS + 1] = {}, *s_y[NS + 1] = {}, *s_z[NS + 1] = {}, *s_x[NS + 1] = {};
+    std::vector<std::vector<int>> sub;       // sub[s]: fronts of the subtrees assigned to stream s, in post-order
+    std::vector<int> top;                    // the remaining fronts, in post-order
+    // the sweeps are ~1e5 small launches with a fixed structure: captured once into HIP graphs (all streams), replayed per factorisation / substitution
+    hipGraphExec_t g_factor = nullptr, g_solve = nullptr; bool use_graph = true;
+    // substitutions: fronts by tree height; the small ones of a height in one launch (nd_fwd_front_kernel / nd_bwd_front_kernel), the large ones per block column
+    static constexpr int FUSE_MAX_BLK = 96;  // 64 x 96 doubles = 48 KB of LDS for the front-local vector
+    struct Level { int off_small, n_small, max_blk; std::vector<int> big; };
+    std::vector<Level> levels; int *d_lvl_list = nullptr, *d_kid_off = nullptr, *d_kid = nullptr;
     template <class Tp> Tp* dalloc(size_t cnt) {
         void* p = nullptr; const size_t nb_ = (cnt ? cnt : 1) * sizeof(Tp);
         HIPCHK(hipMalloc(&p, nb_)); allocs.push_back(p); bytes += (long long)nb_; return (Tp*)p;
@@ -425,30 +530,105 @@ __global__ void nd_out_kernel(long long n, const double* __restrict__ src, doubl
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) dst[t] = add ? dst[t] + src[t] : src[t];
 }
-// multifrontal substitutions: fronts in post-order (forward), in reverse (backward); vectors in the original numbering
+// ---- multifrontal mode: work of one front on a stream with that stream's scratch (index NS = the main stream's)
+static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si) {
+    const Front& F = h->fronts[t];
+    for (int c : h->kids[t]) {
+        const long long nbb = h->fronts[c].nblk_t - h->fronts[c].nblk_e;
+        if (nbb > 0) hipLaunchKernelGGL(nd_extend_add_kernel, dim3((unsigned)(nbb * (nbb + 1) / 2)), dim3(256), 0, st, h->d_fronts, c, h->d_pmap, h->d_tri, h->band);
+    }
+    double* band = h->band + (size_t)F.tile_off * NB2;
+    for (int k = 0; k < F.nblk_e; ++k) {
+        const int ni = F.nblk_t - 1 - k;
+        hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, h->dval + (size_t)F.kbase * NB, h->d_tri, k, h->stat + 2 * F.kbase);
+        if (ni > 0) {
+            hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, h->dval + (size_t)F.kbase * NB, h->s_wbuf[si], h->d_tri, k);
+            hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, st, band, h->s_wbuf[si], h->d_tri, k, ni);
+        }
+    }
+}
+static void nd_forward_front(gfs_handle* h, int t, hipStream_t st, int si) {
+    const Front& F = h->fronts[t];
+    const double* band = h->band + (size_t)F.tile_off * NB2;
+    const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
+    hipLaunchKernelGGL(nd_gather_rhs_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->gb, h->s_b[si]);
+    for (int c : h->kids[t]) {
+        const Front& Fc = h->fronts[c];
+        if (Fc.nb_cp > 0) hipLaunchKernelGGL(nd_pull_child_kernel, dim3((unsigned)((3 * Fc.nb_cp + 255) / 256)), dim3(256), 0, st, Fc, F, h->d_pmap, h->fbnd, h->s_b[si]);
+    }
+    for (int k = 0; k < F.nblk_e; ++k)
+        hipLaunchKernelGGL(fwd_kernel, dim3(F.nblk_t - k), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, h->s_b[si], h->s_y[si], h->d_tri, k);
+    hipLaunchKernelGGL(nd_scatter_fwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->s_y[si], h->s_b[si], h->gy, h->fbnd);
+}
+static void nd_backward_front(gfs_handle* h, int t, hipStream_t st, int si) {
+    const Front& F = h->fronts[t];
+    const double* band = h->band + (size_t)F.tile_off * NB2;
+    const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
+    hipLaunchKernelGGL(nd_gather_bwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->d_bnd, h->gy, h->gx, h->dval, h->s_z[si], h->s_x[si]);
+    if (F.nblk_t > F.nblk_e && F.nblk_e > 0)
+        hipLaunchKernelGGL(nd_bwd_bnd_kernel, dim3(F.nblk_e), dim3(256), 0, st, band, h->d_tri, F.nblk_e, F.nblk_t, h->s_x[si], h->s_z[si]);
+    for (int k = F.nblk_e - 1; k >= 0; --k)
+        hipLaunchKernelGGL(bwd_kernel, dim3(k + 1), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, h->s_z[si], h->s_x[si], h->d_tri, k);
+    hipLaunchKernelGGL(nd_scatter_bwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->s_x[si], h->gx, 0);
+}
+// bottom-up sweep: the independent subtrees on their streams (forked behind the main stream's earlier work), then the top fronts on the main stream
+template <class Fn> static void nd_sweep_up(gfs_handle* h, Fn&& fn) {
+    constexpr int NS = gfs_handle::NS;
+    HIPCHK(hipEventRecord(h->ev_main, h->stream));
+    for (int s = 0; s < NS; ++s) {
+        if (h->sub[s].empty()) continue;
+        HIPCHK(hipStreamWaitEvent(h->st[s], h->ev_main, 0));
+        for (int t : h->sub[s]) fn(h, t, h->st[s], s);
+        HIPCHK(hipEventRecord(h->ev[s], h->st[s]));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev[s], 0));
+    }
+    for (int t : h->top) fn(h, t, h->stream, NS);
+}
+// top-down sweep: the top fronts in reverse on the main stream, then the subtrees in reverse on their streams; joined on the main stream
+template <class Fn> static void nd_sweep_down(gfs_handle* h, Fn&& fn) {
+    constexpr int NS = gfs_handle::NS;
+    for (auto it = h->top.rbegin(); it != h->top.rend(); ++it) fn(h, *it, h->stream, NS);
+    HIPCHK(hipEventRecord(h->ev_main, h->stream));
+    for (int s = 0; s < NS; ++s) {
+        if (h->sub[s].empty()) continue;
+        HIPCHK(hipStreamWaitEvent(h->st[s], h->ev_main, 0));
+        for (auto it = h->sub[s].rbegin(); it != h->sub[s].rend(); ++it) fn(h, *it, h->st[s], s);
+        HIPCHK(hipEventRecord(h->ev[s], h->st[s]));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev[s], 0));
+    }
+}
+// run `body` (kernel launches, event record / wait on h->stream and the side streams) through a graph captured at the first call
+template <class Body> static void nd_run_captured(gfs_handle* h, hipGraphExec_t* exec, Body&& body) {
+    if (!h->use_graph) { body(); return; }
+    if (!*exec) {
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeGlobal));
+        body();
+        HIPCHK(hipStreamEndCapture(h->stream, &g));
+        HIPCHK(hipGraphInstantiate(exec, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+    }
+    HIPCHK(hipGraphLaunch(*exec, h->stream));
+}
+// multifrontal substitutions; vectors in the original numbering
 static void substitute_nd(gfs_handle* h, const double* rhs, double* x, int add) {
     HIPCHK(hipMemcpyAsync(h->gb, rhs, h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    const int nf = (int)h->fronts.size();
-    for (int t = 0; t < nf; ++t) {
-        const Front& F = h->fronts[t];
-        const double* band = h->band + (size_t)F.tile_off * NB2;
-        const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
-        hipLaunchKernelGGL(nd_gather_rhs_kernel, dim3(gl), dim3(256), 0, h->stream, F, h->d_elim, h->gb, h->fw_b);
-        for (int k = 0; k < F.nblk_e; ++k)
-            hipLaunchKernelGGL(fwd_kernel, dim3(F.nblk_t - k), dim3(256), 0, h->stream, band, h->linv + (size_t)F.kbase * NB2, h->fw_b, h->fw_y, h->d_tri, k);
-        hipLaunchKernelGGL(nd_scatter_fwd_kernel, dim3(gl), dim3(256), 0, h->stream, F, h->d_elim, h->d_bnd, h->fw_y, h->fw_b, h->gy, h->gb);
-    }
-    for (int t = nf - 1; t >= 0; --t) {
-        const Front& F = h->fronts[t];
-        const double* band = h->band + (size_t)F.tile_off * NB2;
-        const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
-        hipLaunchKernelGGL(nd_gather_bwd_kernel, dim3(gl), dim3(256), 0, h->stream, F, h->d_elim, h->d_bnd, h->gy, h->gx, h->dval, h->fw_z, h->fw_x);
-        if (F.nblk_t > F.nblk_e && F.nblk_e > 0)
-            hipLaunchKernelGGL(nd_bwd_bnd_kernel, dim3(F.nblk_e), dim3(256), 0, h->stream, band, h->d_tri, F.nblk_e, F.nblk_t, h->fw_x, h->fw_z);
-        for (int k = F.nblk_e - 1; k >= 0; --k)
-            hipLaunchKernelGGL(bwd_kernel, dim3(k + 1), dim3(256), 0, h->stream, band, h->linv + (size_t)F.kbase * NB2, h->fw_z, h->fw_x, h->d_tri, k);
-        hipLaunchKernelGGL(nd_scatter_bwd_kernel, dim3(gl), dim3(256), 0, h->stream, F, h->d_elim, h->fw_x, h->gx, 0);
-    }
+    nd_run_captured(h, &h->g_solve, [&] {
+        constexpr int NS = gfs_handle::NS;
+        for (const auto& L : h->levels) {                                         // forward: heights ascending
+            if (L.n_small > 0)
+                hipLaunchKernelGGL(nd_fwd_front_kernel, dim3(L.n_small), dim3(256), (size_t)(64 * L.max_blk + 64) * sizeof(double), h->stream, h->d_fronts, h->d_lvl_list + L.off_small,
+                                   h->d_kid_off, h->d_kid, h->d_tri, h->band, h->linv, h->d_elim, h->d_pmap, h->gb, h->gy, h->fbnd);
+            for (int t : L.big) nd_forward_front(h, t, h->stream, NS);
+        }
+        for (auto it = h->levels.rbegin(); it != h->levels.rend(); ++it) {          // backward: heights descending
+            const auto& L = *it;
+            for (auto b_ = L.big.rbegin(); b_ != L.big.rend(); ++b_) nd_backward_front(h, *b_, h->stream, NS);
+            if (L.n_small > 0)
+                hipLaunchKernelGGL(nd_bwd_front_kernel, dim3(L.n_small), dim3(256), (size_t)(64 * L.max_blk + 4 * 64) * sizeof(double), h->stream, h->d_fronts, h->d_lvl_list + L.off_small,
+                                   h->d_tri, h->band, h->linv, h->dval, h->d_elim, h->d_bnd, h->gy, h->gx);
+        }
+    });
     hipLaunchKernelGGL(nd_out_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, h->gx, x, add);
     HIPCHK(hipGetLastError());
 }
@@ -563,6 +743,7 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
             }
         }
         h = new gfs_handle(); h->device = device; h->nd = true;
+        if (const char* e_ = getenv("GF_SOLVER_GRAPH")) h->use_graph = std::string(e_) != "0";
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreate(&h->stream));
         h->ncp = ncp; h->n = 3 * ncp; h->npad = h->n; h->nblk = 0; h->bw = 0;
@@ -609,9 +790,63 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
         h->band = h->dalloc<double>((size_t)tiles * NB2);
         h->linv = h->dalloc<double>((size_t)kb * NB2);
         h->dval = h->dalloc<double>((size_t)kb * NB); h->stat = h->dalloc<double>((size_t)2 * kb);
-        h->wbuf = h->dalloc<double>((size_t)std::max(maxb, 1) * NB2);
-        const size_t fl_ = (size_t)maxb * NB;
-        h->fw_b = h->dalloc<double>(fl_); h->fw_y = h->dalloc<double>(fl_); h->fw_z = h->dalloc<double>(fl_); h->fw_x = h->dalloc<double>(fl_);
+        {   // independent subtrees for the side streams: split the largest subtree (by factorisation work) until there are enough of them
+            constexpr int NS = gfs_handle::NS;
+            std::vector<double> work(nfronts, 0.0); std::vector<int> cnt(nfronts, 1);
+            for (int64_t t = 0; t < nfronts; ++t) {
+                const Front& F = h->fronts[t];
+                for (int k = 0; k < F.nblk_e; ++k) { const double r = F.nblk_t - 1 - k; work[t] += 1.0 + r + r * (r + 1) / 2; }
+            }
+            for (int64_t t = 0; t < nfronts; ++t) if (h->fronts[t].parent >= 0) { work[h->fronts[t].parent] += work[t]; cnt[h->fronts[t].parent] += cnt[t]; }   // post-order: children first
+            std::vector<int> roots, topset;
+            for (int64_t t = 0; t < nfronts; ++t) if (h->fronts[t].parent < 0) roots.push_back((int)t);
+            std::vector<int> cand = roots;
+            while ((int)cand.size() < 6 * NS) {
+                int best = -1;
+                for (int i = 0; i < (int)cand.size(); ++i) if (!h->kids[cand[i]].empty() && (best < 0 || work[cand[i]] > work[cand[best]])) best = i;
+                if (best < 0) break;
+                const int t = cand[best];
+                cand.erase(cand.begin() + best); topset.push_back(t);
+                for (int c : h->kids[t]) cand.push_back(c);
+            }
+            std::vector<char> is_top(nfronts, 0);
+            for (int t : topset) is_top[t] = 1;
+            // greedy assignment of the subtrees to the streams (largest first); a subtree = the post-order range [t - cnt[t] + 1, t]
+            std::sort(cand.begin(), cand.end(), [&](int x, int y) { return work[x] > work[y]; });
+            std::vector<double> load(NS, 0.0); std::vector<std::vector<int>> subroots(NS);
+            for (int t : cand) { const int s_ = (int)(std::min_element(load.begin(), load.end()) - load.begin()); load[s_] += work[t]; subroots[s_].push_back(t); }
+            h->sub.assign(NS, {});
+            for (int s_ = 0; s_ < NS; ++s_) {
+                std::sort(subroots[s_].begin(), subroots[s_].end());
+                for (int t : subroots[s_]) for (int q = t - cnt[t] + 1; q <= t; ++q) h->sub[s_].push_back(q);
+            }
+            for (int64_t t = 0; t < nfronts; ++t) if (is_top[t]) h->top.push_back((int)t);
+            for (int s_ = 0; s_ < NS; ++s_) { HIPCHK(hipStreamCreate(&h->st[s_])); HIPCHK(hipEventCreateWithFlags(&h->ev[s_], hipEventDisableTiming)); }
+            HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+            const size_t fl_ = (size_t)maxb * NB;
+            for (int s_ = 0; s_ <= NS; ++s_) {
+                h->s_wbuf[s_] = h->dalloc<double>((size_t)std::max(maxb, 1) * NB2);
+                h->s_b[s_] = h->dalloc<double>(fl_); h->s_y[s_] = h->dalloc<double>(fl_); h->s_z[s_] = h->dalloc<double>(fl_); h->s_x[s_] = h->dalloc<double>(fl_);
+            }
+            h->wbuf = h->s_wbuf[NS];
+        }
+        {   // tree heights and the lists of the whole-front substitution kernels
+            std::vector<int> height(nfronts, 0), koff(nfronts + 1, 0), kflat;
+            for (int64_t t = 0; t < nfronts; ++t) { for (int c : h->kids[t]) { height[t] = std::max(height[t], height[c] + 1); kflat.push_back(c); } koff[t + 1] = (int)kflat.size(); }
+            int hmax = 0; for (int64_t t = 0; t < nfronts; ++t) hmax = std::max(hmax, height[t]);
+            h->levels.assign(hmax + 1, {});
+            std::vector<std::vector<int>> small(hmax + 1);
+            for (int64_t t = 0; t < nfronts; ++t) (h->fronts[t].nblk_t <= gfs_handle::FUSE_MAX_BLK ? small[height[t]] : h->levels[height[t]].big).push_back((int)t);
+            std::vector<int> flat;
+            for (int l = 0; l <= hmax; ++l) {
+                auto& L = h->levels[l]; L.off_small = (int)flat.size(); L.n_small = (int)small[l].size(); L.max_blk = 1;
+                for (int t : small[l]) { flat.push_back(t); L.max_blk = std::max(L.max_blk, h->fronts[t].nblk_t); }
+            }
+            if (kflat.empty()) kflat.push_back(0);
+            if (flat.empty()) flat.push_back(0);
+            h->d_lvl_list = h->up(flat.data(), flat.size()); h->d_kid_off = h->up(koff.data(), koff.size()); h->d_kid = h->up(kflat.data(), kflat.size());
+        }
+        h->fbnd = h->dalloc<double>((size_t)std::max<int64_t>(3 * nbnd, 1));
         h->gy = h->dalloc<double>(h->n); h->gb = h->dalloc<double>(h->n); h->gx = h->dalloc<double>(h->n);
         h->vr = h->dalloc<double>(h->n); h->vsol = h->dalloc<double>(h->n); h->vrhs = h->dalloc<double>(h->n); h->part = h->dalloc<double>(256);
         HIPCHK(hipMemsetAsync(h->gy, 0, h->n * sizeof(double), h->stream)); HIPCHK(hipMemsetAsync(h->gx, 0, h->n * sizeof(double), h->stream));
@@ -629,6 +864,10 @@ void gfs_destroy(gfs_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (void* p : h->allocs) (void)hipFree(p);
+    for (int s_ = 0; s_ < gfs_handle::NS; ++s_) { if (h->ev[s_]) (void)hipEventDestroy(h->ev[s_]); if (h->st[s_]) (void)hipStreamDestroy(h->st[s_]); }
+    if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+    if (h->g_factor) (void)hipGraphExecDestroy(h->g_factor);
+    if (h->g_solve) (void)hipGraphExecDestroy(h->g_solve);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -644,22 +883,7 @@ int gfs_refactor(gfs_handle* h) {
                                h->d_bnd, h->d_tri, h->band);
             const int nf = (int)h->fronts.size();
             hipLaunchKernelGGL(nd_pad_kernel, dim3(nf), dim3(64), 0, h->stream, h->d_fronts, h->d_tri, h->band);
-            for (int t = 0; t < nf; ++t) {
-                const Front& F = h->fronts[t];
-                for (int c : h->kids[t]) {
-                    const long long nbb = h->fronts[c].nblk_t - h->fronts[c].nblk_e;
-                    if (nbb > 0) hipLaunchKernelGGL(nd_extend_add_kernel, dim3((unsigned)(nbb * (nbb + 1) / 2)), dim3(256), 0, h->stream, h->d_fronts, c, h->d_pmap, h->d_tri, h->band);
-                }
-                double* band = h->band + (size_t)F.tile_off * NB2;
-                for (int k = 0; k < F.nblk_e; ++k) {
-                    const int ni = F.nblk_t - 1 - k;
-                    hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, h->stream, band, h->linv + (size_t)F.kbase * NB2, h->dval + (size_t)F.kbase * NB, h->d_tri, k, h->stat + 2 * F.kbase);
-                    if (ni > 0) {
-                        hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, h->stream, band, h->linv + (size_t)F.kbase * NB2, h->dval + (size_t)F.kbase * NB, h->wbuf, h->d_tri, k);
-                        hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, h->stream, band, h->wbuf, h->d_tri, k, ni);
-                    }
-                }
-            }
+            nd_run_captured(h, &h->g_factor, [&] { nd_sweep_up(h, nd_factor_front); });
         } else {
         hipLaunchKernelGGL(band_fill_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->newi, h->valK, h->band, h->rowoff, h->n, h->npad);
         for (long long k = 0; k < h->nblk; ++k) {

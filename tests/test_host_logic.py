@@ -109,6 +109,50 @@ def test_solver_library_exports_every_declared_symbol():
         assert rc != 0 and b"no HIP device" in L.gfs_last_error()
 
 
+def test_nested_dissection_symbolic_phase_and_reference_multifrontal_solve():
+    """goldfish_amd/_nd.py: the fronts of the nested-dissection order (what gfs_create_nd factors on the device) -- every control point
+    eliminated once, boundaries lie outside the subtree and inside the parent's front, sibling subtrees are not coupled -- and the dense
+    NumPy statement of the multifrontal factorisation on those fronts against a direct solve."""
+    import scipy.sparse as sp
+    from goldfish_amd import _nd
+    rng = np.random.default_rng(3)
+    ncp = 900
+    pts = rng.uniform(0, 1, (ncp, 3)) * [1.0, 0.7, 0.05]
+    adj = np.abs(pts[:, None, :2] - pts[None, :, :2]).max(-1) < 0.06
+    nb_lists = [np.flatnonzero(adj[a]) for a in range(ncp)]
+    nb_ptr = np.concatenate([[0], np.cumsum([len(x) for x in nb_lists])]).astype(np.int64)
+    nb = np.concatenate(nb_lists).astype(np.int32)
+    sym = _nd.nested_dissection(nb_ptr, nb, pts, leaf=40)
+    assert sym.nfronts > 8 and sorted(sym.elim) == list(range(ncp))
+    assert np.array_equal(sym.order[sym.elim], np.arange(ncp))
+    for t in range(sym.nfronts):
+        e = sym.elim[sym.elim_off[t]:sym.elim_off[t + 1]]
+        bd = sym.bnd[sym.bnd_off[t]:sym.bnd_off[t + 1]]
+        assert np.all(sym.front_of[e] == t) and np.all(np.diff(sym.order[bd]) > 0)
+        assert np.all(sym.order[bd] >= sym.elim_off[t + 1])                                   # outside the subtree
+        nbrs = np.unique(np.concatenate([nb_lists[a] for a in e])) if e.size else e
+        later = nbrs[sym.order[nbrs] >= sym.elim_off[t + 1]]
+        assert np.isin(later, bd).all()                                                      # every later neighbour is on the boundary
+        if sym.parent[t] >= 0:
+            pt = sym.parent[t]
+            assert pt > t
+            pf = np.concatenate([sym.elim[sym.elim_off[pt]:sym.elim_off[pt + 1]], sym.bnd[sym.bnd_off[pt]:sym.bnd_off[pt + 1]]])
+            assert np.isin(bd, pf).all()                                                     # extend-add target exists
+        else:
+            assert bd.size == 0
+    st = sym.stats()
+    assert st["eliminated_block_columns"] >= (3 * ncp + 63) // 64 and st["bytes"] > 0
+    # SPD block matrix on that pattern; the reference multifrontal solve is a direct solve
+    rows = np.repeat(np.arange(ncp), np.diff(nb_ptr))
+    B = rng.standard_normal((rows.size, 3, 3)) * 0.1
+    K = sp.bsr_matrix((B, nb, nb_ptr), shape=(3 * ncp, 3 * ncp)).tocsr()
+    K = (K + K.T) * 0.5 + sp.identity(3 * ncp) * 8.0
+    b = rng.standard_normal(3 * ncp)
+    x = _nd.multifrontal_reference_solve(sym, K, b)
+    xd = np.linalg.solve(K.toarray(), b)
+    assert np.abs(x - xd).max() < 1e-12 * np.abs(xd).max()
+
+
 def _lib_has_no_gpu():
     from goldfish_amd import _lib
     return _lib.lib().gf_device_count() == 0

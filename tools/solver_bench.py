@@ -27,9 +27,9 @@ for name, spec in cases:
     t = time.perf_counter(); S.refactor(); t_f = time.perf_counter() - t
     t = time.perf_counter(); x = S.solve(b); t_s = time.perf_counter() - t; rr, be = S.rel_residual, S.backward_error
     t = time.perf_counter(); lam = S.solve(g); t_a = time.perf_counter() - t; ra, bea = S.rel_residual, S.backward_error
-    line = (("%s [" + S.method + "]") + ": %d dofs, half bandwidth %d, factor storage %.2f GB; device: ordering + first factorisation %.3f s, re-factorisation %.4f s (%.1f TFLOP/s), Newton solve %.4f s "
-            "(residual %.1e, backward error %.1e), adjoint solve %.4f s (residual %.1e, backward error %.1e)"
-            % (name, A.ndof, info["half_bandwidth"], info["device_bytes"] / 1e9, t_first, t_f, info["factor_flops"] / t_f / 1e12, t_s, rr, be, t_a, ra, bea))
+    fmt = ("%s [" + S.method + "]: %d dofs, half bandwidth %d, factor storage %.2f GB; device: ordering + first factorisation %.3f s, re-factorisation %.4f s (%.1f TFLOP/s), "
+           "Newton solve %.4f s (residual %.1e, backward error %.1e), adjoint solve %.4f s (residual %.1e, backward error %.1e)")
+    line = fmt % (name, A.ndof, info["half_bandwidth"], info["device_bytes"] / 1e9, t_first, t_f, info["factor_flops"] / t_f / 1e12, t_s, rr, be, t_a, ra, bea)
     if host and A.ndof < 150000:
         K = D.csr(_lib.MAT_K).tocsc()
         t = time.perf_counter(); lu = spla.splu(K, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True)); t_h = time.perf_counter() - t
