@@ -102,7 +102,7 @@ def parent_positions(sym):
     return pmap
 
 
-ND_MIN_CP = int(os.environ.get("GF_SOLVER_ND_MIN_CP", "15000"))     # models with more control points factor by nested dissection (when coordinates are given)
+ND_MIN_CP = int(os.environ.get("GF_SOLVER_ND_MIN_CP", "5000"))     # models with more control points factor by nested dissection (when coordinates are given)
 
 
 class DeviceSolver:

@@ -135,6 +135,11 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
         }
     };
 
+#if defined(GF_STAMPS) && defined(GF_STAMPS_FINE)
+#define GF_OUTER_STAMP(slot) GF_STAMP((slot) < 2 ? (slot) : 7, tstamp)
+#else
+#define GF_OUTER_STAMP(slot) GF_STAMP(slot, tstamp)
+#endif
     unsigned long long tstamp = 0; (void)tstamp;
 #ifdef GF_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -156,18 +161,18 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
         }
         wave_lds_sync();
         const double* const tv = s_tv[buf];
-        GF_STAMP(0, tstamp);
+        GF_OUTER_STAMP(0);
 
         // ---- phase 1: three lanes per Gauss point: kinematics + pointwise closed forms -> s_im
         point_phase<P, WITHC>(x, kk, s_tu, tv, s_c, s_d, s_w, s_h, s_pc, s_wgu, s_wgv[buf], s_im);
 
-        GF_STAMP(1, tstamp);
+        GF_OUTER_STAMP(1);
         // ---- the next element's inputs are requested now (they land during the group loop) and parked in LDS behind it:
         //      vmcnt counts loads and stores in order, so a load right behind the flush stores would wait for all of them
-        GF_STAMP(2, tstamp);
+        GF_OUTER_STAMP(2);
         Fetch Fn; Fn.cp = double2{0.0, 0.0}; Fn.tv = 0.0; Fn.wv = 0.0;
         if (more) Fn = fetch(ev + 1, iv0n);
-        GF_STAMP(3, tstamp);
+        GF_OUTER_STAMP(3);
 
         // this lane's basis function in the current element: u index jub, v index = (slot - first row) mod 4
         const int jvb = (sb - iv0) & 3;
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
             const int gp = 4 * grp + kk, gpc = gp < NG ? gp : NG - 1, gu = gpc % P1, gv = gpc / P1;   // Gauss point of this lane's group
             const double* im = s_im[gpc];
             const double wq = gp < NG ? im[IM_WQ] : 0.0;        // padded Gauss-point slots contribute nothing
-            gauss_group<P, WITHC>(L, im, wq, s_tu, tv, gu, gv, jubc, jvc, bval, doK, doC, doH, has_bf, pf, ppd, accK, accC, accH, accB, accR);
+            gauss_group<P, WITHC>(L, im, wq, s_tu, tv, gu, gv, jubc, jvc, bval, doK, doC, doH, has_bf, pf, ppd, accK, accC, accH, accB, accR GF_GROUP_STAMP_ARGS);
         }
         if (has_bf && doC) {
 #pragma unroll
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
 #pragma unroll
                 for (int f = 0; f < 3; ++f) accC[3 * i + f] -= pf[i] * accB[f];
         }
-        GF_STAMP(4, tstamp);
+        GF_OUTER_STAMP(4);
 
         // ---- park the next element's inputs; residual of this element: sum the four Gauss-point groups (entry (local a, i)
         //      comes from lane 4 ju + ((iv0 + jv) & 3))
@@ -202,10 +207,10 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
             O.rblk[(size_t)e * ND + tid] = s_g[w] + s_g[48 + w] + s_g[96 + w] + s_g[144 + w];
         }
 
-        GF_STAMP(5, tstamp);
+        GF_OUTER_STAMP(5);
         // ---- store the pairs whose lower row leaves the window
         flush(iv0, iv0n);
-        GF_STAMP(6, tstamp);
+        GF_OUTER_STAMP(6);
     }
 #ifdef GF_STAMPS
     if ((blockIdx.x & 7) == 0 && tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[k], stamp_acc[k]);

@@ -147,17 +147,34 @@ struct RowLane {
         oJ0 = IM_JNV + (mr == 0 ? 0 : 2); oJ1 = IM_JNV + (mr == 1 ? 1 : 2);
         for (int s = 0; s < 6; ++s) oX[s] = tang ? IM_HMN + hmn_idx(r, s) : IM_DN + 6 * ir + s;
     }
+    // the lane-dependent entries of the record the expansion starts from: requested TOGETHER (and together with the caller's other loads) in front of a
+    // scheduling barrier -- one wave per SIMD has nobody to hide an LDS round trip behind, and left to itself the compiler issues these reads one by one,
+    // each followed by s_waitcnt lgkmcnt(0) and its first use (eight exposed round trips per Gauss-point group)
+    struct Pre { double gr, e2r, nir, bg0, bg1, bg2, pzr, jmof, jn0, jn1, ox[6]; };
+    __device__ __forceinline__ Pre load(const double* im) const {
+        Pre q;
+        q.gr = im[IM_G + rt]; q.e2r = im[oE2]; q.nir = im[IM_N + ir];
+        q.bg0 = im[IM_BG + rt]; q.bg1 = im[IM_BG + 6 + rt]; q.bg2 = im[IM_BG + 12 + rt];
+        q.pzr = im[IM_PZ + r]; q.jmof = im[IM_JMOF + kr]; q.jn0 = im[oJ0]; q.jn1 = im[oJ1];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) q.ox[s] = im[oX[s]];
+        return q;
+    }
     // row r of G (gR) and of Hc (hR, WITHC) at the Gauss point with record im; entry (m', j) at [3 m' + j]
     template <bool WITHC> __device__ __forceinline__ void expand(const double* im, double (&gR)[15], double (&hR)[15]) const {
-        const double gr = im[IM_G + rt], e0 = m0 * gr, e1 = m1 * gr, e2 = mt * im[oE2];
-        const double fnr = f3c * im[IM_N + ir];
-        const double b0 = mt * im[IM_BG + rt] + ck[0] * fnr, b1 = mt * im[IM_BG + 6 + rt] + ck[1] * fnr, b2 = mt * im[IM_BG + 12 + rt] + ck[2] * fnr;
-        const double pzr = im[IM_PZ + r], xfac = mt + (1.0 - mt) * im[IM_JMOF + kr];
-        const double jn[2] = {im[oJ0], im[oJ1]};
+        const Pre q = load(im);
+        expand<WITHC>(im, q, gR, hR);
+    }
+    template <bool WITHC> __device__ __forceinline__ void expand(const double* im, const Pre& q, double (&gR)[15], double (&hR)[15]) const {
+        const double gr = q.gr, e0 = m0 * gr, e1 = m1 * gr, e2 = mt * q.e2r;
+        const double fnr = f3c * q.nir;
+        const double b0 = mt * q.bg0 + ck[0] * fnr, b1 = mt * q.bg1 + ck[1] * fnr, b2 = mt * q.bg2 + ck[2] * fnr;
+        const double pzr = q.pzr, xfac = mt + (1.0 - mt) * q.jmof;
+        const double jn[2] = {q.jn0, q.jn1};
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
             const double g = e0 * im[IM_CEZ + s] + e1 * im[IM_CEZ + 6 + s] + e2 * im[IM_CEZ + 12 + s]
-                           + b0 * im[IM_CBG + s] + b1 * im[IM_CBG + 6 + s] + b2 * im[IM_CBG + 12 + s] - xfac * im[oX[s]] + dij[s % 3] * jn[s / 3];
+                           + b0 * im[IM_CBG + s] + b1 * im[IM_CBG + 6 + s] + b2 * im[IM_CBG + 12 + s] - xfac * q.ox[s] + dij[s % 3] * jn[s / 3];
             gR[s] = g;
             if constexpr (WITHC) {
                 const double zz = pzr * im[IM_JZJ + s] + e0 * im[IM_JDNV + s] + e1 * im[IM_JDNV + 6 + s] + e2 * im[IM_JDNV + 12 + s]
@@ -183,30 +200,49 @@ struct RowLane {
 // ---- one group of 4 Gauss points: the lane's Gauss point is 4 grp + kk (record im, weight wq = 0 on a padded slot), its basis
 //      function has the 1-D indices (ju, jv) in the element (bval = 0: the lane holds no basis function: zero row / column).
 //      Adds to the MFMA accumulators K (6 tiles, i <= j), dR/dCP (9), dR/dh (3), the body-force tiles B (3) and the residual sums.
+// diagnostic build (-DGF_STAMPS -DGF_STAMPS_FINE, tools/stamps.py): the sections of the group step in stamp slots 2 .. 6
+#if defined(GF_STAMPS) && defined(GF_STAMPS_FINE)
+#define GF_GROUP_STAMP_PARAMS , unsigned long long* stamp_acc, unsigned long long& tstamp
+#define GF_GROUP_STAMP_ARGS , stamp_acc, tstamp
+#define GF_GROUP_STAMP(slot) GF_STAMP(slot, tstamp)
+#else
+#define GF_GROUP_STAMP_PARAMS
+#define GF_GROUP_STAMP_ARGS
+#define GF_GROUP_STAMP(slot) do { } while (0)
+#endif
 template <int P, bool WITHC>
 __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, double wq, const double* tu, const double* tv, int gu, int gv,
                                             int ju, int jv, double bval, bool doK, bool doC, bool doH, bool has_bf, const double* pf, const double* ppd,
-                                            gf_d4 (&accK)[6], gf_d4 (&accC)[9], gf_d4 (&accH)[3], gf_d4 (&accB)[3], double (&accR)[3]) {
+                                            gf_d4 (&accK)[6], gf_d4 (&accC)[9], gf_d4 (&accH)[3], gf_d4 (&accB)[3], double (&accR)[3] GF_GROUP_STAMP_PARAMS) {
     constexpr int P1 = P + 1;
+    // -- every load the basis function and the row expansion start from, in one batch (RowLane::load)
+    const double u0 = tu[(gu * 3 + 0) * P1 + ju], u1 = tu[(gu * 3 + 1) * P1 + ju], u2 = tu[(gu * 3 + 2) * P1 + ju];
+    const double v0 = tv[(gv * 3 + 0) * P1 + jv], v1 = tv[(gv * 3 + 1) * P1 + jv], v2 = tv[(gv * 3 + 2) * P1 + jv];
+    const double Wl[6] = {im[IM_W], im[IM_W + 1], im[IM_W + 2], im[IM_W + 3], im[IM_W + 4], im[IM_W + 5]};
+    RowLane::Pre pre;
+    if (doK || doC) pre = L.load(im);
+#ifndef GF_NO_LOAD_BATCH
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // -- basis function of the lane at this Gauss point (registers)
     double phi[5], R0, n0;
     {
-        const double u0 = tu[(gu * 3 + 0) * P1 + ju], u1 = tu[(gu * 3 + 1) * P1 + ju], u2 = tu[(gu * 3 + 2) * P1 + ju];
-        const double v0 = tv[(gv * 3 + 0) * P1 + jv], v1 = tv[(gv * 3 + 1) * P1 + jv], v2 = tv[(gv * 3 + 2) * P1 + jv];
         const double Nb[6] = {u0 * v0, u1 * v0, u0 * v1, u2 * v0, u0 * v2, u1 * v1};
         double R[6];
-        rationalize6(Nb, im + IM_W, R);
+        rationalize6(Nb, Wl, R);
         for (int k = 0; k < 5; ++k) phi[k] = bval * R[k + 1];
         R0 = bval * R[0]; n0 = bval * Nb[0];
     }
+    GF_GROUP_STAMP(2);
     // -- row r of G and Hc at this Gauss point; entry (m', j) at [3 m' + j]
     double gR[15], hR[15];
     for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
     if (doK || doC) {
-        L.template expand<WITHC>(im, gR, hR);
+        L.template expand<WITHC>(im, pre, gR, hR);
         dpp_source_fence(gR);
         if constexpr (WITHC) dpp_source_fence(hR);
     }
+    GF_GROUP_STAMP(3);
     // -- residual and dR/dh prefactors of the lane's basis function at this Gauss point
     {
         const double ls = has_bf ? load_scalar(im, ppd) : 0.0;
@@ -235,6 +271,7 @@ __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, 
     // The B operands of all components of one m are formed as independent FMA chains before their MFMAs are issued (a single
     // chain -> MFMA -> chain sequence serialises on the shared FP64 pipe).
     constexpr int QI[6] = {0, 0, 0, 1, 1, 2}, QJ[6] = {0, 1, 2, 1, 2, 2};
+    GF_GROUP_STAMP(4);
     if (doK) {
         static_for<5>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
@@ -245,6 +282,7 @@ __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, 
             for (int q = 0; q < 6; ++q) accK[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], tq[q], accK[q], 0, 0, 0);
         });
     }
+    GF_GROUP_STAMP(5);
     if (doC) {
         static_for<5>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
@@ -263,6 +301,7 @@ __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, 
             }
         }
     }
+    GF_GROUP_STAMP(6);
 }
 
 }  // namespace gf

@@ -80,7 +80,7 @@ __global__ void band_fill_kernel(long long ncp, const long long* __restrict__ nb
 }
 
 // diagonal tile of block column k: L D L^T (lower, no pivoting) and the inverse of the unit lower factor
-__global__ __launch_bounds__(256) void diag_kernel(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
+__device__ __forceinline__ void diag_body(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
     __shared__ double s[NB * (NB + 1)], v[NB * (NB + 1)];
     constexpr int S1 = NB + 1;
     const int tid = threadIdx.x;
@@ -128,11 +128,14 @@ __global__ __launch_bounds__(256) void diag_kernel(double* __restrict__ band, do
     double* Li = linv + (size_t)k * NB2;
     for (int q = tid; q < NB2; q += 256) Li[q] = s[(q >> 6) * S1 + (q & 63)];
 }
+__global__ __launch_bounds__(256) void diag_kernel(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
+    diag_body(band, linv, dval, rowoff, k, stat);
+}
 
 // panel tile i = k + 1 + blockIdx.x: W = A_ik L_kk^-T (to wbuf), L_ik = W D_k^-1 (in place)
-__global__ __launch_bounds__(256) void panel_kernel(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k) {
+__device__ __forceinline__ void panel_body(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, int g) {
     __shared__ __attribute__((aligned(16))) double sA[NB * LS], sB[NB * LS];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double* A = band + (size_t)(rowoff[k + 1 + g] + (g + 1)) * NB2;
     load_tile(A, sA, tid); load_tile(linv + (size_t)k * NB2, sB, tid);
     __syncthreads();
@@ -150,17 +153,21 @@ __global__ __launch_bounds__(256) void panel_kernel(double* __restrict__ band, c
         }
     }
 }
+__global__ __launch_bounds__(256) void panel_kernel(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k) {
+    panel_body(band, linv, dval, wbuf, rowoff, k, (int)blockIdx.x);
+}
 
 // trailing tile (i, j), k < j <= i: A_ij -= W_ik L_jk^T
-__global__ __launch_bounds__(256) void update_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, int ni) {
+// linear index -> (gi >= gj) over a lower triangle of tiles
+__device__ __forceinline__ void tri_index(int bidx, int& gi, int& gj) {
+    gi = (int)((sqrt(8.0 * bidx + 1.0) - 1.0) * 0.5);
+    while ((gi + 1) * (gi + 2) / 2 <= bidx) ++gi;
+    while (gi * (gi + 1) / 2 > bidx) --gi;
+    gj = bidx - gi * (gi + 1) / 2;
+}
+__device__ __forceinline__ void update_tile(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, int gi, int gj) {
     __shared__ __attribute__((aligned(16))) double sA[NB * LS], sB[NB * LS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // linear index -> (gi >= gj) over the lower triangle of the ni x ni tile block
-    int gi = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
-    while ((gi + 1) * (gi + 2) / 2 <= (int)blockIdx.x) ++gi;
-    while (gi * (gi + 1) / 2 > (int)blockIdx.x) --gi;
-    const int gj = blockIdx.x - gi * (gi + 1) / 2;
-    if (gi >= ni) return;
     const int i = k + 1 + gi, j = k + 1 + gj;
     load_tile(wbuf + (size_t)gi * NB2, sA, tid);
     load_tile(band + (size_t)(rowoff[j] + (gj + 1)) * NB2, sB, tid);
@@ -172,6 +179,59 @@ __global__ __launch_bounds__(256) void update_kernel(double* __restrict__ band, 
         for (int rg = 0; rg < 4; ++rg) acc[nj][rg] = C[(16 * wave + 4 * rg + (lane >> 4)) * NB + 16 * nj + (lane & 15)];
     __syncthreads();
     tile_abt(sA, sB, acc, wave, lane, -1.0);
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) C[(16 * wave + 4 * rg + (lane >> 4)) * NB + 16 * nj + (lane & 15)] = acc[nj][rg];
+}
+__global__ __launch_bounds__(256) void update_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, int ni) {
+    int gi, gj; tri_index((int)blockIdx.x, gi, gj);
+    if (gi >= ni) return;
+    update_tile(band, wbuf, rowoff, k, gi, gj);
+}
+// the same update restricted to the trailing columns k + 1 .. k + nin (the rest of a panel group): blockIdx = (row gi, column gj < nin)
+__global__ __launch_bounds__(256) void update_narrow_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k) {
+    if (blockIdx.x < blockIdx.y) return;
+    update_tile(band, wbuf, rowoff, k, (int)blockIdx.x, (int)blockIdx.y);
+}
+// trailing update behind a GROUP of w block columns k0 .. k0 + w - 1 (all factored, panels W_c in wbuf + c wstride tiles): tile (i, j), i >= j >= k0 + w,
+//     A_ij -= sum_c W_i,k0+c L_j,k0+c^T
+// one read-modify-write of the target tile per group instead of per column (the single-column update moves 64 KB of HBM per 64^3 product: bandwidth bound);
+// the next column's operand tiles are requested into registers before the MFMAs of the current one.
+__device__ __forceinline__ void fetch_tile(const double* __restrict__ g, double2 (&r)[8], int tid) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[q] = *reinterpret_cast<const double2*>(g + 2 * (tid + 256 * q));
+}
+__device__ __forceinline__ void park_tile(const double2 (&r)[8], double* __restrict__ s, int tid) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int idx = 2 * (tid + 256 * q), rr = idx >> 6, c = idx & 63; s[rr * LS + c] = r[q].x; s[rr * LS + c + 1] = r[q].y; }
+}
+__global__ __launch_bounds__(256) void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow) {
+    __shared__ __attribute__((aligned(16))) double sA[NB * LS], sB[NB * LS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int gi, gj; tri_index((int)blockIdx.x, gi, gj);
+    if (gi >= nrow) return;
+    const int i = k0 + w + gi, j = k0 + w + gj;
+    double* C = band + (size_t)(rowoff[i] + (gi - gj)) * NB2;
+    double2 ra[8], rb[8];
+    fetch_tile(wbuf + (size_t)(i - (k0 + 1)) * NB2, ra, tid);
+    fetch_tile(band + (size_t)(rowoff[j] + (j - k0)) * NB2, rb, tid);
+    d4 acc[4];
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) acc[nj][rg] = C[(16 * wave + 4 * rg + (lane >> 4)) * NB + 16 * nj + (lane & 15)];
+    for (int c = 0; c < w; ++c) {
+        park_tile(ra, sA, tid); park_tile(rb, sB, tid);
+        __syncthreads();
+        if (c + 1 < w) {
+            const int k = k0 + c + 1;
+            fetch_tile(wbuf + (size_t)((c + 1) * wstride + (i - (k + 1))) * NB2, ra, tid);
+            fetch_tile(band + (size_t)(rowoff[j] + (j - k)) * NB2, rb, tid);
+        }
+        tile_abt(sA, sB, acc, wave, lane, -1.0);
+        __syncthreads();
+    }
 #pragma unroll
     for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
@@ -342,6 +402,51 @@ __global__ __launch_bounds__(256) void nd_extend_add_kernel(const Front* __restr
         arena[nd_entry(Fp, tri, R, C)] += src[q];
     }
 }
+// ---- level-batched factorisation of the small fronts: the fronts of one tree height are independent, so block column k of ALL of them is one diag / panel /
+//      update launch (blockIdx.y = front of the level's list, sorted by eliminated block columns so that the fronts that still have a column k are a prefix;
+//      blockIdx.x beyond a front's own panel / trailing block exits) -- the diagonal tile's serial chain is paid per (height, k) instead of per (front, k).
+__global__ __launch_bounds__(256) void nd_diag_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ tri, double* __restrict__ arena,
+                                                            double* __restrict__ linv, double* __restrict__ dval, double* __restrict__ stat, int k) {
+    const Front F = fronts[list[blockIdx.x]];
+    diag_body(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, tri, k, stat + 2 * F.kbase);
+}
+__global__ __launch_bounds__(256) void nd_panel_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs, const long long* __restrict__ tri,
+                                                             double* __restrict__ arena, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, int k) {
+    const Front F = fronts[list[blockIdx.y]];
+    if ((int)blockIdx.x >= F.nblk_t - 1 - k) return;
+    panel_body(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, wbuf + (size_t)wofs[blockIdx.y] * NB2, tri, k, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(256) void nd_update_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs, const long long* __restrict__ tri,
+                                                              double* __restrict__ arena, const double* __restrict__ wbuf, int k) {
+    const Front F = fronts[list[blockIdx.y]];
+    const int ni = F.nblk_t - 1 - k;
+    if ((long long)blockIdx.x >= (long long)ni * (ni + 1) / 2) return;
+    int gi, gj; tri_index((int)blockIdx.x, gi, gj);
+    update_tile(arena + (size_t)F.tile_off * NB2, wbuf + (size_t)wofs[blockIdx.y] * NB2, tri, k, gi, gj);
+}
+// Schur complements of a list of children (no two of the same parent in one launch: one writer per entry) added into their parents
+__global__ __launch_bounds__(256) void nd_extend_add_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const int* __restrict__ pmap, const long long* __restrict__ tri,
+                                                                  double* __restrict__ arena) {
+    const int c = list[blockIdx.y];
+    const Front Fc = fronts[c]; const Front Fp = fronts[Fc.parent];
+    const long long nbb = Fc.nblk_t - Fc.nblk_e;
+    if ((long long)blockIdx.x >= nbb * (nbb + 1) / 2) return;
+    int gi = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((gi + 1) * (gi + 2) / 2 <= (int)blockIdx.x) ++gi;
+    while (gi * (gi + 1) / 2 > (int)blockIdx.x) --gi;
+    const int gj = blockIdx.x - gi * (gi + 1) / 2;
+    const int I = Fc.nblk_e + gi, J = Fc.nblk_e + gj;
+    const double* src = arena + (size_t)(Fc.tile_off + tri[I] + (I - J)) * NB2;
+    const int nbd = 3 * Fc.nb_cp;
+    for (int q = threadIdx.x; q < NB2; q += 256) {
+        const int rr = q >> 6, cc = q & 63;
+        const int rl = 64 * gi + rr, cl = 64 * gj + cc;
+        if (rl >= nbd || cl >= nbd || rl < cl) continue;
+        const int pr = pmap[Fc.bnd_off + rl / 3], pc = pmap[Fc.bnd_off + cl / 3];
+        const int R = nd_dofpos(Fp, pr, rl % 3), C = nd_dofpos(Fp, pc, cl % 3);
+        arena[nd_entry(Fp, tri, R, C)] += src[q];
+    }
+}
 // front-local right-hand side: the eliminated dofs from the global vector (original numbering), zeros on the padding and the boundary part
 __global__ void nd_gather_rhs_kernel(Front F, const int* __restrict__ elim, const double* __restrict__ b, double* __restrict__ w) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -508,6 +613,11 @@ struct gfs_handle {
     static constexpr int FUSE_MAX_BLK = 96;  // 64 x 96 doubles = 48 KB of LDS for the front-local vector
     struct Level { int off_small, n_small, max_blk; std::vector<int> big; };
     std::vector<Level> levels; int *d_lvl_list = nullptr, *d_kid_off = nullptr, *d_kid = nullptr;
+    // factorisation by tree height: extend-add rounds (the r-th children of all fronts of the height), the small fronts column by column in batched launches,
+    // the large fronts per block column on the side streams
+    struct Round { int off, n; long long max_tiles; };
+    struct FLevel { int off = 0, n = 0; std::vector<int> nk, max_ni; std::vector<Round> rounds; std::vector<int> big; };
+    std::vector<FLevel> flevels; int *d_flist = nullptr, *d_ealist = nullptr; long long* d_fwofs = nullptr; double* bwbuf = nullptr; int batch_blk = 96, panel_w = 4;
     template <class Tp> Tp* dalloc(size_t cnt) {
         void* p = nullptr; const size_t nb_ = (cnt ? cnt : 1) * sizeof(Tp);
         HIPCHK(hipMalloc(&p, nb_)); allocs.push_back(p); bytes += (long long)nb_; return (Tp*)p;
@@ -531,20 +641,28 @@ __global__ void nd_out_kernel(long long n, const double* __restrict__ src, doubl
     if (t < n) dst[t] = add ? dst[t] + src[t] : src[t];
 }
 // ---- multifrontal mode: work of one front on a stream with that stream's scratch (index NS = the main stream's)
-static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si) {
+static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool extend_add = true) {
     const Front& F = h->fronts[t];
-    for (int c : h->kids[t]) {
+    if (extend_add) for (int c : h->kids[t]) {
         const long long nbb = h->fronts[c].nblk_t - h->fronts[c].nblk_e;
         if (nbb > 0) hipLaunchKernelGGL(nd_extend_add_kernel, dim3((unsigned)(nbb * (nbb + 1) / 2)), dim3(256), 0, st, h->d_fronts, c, h->d_pmap, h->d_tri, h->band);
     }
     double* band = h->band + (size_t)F.tile_off * NB2;
-    for (int k = 0; k < F.nblk_e; ++k) {
-        const int ni = F.nblk_t - 1 - k;
-        hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, h->dval + (size_t)F.kbase * NB, h->d_tri, k, h->stat + 2 * F.kbase);
-        if (ni > 0) {
-            hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, h->dval + (size_t)F.kbase * NB, h->s_wbuf[si], h->d_tri, k);
-            hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, st, band, h->s_wbuf[si], h->d_tri, k, ni);
+    double* linv = h->linv + (size_t)F.kbase * NB2; double* dval = h->dval + (size_t)F.kbase * NB;
+    const int WP = std::max(h->panel_w, 1); const long long wstride = h->max_blk;
+    for (int k0 = 0; k0 < F.nblk_e; k0 += WP) {                       // groups of WP block columns: one wide trailing update per group
+        const int w = std::min(WP, F.nblk_e - k0);
+        for (int c = 0; c < w; ++c) {
+            const int k = k0 + c, ni = F.nblk_t - 1 - k, nin = k0 + w - 1 - k;
+            double* wb = h->s_wbuf[si] + (size_t)c * wstride * NB2;
+            hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, st, band, linv, dval, h->d_tri, k, h->stat + 2 * F.kbase);
+            if (ni > 0) hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, st, band, linv, dval, wb, h->d_tri, k);
+            if (w == 1 && ni > 0) hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, st, band, wb, h->d_tri, k, ni);
+            else if (nin > 0) hipLaunchKernelGGL(update_narrow_kernel, dim3(ni, nin), dim3(256), 0, st, band, wb, h->d_tri, k);
         }
+        const int nrow = F.nblk_t - (k0 + w);
+        if (w > 1 && nrow > 0)
+            hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, h->s_wbuf[si], wstride, h->d_tri, k0, w, nrow);
     }
 }
 static void nd_forward_front(gfs_handle* h, int t, hipStream_t st, int si) {
@@ -595,6 +713,31 @@ template <class Fn> static void nd_sweep_down(gfs_handle* h, Fn&& fn) {
         for (auto it = h->sub[s].rbegin(); it != h->sub[s].rend(); ++it) fn(h, *it, h->st[s], s);
         HIPCHK(hipEventRecord(h->ev[s], h->st[s]));
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev[s], 0));
+    }
+}
+// factorisation sweep by tree height
+static void nd_factor_levels(gfs_handle* h) {
+    constexpr int NS = gfs_handle::NS;
+    for (const auto& L : h->flevels) {
+        for (const auto& R : L.rounds)
+            hipLaunchKernelGGL(nd_extend_add_batch_kernel, dim3((unsigned)R.max_tiles, (unsigned)R.n), dim3(256), 0, h->stream, h->d_fronts, h->d_ealist + R.off, h->d_pmap, h->d_tri, h->band);
+        int used = 0;
+        if (!L.big.empty()) {
+            HIPCHK(hipEventRecord(h->ev_main, h->stream));
+            used = std::min<int>(NS, (int)L.big.size());
+            for (int s = 0; s < used; ++s) HIPCHK(hipStreamWaitEvent(h->st[s], h->ev_main, 0));
+            for (size_t i = 0; i < L.big.size(); ++i) { const int s = (int)(i % NS); nd_factor_front(h, L.big[i], h->st[s], s, false); }
+        }
+        for (size_t k = 0; k < L.nk.size(); ++k) {
+            const int nk = L.nk[k], mni = L.max_ni[k];
+            hipLaunchKernelGGL(nd_diag_batch_kernel, dim3(nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_tri, h->band, h->linv, h->dval, h->stat, (int)k);
+            if (mni > 0) {
+                hipLaunchKernelGGL(nd_panel_batch_kernel, dim3(mni, nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off, h->d_tri, h->band, h->linv, h->dval, h->bwbuf, (int)k);
+                hipLaunchKernelGGL(nd_update_batch_kernel, dim3((unsigned)((long long)mni * (mni + 1) / 2), nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off, h->d_tri,
+                                   h->band, h->bwbuf, (int)k);
+            }
+        }
+        for (int s = 0; s < used; ++s) { HIPCHK(hipEventRecord(h->ev[s], h->st[s])); HIPCHK(hipStreamWaitEvent(h->stream, h->ev[s], 0)); }
     }
 }
 // run `body` (kernel launches, event record / wait on h->stream and the side streams) through a graph captured at the first call
@@ -790,6 +933,7 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
         h->band = h->dalloc<double>((size_t)tiles * NB2);
         h->linv = h->dalloc<double>((size_t)kb * NB2);
         h->dval = h->dalloc<double>((size_t)kb * NB); h->stat = h->dalloc<double>((size_t)2 * kb);
+        if (const char* e = std::getenv("GF_SOLVER_PANEL_W")) h->panel_w = std::max(1, std::min(8, std::atoi(e)));
         {   // independent subtrees for the side streams: split the largest subtree (by factorisation work) until there are enough of them
             constexpr int NS = gfs_handle::NS;
             std::vector<double> work(nfronts, 0.0); std::vector<int> cnt(nfronts, 1);
@@ -825,7 +969,7 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
             HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
             const size_t fl_ = (size_t)maxb * NB;
             for (int s_ = 0; s_ <= NS; ++s_) {
-                h->s_wbuf[s_] = h->dalloc<double>((size_t)std::max(maxb, 1) * NB2);
+                h->s_wbuf[s_] = h->dalloc<double>((size_t)std::max(maxb, 1) * NB2 * std::max(h->panel_w, 1));
                 h->s_b[s_] = h->dalloc<double>(fl_); h->s_y[s_] = h->dalloc<double>(fl_); h->s_z[s_] = h->dalloc<double>(fl_); h->s_x[s_] = h->dalloc<double>(fl_);
             }
             h->wbuf = h->s_wbuf[NS];
@@ -845,6 +989,45 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
             if (kflat.empty()) kflat.push_back(0);
             if (flat.empty()) flat.push_back(0);
             h->d_lvl_list = h->up(flat.data(), flat.size()); h->d_kid_off = h->up(koff.data(), koff.size()); h->d_kid = h->up(kflat.data(), kflat.size());
+        }
+        {   // factorisation levels (GF_SOLVER_BATCH_BLK: fronts of at most that many blocks are factored in batched launches per tree height; 0: per front on streams)
+            if (const char* e = std::getenv("GF_SOLVER_BATCH_BLK")) h->batch_blk = std::atoi(e);
+            std::vector<int> height(nfronts, 0);
+            for (int64_t t = 0; t < nfronts; ++t) for (int c : h->kids[t]) height[t] = std::max(height[t], height[c] + 1);
+            int hmax = 0; for (int64_t t = 0; t < nfronts; ++t) hmax = std::max(hmax, height[t]);
+            h->flevels.assign(hmax + 1, {});
+            std::vector<std::vector<int>> small(hmax + 1), all(hmax + 1);
+            for (int64_t t = 0; t < nfronts; ++t) {
+                all[height[t]].push_back((int)t);
+                (h->fronts[t].nblk_t <= h->batch_blk ? small[height[t]] : h->flevels[height[t]].big).push_back((int)t);
+            }
+            std::vector<int> flist, ealist; std::vector<long long> wofs; long long wmax = 1;
+            for (int l = 0; l <= hmax; ++l) {
+                auto& L = h->flevels[l];
+                std::stable_sort(small[l].begin(), small[l].end(), [&](int x, int y) { return h->fronts[x].nblk_e > h->fronts[y].nblk_e; });
+                L.off = (int)flist.size(); L.n = (int)small[l].size();
+                long long w = 0;
+                for (int t : small[l]) { flist.push_back(t); wofs.push_back(w); w += std::max(h->fronts[t].nblk_t - 1, 1); }
+                wmax = std::max(wmax, w);
+                const int kmax = L.n ? h->fronts[small[l][0]].nblk_e : 0;
+                L.nk.assign(kmax, 0); L.max_ni.assign(kmax, 0);
+                for (int t : small[l]) for (int k = 0; k < h->fronts[t].nblk_e; ++k) { ++L.nk[k]; L.max_ni[k] = std::max(L.max_ni[k], h->fronts[t].nblk_t - 1 - k); }
+                // extend-add rounds: round r = the r-th child (with a boundary) of every front of this height
+                size_t maxkids = 0; for (int t : all[l]) maxkids = std::max(maxkids, h->kids[t].size());
+                for (size_t r = 0; r < maxkids; ++r) {
+                    gfs_handle::Round R{(int)ealist.size(), 0, 0};
+                    for (int t : all[l]) if (r < h->kids[t].size()) {
+                        const int c = h->kids[t][r]; const long long nbb = h->fronts[c].nblk_t - h->fronts[c].nblk_e;
+                        if (nbb <= 0) continue;
+                        ealist.push_back(c); ++R.n; R.max_tiles = std::max(R.max_tiles, nbb * (nbb + 1) / 2);
+                    }
+                    if (R.n > 0) L.rounds.push_back(R);
+                }
+            }
+            if (flist.empty()) { flist.push_back(0); wofs.push_back(0); }
+            if (ealist.empty()) ealist.push_back(0);
+            h->d_flist = h->up(flist.data(), flist.size()); h->d_fwofs = h->up(wofs.data(), wofs.size()); h->d_ealist = h->up(ealist.data(), ealist.size());
+            h->bwbuf = h->dalloc<double>((size_t)wmax * NB2);
         }
         h->fbnd = h->dalloc<double>((size_t)std::max<int64_t>(3 * nbnd, 1));
         h->gy = h->dalloc<double>(h->n); h->gb = h->dalloc<double>(h->n); h->gx = h->dalloc<double>(h->n);
@@ -883,7 +1066,8 @@ int gfs_refactor(gfs_handle* h) {
                                h->d_bnd, h->d_tri, h->band);
             const int nf = (int)h->fronts.size();
             hipLaunchKernelGGL(nd_pad_kernel, dim3(nf), dim3(64), 0, h->stream, h->d_fronts, h->d_tri, h->band);
-            nd_run_captured(h, &h->g_factor, [&] { nd_sweep_up(h, nd_factor_front); });
+            if (h->batch_blk > 0) nd_run_captured(h, &h->g_factor, [&] { nd_factor_levels(h); });
+            else nd_run_captured(h, &h->g_factor, [&] { nd_sweep_up(h, [](gfs_handle* hh, int t, hipStream_t st, int si) { nd_factor_front(hh, t, st, si); }); });
         } else {
         hipLaunchKernelGGL(band_fill_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->newi, h->valK, h->band, h->rowoff, h->n, h->npad);
         for (long long k = 0; k < h->nblk; ++k) {

@@ -19,6 +19,8 @@ rec = D.assembly_path == 4
 nw = (D.n_elements / 8.0) if rec else (1 if mfma else 2) * ((D.n_elements + 31) // 32)      # 1 in 32 elements sampled (row-record kernel: 1 in 8 items; per element)
 if P == 4 and mfma:
     names = ["phase0 load", "phase1 pointwise (one lane per Gauss point)", "basis of both tiles at the Gauss point", "row expansion (per pass)", "rz / rh + dR/dh MFMAs", "K: T formation + MFMAs", "dR/dCP: T formation + MFMAs", "element-block stores"]
+elif rec and os.environ.get("GF_STAMPS_FINE"):       # library built with -DGF_STAMPS -DGF_STAMPS_FINE: the sections of the shared group step
+    names = ["ring -> staging", "phase1 pointwise", "group: loads + basis function", "group: row expansion", "group: residual / dR/dh prefactors", "group: K (T formation + MFMAs)", "group: dR/dCP (T formation + MFMAs)", "fetch, park, residual, record stores"]
 elif rec:
     names = ["ring -> staging", "phase1 pointwise", "-", "fetch issue (next element)", "group loop (expansion, T, MFMA)", "park + residual", "record stores", "-"]
 elif mfma:
