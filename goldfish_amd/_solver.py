@@ -14,7 +14,8 @@ from scipy.sparse.csgraph import reverse_cuthill_mckee
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgoldfish_solver.so")
-EXPORTS = ["gfs_last_error", "gfs_create", "gfs_create_nd", "gfs_destroy", "gfs_refactor", "gfs_solve", "gfs_solve_dev", "gfs_info"]
+EXPORTS = ["gfs_last_error", "gfs_create", "gfs_create_nd", "gfs_destroy", "gfs_refactor", "gfs_solve", "gfs_solve_dev", "gfs_set_general", "gfs_solve_transposed",
+           "gfs_solve_transposed_dev", "gfs_info"]
 _L = None
 
 
@@ -33,6 +34,9 @@ def lib():
         L.gfs_refactor.argtypes = [vp]
         L.gfs_solve.argtypes = [vp, dp, dp, C.c_int, dp]
         L.gfs_solve_dev.argtypes = [vp, vp, vp, C.c_int, dp]
+        L.gfs_set_general.argtypes = [vp, C.c_int]
+        L.gfs_solve_transposed.argtypes = [vp, dp, dp, C.c_int, dp]
+        L.gfs_solve_transposed_dev.argtypes = [vp, vp, vp, C.c_int, dp]
         L.gfs_info.argtypes = [vp, dp]
         _L = L
     return _L
@@ -106,13 +110,16 @@ ND_MIN_CP = int(os.environ.get("GF_SOLVER_ND_MIN_CP", "5000"))     # models with
 
 
 class DeviceSolver:
-    """K x = b (= K^T x = b: K is symmetric) with the K of a goldfish_amd._lib.DeviceModel; factors resident in HBM.
+    """K x = b and K^T x = b with the K of a goldfish_amd._lib.DeviceModel; factors resident in HBM.  ``general`` (a K that is not symmetric: the
+    load stiffness of a follower pressure): the symmetric part is factored and preconditions the refinement against K / K^T itself
+    (gfs_set_general); ``max_refine`` then defaults to 15 steps instead of 3.
     ``method``: "skyline" (block skyline after RCM: small and medium models), "nd" (nested-dissection multifrontal: goldfish_amd/_nd.py +
     gfs_create_nd; needs the control points' coordinates), "auto": nd above ND_MIN_CP control points."""
 
-    def __init__(self, dev_model, max_refine=3, coords=None, method="auto", leaf=256):
+    def __init__(self, dev_model, max_refine=None, coords=None, method="auto", leaf=256, general=False):
         from . import _lib
-        self.D, self.max_refine = dev_model, max_refine
+        self.general = bool(general)
+        self.D, self.max_refine = dev_model, (15 if general else 3) if max_refine is None else max_refine
         rowptr, col = dev_model.pattern(_lib.MAT_K)
         self.nb_ptr, self.nb = control_point_graph(rowptr, col)
         del rowptr, col
@@ -140,6 +147,8 @@ class DeviceSolver:
             raise RuntimeError(lib().gfs_last_error().decode())
         self.h = h
         self.rel_residual = self.backward_error = None
+        if self.general and lib().gfs_set_general(self.h, 1):
+            raise RuntimeError(lib().gfs_last_error().decode())
         self.refactor()                                       # numeric factors of the current K
 
     def close(self):
@@ -155,13 +164,14 @@ class DeviceSolver:
         if lib().gfs_refactor(self.h):
             raise RuntimeError(lib().gfs_last_error().decode())
 
-    def solve(self, b):
+    def solve(self, b, transpose=False):
         b = np.ascontiguousarray(b, float)
         if b.size != self.n:
             raise ValueError("DeviceSolver.solve: expected %d values, got %d" % (self.n, b.size))
         x, rr = np.empty(self.n), C.c_double(0.0)
         dp = C.POINTER(C.c_double)
-        if lib().gfs_solve(self.h, b.ctypes.data_as(dp), x.ctypes.data_as(dp), int(self.max_refine), C.byref(rr)):
+        fn = lib().gfs_solve_transposed if transpose else lib().gfs_solve
+        if fn(self.h, b.ctypes.data_as(dp), x.ctypes.data_as(dp), int(self.max_refine), C.byref(rr)):
             raise RuntimeError(lib().gfs_last_error().decode())
         self.rel_residual = rr.value
         self.backward_error = self.info()["backward_error"]

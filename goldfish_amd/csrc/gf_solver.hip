@@ -55,7 +55,16 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ g, double* 
 }
 
 // K (block CSR of libgoldfish_hip, original numbering) -> lower block band in the factorisation order; identity on the padding
-__global__ void band_fill_kernel(long long ncp, const long long* __restrict__ nb_ptr, const int* __restrict__ nb, const int* __restrict__ newi,
+// value of entry ((a, i), (b, j)), b = nb[ptr + k], for the factorisation: K itself, or -- general mode (rev != null: K need not be symmetric) -- its
+// symmetric part (K + K^T) / 2, the transposed entry found through rev[ptr + k] = position of a in b's neighbour list
+__device__ __forceinline__ double fact_value(const double* __restrict__ valK, const long long* __restrict__ nb_ptr, const int* __restrict__ rev, long long ptr, long long deg,
+                                             long long k, int b, int i, int j) {
+    const double v = valK[9 * ptr + (long long)i * 3 * deg + 3 * k + j];
+    if (!rev) return v;
+    const long long pb = nb_ptr[b], db = nb_ptr[b + 1] - pb;
+    return 0.5 * (v + valK[9 * pb + (long long)j * 3 * db + 3 * (long long)rev[ptr + k] + i]);
+}
+__global__ void band_fill_kernel(long long ncp, const long long* __restrict__ nb_ptr, const int* __restrict__ nb, const int* __restrict__ newi, const int* __restrict__ rev,
                                  const double* __restrict__ valK, double* __restrict__ band, const long long* __restrict__ rowoff, long long n, long long npad) {
     const long long a = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -63,7 +72,8 @@ __global__ void band_fill_kernel(long long ncp, const long long* __restrict__ nb
         const long long ptr = nb_ptr[a], deg = nb_ptr[a + 1] - ptr;
         const long long pa = newi[a];
         for (long long k = lane; k < deg; k += 64) {
-            const long long pb = newi[nb[ptr + k]];
+            const int bcp = nb[ptr + k];
+            const long long pb = newi[bcp];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -71,7 +81,7 @@ __global__ void band_fill_kernel(long long ncp, const long long* __restrict__ nb
                     const long long r = 3 * pa + i, c = 3 * pb + j;
                     if (r < c) continue;
                     const long long I = r >> 6, d = I - (c >> 6);
-                    band[(size_t)(rowoff[I] + d) * NB2 + (r & 63) * NB + (c & 63)] = valK[9 * ptr + (long long)i * 3 * deg + 3 * k + j];
+                    band[(size_t)(rowoff[I] + d) * NB2 + (r & 63) * NB + (c & 63)] = fact_value(valK, nb_ptr, rev, ptr, deg, k, bcp, i, j);
                 }
         }
     }
@@ -320,6 +330,38 @@ __global__ __launch_bounds__(256) void residual_kernel(long long ncp, const long
     for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
     if (lane == 0) { r[3 * a] = b[3 * a] - s0; r[3 * a + 1] = b[3 * a + 1] - s1; r[3 * a + 2] = b[3 * a + 2] - s2; }
 }
+// r = b - K^T x through the reverse index (general mode): entry ((b, j), (a, i)) lies in b's rows at a's position rev[ptr + k]
+__global__ __launch_bounds__(256) void residual_t_kernel(long long ncp, const long long* __restrict__ nb_ptr, const int* __restrict__ nb, const int* __restrict__ rev,
+                                                         const double* __restrict__ val, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ r) {
+    const long long a = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (a >= ncp) return;
+    const long long ptr = nb_ptr[a], deg = nb_ptr[a + 1] - ptr;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (long long k = lane; k < deg; k += 64) {
+        const long long bc = nb[ptr + k], pb = nb_ptr[bc], db = nb_ptr[bc + 1] - pb, kb = rev[ptr + k];
+        const double* v = val + 9 * pb + 3 * kb;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double xv = x[3 * bc + j];
+            s0 += v[j * 3 * db] * xv; s1 += v[j * 3 * db + 1] * xv; s2 += v[j * 3 * db + 2] * xv;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+    if (lane == 0) { r[3 * a] = b[3 * a] - s0; r[3 * a + 1] = b[3 * a + 1] - s1; r[3 * a + 2] = b[3 * a + 2] - s2; }
+}
+// reverse index of the (symmetric) block pattern: rev[ptr_a + k] = position of a in the neighbour list of b = nb[ptr_a + k]; -1 (and *bad = 1) if absent
+__global__ void rev_index_kernel(long long nent, long long ncp, const long long* __restrict__ nb_ptr, const int* __restrict__ nb, int* __restrict__ rev, int* __restrict__ bad) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nent) return;
+    long long lo = 0, hi = ncp - 1;                                   // row a of entry e: last a with nb_ptr[a] <= e
+    while (lo < hi) { const long long mid = (lo + hi + 1) >> 1; if (nb_ptr[mid] <= e) lo = mid; else hi = mid - 1; }
+    const int a = (int)lo, b = nb[e];
+    int pos = -1;
+    for (long long q = nb_ptr[b]; q < nb_ptr[b + 1]; ++q) if (nb[q] == a) { pos = (int)(q - nb_ptr[b]); break; }
+    rev[e] = pos;
+    if (pos < 0) *bad = 1;
+}
 // sum of squares in fixed order: per-block partials, summed on the host
 __global__ __launch_bounds__(256) void sumsq_kernel(long long n, const double* __restrict__ v, double* __restrict__ part) {
     __shared__ double s[256];
@@ -354,7 +396,7 @@ __device__ __forceinline__ int nd_pos(const Front& F, int t, int c, const int* _
 }
 // K (block CSR, original numbering) -> fronts: the block (a, b) belongs to the front that eliminates the earlier of the two, and is stored
 // there when a's position is not in front of b's (lower triangle); one wave per control point a
-__global__ void nd_scatter_kernel(long long ncp, const long long* __restrict__ nb_ptr, const int* __restrict__ nb, const double* __restrict__ valK,
+__global__ void nd_scatter_kernel(long long ncp, const long long* __restrict__ nb_ptr, const int* __restrict__ nb, const int* __restrict__ rev, const double* __restrict__ valK,
                                   const Front* __restrict__ fronts, const int* __restrict__ front_of, const long long* __restrict__ order, const int* __restrict__ bnd,
                                   const long long* __restrict__ tri, double* __restrict__ arena) {
     const long long a = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -374,7 +416,7 @@ __global__ void nd_scatter_kernel(long long ncp, const long long* __restrict__ n
             for (int j = 0; j < 3; ++j) {
                 const int R = nd_dofpos(F, pa, i), C = nd_dofpos(F, pb, j);
                 if (R < C) continue;
-                arena[nd_entry(F, tri, R, C)] = valK[9 * ptr + (long long)i * 3 * deg + 3 * k + j];
+                arena[nd_entry(F, tri, R, C)] = fact_value(valK, nb_ptr, rev, ptr, deg, k, b, i, j);
             }
     }
 }
@@ -594,6 +636,7 @@ struct gfs_handle {
     double *band = nullptr, *linv = nullptr, *dval = nullptr, *wbuf = nullptr, *stat = nullptr;
     double *vb = nullptr, *vy = nullptr, *vz = nullptr, *vx = nullptr, *vr = nullptr, *vsol = nullptr, *vrhs = nullptr, *part = nullptr;
     std::vector<void*> allocs; long long bytes = 0; bool factored = false, small_pivot = false;
+    int* d_rev = nullptr; bool general = false;     // general mode (gfs_set_general): K need not be symmetric
     long long nnz9 = 0; double normK = 0.0, backward_error = 0.0;     // Frobenius norm of the factored K; backward error of the last solve
     // nested-dissection multifrontal mode
     bool nd = false; std::vector<Front> fronts; std::vector<std::vector<int>> kids; Front* d_fronts = nullptr;
@@ -1062,14 +1105,14 @@ int gfs_refactor(gfs_handle* h) {
         h->factored = false;
         HIPCHK(hipMemsetAsync(h->band, 0, (size_t)h->ntiles * NB2 * sizeof(double), h->stream));
         if (h->nd) {
-            hipLaunchKernelGGL(nd_scatter_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->valK, h->d_fronts, h->d_front_of, h->d_order,
+            hipLaunchKernelGGL(nd_scatter_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->general ? h->d_rev : nullptr, h->valK, h->d_fronts, h->d_front_of, h->d_order,
                                h->d_bnd, h->d_tri, h->band);
             const int nf = (int)h->fronts.size();
             hipLaunchKernelGGL(nd_pad_kernel, dim3(nf), dim3(64), 0, h->stream, h->d_fronts, h->d_tri, h->band);
             if (h->batch_blk > 0) nd_run_captured(h, &h->g_factor, [&] { nd_factor_levels(h); });
             else nd_run_captured(h, &h->g_factor, [&] { nd_sweep_up(h, [](gfs_handle* hh, int t, hipStream_t st, int si) { nd_factor_front(hh, t, st, si); }); });
         } else {
-        hipLaunchKernelGGL(band_fill_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->newi, h->valK, h->band, h->rowoff, h->n, h->npad);
+        hipLaunchKernelGGL(band_fill_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->newi, h->general ? h->d_rev : nullptr, h->valK, h->band, h->rowoff, h->n, h->npad);
         for (long long k = 0; k < h->nblk; ++k) {
             const int ni = h->nik[k];
             hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, h->stream, h->band, h->linv, h->dval, h->rowoff, (int)k, h->stat);
@@ -1094,9 +1137,31 @@ int gfs_refactor(gfs_handle* h) {
     return 0;
 }
 
-int gfs_solve_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual) {
+int gfs_set_general(gfs_handle* h, int nonsymmetric) {
+    if (!h) return sfail("gfs_set_general: null handle");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        if (nonsymmetric && !h->d_rev) {
+            long long nent = 0;
+            HIPCHK(hipMemcpy(&nent, h->nb_ptr + h->ncp, sizeof(long long), hipMemcpyDeviceToHost));
+            h->d_rev = h->dalloc<int>((size_t)nent);
+            int* d_bad = h->dalloc<int>(1); int bad = 0;
+            HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), h->stream));
+            hipLaunchKernelGGL(rev_index_kernel, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, h->stream, nent, h->ncp, h->nb_ptr, h->nb, h->d_rev, d_bad);
+            HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (bad) throw std::runtime_error("gfs_set_general: the block pattern of K is not symmetric");
+        }
+        if (h->general != (nonsymmetric != 0)) h->factored = false;       // the factors belong to the other mode
+        h->general = nonsymmetric != 0;
+    } catch (const std::exception& ex) { return sfail(ex.what()); }
+    return 0;
+}
+
+static int solve_dev_impl(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual, int transpose) {
     if (!h || !d_b || !d_x) return sfail("gfs_solve: null argument");
     if (!h->factored) return sfail("gfs_solve: no factorisation (call gfs_refactor)");
+    transpose = transpose && h->general;                                  // symmetric K: the same system
     try {
         HIPCHK(hipSetDevice(h->device));
         const unsigned gcp = (unsigned)((h->ncp * 64 + 255) / 256);
@@ -1104,7 +1169,8 @@ int gfs_solve_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine,
         const double nb_ = norm2(h, d_b, h->n);
         double best = -1.0;
         for (int itr = 0; itr <= max_refine; ++itr) {
-            hipLaunchKernelGGL(residual_kernel, dim3(gcp), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->valK, d_b, h->vsol, h->vr);
+            if (transpose) hipLaunchKernelGGL(residual_t_kernel, dim3(gcp), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->d_rev, h->valK, d_b, h->vsol, h->vr);
+            else hipLaunchKernelGGL(residual_kernel, dim3(gcp), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->valK, d_b, h->vsol, h->vr);
             const double nr = norm2(h, h->vr, h->n);
             if (best >= 0.0 && !(nr < 0.5 * best)) {            // the last correction did not help: keep the previous iterate
                 if (nr >= best) HIPCHK(hipMemcpyAsync(h->vsol, h->vrhs, h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream)); else best = nr;
@@ -1126,7 +1192,10 @@ int gfs_solve_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine,
     return 0;
 }
 
-int gfs_solve(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual) {
+int gfs_solve_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual) { return solve_dev_impl(h, d_b, d_x, max_refine, rel_residual, 0); }
+int gfs_solve_transposed_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual) { return solve_dev_impl(h, d_b, d_x, max_refine, rel_residual, 1); }
+
+static int solve_host_impl(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual, int transpose) {
     if (!h || !b || !x) return sfail("gfs_solve: null argument");
     try {
         HIPCHK(hipSetDevice(h->device));
@@ -1135,13 +1204,16 @@ int gfs_solve(gfs_handle* h, const double* b, double* x, int max_refine, double*
         if (hipMalloc(&dx, h->n * sizeof(double)) != hipSuccess) { (void)hipFree(db); throw std::runtime_error("gfs_solve: out of device memory"); }
         int rc = 1;
         if (hipMemcpy(db, b, h->n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess) {
-            rc = gfs_solve_dev(h, db, dx, max_refine, rel_residual);
+            rc = solve_dev_impl(h, db, dx, max_refine, rel_residual, transpose);
             if (!rc && hipMemcpy(x, dx, h->n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = sfail("gfs_solve: copy to the host failed");
         } else rc = sfail("gfs_solve: copy to the device failed");
         (void)hipFree(db); (void)hipFree(dx);
         return rc;
     } catch (const std::exception& ex) { return sfail(ex.what()); }
 }
+
+int gfs_solve(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual) { return solve_host_impl(h, b, x, max_refine, rel_residual, 0); }
+int gfs_solve_transposed(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual) { return solve_host_impl(h, b, x, max_refine, rel_residual, 1); }
 
 int gfs_info(gfs_handle* h, double info[8]) {
     if (!h || !info) return sfail("gfs_info: null argument");

@@ -463,8 +463,8 @@ class NonMatchingOpt:
 
     @property
     def symmetric_K(self):
-        """False when a follower pressure contributes its load stiffness (then K^T differs from K and the symmetric device
-        factorisation does not apply: solves run on the host path)."""
+        """False when a follower pressure contributes its load stiffness (then K^T differs from K: the device solver factors the
+        symmetric part and refines against K or K^T itself, _solver.DeviceSolver(general=True))."""
         self.dev
         return bool(getattr(getattr(self, "_arrays_cache", None), "symmetric_K", True))
 
@@ -476,25 +476,25 @@ class NonMatchingOpt:
         (goldfish_amd/_solver.py, csrc/gf_solver.hip); K's values are read in place from the library's buffer.  The
         factorisation does not pivot across tiles: every solve is checked (normwise backward error after refinement, finite
         values) and one that fails -- or a band that does not fit the device, or a zero pivot -- falls back, with a warning,
-        to the host path for this K.
+        to the host path for this K.  A non-symmetric K (follower pressure) is solved on the device too: factors of its symmetric
+        part, refinement against K / K^T; the same backward-error check decides whether that converged.
         ``"host"``: scipy SuperLU on a host copy of K (what MUMPS does in the reference; kept as the cross-check of the tests).
         Replaces GOLDFISH/utils/opt_utils.py:156-209 (MUMPS on a copy of K per call)."""
         rhs = np.asarray(rhs, float)
         ver = getattr(self, "_k_version", 0)
-        if not self.symmetric_K:
-            return self._host_solve(rhs, ver, transpose)
         if self.linear_solver == "device" and getattr(self, "_dsolver_failed_version", None) != ver:
             from . import _solver
             why = None
             try:
                 if getattr(self, "_dsolver", None) is None or self._dsolver.D is not self.dev:
                     w = np.concatenate([sp_.cp_hom_flat()[:, 3] for sp_ in self.splines])
-                    self._dsolver = _solver.DeviceSolver(self.dev, coords=np.stack([self.cp_iga[f] / w for f in range(3)], 1))
+                    # a follower pressure's K is not symmetric: the device solver then factors its symmetric part and refines against K / K^T
+                    self._dsolver = _solver.DeviceSolver(self.dev, coords=np.stack([self.cp_iga[f] / w for f in range(3)], 1), general=not self.symmetric_K)
                     self._dsolver_version = ver
                 elif self._dsolver_version != ver:
                     self._dsolver.refactor()
                     self._dsolver_version = ver
-                x = self._dsolver.solve(rhs)
+                x = self._dsolver.solve(rhs, transpose=transpose and not self.symmetric_K)
                 rr, be = self._dsolver.rel_residual, self._dsolver.backward_error
                 self.linear_solve_relative_residual, self.linear_solve_backward_error = rr, be
                 if np.all(np.isfinite(x)) and be <= self.linear_solve_rtol:
@@ -506,7 +506,7 @@ class NonMatchingOpt:
             import warnings
             warnings.warn("solve_K: device L D L^T rejected for this tangent (%s); falling back to the host sparse LU" % why, RuntimeWarning)
             self._dsolver_failed_version = ver
-        return self._host_solve(rhs, ver)
+        return self._host_solve(rhs, ver, transpose and not self.symmetric_K)
 
     def RIGA(self):
         """Non-matching residual in IGA dofs, Dirichlet rows zeroed (nonmatching_opt.py:941-948)."""

@@ -46,6 +46,15 @@ int gfs_refactor(gfs_handle* h);
  * rel_residual (may be NULL): |b - K x| / |b| of the returned solution (2-norm). */
 int gfs_solve(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual);
 int gfs_solve_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual);
+/* General mode for a K that is not symmetric (the load stiffness of a follower pressure, GOLDFISH's solve_ATx_b next to solve_Ax_b,
+ * utils/opt_utils.py:156-209): gfs_set_general(h, 1) builds the reverse index of the (symmetric) block pattern once; from then on gfs_refactor
+ * factors the SYMMETRIC PART (K + K^T) / 2 and the solves use it as the preconditioner of the iterative refinement, whose residual is taken with
+ * K itself (gfs_solve*: K x = b) or with K^T (gfs_solve_transposed*: K^T x = b).  Converges when the skew part is small against the symmetric
+ * part (refinement contracts by |S^-1 (K - S)|); the returned residual and gfs_info's backward error say whether it did -- give max_refine
+ * room (10 - 20).  With general mode off (the default) the transposed solves are the plain ones. */
+int gfs_set_general(gfs_handle* h, int nonsymmetric);
+int gfs_solve_transposed(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual);
+int gfs_solve_transposed_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual);
 /* info[0] = half bandwidth (dofs), [1] = block columns, [2] = band tiles per block row, [3] = device bytes,
  * [4] = flops of one factorisation, [5] = 1 if the last factorisation met a pivot below 1e-14 * max |diag|, else 0,
  * [6] = normwise backward error |b - K x| / (|K|_F |x| + |b|) of the last solve (what a backward-stable solve keeps at round-off

@@ -886,6 +886,11 @@ def test_tube_under_internal_pressure_known_answers():
     assert _rel(y, K.T @ x) < 1e-12
     b = rng.standard_normal(nm.vec_iga_dof)
     assert _rel(K.T @ nm.solve_K(b, transpose=True), b) < 1e-8 and _rel(K @ nm.solve_K(b), b) < 1e-8
+    # ... and they ran on the device: factors of the symmetric part, refinement against K / K^T (gfs_set_general), accepted by the backward error
+    assert nm._dsolver is not None and nm._dsolver.general and getattr(nm, "_dsolver_failed_version", None) != nm._k_version
+    assert nm.linear_solve_backward_error <= nm.linear_solve_rtol
+    xt = nm._dsolver.solve(b, transpose=True)
+    assert _rel(K.T @ xt, b) < 1e-8 and _rel(K @ xt, b) > 1e-6          # the transposed system, not the plain one
 
 
 def test_tube_shape_optimisation_rounds_the_cross_section():
