@@ -2,10 +2,11 @@
 //
 // 25 basis functions = 2 x 2 MFMA tiles of 16 (9 columns / rows of the second tiles are padding), 25 Gauss points = 7 groups
 // of 4 (3 padded slots with zero weight).  The 2 x 2 x 15 accumulator tiles (240 doubles per lane) do not fit the register
-// file, so the element is processed in two passes over the b tiles: a pass keeps the accumulators of both a tiles
-// (2 x 15 tiles = 120 doubles in AGPRs + 2 x 3 dR/dh tiles), forms T_b for its b tile once per group and feeds it to both
-// a tiles.  The row expansion is repeated per pass (15 % of the kernel).  Phase 1 is one lane per Gauss point (25 x 3 lanes
-// would not fit a wave; phase 1 is 6 % here).  One wave per element, 40.5 KB LDS -> four elements per CU.
+// file, so the element is processed in three passes whose accumulators each fit the 256 AGPRs: pass K (residual + K: the tile
+// pairs (0, 0), (1, 1) with the components i <= j and (1, 0) with all nine; (0, 1) follows from the symmetry at the store:
+// 21 tiles) and one pass per b tile for dR/dCP + dR/dh (2 x 9 + 2 x 3 tiles).  Round 2 ran two passes over the b tiles with
+// K, dR/dCP and dR/dh together (36 tiles = 288 registers > 256: the compiler moved tiles in and out around the MFMAs).
+// Phase 1 is one lane per Gauss point (25 x 3 lanes would not fit a wave).  One wave per element, 40.5 KB LDS -> four per CU.
 #pragma once
 #include "gf_gauss_loop.hpp"
 
@@ -103,50 +104,46 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
     constexpr int IJ_I[6] = {0, 0, 0, 1, 1, 2}, IJ_J[6] = {0, 1, 2, 1, 2, 2};
     constexpr int QI[6] = {0, 0, 0, 1, 1, 2}, QJ[6] = {0, 1, 2, 1, 2, 2};
     double* out = blk + (size_t)blockIdx.x * Cfg::BLK;
-    double accR[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-
-    for (int tb = 0; tb < 2; ++tb) {
-        gf_d4 accK[2][6], accC[2][9], accH[2][3];
-        for (int ta = 0; ta < 2; ++ta) {
-            for (int q = 0; q < 6; ++q) accK[ta][q] = gf_d4{0, 0, 0, 0};
-            for (int q = 0; q < 9; ++q) accC[ta][q] = gf_d4{0, 0, 0, 0};
-            for (int q = 0; q < 3; ++q) accH[ta][q] = gf_d4{0, 0, 0, 0};
+    const RowLane RLg(x);          // lane constants of the row expansion (round 2 re-derived them per group: with 288 accumulator registers a dozen of them were spilled)
+    // basis functions of both tiles at the lane's Gauss point of a group (registers)
+    auto basis = [&](const double* im, int gu, int gv, double (&phi)[2][5], double (&R0)[2], double (&n0)[2]) {
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int ju = bf[tl] % P1, jv = bf[tl] / P1;
+            const double u0 = s_tu[(gu * 3 + 0) * P1 + ju], u1 = s_tu[(gu * 3 + 1) * P1 + ju], u2 = s_tu[(gu * 3 + 2) * P1 + ju];
+            const double v0 = s_tv[(gv * 3 + 0) * P1 + jv], v1 = s_tv[(gv * 3 + 1) * P1 + jv], v2 = s_tv[(gv * 3 + 2) * P1 + jv];
+            const double Nb[6] = {u0 * v0, u1 * v0, u0 * v1, u2 * v0, u0 * v2, u1 * v1};
+            double R[6];
+            rationalize6(Nb, im + IM_W, R);
+            for (int k = 0; k < 5; ++k) phi[tl][k] = bval[tl] * R[k + 1];
+            R0[tl] = bval[tl] * R[0]; n0[tl] = bval[tl] * Nb[0];
         }
+    };
+
+    // ================= pass K: residual + K.  The tile pairs (a tile, b tile) = (0, 0), (1, 1) with the six components i <= j and (1, 0) with all
+    // nine -- K^(ij)[a][b] = K^(ji)[b][a] gives the pair (0, 1) at the store -- : 21 accumulator tiles (168 registers) instead of the 24 of two
+    // b-tile passes, ONE row expansion of G per Gauss-point group, T_b of both b tiles formed once.
+    {
+        gf_d4 accK00[6], accK11[6], accK10[9];
+        for (int q = 0; q < 6; ++q) { accK00[q] = gf_d4{0, 0, 0, 0}; accK11[q] = gf_d4{0, 0, 0, 0}; }
+        for (int q = 0; q < 9; ++q) accK10[q] = gf_d4{0, 0, 0, 0};
+        double accR[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
         for (int grp = 0; grp < NGRP; ++grp) {
             const int gp = 4 * grp + kk, gpc = gp < NG ? gp : NG - 1;
             const int gu = gpc % P1, gv = gpc / P1;
             const double* im = s_im[gpc];
             const double wq = gp < NG ? im[IM_WQ] : 0.0;               // padded Gauss-point slots contribute nothing
-            // -- basis functions of both tiles at this Gauss point
             double phi[2][5], R0[2], n0[2];
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) {
-                const int ju = bf[tl] % P1, jv = bf[tl] / P1;
-                const double u0 = s_tu[(gu * 3 + 0) * P1 + ju], u1 = s_tu[(gu * 3 + 1) * P1 + ju], u2 = s_tu[(gu * 3 + 2) * P1 + ju];
-                const double v0 = s_tv[(gv * 3 + 0) * P1 + jv], v1 = s_tv[(gv * 3 + 1) * P1 + jv], v2 = s_tv[(gv * 3 + 2) * P1 + jv];
-                const double Nb[6] = {u0 * v0, u1 * v0, u0 * v1, u2 * v0, u0 * v2, u1 * v1};
-                double R[6];
-                rationalize6(Nb, im + IM_W, R);
-                for (int k = 0; k < 5; ++k) phi[tl][k] = bval[tl] * R[k + 1];
-                R0[tl] = bval[tl] * R[0]; n0[tl] = bval[tl] * Nb[0];
-            }
+            basis(im, gu, gv, phi, R0, n0);
             GF_STAMP(2, tstamp);
-            // -- row r of G and Hc
             double gR[15], hR[15];
             for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
-            if (doK || doC) {
-                // The lane constants of the row expansion (13 offsets, 10 masks) are re-derived from the lane index here instead of being
-                // kept across the group loop: kept, a dozen of them were spilled and came back through scratch loads, each behind an
-                // s_waitcnt vmcnt(0), nine times per group (the asm keeps the derivation inside the loop).
-                int xl = x;
-                asm volatile("" : "+v"(xl));
-                RowLane RLg; RLg.init(xl);
-                RLg.template expand<WITHC>(im, gR, hR); dpp_source_fence(gR); if constexpr (WITHC) dpp_source_fence(hR);
+            if (doK) {
+                RLg.template expand<false>(im, gR, hR); dpp_source_fence(gR);
             }
             GF_STAMP(3, tstamp);
-            // -- residual (first pass only) and dR/dh prefactors of both a tiles
-            const double ls = (has_bf && tb == 0) ? load_scalar(im, ppd) : 0.0;
-            if (tb == 0) {
+            {
+                const double ls = has_bf ? load_scalar(im, ppd) : 0.0;
 #pragma unroll
                 for (int ta = 0; ta < 2; ++ta)
                     for (int i = 0; i < 3; ++i) {
@@ -155,6 +152,88 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
                         accR[ta][i] += wq * (rz - ls * pf[i] * R0[ta]);
                     }
             }
+            GF_STAMP(4, tstamp);
+            if (doK) {
+                double pb0[5], pb1[5];
+                for (int m = 0; m < 5; ++m) { pb0[m] = wq * phi[0][m]; pb1[m] = wq * phi[1][m]; }
+                static_for<5>([&](auto m_) {
+                    constexpr int m = decltype(m_)::value;
+                    double t0[9], t1[6];
+                    static_for<9>([&](auto q_) { constexpr int q = decltype(q_)::value; t0[q] = row_dot<3 * m + q / 3, q % 3>(gR, pb0); });
+                    static_for<6>([&](auto q_) { constexpr int q = decltype(q_)::value; t1[q] = row_dot<3 * m + QI[q], QJ[q]>(gR, pb1); });
+                    mfma_hazard_gap(t0); mfma_hazard_gap(t1);
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) accK00[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[0][m], t0[3 * QI[q] + QJ[q]], accK00[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) accK10[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[1][m], t0[q], accK10[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) accK11[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[1][m], t1[q], accK11[q], 0, 0, 0);
+                });
+            }
+            GF_STAMP(5, tstamp);
+        }
+        // ---- K of the element block: register rr of lane (x, kk) is (a, b) = (16 ta + kk + 4 rr, 16 tb + x)
+        if (doK) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int a0 = kk + 4 * rr, a1 = 16 + kk + 4 * rr, b0 = x, b1 = 16 + x;
+#pragma unroll
+                for (int ij = 0; ij < 6; ++ij) {
+                    const int i = IJ_I[ij], j = IJ_J[ij];
+                    out[Cfg::OFF_K + (3 * a0 + i) * ND + 3 * b0 + j] = accK00[ij][rr];
+                    if (i < j) out[Cfg::OFF_K + (3 * b0 + j) * ND + 3 * a0 + i] = accK00[ij][rr];
+                    if (a1 < NB && b1 < NB) {
+                        out[Cfg::OFF_K + (3 * a1 + i) * ND + 3 * b1 + j] = accK11[ij][rr];
+                        if (i < j) out[Cfg::OFF_K + (3 * b1 + j) * ND + 3 * a1 + i] = accK11[ij][rr];
+                    }
+                }
+                if (a1 < NB) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) {
+                        out[Cfg::OFF_K + (3 * a1 + q / 3) * ND + 3 * b0 + q % 3] = accK10[q][rr];
+                        out[Cfg::OFF_K + (3 * b0 + q % 3) * ND + 3 * a1 + q / 3] = accK10[q][rr];          // the (0, 1) pair by symmetry
+                    }
+                }
+            }
+        }
+        GF_STAMP(7, tstamp);
+        // ---- residual: sum the four Gauss-point slots of a group (two steps through the staging area: 2 x 32 x 3 doubles)
+        wave_lds_sync();
+        if (kk >= 2) for (int ta = 0; ta < 2; ++ta) for (int i = 0; i < 3; ++i) s_g[(((kk - 2) * 2 + ta) * 16 + x) * 3 + i] = accR[ta][i];
+        wave_lds_sync();
+        if (kk < 2) for (int ta = 0; ta < 2; ++ta) for (int i = 0; i < 3; ++i) accR[ta][i] += s_g[((kk * 2 + ta) * 16 + x) * 3 + i];
+        wave_lds_sync();
+        if (kk == 1) for (int ta = 0; ta < 2; ++ta) for (int i = 0; i < 3; ++i) s_g[(ta * 16 + x) * 3 + i] = accR[ta][i];
+        wave_lds_sync();
+        if (kk == 0 && (flags & GF_ASM_R_BIT)) for (int ta = 0; ta < 2; ++ta) {
+            const int a = 16 * ta + x;
+            if (a < NB) for (int i = 0; i < 3; ++i) out[Cfg::OFF_R + 3 * a + i] = accR[ta][i] + s_g[(ta * 16 + x) * 3 + i];
+        }
+        wave_lds_sync();
+    }
+
+    // ================= passes C: dR/dCP and dR/dh, one pass per b tile (2 x 9 + 2 x 3 accumulator tiles = 192 registers): T_b of the pass's b tile
+    // feeds both a tiles
+    if (doC || doH) for (int tb = 0; tb < 2; ++tb) {
+        gf_d4 accC[2][9], accH[2][3];
+        for (int ta = 0; ta < 2; ++ta) {
+            for (int q = 0; q < 9; ++q) accC[ta][q] = gf_d4{0, 0, 0, 0};
+            for (int q = 0; q < 3; ++q) accH[ta][q] = gf_d4{0, 0, 0, 0};
+        }
+        for (int grp = 0; grp < NGRP; ++grp) {
+            const int gp = 4 * grp + kk, gpc = gp < NG ? gp : NG - 1;
+            const int gu = gpc % P1, gv = gpc / P1;
+            const double* im = s_im[gpc];
+            const double wq = gp < NG ? im[IM_WQ] : 0.0;
+            double phi[2][5], R0[2], n0[2];
+            basis(im, gu, gv, phi, R0, n0);
+            GF_STAMP(2, tstamp);
+            double gR[15], hR[15];
+            for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
+            if constexpr (WITHC) if (doC) {
+                RLg.template expand<true>(im, gR, hR); dpp_source_fence(hR);
+            }
+            GF_STAMP(3, tstamp);
             double pb[5];
             for (int m = 0; m < 5; ++m) pb[m] = wq * (tb == 0 ? phi[0][m] : phi[1][m]);
             const double n0b = tb == 0 ? n0[0] : n0[1];
@@ -174,22 +253,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
                 }
             }
             GF_STAMP(4, tstamp);
-            // -- contraction: T_b of this pass's b tile feeds both a tiles
-            if (doK) {
-                static_for<5>([&](auto m_) {
-                    constexpr int m = decltype(m_)::value;
-                    double t[6];
-                    static_for<6>([&](auto q_) { constexpr int q = decltype(q_)::value; t[q] = row_dot<3 * m + QI[q], QJ[q]>(gR, pb); });
-                    mfma_hazard_gap(t);
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) {
-                        accK[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[0][m], t[q], accK[0][q], 0, 0, 0);
-                        accK[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[1][m], t[q], accK[1][q], 0, 0, 0);
-                    }
-                });
-            }
-            GF_STAMP(5, tstamp);
-            if (doC) {
+            if constexpr (WITHC) if (doC) {
                 static_for<5>([&](auto m_) {
                     constexpr int m = decltype(m_)::value;
                     double t[9];
@@ -216,7 +280,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
             }
             GF_STAMP(6, tstamp);
         }
-        // ---- write the (a tiles, b tile tb) part of the element block: register rr of lane (x, kk) is (a, b) = (16 ta + kk + 4 rr, 16 tb + x)
+        // ---- the (a tiles, b tile tb) part of dR/dCP and dR/dh
         const int b = 16 * tb + x;
         if (b < NB) {
 #pragma unroll
@@ -225,15 +289,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
                 for (int rr = 0; rr < 4; ++rr) {
                     const int a = 16 * ta + kk + 4 * rr;
                     if (a >= NB) continue;
-                    if (doK) {
-#pragma unroll
-                        for (int ij = 0; ij < 6; ++ij) {
-                            const int i = IJ_I[ij], j = IJ_J[ij];
-                            out[Cfg::OFF_K + (3 * a + i) * ND + 3 * b + j] = accK[ta][ij][rr];
-                            if (i < j) out[Cfg::OFF_K + (3 * b + j) * ND + 3 * a + i] = accK[ta][ij][rr];
-                        }
-                    }
-                    if (doC) {
+                    if constexpr (WITHC) if (doC) {
 #pragma unroll
                         for (int q = 0; q < 9; ++q) out[Cfg::OFF_C + (3 * a + q / 3) * ND + 3 * b + q % 3] = accC[ta][q][rr];
                     }
@@ -248,18 +304,6 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
 #ifdef GF_STAMPS
     if ((blockIdx.x & 31) == 0 && tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[k], stamp_acc[k]);
 #endif
-    // ---- residual: sum the four Gauss-point slots of a group (two steps through the staging area: 2 x 32 x 3 doubles)
-    wave_lds_sync();
-    if (kk >= 2) for (int ta = 0; ta < 2; ++ta) for (int i = 0; i < 3; ++i) s_g[(((kk - 2) * 2 + ta) * 16 + x) * 3 + i] = accR[ta][i];
-    wave_lds_sync();
-    if (kk < 2) for (int ta = 0; ta < 2; ++ta) for (int i = 0; i < 3; ++i) accR[ta][i] += s_g[((kk * 2 + ta) * 16 + x) * 3 + i];
-    wave_lds_sync();
-    if (kk == 1) for (int ta = 0; ta < 2; ++ta) for (int i = 0; i < 3; ++i) s_g[(ta * 16 + x) * 3 + i] = accR[ta][i];
-    wave_lds_sync();
-    if (kk == 0 && (flags & GF_ASM_R_BIT)) for (int ta = 0; ta < 2; ++ta) {
-        const int a = 16 * ta + x;
-        if (a < NB) for (int i = 0; i < 3; ++i) out[Cfg::OFF_R + 3 * a + i] = accR[ta][i] + s_g[(ta * 16 + x) * 3 + i];
-    }
 }
 
 }  // namespace gf
