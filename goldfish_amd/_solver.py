@@ -13,7 +13,7 @@ import scipy.sparse as sp
 from scipy.sparse.csgraph import reverse_cuthill_mckee
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgoldfish_solver.so")
+LIB_PATH = os.environ.get("GF_SOLVER_LIB", os.path.join(_HERE, "libgoldfish_solver.so"))   # GF_SOLVER_LIB: A/B builds while tuning
 EXPORTS = ["gfs_last_error", "gfs_create", "gfs_create_nd", "gfs_destroy", "gfs_refactor", "gfs_solve", "gfs_solve_dev", "gfs_set_general", "gfs_solve_transposed",
            "gfs_solve_transposed_dev", "gfs_info"]
 _L = None

@@ -35,8 +35,10 @@ def build(force=False, verbose=False):
                                os.path.join(CSRC, "point_host_test.cpp"), "-o", host])
     solver = os.path.join(HERE, "libgoldfish_solver.so")      # block-banded L D L^T factorisation + solves on the device, include/goldfish_solver.h
     if force or needs_build(solver, ["gf_solver.hip", os.path.join("..", "..", "include", "goldfish_solver.h")]):
-        subprocess.check_call([_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", os.path.join(CSRC, "gf_solver.hip"),
-                               "-o", solver])
+        # -amdgpu-mfma-vgpr-form: v_mfma_f64_16x16x4 with its accumulators in arch VGPRs issues every 64 cycles, with AGPR accumulators (the
+        # compiler's default for these kernels) every 131 (tools/ubench_acc.hip, profiles/r03_ubench_fp64_mfma.txt); the tile kernels have registers to spare
+        subprocess.check_call([_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form",
+                               os.path.join(CSRC, "gf_solver.hip"), "-o", solver])
     return LIB
 
 

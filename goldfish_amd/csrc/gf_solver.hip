@@ -89,54 +89,70 @@ __global__ void band_fill_kernel(long long ncp, const long long* __restrict__ nb
     if (t < npad - n) { const long long r = n + t, I = r >> 6; band[(size_t)rowoff[I] * NB2 + (r & 63) * NB + (r & 63)] = 1.0; }
 }
 
-// diagonal tile of block column k: L D L^T (lower, no pivoting) and the inverse of the unit lower factor
+// diagonal tile of block column k: L D L^T (lower, no pivoting) and the inverse of the unit lower factor.
+// Round 3, end: register-resident.  The first version kept the tile in LDS and walked its trailing part with a loop of run-time bounds per elimination
+// step (a dependent LDS read - FMA - LDS write chain per entry): 93 us per tile, the serial chain of every front.  Now thread (i, jg) holds row i, columns
+// 16 jg .. 16 jg + 15 in registers; per step p the owners of column p publish it through LDS (zero at and above the pivot, so the finished columns and
+// the rows above need no predicate), one barrier, 16 FMAs; the steps are unrolled (register indices are compile-time).  The inverse of the unit lower
+// factor: column c by the four lanes 4 c .. 4 c + 3 (lane q4 keeps x_m, m = q4 mod 4, in registers), row by row with a full-width dot product against
+// the row of L in LDS (zeros above the diagonal: no run-time bounds), rows unrolled.
 __device__ __forceinline__ void diag_body(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
-    __shared__ double s[NB * (NB + 1)], v[NB * (NB + 1)];
     constexpr int S1 = NB + 1;
-    const int tid = threadIdx.x;
+    __shared__ double sL[NB * S1];
+    __shared__ __attribute__((aligned(16))) double col[2][NB];
+    __shared__ double sd[NB];
+    const int tid = threadIdx.x, i = tid >> 2, jg = tid & 3;
     double* A = band + (size_t)rowoff[k] * NB2;
-    for (int q = tid; q < NB2; q += 256) s[(q >> 6) * S1 + (q & 63)] = A[q];
-    // thread (i, jg): rows i, columns 16 jg .. 16 jg + 15 of the trailing update
-    const int i = tid >> 2, jg = tid & 3;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) { const double2 v = *reinterpret_cast<const double2*>(A + i * NB + 16 * jg + c); a[c] = v.x; a[c + 1] = v.y; }
+#pragma unroll
     for (int p = 0; p < NB; ++p) {
+        double* cb = col[p & 1];
+        if (jg == p / 16) { cb[i] = i > p ? a[p % 16] : 0.0; if (i == p) sd[p] = a[p % 16]; }
         __syncthreads();
-        if (i > p) {
-            const double lip = s[i * S1 + p] / s[p * S1 + p];
-            const int j0 = max(16 * jg, p + 1), j1 = min(16 * jg + 15, i);
-            for (int j = j0; j <= j1; ++j) s[i * S1 + j] -= lip * s[j * S1 + p];
+        const double lip = cb[i] / sd[p];
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(cb + 16 * jg + c);
+            a[c] -= lip * v.x; a[c + 1] -= lip * v.y;
         }
     }
     __syncthreads();
-    if (tid < NB) { dval[(size_t)k * NB + tid] = s[tid * S1 + tid]; }
-    __syncthreads();
-    // scale the columns: L[i][p] = a[i][p] / d_p (i > p); unit diagonal, zero above
-    for (int q = tid; q < NB2; q += 256) {
-        const int r = q >> 6, c = q & 63;
-        const double l = r > c ? s[r * S1 + c] / s[c * S1 + c] : (r == c ? 1.0 : 0.0);
-        v[r * S1 + c] = l;
+    // a[c] for j = 16 jg + c < i: a_ij at the time column j became final = L_ij d_j
+    if (tid < NB) dval[(size_t)k * NB + tid] = sd[tid];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int j = 16 * jg + c;
+        const double l = j < i ? a[c] / sd[j] : 0.0;
+        sL[i * S1 + j] = l;                                   // strictly lower part of L (zero on and above the diagonal: the inverse below wants that)
+        a[c] = j < i ? l : (j == i ? sd[i] : 0.0);            // what the band keeps: d on the diagonal, L below, zero above
     }
-    __syncthreads();
-    for (int q = tid; q < NB2; q += 256) { const int r = q >> 6, c = q & 63; A[q] = r == c ? s[r * S1 + r] : (r > c ? v[r * S1 + c] : 0.0); }
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(A + i * NB + 16 * jg + c) = double2{a[c], a[c + 1]};
     // smallest / largest |d| of the tile (singularity report)
     if (tid == 0) {
         double mn = 1e300, mx = 0.0;
-        for (int p = 0; p < NB; ++p) { const double d = fabs(s[p * S1 + p]); mn = fmin(mn, d); mx = fmax(mx, d); }
+        for (int p = 0; p < NB; ++p) { const double d = fabs(sd[p]); mn = fmin(mn, d); mx = fmax(mx, d); }
         stat[2 * k] = mn; stat[2 * k + 1] = mx;
     }
     __syncthreads();
-    // inverse of the unit lower factor: column c by the four lanes 4 c .. 4 c + 3 (same wave: LDS operations of a wave are in order),
-    // row by row; s is reused for the inverse
+    // inverse of the unit lower factor: x = column c of it, x_r = delta_rc - sum_{m < r} L_rm x_m
     const int c = tid >> 2, q4 = tid & 3;
-    for (int r = 0; r < NB; ++r) {
-        double part = 0.0;
-        for (int m = c + q4; m < r; m += 4) part += v[r * S1 + m] * s[m * S1 + c];      // inv[m][c], m < r: written in earlier iterations
-        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
-        if (q4 == 0) s[r * S1 + c] = r < c ? 0.0 : (r == c ? 1.0 : -part);
-        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the write is done before the next row reads it (same wave)
-    }
-    __syncthreads();
+    double xr[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) xr[t] = 0.0;
     double* Li = linv + (size_t)k * NB2;
-    for (int q = tid; q < NB2; q += 256) Li[q] = s[(q >> 6) * S1 + (q & 63)];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) { p0 += sL[r * S1 + 4 * t + q4] * xr[t]; p1 += sL[r * S1 + 4 * (t + 1) + q4] * xr[t + 1]; }
+        double part = p0 + p1;
+        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+        const double xv = (r == c ? 1.0 : 0.0) - part;         // rows above c: L's row is zero there and so are the x_m: xv = 0
+        if (q4 == r % 4) { xr[r / 4] = xv; Li[r * NB + c] = xv; }
+    }
 }
 __global__ __launch_bounds__(256) void diag_kernel(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
     diag_body(band, linv, dval, rowoff, k, stat);
@@ -216,11 +232,9 @@ __device__ __forceinline__ void park_tile(const double2 (&r)[8], double* __restr
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const int idx = 2 * (tid + 256 * q), rr = idx >> 6, c = idx & 63; s[rr * LS + c] = r[q].x; s[rr * LS + c + 1] = r[q].y; }
 }
-__global__ __launch_bounds__(256) void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow) {
+__device__ __forceinline__ void update_wide_tile(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int gi, int gj) {
     __shared__ __attribute__((aligned(16))) double sA[NB * LS], sB[NB * LS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int gi, gj; tri_index((int)blockIdx.x, gi, gj);
-    if (gi >= nrow) return;
     const int i = k0 + w + gi, j = k0 + w + gj;
     double* C = band + (size_t)(rowoff[i] + (gi - gj)) * NB2;
     double2 ra[8], rb[8];
@@ -246,6 +260,11 @@ __global__ __launch_bounds__(256) void update_wide_kernel(double* __restrict__ b
     for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) C[(16 * wave + 4 * rg + (lane >> 4)) * NB + 16 * nj + (lane & 15)] = acc[nj][rg];
+}
+__global__ __launch_bounds__(256) void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow) {
+    int gi, gj; tri_index((int)blockIdx.x, gi, gj);
+    if (gi >= nrow) return;
+    update_wide_tile(band, wbuf, wstride, rowoff, k0, w, gi, gj);
 }
 
 // forward substitution, block column k: y_k = L_kk^-1 b_k (every workgroup; workgroup 0 keeps it), b_{k+g} -= L_{k+g,k} y_k (workgroup g >= 1)
@@ -693,6 +712,9 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
     double* band = h->band + (size_t)F.tile_off * NB2;
     double* linv = h->linv + (size_t)F.kbase * NB2; double* dval = h->dval + (size_t)F.kbase * NB;
     const int WP = std::max(h->panel_w, 1); const long long wstride = h->max_blk;
+    // (Measured and dropped, round 3: look-ahead -- the bulk of a group's wide update on a partner stream while this stream goes on with the next group's
+    //  diag / panel / narrow chain: 0.473 instead of 0.407 s at C4.  The chain's one-workgroup diagonal tile runs at a third of its speed next to the
+    //  MFMA-heavy update workgroups it shares a CU with, so the chain does not get shorter and the split update costs a launch more per group.)
     for (int k0 = 0; k0 < F.nblk_e; k0 += WP) {                       // groups of WP block columns: one wide trailing update per group
         const int w = std::min(WP, F.nblk_e - k0);
         for (int c = 0; c < w; ++c) {
