@@ -21,8 +21,22 @@ template <int MODE> __global__ __launch_bounds__(64) void k(double* out, int ite
             if (MODE == 3) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(acs[q]) : "v"(a), "v"(b));
         }
     }
+    if (MODE >= 4) {           // the element kernels' pattern: tiles of four 4 x 4 x 4 products, A operand a4[s] per product, B operand t[q] per tile
+        double a4[4] = {a, a + 1.0, a + 2.0, a + 3.0}, t[NT];
+        for (int q = 0; q < NT; ++q) t[q] = b + q;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (MODE == 4) acc[q][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[s], t[q], acc[q][s], 0, 0, 0);
+                    if (MODE == 5) acc[q][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[0], t[q], acc[q][s], 0, 0, 0);
+                    if (MODE == 6) acc[q][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[s], t[0], acc[q][s], 0, 0, 0);
+                }
+        }
+    }
     double s = 0;
-    for (int q = 0; q < NT; ++q) s += acc[q][0] + acc[q][3];
+    for (int q = 0; q < NT; ++q) s += acc[q][0] + acc[q][3] + acc[q][1] + acc[q][2];
     for (int q = 0; q < 4 * NT; ++q) s += acs[q];
     out[blockIdx.x * 64 + threadIdx.x] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) { cyc[0] = clock64() - c0; cyc[1] = wall_clock64() - w0; }
@@ -43,5 +57,8 @@ int main() {
     run<1>(d, "v_mfma_f64_16x16x4, accumulators in arch VGPRs", 12, 2048.0);
     run<2>(d, "v_mfma_f64_4x4x4, accumulators in AGPRs", 48, 512.0);
     run<3>(d, "v_mfma_f64_4x4x4, accumulators in arch VGPRs", 48, 512.0);
+    run<4>(d, "v_mfma_f64_4x4x4 tiles: A per product, B per tile", 48, 512.0);
+    run<5>(d, "v_mfma_f64_4x4x4 tiles: one A, B per tile", 48, 512.0);
+    run<6>(d, "v_mfma_f64_4x4x4 tiles: A per product, one B", 48, 512.0);
     return 0;
 }

@@ -29,6 +29,22 @@ template <int NT, int MODE> __global__ __launch_bounds__(64) void k(double* out,
             asm volatile("s_nop 1");
 #pragma unroll
             for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi, t[q], acc[q], 0, 0, 0);
+        } else if (MODE == 4) {          // chains, then the tiles as four v_mfma_f64_4x4x4 each, A operand rotated through its 16-lane row
+#pragma unroll
+            for (int q = 0; q < NT; ++q) chain(t[q]);
+            double a4[4] = {phi, phi, phi, phi};
+            {
+                const int lo = __double2loint(phi), hi = __double2hiint(phi);
+                a4[1] = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x12c, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, 0x12c, 0xf, 0xf, false));
+                a4[2] = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false));
+                a4[3] = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x124, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xf, 0xf, false));
+            }
+            asm volatile("s_nop 1");
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[q][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[s], t[q], acc[q][s], 0, 0, 0);
+            phi += 1e-9;
         } else {
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
@@ -85,6 +101,7 @@ template <int NT, int MODE> void run(double* d, const char* what, int blocks = 1
 int main() {
     double* d; hipMalloc(&d, 8 * 64 * 8192);
     run<6, 0>(d, "MFMAs only"); run<6, 1>(d, "DPP chains only"); run<6, 2>(d, "chains, then MFMAs"); run<6, 3>(d, "chains interleaved with the previous MFMAs");
+    run<6, 4>(d, "chains, then tiles of four 4x4x4"); run<9, 4>(d, "chains, then tiles of four 4x4x4"); run<15, 4>(d, "chains, then tiles of four 4x4x4");
     run<9, 0>(d, "MFMAs only"); run<9, 1>(d, "DPP chains only"); run<9, 2>(d, "chains, then MFMAs"); run<9, 3>(d, "chains interleaved with the previous MFMAs");
     run<15, 0>(d, "MFMAs only"); run<15, 1>(d, "DPP chains only"); run<15, 2>(d, "chains, then MFMAs"); run<15, 3>(d, "chains interleaved with the previous MFMAs");
     // is the matrix pipe's rate a per-wave or a per-SIMD limit, and what clock does the chip hold under it?
