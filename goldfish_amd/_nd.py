@@ -138,13 +138,23 @@ def nested_dissection(nb_ptr, nb, coords, leaf=192):
             kids[parent[t]].append(t)
     nb_ptr = np.asarray(nb_ptr, np.int64)
     nbl = np.asarray(nb, np.int64)
+    # the later-eliminated neighbours of every front's own control points, for all fronts at once: edges (a, b) with order[b] beyond the subtree of front_of[a]
+    ra = np.repeat(np.arange(ncp, dtype=np.int64), np.diff(nb_ptr))
+    later = order[nbl] >= hi[front_of[ra]]
+    ef, eb = front_of[ra[later]], nbl[later]
+    o2 = np.lexsort((order[eb], ef))
+    ef, eb = ef[o2], eb[o2]
+    keep = np.ones(ef.size, bool)
+    keep[1:] = (ef[1:] != ef[:-1]) | (eb[1:] != eb[:-1])
+    ef, eb = ef[keep], eb[keep]
+    own_off = np.concatenate([[0], np.cumsum(np.bincount(ef, minlength=nf))]).astype(np.int64)
     for t in range(nf):
-        e = elim[elim_off[t]:elim_off[t + 1]]
-        idx = np.concatenate([np.arange(nb_ptr[a], nb_ptr[a + 1]) for a in e]) if e.size else np.zeros(0, np.int64)
-        cand = [nbl[idx]] + [bnds[c] for c in kids[t]]
-        cand = np.unique(np.concatenate(cand)) if cand else np.zeros(0, np.int64)
-        cand = cand[order[cand] >= hi[t]]
-        bnds[t] = cand[np.argsort(order[cand], kind="stable")]
+        cand = eb[own_off[t]:own_off[t + 1]]                    # sorted by elimination order, unique
+        if kids[t]:
+            cand = np.unique(np.concatenate([cand] + [bnds[c] for c in kids[t]]))
+            cand = cand[order[cand] >= hi[t]]
+            cand = cand[np.argsort(order[cand], kind="stable")]
+        bnds[t] = cand
     bnd_off = np.concatenate([[0], np.cumsum([b.size for b in bnds])]).astype(np.int64)
     bnd = np.concatenate(bnds).astype(np.int64) if nf else np.zeros(0, np.int64)
     return Symbolic(elim, elim_off, bnd, bnd_off, parent, order, front_of)

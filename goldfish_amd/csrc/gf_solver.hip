@@ -317,6 +317,74 @@ __global__ __launch_bounds__(256) void bwd_kernel(const double* __restrict__ ban
     if (tid < NB) z[(size_t)(k - g) * NB + tid] -= sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
 }
 
+// ---- substitutions of a dense front, a GROUP of w <= 4 block columns per launch (one launch per block column is latency: 6 us each, 1 727 columns in the
+//      large fronts of C4).  Every workgroup solves the group's w x w block triangle itself (a few 64 x 64 matrix-vector products on tiles that sit in L2:
+//      cheaper than a second launch or a cross-workgroup hand-over), workgroup 0 keeps the result, workgroup g >= 1 applies it to one block row outside.
+__device__ __forceinline__ double mv_row(const double* __restrict__ L, const double* __restrict__ v, int r, int q4) {      // (L v)_r, four lanes per row
+    const double* Lr = L + r * NB + 16 * q4;
+    double part = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) part += Lr[c] * v[16 * q4 + c];
+    part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+    return part;
+}
+__global__ __launch_bounds__(256) void fwd_group_kernel(const double* __restrict__ band, const double* __restrict__ linv, double* __restrict__ b, double* __restrict__ y,
+                                                        const long long* __restrict__ tri, int k0, int w) {
+    __shared__ double sb[4][NB], sy[4][NB];
+    const int tid = threadIdx.x, r = tid >> 2, q4 = tid & 3, g = blockIdx.x;
+    for (int q = tid; q < w * NB; q += 256) sb[q >> 6][q & 63] = b[(size_t)k0 * NB + q];
+    __syncthreads();
+    for (int c = 0; c < w; ++c) {
+        const double yv = mv_row(linv + (size_t)(k0 + c) * NB2, sb[c], r, q4);
+        if (q4 == 0) sy[c][r] = yv;
+        __syncthreads();
+        for (int c2 = c + 1; c2 < w; ++c2) {
+            const double part = mv_row(band + (size_t)(tri[k0 + c2] + (c2 - c)) * NB2, sy[c], r, q4);
+            if (q4 == 0) sb[c2][r] -= part;
+        }
+        __syncthreads();
+    }
+    if (g == 0) { for (int q = tid; q < w * NB; q += 256) y[(size_t)k0 * NB + q] = sy[q >> 6][q & 63]; return; }
+    const int I = k0 + w + (g - 1);
+    double part = 0.0;
+    for (int c = 0; c < w; ++c) part += mv_row(band + (size_t)(tri[I] + (I - (k0 + c))) * NB2, sy[c], r, q4);
+    if (q4 == 0) b[(size_t)I * NB + r] -= part;
+}
+// (L^T v)_c over the 16 rows 16 rq .. 16 rq + 15 of a tile: partial sums of the four row quarters, to be added by the caller
+__device__ __forceinline__ double mvt_part(const double* __restrict__ L, const double* __restrict__ v, int c, int rq) {
+    const double* Lc = L + (16 * rq) * NB + c;
+    double part = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) part += Lc[rr * NB] * v[16 * rq + rr];
+    return part;
+}
+__global__ __launch_bounds__(256) void bwd_group_kernel(const double* __restrict__ band, const double* __restrict__ linv, double* __restrict__ z, double* __restrict__ x,
+                                                        const long long* __restrict__ tri, int k0, int w) {
+    __shared__ double sz[4][NB], sx[4][NB], sp[4][NB];
+    const int tid = threadIdx.x, c = tid & 63, rq = tid >> 6, g = blockIdx.x;
+    for (int q = tid; q < w * NB; q += 256) sz[q >> 6][q & 63] = z[(size_t)k0 * NB + q];
+    __syncthreads();
+    for (int cc = w - 1; cc >= 0; --cc) {
+        sp[rq][c] = mvt_part(linv + (size_t)(k0 + cc) * NB2, sz[cc], c, rq);
+        __syncthreads();
+        if (tid < NB) sx[cc][tid] = sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+        __syncthreads();
+        for (int c2 = cc - 1; c2 >= 0; --c2) {
+            sp[rq][c] = mvt_part(band + (size_t)(tri[k0 + cc] + (cc - c2)) * NB2, sx[cc], c, rq);
+            __syncthreads();
+            if (tid < NB) sz[c2][tid] -= sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+            __syncthreads();
+        }
+    }
+    if (g == 0) { for (int q = tid; q < w * NB; q += 256) x[(size_t)k0 * NB + q] = sx[q >> 6][q & 63]; return; }
+    const int J = k0 - g;
+    double part = 0.0;
+    for (int cc = 0; cc < w; ++cc) part += mvt_part(band + (size_t)(tri[k0 + cc] + (k0 + cc - J)) * NB2, sx[cc], c, rq);
+    sp[rq][c] = part;
+    __syncthreads();
+    if (tid < NB) z[(size_t)J * NB + tid] -= sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+}
+
 __global__ void permute_in_kernel(long long ncp, const int* __restrict__ newi, const double* __restrict__ src, double* __restrict__ dst) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 3 * ncp) dst[3 * (long long)newi[t / 3] + t % 3] = src[t];
@@ -751,8 +819,10 @@ static void nd_forward_front(gfs_handle* h, int t, hipStream_t st, int si) {
         const Front& Fc = h->fronts[c];
         if (Fc.nb_cp > 0) hipLaunchKernelGGL(nd_pull_child_kernel, dim3((unsigned)((3 * Fc.nb_cp + 255) / 256)), dim3(256), 0, st, Fc, F, h->d_pmap, h->fbnd, h->s_b[si]);
     }
-    for (int k = 0; k < F.nblk_e; ++k)
-        hipLaunchKernelGGL(fwd_kernel, dim3(F.nblk_t - k), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, h->s_b[si], h->s_y[si], h->d_tri, k);
+    for (int k0 = 0; k0 < F.nblk_e; k0 += 4) {
+        const int w = std::min(4, F.nblk_e - k0);
+        hipLaunchKernelGGL(fwd_group_kernel, dim3(1 + F.nblk_t - (k0 + w)), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, h->s_b[si], h->s_y[si], h->d_tri, k0, w);
+    }
     hipLaunchKernelGGL(nd_scatter_fwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->s_y[si], h->s_b[si], h->gy, h->fbnd);
 }
 static void nd_backward_front(gfs_handle* h, int t, hipStream_t st, int si) {
@@ -762,8 +832,10 @@ static void nd_backward_front(gfs_handle* h, int t, hipStream_t st, int si) {
     hipLaunchKernelGGL(nd_gather_bwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->d_bnd, h->gy, h->gx, h->dval, h->s_z[si], h->s_x[si]);
     if (F.nblk_t > F.nblk_e && F.nblk_e > 0)
         hipLaunchKernelGGL(nd_bwd_bnd_kernel, dim3(F.nblk_e), dim3(256), 0, st, band, h->d_tri, F.nblk_e, F.nblk_t, h->s_x[si], h->s_z[si]);
-    for (int k = F.nblk_e - 1; k >= 0; --k)
-        hipLaunchKernelGGL(bwd_kernel, dim3(k + 1), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, h->s_z[si], h->s_x[si], h->d_tri, k);
+    for (int k0 = ((F.nblk_e - 1) / 4) * 4; k0 >= 0; k0 -= 4) {
+        const int w = std::min(4, F.nblk_e - k0);
+        hipLaunchKernelGGL(bwd_group_kernel, dim3(1 + k0), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, h->s_z[si], h->s_x[si], h->d_tri, k0, w);
+    }
     hipLaunchKernelGGL(nd_scatter_bwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->s_x[si], h->gx, 0);
 }
 // bottom-up sweep: the independent subtrees on their streams (forked behind the main stream's earlier work), then the top fronts on the main stream
