@@ -51,9 +51,9 @@ def nested_dissection(nb_ptr, nb, coords, leaf=192):
     splits all regions of the current level with array operations over the edge list."""
     ncp = nb_ptr.size - 1
     X = np.asarray(coords, float).reshape(ncp, -1)
-    rows = np.repeat(np.arange(ncp, dtype=np.int64), np.diff(nb_ptr))
-    cols = np.asarray(nb, np.int64)
-    keep = rows != cols
+    rows = np.repeat(np.arange(ncp, dtype=np.int32), np.diff(nb_ptr))      # 32-bit indices: the passes below are gathers over the edge list (66 M edges at C4)
+    cols = np.asarray(nb, np.int32)
+    keep = rows < cols                                                    # the pattern is symmetric: one direction per edge, both tested below
     rows, cols = rows[keep], cols[keep]
     region = np.zeros(ncp, np.int64)              # tree node (heap numbering: children of r are 2 r + 1, 2 r + 2) a control point currently lies in
     done = np.zeros(ncp, bool)                    # True: the control point has its final tree node (a separator or a leaf)
@@ -87,15 +87,21 @@ def nested_dissection(nb_ptr, nb, coords, leaf=192):
         side = (rank >= (count[seg] + 1) // 2)                         # False: first half (A), True: second half (B)
         side_of = np.zeros(ncp, np.int8)
         side_of[act] = side.astype(np.int8) + 1                        # 1: A, 2: B, 0: not in a region that is being split
-        # separator: control points of A coupled to a control point of B of the same region
-        m = (side_of[rows] == 1) & (side_of[cols] == 2) & (region[rows] == region[cols]) & ~done[rows] & ~done[cols]
+        # separator: control points of A coupled to a control point of B of the same region.  The edge list only holds edges whose ends are both
+        # still active and in the same region (pruned at the end of every pass), so the test is on the sides alone
+        sr, sc = side_of[rows], side_of[cols]
         sep = np.zeros(ncp, bool)
-        sep[rows[m]] = True
+        sep[rows[(sr == 1) & (sc == 2)]] = True
+        sep[cols[(sr == 2) & (sc == 1)]] = True
         is_sep = sep[act]
         node_of[act[is_sep]] = uniq[seg[is_sep]]
         done[act[is_sep]] = True
         rest = ~is_sep
         region[act[rest]] = 2 * uniq[seg[rest]] + 1 + side[rest]
+        live = ~(done[rows] | done[cols])
+        rows, cols = rows[live], cols[live]
+        live = region[rows] == region[cols]
+        rows, cols = rows[live], cols[live]
     # post-order of the tree nodes that own control points; heap numbering gives parents by (r - 1) // 2
     nodes = np.unique(node_of)
     present = set(int(r) for r in nodes)
@@ -139,14 +145,11 @@ def nested_dissection(nb_ptr, nb, coords, leaf=192):
     nb_ptr = np.asarray(nb_ptr, np.int64)
     nbl = np.asarray(nb, np.int64)
     # the later-eliminated neighbours of every front's own control points, for all fronts at once: edges (a, b) with order[b] beyond the subtree of front_of[a]
-    ra = np.repeat(np.arange(ncp, dtype=np.int64), np.diff(nb_ptr))
-    later = order[nbl] >= hi[front_of[ra]]
-    ef, eb = front_of[ra[later]], nbl[later]
-    o2 = np.lexsort((order[eb], ef))
-    ef, eb = ef[o2], eb[o2]
-    keep = np.ones(ef.size, bool)
-    keep[1:] = (ef[1:] != ef[:-1]) | (eb[1:] != eb[:-1])
-    ef, eb = ef[keep], eb[keep]
+    thr = hi[front_of]                                                     # per control point: first elimination position outside its front's subtree
+    later = order[nbl] >= np.repeat(thr, np.diff(nb_ptr))
+    ea = np.repeat(np.arange(ncp, dtype=np.int64), np.diff(nb_ptr))[later]
+    key = np.unique(front_of[ea] * np.int64(ncp) + order[nbl[later]])      # (front, elimination position of the neighbour): sorted, duplicates dropped
+    ef, eb = key // ncp, elim[key % ncp]
     own_off = np.concatenate([[0], np.cumsum(np.bincount(ef, minlength=nf))]).astype(np.int64)
     for t in range(nf):
         cand = eb[own_off[t]:own_off[t + 1]]                    # sorted by elimination order, unique
