@@ -106,7 +106,7 @@ class _FakeSolver:
     def __init__(self, D, x, rr):
         self.D, self.x, self.rel_residual, self.backward_error, self.closed = D, x, rr, rr, False
 
-    def solve(self, b):
+    def solve(self, b, transpose=False):
         return self.x(b)
 
     def refactor(self):
