@@ -274,7 +274,12 @@ def main():
                               "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "note": "the tangent / shape-Jacobian contraction is FP64 bound (SURVEY.md 8(d)); "
                                       "this is the binding roofline of the dominant kernel; flop count = the formulation's "
-                                      "FMA*2 per Gauss-point update (DESIGN.md section 4), not hardware-issued flops"},
+                                      "FMA*2 per Gauss-point update (DESIGN.md section 4), not hardware-issued flops",
+                              # what the pipe sustains on this GPU (tools/ubench_acc, ubench_batch, ubench_f64 -> profiles/r03_ubench_fp64_mfma.txt): not a second peak,
+                              # the explanation of where the kernel sits against the data-sheet figure above
+                              "pipe_measured": {"v_mfma_f64_16x16x4_vgpr_accumulators_tflops": 74.0, "v_mfma_f64_16x16x4_agpr_accumulators_tflops_one_wave_per_simd": 36.0,
+                                                "v_mfma_f64_16x16x4_agpr_accumulators_tflops_two_waves_per_simd": 45.0, "v_fma_f64_tflops": 56.0,
+                                                "mfma_and_fp64_valu_co_execute": False}},
             "apply_linear_roofline": apply,
             "newton_pass": {"what": "R + K only (one Newton iteration of solve_nonlinear), rank 0's share", "ms": newton_ms},
             "device_bytes": D.device_bytes,
