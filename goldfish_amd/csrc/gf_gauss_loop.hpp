@@ -38,6 +38,15 @@ template <int LANE, int J> __device__ __forceinline__ double row_dot(const doubl
     fmac_bcast<LANE>(t, g[12 + J], p[4]);
     return t;
 }
+// the same for a CURVATURE row (m >= 2) of G / Hc: its curvature columns are rank one in the components -- G[(2 + k, i), (2 + c, j)] = n_i n_j f_k f_c (J t^3 C)_kc,
+// Hc: n_i (n_j - N_j) ... (kl_point.hpp:310, 327) -- so that part of the dot product is one product of two per-lane factors (t0) and only the two tangent
+// columns come from the row's lane: a multiply and two DPP FMAs instead of an initialising move and five
+template <int LANE, int J> __device__ __forceinline__ double row_dot2(double t0, const double (&g)[15], const double (&p)[5]) {
+    double t = t0;
+    fmac_bcast<LANE>(t, g[J], p[0]);
+    fmac_bcast<LANE>(t, g[3 + J], p[1]);
+    return t;
+}
 // The row registers are written by VALU instructions and read through DPP by inline assembly the hazard recogniser cannot
 // see: tying them to a 2-wait-state nop keeps every producer in front of it and every DPP read behind it.
 __device__ __forceinline__ void dpp_source_fence(double (&g)[15]) {
@@ -271,12 +280,32 @@ __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, 
     // The B operands of all components of one m are formed as independent FMA chains before their MFMAs are issued (a single
     // chain -> MFMA -> chain sequence serialises on the shared FP64 pipe).
     constexpr int QI[6] = {0, 0, 0, 1, 1, 2}, QJ[6] = {0, 1, 2, 1, 2, 2};
+    // curvature rows: psi_k = f_k sum_c f_c (J t^3 C)_kc w phi_b,2+c (f = 1, 1, 2) and the products of the normals, per lane
+    double psi[3], nn[6], nnb[9];
+    if (doK || doC) {
+        const double ct[6] = {im[IM_CT3], im[IM_CT3 + 1], im[IM_CT3 + 2], im[IM_CT3 + 3], im[IM_CT3 + 4], im[IM_CT3 + 5]};
+        const double nv[3] = {im[IM_N], im[IM_N + 1], im[IM_N + 2]};
+        const double p4 = 2.0 * pb[4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) psi[k] = (k == 2 ? 2.0 : 1.0) * (ct[sym3(k, 0)] * pb[2] + ct[sym3(k, 1)] * pb[3] + ct[sym3(k, 2)] * p4);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) nn[q] = nv[QI[q]] * nv[QJ[q]];
+        if constexpr (WITHC) {
+            const double dn[3] = {nv[0] - im[IM_NB], nv[1] - im[IM_NB + 1], nv[2] - im[IM_NB + 2]};
+#pragma unroll
+            for (int q = 0; q < 9; ++q) nnb[q] = nv[q / 3] * dn[q % 3];
+        }
+    }
     GF_GROUP_STAMP(4);
     if (doK) {
         static_for<5>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
             double tq[6];
-            static_for<6>([&](auto q_) { constexpr int q = decltype(q_)::value; tq[q] = row_dot<3 * m + QI[q], QJ[q]>(gR, pb); });
+            static_for<6>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                if constexpr (m < 2) tq[q] = row_dot<3 * m + QI[q], QJ[q]>(gR, pb);
+                else tq[q] = row_dot2<3 * m + QI[q], QJ[q]>(nn[q] * psi[m - 2], gR, pb);
+            });
             mfma_hazard_gap(tq);
 #pragma unroll
             for (int q = 0; q < 6; ++q) accK[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], tq[q], accK[q], 0, 0, 0);
@@ -287,7 +316,11 @@ __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, 
         static_for<5>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
             double tq[9];
-            static_for<9>([&](auto q_) { constexpr int q = decltype(q_)::value; tq[q] = row_dot<3 * m + q / 3, q % 3>(hR, pb); });
+            static_for<9>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                if constexpr (m < 2) tq[q] = row_dot<3 * m + q / 3, q % 3>(hR, pb);
+                else tq[q] = row_dot2<3 * m + q / 3, q % 3>(nnb[q] * psi[m - 2], hR, pb);
+            });
             mfma_hazard_gap(tq);
 #pragma unroll
             for (int q = 0; q < 9; ++q) accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], tq[q], accC[q], 0, 0, 0);
