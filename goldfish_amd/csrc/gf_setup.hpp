@@ -474,7 +474,20 @@ inline void HostModel::build_rec(int seg_len) {
     // too small to fill the device that way -- then the strips are cut until there are a few items per SIMD
     int64_t nstrips = 0;
     for (int s = 0; s < n_owned; ++s) nstrips += patches[s].nelu;
-    const int cut = seg_len > 0 ? 1 : int(std::min<int64_t>(64, (4 * 1024 + nstrips - 1) / std::max<int64_t>(nstrips, 1)));
+    // (one wave per SIMD = 1024 items in flight on MI355X: the launch runs in rounds, and a last round that is half empty costs as much as a full one -- among the
+    //  cuts that give at least ~4 items per SIMD the one with the fullest rounds is taken, e.g. one GPU's eighth of C4, 1 536 strips: 2 x 1 536 = 3 full rounds
+    //  rather than 3 x 1 536 = 4.5)
+    int cut = 1;
+    if (seg_len <= 0) {
+        const int64_t slots = 1024, ns = std::max<int64_t>(nstrips, 1);
+        const int c0 = int(std::min<int64_t>(64, (2 * slots + ns - 1) / ns)), c1 = int(std::min<int64_t>(64, (4 * slots + ns - 1) / ns));
+        double best = -1.0;
+        for (int c = c0; c <= std::max(c0, c1); ++c) {
+            const int64_t items = ns * c, rounds = (items + slots - 1) / slots;
+            const double eff = double(items) / double(rounds * slots) - 0.01 * (c - c0);          // fuller rounds first, fewer segments among equals
+            if (eff > best) { best = eff; cut = c; }
+        }
+    }
     for (int s = 0; s < n_owned; ++s) {
         const PatchDev& P = patches[s];
         int nseg = seg_len > 0 ? std::max(1, (P.nelv + seg_len / 2) / std::max(seg_len, P1)) : cut;
