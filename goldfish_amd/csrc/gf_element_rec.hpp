@@ -26,7 +26,7 @@ template <bool WITHC> struct RecCfg { static constexpr int NT = WITHC ? 18 : 9, 
 
 struct RecOut { double* rec; double* rblk; int rec_rows; };
 
-template <int P, bool WITHC = true>
+template <int P, bool WITHC = true, bool ALLF = false>      // ALLF: flags = R + K + dR/dCP + dR/dh known at compile time (gauss_group)
 __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const WalkItem* __restrict__ items, int flags, RecOut O) {
     static_assert(P == 2 || P == 3, "one 16 x 16 tile: p <= 3");
     using RC = RecCfg<WITHC>;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
             const int gp = 4 * grp + kk, gpc = gp < NG ? gp : NG - 1, gu = gpc % P1, gv = gpc / P1;   // Gauss point of this lane's group
             const double* im = s_im[gpc];
             const double wq = gp < NG ? im[IM_WQ] : 0.0;        // padded Gauss-point slots contribute nothing
-            gauss_group<P, WITHC>(L, im, wq, s_tu, tv, gu, gv, jubc, jvc, bval, doK, doC, doH, has_bf, pf, ppd, accK, accC, accH, accB, accR GF_GROUP_STAMP_ARGS);
+            gauss_group<P, WITHC, ALLF>(L, im, wq, s_tu, tv, gu, gv, jubc, jvc, bval, doK, doC, doH, has_bf, pf, ppd, accK, accC, accH, accB, accR GF_GROUP_STAMP_ARGS);
         }
         if (has_bf && doC) {
 #pragma unroll

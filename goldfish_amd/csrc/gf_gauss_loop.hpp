@@ -204,6 +204,42 @@ struct RowLane {
             }
         }
     }
+    // the same expansion in two steps, for the full-pass instance of gauss_group: the row of G first (what the K batches read), the row of Hc = G + PzZ
+    // later (from the row of G and ten scalars), so that the second step can be issued between the K MFMAs
+    struct Mid { double e0, e1, e2, b0, b1, b2, pzr, gam[3]; };
+    __device__ __forceinline__ void expand_g(const double* im, const Pre& q, double (&gR)[15], Mid& M) const {
+        const double gr = q.gr;
+        M.e0 = m0 * gr; M.e1 = m1 * gr; M.e2 = mt * q.e2r;
+        const double fnr = f3c * q.nir;
+        M.b0 = mt * q.bg0 + ck[0] * fnr; M.b1 = mt * q.bg1 + ck[1] * fnr; M.b2 = mt * q.bg2 + ck[2] * fnr;
+        M.pzr = q.pzr;
+        const double xfac = mt + (1.0 - mt) * q.jmof;
+        const double jn[2] = {q.jn0, q.jn1};
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+            gR[s] = M.e0 * im[IM_CEZ + s] + M.e1 * im[IM_CEZ + 6 + s] + M.e2 * im[IM_CEZ + 12 + s]
+                  + M.b0 * im[IM_CBG + s] + M.b1 * im[IM_CBG + 6 + s] + M.b2 * im[IM_CBG + 12 + s] - xfac * q.ox[s] + dij[s % 3] * jn[s / 3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double fc = (c == 2) ? 2.0 : 1.0;
+            M.gam[c] = fc * (M.b0 * im[IM_CT3 + sym3(0, c)] + M.b1 * im[IM_CT3 + sym3(1, c)] + M.b2 * im[IM_CT3 + sym3(2, c)]);
+            const double alpha = mt * (fc * im[IM_CBG + 6 * c + rt]) + (1.0 - mt) * M.gam[c], beta = mt * im[IM_JMOF + c];
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) gR[6 + 3 * c + jj] = im[IM_N + jj] * alpha - beta * im[IM_DN + 6 * jj + rt];
+        }
+    }
+    __device__ __forceinline__ void expand_h(const double* im, const Mid& M, const double (&gR)[15], double (&hR)[15]) const {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const double zz = M.pzr * im[IM_JZJ + s] + M.e0 * im[IM_JDNV + s] + M.e1 * im[IM_JDNV + 6 + s] + M.e2 * im[IM_JDNV + 12 + s]
+                            - (M.b0 * im[IM_JDMO + s] + M.b1 * im[IM_JDMO + 6 + s] + M.b2 * im[IM_JDMO + 12 + s]);
+            hR[s] = gR[s] + zz;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) hR[6 + 3 * c + jj] = gR[6 + 3 * c + jj] - M.gam[c] * im[IM_NB + jj];
+    }
 };
 
 // ---- one group of 4 Gauss points: the lane's Gauss point is 4 grp + kk (record im, weight wq = 0 on a padded slot), its basis
@@ -219,11 +255,14 @@ struct RowLane {
 #define GF_GROUP_STAMP_ARGS
 #define GF_GROUP_STAMP(slot) do { } while (0)
 #endif
-template <int P, bool WITHC>
+// ALLF: the full pass (R + K + dR/dCP + dR/dh) as a compile-time fact -- the flags then fold away and the whole group step is ONE basic block, which lets the
+// scheduler move the plain FP64 work (residual / dR/dh prefactors, issued behind the first K batch) in between the MFMAs, into the unused part of their issue slots
+template <int P, bool WITHC, bool ALLF = false>
 __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, double wq, const double* tu, const double* tv, int gu, int gv,
-                                            int ju, int jv, double bval, bool doK, bool doC, bool doH, bool has_bf, const double* pf, const double* ppd,
+                                            int ju, int jv, double bval, bool doK_, bool doC_, bool doH_, bool has_bf, const double* pf, const double* ppd,
                                             gf_d4 (&accK)[6], gf_d4 (&accC)[9], gf_d4 (&accH)[3], gf_d4 (&accB)[3], double (&accR)[3] GF_GROUP_STAMP_PARAMS) {
     constexpr int P1 = P + 1;
+    const bool doK = ALLF || doK_, doC = (ALLF && WITHC) || doC_, doH = ALLF || doH_;
     // -- every load the basis function and the row expansion start from, in one batch (RowLane::load)
     const double u0 = tu[(gu * 3 + 0) * P1 + ju], u1 = tu[(gu * 3 + 1) * P1 + ju], u2 = tu[(gu * 3 + 2) * P1 + ju];
     const double v0 = tv[(gv * 3 + 0) * P1 + jv], v1 = tv[(gv * 3 + 1) * P1 + jv], v2 = tv[(gv * 3 + 2) * P1 + jv];
@@ -246,23 +285,29 @@ __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, 
     // -- row r of G and Hc at this Gauss point; entry (m', j) at [3 m' + j]
     double gR[15], hR[15];
     for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
-    if (doK || doC) {
+    RowLane::Mid mid;
+    if constexpr (ALLF) {
+        L.expand_g(im, pre, gR, mid);
+        dpp_source_fence(gR);
+    } else if (doK || doC) {
         L.template expand<WITHC>(im, pre, gR, hR);
         dpp_source_fence(gR);
         if constexpr (WITHC) dpp_source_fence(hR);
     }
     GF_GROUP_STAMP(3);
-    // -- residual and dR/dh prefactors of the lane's basis function at this Gauss point
+    // -- residual and dR/dh prefactors of the lane's basis function at this Gauss point (ALLF: issued behind the first K batch, see above)
+    double pb[5];
+    for (int m = 0; m < 5; ++m) pb[m] = wq * phi[m];
+    auto prefactors = [&]() {
     {
-        const double ls = has_bf ? load_scalar(im, ppd) : 0.0;
+        // ALLF: no branch on the load (pf = 0 without one: the product vanishes)
+        const double ls = ALLF ? load_scalar(im, ppd) : (has_bf ? load_scalar(im, ppd) : 0.0);
         for (int i = 0; i < 3; ++i) {
             double rz = 0.0;
             for (int m = 0; m < 5; ++m) rz += phi[m] * im[IM_PZ + 3 * m + i];
             accR[i] += wq * (rz - ls * pf[i] * R0);
         }
     }
-    double pb[5];
-    for (int m = 0; m < 5; ++m) pb[m] = wq * phi[m];
     if (doH) {
         double nn = 0.0;
         for (int k = 0; k < 3; ++k) nn += phi[2 + k] * im[IM_JCK4 + k] * (k == 2 ? 2.0 : 1.0);
@@ -275,6 +320,8 @@ __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, 
             accH[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wq * rh, n0, accH[i], 0, 0, 0);
         }
     }
+    };
+    if constexpr (!ALLF) prefactors();
     // -- contraction: one MFMA per (component, m); the B operand T_b is formed from the expanded row on the fly.
     // K component (i, j), m: T_b = w sum_m' G[(m,i),(m',j)] phi_b[m'] -- the five entries are gR[3 m' + j] of lane 3 m + i.
     // The B operands of all components of one m are formed as independent FMA chains before their MFMAs are issued (a single
@@ -309,6 +356,8 @@ __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, 
             mfma_hazard_gap(tq);
 #pragma unroll
             for (int q = 0; q < 6; ++q) accK[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[m], tq[q], accK[q], 0, 0, 0);
+            if constexpr (ALLF && m == 0) prefactors();
+            if constexpr (ALLF && WITHC && m == 1) { L.expand_h(im, mid, gR, hR); dpp_source_fence(hR); }
         });
     }
     GF_GROUP_STAMP(5);

@@ -331,7 +331,9 @@ template <int P> static void run_assemble_rec(gf_handle* h, int flags) {
     const RecOut O{h->d_rec, h->d_blk, H.rec_rows};
     const int slot = h->ev_n % 64, n = (int)H.rec_items.size();
     HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
-    if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_rec_kernel<PW, true>), dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_rec_items, flags, O);
+    constexpr int ALL_BITS = GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP | GF_ASM_DRDH;
+    if ((flags & ALL_BITS) == ALL_BITS) hipLaunchKernelGGL((kl_element_rec_kernel<PW, true, true>), dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_rec_items, flags, O);
+    else if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_rec_kernel<PW, true>), dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_rec_items, flags, O);
     else hipLaunchKernelGGL((kl_element_rec_kernel<PW, false>), dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_rec_items, flags, O);
     HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
     h->ev_n++;
