@@ -112,14 +112,15 @@ ND_MIN_CP = int(os.environ.get("GF_SOLVER_ND_MIN_CP", "5000"))     # models with
 class DeviceSolver:
     """K x = b and K^T x = b with the K of a goldfish_amd._lib.DeviceModel; factors resident in HBM.  ``general`` (a K that is not symmetric: the
     load stiffness of a follower pressure): the symmetric part is factored and preconditions the refinement against K / K^T itself
-    (gfs_set_general); ``max_refine`` then defaults to 15 steps instead of 3.
+    (gfs_set_general); ``max_refine`` then defaults to 40 steps instead of 3 (the refinement is the solver for the skew part and stops by itself when the
+    residual no longer drops).
     ``method``: "skyline" (block skyline after RCM: small and medium models), "nd" (nested-dissection multifrontal: goldfish_amd/_nd.py +
     gfs_create_nd; needs the control points' coordinates), "auto": nd above ND_MIN_CP control points."""
 
     def __init__(self, dev_model, max_refine=None, coords=None, method="auto", leaf=256, general=False):
         from . import _lib
         self.general = bool(general)
-        self.D, self.max_refine = dev_model, (15 if general else 3) if max_refine is None else max_refine
+        self.D, self.max_refine = dev_model, (40 if general else 3) if max_refine is None else max_refine
         rowptr, col = dev_model.pattern(_lib.MAT_K)
         self.nb_ptr, self.nb = control_point_graph(rowptr, col)
         del rowptr, col

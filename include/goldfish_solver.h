@@ -51,7 +51,7 @@ int gfs_solve_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine,
  * factors the SYMMETRIC PART (K + K^T) / 2 and the solves use it as the preconditioner of the iterative refinement, whose residual is taken with
  * K itself (gfs_solve*: K x = b) or with K^T (gfs_solve_transposed*: K^T x = b).  Converges when the skew part is small against the symmetric
  * part (refinement contracts by |S^-1 (K - S)|); the returned residual and gfs_info's backward error say whether it did -- give max_refine
- * room (10 - 20).  With general mode off (the default) the transposed solves are the plain ones. */
+ * room (40: the loop ends by itself when the residual no longer drops).  With general mode off (the default) the transposed solves are the plain ones. */
 int gfs_set_general(gfs_handle* h, int nonsymmetric);
 int gfs_solve_transposed(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual);
 int gfs_solve_transposed_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual);

@@ -431,6 +431,33 @@ def test_device_linear_solver_nested_dissection_against_superlu():
         assert err < max(1e-9, 20 * self_err), (ndof, err, self_err)
 
 
+def test_device_solver_general_mode_in_both_factorisations():
+    """gfs_set_general (a K that is not symmetric: the load stiffness of a follower pressure) in the skyline AND in the nested-dissection mode:
+    factors of the symmetric part, refinement against K (gfs_solve) or K^T (gfs_solve_transposed) through the device-built reverse index --
+    both systems of the pressurised ring at hoop strain 0.3 against the assembled matrix, and the two must differ."""
+    from goldfish_amd import _solver
+    from goldfish_amd.nonmatching_opt import NonMatchingOpt
+    nm = NonMatchingOpt.from_spec(G.pressurised_tube(pressure=3.0e6, E=1.0e9))
+    nm.solve_nonlinear_nonmatching_problem(rtol=1e-9, max_it=30)
+    nm._assemble(3)
+    K = nm.dRIGAduIGA()
+    assert abs(K - K.T).max() > 1e-8 * abs(K).max()
+    b = np.random.default_rng(5).standard_normal(nm.vec_iga_dof)
+    w = np.concatenate([sp_.cp_hom_flat()[:, 3] for sp_ in nm.splines])
+    X = np.stack([nm.cp_iga[f] / w for f in range(3)], 1)
+    for method, kw in (("skyline", {}), ("nd", dict(leaf=48))):
+        S = _solver.DeviceSolver(nm.dev, coords=X, method=method, general=True, **kw)
+        x = S.solve(b)
+        assert _rel(K @ x, b) < 1e-8 and S.backward_error < 1e-12, (method, S.rel_residual, S.backward_error)
+        xt = S.solve(b, transpose=True)
+        assert _rel(K.T @ xt, b) < 1e-8 and _rel(K @ xt, b) > 1e-6, method
+        S.close()
+    # a symmetric-mode handle on the same matrix factors the lower triangle only: its refinement still runs against K itself, the transposed solve is the plain one
+    S = _solver.DeviceSolver(nm.dev, coords=X, method="skyline")
+    assert np.array_equal(S.solve(b), S.solve(b, transpose=True))
+    S.close()
+
+
 def test_device_solver_is_the_default_newton_and_adjoint_path():
     """solve_nonlinear / solve_linear run on the device solver by default (GOLDFISH/operations/disp_imop.py:38-44, 130-142);
     ``linear_solver = "host"`` (SuperLU on a copy of K) gives the same Newton solution and adjoint."""
