@@ -269,9 +269,7 @@ __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, 
     const double Wl[6] = {im[IM_W], im[IM_W + 1], im[IM_W + 2], im[IM_W + 3], im[IM_W + 4], im[IM_W + 5]};
     RowLane::Pre pre;
     if (doK || doC) pre = L.load(im);
-#ifndef GF_NO_LOAD_BATCH
     __builtin_amdgcn_sched_barrier(0);
-#endif
     // -- basis function of the lane at this Gauss point (registers)
     double phi[5], R0, n0;
     {
