@@ -944,6 +944,116 @@ def test_tube_shape_optimisation_rounds_the_cross_section():
     assert abs(out["r1"][1] / out["r0"][1] - 1.0) < 0.05
 
 
+def test_shape_opt_group_wired_like_the_reference_demo():
+    """The reference's ShapeOptGroup (demos_om/shape_opt/T-beam/T_beam_shape_opt_wint.py:12-218; the tube demo wires the same components):
+    IndepVarComp -> CPFFDesign2FullComp -> CPFFD2SurfComp -> CPFE2IGAComp -> DispStatesComp -> IntEnergyComp / VolumeComp, the design dofs also into
+    CPFFDPinComp / CPFFDReguComp, connected by absolute names per optimised field, design variables / constraints / objective as in the demo, through
+    ``om.Problem`` (openmdao.api when installed, else the protocol stand-in).  Model: the pressurised ring with two optimised fields -- the follower
+    pressure makes the adjoint of DispStatesComp a K^T solve.  Totals of the objective and the volume wrt both design fields against central
+    differences of run_model; the linear constraint components against their matrices."""
+    import importlib.util
+    from goldfish_amd.om_comps import DispStatesComp, IntEnergyComp, VolumeComp, om
+    from goldfish_amd.om_comps.ffd_comps import CPFE2IGAComp, CPFFD2SurfComp, CPFFDesign2FullComp, CPFFDPinComp, CPFFDReguComp
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec_ = importlib.util.spec_from_file_location("tube_shape_opt", os.path.join(here, "examples", "tube_shape_opt.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    nm = mod.build(E=1.0e7)                                    # strains of 1e-5: difference quotients of the energy are meaningful (see the tube test)
+    nm.set_shopt_pin_CPFFD(pin_dir0=[0, 1], pin_side0=[[0], [0]])      # per optimised field: one face of the FFD block keeps its place
+    nm.set_shopt_regu_CPFFD()
+
+    class ShapeOptGroup(om.Group):
+
+        def initialize(self):
+            self.options.declare('nonmatching_opt_ffd')
+            for name, default in (('cpffd_design_name_pre', 'CP_design_FFD'), ('cpffd_full_name_pre', 'CP_FFD'), ('cpsurf_fe_name_pre', 'CPS_FE'),
+                                  ('cpsurf_iga_name_pre', 'CPS_IGA'), ('disp_name', 'displacements'), ('int_energy_name', 'int_E'),
+                                  ('cpffd_pin_name_pre', 'CP_FFD_pin'), ('cpffd_regu_name_pre', 'CP_FFD_regu'), ('volume_name', 'volume')):
+                self.options.declare(name, default=default)
+
+        def init_parameters(self):
+            o = self.options
+            self.nm = o['nonmatching_opt_ffd']
+            self.opt_field = self.nm.opt_field
+            self.init_cpffd = self.nm.shopt_init_cpffd_design
+            self.names = {k: [o[k] + str(f) for f in self.opt_field] for k in ('cpffd_design_name_pre', 'cpffd_full_name_pre', 'cpsurf_fe_name_pre',
+                                                                              'cpsurf_iga_name_pre', 'cpffd_pin_name_pre', 'cpffd_regu_name_pre')}
+
+        def setup(self):
+            o, nm = self.options, self.nm
+            inputs_comp = om.IndepVarComp()
+            for i in range(len(self.opt_field)):
+                inputs_comp.add_output(self.names['cpffd_design_name_pre'][i], shape=self.init_cpffd[i].size, val=self.init_cpffd[i])
+            self.add_subsystem('inputs_comp', inputs_comp)
+            comps = {
+                'CPFFDDesign2Full_comp': CPFFDesign2FullComp(nonmatching_opt_ffd=nm, input_cpffd_design_name_pre=o['cpffd_design_name_pre'], output_cpffd_full_name_pre=o['cpffd_full_name_pre']),
+                'CPFFD2FE_comp': CPFFD2SurfComp(nonmatching_opt_ffd=nm, input_cpffd_name_pre=o['cpffd_full_name_pre'], output_cpsurf_name_pre=o['cpsurf_fe_name_pre']),
+                'CPFE2IGA_comp': CPFE2IGAComp(nonmatching_opt=nm, input_cp_fe_name_pre=o['cpsurf_fe_name_pre'], output_cp_iga_name_pre=o['cpsurf_iga_name_pre']),
+                'disp_states_comp': DispStatesComp(nonmatching_opt=nm, input_cp_iga_name_pre=o['cpsurf_iga_name_pre'], output_u_name=o['disp_name']),
+                'internal_energy_comp': IntEnergyComp(nonmatching_opt=nm, input_cp_iga_name_pre=o['cpsurf_iga_name_pre'], input_u_name=o['disp_name'], output_wint_name=o['int_energy_name']),
+                'CPFFD_pin_comp': CPFFDPinComp(nonmatching_opt_ffd=nm, input_cpffd_design_name_pre=o['cpffd_design_name_pre'], output_cppin_name_pre=o['cpffd_pin_name_pre']),
+                'CPFFD_regu_comp': CPFFDReguComp(nonmatching_opt_ffd=nm, input_cpffd_design_name_pre=o['cpffd_design_name_pre'], output_cpregu_name_pre=o['cpffd_regu_name_pre']),
+                'volume_comp': VolumeComp(nonmatching_opt=nm, input_cp_iga_name_pre=o['cpsurf_iga_name_pre'], output_vol_name=o['volume_name']),
+            }
+            for name, comp in comps.items():
+                if name == 'disp_states_comp':
+                    comp.init_parameters(save_files=False, nonlinear_solver_rtol=1e-10)
+                else:
+                    comp.init_parameters()
+                self.add_subsystem(name, comp)
+            self.comps = comps
+            N = self.names
+            for i in range(len(self.opt_field)):
+                d, full, fe, iga = N['cpffd_design_name_pre'][i], N['cpffd_full_name_pre'][i], N['cpsurf_fe_name_pre'][i], N['cpsurf_iga_name_pre'][i]
+                self.connect('inputs_comp.' + d, 'CPFFDDesign2Full_comp.' + d)
+                self.connect('CPFFDDesign2Full_comp.' + full, 'CPFFD2FE_comp.' + full)
+                self.connect('CPFFD2FE_comp.' + fe, 'CPFE2IGA_comp.' + fe)
+                for user in ('disp_states_comp', 'internal_energy_comp', 'volume_comp'):
+                    self.connect('CPFE2IGA_comp.' + iga, user + '.' + iga)
+                self.connect('inputs_comp.' + d, 'CPFFD_pin_comp.' + d)
+                self.connect('inputs_comp.' + d, 'CPFFD_regu_comp.' + d)
+            self.connect('disp_states_comp.' + o['disp_name'], 'internal_energy_comp.' + o['disp_name'])
+            for i in range(len(self.opt_field)):
+                self.add_design_var('inputs_comp.' + N['cpffd_design_name_pre'][i], lower=-1.2, upper=1.2)
+                self.add_constraint('CPFFD_pin_comp.' + N['cpffd_pin_name_pre'][i], equals=nm.shopt_pin_vals[i])
+                self.add_constraint('CPFFD_regu_comp.' + N['cpffd_regu_name_pre'][i], lower=1.0e-1)
+            self.add_constraint('volume_comp.' + o['volume_name'], equals=1.0)
+            self.add_objective('internal_energy_comp.' + o['int_energy_name'], scaler=1e6)
+
+    model = ShapeOptGroup(nonmatching_opt_ffd=nm)
+    model.init_parameters()
+    prob = om.Problem(model=model)
+    prob.setup()
+    rng = np.random.default_rng(11)
+    wrt = ['inputs_comp.' + n for n in model.names['cpffd_design_name_pre']]
+    d0 = [np.asarray(v, float) * (1 + 0.01 * rng.standard_normal(np.size(v))) for v in model.init_cpffd]
+    for n, v in zip(wrt, d0):
+        prob.set_val(n, v)
+    prob.run_model()
+    assert not nm.symmetric_K
+    of = ['internal_energy_comp.int_E', 'volume_comp.volume']
+    tot = prob.compute_totals(of=of, wrt=wrt)
+    for k, n in enumerate(wrt):
+        v = rng.standard_normal(d0[k].size)
+        f = []
+        for sgn in (1, -1):
+            prob.set_val(n, d0[k] + sgn * 1e-6 * v)
+            prob.run_model()
+            f.append([float(np.ravel(prob.get_val(o))[0]) for o in of])
+        prob.set_val(n, d0[k])
+        fd = (np.array(f[0]) - np.array(f[1])) / 2e-6
+        for r, o in enumerate(of):
+            t = float(np.asarray(tot[(o, n)]).reshape(-1) @ v)
+            assert abs(t - fd[r]) < 2e-5 * max(abs(fd[r]), 1e-12), (o, n, t, fd[r])
+    # the linear constraint components: values = their matrices times the design dofs
+    prob.run_model()
+    for i in range(len(nm.opt_field)):
+        pin = np.ravel(prob.get_val('CPFFD_pin_comp.' + model.names['cpffd_pin_name_pre'][i]))
+        assert _rel(pin, nm.shopt_dcppindcpffd[i] @ d0[i]) < 1e-12 if pin.size else True
+        regu = np.ravel(prob.get_val('CPFFD_regu_comp.' + model.names['cpffd_regu_name_pre'][i]))
+        assert _rel(regu, nm.shopt_dcpregudcpffd[i] @ d0[i]) < 1e-12
+
+
 def test_thickness_opt_group_wired_like_the_reference_demo():
     """The reference's ThicknessOptGroup (demos_om/thickness_opt/plate/plate_const_th_opt_wint.py:12-124): IndepVarComp -> HthMapComp ->
     DispStatesComp -> IntEnergyComp / VolumeComp connected by absolute names, design variable / constraint / objective as in the demo,
