@@ -894,3 +894,23 @@ def test_om_shim_groups_totals_and_strictness():
         g.connect(src, tgt) if exc is not ValueError or src != "imp.s" else g._conns.append((src, tgt))
         with pytest.raises(exc):
             om.Problem(model=g).setup()
+
+
+def test_traffic_tool_counts_every_kernel_of_a_pass_once():
+    """tools/traffic_from_pmc.py over the committed PMC CSVs: the p = 4 gather (no WITHC template argument) is in the full pass, only the
+    full-pass pen_owner instance is, per-launch averages do not mix full-pass and Newton-pass launches, and the step total is the sum of
+    the kernels the step launches (round-3 verdict, What's weak 4)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("traffic_from_pmc", os.path.join(ROOT, "tools", "traffic_from_pmc.py"))
+    T = importlib.util.module_from_spec(spec); spec.loader.exec_module(T)
+    out = T.build("r03_c5share_v2", 9012750, os.path.join(ROOT, "profiles"))
+    fp, K = out["full_pass_kernels"], out["kernels"]
+    assert "kl_gather_kernel<4>" in fp and "pen_owner_kernel<4, 3, true, true>" in fp and "pen_owner_kernel<4, 3, false, true>" not in fp
+    g = K["kl_gather_kernel<4>"]
+    assert (g["launches_full_pass"], g["launches_other"]) == (2, 5)
+    assert g["hbm_side_bytes_corrected_per_launch"] > 2.0 * g["other_pass_hbm_side_bytes_corrected_per_launch"]      # 50.9 vs 22.5 GB
+    assert abs(out["full_pass_bytes_per_step"] - sum(K[k]["hbm_side_bytes_corrected_per_launch"] for k in fp)) < 1.0
+    assert 90e9 < out["full_pass_bytes_per_step"] < 100e9
+    out3 = T.build("r03_v4", 9421968, os.path.join(ROOT, "profiles"))
+    assert "kl_gather_rec_kernel<3, true>" in out3["full_pass_kernels"] and "kl_gather_rec_kernel<3, false>" not in out3["full_pass_kernels"]
+    assert 33e9 < out3["full_pass_bytes_per_step"] < 36e9
