@@ -148,6 +148,7 @@ class DeviceSolver:
             raise RuntimeError(lib().gfs_last_error().decode())
         self.h = h
         self.rel_residual = self.backward_error = None
+        self.small_pivot = False
         if self.general and lib().gfs_set_general(self.h, 1):
             raise RuntimeError(lib().gfs_last_error().decode())
         self.refactor()                                       # numeric factors of the current K
@@ -175,7 +176,8 @@ class DeviceSolver:
         if fn(self.h, b.ctypes.data_as(dp), x.ctypes.data_as(dp), int(self.max_refine), C.byref(rr)):
             raise RuntimeError(lib().gfs_last_error().decode())
         self.rel_residual = rr.value
-        self.backward_error = self.info()["backward_error"]
+        inf = self.info()
+        self.backward_error, self.small_pivot = inf["backward_error"], inf["small_pivot"]
         return x
 
     def info(self):

@@ -902,11 +902,22 @@ template <class Body> static void nd_run_captured(gfs_handle* h, hipGraphExec_t*
     if (!h->use_graph) { body(); return; }
     if (!*exec) {
         hipGraph_t g = nullptr;
-        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeGlobal));
-        body();
+        // thread-local capture: only this thread's calls are checked against the capture, and a failure inside body() must not leave the stream
+        // (and the forked side streams) capturing -- the caller's fallback (host LU: hipMemcpy of K on this thread, gfs_destroy) would fail on
+        // exactly the path it exists for.  On an exception the capture is ended, the partial graph dropped, graphs switched off.
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        try { body(); }
+        catch (...) {
+            (void)hipStreamEndCapture(h->stream, &g);
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            h->use_graph = false;
+            throw;
+        }
         HIPCHK(hipStreamEndCapture(h->stream, &g));
-        HIPCHK(hipGraphInstantiate(exec, g, nullptr, nullptr, 0));
+        const hipError_t ei = hipGraphInstantiate(exec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
+        if (ei != hipSuccess) { *exec = nullptr; h->use_graph = false; throw std::runtime_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
     }
     HIPCHK(hipGraphLaunch(*exec, h->stream));
 }

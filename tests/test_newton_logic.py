@@ -195,3 +195,82 @@ def test_lazy_fields_is_a_complete_mapping():
         assert set(g.copy()) == {"W", "a", "b"}
     finally:
         _lib.lib = old
+
+
+def test_overshooting_first_step_is_not_a_contraction():
+    """hist = 1, 50, 0.9, 0.8, 0.7, ... -- the overshoot of the linear first step made min(hist) < 0.1 max(hist) true although nothing had
+    contracted below the first residual; the loop then declared a floor at 0.7.  A slowly but steadily descending iteration runs on."""
+    seq = [1.0, 50.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3, 0.2, 0.05, 1e-4]
+    calls = {"n": 0}
+
+    class NM(FakeNM):
+        def update_uIGA(self, u):
+            super().update_uIGA(u)
+            calls["n"] = int(round(self.u_iga[0]))
+
+    nm = NM(lambda u: np.array([seq[min(int(round(u[0])), len(seq) - 1)]]), lambda u: np.array([[-seq[min(int(round(u[0])), len(seq) - 1)]]]), 1)
+    # K = -R  =>  du = solve(K, -R) = +1: every Newton step moves to the next entry of the sequence
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        nm.solve_nonlinear_nonmatching_problem(rtol=1e-3, max_it=30)
+    assert nm.newton_converged and not nm.newton_stagnated and nm.newton_iterations == len(seq) - 1
+
+
+def test_backtracking_trials_assemble_the_residual_only():
+    """every rejected trial paid a tangent assembly.  The full step asks for R + K, shortened trials for R, the accepted state for K."""
+    asked = []
+
+    class NM(FakeNM):
+        def _assemble(self, flags):
+            asked.append(flags)
+    nm = NM(lambda u: np.arctan(u), lambda u: np.diag(1.0 / (1.0 + u ** 2)), 1, u0=[3.0])
+    nm.solve_nonlinear_nonmatching_problem(rtol=1e-12, max_it=30, zero_mortar_funcs=False)
+    assert nm.newton_converged and _lib.ASM_R in asked and _lib.ASM_K in asked
+    n_trials = sum(1 for f in asked if f == _lib.ASM_R)
+    assert n_trials >= 1 and asked.count(_lib.ASM_R | _lib.ASM_K) == nm.newton_iterations + 1
+
+
+def test_stalled_general_mode_solve_and_small_pivot_fall_back(monkeypatch):
+    """with linear_solve_rtol = 1e-10 on the Frobenius-norm backward error a general-mode refinement that stalled (follower pressure: the
+    stationary iteration on the symmetric part's factors) could pass.  The bar is 1e-12 now, 1e-14 when the factorisation reported a small pivot; a
+    permanent failure (the factors do not fit) is latched instead of rebuilding the solver for every tangent."""
+    import scipy.sparse as sp
+    from goldfish_amd import _solver
+    K = sp.csr_matrix(np.array([[2.0, 1.0], [0.5, -3.0]]))
+
+    class Dev:
+        def csr(self, which):
+            return K
+    nm = NonMatchingOpt.__new__(NonMatchingOpt)
+    nm._dev, nm._k_version = Dev(), 1
+    monkeypatch.setattr(NonMatchingOpt, "dev", property(lambda self: self._dev))
+    monkeypatch.setattr(NonMatchingOpt, "linear_solver", "device")
+    monkeypatch.setattr(NonMatchingOpt, "symmetric_K", property(lambda self: False))
+    b = np.array([1.0, 2.0])
+    exact = lambda r: np.linalg.solve(K.toarray(), r)
+    nm._dsolver, nm._dsolver_version = _FakeSolver(nm._dev, lambda r: 0.9 * exact(r), 3e-11), 1       # stalled at 3e-11: passed in round 3
+    with pytest.warns(RuntimeWarning, match="backward error"):
+        assert np.allclose(K @ nm.solve_K(b), b)
+    nm._k_version = 2
+    ok = _FakeSolver(nm._dev, exact, 1e-13)
+    ok.small_pivot = True                                                                              # 1e-13 passes 1e-12 but not the small-pivot bar
+    nm._dsolver, nm._dsolver_version = ok, 2
+    with pytest.warns(RuntimeWarning, match="small pivot"):
+        assert np.allclose(K.T @ nm.solve_K(b, transpose=True), b)
+    # permanent failure: latched, one warning, no second construction
+    built = []
+
+    class Boom:
+        def __init__(self, *a, **k):
+            built.append(1)
+            raise RuntimeError("gfs_create_nd: the fronts need 400 GB, more than the free device memory")
+    monkeypatch.setattr(_solver, "DeviceSolver", Boom)
+    nm.splines, nm.cp_iga = [type("S", (), {"cp_hom_flat": staticmethod(lambda: np.ones((2, 4)))})()], [np.zeros(2)] * 3
+    nm._k_version, nm._dsolver = 3, None
+    with pytest.warns(RuntimeWarning, match="cannot be used for this model"):
+        assert np.allclose(K @ nm.solve_K(b), b)
+    nm._k_version = 4
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert np.allclose(K @ nm.solve_K(b), b)
+    assert built == [1]
