@@ -5,13 +5,14 @@ One "step" = one pass of the hot path over the synthetic multi-patch shell: resi
 tangent K, dR/dCP (3 fields) and dR/dh (everything DispImOpeartion.apply_nonlinear +
 linearize produce, GOLDFISH/operations/disp_imop.py:33-56), penalty coupling included,
 with control points, thickness and displacements already resident in HBM.
-metric = element-Gauss-point updates per second (BASELINE.json); the default workload is C4
-(16x16 bicubic NURBS patches, ~2.0M dofs, ~9.4M Gauss points), the configuration
-BASELINE.json's metric is quoted on at one GPU; for N > 1 the same model is patch-sharded
-(strong scaling) and every step ends with the RCCL all-gather of the owned residual rows.
-C5 (32x32 quartic patches of the fuselage skin, ~10M dofs, 71.9M Gauss points) is
-`--geometry fuselage --patches 32 32 --nel 53 --degree 4` (whether it fits one GPU: DESIGN.md section 4, measured), one GPU's
-share of it `--geometry fuselage --patches 16 8 --nel 53 --degree 4`.
+metric = element-Gauss-point updates per second (BASELINE.json names no configuration for it); the default workload is C4
+(BASELINE.json configs[3], SURVEY.md 8(d): 16x16 bicubic NURBS patches, ~2.0M dofs, ~9.4M Gauss points) -- the bicubic
+configuration the reference's demos correspond to; for N > 1 the same model is patch-sharded (strong scaling) and every step
+ends with the RCCL all-gather of the owned residual rows.  C5 (configs[4]: 32x32 quartic patches of the fuselage skin, ~10M dofs,
+71.9M Gauss points) is the LARGEST configuration and also fits one MI355X (100 GB): at N = 1 the default run measures it too and
+reports it as the `secondary` record of the same JSON line (own roofline / roofline_fp64; skipped, with the reason, when the device
+has less than 110 GB free or with --no-secondary).  By hand: `--geometry fuselage --patches 32 32 --nel 53 --degree 4`; one GPU's
+share of it: `--geometry fuselage --patches 16 8 --nel 53 --degree 4`.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--geometry shell|fuselage] [--patches NX NY] [--nel E] [--degree P]
 N > 1:  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -102,7 +103,7 @@ def kname_of(D, p):
     return {4: "kl_element_rec_kernel", 3: "kl_element_kernel"}.get(D.assembly_path, "kl_element_mfma4_kernel" if p == 4 else "kl_element_mfma_kernel")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -112,7 +113,29 @@ def main():
     ap.add_argument("--nel", type=int, default=48)
     ap.add_argument("--degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1, default workload: do not add the C5 record")
+    ap.add_argument("--full-pass-only", action="store_true", help="skip the apply_linear and Newton-pass legs (PMC passes: every launch belongs to a full pass)")
+    return ap.parse_args(argv)
+
+
+def git_head():
+    try:
+        import subprocess
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
+def last_commit_of(path):
+    try:
+        import subprocess
+        return subprocess.check_output(["git", "-C", ROOT, "log", "-n", "1", "--format=%h", "--", path], stderr=subprocess.DEVNULL).decode().strip() or None
+    except Exception:
+        return None
+
+
+def main():
+    args = parse_args()
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -139,6 +162,33 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    out = measure(args, torch, dist, rank, local_rank, world)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, usable_cores())
+            except Exception as ex:       # the oracle is only the reported baseline; never the product
+                out["cpu_baseline"] = {"error": str(ex)}
+        # C5 beside C4 (round-3 verdict 6): the largest configuration also fits one GPU; measured in the same run when there is room
+        if world == 1 and workload_name(args) == "C4" and not args.no_secondary and not args.full_pass_only:
+            free_b, _tot = torch.cuda.mem_get_info()
+            if free_b >= 110e9:
+                try:
+                    a2 = parse_args(["--geometry", "fuselage", "--patches", "32", "32", "--nel", "53", "--degree", "4", "--steps", "2", "--warmup", "1"])
+                    sec = measure(a2, torch, None, 0, local_rank, 1)
+                    out["secondary"] = {k: sec[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "roofline_fp64",
+                                                            "apply_linear_roofline", "newton_pass", "device_bytes")}
+                except Exception as ex:
+                    out["secondary"] = {"skipped": "C5 run failed: %s" % ex}
+            else:
+                out["secondary"] = {"skipped": "C5 needs ~100 GB of device memory; %.0f GB free" % (free_b / 1e9)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def measure(args, torch, dist, rank, local_rank, world):
+    """One workload: set-up, warm-up, the timed steps, the apply_linear and Newton-pass legs; returns the record (rank 0) or None."""
     from goldfish_amd import _lib, geometry as G, sharding
     if dist is not None:
         dist.barrier()
@@ -160,6 +210,7 @@ def main():
     class _Buf:
         def __init__(self, ptr, n):
             self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+    rehearse = os.environ.get("GF_BENCH_REHEARSE") == "1"
     exchange = world > 1 or os.environ.get("GF_BENCH_FORCE_EXCHANGE") == "1"     # the env switch rehearses the N>1 code path on one GPU
     R_loc = torch.as_tensor(_Buf(_lib.lib().gf_device_ptr(D.h, _lib.BUF_R), A.ndof), device="cuda") if exchange else None
     R_glob = torch.zeros(3 * shard.total_cp_global, dtype=torch.float64, device="cuda") if exchange else None
@@ -201,7 +252,7 @@ def main():
     # (DispImOpeartion.apply_linear_fwd, disp_imop.py:58-72), device pointers, HIP events on torch's stream are
     # not used: the library's own stream is timed by wall clock around a synchronised batch
     apply = None
-    if rank == 0:
+    if rank == 0 and not args.full_pass_only:
         xk = torch.ones(A.ndof, dtype=torch.float64, device="cuda")
         yk = torch.zeros(A.ndof, dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
@@ -221,7 +272,7 @@ def main():
                  "achieved": byt / ta / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / ta / 1e9 / HBM_PEAK_GBS}
     # the pass a Newton iteration needs (R + K only; leaner element-kernel and gather instances), outside the timed region
     newton_ms = None
-    if rank == 0:
+    if rank == 0 and not args.full_pass_only:
         for _ in range(2):
             D.assemble(_lib.ASM_R | _lib.ASM_K, sync=False)
         D.sync()
@@ -236,11 +287,12 @@ def main():
         dt = float(tt.item())
     value = n_gp_total * args.steps / dt
 
+    out = None
     if rank == 0:
         p = args.degree
         alg_bytes = ALG_BYTES_PER_GP[p] * n_gp_local
         achieved = alg_bytes / (kern_ms_step * 1e-3) / 1e9 if kern_ms_step > 0 else 0.0
-        traffic = counter_flop = step_traffic = None
+        traffic = counter_flop = step_traffic = traffic_source = None
         import glob
         for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic*.json"))):     # PMC-derived bytes / flop of the profiled workloads (tools/traffic_from_pmc.py)
             try:
@@ -249,6 +301,8 @@ def main():
                     traffic = tj.get("element_kernel_bytes_per_launch")
                     counter_flop = tj.get("element_kernel_fp64_flop_issued_per_launch")
                     step_traffic = tj.get("full_pass_bytes_per_step")
+                    # stored builder measurement (rocprofv3 PMC passes of an earlier run of this workload), not this run's: say which
+                    traffic_source = "%s@%s (from %s)" % (os.path.relpath(tf, ROOT), last_commit_of(tf), tj.get("source", "profiles/*_pmc_*.csv"))
             except Exception:
                 pass
         mfma = os.environ.get("GF_ELEMENT", "mfma") != "valu"
@@ -268,35 +322,31 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms_step, "launches_timed": kern_n,
-                         "launches_per_step": kern_n / max(args.steps, 1), "step_traffic_all_kernels": step_traffic},
+                         "launches_per_step": kern_n / max(args.steps, 1), "step_traffic_all_kernels": step_traffic,
+                         "traffic_source": traffic_source, "timing": "HIP events on the library's stream around every launch of the element kernel(s), this run"},
             "roofline_fp64": {"bound": "fp64 (v_mfma_f64 + FP64 VALU share one pipe)" if mfma else "fp64-valu", "kernel": kname,
                               "achieved": ALG_FLOP_PER_GP[p] * n_gp_local / (kern_ms_step * 1e-3) / 1e12 if kern_ms_step > 0 else 0.0,
                               "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "note": "the tangent / shape-Jacobian contraction is FP64 bound (SURVEY.md 8(d)); "
                                       "this is the binding roofline of the dominant kernel; flop count = the formulation's "
                                       "FMA*2 per Gauss-point update (DESIGN.md section 4), not hardware-issued flops",
-                              # what the pipe sustains on this GPU (tools/ubench_acc, ubench_batch, ubench_f64 -> profiles/r03_ubench_fp64_mfma.txt): not a second peak,
-                              # the explanation of where the kernel sits against the data-sheet figure above
-                              "pipe_measured": {"v_mfma_f64_16x16x4_vgpr_accumulators_tflops": 74.0, "v_mfma_f64_16x16x4_agpr_accumulators_tflops_one_wave_per_simd": 36.0,
+                              # what the pipe sustains on this GPU: microbenchmarks of an earlier run (tools/ubench_acc, ubench_batch, ubench_f64), NOT measured in this run --
+                              # not a second peak, the explanation of where the kernel sits against the data-sheet figure above
+                              "pipe_measured": {"source": "profiles/r03_ubench_fp64_mfma.txt@%s (stored microbenchmark output, round 3)" % last_commit_of(os.path.join(ROOT, "profiles", "r03_ubench_fp64_mfma.txt")),
+                                                "v_mfma_f64_16x16x4_vgpr_accumulators_tflops": 74.0, "v_mfma_f64_16x16x4_agpr_accumulators_tflops_one_wave_per_simd": 36.0,
                                                 "v_mfma_f64_16x16x4_agpr_accumulators_tflops_two_waves_per_simd": 45.0, "v_fma_f64_tflops": 56.0,
                                                 "mfma_and_fp64_valu_co_execute": False}},
             "apply_linear_roofline": apply,
             "newton_pass": {"what": "R + K only (one Newton iteration of solve_nonlinear), rank 0's share", "ms": newton_ms},
-            "device_bytes": D.device_bytes,
+            "device_bytes": D.device_bytes, "head": git_head(),
         }
         out["roofline_fp64"]["frac"] = out["roofline_fp64"]["achieved"] / FP64_PEAK_TFLOPS
         if counter_flop and kern_ms_step > 0:      # the same fraction with the flop count the SQ counters report for this kernel and workload (profiles/traffic.json)
             out["roofline_fp64"]["counter_flop_per_launch"] = counter_flop
+            out["roofline_fp64"]["counter_flop_source"] = traffic_source
             out["roofline_fp64"]["frac_counters"] = counter_flop / (kern_ms_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args, usable_cores())
-            except Exception as ex:       # the oracle is only the reported baseline; never the product
-                out["cpu_baseline"] = {"error": str(ex)}
-        print(json.dumps(out), flush=True)
     D.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -20,7 +20,7 @@ BUF_CP, BUF_U, BUF_H, BUF_R, BUF_VAL_K, BUF_VAL_C0, BUF_VAL_C1, BUF_VAL_C2, BUF_
 EXPORTS = ["gf_device_count", "gf_last_error", "gf_create", "gf_destroy", "gf_total_cp", "gf_num_dofs",
            "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes", "gf_set_cp",
            "gf_set_thickness", "gf_set_u", "gf_nnz", "gf_pattern", "gf_assemble", "gf_sync", "gf_get_residual",
-           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_shape_regu", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms", "gf_assembly_path", "gf_stream", "gf_apply_many", "gf_get_functional_gradient", "gf_penalty_dxi_range"]
+           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_shape_regu", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms", "gf_assembly_path", "gf_stream", "gf_apply_many", "gf_get_functional_gradient", "gf_penalty_dxi_range", "gf_functionals_per_patch"]
 
 
 def lib():
@@ -43,7 +43,7 @@ def lib():
             "gf_stress_forms": ([vp, ci, C.c_double, dp, i64, ci, ci, dp, dp, dp, dp, dp, ci], None), "gf_device_ptr": ([vp, ci], vp),
             "gf_apply_dev": ([vp, ci, ci, vp, vp], None), "gf_kernel_ms": ([vp, C.POINTER(ci)], C.c_double), "gf_assembly_path": ([vp], None),
             "gf_get_functional_gradient": ([vp, ci, dp, i64], None), "gf_apply_many": ([vp, ci, ci, C.POINTER(ci), C.POINTER(dp), C.POINTER(dp)], None),
-            "gf_stream": ([vp], vp)}
+            "gf_stream": ([vp], vp), "gf_functionals_per_patch": ([vp, dp, dp, i64], None)}
         for name in ("gf_total_cp", "gf_num_dofs", "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes"):
             sig[name] = ([vp], i64)
         for name, (argtypes, restype) in sig.items():
@@ -224,9 +224,14 @@ class DeviceModel:
         out = np.zeros(3)
         null = C.POINTER(C.c_double)()
         _check(lib().gf_functionals(self.h, _dp(out), null, null, null, null, null, int(apply_bcs)))
+        npatch, extra = int(self.arrays.n_patches), {}
+        if hasattr(lib(), "gf_functionals_per_patch"):
+            wp, vp_ = np.zeros(npatch), np.zeros(npatch)
+            _check(lib().gf_functionals_per_patch(self.h, _dp(wp), _dp(vp_), npatch))
+            extra = dict(Wint_patch=wp, volume_patch=vp_)
         g = _LazyFields(self, {"dWdu": (0, (self.ndof,)), "dWdcp": (1, (3, self.total_cp)), "dWdh": (2, (self.total_cp,)),
                                "dVdcp": (3, (3, self.total_cp)), "dVdh": (4, (self.total_cp,))},
-                        dict(Wint=out[0], volume=out[1], Wpen=out[2]))
+                        dict(Wint=out[0], volume=out[1], Wpen=out[2], **extra))
         self._lazy_fun = weakref.ref(g)           # only a result somebody still holds has to be completed before the buffer is reused
         return g
 

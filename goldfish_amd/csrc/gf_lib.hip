@@ -39,6 +39,7 @@ struct gf_handle {
     const long long *d_elem_off = nullptr, *d_if_off = nullptr; double* d_red = nullptr; long long nred = 0;   // per-patch / per-interface reductions on the device
     double* d_dxi = nullptr; long long dxi_doubles = 0;   // gf_penalty_dxi: block buffer kept between calls
     int fun_owner = -1;                              // which entry wrote d_fun last (0 = gf_functionals)
+    std::vector<double> fun_wp, fun_vp;              // per-patch W_int / volume of the last gf_functionals call (gf_functionals_per_patch)
     double* d_many = nullptr;                        // gf_apply_many: five more vectors of ndof doubles (allocated on first use)
     double* d_pt_nu2 = nullptr;                                        // second derivatives of the basis at the mortar vertices (gf_penalty_dxi)
     double *d_fun = nullptr, *d_pen_en = nullptr, *d_ve = nullptr;    // functional gradients [11*total_cp], penalty energies [npts]
@@ -777,7 +778,17 @@ int gf_functionals(gf_handle* h, double out[3], double* dWdu, double* dWdcp, dou
         // an interface cut by the partition is present on both ranks: its energy is counted by the owner of side A
         for (int i = 0; i < H.ni; ++i) if (H.if_patch[2 * i] < H.n_owned) Wp += pi[i];
         out[0] = (double)W; out[1] = (double)V; out[2] = (double)Wp;
+        h->fun_wp = wp; h->fun_vp = vp;
+        for (int s = H.n_owned; s < H.np; ++s) { h->fun_wp[s] = 0.0; h->fun_vp[s] = 0.0; }      // ghost patches of a shard: reported by their owner
     } catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
+}
+
+int gf_functionals_per_patch(gf_handle* h, double* W_patch, double* V_patch, int64_t np) {
+    if (!h) return fail("gf_functionals_per_patch: null handle");
+    if (np != (int64_t)h->H.np) return fail("gf_functionals_per_patch: arrays must hold one value per patch");
+    if (h->fun_wp.size() != (size_t)np) return fail("gf_functionals_per_patch: no gf_functionals call has been made on this handle");
+    for (int64_t s = 0; s < np; ++s) { if (W_patch) W_patch[s] = h->fun_wp[s]; if (V_patch) V_patch[s] = h->fun_vp[s]; }
     return 0;
 }
 

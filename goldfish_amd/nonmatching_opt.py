@@ -304,6 +304,8 @@ class NonMatchingOpt:
     def shopt_cpsurf_fe_hom_list(self):
         """(n, 4) homogeneous control points of the optimised patches (nonmatching_opt_ffd.py:60-141)."""
         cols = self._shopt_cols[0]
+        if any(not np.array_equal(c, cols) for c in self._shopt_cols[1:]):
+            cols = np.unique(np.concatenate(self._shopt_cols))          # fields with different patch sets: the block is sized over their union
         w = np.concatenate([s.cp_hom_flat()[:, 3] for s in self.splines])[cols]
         return np.stack([self.cp_iga[f][cols] for f in range(3)] + [w], 1)
 
@@ -794,18 +796,25 @@ class NonMatchingOptFFD(NonMatchingOpt):
         self.shopt_num_desvars = [self.shopt_cpffd_size for _ in self.opt_field]
         self.shopt_cpffd_design_dof = [list(range(self.shopt_cpffd_size)) for _ in self.opt_field]
         self.shopt_cpffd_design_dof_full = [list(d) for d in self.shopt_cpffd_design_dof]
-        cols0 = self._shopt_cols[0]
-        for c in self._shopt_cols[1:]:
-            if not np.array_equal(c, cols0):
-                raise NotImplementedError("set_shopt_FFD: every opt field must optimise the same patches (single FFD block)")
-        w = np.concatenate([s.cp_hom_flat()[:, 3] for s in self.splines])[cols0]
-        X = np.stack([self.cp_iga[f][cols0] / w for f in range(3)], 1)           # physical control points
-        D = CP_FFD_matrix(X, self.shopt_ffd_degree, self.shopt_knotsffd).tocsr()
-        self.shopt_dcpsurf_fedcpffd = sp.diags(w).dot(D).tocoo()
+        # nonmatching_opt_ffd.py:60-72 shares ONE patch list between the fields, so the reference has one map; a list per field (accepted by
+        # set_shopt_surf_inds_FFD here) gives one map per field: the FFD block is the same, the rows are the control points of that field's patches
+        w_all = np.concatenate([s.cp_hom_flat()[:, 3] for s in self.splines])
+        maps = []
+        for cols in self._shopt_cols:
+            same = next((m for c, m in zip(self._shopt_cols, maps) if np.array_equal(c, cols)), None)
+            if same is not None:
+                maps.append(same)
+                continue
+            w = w_all[cols]
+            X = np.stack([self.cp_iga[f][cols] / w for f in range(3)], 1)           # physical control points
+            maps.append(sp.diags(w).dot(CP_FFD_matrix(X, self.shopt_ffd_degree, self.shopt_knotsffd).tocsr()).tocoo())
+        self.shopt_dcpsurf_fedcpffd_list = maps                                      # one entry per opt field (the same object when the patch sets agree)
+        self.shopt_dcpsurf_fedcpffd = maps[0]
+        self.shopt_ffd_shared_patches = all(m is maps[0] for m in maps)
         self.shopt_init_cpffd_full = [self.shopt_cpffd_flat[:, f].copy() for f in self.opt_field]
         self.shopt_cpffd_pin_dof = [[] for _ in self.opt_field]
         self.shopt_align_dir = [None for _ in self.opt_field]
-        return self.shopt_dcpsurf_fedcpffd
+        return self.shopt_dcpsurf_fedcpffd if self.shopt_ffd_shared_patches else self.shopt_dcpsurf_fedcpffd_list
 
     # ------------------------------------------------------------------ FFD lattice helpers
     @staticmethod

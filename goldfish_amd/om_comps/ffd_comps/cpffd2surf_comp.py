@@ -12,7 +12,7 @@ class CPFFD2SurfComp(LinearMapsComp):
         if getattr(nm, 'shopt_multiffd', False):
             self.derivs, self.init_cpffd = [d.tocoo() for d in nm.shopt_dcpsurf_fedcp_mffd], nm.shopt_init_cp_mffd_full
         else:
-            self.derivs = [nm.shopt_dcpsurf_fedcpffd] * len(self.opt_field)
+            self.derivs = list(getattr(nm, 'shopt_dcpsurf_fedcpffd_list', [nm.shopt_dcpsurf_fedcpffd] * len(self.opt_field)))
             self.init_cpffd = [nm.shopt_cpffd_flat[:, f] for f in self.opt_field]
         self.input_cpffd_name_list = [self.input_cpffd_name_pre + str(f) for f in self.opt_field]
         self.output_cpsurf_name_list = [self.output_cpsurf_name_pre + str(f) for f in self.opt_field]

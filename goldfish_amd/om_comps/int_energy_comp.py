@@ -9,8 +9,9 @@ class IntEnergyComp(FunctionalComp):
                ('input_u_name', 'displacements'), ('output_wint_name', 'w_int'))
     OUTPUT_OPTION = 'output_wint_name'
 
-    def _operation(self):
-        self.wint_exop = IntEnergyExOperation(self.nonmatching_opt)
+    def _operation(self, wint_regu=None):
+        """int_energy_comp.py:16-23: init_parameters(wint_regu=None) hands the per-patch regularisation terms to the operation."""
+        self.wint_exop = IntEnergyExOperation(self.nonmatching_opt, wint_regu)
 
     def _value(self):
         return self.wint_exop.Wint()

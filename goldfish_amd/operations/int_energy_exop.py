@@ -4,16 +4,46 @@ partials (reference: GOLDFISH/operations/int_energy_exop.py:3-107).  One device 
 import numpy as np
 
 
+class ShapeRegu(object):
+    """One patch's ``wint_regu`` term (int_energy_exop.py:15-18, 31-32 adds an arbitrary UFL form per patch to the energy form; the one the
+    reference's demos build is the shape regularisation of demos_om/shape_opt/eVTOL/int_energy_regu_exop.py:30-38):
+
+        coef * int |grad_s(P_field - P_field^0)|^2 dA
+
+    with the surface gradient on the current geometry, P_field the homogeneous coordinate ``field`` of the control net and P^0 its value when
+    the operation is created (or ``cp0``, an array over the patch's control points).  Device: gf_shape_regu -> kl_pointfun_kernel<P, 2>."""
+
+    def __init__(self, coef, field=2, cp0=None):
+        self.coef, self.field = float(coef), int(field)
+        self.cp0 = None if cp0 is None else np.asarray(cp0, float).ravel()
+        if self.field not in (0, 1, 2):
+            raise ValueError("ShapeRegu: field must be 0, 1 or 2")
+
+
 class IntEnergyExOperation(object):
 
     def __init__(self, nonmatching_opt, wint_regu=None):
-        if wint_regu is not None:
-            raise NotImplementedError("regularisation terms are SURVEY.md 8(f) N4")
-        self.nonmatching_opt = nonmatching_opt
+        self.nonmatching_opt = nm = nonmatching_opt
         self.num_splines = nonmatching_opt.num_splines
         self.splines = nonmatching_opt.splines
         self.opt_shape = nonmatching_opt.opt_shape
         self.opt_thickness = nonmatching_opt.opt_thickness
+        self.wint_regu = [None] * self.num_splines if wint_regu is None else list(wint_regu)
+        if len(self.wint_regu) != self.num_splines:
+            raise ValueError("wint_regu: one entry (None or a ShapeRegu) per patch")
+        self._regu_fields = {}                  # field -> (per-patch coefficients, initial coordinate field)
+        for s, r in enumerate(self.wint_regu):
+            if r is None:
+                continue
+            if not isinstance(r, ShapeRegu):
+                raise TypeError("wint_regu[%d]: the reference adds a UFL form here; the device path evaluates goldfish_amd.operations."
+                                "int_energy_exop.ShapeRegu terms (the regularisation of the reference's eVTOL demo), got %r" % (s, type(r)))
+            coef, cp0 = self._regu_fields.setdefault(r.field, (np.zeros(self.num_splines), nm.cp_iga[r.field].copy()))
+            coef[s] = r.coef
+            if r.cp0 is not None:
+                if r.cp0.size != nm.vec_scalar_iga_dof_list[s]:
+                    raise ValueError("wint_regu[%d].cp0: expected %d values" % (s, nm.vec_scalar_iga_dof_list[s]))
+                cp0[nm.cp_off[s]:nm.cp_off[s + 1]] = r.cp0
         if self.opt_shape:
             self.opt_field = nonmatching_opt.opt_field
             self.shopt_surf_inds = nonmatching_opt.shopt_surf_inds
@@ -21,21 +51,31 @@ class IntEnergyExOperation(object):
     def _f(self, apply_bcs=True):
         return self.nonmatching_opt.functionals(apply_bcs=apply_bcs)
 
+    def _regu(self):
+        """[(value, dcp (3, total_cp))] of the regularisation terms, one device evaluation per regularised coordinate field and state."""
+        nm = self.nonmatching_opt
+        return [nm._cached(("wint_regu", f, coef.tobytes(), cp0.tobytes()), lambda f=f, coef=coef, cp0=cp0: nm.dev.shape_regu(f, cp0, coef))
+                for f, (coef, cp0) in sorted(self._regu_fields.items())]
+
     def Wint(self):
         """int_energy_exop.py:55-59."""
-        return float(self._f()["Wint"])
+        return float(self._f()["Wint"]) + float(sum(r["value"] for r in self._regu()))
 
     def dWintduIGA(self, array=True, apply_bcs=True):
-        """int_energy_exop.py:61-73 (Dirichlet rows zeroed by FE2IGA(..., apply_bcs))."""
+        """int_energy_exop.py:61-73 (Dirichlet rows zeroed by FE2IGA(..., apply_bcs)).  The regularisation does not depend on u."""
         return self._f(apply_bcs)["dWdu"]
 
     def dWintdCPIGA(self, field, array=True):
         """int_energy_exop.py:75-90."""
         nm = self.nonmatching_opt
-        return self._f()["dWdcp"][field][nm._shopt_cols[self.opt_field.index(field)]]
+        cols = nm._shopt_cols[self.opt_field.index(field)]
+        g = self._f()["dWdcp"][field][cols]
+        for r in self._regu():
+            g = g + r["dcp"][field][cols]
+        return g
 
     def dWintdh_th(self, extract=False, array=True):
-        """int_energy_exop.py:92-107."""
+        """int_energy_exop.py:92-107.  The regularisation does not depend on the thickness."""
         nm = self.nonmatching_opt
         g = self._f()["dWdh"]
         return g if nm.var_thickness else np.add.reduceat(g, nm.cp_off[:-1])

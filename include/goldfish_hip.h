@@ -97,6 +97,10 @@ int gf_functionals(gf_handle* h, double out[3], double* dWdu, double* dWdcp, dou
  * 2 dWdh [total_cp], 3 dVdcp [3 total_cp], 4 dVdh [total_cp].  Fails if another functional entry (gf_compliance, gf_stress_forms,
  * gf_shape_regu) has used the gradient buffer since. */
 int gf_get_functional_gradient(gf_handle* h, int field, double* out, int64_t n);
+/* per-patch W_int and volume of the LAST gf_functionals call (the terms of the sums out[0], out[1]; ghost patches of a shard: 0) --
+ * VolumeExOperation(vol_surf_inds = a subset of the patches) sums the listed ones (operations/volume_exop.py:9-27, 46-50).
+ * Either pointer may be NULL; np = number of patches. */
+int gf_functionals_per_patch(gf_handle* h, double* W_patch, double* V_patch, int64_t np);
 int gf_compliance(gf_handle* h, const double* forces, int64_t nf, double* C, double* dCdu, double* dCdcp, int apply_bcs);
 
 /* MaxvMStressExOperation (operations/max_vmstress_exop.py): the per-patch aggregation forms

@@ -834,6 +834,66 @@ def test_regularised_energy_operation_and_comp():
     assert max(prob.check_partials(compact_print=False, free_mask=free).values()) < 1e-5
 
 
+def test_volume_of_a_patch_subset_and_wint_regu_terms(oracle_lib):
+    """VolumeExOperation(vol_surf_inds = subset) (volume_exop.py:9-27: the other patches contribute Constant(0) dx) and
+    IntEnergyExOperation(wint_regu = [...]) (int_energy_exop.py:15-32) -- both raised NotImplementedError until round 4.  The subset volume
+    against the oracle's per-patch model, its partials against central differences; the regularised energy against IntEnergyReguExOperation."""
+    from goldfish_amd.operations.volume_exop import VolumeExOperation
+    from goldfish_amd.operations.int_energy_exop import IntEnergyExOperation, ShapeRegu
+    from goldfish_amd.operations.int_energy_regu_exop import IntEnergyReguExOperation
+    from goldfish_amd.om_comps import VolumeComp, IntEnergyComp, om
+    from oracle.oracle_py import Oracle
+    spec, th, nm = _problem()
+    rng = np.random.default_rng(11)
+    full, sub = VolumeExOperation(nm), VolumeExOperation(nm, vol_surf_inds=[1])
+    f = nm.functionals()
+    assert abs(f["volume_patch"].sum() - f["volume"]) < 1e-13 * f["volume"] and abs(f["Wint_patch"].sum() - f["Wint"]) <= 1e-13 * abs(f["Wint"]) + 1e-300
+    one = G.ProblemSpec(patches=[spec.patches[1]], E=spec.E, nu=spec.nu, h_th=spec.h_th, interfaces=[], body_force=[spec.body_force[1]], point_loads=[]) \
+        if hasattr(G, "ProblemSpec") else None
+    if one is not None:                                               # patch 1 alone in the oracle: its volume is the subset's
+        Ao = arrays_from_spec(one, [th[1]])
+        Vo = Oracle(Ao, thickness=th[1], u=np.zeros(Ao.ndof)).functionals()["volume"]
+        assert abs(sub.volume() - Vo) < 1e-11 * Vo
+    assert 0.0 < sub.volume() < full.volume() and abs(sub.volume() + VolumeExOperation(nm, [0]).volume() - full.volume()) < 1e-12 * full.volume()
+    gh = sub.dvoldh_th()
+    assert np.all(gh[:nm.cp_off[1]] == 0.0) and np.array_equal(gh[nm.cp_off[1]:], full.dvoldh_th()[nm.cp_off[1]:])
+    for i, field in enumerate(nm.opt_field):
+        x0 = nm.cp_iga[field][nm._shopt_cols[i]].copy()
+        g, d = sub.dvoldCPIGA(field), rng.standard_normal(x0.size)
+        eps = 1e-6
+        nm.update_CPIGA(x0 + eps * d, field); vp = sub.volume()
+        nm.update_CPIGA(x0 - eps * d, field); vm = sub.volume()
+        nm.update_CPIGA(x0, field)
+        assert abs((vp - vm) / (2 * eps) - g @ d) < 1e-6 * max(abs(g @ d), 1e-12), field
+    comp = VolumeComp(nonmatching_opt=nm, vol_surf_inds=[1])
+    comp.init_parameters()
+    prob = om.Problem(model=comp)
+    prob.setup(); prob.run_model()
+    assert max(prob.check_partials(compact_print=False).values()) < 1e-5
+    # ---- wint_regu: the eVTOL demo's term on every patch through the base operation = IntEnergyReguExOperation
+    nm.update_uIGA(1e-3 * rng.standard_normal(nm.vec_iga_dof))
+    ref = IntEnergyReguExOperation(nm, regu_para=1.0e6)
+    op = IntEnergyExOperation(nm, wint_regu=[ShapeRegu(c, field=2) for c in ref.regu_para_full])
+    only1 = IntEnergyExOperation(nm, wint_regu=[None, ShapeRegu(ref.regu_para_full[1], field=2)])
+    cp2 = nm.get_init_CPIGA()[2].copy()
+    nm.update_CPIGA(cp2 + 0.02 * rng.standard_normal(cp2.size), 2)
+    base = IntEnergyExOperation(nm)
+    assert abs(op.Wint() - ref.Wint()) < 1e-12 * abs(ref.Wint()) and base.Wint() < only1.Wint() < op.Wint()
+    for field in nm.opt_field:
+        assert _rel(op.dWintdCPIGA(field), ref.dWintdCPIGA(field)) < 1e-12
+    g1 = only1.dWintdCPIGA(2) - base.dWintdCPIGA(2)
+    assert np.all(g1[:nm.cp_off[1]] == 0.0) and np.abs(g1[nm.cp_off[1]:]).max() > 0.0       # patch 0 carries no term
+    with pytest.raises(TypeError):
+        IntEnergyExOperation(nm, wint_regu=[object(), None])
+    comp = IntEnergyComp(nonmatching_opt=nm)
+    comp.init_parameters(wint_regu=[None, ShapeRegu(ref.regu_para_full[1], field=2)])
+    prob = om.Problem(model=comp)
+    prob.setup(); prob.run_model()
+    free = np.ones(nm.vec_iga_dof, bool)
+    free[np.asarray(nm.dev and nm.zero_dofs)] = False
+    assert max(prob.check_partials(compact_print=False, free_mask=free).values()) < 1e-5
+
+
 def test_moving_intersection_optimisation_finds_the_symmetric_optimum():
     """examples/tbeam_moving_intersection.py (set-up of demos_om/shape_opt_mint/T-beam): the web starts 0.4 off centre under a
     load that is symmetric about the flange's centre line; with the intersection moving along (xi(CP), dR/dxi in the total

@@ -234,6 +234,39 @@ def _ffd_problem():
     return pb, blk
 
 
+def test_ffd_fields_with_different_patch_sets():
+    """set_shopt_FFD refused opt fields that optimise different patch sets (round-3 verdict, missing 5); the reference shares one list
+    (nonmatching_opt_ffd.py:60-72), a list per field gives one map per field over the same block."""
+    from goldfish_amd.nonmatching_opt import NonMatchingOptFFD
+    from goldfish_amd.om_comps import om
+    from goldfish_amd.om_comps.ffd_comps import CPFFD2SurfComp
+    from goldfish_amd.utils.ffd_utils import create_3D_block
+    pb = NonMatchingOptFFD.from_spec(G.tbeam_2patch(4), klass=NonMatchingOptFFD)
+    pb.set_shopt_surf_inds_FFD([1, 2], [[0, 1], [1]])                    # field 1 moves both patches, field 2 only the web
+    lims = [list(x) for x in pb.cpsurf_des_lims]
+    for f in range(3):
+        pad = 0.1 * max(lims[f][1] - lims[f][0], 1.0)
+        lims[f] = [lims[f][0] - pad, lims[f][1] + pad]
+    blk = create_3D_block([3, 2, 2], 2, lims)
+    maps = pb.set_shopt_FFD(blk.knots, blk.control)
+    assert isinstance(maps, list) and len(maps) == 2 and not pb.shopt_ffd_shared_patches
+    n0, n1 = pb.splines[0].ncp, pb.splines[1].ncp
+    assert maps[0].shape == (n0 + n1, pb.shopt_cpffd_size) and maps[1].shape == (n1, pb.shopt_cpffd_size)
+    q = pb.shopt_cpffd_flat
+    for i, field in enumerate(pb.opt_field):                             # undeformed block: identity on the surface control points of that field's patches
+        assert np.abs(maps[i] @ q[:, field] - pb.cp_iga[field][pb._shopt_cols[i]]).max() < 1e-10
+    assert np.abs(maps[0].tocsr()[n0:] - maps[1].tocsr()).max() < 1e-14   # the web's rows are the same in both maps
+    comp = CPFFD2SurfComp(nonmatching_opt_ffd=pb)
+    comp.init_parameters()
+    prob = om.Problem(model=comp)
+    prob.setup(); prob.run_model()
+    assert np.ravel(prob.get_val("CP_FE1")).size == n0 + n1 and np.ravel(prob.get_val("CP_FE2")).size == n1
+    shared = NonMatchingOptFFD.from_spec(G.tbeam_2patch(4), klass=NonMatchingOptFFD)
+    shared.set_shopt_surf_inds_FFD([1, 2], [0, 1])
+    m = shared.set_shopt_FFD(blk.knots, blk.control)
+    assert not isinstance(m, list) and shared.shopt_ffd_shared_patches and shared.shopt_dcpsurf_fedcpffd_list[1] is m
+
+
 def test_ffd_constraint_maps_against_their_definitions():
     """N2: align / pin / regularisation maps of the FFD block, checked against brute-force
     constructions of their definitions (GOLDFISH/nonmatching_opt_ffd.py:691-883, 1034-1244)."""
