@@ -1,0 +1,387 @@
+// gf_element_rec4.hpp -- p = 4: the MFMA element kernel as a WALK over a strip of elements that keeps its accumulators across elements and
+// stores every control-point pair once per work item ("row records"), like gf_element_rec.hpp does for p = 2, 3, and the gather of those records.
+//
+// Why: kl_element_mfma4_kernel writes one 105 KB block per element (2 x 75^2 + 75 x 25 + 75 doubles) and kl_gather_kernel<4> reads every block back:
+// 41.7 + 50.9 GB of HBM-side traffic per pass over one GPU's share of C5 for 4.94 GB of algorithmic bytes (profiles/traffic_p4_c5share.json, round 4
+// correction).  Walking along v, a pair of control points stays in ONE accumulator register while the window passes its rows, so it is stored once per
+// strip it lies in (5 times instead of 25): 37.8 KB per element, nothing read back, no launch order.
+//
+// Tiles.  25 basis functions per element = a 5 x 5 window of control points.  Operand lane x of tile t holds the basis function
+//     tile 0: u index x / 5 (0..2), v slot x % 5, x < 15        tile 1: u index 3 + x / 5 (3..4), v slot x % 5, x < 10
+// with slot = (control-point row) mod 5: moving the window changes which entry of the 1-D v table a lane evaluates (jv = (slot - first row) mod 5), never
+// where a sum sits.  The 2 x 2 x 15 accumulator tiles do not fit the register file (as in gf_element_mfma4.hpp), and accumulators that must survive from
+// element to element cannot be time-multiplexed inside one walk, so the three passes of the block kernel become THREE WALKS (three launches), each with its
+// own phase 1:   PASS 0: residual + K ((0,0), (1,1): i <= j; (1,0): all nine; the transposed entries are written from the symmetry K^(ij)[a][b] = K^(ji)[b][a])
+//                PASS 1 / 2: dR/dCP + dR/dh for the b tile PASS - 1 (T_b feeds both a tiles).
+//
+// Record of row rho of a work item (Rec4Cfg<NC>::SZ doubles, NC values per ORDERED pair: K^(ij) at 3 i + j, dR/dCP^(if) at 9 + 3 i + f, dR/dh^(i) at 18 + i;
+// NC = 9 for the Newton pass): the pairs (A, B) whose lower row is rho,
+//     area 1  [ua][c][d][ub]        A = (iu0 + ua, rho),      B = (iu0 + ub, rho + d), d = 0..4
+//     area 2  [ua][d - 1][c][ub]    A = (iu0 + ua, rho + d),  B = (iu0 + ub, rho),     d = 1..4
+// -- every ordered pair with all its components, so the gather of a control point a reads contiguous runs ([ua = its u index]: 25 NC doubles of area 1, 5 NC
+// per row offset of area 2) and needs no mirrored reads.  Record index = (item - first item of the chunk) * rec_rows + (rho - first row of the item).
+// Reference path: the same integrals as kl_element_mfma4_kernel (GOLDFISH/nonmatching_opt.py:941-1015 via PENGoLINS' assembly).
+#pragma once
+#include "gf_gauss_loop.hpp"
+
+namespace gf {
+
+template <int NC> struct Rec4Cfg { static constexpr int A1 = 5 * NC * 25, SZ = A1 + 5 * 4 * NC * 5; };
+struct Rec4Out { double* rec; double* rblk; int rec_rows; };
+
+__device__ __forceinline__ int mod5(int v) { int r = v % 5; return r < 0 ? r + 5 : r; }
+
+template <int PASS, int NC>            // PASS 0: R + K; 1, 2: dR/dCP + dR/dh of b tile PASS - 1.  NC: values per pair in the record (21: full layout, 9: K only)
+__global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const WalkItem* __restrict__ items, int flags, Rec4Out O) {
+    static_assert(PASS == 0 || NC == 21, "the dR/dCP / dR/dh walks write the full record layout");
+    using RC = Rec4Cfg<NC>;
+    constexpr int P = 4, P1 = 5, NB = 25, NG = 25, ND = 75, NGRP = 7, TS = P1 * 3 * P1;
+    const int tid = threadIdx.x, x = tid & 15, kk = tid >> 4;
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uni64 = [&](long long v) { return (long long)(((unsigned long long)(unsigned)uni((int)((unsigned long long)v >> 32)) << 32) | (unsigned)uni((int)(unsigned long long)v)); };
+    WalkItem it = items[blockIdx.x];
+    it.patch = uni(it.patch); it.eu = uni(it.eu); it.ev0 = uni(it.ev0); it.nel = uni(it.nel); it.iu0 = uni(it.iu0);
+    const PatchDev& Pt = M.patches[it.patch];
+    const int p_nu = uni(Pt.nu), p_nelu = uni(Pt.nelu), p_tabu = uni(Pt.tabu), p_tabv = uni(Pt.tabv), p_wu = uni(Pt.wu), p_wv = uni(Pt.wv), p_spv = uni(Pt.spv);
+    const long long p_cp_off = uni64(Pt.cp_off), p_elem_off = uni64(Pt.elem_off);
+    __shared__ int s_iv[REC_MAX_NEL + 1];               // first control-point row of every element of the item (+ one behind: every row has left)
+    for (int k = threadIdx.x; k <= it.nel && k <= REC_MAX_NEL; k += 64) s_iv[k] = M.ints[p_spv + it.ev0 + (k < it.nel ? k : it.nel - 1)] - P + (k < it.nel ? 0 : P1);
+    __shared__ double s_pc[8];
+    if (threadIdx.x < 8) s_pc[threadIdx.x] = (&Pt.E)[threadIdx.x];
+    const double* const pf = s_pc + 2; const double* const ppd = s_pc + 5;
+
+    __shared__ __attribute__((aligned(16))) double s_g[8 * NB];      // control points of the element (phases 0-1), then the residual reduction
+    double (*s_c)[3] = reinterpret_cast<double (*)[3]>(s_g);
+    double (*s_d)[3] = reinterpret_cast<double (*)[3]>(s_g + 3 * NB);
+    double* s_h = s_g + 6 * NB; double* s_w = s_g + 7 * NB;
+    __shared__ double s_tu[TS], s_tv[TS], s_wg[2 * P1];
+    __shared__ __attribute__((aligned(16))) double s_im[NG][IM_SIZE];
+    wave_lds_sync();
+
+    const bool doK = PASS == 0 && (flags & GF_ASM_K_BIT) != 0, doC = PASS != 0 && (flags & GF_ASM_C_BIT) != 0, doH = PASS != 0 && (flags & GF_ASM_H_BIT) != 0;
+    const bool has_bf = (pf[0] != 0.0) || (pf[1] != 0.0) || (pf[2] != 0.0);
+    // ---- static roles of this lane.  B operand (column) of tile t: lane x; A operand rows held in register rr of a D tile: x_a = kk + 4 rr
+    const int slot_b = x % 5, jq = x / 5;
+    const bool bvalid[2] = {x < 15, x < 10};
+    const int ub[2] = {jq < 3 ? jq : 0, jq < 2 ? 3 + jq : 3};
+    const double bval[2] = {bvalid[0] ? 1.0 : 0.0, bvalid[1] ? 1.0 : 0.0};
+    int ua[2][4], slot_a[4]; bool avalid[2][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int xa = kk + 4 * rr, q = xa / 5;
+        slot_a[rr] = xa % 5;
+        avalid[0][rr] = xa < 15; avalid[1][rr] = xa < 10;
+        ua[0][rr] = q < 3 ? q : 0; ua[1][rr] = q < 2 ? 3 + q : 3;
+    }
+    const RowLane RLg(x);
+
+    // ---- inputs of one element: 64 bytes per control point (c_xy | c_zw | u_xy | u_z, h: lane task = 4 * local index + quarter, 100 tasks in two rounds),
+    //      the v table and the v weights.  Requested in front of the flush stores (vmcnt is in order: a load behind the stores would wait for all of them),
+    //      parked in LDS behind them.
+    struct Fetch { double2 cp[2]; double tv[2], wv; };
+    auto fetch = [&](int ev, int iv0f) {
+        Fetch F;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int task = tid + 64 * r, pa_cp = task >> 2, pa_q = task & 3;
+            F.cp[r] = double2{0.0, 0.0};
+            if (pa_cp < NB) {
+                const long long g = p_cp_off + (it.iu0 + pa_cp % P1) + (long long)(iv0f + pa_cp / P1) * p_nu;
+                if (pa_q < 2) F.cp[r] = reinterpret_cast<const double2*>(M.cp4 + 4 * g)[pa_q];
+                else if (pa_q == 2) { F.cp[r].x = M.u[3 * g]; F.cp[r].y = M.u[3 * g + 1]; }
+                else { F.cp[r].x = M.u[3 * g + 2]; F.cp[r].y = M.h[g]; }
+            }
+            const int k = tid + 64 * r;
+            F.tv[r] = k < TS ? M.tab[p_tabv + ev * TS + k] : 0.0;
+        }
+        F.wv = tid < P1 ? M.tab[p_wv + ev * P1 + tid] : 0.0;
+        return F;
+    };
+    auto park = [&](const Fetch& F) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int task = tid + 64 * r, a = task >> 2, pa_q = task & 3;
+            if (a < NB) {
+                if (pa_q == 0) { s_c[a][0] = F.cp[r].x; s_c[a][1] = F.cp[r].y; }
+                else if (pa_q == 1) { s_c[a][2] = F.cp[r].x; s_w[a] = F.cp[r].y; }
+                else if (pa_q == 2) { s_d[a][0] = F.cp[r].x; s_d[a][1] = F.cp[r].y; }     // displacements for now; c is added below
+                else { s_d[a][2] = F.cp[r].x; s_h[a] = F.cp[r].y; }
+            }
+            const int k = tid + 64 * r;
+            if (k < TS) s_tv[k] = F.tv[r];
+        }
+        if (tid < P1) s_wg[P1 + tid] = F.wv;
+        wave_lds_sync();
+        if (tid < NB) { s_d[tid][0] += s_c[tid][0]; s_d[tid][1] += s_c[tid][1]; s_d[tid][2] += s_c[tid][2]; }      // deformed control points c + u
+    };
+    const int iv_first = s_iv[0];
+    {   // prologue: u table and weights of the strip, inputs of the first element
+        for (int k = tid; k < TS; k += 64) s_tu[k] = M.tab[p_tabu + it.eu * TS + k];
+        if (tid < P1) s_wg[tid] = M.tab[p_wu + it.eu * P1 + tid];
+        const Fetch F = fetch(it.ev0, iv_first);
+        park(F);
+    }
+    const __amdgpu_buffer_rsrc_t rR = buf_rsrc(O.rec + (size_t)blockIdx.x * O.rec_rows * RC::SZ, (unsigned)(O.rec_rows * RC::SZ * 8));
+
+    // accumulators of the pass (they live across the elements of the item)
+    constexpr int NK00 = PASS == 0 ? 6 : 1, NK10 = PASS == 0 ? 9 : 1, NCC = PASS != 0 ? 9 : 1, NCH = PASS != 0 ? 3 : 1;
+    gf_d4 accK00[NK00], accK11[NK00], accK10[NK10], accC[2][NCC], accH[2][NCH];
+    for (int q = 0; q < NK00; ++q) { accK00[q] = gf_d4{0, 0, 0, 0}; accK11[q] = gf_d4{0, 0, 0, 0}; }
+    for (int q = 0; q < NK10; ++q) accK10[q] = gf_d4{0, 0, 0, 0};
+    for (int ta = 0; ta < 2; ++ta) {
+        for (int q = 0; q < NCC; ++q) accC[ta][q] = gf_d4{0, 0, 0, 0};
+        for (int q = 0; q < NCH; ++q) accH[ta][q] = gf_d4{0, 0, 0, 0};
+    }
+    constexpr int QI[6] = {0, 0, 0, 1, 1, 2}, QJ[6] = {0, 1, 2, 1, 2, 2};
+
+    for (int t = 0; t < it.nel; ++t) {
+        const int ev = it.ev0 + t;
+        const long long e = p_elem_off + it.eu + (long long)ev * p_nelu;
+        const int iv0 = s_iv[t], iv0n = s_iv[t + 1];
+        const bool more = t + 1 < it.nel;
+        wave_lds_sync();
+        // ---- phase 1: one lane per Gauss point (sum-factorised control-point sums, quotient rule, pointwise record)
+        if (tid < NG) {
+            const int gu = tid % P1, gv = tid / P1;
+            double Ac[3][6], Ad[3][6], W[6], th = 0.0;
+            for (int k = 0; k < 6; ++k) { W[k] = 0.0; for (int i = 0; i < 3; ++i) { Ac[i][k] = 0.0; Ad[i][k] = 0.0; } }
+            double U[3][P1];
+            for (int d = 0; d < 3; ++d) for (int j = 0; j < P1; ++j) U[d][j] = s_tu[(gu * 3 + d) * P1 + j];
+#pragma unroll
+            for (int jv = 0; jv < P1; ++jv) {
+                const double v0 = s_tv[(gv * 3 + 0) * P1 + jv], v1 = s_tv[(gv * 3 + 1) * P1 + jv], v2 = s_tv[(gv * 3 + 2) * P1 + jv];
+                double S[7][3], Sh = 0.0;
+                for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) S[q][d] = 0.0;
+#pragma unroll
+                for (int ju = 0; ju < P1; ++ju) {
+                    const int a = ju + P1 * jv;
+                    const double qv[7] = {s_c[a][0], s_c[a][1], s_c[a][2], s_d[a][0], s_d[a][1], s_d[a][2], s_w[a]};
+                    for (int q = 0; q < 7; ++q) for (int d = 0; d < 3; ++d) S[q][d] += U[d][ju] * qv[q];
+                    Sh += U[0][ju] * s_h[a];
+                }
+                th += v0 * Sh;
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    double* A = q < 3 ? Ac[q] : (q < 6 ? Ad[q - 3] : W);
+                    A[0] += v0 * S[q][0]; A[1] += v0 * S[q][1]; A[2] += v1 * S[q][0];
+                    A[3] += v0 * S[q][2]; A[4] += v2 * S[q][0]; A[5] += v1 * S[q][1];
+                }
+            }
+            W[0] = 1.0 / W[0];
+            double z[15], Z[15], R[6];
+            for (int i = 0; i < 3; ++i) {
+                rationalize6(Ac[i], W, R);
+                for (int m = 0; m < 5; ++m) Z[3 * m + i] = R[m + 1];
+                rationalize6(Ad[i], W, R);
+                for (int m = 0; m < 5; ++m) z[3 * m + i] = R[m + 1];
+            }
+            double* im = s_im[tid];
+            shell_point(z, Z, th, s_pc[0], s_pc[1], im);
+            for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
+            im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
+        }
+        wave_lds_sync();
+
+        // this lane's basis functions in the current element: tile t -> (u index ub[t], v index = (slot - first row) mod 5)
+        const int jvb = mod5(slot_b - iv0);
+        auto basis = [&](const double* im, int gu, int gv, double (&phi)[2][5], double (&R0)[2], double (&n0)[2]) {
+            const double v0 = s_tv[(gv * 3 + 0) * P1 + jvb], v1 = s_tv[(gv * 3 + 1) * P1 + jvb], v2 = s_tv[(gv * 3 + 2) * P1 + jvb];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const int ju = ub[tl];
+                const double u0 = s_tu[(gu * 3 + 0) * P1 + ju], u1 = s_tu[(gu * 3 + 1) * P1 + ju], u2 = s_tu[(gu * 3 + 2) * P1 + ju];
+                const double Nb[6] = {u0 * v0, u1 * v0, u0 * v1, u2 * v0, u0 * v2, u1 * v1};
+                double R[6];
+                rationalize6(Nb, im + IM_W, R);
+                for (int k = 0; k < 5; ++k) phi[tl][k] = bval[tl] * R[k + 1];
+                R0[tl] = bval[tl] * R[0]; n0[tl] = bval[tl] * Nb[0];
+            }
+        };
+
+        double accR[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        if constexpr (PASS == 0) {
+            for (int grp = 0; grp < NGRP; ++grp) {
+                const int gp = 4 * grp + kk, gpc = gp < NG ? gp : NG - 1;
+                const int gu = gpc % P1, gv = gpc / P1;
+                const double* im = s_im[gpc];
+                const double wq = gp < NG ? im[IM_WQ] : 0.0;               // padded Gauss-point slots contribute nothing
+                double phi[2][5], R0[2], n0[2];
+                basis(im, gu, gv, phi, R0, n0);
+                double gR[15], hR[15];
+                for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
+                if (doK) { RLg.template expand<false>(im, gR, hR); dpp_source_fence(gR); }
+                {
+                    const double ls = has_bf ? load_scalar(im, ppd) : 0.0;
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta)
+                        for (int i = 0; i < 3; ++i) {
+                            double rz = 0.0;
+                            for (int m = 0; m < 5; ++m) rz += phi[ta][m] * im[IM_PZ + 3 * m + i];
+                            accR[ta][i] += wq * (rz - ls * pf[i] * R0[ta]);
+                        }
+                }
+                if (doK) {
+                    double pb0[5], pb1[5];
+                    for (int m = 0; m < 5; ++m) { pb0[m] = wq * phi[0][m]; pb1[m] = wq * phi[1][m]; }
+                    static_for<5>([&](auto m_) {
+                        constexpr int m = decltype(m_)::value;
+                        double t0[9], t1[6];
+                        static_for<9>([&](auto q_) { constexpr int q = decltype(q_)::value; t0[q] = row_dot<3 * m + q / 3, q % 3>(gR, pb0); });
+                        static_for<6>([&](auto q_) { constexpr int q = decltype(q_)::value; t1[q] = row_dot<3 * m + QI[q], QJ[q]>(gR, pb1); });
+                        mfma_hazard_gap(t0); mfma_hazard_gap(t1);
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) accK00[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[0][m], t0[3 * QI[q] + QJ[q]], accK00[q], 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) accK10[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[1][m], t0[q], accK10[q], 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) accK11[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[1][m], t1[q], accK11[q], 0, 0, 0);
+                    });
+                }
+            }
+        } else {
+            constexpr int tb = PASS - 1;
+            for (int grp = 0; grp < NGRP; ++grp) {
+                const int gp = 4 * grp + kk, gpc = gp < NG ? gp : NG - 1;
+                const int gu = gpc % P1, gv = gpc / P1;
+                const double* im = s_im[gpc];
+                const double wq = gp < NG ? im[IM_WQ] : 0.0;
+                double phi[2][5], R0[2], n0[2];
+                basis(im, gu, gv, phi, R0, n0);
+                double gR[15], hR[15];
+                for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
+                if (doC) { RLg.template expand<true>(im, gR, hR); dpp_source_fence(hR); }
+                double pb[5];
+                for (int m = 0; m < 5; ++m) pb[m] = wq * phi[tb][m];
+                const double n0b = n0[tb];
+                if (doH) {
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta) {
+                        double nn = 0.0;
+                        for (int k = 0; k < 3; ++k) nn += phi[ta][2 + k] * im[IM_JCK4 + k] * (k == 2 ? 2.0 : 1.0);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const double g1i = im[IM_G + i], g2i = im[IM_G + 3 + i];
+                            double rh = phi[ta][0] * (im[IM_JCE] * g1i + im[IM_JCE + 2] * g2i) + phi[ta][1] * (im[IM_JCE + 1] * g2i + im[IM_JCE + 2] * g1i);
+                            for (int k = 0; k < 3; ++k) rh -= im[IM_JCK4 + k] * (phi[ta][0] * im[IM_BG + 6 * k + i] + phi[ta][1] * im[IM_BG + 6 * k + 3 + i]);
+                            rh -= im[IM_N + i] * nn;
+                            accH[ta][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wq * rh, n0b, accH[ta][i], 0, 0, 0);
+                        }
+                    }
+                }
+                if (doC) {
+                    static_for<5>([&](auto m_) {
+                        constexpr int m = decltype(m_)::value;
+                        double tq[9];
+                        static_for<9>([&](auto q_) { constexpr int q = decltype(q_)::value; tq[q] = row_dot<3 * m + q / 3, q % 3>(hR, pb); });
+                        mfma_hazard_gap(tq);
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) {
+                            accC[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[0][m], tq[q], accC[0][q], 0, 0, 0);
+                            accC[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[1][m], tq[q], accC[1][q], 0, 0, 0);
+                        }
+                    });
+                    if (has_bf) {                    // d(-f . u dA)/dc : -w f_i R_a (dJ/dZ . phi_b)
+                        const LoadGeom lg = load_geom(im, ppd);
+#pragma unroll
+                        for (int f = 0; f < 3; ++f) {
+                            const double jz = load_dz_dot(im, ppd, lg, f, pb[0], pb[1]);
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                accC[0][3 * i + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pf[i] * R0[0], jz, accC[0][3 * i + f], 0, 0, 0);
+                                accC[1][3 * i + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pf[i] * R0[1], jz, accC[1][3 * i + f], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- residual of this element (PASS 0): sum the four Gauss-point slots of a group through the staging area, entry (local a, i) of the element
+        wave_lds_sync();
+        if constexpr (PASS == 0) {
+            if (kk >= 2) for (int ta = 0; ta < 2; ++ta) for (int i = 0; i < 3; ++i) s_g[(((kk - 2) * 2 + ta) * 16 + x) * 3 + i] = accR[ta][i];
+            wave_lds_sync();
+            if (kk < 2) for (int ta = 0; ta < 2; ++ta) for (int i = 0; i < 3; ++i) accR[ta][i] += s_g[((kk * 2 + ta) * 16 + x) * 3 + i];
+            wave_lds_sync();
+            if (kk == 1) for (int ta = 0; ta < 2; ++ta) for (int i = 0; i < 3; ++i) s_g[(ta * 16 + x) * 3 + i] = accR[ta][i];
+            wave_lds_sync();
+            if (kk == 0 && (flags & GF_ASM_R_BIT)) for (int ta = 0; ta < 2; ++ta) {
+                if (bvalid[ta]) {
+                    const int a = ub[ta] + P1 * jvb;
+                    for (int i = 0; i < 3; ++i) O.rblk[(size_t)e * ND + 3 * a + i] = accR[ta][i] + s_g[(ta * 16 + x) * 3 + i];
+                }
+            }
+            wave_lds_sync();
+        }
+
+        // ---- the next element's inputs are requested in front of the flush stores
+        Fetch Fn;
+        if (more) Fn = fetch(ev + 1, iv0n);
+
+        // ---- flush: the pairs whose lower row leaves the window (rows < iv0n) are complete for this item
+        const int rowb = iv0 + mod5(slot_b - iv0);
+        int rowa[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) rowa[rr] = iv0 + mod5(slot_a[rr] - iv0);
+        // byte offsets of component 0 of the ordered pair (A = (uA, rA), B = (uB, rB)) and its component stride
+        auto pair_off = [&](int uA, int rA, int uB, int rB, unsigned& cs) {
+            const int rho = rA < rB ? rA : rB, d = rA < rB ? rB - rA : rA - rB;
+            const bool a1 = rA <= rB;
+            cs = 8u * (a1 ? 25u : 5u);
+            return 8u * (unsigned)((rho - iv_first) * RC::SZ + (a1 ? (uA * NC * 5 + d) * 5 + uB : RC::A1 + (uA * 4 + d - 1) * NC * 5 + uB));
+        };
+        auto flush_tile = [&](auto tag, int ta, int tb2, gf_d4* acc, int ncomp) {
+            constexpr int KIND = decltype(tag)::value;       // 0: K diagonal quadrant (6 comps i <= j, mirrored); 1: K (1,0) quadrant (9 comps, mirrored); 2: dR/dCP (9); 3: dR/dh (3)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int rA = rowa[rr], lo = rA < rowb ? rA : rowb;
+                const bool ok = avalid[ta][rr] && bvalid[tb2] && lo < iv0n;
+                if (ok) {
+                    unsigned cs, cst;
+                    const unsigned o = pair_off(ua[ta][rr], rA, ub[tb2], rowb, cs);
+                    if constexpr (KIND <= 1) {
+                        const unsigned ot = pair_off(ub[tb2], rowb, ua[ta][rr], rA, cst);
+                        if constexpr (KIND == 0) {
+#pragma unroll
+                            for (int q = 0; q < 6; ++q) {
+                                buf_st(rR, o + (3 * QI[q] + QJ[q]) * cs, acc[q][rr]);
+                                if (QI[q] != QJ[q]) buf_st(rR, ot + (3 * QJ[q] + QI[q]) * cst, acc[q][rr]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 9; ++q) {
+                                buf_st(rR, o + q * cs, acc[q][rr]);
+                                buf_st(rR, ot + (3 * (q % 3) + q / 3) * cst, acc[q][rr]);
+                            }
+                        }
+                    } else if constexpr (KIND == 2) {
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) buf_st(rR, o + (9 + q) * cs, acc[q][rr]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) buf_st(rR, o + (18 + q) * cs, acc[q][rr]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < (KIND == 0 ? 6 : (KIND == 3 ? 3 : 9)); ++q) acc[q][rr] = ok ? 0.0 : acc[q][rr];
+                (void)ncomp;
+            }
+        };
+        if constexpr (PASS == 0) {
+            if (doK) {
+                flush_tile(std::integral_constant<int, 0>{}, 0, 0, accK00, 6);
+                flush_tile(std::integral_constant<int, 0>{}, 1, 1, accK11, 6);
+                flush_tile(std::integral_constant<int, 1>{}, 1, 0, accK10, 9);
+            }
+        } else {
+            constexpr int tb = PASS - 1;
+            if (doC) { flush_tile(std::integral_constant<int, 2>{}, 0, tb, accC[0], 9); flush_tile(std::integral_constant<int, 2>{}, 1, tb, accC[1], 9); }
+            if (doH) { flush_tile(std::integral_constant<int, 3>{}, 0, tb, accH[0], 3); flush_tile(std::integral_constant<int, 3>{}, 1, tb, accH[1], 3); }
+        }
+        // ---- park the next element's inputs
+        wave_lds_sync();
+        if (more) park(Fn);
+    }
+}
+
+}  // namespace gf

@@ -141,6 +141,11 @@ if __name__ == "__main__":
     tag, gps = sys.argv[1], int(sys.argv[2])
     outfile = sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json"
     out = build(tag, gps)
+    try:
+        import subprocess
+        out["generated_at_commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        out["generated_at_commit"] = None
     json.dump(out, open(outfile, "w"), indent=1)
     print(json.dumps({k: round(v["hbm_side_bytes_corrected_per_launch"] / 1e9, 2) for k, v in out["kernels"].items() if "hbm_side_bytes_corrected_per_launch" in v}))
     print("full pass:", out["full_pass_kernels"], "%.2f GB per step" % (out["full_pass_bytes_per_step"] / 1e9))
