@@ -332,7 +332,7 @@ def measure(args, torch, dist, rank, local_rank, world):
                                       "FMA*2 per Gauss-point update (DESIGN.md section 4), not hardware-issued flops",
                               # what the pipe sustains on this GPU: microbenchmarks of an earlier run (tools/ubench_acc, ubench_batch, ubench_f64), NOT measured in this run --
                               # not a second peak, the explanation of where the kernel sits against the data-sheet figure above
-                              "pipe_measured": {"source": "profiles/r03_ubench_fp64_mfma.txt (stored microbenchmark output of round 3, commit 26f73d5 or earlier; NOT measured in this run)",
+                              "pipe_measured": {"source": "profiles/r03_ubench_fp64_mfma.txt (stored microbenchmark output of round 3, commit a6d8311; NOT measured in this run)",
                                                 "v_mfma_f64_16x16x4_vgpr_accumulators_tflops": 74.0, "v_mfma_f64_16x16x4_agpr_accumulators_tflops_one_wave_per_simd": 36.0,
                                                 "v_mfma_f64_16x16x4_agpr_accumulators_tflops_two_waves_per_simd": 45.0, "v_fma_f64_tflops": 56.0,
                                                 "mfma_and_fp64_valu_co_execute": False}},
