@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgoldfish_hip.so")
-SOURCES = ["gf_lib.hip", "gf_kernels.hpp", "gf_gauss_loop.hpp", "gf_element_mfma.hpp", "gf_element_mfma4.hpp", "gf_element_rec.hpp", "gf_penalty_row16.hpp", "gf_penalty_point16.hpp", "gf_setup.hpp", "kl_point.hpp",
+SOURCES = ["gf_lib.hip", "gf_kernels.hpp", "gf_gauss_loop.hpp", "gf_element_mfma.hpp", "gf_element_mfma4.hpp", "gf_element_rec.hpp", "gf_element_rec4.hpp", "gf_extra_loads.hpp", "gf_penalty_row16.hpp", "gf_penalty_point16.hpp", "gf_setup.hpp", "kl_point.hpp",
            os.path.join("..", "..", "include", "goldfish_hip.h"), os.path.join("..", "..", "include", "goldfish_model.h")]
 
 

@@ -27,7 +27,7 @@
 namespace gf {
 
 template <int NC> struct Rec4Cfg { static constexpr int A1 = 5 * NC * 25, SZ = A1 + 5 * 4 * NC * 5; };
-struct Rec4Out { double* rec; double* rblk; int rec_rows; };
+struct Rec4Out { double* rec; double* rblk; int rec_rows; long long e_first; };     // rblk: 75 residual doubles per element of the chunk (element e at e - e_first)
 
 __device__ __forceinline__ int mod5(int v) { int r = v % 5; return r < 0 ? r + 5 : r; }
 
@@ -44,8 +44,12 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
     const PatchDev& Pt = M.patches[it.patch];
     const int p_nu = uni(Pt.nu), p_nelu = uni(Pt.nelu), p_tabu = uni(Pt.tabu), p_tabv = uni(Pt.tabv), p_wu = uni(Pt.wu), p_wv = uni(Pt.wv), p_spv = uni(Pt.spv);
     const long long p_cp_off = uni64(Pt.cp_off), p_elem_off = uni64(Pt.elem_off);
-    __shared__ int s_iv[REC_MAX_NEL + 1];               // first control-point row of every element of the item (+ one behind: every row has left)
-    for (int k = threadIdx.x; k <= it.nel && k <= REC_MAX_NEL; k += 64) s_iv[k] = M.ints[p_spv + it.ev0 + (k < it.nel ? k : it.nel - 1)] - P + (k < it.nel ? 0 : P1);
+    // row advance from every element of the item to the next one (after the last element every row leaves: P1); one byte each -- with an int table the
+    // kernel's LDS passes 40 KB and only three waves fit a CU
+    __shared__ unsigned char s_dv[REC_MAX_NEL + 1];
+    for (int k = threadIdx.x; k < it.nel && k <= REC_MAX_NEL; k += 64)
+        s_dv[k] = (unsigned char)(k + 1 < it.nel ? M.ints[p_spv + it.ev0 + k + 1] - M.ints[p_spv + it.ev0 + k] : P1);
+    const int iv_first = uni(M.ints[p_spv + it.ev0] - P);
     __shared__ double s_pc[8];
     if (threadIdx.x < 8) s_pc[threadIdx.x] = (&Pt.E)[threadIdx.x];
     const double* const pf = s_pc + 2; const double* const ppd = s_pc + 5;
@@ -65,14 +69,6 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
     const bool bvalid[2] = {x < 15, x < 10};
     const int ub[2] = {jq < 3 ? jq : 0, jq < 2 ? 3 + jq : 3};
     const double bval[2] = {bvalid[0] ? 1.0 : 0.0, bvalid[1] ? 1.0 : 0.0};
-    int ua[2][4], slot_a[4]; bool avalid[2][4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int xa = kk + 4 * rr, q = xa / 5;
-        slot_a[rr] = xa % 5;
-        avalid[0][rr] = xa < 15; avalid[1][rr] = xa < 10;
-        ua[0][rr] = q < 3 ? q : 0; ua[1][rr] = q < 2 ? 3 + q : 3;
-    }
     const RowLane RLg(x);
 
     // ---- inputs of one element: 64 bytes per control point (c_xy | c_zw | u_xy | u_z, h: lane task = 4 * local index + quarter, 100 tasks in two rounds),
@@ -114,7 +110,6 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
         wave_lds_sync();
         if (tid < NB) { s_d[tid][0] += s_c[tid][0]; s_d[tid][1] += s_c[tid][1]; s_d[tid][2] += s_c[tid][2]; }      // deformed control points c + u
     };
-    const int iv_first = s_iv[0];
     {   // prologue: u table and weights of the strip, inputs of the first element
         for (int k = tid; k < TS; k += 64) s_tu[k] = M.tab[p_tabu + it.eu * TS + k];
         if (tid < P1) s_wg[tid] = M.tab[p_wu + it.eu * P1 + tid];
@@ -134,12 +129,13 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
     }
     constexpr int QI[6] = {0, 0, 0, 1, 1, 2}, QJ[6] = {0, 1, 2, 1, 2, 2};
 
+    int iv0 = iv_first;
     for (int t = 0; t < it.nel; ++t) {
         const int ev = it.ev0 + t;
         const long long e = p_elem_off + it.eu + (long long)ev * p_nelu;
-        const int iv0 = s_iv[t], iv0n = s_iv[t + 1];
-        const bool more = t + 1 < it.nel;
         wave_lds_sync();
+        const int iv0n = iv0 + uni((int)s_dv[t]);
+        const bool more = t + 1 < it.nel;
         // ---- phase 1: one lane per Gauss point (sum-factorised control-point sums, quotient rule, pointwise record)
         if (tid < NG) {
             const int gu = tid % P1, gv = tid / P1;
@@ -308,7 +304,7 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
             if (kk == 0 && (flags & GF_ASM_R_BIT)) for (int ta = 0; ta < 2; ++ta) {
                 if (bvalid[ta]) {
                     const int a = ub[ta] + P1 * jvb;
-                    for (int i = 0; i < 3; ++i) O.rblk[(size_t)e * ND + 3 * a + i] = accR[ta][i] + s_g[(ta * 16 + x) * 3 + i];
+                    for (int i = 0; i < 3; ++i) O.rblk[(size_t)(e - O.e_first) * ND + 3 * a + i] = accR[ta][i] + s_g[(ta * 16 + x) * 3 + i];
                 }
             }
             wave_lds_sync();
@@ -319,10 +315,19 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
         if (more) Fn = fetch(ev + 1, iv0n);
 
         // ---- flush: the pairs whose lower row leaves the window (rows < iv0n) are complete for this item
+        // (the A-side roles of the four registers of a D tile are re-derived here from an opaque copy of the lane id: kept in registers across the Gauss-point
+        //  loop they are two dozen values the register allocator has to spill)
+        int kk2 = kk;
+        asm volatile("" : "+v"(kk2));
         const int rowb = iv0 + mod5(slot_b - iv0);
-        int rowa[4];
+        int rowa[4], ua[2][4]; bool avalid[2][4];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) rowa[rr] = iv0 + mod5(slot_a[rr] - iv0);
+        for (int rr = 0; rr < 4; ++rr) {
+            const int xa = kk2 + 4 * rr, q = xa / 5;
+            rowa[rr] = iv0 + mod5(xa % 5 - iv0);
+            avalid[0][rr] = xa < 15; avalid[1][rr] = xa < 10;
+            ua[0][rr] = q < 3 ? q : 0; ua[1][rr] = q < 2 ? 3 + q : 3;
+        }
         // byte offsets of component 0 of the ordered pair (A = (uA, rA), B = (uB, rB)) and its component stride
         auto pair_off = [&](int uA, int rA, int uB, int rB, unsigned& cs) {
             const int rho = rA < rB ? rA : rB, d = rA < rB ? rB - rA : rA - rB;
@@ -381,7 +386,108 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
         // ---- park the next element's inputs
         wave_lds_sync();
         if (more) park(Fn);
+        iv0 = iv0n;
     }
+}
+
+// Record gather, p = 4: ONE wave per control point a = (ia, ja) sums, item by item (strips ascending, segments ascending: a fixed order), what the row
+// records hold for its three dof rows, then writes the rows (gather_write_rows: Dirichlet entries, coupling-only columns, penalty rows).  From a work item
+// (strip iu0 .. iu0 + 4) with ua = ia - iu0:
+//   G1  record ja,     area 1 [ua][c][d][ub]:      the pairs (a, b = (iu0 + ub, ja + d)), d = 0..4, all components: 25 NC contiguous doubles
+//   G3  record ja - d, area 2 [ua][d - 1][c][ub]:  the pairs (a, b = (iu0 + ub, ja - d)), d = 1..4: 5 NC contiguous doubles per d
+// Every ordered pair is stored with all its components (the element kernel writes the transposed K entries), so there are no mirrored reads.  A pair is
+// present in an item only if one of the item's elements holds both rows (RecCp4::info, bit 16 + (jb - ja + 4)); everything else in a record row is never
+// written and never read.
+template <int NC>
+__global__ __launch_bounds__(64) void kl_gather_rec4_kernel(DevModel M, long long a_first, long long a_end, int flags, const double* __restrict__ rec, long long row_base,
+                                                            const RecCp4* __restrict__ reccp, double* __restrict__ valK, double* __restrict__ valC0,
+                                                            double* __restrict__ valC1, double* __restrict__ valC2, double* __restrict__ valH, int pen_add) {
+    using RC = Rec4Cfg<NC>;
+    constexpr int WB = 9, NBOX = WB * WB, SZ = RC::SZ, A1 = RC::A1;
+    constexpr bool WITHC = NC == 21;
+    // workgroup w runs on XCD w % 8: every XCD takes a contiguous range of control points (the record lines shared by neighbours meet in one L2)
+    const long long chunk = (a_end - a_first + 7) / 8;
+    const long long a = a_first + (long long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((long long)(blockIdx.x >> 3) >= chunk || a >= a_end) return;
+    const CpDesc& cd = M.cpdesc[a];
+    const int ja = cd.ja, j0 = cd.j0, wbox = cd.i1 - cd.i0 + 1;
+    const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c, ptr_s = M.nb_ptr_s[a], deg_s = M.nb_ptr_s[a + 1] - ptr_s;
+    const int lane = threadIdx.x;
+    __shared__ double acc[21 * NBOX];                   // aK [3][NBOX][3] | aH [3][NBOX] | aC [3 f][3 i][NBOX]
+    __shared__ unsigned short s_meta[GATHER_MAXMETA];
+    const RecCp4 rc = reccp[a];                         // the work items of a (wave-uniform: scalar loads)
+    const bool pen_row_a = M.pen_row[a] != 0;
+    for (int k = lane; k < 21 * NBOX; k += 64) acc[k] = 0.0;
+    const bool doC = WITHC && (flags & GF_ASM_C_BIT) != 0, doK = (flags & GF_ASM_K_BIT) != 0, doH = WITHC && (flags & GF_ASM_H_BIT) != 0;
+    // accumulator address of component c at box slot 0 and its stride in the slot (3 for K, 1 otherwise)
+    auto comp_base = [&](int c) { return c < 9 ? (c / 3) * NBOX * 3 + c % 3 : (c < 18 ? 12 * NBOX + (((c - 9) % 3) * 3 + (c - 9) / 3) * NBOX : 9 * NBOX + (c - 18) * NBOX); };
+    constexpr int N1 = NC * 25, NP1 = (N1 + 63) / 64, N3 = 4 * NC * 5, NP3 = (N3 + 63) / 64, NV = NP1 + NP3;
+    // per-lane task table (independent of the item): tk = accumulator address for iu0 = i0 | stride3 << 15 | presence bit << 16 | valid << 20; to = offset of the value
+    // relative to the row record of ja (+ ua * mul)
+    int tk[NV], to[NV];
+#pragma unroll
+    for (int ps = 0; ps < NP1; ++ps) {
+        const int e = lane + 64 * ps, ec = e < N1 ? e : 0, c = ec / 25, d = (ec % 25) / 5, ubx = ec % 5;
+        const bool en = c < 9 ? doK : (c < 18 ? doC : doH);
+        const bool ok = e < N1 && en;
+        tk[ps] = ((comp_base(c) + (ubx + (ja + d - j0) * wbox) * (c < 9 ? 3 : 1)) & 0x7fff) | (c < 9 ? 1 << 15 : 0) | ((4 + d) << 16) | (ok ? 1 << 20 : 0);
+        to[ps] = ec;                                                  // + ua * NC * 25
+    }
+#pragma unroll
+    for (int ps = 0; ps < NP3; ++ps) {
+        const int e = lane + 64 * ps, ec = e < N3 ? e : 0, d = 1 + ec / (NC * 5), r = ec % (NC * 5), c = r / 5, ubx = r % 5;
+        const bool en = c < 9 ? doK : (c < 18 ? doC : doH);
+        const bool ok = e < N3 && en;
+        tk[NP1 + ps] = ((comp_base(c) + (ubx + (ja - d - j0) * wbox) * (c < 9 ? 3 : 1)) & 0x7fff) | (c < 9 ? 1 << 15 : 0) | ((4 - d) << 16) | (ok ? 1 << 20 : 0);
+        to[NP1 + ps] = -d * SZ + A1 + (d - 1) * NC * 5 + r;            // + ua * 4 * NC * 5
+    }
+    struct Item { double v[NV]; int du; unsigned pm; };
+    auto load_item = [&](int n) {
+        Item I;
+        int row = rc.it[0].row; unsigned info = rc.it[0].info;
+#pragma unroll
+        for (int q = 1; q < 10; ++q) if (q == n) { row = rc.it[q].row; info = rc.it[q].info; }       // register-resident table: no dynamic indexing
+        I.du = int(info & 255u); I.pm = info >> 16;
+        const int uaa = int((info >> 8) & 255u);
+        const double* Rja = rec + (size_t)((long long)row - row_base) * SZ;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int mul = v < NP1 ? NC * 25 : 4 * NC * 5;
+            const bool ok = ((tk[v] >> 20) & 1) && ((I.pm >> ((tk[v] >> 16) & 15)) & 1);
+            // unconditional load (an absent pair reads the head of the row record; its value is never added): see kl_gather_rec_kernel
+            I.v[v] = Rja[ok ? to[v] + uaa * mul : 0];
+        }
+        return I;
+    };
+    auto add_item = [&](const Item& I) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bool ok = ((tk[v] >> 20) & 1) && ((I.pm >> ((tk[v] >> 16) & 15)) & 1);
+            if (ok) (void)__hip_atomic_fetch_add(&acc[(tk[v] & 0x7fff) + I.du * ((tk[v] >> 15) & 1 ? 3 : 1)], I.v[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    const int nit = rc.nit;
+    constexpr int NBT = 2;                              // work items whose loads are in flight together
+    Item B[NBT];
+#pragma unroll
+    for (int q = 0; q < NBT; ++q) if (q < nit) B[q] = load_item(q);
+    constexpr int NM = (GATHER_MAXMETA + 63) / 64;
+    unsigned short mt[NM];
+#pragma unroll
+    for (int q = 0; q < NM; ++q) { const int k = lane + 64 * q; mt[q] = k < (int)deg_c ? M.nb_meta[ptr_c + k] : (unsigned short)0; }
+    for (int n0 = 0; n0 < nit; n0 += NBT) {
+#pragma unroll
+        for (int q = 0; q < NBT; ++q) {
+            if (n0 + q < nit) add_item(B[q]);
+            if (n0 + NBT + q < nit) B[q] = load_item(n0 + NBT + q);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NM; ++q) { const int k = lane + 64 * q; if (k < GATHER_MAXMETA) s_meta[k] = mt[q]; }
+    wave_lds_sync();
+    const bool padd = pen_add && pen_row_a;
+    gather_write_rows<NBOX, WITHC>(M, a, lane, doK, doC, doH, padd, (unsigned)rc.flags, ptr_c, deg_c, ptr_s, deg_s, s_meta, acc, acc + 12 * NBOX, acc + 9 * NBOX,
+                                   valK, valC0, valC1, valC2, valH);
 }
 
 }  // namespace gf

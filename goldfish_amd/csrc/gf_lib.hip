@@ -16,6 +16,7 @@ constexpr int GF_ASM_R_BIT = 1, GF_ASM_K_BIT = 2, GF_ASM_C_BIT = 4, GF_ASM_H_BIT
 #include "gf_element_mfma.hpp"
 #include "gf_element_mfma4.hpp"
 #include "gf_element_rec.hpp"
+#include "gf_element_rec4.hpp"
 #include "gf_penalty_row16.hpp"
 #include "gf_penalty_point16.hpp"
 #include "gf_extra_loads.hpp"
@@ -49,6 +50,7 @@ struct gf_handle {
     bool assembled[5] = {false, false, false, false, false};
     bool rec = false;                                 // p = 2, 3, MFMA path, default: walking kernel that stores row records + kl_gather_rec_kernel (gf_element_rec.hpp); GF_ASSEMBLY=block: one block per element + row gather
     const WalkItem* d_rec_items = nullptr; const RecCp* d_rec_cp = nullptr; double* d_rec = nullptr; long long rec_doubles = 0;
+    bool rec4 = false; const RecCp4* d_rec_cp4 = nullptr;   // p = 4, default: three walks that store row records + kl_gather_rec4_kernel (gf_element_rec4.hpp); GF_ASSEMBLY=block: element blocks
     bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
     const int *d_rev_s = nullptr, *d_rev_c = nullptr;
     const int* d_load_cps = nullptr;                  // control points of the follower pressure / edge tractions (gf_extra_loads.hpp)
@@ -90,12 +92,12 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         {
             // p = 2, 3 on the matrix pipe: row records + record gather (gf_element_rec.hpp) by default; GF_ASSEMBLY=block: one block per
             // element + row gather (the cross-check path of the tests)
-            bool want_rec = h->mfma && H.degree <= 3;
+            bool want_rec = h->mfma && H.degree <= 4;
             if (const char* s = getenv("GF_ASSEMBLY")) want_rec = want_rec && std::string(s) != "block";
             int seg = 0;                                      // whole strips unless the model is small (HostModel::build_rec); GF_REC_SEG: elements per work item
             if (const char* s = getenv("GF_REC_SEG")) seg = std::max(1, atoi(s));
             H.tick("penalty owner lists, visit records");
-            if (want_rec) { H.build_rec(seg); h->rec = true; H.tick("row-record tables"); }
+            if (want_rec) { H.build_rec(seg); h->rec = H.degree <= 3; h->rec4 = H.degree == 4; H.tick("row-record tables"); }
         }
         std::vector<long long> nbs(H.nb_ptr_s.begin(), H.nb_ptr_s.end()), nbc(H.nb_ptr_c.begin(), H.nb_ptr_c.end());
         h->d_cp4 = h->dalloc<double>(4 * H.total_cp); h->d_u = h->dalloc<double>(H.ndof); h->d_h = h->dalloc<double>(H.total_cp); h->d_R = h->dalloc<double>(H.ndof);
@@ -161,12 +163,17 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             if (H.nb_ptr_c[a + 1] - H.nb_ptr_c[a] > GATHER_MAXMETA) throw std::runtime_error("gf_create: a control point has more than " + std::to_string(GATHER_MAXMETA) + " neighbours (GATHER_MAXMETA)");
         // element-block scratch, chunked over whole patches
         const int P = H.degree, NB = (P + 1) * (P + 1), ND = 3 * NB;
-        const long long blk_doubles = h->rec ? (long long)ND : 2LL * ND * ND + (long long)ND * NB + ND;   // row-record path: residual entries only
+        const bool recs = h->rec || h->rec4;
+        // doubles of scratch per element: element blocks, or (row-record paths) the residual entries + the element's share of the records
+        const long long rec_sz = h->rec4 ? Rec4Cfg<21>::SZ : RecCfg<true>::SZ;
+        const long long blk_doubles = recs ? (long long)ND : 2LL * ND * ND + (long long)ND * NB + ND;
         double budget_gb = 40.0;
         if (const char* s = getenv("GF_SCRATCH_GB")) budget_gb = atof(s);
-        if (h->rec) budget_gb = 1e9;                      // no element blocks: one chunk
-        const long long max_elems = std::max<long long>(1, (long long)(budget_gb * 1e9 / (blk_doubles * 8.0)));
-        long long biggest = 0;
+        if (h->rec) budget_gb = 1e9;                      // p = 2, 3 records: one chunk
+        // p = 4 records: ~rec_sz doubles per element (one record row per element row and strip); chunks of whole patches within the budget
+        const double per_elem = h->rec4 ? double(rec_sz + ND) : double(blk_doubles);
+        const long long max_elems = std::max<long long>(1, (long long)(budget_gb * 1e9 / (per_elem * 8.0)));
+        long long biggest = 0, biggest_items = 0;
         for (int s = 0; s < H.n_owned;) {
             Chunk c; c.p0 = s; c.e0 = H.patches[s].elem_off; c.a0 = H.patches[s].cp_off;
             long long ne = 0;
@@ -177,12 +184,17 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             }
             c.p1 = s; c.e1 = c.e0 + ne; c.a1 = (s < H.np) ? H.patches[s].cp_off : H.total_cp;
             h->chunks.push_back(c); biggest = std::max(biggest, ne);
+            if (recs) {
+                const long long i0 = H.rec_patch[c.p0].item_off, i1 = c.p1 < H.n_owned ? H.rec_patch[c.p1].item_off : (long long)H.rec_items.size();
+                biggest_items = std::max(biggest_items, i1 - i0);
+            }
         }
         long long scratch_doubles = biggest * blk_doubles;
-        if (h->rec) {
+        if (recs) {
             scratch_doubles = std::max<long long>(scratch_doubles, H.nelem * (long long)(11 * NB + 2));   // the functionals' element blocks (FunCfg::STRIDE) share the scratch
-            h->d_rec_items = h->upload(H.rec_items); h->d_rec_cp = h->upload(H.rec_cp);
-            h->rec_doubles = (long long)H.rec_items.size() * H.rec_rows * RecCfg<true>::SZ;
+            h->d_rec_items = h->upload(H.rec_items);
+            if (h->rec4) h->d_rec_cp4 = h->upload(H.rec_cp4); else h->d_rec_cp = h->upload(H.rec_cp);
+            h->rec_doubles = biggest_items * H.rec_rows * rec_sz;
             h->d_rec = h->dalloc<double>((size_t)h->rec_doubles);
         }
         h->d_blk = h->dalloc<double>((size_t)scratch_doubles);
@@ -355,6 +367,45 @@ template <int P> static void run_assemble_rec(gf_handle* h, int flags) {
     HIPCHK(hipGetLastError());
 }
 
+// p = 4 row-record path (gf_element_rec4.hpp): penalty rows first (written), then per chunk of patches the walks -- PASS 0 (R + K), PASS 1, 2 (dR/dCP +
+// dR/dh per b tile) -- over the chunk's work items and the record gather of the chunk's control points.
+static void run_assemble_rec4(gf_handle* h, int flags) {
+    const HostModel& H = h->H;
+    const bool mats = (flags & ~GF_ASM_R) != 0, full = (flags & (GF_ASM_DRDCP | GF_ASM_DRDH)) != 0;
+    const int pen = run_penalty<4>(h, flags);
+    for (const Chunk& c : h->chunks) {
+        const long long i0 = H.rec_patch[c.p0].item_off, i1 = c.p1 < H.n_owned ? H.rec_patch[c.p1].item_off : (long long)H.rec_items.size();
+        const unsigned n = (unsigned)(i1 - i0);
+        const Rec4Out O{h->d_rec, h->d_blk, H.rec_rows, c.e0};
+        const WalkItem* items = h->d_rec_items + i0;
+        const int slot = h->ev_n % 64;
+        HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
+        if (flags & (GF_ASM_R | GF_ASM_K)) {
+            if (full) hipLaunchKernelGGL((kl_element_rec4_kernel<0, 21>), dim3(n), dim3(64), 0, h->stream, h->M, items, flags, O);
+            else hipLaunchKernelGGL((kl_element_rec4_kernel<0, 9>), dim3(n), dim3(64), 0, h->stream, h->M, items, flags, O);
+        }
+        if (full) {
+            hipLaunchKernelGGL((kl_element_rec4_kernel<1, 21>), dim3(n), dim3(64), 0, h->stream, h->M, items, flags, O);
+            hipLaunchKernelGGL((kl_element_rec4_kernel<2, 21>), dim3(n), dim3(64), 0, h->stream, h->M, items, flags, O);
+        }
+        HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
+        h->ev_n++;
+        const long long ne = c.e1 - c.e0, na = c.a1 - c.a0;
+        if (mats && na > 0) {
+            const dim3 grid((unsigned)(((na + 7) / 8) * 8));
+            const long long row_base = i0 * H.rec_rows;
+            if (full) hipLaunchKernelGGL((kl_gather_rec4_kernel<21>), grid, dim3(64), 0, h->stream, h->M, c.a0, c.a1, flags, h->d_rec, row_base, h->d_rec_cp4,
+                                         h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], pen);
+            else hipLaunchKernelGGL((kl_gather_rec4_kernel<9>), grid, dim3(64), 0, h->stream, h->M, c.a0, c.a1, flags, h->d_rec, row_base, h->d_rec_cp4,
+                                    h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3], h->d_val[4], pen);
+        }
+        if (flags & GF_ASM_R) hipLaunchKernelGGL(kl_rgather_kernel<4>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, h->M, c.a0, c.a1, c.e0, ne, h->d_blk, h->d_R, pen, 75, 0);
+    }
+    run_extra_loads<4>(h, flags);
+    if (flags & GF_ASM_R) finish_residual(h);
+    HIPCHK(hipGetLastError());
+}
+
 template <int P> static void run_assemble(gf_handle* h, int flags) {
     using Cfg = ElemCfg<P>;
     const HostModel& H = h->H;
@@ -363,6 +414,7 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
     // and dropped: next to the element kernel they cost it LDS occupancy (17.7 -> 22.8 ms), next to the gather both slow down
     // by what the overlap saves (profiles/r01_v8_*).
     if ((P == 2 || P == 3) && h->rec) { run_assemble_rec<P>(h, flags); return; }
+    if (P == 4 && h->rec4) { run_assemble_rec4(h, flags); return; }
     const int pen = run_penalty<P>(h, flags);
     for (size_t ci = 0; ci < h->chunks.size(); ++ci) {
         const Chunk& c = h->chunks[ci];
@@ -596,7 +648,7 @@ double gf_kernel_ms(gf_handle* h, int* n_launches) {
 
 void* gf_stream(gf_handle* h) { return h ? (void*)h->stream : nullptr; }
 
-int gf_assembly_path(const gf_handle* h) { return !h ? -1 : (h->rec ? 4 : (h->mfma ? 0 : 3)); }
+int gf_assembly_path(const gf_handle* h) { return !h ? -1 : (h->rec4 ? 5 : (h->rec ? 4 : (h->mfma ? 0 : 3))); }
 
 int gf_get_functional_gradient(gf_handle* h, int field, double* out, int64_t n) {
     if (!h || !out) return fail("gf_get_functional_gradient: null argument");

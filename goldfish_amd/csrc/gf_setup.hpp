@@ -51,6 +51,8 @@ struct RecPatch { int item_off, nseg, seg_of, ev0_of; };
 // row record of ja in that item; info = (iu0 - i0) | (ia - iu0) << 8 | pm << 16, pm bit d: the rows ja and ja - 3 + d share an element
 // of the item (only then the pair (ja, ja - 3 + d) is present in its records)
 struct RecCp { int nit, flags; struct { int row; unsigned info; } it[8]; };   // flags: bits 0-2 Dirichlet dofs of the control point
+// p = 4 (gf_element_rec4.hpp): a control point lies in up to 5 strips x 2 segments; pm bit d: the rows ja and ja - 4 + d share an element of the item
+struct RecCp4 { int nit, flags; struct { int row; unsigned info; } it[10]; };
 
 struct PenRowItem { int a, code, lo, hi; };           // code = iface*2 + s
 // one (owned control point, mortar vertex) visit of the penalty row kernel: everything the kernel needs to address the
@@ -121,7 +123,7 @@ struct HostModel {
     std::vector<int> elem_patch;        // [nelem]
     std::vector<ElemDesc> elem_desc;    // [nelem]
     std::vector<CpDesc> cp_desc;        // [total_cp]
-    std::vector<WalkItem> rec_items; std::vector<RecPatch> rec_patch; std::vector<RecCp> rec_cp; int rec_rows = 0;   // row-record path
+    std::vector<WalkItem> rec_items; std::vector<RecPatch> rec_patch; std::vector<RecCp> rec_cp; std::vector<RecCp4> rec_cp4; int rec_rows = 0;   // row-record path
     void build_rec(int seg_len);
     std::vector<int> cp_patch;          // [total_cp]
     std::vector<double> weights;
@@ -467,8 +469,8 @@ inline void HostModel::build(const gf_model_desc* D) {
 // Tables of the row-record path: work items in natural order (patch, strip, segment) -- nothing depends on launch order --, per
 // patch the segment of every element row, and the number of record rows an item can touch.  Called before the tables are uploaded.
 inline void HostModel::build_rec(int seg_len) {
-    if (degree < 2 || degree > 3) throw std::runtime_error("build_rec: p = 2, 3 only");
-    const int P1 = degree + 1;
+    if (degree < 2 || degree > 4) throw std::runtime_error("build_rec: p = 2, 3, 4 only");
+    const int P1 = degree + 1, PW = degree == 4 ? 4 : 3, MAXIT = degree == 4 ? 10 : 8;      // PW: row reach of a pair in the record layout (the p = 2 kernel runs on the p = 3 tile)
     rec_items.clear(); rec_patch.assign(np, RecPatch{0, 0, 0, 0}); rec_rows = 0;
     // seg_len <= 0: whole strips (no partial sums at segment ends: 11 % fewer record bytes than 24-element items) unless the model is
     // too small to fill the device that way -- then the strips are cut until there are a few items per SIMD
@@ -505,33 +507,36 @@ inline void HostModel::build_rec(int seg_len) {
             rec_rows = std::max(rec_rows, (ints[P.spv + e1 - 1] + 1) - (ints[P.spv + e0] - P.q));     // rows first .. last of the item's windows
         }
     }
-    rec_cp.assign(total_cp, RecCp{});
+    if (degree == 4) rec_cp4.assign(total_cp, RecCp4{}); else rec_cp.assign(total_cp, RecCp{});
     for (int s = 0; s < n_owned; ++s) {
         const PatchDev& P = patches[s];
         const RecPatch& R = rec_patch[s];
         const int* c2v = &ints[P.c2v];
         for (int64_t a = P.cp_off; a < P.cp_off + int64_t(P.nu) * P.nv; ++a) {
             const CpDesc& c = cp_desc[a];
-            RecCp& rc = rec_cp[a];
-            rc.flags = (zero[3 * a] ? 1 : 0) | (zero[3 * a + 1] ? 2 : 0) | (zero[3 * a + 2] ? 4 : 0);
+            const int zf = (zero[3 * a] ? 1 : 0) | (zero[3 * a + 1] ? 2 : 0) | (zero[3 * a + 2] ? 4 : 0);
+            int nit = 0, rows_[10]; unsigned infos_[10];
             const int lov_a = c2v[2 * c.ja], hiv_a = c2v[2 * c.ja + 1];
-            if (lov_a > hiv_a) continue;
-            const int g_lo = ints[R.seg_of + lov_a], g_hi = ints[R.seg_of + hiv_a];
-            if (c.neu * (g_hi - g_lo + 1) > 8) throw std::runtime_error("build_rec: a control point lies in more than 8 work items");
-            for (int k = 0; k < c.neu; ++k) for (int g = g_lo; g <= g_hi; ++g) {
-                const int E0 = ints[R.ev0_of + g], E1 = ints[R.ev0_of + g + 1], ivf = ints[P.spv + E0] - P.q;
-                unsigned pm = 0;
-                for (int d = 0; d < 7; ++d) {
-                    const int jb = c.ja - 3 + d;
-                    if (jb < 0 || jb >= P.nv) continue;
-                    const int lo = std::max(lov_a, c2v[2 * jb]), hi = std::min(hiv_a, c2v[2 * jb + 1]);
-                    if (lo <= hi && lo < E1 && hi >= E0) pm |= 1u << d;
+            if (lov_a <= hiv_a) {
+                const int g_lo = ints[R.seg_of + lov_a], g_hi = ints[R.seg_of + hiv_a];
+                if (c.neu * (g_hi - g_lo + 1) > MAXIT) throw std::runtime_error("build_rec: a control point lies in more than " + std::to_string(MAXIT) + " work items");
+                for (int k = 0; k < c.neu; ++k) for (int g = g_lo; g <= g_hi; ++g) {
+                    const int E0 = ints[R.ev0_of + g], E1 = ints[R.ev0_of + g + 1], ivf = ints[P.spv + E0] - P.q;
+                    unsigned pm = 0;
+                    for (int d = 0; d < 2 * PW + 1; ++d) {
+                        const int jb = c.ja - PW + d;
+                        if (jb < 0 || jb >= P.nv) continue;
+                        const int lo = std::max(lov_a, c2v[2 * jb]), hi = std::min(hiv_a, c2v[2 * jb + 1]);
+                        if (lo <= hi && lo < E1 && hi >= E0) pm |= 1u << d;
+                    }
+                    const int item = R.item_off + (c.eu0 + k) * R.nseg + g;
+                    rows_[nit] = item * rec_rows + (c.ja - ivf);
+                    infos_[nit] = unsigned(c.bu[k] - c.i0) | unsigned(c.ia - c.bu[k]) << 8 | pm << 16;
+                    ++nit;
                 }
-                const int item = R.item_off + (c.eu0 + k) * R.nseg + g;
-                rc.it[rc.nit].row = item * rec_rows + (c.ja - ivf);
-                rc.it[rc.nit].info = unsigned(c.bu[k] - c.i0) | unsigned(c.ia - c.bu[k]) << 8 | pm << 16;
-                ++rc.nit;
             }
+            if (degree == 4) { RecCp4& rc = rec_cp4[a]; rc.flags = zf; rc.nit = nit; for (int q = 0; q < nit; ++q) { rc.it[q].row = rows_[q]; rc.it[q].info = infos_[q]; } }
+            else { RecCp& rc = rec_cp[a]; rc.flags = zf; rc.nit = nit; for (int q = 0; q < nit; ++q) { rc.it[q].row = rows_[q]; rc.it[q].info = infos_[q]; } }
         }
     }
 }

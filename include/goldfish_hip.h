@@ -156,8 +156,8 @@ double gf_kernel_ms(gf_handle* h, int* n_launches);
 void* gf_stream(gf_handle* h);
 
 /* which element path gf_assemble runs on this handle: 4 = walking MFMA kernel that stores row records + record gather (default for
- * p = 2, 3), 0 = MFMA element kernel, one block per element + row gather (p = 4; GF_WALK=0), 2 = walking kernel that accumulates
- * straight into the CSR arrays (GF_WALK=1, p = 2, 3), 3 = FP64-VALU element kernel + gather (GF_ELEMENT=valu) */
+ * p = 2, 3), 5 = the same for p = 4 (three walks per pass, gf_element_rec4.hpp; default for p = 4), 0 = MFMA element kernel, one block per
+ * element + row gather (GF_ASSEMBLY=block: the cross-check path), 3 = FP64-VALU element kernel + gather (GF_ELEMENT=valu) */
 int gf_assembly_path(const gf_handle* h);
 
 #ifdef __cplusplus

@@ -39,6 +39,7 @@ CASES = {
     "C3_wing16_100kdof": lambda: G.wing_16patch_from_interface_data(
         np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_wing_int_data.npz"), allow_pickle=True), nel=44),
     "C5_fuselage3x2_p4": lambda: G.synthetic_fuselage(3, 2, nel=6, p=4, jitter=1),
+    "shell2x2_p4_nel11": lambda: G.synthetic_shell(2, 2, nel=11, p=4, jitter=1),      # strips long enough for two segments of >= 5 elements (row records, p = 4)
     # load per unit projected area along a general direction (gf_model_desc.load_proj; the arch demo's source term)
     "slr9_nurbs_p3_projected_load": lambda: _with_projected_load(G.scordelis_lo_9patch(3, nels=[2, 1, 2, 3, 2, 3, 2, 1, 2])),
     "shell2x2_p3_double_knots": lambda: G.with_double_knots(G.synthetic_shell(2, 2, nel=6, p=3, jitter=1)),
@@ -70,7 +71,7 @@ def test_assembly_parity(oracle_lib, case):
     A, h, u = _state(spec)
     O = Oracle(A, thickness=h, u=u)
     D = _lib.DeviceModel(A)
-    assert D.assembly_path == (0 if int(A.degree[0]) == 4 else 4)     # p = 2, 3: walking MFMA kernel + row records + record gather; p = 4: one block per element + row gather
+    assert D.assembly_path == (5 if int(A.degree[0]) == 4 else 4)     # walking MFMA kernels + row records + record gather (p = 4: three walks per pass, gf_element_rec4.hpp)
     D.set_thickness(h)
     D.set_u(u)
     D.assemble(_lib.ASM_ALL)
@@ -104,8 +105,9 @@ def test_row_record_path_segment_lengths_and_block_path(oracle_lib, monkeypatch,
     bitwise reproducible run to run (fixed strip and segment order per entry)."""
     from goldfish_amd import _lib
     from oracle.oracle_py import Oracle
-    for case in ("tbeam2_p2", "shell3x2_p3", "C3_wing16_refdata", "slr9_nurbs_p3_projected_load", "shell2x2_p3_double_knots"):
+    for case in ("tbeam2_p2", "shell3x2_p3", "C3_wing16_refdata", "slr9_nurbs_p3_projected_load", "shell2x2_p3_double_knots", "shell2x2_p4_nel11", "shell2x2_p4_projected_load"):
         A, h, u = _state(CASES[case](), seed=11)
+        deg = int(A.degree[0])
         O = Oracle(A, thickness=h, u=u)
         vals, Ro = O.assemble(), O.residual()
         out = {}
@@ -114,7 +116,7 @@ def test_row_record_path_segment_lengths_and_block_path(oracle_lib, monkeypatch,
             else: monkeypatch.setenv("GF_ASSEMBLY", "block")                    # one block per element + row gather: the cross-check path
             monkeypatch.setenv("GF_REC_SEG", seg)
             D = _lib.DeviceModel(A)
-            assert D.assembly_path == (4 if walk == "2" else 0)
+            assert D.assembly_path == ((5 if deg == 4 else 4) if walk == "2" else 0)
             D.set_thickness(h)
             D.set_u(u)
             D.assemble(_lib.ASM_ALL)
