@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
     static_assert(PASS == 0 || NC == 21, "the dR/dCP / dR/dh walks write the full record layout");
     using RC = Rec4Cfg<NC>;
     constexpr int P = 4, P1 = 5, NB = 25, NG = 25, ND = 75, NGRP = 7, TS = P1 * 3 * P1;
-    const int tid = threadIdx.x, x = tid & 15, kk = tid >> 4;
+    const int tid = threadIdx.x;
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     auto uni64 = [&](long long v) { return (long long)(((unsigned long long)(unsigned)uni((int)((unsigned long long)v >> 32)) << 32) | (unsigned)uni((int)(unsigned long long)v)); };
     WalkItem it = items[blockIdx.x];
@@ -64,19 +64,16 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
 
     const bool doK = PASS == 0 && (flags & GF_ASM_K_BIT) != 0, doC = PASS != 0 && (flags & GF_ASM_C_BIT) != 0, doH = PASS != 0 && (flags & GF_ASM_H_BIT) != 0;
     const bool has_bf = (pf[0] != 0.0) || (pf[1] != 0.0) || (pf[2] != 0.0);
-    // ---- static roles of this lane.  B operand (column) of tile t: lane x; A operand rows held in register rr of a D tile: x_a = kk + 4 rr
-    const int slot_b = x % 5, jq = x / 5;
-    const bool bvalid[2] = {x < 15, x < 10};
-    const int ub[2] = {jq < 3 ? jq : 0, jq < 2 ? 3 + jq : 3};
-    const double bval[2] = {bvalid[0] ? 1.0 : 0.0, bvalid[1] ? 1.0 : 0.0};
-    const RowLane RLg(x);
-
     // ---- inputs of one element: 64 bytes per control point (c_xy | c_zw | u_xy | u_z, h: lane task = 4 * local index + quarter, 100 tasks in two rounds),
     //      the v table and the v weights.  Requested in front of the flush stores (vmcnt is in order: a load behind the stores would wait for all of them),
     //      parked in LDS behind them.
     struct Fetch { double2 cp[2]; double tv[2], wv; };
+    // (lane constants of fetch / park / flush are re-derived from an opaque copy of the lane id where they are used: kept alive across the element loop they
+    //  are spilled to scratch, and every reload is an exposed memory round trip for a wave that runs alone on its SIMD)
+    auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
     auto fetch = [&](int ev, int iv0f) {
         Fetch F;
+        const int tid = opaque((int)threadIdx.x);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int task = tid + 64 * r, pa_cp = task >> 2, pa_q = task & 3;
@@ -94,6 +91,7 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
         return F;
     };
     auto park = [&](const Fetch& F) {
+        const int tid = opaque((int)threadIdx.x);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int task = tid + 64 * r, a = task >> 2, pa_q = task & 3;
@@ -129,6 +127,11 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
     }
     constexpr int QI[6] = {0, 0, 0, 1, 1, 2}, QJ[6] = {0, 1, 2, 1, 2, 2};
 
+    unsigned long long tstamp = 0; (void)tstamp;
+#ifdef GF_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    tstamp = clock64();
+#endif
     int iv0 = iv_first;
     for (int t = 0; t < it.nel; ++t) {
         const int ev = it.ev0 + t;
@@ -172,12 +175,22 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
                 for (int m = 0; m < 5; ++m) z[3 * m + i] = R[m + 1];
             }
             double* im = s_im[tid];
-            shell_point(z, Z, th, s_pc[0], s_pc[1], im);
+            shell_point<PASS != 0>(z, Z, th, s_pc[0], s_pc[1], im);      // the K walk needs no reference-configuration derivatives
             for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
             im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
         }
         wave_lds_sync();
+        GF_STAMP(0, tstamp);
 
+        // ---- roles of this lane, derived HERE from an opaque copy of the lane id: nothing lane-constant is alive during phase 1, whose working set fills
+        //      the arch VGPRs while the accumulators of the walk sit in the AGPRs (kept across the element loop these ~50 registers went to scratch).
+        //      B operand (column) of tile t: lane x; A operand rows held in register rr of a D tile: x_a = kk + 4 rr
+        const int tidl = opaque((int)threadIdx.x), x = tidl & 15, kk = tidl >> 4;
+        const int slot_b = x % 5, jq = x / 5;
+        const bool bvalid[2] = {x < 15, x < 10};
+        const int ub[2] = {jq < 3 ? jq : 0, jq < 2 ? 3 + jq : 3};
+        const double bval[2] = {bvalid[0] ? 1.0 : 0.0, bvalid[1] ? 1.0 : 0.0};
+        const RowLane RLg(x);
         // this lane's basis functions in the current element: tile t -> (u index ub[t], v index = (slot - first row) mod 5)
         const int jvb = mod5(slot_b - iv0);
         auto basis = [&](const double* im, int gu, int gv, double (&phi)[2][5], double (&R0)[2], double (&n0)[2]) {
@@ -203,9 +216,11 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
                 const double wq = gp < NG ? im[IM_WQ] : 0.0;               // padded Gauss-point slots contribute nothing
                 double phi[2][5], R0[2], n0[2];
                 basis(im, gu, gv, phi, R0, n0);
+                GF_STAMP(1, tstamp);
                 double gR[15], hR[15];
                 for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
                 if (doK) { RLg.template expand<false>(im, gR, hR); dpp_source_fence(gR); }
+                GF_STAMP(2, tstamp);
                 {
                     const double ls = has_bf ? load_scalar(im, ppd) : 0.0;
 #pragma unroll
@@ -216,6 +231,7 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
                             accR[ta][i] += wq * (rz - ls * pf[i] * R0[ta]);
                         }
                 }
+                GF_STAMP(3, tstamp);
                 if (doK) {
                     double pb0[5], pb1[5];
                     for (int m = 0; m < 5; ++m) { pb0[m] = wq * phi[0][m]; pb1[m] = wq * phi[1][m]; }
@@ -233,6 +249,7 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
                         for (int q = 0; q < 6; ++q) accK11[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(phi[1][m], t1[q], accK11[q], 0, 0, 0);
                     });
                 }
+                GF_STAMP(4, tstamp);
             }
         } else {
             constexpr int tb = PASS - 1;
@@ -243,9 +260,11 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
                 const double wq = gp < NG ? im[IM_WQ] : 0.0;
                 double phi[2][5], R0[2], n0[2];
                 basis(im, gu, gv, phi, R0, n0);
+                GF_STAMP(1, tstamp);
                 double gR[15], hR[15];
                 for (int s = 0; s < 15; ++s) { gR[s] = 0.0; hR[s] = 0.0; }
                 if (doC) { RLg.template expand<true>(im, gR, hR); dpp_source_fence(hR); }
+                GF_STAMP(2, tstamp);
                 double pb[5];
                 for (int m = 0; m < 5; ++m) pb[m] = wq * phi[tb][m];
                 const double n0b = n0[tb];
@@ -264,6 +283,7 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
                         }
                     }
                 }
+                GF_STAMP(3, tstamp);
                 if (doC) {
                     static_for<5>([&](auto m_) {
                         constexpr int m = decltype(m_)::value;
@@ -289,6 +309,7 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
                         }
                     }
                 }
+                GF_STAMP(4, tstamp);
             }
         }
 
@@ -313,13 +334,15 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
         // ---- the next element's inputs are requested in front of the flush stores
         Fetch Fn;
         if (more) Fn = fetch(ev + 1, iv0n);
+        GF_STAMP(5, tstamp);
 
         // ---- flush: the pairs whose lower row leaves the window (rows < iv0n) are complete for this item
         // (the A-side roles of the four registers of a D tile are re-derived here from an opaque copy of the lane id: kept in registers across the Gauss-point
         //  loop they are two dozen values the register allocator has to spill)
-        int kk2 = kk;
-        asm volatile("" : "+v"(kk2));
-        const int rowb = iv0 + mod5(slot_b - iv0);
+        const int tid2 = opaque((int)threadIdx.x), kk2 = tid2 >> 4, x2 = tid2 & 15;
+        const int rowb = iv0 + mod5(x2 % 5 - iv0);
+        const bool bvalid2[2] = {x2 < 15, x2 < 10};
+        const int ub2[2] = {x2 / 5 < 3 ? x2 / 5 : 0, x2 / 5 < 2 ? 3 + x2 / 5 : 3};
         int rowa[4], ua[2][4]; bool avalid[2][4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
@@ -340,32 +363,36 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int rA = rowa[rr], lo = rA < rowb ? rA : rowb;
-                const bool ok = avalid[ta][rr] && bvalid[tb2] && lo < iv0n;
-                if (ok) {
-                    unsigned cs, cst;
-                    const unsigned o = pair_off(ua[ta][rr], rA, ub[tb2], rowb, cs);
-                    if constexpr (KIND <= 1) {
-                        const unsigned ot = pair_off(ub[tb2], rowb, ua[ta][rr], rA, cst);
-                        if constexpr (KIND == 0) {
+                const bool ok = avalid[ta][rr] && bvalid2[tb2] && lo < iv0n;
+                // no branch around the stores: a pair that is not flushed gets an offset beyond the buffer's num_records and the hardware's range check drops
+                // the store.  Straight-line code lets the compiler COUNT the stores behind the fetch loads (s_waitcnt vmcnt(n) instead of vmcnt(0): the park
+                // below then does not wait for the stores to drain), and the flush issues without exec-mask bookkeeping.
+                constexpr unsigned OOB = 0xF0000000u;
+                unsigned cs, cst;
+                unsigned o = pair_off(ua[ta][rr], rA, ub2[tb2], rowb, cs);
+                o = ok ? o : OOB;
+                if constexpr (KIND <= 1) {
+                    unsigned ot = pair_off(ub2[tb2], rowb, ua[ta][rr], rA, cst);
+                    ot = ok ? ot : OOB;
+                    if constexpr (KIND == 0) {
 #pragma unroll
-                            for (int q = 0; q < 6; ++q) {
-                                buf_st(rR, o + (3 * QI[q] + QJ[q]) * cs, acc[q][rr]);
-                                if (QI[q] != QJ[q]) buf_st(rR, ot + (3 * QJ[q] + QI[q]) * cst, acc[q][rr]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 9; ++q) {
-                                buf_st(rR, o + q * cs, acc[q][rr]);
-                                buf_st(rR, ot + (3 * (q % 3) + q / 3) * cst, acc[q][rr]);
-                            }
+                        for (int q = 0; q < 6; ++q) {
+                            buf_st(rR, o + (3 * QI[q] + QJ[q]) * cs, acc[q][rr]);
+                            if (QI[q] != QJ[q]) buf_st(rR, ot + (3 * QJ[q] + QI[q]) * cst, acc[q][rr]);
                         }
-                    } else if constexpr (KIND == 2) {
-#pragma unroll
-                        for (int q = 0; q < 9; ++q) buf_st(rR, o + (9 + q) * cs, acc[q][rr]);
                     } else {
 #pragma unroll
-                        for (int q = 0; q < 3; ++q) buf_st(rR, o + (18 + q) * cs, acc[q][rr]);
+                        for (int q = 0; q < 9; ++q) {
+                            buf_st(rR, o + q * cs, acc[q][rr]);
+                            buf_st(rR, ot + (3 * (q % 3) + q / 3) * cst, acc[q][rr]);
+                        }
                     }
+                } else if constexpr (KIND == 2) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) buf_st(rR, o + (9 + q) * cs, acc[q][rr]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) buf_st(rR, o + (18 + q) * cs, acc[q][rr]);
                 }
 #pragma unroll
                 for (int q = 0; q < (KIND == 0 ? 6 : (KIND == 3 ? 3 : 9)); ++q) acc[q][rr] = ok ? 0.0 : acc[q][rr];
@@ -383,11 +410,16 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
             if (doC) { flush_tile(std::integral_constant<int, 2>{}, 0, tb, accC[0], 9); flush_tile(std::integral_constant<int, 2>{}, 1, tb, accC[1], 9); }
             if (doH) { flush_tile(std::integral_constant<int, 3>{}, 0, tb, accH[0], 3); flush_tile(std::integral_constant<int, 3>{}, 1, tb, accH[1], 3); }
         }
+        GF_STAMP(6, tstamp);
         // ---- park the next element's inputs
         wave_lds_sync();
         if (more) park(Fn);
         iv0 = iv0n;
+        GF_STAMP(7, tstamp);
     }
+#ifdef GF_STAMPS
+    if ((blockIdx.x & 7) == 0 && tid == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[k], stamp_acc[k]);
+#endif
 }
 
 // Record gather, p = 4: ONE wave per control point a = (ia, ja) sums, item by item (strips ascending, segments ascending: a fixed order), what the row
@@ -415,7 +447,10 @@ __global__ __launch_bounds__(64) void kl_gather_rec4_kernel(DevModel M, long lon
     const int lane = threadIdx.x;
     __shared__ double acc[21 * NBOX];                   // aK [3][NBOX][3] | aH [3][NBOX] | aC [3 f][3 i][NBOX]
     __shared__ unsigned short s_meta[GATHER_MAXMETA];
-    const RecCp4 rc = reccp[a];                         // the work items of a (wave-uniform: scalar loads)
+    // the work items of a: (row, info) per item, parked in LDS by the first lanes and read back uniformly per item (held in registers the 22-dword
+    // descriptor went to VGPRs + scratch with dynamic indexing: the kernel is short of SGPRs)
+    __shared__ int s_it[2 * 10 + 2];
+    if (lane < 22) s_it[lane] = reinterpret_cast<const int*>(reccp + a)[lane < 20 ? 2 + lane : lane - 20];      // [0..19]: it[k].row, it[k].info; [20]: nit, [21]: flags
     const bool pen_row_a = M.pen_row[a] != 0;
     for (int k = lane; k < 21 * NBOX; k += 64) acc[k] = 0.0;
     const bool doC = WITHC && (flags & GF_ASM_C_BIT) != 0, doK = (flags & GF_ASM_K_BIT) != 0, doH = WITHC && (flags & GF_ASM_H_BIT) != 0;
@@ -444,9 +479,7 @@ __global__ __launch_bounds__(64) void kl_gather_rec4_kernel(DevModel M, long lon
     struct Item { double v[NV]; int du; unsigned pm; };
     auto load_item = [&](int n) {
         Item I;
-        int row = rc.it[0].row; unsigned info = rc.it[0].info;
-#pragma unroll
-        for (int q = 1; q < 10; ++q) if (q == n) { row = rc.it[q].row; info = rc.it[q].info; }       // register-resident table: no dynamic indexing
+        const int row = __builtin_amdgcn_readfirstlane(s_it[2 * n]); const unsigned info = (unsigned)__builtin_amdgcn_readfirstlane(s_it[2 * n + 1]);
         I.du = int(info & 255u); I.pm = info >> 16;
         const int uaa = int((info >> 8) & 255u);
         const double* Rja = rec + (size_t)((long long)row - row_base) * SZ;
@@ -466,7 +499,8 @@ __global__ __launch_bounds__(64) void kl_gather_rec4_kernel(DevModel M, long lon
             if (ok) (void)__hip_atomic_fetch_add(&acc[(tk[v] & 0x7fff) + I.du * ((tk[v] >> 15) & 1 ? 3 : 1)], I.v[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
-    const int nit = rc.nit;
+    wave_lds_sync();
+    const int nit = __builtin_amdgcn_readfirstlane(s_it[20]), zflags = __builtin_amdgcn_readfirstlane(s_it[21]);
     constexpr int NBT = 2;                              // work items whose loads are in flight together
     Item B[NBT];
 #pragma unroll
@@ -486,7 +520,7 @@ __global__ __launch_bounds__(64) void kl_gather_rec4_kernel(DevModel M, long lon
     for (int q = 0; q < NM; ++q) { const int k = lane + 64 * q; if (k < GATHER_MAXMETA) s_meta[k] = mt[q]; }
     wave_lds_sync();
     const bool padd = pen_add && pen_row_a;
-    gather_write_rows<NBOX, WITHC>(M, a, lane, doK, doC, doH, padd, (unsigned)rc.flags, ptr_c, deg_c, ptr_s, deg_s, s_meta, acc, acc + 12 * NBOX, acc + 9 * NBOX,
+    gather_write_rows<NBOX, WITHC>(M, a, lane, doK, doC, doH, padd, (unsigned)zflags, ptr_c, deg_c, ptr_s, deg_s, s_meta, acc, acc + 12 * NBOX, acc + 9 * NBOX,
                                    valK, valC0, valC1, valC2, valH);
 }
 

@@ -117,6 +117,8 @@ GF_HD __forceinline__ void symmv(const double* C, const double* x, double* y) {
 }
 
 // Everything a Gauss point contributes, in compact form.  z, Z: [15]; out: IM record (W slots untouched).
+// REF = false (passes without dR/dCP: the K walk of gf_element_rec4.hpp): the reference-configuration derivatives (IM_JZJ, IM_JDNV, IM_JDMO) are not produced.
+template <bool REF = true>
 GF_HD inline void shell_point(const double* z, const double* Z, double t, double E, double nu, double* im) {
     const double f3[3] = {1.0, 1.0, 2.0};
     double n[3], N[3], j, Jn, Dn[3][6], DN[3][6];
@@ -167,6 +169,7 @@ GF_HD inline void shell_point(const double* z, const double* Z, double t, double
     hess_M_dot_n(z, z + 3, n, j, M, H);
     for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) im[IM_HMN + hmn_idx(r, c)] = J * H[r][c];
     // reference path: JZ/J, J dnv/dZ, J dmo/dZ (tangent columns)
+    if constexpr (!REF) return;
     double JZ[6];
     cross3(Z + 3, N, JZ); cross3(N, Z, JZ + 3);
     for (int c = 0; c < 6; ++c) im[IM_JZJ + c] = JZ[c] / J;

@@ -29,6 +29,8 @@ def targs(name):
 def pass_tag(name):
     """'full' / 'other' when the template arguments say which pass the instance belongs to, None when the name does not tell."""
     a = targs(name)
+    if name.startswith(("kl_element_rec4_kernel", "kl_gather_rec4_kernel")):      # <PASS, NC> / <NC>: NC = 21 is the full record layout (full pass), 9 the Newton pass
+        return "full" if a and a[-1] == "21" else "other"
     if name.startswith(("kl_element_rec_kernel", "kl_gather_rec_kernel", "kl_element_mfma_kernel", "kl_element_mfma4_kernel", "kl_gather1_kernel")):
         if name.startswith("kl_element_rec_kernel") and len(a) == 2 and a[1] == "true":
             return "other"              # <P, true> without ALLF: a partial pass with dR/dCP (linearize after a Newton solve); the full pass runs <P, true, true>
