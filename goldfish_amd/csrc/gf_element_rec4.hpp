@@ -14,19 +14,30 @@
 // own phase 1:   PASS 0: residual + K ((0,0), (1,1): i <= j; (1,0): all nine; the transposed entries are written from the symmetry K^(ij)[a][b] = K^(ji)[b][a])
 //                PASS 1 / 2: dR/dCP + dR/dh for the b tile PASS - 1 (T_b feeds both a tiles).
 //
-// Record of row rho of a work item (Rec4Cfg<NC>::SZ doubles, NC values per ORDERED pair: K^(ij) at 3 i + j, dR/dCP^(if) at 9 + 3 i + f, dR/dh^(i) at 18 + i;
-// NC = 9 for the Newton pass): the pairs (A, B) whose lower row is rho,
-//     area 1  [ua][c][d][ub]        A = (iu0 + ua, rho),      B = (iu0 + ub, rho + d), d = 0..4
-//     area 2  [ua][d - 1][c][ub]    A = (iu0 + ua, rho + d),  B = (iu0 + ub, rho),     d = 1..4
-// -- every ordered pair with all its components, so the gather of a control point a reads contiguous runs ([ua = its u index]: 25 NC doubles of area 1, 5 NC
-// per row offset of area 2) and needs no mirrored reads.  Record index = (item - first item of the chunk) * rec_rows + (rho - first row of the item).
+// Record of row rho of a work item (Rec4Cfg<NC>::SZ doubles; NC = 21 values per ORDERED pair in the full layout, 9 for the Newton pass): the pairs (A, B) whose
+// lower row is rho, in three PARTS, each written by exactly one of the walks (so no cache line is written by two kernels: with the components of all walks
+// interleaved the dR/dCP walks read-modify-wrote each other's lines, 8.5 GB per launch for 5.2 GB of stores):
+//     part K   (PASS 0):  9 components K^(ij) at 3 i + j,                                    B columns ub = 0..4
+//     part C0  (PASS 1): 12 components dR/dCP^(if) at 3 i + f, dR/dh^(i) at 9 + i,           B columns ub = 0..2  (b tile 0)
+//     part C1  (PASS 2): the same 12 components,                                             B columns ub = 3..4  (b tile 1)
+// and inside a part (NCp components, Wp columns)
+//     area 1  [ua][c][d][ub']        A = (iu0 + ua, rho),      B = (iu0 + ub, rho + d), d = 0..4
+//     area 2  [ua][d - 1][c][ub']    A = (iu0 + ua, rho + d),  B = (iu0 + ub, rho),     d = 1..4
+// -- every ordered pair with all its components, so the gather of a control point a reads contiguous runs ([ua = its u index]) and needs no mirrored reads.
+// Record index = (item - first item of the chunk) * rec_rows + (rho - first row of the item).
 // Reference path: the same integrals as kl_element_mfma4_kernel (GOLDFISH/nonmatching_opt.py:941-1015 via PENGoLINS' assembly).
 #pragma once
 #include "gf_gauss_loop.hpp"
 
 namespace gf {
 
-template <int NC> struct Rec4Cfg { static constexpr int A1 = 5 * NC * 25, SZ = A1 + 5 * 4 * NC * 5; };
+// part p = 0 (K), 1 (C0), 2 (C1): components, columns, first column, offset in the row record, size of its area 1
+struct Rec4Part { int nc, w, ub0, off, a1; };
+__host__ __device__ constexpr Rec4Part rec4_part(int p) {
+    return p == 0 ? Rec4Part{9, 5, 0, 0, 5 * 9 * 5 * 5} : (p == 1 ? Rec4Part{12, 3, 0, 2025, 5 * 12 * 5 * 3} : Rec4Part{12, 2, 3, 2025 + 1620, 5 * 12 * 5 * 2});
+}
+template <int NC> struct Rec4Cfg { static constexpr int NPART = NC == 21 ? 3 : 1, SZ = NC == 21 ? 4725 : 2025; };
+static_assert(rec4_part(0).a1 + 5 * 4 * 9 * 5 == 2025 && rec4_part(1).a1 + 5 * 4 * 12 * 3 == 1620 && rec4_part(2).off + rec4_part(2).a1 + 5 * 4 * 12 * 2 == 4725, "record parts");
 struct Rec4Out { double* rec; double* rblk; int rec_rows; long long e_first; };     // rblk: 75 residual doubles per element of the chunk (element e at e - e_first)
 
 __device__ __forceinline__ int mod5(int v) { int r = v % 5; return r < 0 ? r + 5 : r; }
@@ -352,11 +363,12 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
             ua[0][rr] = q < 3 ? q : 0; ua[1][rr] = q < 2 ? 3 + q : 3;
         }
         // byte offsets of component 0 of the ordered pair (A = (uA, rA), B = (uB, rB)) and its component stride
-        auto pair_off = [&](int uA, int rA, int uB, int rB, unsigned& cs) {
+        constexpr Rec4Part PT = rec4_part(PASS);           // the part of the row records this walk writes
+        auto pair_off = [&](int uA, int rA, int uB, int rB, unsigned& cs) {        // uB: column inside the part (ub - PT.ub0)
             const int rho = rA < rB ? rA : rB, d = rA < rB ? rB - rA : rA - rB;
             const bool a1 = rA <= rB;
-            cs = 8u * (a1 ? 25u : 5u);
-            return 8u * (unsigned)((rho - iv_first) * RC::SZ + (a1 ? (uA * NC * 5 + d) * 5 + uB : RC::A1 + (uA * 4 + d - 1) * NC * 5 + uB));
+            cs = 8u * (unsigned)(a1 ? 5 * PT.w : PT.w);
+            return 8u * (unsigned)((rho - iv_first) * RC::SZ + PT.off + (a1 ? (uA * PT.nc * 5 + d) * PT.w + uB : PT.a1 + (uA * 4 + d - 1) * PT.nc * PT.w + uB));
         };
         auto flush_tile = [&](auto tag, int ta, int tb2, gf_d4* acc, int ncomp) {
             constexpr int KIND = decltype(tag)::value;       // 0: K diagonal quadrant (6 comps i <= j, mirrored); 1: K (1,0) quadrant (9 comps, mirrored); 2: dR/dCP (9); 3: dR/dh (3)
@@ -369,7 +381,7 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
                 // below then does not wait for the stores to drain), and the flush issues without exec-mask bookkeeping.
                 constexpr unsigned OOB = 0xF0000000u;
                 unsigned cs, cst;
-                unsigned o = pair_off(ua[ta][rr], rA, ub2[tb2], rowb, cs);
+                unsigned o = pair_off(ua[ta][rr], rA, ub2[tb2] - PT.ub0, rowb, cs);
                 o = ok ? o : OOB;
                 if constexpr (KIND <= 1) {
                     unsigned ot = pair_off(ub2[tb2], rowb, ua[ta][rr], rA, cst);
@@ -389,10 +401,10 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
                     }
                 } else if constexpr (KIND == 2) {
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) buf_st(rR, o + (9 + q) * cs, acc[q][rr]);
+                    for (int q = 0; q < 9; ++q) buf_st(rR, o + q * cs, acc[q][rr]);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) buf_st(rR, o + (18 + q) * cs, acc[q][rr]);
+                    for (int q = 0; q < 3; ++q) buf_st(rR, o + (9 + q) * cs, acc[q][rr]);
                 }
 #pragma unroll
                 for (int q = 0; q < (KIND == 0 ? 6 : (KIND == 3 ? 3 : 9)); ++q) acc[q][rr] = ok ? 0.0 : acc[q][rr];
@@ -425,8 +437,8 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
 // Record gather, p = 4: ONE wave per control point a = (ia, ja) sums, item by item (strips ascending, segments ascending: a fixed order), what the row
 // records hold for its three dof rows, then writes the rows (gather_write_rows: Dirichlet entries, coupling-only columns, penalty rows).  From a work item
 // (strip iu0 .. iu0 + 4) with ua = ia - iu0:
-//   G1  record ja,     area 1 [ua][c][d][ub]:      the pairs (a, b = (iu0 + ub, ja + d)), d = 0..4, all components: 25 NC contiguous doubles
-//   G3  record ja - d, area 2 [ua][d - 1][c][ub]:  the pairs (a, b = (iu0 + ub, ja - d)), d = 1..4: 5 NC contiguous doubles per d
+//   G1  record ja,     area 1 [ua][c][d][ub'] of every part:      the pairs (a, b = (iu0 + ub, ja + d)), d = 0..4: 225 + 180 + 120 doubles in three runs
+//   G3  record ja - d, area 2 [ua][d - 1][c][ub'] of every part:  the pairs (a, b = (iu0 + ub, ja - d)), d = 1..4: 45 + 36 + 24 doubles per d
 // Every ordered pair is stored with all its components (the element kernel writes the transposed K entries), so there are no mirrored reads.  A pair is
 // present in an item only if one of the item's elements holds both rows (RecCp4::info, bit 16 + (jb - ja + 4)); everything else in a record row is never
 // written and never read.
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(64) void kl_gather_rec4_kernel(DevModel M, long lon
                                                             const RecCp4* __restrict__ reccp, double* __restrict__ valK, double* __restrict__ valC0,
                                                             double* __restrict__ valC1, double* __restrict__ valC2, double* __restrict__ valH, int pen_add) {
     using RC = Rec4Cfg<NC>;
-    constexpr int WB = 9, NBOX = WB * WB, SZ = RC::SZ, A1 = RC::A1;
+    constexpr int WB = 9, NBOX = WB * WB, SZ = RC::SZ;
     constexpr bool WITHC = NC == 21;
     // workgroup w runs on XCD w % 8: every XCD takes a contiguous range of control points (the record lines shared by neighbours meet in one L2)
     const long long chunk = (a_end - a_first + 7) / 8;
@@ -456,25 +468,40 @@ __global__ __launch_bounds__(64) void kl_gather_rec4_kernel(DevModel M, long lon
     const bool doC = WITHC && (flags & GF_ASM_C_BIT) != 0, doK = (flags & GF_ASM_K_BIT) != 0, doH = WITHC && (flags & GF_ASM_H_BIT) != 0;
     // accumulator address of component c at box slot 0 and its stride in the slot (3 for K, 1 otherwise)
     auto comp_base = [&](int c) { return c < 9 ? (c / 3) * NBOX * 3 + c % 3 : (c < 18 ? 12 * NBOX + (((c - 9) % 3) * 3 + (c - 9) / 3) * NBOX : 9 * NBOX + (c - 18) * NBOX); };
-    constexpr int N1 = NC * 25, NP1 = (N1 + 63) / 64, N3 = 4 * NC * 5, NP3 = (N3 + 63) / 64, NV = NP1 + NP3;
-    // per-lane task table (independent of the item): tk = accumulator address for iu0 = i0 | stride3 << 15 | presence bit << 16 | valid << 20; to = offset of the value
-    // relative to the row record of ja (+ ua * mul)
-    int tk[NV], to[NV];
+    // ---- per-lane task table (independent of the item).  Task t = lane + 64 ps runs through G1 (area 1) of the parts, then G3 (area 2) of the parts:
+    //      tk = accumulator address for iu0 = i0 | stride3 << 15 | presence bit << 16 | valid << 20 | (stride of the value in ua) << 21; to = offset of the value
+    //      relative to the row record of ja (+ ua * stride)
+    constexpr int NPART = RC::NPART;
+    constexpr int NTASK = NC == 21 ? 525 + 420 : 225 + 180, NV = (NTASK + 63) / 64;
+    unsigned tk[NV]; int to[NV];
 #pragma unroll
-    for (int ps = 0; ps < NP1; ++ps) {
-        const int e = lane + 64 * ps, ec = e < N1 ? e : 0, c = ec / 25, d = (ec % 25) / 5, ubx = ec % 5;
-        const bool en = c < 9 ? doK : (c < 18 ? doC : doH);
-        const bool ok = e < N1 && en;
-        tk[ps] = ((comp_base(c) + (ubx + (ja + d - j0) * wbox) * (c < 9 ? 3 : 1)) & 0x7fff) | (c < 9 ? 1 << 15 : 0) | ((4 + d) << 16) | (ok ? 1 << 20 : 0);
-        to[ps] = ec;                                                  // + ua * NC * 25
-    }
+    for (int ps = 0; ps < NV; ++ps) {
+        int e = lane + 64 * ps, c = 0, drow = 0, ubx = 0, off = 0, mul = 0;
+        bool found = false;
 #pragma unroll
-    for (int ps = 0; ps < NP3; ++ps) {
-        const int e = lane + 64 * ps, ec = e < N3 ? e : 0, d = 1 + ec / (NC * 5), r = ec % (NC * 5), c = r / 5, ubx = r % 5;
+        for (int pp = 0; pp < NPART; ++pp) {               // G1: area 1 of part pp, [c][d][ub']
+            constexpr Rec4Part Q0 = rec4_part(0), Q1 = rec4_part(1), Q2 = rec4_part(2);
+            const Rec4Part Q = pp == 0 ? Q0 : (pp == 1 ? Q1 : Q2);
+            const int n = Q.nc * 5 * Q.w;
+            if (!found && e < n) { found = true; c = (pp == 0 ? 0 : 9) + e / (5 * Q.w); drow = (e % (5 * Q.w)) / Q.w; ubx = Q.ub0 + e % Q.w; off = Q.off + e; mul = n; }
+            if (!found) e -= n;
+        }
+#pragma unroll
+        for (int pp = 0; pp < NPART; ++pp) {               // G3: area 2 of part pp, [d - 1][c][ub']
+            constexpr Rec4Part Q0 = rec4_part(0), Q1 = rec4_part(1), Q2 = rec4_part(2);
+            const Rec4Part Q = pp == 0 ? Q0 : (pp == 1 ? Q1 : Q2);
+            const int n = 4 * Q.nc * Q.w;
+            if (!found && e < n) {
+                found = true;
+                const int d = 1 + e / (Q.nc * Q.w), r = e % (Q.nc * Q.w);
+                c = (pp == 0 ? 0 : 9) + r / Q.w; drow = -d; ubx = Q.ub0 + r % Q.w; off = -d * SZ + Q.off + Q.a1 + (d - 1) * Q.nc * Q.w + r; mul = n;
+            }
+            if (!found) e -= n;
+        }
         const bool en = c < 9 ? doK : (c < 18 ? doC : doH);
-        const bool ok = e < N3 && en;
-        tk[NP1 + ps] = ((comp_base(c) + (ubx + (ja - d - j0) * wbox) * (c < 9 ? 3 : 1)) & 0x7fff) | (c < 9 ? 1 << 15 : 0) | ((4 - d) << 16) | (ok ? 1 << 20 : 0);
-        to[NP1 + ps] = -d * SZ + A1 + (d - 1) * NC * 5 + r;            // + ua * 4 * NC * 5
+        const bool ok = found && en;
+        tk[ps] = (unsigned)((comp_base(c) + (ubx + (ja + drow - j0) * wbox) * (c < 9 ? 3 : 1)) & 0x7fff) | (c < 9 ? 1u << 15 : 0u) | ((unsigned)(4 + drow) << 16) | (ok ? 1u << 20 : 0u) | ((unsigned)mul << 21);
+        to[ps] = off;
     }
     struct Item { double v[NV]; int du; unsigned pm; };
     auto load_item = [&](int n) {
@@ -485,7 +512,7 @@ __global__ __launch_bounds__(64) void kl_gather_rec4_kernel(DevModel M, long lon
         const double* Rja = rec + (size_t)((long long)row - row_base) * SZ;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int mul = v < NP1 ? NC * 25 : 4 * NC * 5;
+            const int mul = int(tk[v] >> 21);
             const bool ok = ((tk[v] >> 20) & 1) && ((I.pm >> ((tk[v] >> 16) & 15)) & 1);
             // unconditional load (an absent pair reads the head of the row record; its value is never added): see kl_gather_rec_kernel
             I.v[v] = Rja[ok ? to[v] + uaa * mul : 0];
