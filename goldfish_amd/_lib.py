@@ -276,6 +276,10 @@ class DeviceModel:
         _check(lib().gf_penalty_dxi_range(self.h, int(v_first), int(npts), _dp(blocks), blocks.size, win.ctypes.data_as(C.POINTER(C.c_int32)), win.size), ValueError)
         return blocks, win
 
+    def k_values_ptr(self):
+        """Device pointer of K's values (layout of pattern(MAT_K)): what goldfish_amd._solver.DeviceSolver factors in place."""
+        return lib().gf_device_ptr(self.h, BUF_VAL_K)
+
     def kernel_ms(self):
         n = C.c_int(0)
         ms = lib().gf_kernel_ms(self.h, C.byref(n))

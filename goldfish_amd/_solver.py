@@ -129,7 +129,8 @@ class DeviceSolver:
         if method == "auto":
             method = "nd" if (coords is not None and ncp >= ND_MIN_CP) else "skyline"
         self.method = method
-        dK = _lib.lib().gf_device_ptr(dev_model.h, _lib.BUF_VAL_K)
+        # K's values on this device in the layout of dev_model.pattern(MAT_K): the library's own buffer, or (sharded model) the replicated global K
+        dK = dev_model.k_values_ptr()
         h = C.c_void_p()
         i64 = lambda a: np.ascontiguousarray(a, np.int64).ctypes.data_as(C.POINTER(C.c_int64))
         if method == "nd":
@@ -163,6 +164,8 @@ class DeviceSolver:
     def refactor(self):
         """Numeric factorisation of the values of K currently on the device (after a new assembly)."""
         self.D.sync()                                         # the assembly runs on the model's stream, the solver on its own
+        if hasattr(self.D, "refresh_k_values"):                 # sharded model: gather the owned value rows of all ranks into the replicated K (collective)
+            self.D.refresh_k_values()
         if lib().gfs_refactor(self.h):
             raise RuntimeError(lib().gfs_last_error().decode())
 

@@ -56,7 +56,21 @@ class NonMatchingOpt:
             raise NotImplementedError("shell contact (ShNAPr) is outside the device path (DESIGN.md, out of scope)")
         self.splines = list(splines)
         self.num_splines = len(self.splines)
+        # ``comm`` (nonmatching_opt.py:12-15, 35-37: the MPI communicator every nest vector lives on): None or a one-rank group = one process, one GPU.
+        # torch.distributed itself (the default group) or one of its process groups: the patches are sharded over the ranks (sharding.ShardedDeviceModel: each
+        # rank assembles the rows of its own patches on its own GPU; vectors in and out are replicated, as the reference's comm.allgather leaves them,
+        # utils/opt_utils.py:41-54).  ``device``: the GPU of this process (under torchrun: LOCAL_RANK).
         self.comm = comm
+        self._dist = self._group = None
+        self.rank, self.world = 0, 1
+        if comm is not None:
+            import torch.distributed as dist
+            group = None if comm is dist else comm
+            if not dist.is_initialized():
+                raise RuntimeError("NonMatchingOpt(comm=...): torch.distributed is not initialised (init_process_group first)")
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+            if self.world > 1:
+                self._dist, self._group = dist, group
         self.device = device
         n = self.num_splines
         self.E = [float(e) for e in np.broadcast_to(np.asarray(E, float), (n,))]
@@ -329,11 +343,28 @@ class NonMatchingOpt:
         et = [(s, d, side, tuple(f)) for s, r in enumerate(self.residuals) for (d, side, f) in getattr(r, "edge_tractions", ())]
         return ModelArrays(self.splines, self.E, self.nu, bf, self.interfaces, alphas, pls, load_proj=lp, pressure=pr, edge_traction=et)
 
+    def _spec(self):
+        """The model as a geometry.ProblemSpec (what the sharding code partitions)."""
+        from .geometry import ProblemSpec
+        pls = [(s, ps.xi, ps.field, ps.value) for ps, s in zip(self.point_sources or [], self.point_source_inds or [])]
+        ets = [(s, d, side, tuple(f)) for s, r in enumerate(self.residuals) for (d, side, f) in getattr(r, "edge_tractions", ())]
+        return ProblemSpec(self.splines, list(self.interfaces), list(self.E), list(self.nu), None, [list(r.body_force) for r in self.residuals], pls,
+                           self.penalty_coefficient, "NonMatchingOpt", [list(getattr(r, "projected", (0.0, 0.0, 0.0))) for r in self.residuals],
+                           pressure=[float(getattr(r, "pressure", 0.0)) for r in self.residuals], edge_traction=ets or None)
+
+    @property
+    def sharded(self):
+        return self._dist is not None
+
     @property
     def dev(self):
         if self._dev is None:
-            self._arrays_cache = self._arrays()
-            self._dev = _lib.DeviceModel(self._arrays_cache, device=self.device)
+            self._arrays_cache = self._arrays()              # the global model's tables (Dirichlet dofs, symmetry of K, interface offsets), on every rank
+            if self.sharded:
+                from .sharding import ShardedDeviceModel
+                self._dev = ShardedDeviceModel(self._spec(), self._dist, self.rank, self.world, device=self.device, thickness_global=self.h_th, group=self._group)
+            else:
+                self._dev = _lib.DeviceModel(self._arrays_cache, device=self.device)
             for f in range(3):
                 self._dev.set_cp(f, self.cp_iga[f])
             self._dev.set_thickness(np.concatenate(self.h_th))
@@ -610,6 +641,8 @@ class NonMatchingOpt:
         per-vertex blocks (gf_penalty_dxi -> pen_dxi_kernel); here they are scattered to dofs / coordinates, and the
         tangent blocks are chained with d(tau)/d(xi_A) of the vertex stencil (model.Interface: second-order differences)."""
         c2x, dev = self.cpiga2xi, self.dev
+        if self.sharded:
+            raise NotImplementedError("dRIGAdxi on a sharded model (moving intersections across ranks) is not implemented: run shape_opt_mint problems on one GPU")
         A = self._arrays_cache
         p = self.splines[0].p
         P1, nb = p + 1, (p + 1) ** 2
@@ -745,11 +778,11 @@ class NonMatchingOpt:
 
     # ------------------------------------------------------------------ convenience
     @classmethod
-    def from_spec(cls, spec, thickness=None, device=0, klass=None):
+    def from_spec(cls, spec, thickness=None, device=0, klass=None, comm=None):
         """Build the problem from a goldfish_amd.geometry.ProblemSpec."""
         klass = klass or cls
         h = thickness if thickness is not None else spec.h_th
-        pb = klass(spec.patches, spec.E, h, spec.nu, device=device)
+        pb = klass(spec.patches, spec.E, h, spec.nu, comm=comm, device=device)
         if spec.interfaces:
             pb.create_mortar_meshes([i.npts - 1 for i in spec.interfaces])
             pb.mortar_meshes_setup([[i.a, i.b] for i in spec.interfaces], [[i.xi_a, i.xi_b] for i in spec.interfaces],

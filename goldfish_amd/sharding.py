@@ -150,7 +150,9 @@ def shard_spec(spec, rank, world, part=None):
             loc = Interface(g2l[itf.a], g2l[itf.b], itf.xi_a, itf.xi_b)   # keeps the (A, B) orientation
             itfs.append(loc)
     pls = [(g2l[s], xi, f, v) for (s, xi, f, v) in spec.point_loads if s in mine]
-    local = ProblemSpec([spec.patches[g] for g in order], itfs, spec.E, spec.nu, spec.h_th,
+    def per_patch(v):                # a per-patch list follows the local patch order; a scalar is shared
+        return [np.asarray(v).ravel()[g] for g in order] if np.ndim(v) > 0 and np.size(v) == len(spec.patches) else v
+    local = ProblemSpec([spec.patches[g] for g in order], itfs, per_patch(spec.E), per_patch(spec.nu), spec.h_th,
                         [spec.body_force[g] for g in order], pls, spec.penalty_coefficient,
                         "%s[rank %d/%d]" % (spec.name, rank, world),
                         None if getattr(spec, "load_proj", None) is None else [spec.load_proj[g] for g in order],
@@ -245,19 +247,122 @@ class ShardedDeviceModel:
                                   gradients like reverse products
     ``dist`` is torch.distributed (backend nccl == RCCL over xGMI on a multi-GPU node, gloo in tests)."""
 
-    def __init__(self, spec, dist, rank, world, device=0, thickness_global=None):
+    def __init__(self, spec, dist, rank, world, device=0, thickness_global=None, group=None):
         from . import _lib
-        self._lib, self.dist, self.rank, self.world = _lib, dist, rank, world
+        self._lib, self.dist, self.rank, self.world, self.group = _lib, dist, rank, world, group
         self.shard = shard_spec(spec, rank, world)
         self.A = shard_arrays(self.shard, thickness_global)
         self.D = _lib.DeviceModel(self.A, device=device)
+        self.device = int(device)
+        self.arrays = self.A
         self.cols_g = self.shard.local_cols_to_global()
         self.total_cp, self.ndof = self.shard.total_cp_global, 3 * self.shard.total_cp_global
         self.n_owned_cp = int(self.shard.cp_off_local[self.shard.n_owned])
         self._own_rows = {w: self.shard.owned_rows_global(w) for w in (1, 3)}
+        self._gpat = {}
+        self._kglob = None
 
     def close(self):
-        self.D.close()
+        if getattr(self, "D", None) is not None:
+            self.D.close()
+        self._kglob = None
+
+    def sync(self):
+        self.D.sync()
+
+    # ------------------------------------------------------------------ the DeviceModel surface with global-vector semantics (NonMatchingOpt(comm=...))
+    def _allgather_concat(self, arr):
+        """Concatenation over the ranks (rank order) of a 1-D array whose length differs per rank: lengths first, then one all-gather of padded arrays."""
+        import torch
+        arr = np.ascontiguousarray(arr)
+        if self.world == 1:
+            return arr
+        cuda = self.dist.get_backend(self.group) == "nccl"
+        dev = torch.device("cuda", self.device) if cuda else torch.device("cpu")
+        n = torch.tensor([arr.size], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        self.dist.all_gather(sizes, n, group=self.group)
+        sizes = [int(x.item()) for x in sizes]
+        mx = max(sizes)
+        send = torch.zeros(mx, dtype=torch.from_numpy(arr[:0]).dtype, device=dev)
+        send[:arr.size] = torch.from_numpy(arr).to(dev)
+        parts = [torch.empty_like(send) for _ in range(self.world)]
+        self.dist.all_gather(parts, send, group=self.group)
+        return np.concatenate([p_[:k].cpu().numpy() for p_, k in zip(parts, sizes)])
+
+    def _global_pattern(self, which):
+        """(indptr, indices, perm, nnz_owned) of the GLOBAL matrix ``which``: the owned rows of every rank with their columns in global numbering, in CSR order
+        with sorted columns -- the layout gf_pattern gives for the unsharded model; perm maps a CSR position to its place in the concatenation of the ranks'
+        owned local values.  Collective, built once per pattern (K | dR/dCP | dR/dh)."""
+        import scipy.sparse as sp
+        _lib = self._lib
+        kind = 0 if which == _lib.MAT_K else (2 if which == _lib.MAT_DRDH else 1)
+        if kind not in self._gpat:
+            rp, col = self.D.pattern(which)
+            rp, col = np.asarray(rp, np.int64), np.asarray(col, np.int64)
+            nrow = 3 * self.n_owned_cp
+            nnz = int(rp[nrow])
+            rows_l = np.repeat(np.arange(nrow), np.diff(rp[:nrow + 1]))
+            bw = 3 if kind == 0 else 1
+            grow = 3 * self.cols_g[rows_l // 3] + rows_l % 3
+            gcol = bw * self.cols_g[col[:nnz] // bw] + col[:nnz] % bw
+            R, Cc = self._allgather_concat(grow.astype(np.int64)), self._allgather_concat(gcol.astype(np.int64))
+            ncol = self.ndof if kind == 0 else self.total_cp
+            Gm = sp.coo_matrix((np.arange(1, R.size + 1, dtype=np.float64), (R, Cc)), shape=(self.ndof, ncol)).tocsr()
+            Gm.sort_indices()
+            if Gm.nnz != R.size:
+                raise RuntimeError("sharded pattern: a matrix entry is owned by two ranks")
+            self._gpat[kind] = (Gm.indptr.astype(np.int64), Gm.indices.astype(np.int32), (Gm.data - 1.0).astype(np.int64), nnz)
+        return self._gpat[kind]
+
+    def pattern(self, which):
+        ip, ix, _, _ = self._global_pattern(which)
+        return ip, ix
+
+    def values(self, which):
+        """Values of the global matrix in the order of ``pattern`` (all ranks' owned rows: one all-gather of the owned values)."""
+        _, _, perm, nnz = self._global_pattern(which)
+        return self._allgather_concat(self.D.values(which)[:nnz])[perm]
+
+    def csr(self, which):
+        import scipy.sparse as sp
+        ip, ix, perm, nnz = self._global_pattern(which)
+        ncol = self.ndof if which == self._lib.MAT_K else self.total_cp
+        return sp.csr_matrix((self._allgather_concat(self.D.values(which)[:nnz])[perm], ix, ip), shape=(self.ndof, ncol))
+
+    def apply_many(self, which, xs, ys, transpose=False):
+        """DeviceModel.apply_many with replicated global vectors: transpose=False: ys[0] += sum_m A_m xs[m]; transpose=True: ys[m] += A_m^T xs[0]."""
+        for m, w in enumerate(which):
+            if transpose:
+                ys[m][:] += self.apply(w, xs[0], transpose=True)
+            else:
+                ys[0][:] += self.apply(w, xs[m])
+        return ys
+
+    def compliance(self, forces, apply_bcs=True):
+        """Global compliance functional (gf_compliance): owned patches per rank, value and owned gradient rows summed over the ranks."""
+        order = np.asarray(self.shard.order)
+        f = np.asarray(forces, float).reshape(-1, 3)[order]
+        F = self.D.compliance(f, apply_bcs=apply_bcs)
+        n = self.n_owned_cp
+        du, dcp = np.array(F["dCdu"], float), np.array(F["dCdcp"], float)
+        du[3 * n:] = 0.0
+        dcp[:, n:] = 0.0
+        return dict(C=float(self._allreduce(np.array([F["C"]]))[0]), dCdu=self._rows_to_global(du, 3), dCdcp=np.stack([self._rows_to_global(dcp[k], 1) for k in range(3)]))
+
+    # -- replicated global K on this rank's device: what the direct solver factors (stage 1 of the sharded solve: every rank gathers the owned value rows
+    #    of all ranks and factors the same matrix -- correct and redundant; the assembly is sharded, the factorisation is not)
+    def k_values_ptr(self):
+        import torch
+        if self._kglob is None:                               # the buffer the solver borrows; filled by refresh_k_values before every factorisation
+            self._kglob = torch.zeros(self._global_pattern(self._lib.MAT_K)[1].size, dtype=torch.float64, device=torch.device("cuda", self.device))
+        return int(self._kglob.data_ptr())
+
+    def refresh_k_values(self):
+        import torch
+        self.k_values_ptr()
+        self._kglob.copy_(torch.from_numpy(self.values(self._lib.MAT_K)))
+        torch.cuda.synchronize(self.device)
 
     # -- replicated inputs
     def set_cp(self, field, v):
@@ -278,9 +383,9 @@ class ShardedDeviceModel:
         if self.world == 1:
             return arr
         t = torch.from_numpy(np.ascontiguousarray(arr))
-        if self.dist.get_backend() == "nccl":
-            t = t.cuda()
-        self.dist.all_reduce(t)
+        if self.dist.get_backend(self.group) == "nccl":
+            t = t.to(torch.device("cuda", self.device))
+        self.dist.all_reduce(t, group=self.group)
         return t.cpu().numpy()
 
     def _rows_to_global(self, local_rows, width):
@@ -297,8 +402,11 @@ class ShardedDeviceModel:
     def residual(self):
         return self._rows_to_global(self.D.residual(), 3)
 
-    def apply(self, which, x, transpose=False):
-        """Returns A x (or A^T x) for the replicated global x as a replicated global vector."""
+    def apply(self, which, x, y=None, transpose=False):
+        """A x (or A^T x) for the replicated global x as a replicated global vector; with ``y`` (DeviceModel.apply's signature) it is added to y in place."""
+        if y is not None and not isinstance(y, (bool, np.bool_)):
+            y[:] += self.apply(which, x, transpose=transpose)
+            return y
         _lib = self._lib
         x = np.asarray(x, float)
         if not transpose:
@@ -323,6 +431,12 @@ class ShardedDeviceModel:
         F = self.D.functionals(apply_bcs=apply_bcs)
         sc = self._allreduce(np.array([F["Wint"], F["volume"], F["Wpen"]]))
         out = dict(Wint=sc[0], volume=sc[1], Wpen=sc[2])
+        if "volume_patch" in F:                              # per-patch terms (VolumeExOperation(vol_surf_inds = subset)): the owner reports its patches
+            order, no, npg = np.asarray(self.shard.order), self.shard.n_owned, len(self.shard.cp_off_global) - 1
+            pp = np.zeros((2, npg))
+            pp[0, order[:no]], pp[1, order[:no]] = F["Wint_patch"][:no], F["volume_patch"][:no]
+            pp = self._allreduce(pp.ravel()).reshape(2, npg)
+            out["Wint_patch"], out["volume_patch"] = pp[0], pp[1]
         n = self.n_owned_cp
 
         def own(v, width=1):                                # gradients are assembled for owned control points only

@@ -1115,8 +1115,9 @@ def test_shape_opt_group_wired_like_the_reference_demo():
         assert _rel(regu, nm.shopt_dcpregudcpffd[i] @ d0[i]) < 1e-12
 
 
-def test_thickness_opt_group_wired_like_the_reference_demo():
-    """The reference's ThicknessOptGroup (demos_om/thickness_opt/plate/plate_const_th_opt_wint.py:12-124): IndepVarComp -> HthMapComp ->
+def _thickness_opt_group_totals(comm=None, device=0):
+    """Totals of the reference's ThicknessOptGroup wired through om.Problem and their central differences; ``comm``: torch.distributed -> patch-sharded problem.
+    The reference's ThicknessOptGroup (demos_om/thickness_opt/plate/plate_const_th_opt_wint.py:12-124): IndepVarComp -> HthMapComp ->
     DispStatesComp -> IntEnergyComp / VolumeComp connected by absolute names, design variable / constraint / objective as in the demo,
     run through ``om.Problem`` -- the real openmdao.api when it is installed, the protocol stand-in (goldfish_amd/om_shim.py: Group,
     connect, reverse-mode compute_totals, OpenMDAO's size / declaration checks) in the build image, where no OpenMDAO wheel exists.
@@ -1168,7 +1169,7 @@ def test_thickness_opt_group_wired_like_the_reference_demo():
             self.add_constraint('volume_comp.' + self.volume_name, equals=1.0e-2)
             self.add_objective('int_energy_comp.' + self.int_energy_name, scaler=1e3)
 
-    nm = NonMatchingOpt.from_spec(G.plate_6patch())
+    nm = NonMatchingOpt.from_spec(G.plate_6patch(), comm=comm, device=device)
     nm.set_thickness_opt(var_thickness=False)
     model = ThicknessOptGroup(nonmatching_opt=nm)
     model.init_parameters()
@@ -1189,7 +1190,75 @@ def test_thickness_opt_group_wired_like_the_reference_demo():
             prob.run_model()
             f.append([float(np.ravel(prob.get_val(o))[0]) for o in of])
         J[:, k] = (np.array(f[0]) - np.array(f[1])) / 2e-6
-    for r, o in enumerate(of):
-        t = np.asarray(tot[(o, wrt[0])]).reshape(-1)
-        assert _rel(t, J[r]) < 1e-5, (o, t, J[r])
-    assert abs(float(np.ravel(prob.get_val('volume_comp.volume'))[0]) - 1.0e-2) < 2e-3     # unit plate, thickness ~1e-2
+    prob.set_val('inputs_comp.thickness', h0)
+    prob.run_model()
+    T = np.stack([np.asarray(tot[(o, wrt[0])]).reshape(-1) for o in of])
+    return dict(T=T, J=J, volume=float(np.ravel(prob.get_val('volume_comp.volume'))[0]), w_int=float(np.ravel(prob.get_val('int_energy_comp.w_int'))[0]),
+                u=np.ravel(prob.get_val('disp_states_comp.displacements')).copy(), solver=nm.linear_solver, sharded=nm.sharded,
+                device_solver_used=getattr(nm, "_dsolver", None) is not None and getattr(nm, "_dsolver_failed_version", None) is None)
+
+
+def test_thickness_opt_group_wired_like_the_reference_demo():
+    r = _thickness_opt_group_totals()
+    for row in range(2):
+        assert _rel(r["T"][row], r["J"][row]) < 1e-5, (row, r["T"][row], r["J"][row])
+    assert abs(r["volume"] - 1.0e-2) < 2e-3     # unit plate, thickness ~1e-2
+
+
+def _group_rank_worker(rank, world, port, q, backend):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = rank if backend == "nccl" else 0               # nccl (= RCCL): one GPU per rank; gloo: every rank on GPU 0
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    r = _thickness_opt_group_totals(comm=dist, device=dev)
+    if rank == 0:
+        q.put(r)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_group_ranks(world, backend):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_group_rank_worker, args=(r, world, port, q, backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    return res
+
+
+def _check_sharded_group(r):
+    ref = _thickness_opt_group_totals()                   # the same problem in this process, unsharded
+    assert r["sharded"] and r["solver"] == "device" and r["device_solver_used"]       # Newton steps and adjoints on the device: every rank factors the gathered K
+    for row in range(2):
+        assert _rel(r["T"][row], r["J"][row]) < 1e-5, (row, r["T"][row], r["J"][row])
+        assert _rel(r["T"][row], ref["T"][row]) < 1e-7
+    assert abs(r["volume"] - ref["volume"]) < 1e-12 * ref["volume"] and abs(r["w_int"] - ref["w_int"]) < 1e-8 * abs(ref["w_int"])
+    assert _rel(r["u"], ref["u"]) < 1e-7
+
+
+def test_thickness_opt_group_on_a_sharded_problem_two_ranks_one_gpu():
+    """NonMatchingOpt(comm = torch.distributed): the reference's ThicknessOptGroup with the patches sharded over two ranks (gloo; both on the one GPU of the
+    box) -- states, functionals, adjoint solves and totals equal the unsharded run's (round-3 verdict, next 3)."""
+    _check_sharded_group(_run_group_ranks(2, "gloo"))
+
+
+def test_thickness_opt_group_on_a_sharded_problem_over_rccl():
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one GPU visible: RCCL needs at least two")
+    _check_sharded_group(_run_group_ranks(min(n, 3), "nccl"))
