@@ -15,7 +15,7 @@ from scipy.sparse.csgraph import reverse_cuthill_mckee
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GF_SOLVER_LIB", os.path.join(_HERE, "libgoldfish_solver.so"))   # GF_SOLVER_LIB: A/B builds while tuning
 EXPORTS = ["gfs_last_error", "gfs_create", "gfs_create_nd", "gfs_destroy", "gfs_refactor", "gfs_solve", "gfs_solve_dev", "gfs_set_general", "gfs_solve_transposed",
-           "gfs_solve_transposed_dev", "gfs_info"]
+           "gfs_solve_transposed_dev", "gfs_info", "gfs_solve_multi", "gfs_solve_multi_dev"]
 _L = None
 
 
@@ -38,6 +38,8 @@ def lib():
         L.gfs_solve_transposed.argtypes = [vp, dp, dp, C.c_int, dp]
         L.gfs_solve_transposed_dev.argtypes = [vp, vp, vp, C.c_int, dp]
         L.gfs_info.argtypes = [vp, dp]
+        L.gfs_solve_multi.argtypes = [vp, C.c_int, dp, dp, C.c_int, dp, C.c_int]
+        L.gfs_solve_multi_dev.argtypes = [vp, C.c_int, vp, vp, C.c_int, dp, C.c_int]
         _L = L
     return _L
 
@@ -182,6 +184,31 @@ class DeviceSolver:
         inf = self.info()
         self.backward_error, self.small_pivot = inf["backward_error"], inf["small_pivot"]
         return x
+
+    MAX_RHS = 8
+
+    def solve_multi(self, B, transpose=False):
+        """X[k] = K^{-1} B[k] (or K^{-T} B[k]) for the rows of B in ONE call (gfs_solve_multi): in the nested-dissection mode the substitution sweeps of the
+        right-hand sides run next to each other on the device; ``rel_residuals`` holds one value per row, ``backward_error`` the largest."""
+        B = np.ascontiguousarray(np.atleast_2d(B), float)
+        if B.shape[1] != self.n:
+            raise ValueError("DeviceSolver.solve_multi: expected rows of %d values, got %d" % (self.n, B.shape[1]))
+        X = np.empty_like(B)
+        rr_all = []
+        dp = C.POINTER(C.c_double)
+        for k0 in range(0, B.shape[0], self.MAX_RHS):
+            blk = np.ascontiguousarray(B[k0:k0 + self.MAX_RHS])
+            out, rr = np.empty_like(blk), np.zeros(blk.shape[0])
+            if lib().gfs_solve_multi(self.h, blk.shape[0], blk.ctypes.data_as(dp), out.ctypes.data_as(dp), int(self.max_refine), rr.ctypes.data_as(dp), int(bool(transpose))):
+                raise RuntimeError(lib().gfs_last_error().decode())
+            X[k0:k0 + blk.shape[0]] = out
+            rr_all.append(rr)
+            inf = self.info()
+            self.backward_error = inf["backward_error"] if k0 == 0 else max(self.backward_error, inf["backward_error"])
+            self.small_pivot = inf["small_pivot"]
+        self.rel_residuals = np.concatenate(rr_all)
+        self.rel_residual = float(self.rel_residuals.max())
+        return X
 
     def info(self):
         v = (C.c_double * 8)()

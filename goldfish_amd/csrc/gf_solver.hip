@@ -760,6 +760,12 @@ struct gfs_handle {
     struct Round { int off, n; long long max_tiles; };
     struct FLevel { int off = 0, n = 0; std::vector<int> nk, max_ni; std::vector<Round> rounds; std::vector<int> big; };
     std::vector<FLevel> flevels; int *d_flist = nullptr, *d_ealist = nullptr; long long* d_fwofs = nullptr; double* bwbuf = nullptr; int batch_blk = 96, panel_w = 4;
+    // substitution workspaces: [0] aliases the handle's own buffers and stream; [1 ..] are created by the first multi-right-hand-side solve, one stream each, so
+    // that the sweeps of several right-hand sides (latency-bound chains of small launches) run next to each other (gfs_solve_multi)
+    struct SolveWs { hipStream_t stream = nullptr; double *gb = nullptr, *gy = nullptr, *gx = nullptr, *fbnd = nullptr, *sb = nullptr, *sy = nullptr, *sz = nullptr, *sx = nullptr,
+                     *vr = nullptr, *vsol = nullptr, *vrhs = nullptr, *part = nullptr; hipGraphExec_t g_solve = nullptr; };
+    static constexpr int MAX_RHS = 8;
+    std::vector<SolveWs> ws; long long ws_front_len = 0, ws_bnd_len = 0;
     template <class Tp> Tp* dalloc(size_t cnt) {
         void* p = nullptr; const size_t nb_ = (cnt ? cnt : 1) * sizeof(Tp);
         HIPCHK(hipMalloc(&p, nb_)); allocs.push_back(p); bytes += (long long)nb_; return (Tp*)p;
@@ -810,33 +816,35 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
             hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, h->s_wbuf[si], wstride, h->d_tri, k0, w, nrow);
     }
 }
-static void nd_forward_front(gfs_handle* h, int t, hipStream_t st, int si) {
+static void nd_forward_front(gfs_handle* h, int t, const gfs_handle::SolveWs& W) {
     const Front& F = h->fronts[t];
+    hipStream_t st = W.stream;
     const double* band = h->band + (size_t)F.tile_off * NB2;
     const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
-    hipLaunchKernelGGL(nd_gather_rhs_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->gb, h->s_b[si]);
+    hipLaunchKernelGGL(nd_gather_rhs_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, W.gb, W.sb);
     for (int c : h->kids[t]) {
         const Front& Fc = h->fronts[c];
-        if (Fc.nb_cp > 0) hipLaunchKernelGGL(nd_pull_child_kernel, dim3((unsigned)((3 * Fc.nb_cp + 255) / 256)), dim3(256), 0, st, Fc, F, h->d_pmap, h->fbnd, h->s_b[si]);
+        if (Fc.nb_cp > 0) hipLaunchKernelGGL(nd_pull_child_kernel, dim3((unsigned)((3 * Fc.nb_cp + 255) / 256)), dim3(256), 0, st, Fc, F, h->d_pmap, W.fbnd, W.sb);
     }
     for (int k0 = 0; k0 < F.nblk_e; k0 += 4) {
         const int w = std::min(4, F.nblk_e - k0);
-        hipLaunchKernelGGL(fwd_group_kernel, dim3(1 + F.nblk_t - (k0 + w)), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, h->s_b[si], h->s_y[si], h->d_tri, k0, w);
+        hipLaunchKernelGGL(fwd_group_kernel, dim3(1 + F.nblk_t - (k0 + w)), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, W.sb, W.sy, h->d_tri, k0, w);
     }
-    hipLaunchKernelGGL(nd_scatter_fwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->s_y[si], h->s_b[si], h->gy, h->fbnd);
+    hipLaunchKernelGGL(nd_scatter_fwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, W.sy, W.sb, W.gy, W.fbnd);
 }
-static void nd_backward_front(gfs_handle* h, int t, hipStream_t st, int si) {
+static void nd_backward_front(gfs_handle* h, int t, const gfs_handle::SolveWs& W) {
     const Front& F = h->fronts[t];
+    hipStream_t st = W.stream;
     const double* band = h->band + (size_t)F.tile_off * NB2;
     const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
-    hipLaunchKernelGGL(nd_gather_bwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->d_bnd, h->gy, h->gx, h->dval, h->s_z[si], h->s_x[si]);
+    hipLaunchKernelGGL(nd_gather_bwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->d_bnd, W.gy, W.gx, h->dval, W.sz, W.sx);
     if (F.nblk_t > F.nblk_e && F.nblk_e > 0)
-        hipLaunchKernelGGL(nd_bwd_bnd_kernel, dim3(F.nblk_e), dim3(256), 0, st, band, h->d_tri, F.nblk_e, F.nblk_t, h->s_x[si], h->s_z[si]);
+        hipLaunchKernelGGL(nd_bwd_bnd_kernel, dim3(F.nblk_e), dim3(256), 0, st, band, h->d_tri, F.nblk_e, F.nblk_t, W.sx, W.sz);
     for (int k0 = ((F.nblk_e - 1) / 4) * 4; k0 >= 0; k0 -= 4) {
         const int w = std::min(4, F.nblk_e - k0);
-        hipLaunchKernelGGL(bwd_group_kernel, dim3(1 + k0), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, h->s_z[si], h->s_x[si], h->d_tri, k0, w);
+        hipLaunchKernelGGL(bwd_group_kernel, dim3(1 + k0), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, W.sz, W.sx, h->d_tri, k0, w);
     }
-    hipLaunchKernelGGL(nd_scatter_bwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->s_x[si], h->gx, 0);
+    hipLaunchKernelGGL(nd_scatter_bwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, W.sx, W.gx, 0);
 }
 // bottom-up sweep: the independent subtrees on their streams (forked behind the main stream's earlier work), then the top fronts on the main stream
 template <class Fn> static void nd_sweep_up(gfs_handle* h, Fn&& fn) {
@@ -898,54 +906,78 @@ static void nd_factor_levels(gfs_handle* h) {
     }
 }
 // run `body` (kernel launches, event record / wait on h->stream and the side streams) through a graph captured at the first call
-template <class Body> static void nd_run_captured(gfs_handle* h, hipGraphExec_t* exec, Body&& body) {
+template <class Body> static void nd_run_captured(gfs_handle* h, hipGraphExec_t* exec, Body&& body, hipStream_t cs = nullptr) {
+    if (!cs) cs = h->stream;
     if (!h->use_graph) { body(); return; }
     if (!*exec) {
         hipGraph_t g = nullptr;
         // thread-local capture: only this thread's calls are checked against the capture, and a failure inside body() must not leave the stream
         // (and the forked side streams) capturing -- the caller's fallback (host LU: hipMemcpy of K on this thread, gfs_destroy) would fail on
         // exactly the path it exists for.  On an exception the capture is ended, the partial graph dropped, graphs switched off.
-        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         try { body(); }
         catch (...) {
-            (void)hipStreamEndCapture(h->stream, &g);
+            (void)hipStreamEndCapture(cs, &g);
             if (g) (void)hipGraphDestroy(g);
             (void)hipGetLastError();
             h->use_graph = false;
             throw;
         }
-        HIPCHK(hipStreamEndCapture(h->stream, &g));
+        HIPCHK(hipStreamEndCapture(cs, &g));
         const hipError_t ei = hipGraphInstantiate(exec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (ei != hipSuccess) { *exec = nullptr; h->use_graph = false; throw std::runtime_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
     }
-    HIPCHK(hipGraphLaunch(*exec, h->stream));
+    HIPCHK(hipGraphLaunch(*exec, cs));
 }
 // multifrontal substitutions; vectors in the original numbering
-static void substitute_nd(gfs_handle* h, const double* rhs, double* x, int add) {
-    HIPCHK(hipMemcpyAsync(h->gb, rhs, h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    nd_run_captured(h, &h->g_solve, [&] {
-        constexpr int NS = gfs_handle::NS;
+static void substitute_nd(gfs_handle* h, gfs_handle::SolveWs& W, const double* rhs, double* x, int add) {
+    HIPCHK(hipMemcpyAsync(W.gb, rhs, h->n * sizeof(double), hipMemcpyDeviceToDevice, W.stream));
+    nd_run_captured(h, &W.g_solve, [&] {
         for (const auto& L : h->levels) {                                         // forward: heights ascending
             if (L.n_small > 0)
-                hipLaunchKernelGGL(nd_fwd_front_kernel, dim3(L.n_small), dim3(256), (size_t)(64 * L.max_blk + 64) * sizeof(double), h->stream, h->d_fronts, h->d_lvl_list + L.off_small,
-                                   h->d_kid_off, h->d_kid, h->d_tri, h->band, h->linv, h->d_elim, h->d_pmap, h->gb, h->gy, h->fbnd);
-            for (int t : L.big) nd_forward_front(h, t, h->stream, NS);
+                hipLaunchKernelGGL(nd_fwd_front_kernel, dim3(L.n_small), dim3(256), (size_t)(64 * L.max_blk + 64) * sizeof(double), W.stream, h->d_fronts, h->d_lvl_list + L.off_small,
+                                   h->d_kid_off, h->d_kid, h->d_tri, h->band, h->linv, h->d_elim, h->d_pmap, W.gb, W.gy, W.fbnd);
+            for (int t : L.big) nd_forward_front(h, t, W);
         }
         for (auto it = h->levels.rbegin(); it != h->levels.rend(); ++it) {          // backward: heights descending
             const auto& L = *it;
-            for (auto b_ = L.big.rbegin(); b_ != L.big.rend(); ++b_) nd_backward_front(h, *b_, h->stream, NS);
+            for (auto b_ = L.big.rbegin(); b_ != L.big.rend(); ++b_) nd_backward_front(h, *b_, W);
             if (L.n_small > 0)
-                hipLaunchKernelGGL(nd_bwd_front_kernel, dim3(L.n_small), dim3(256), (size_t)(64 * L.max_blk + 4 * 64) * sizeof(double), h->stream, h->d_fronts, h->d_lvl_list + L.off_small,
-                                   h->d_tri, h->band, h->linv, h->dval, h->d_elim, h->d_bnd, h->gy, h->gx);
+                hipLaunchKernelGGL(nd_bwd_front_kernel, dim3(L.n_small), dim3(256), (size_t)(64 * L.max_blk + 4 * 64) * sizeof(double), W.stream, h->d_fronts, h->d_lvl_list + L.off_small,
+                                   h->d_tri, h->band, h->linv, h->dval, h->d_elim, h->d_bnd, W.gy, W.gx);
         }
-    });
-    hipLaunchKernelGGL(nd_out_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->n, h->gx, x, add);
+    }, W.stream);
+    hipLaunchKernelGGL(nd_out_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, W.stream, h->n, W.gx, x, add);
     HIPCHK(hipGetLastError());
 }
 
+// workspace k of the handle: 0 aliases the handle's own vectors and stream, the others are allocated on first use (nested-dissection mode only)
+static gfs_handle::SolveWs& solve_ws(gfs_handle* h, int k) {
+    constexpr int NS = gfs_handle::NS;
+    if (h->ws.empty()) {
+        gfs_handle::SolveWs W;
+        W.stream = h->stream; W.gb = h->gb; W.gy = h->gy; W.gx = h->gx; W.fbnd = h->fbnd; W.sb = h->s_b[NS]; W.sy = h->s_y[NS]; W.sz = h->s_z[NS]; W.sx = h->s_x[NS];
+        W.vr = h->vr; W.vsol = h->vsol; W.vrhs = h->vrhs; W.part = h->part; W.g_solve = nullptr;
+        h->ws.push_back(W);
+    }
+    while ((int)h->ws.size() <= k) {
+        if (!h->nd) throw std::runtime_error("gfs_solve_multi: concurrent right-hand sides need the nested-dissection mode");
+        gfs_handle::SolveWs W;
+        HIPCHK(hipStreamCreate(&W.stream));
+        W.gb = h->dalloc<double>(h->n); W.gy = h->dalloc<double>(h->n); W.gx = h->dalloc<double>(h->n);
+        W.fbnd = h->dalloc<double>((size_t)std::max<long long>(h->ws_bnd_len, 1));
+        W.sb = h->dalloc<double>((size_t)h->ws_front_len); W.sy = h->dalloc<double>((size_t)h->ws_front_len); W.sz = h->dalloc<double>((size_t)h->ws_front_len); W.sx = h->dalloc<double>((size_t)h->ws_front_len);
+        W.vr = h->dalloc<double>(h->n); W.vsol = h->dalloc<double>(h->n); W.vrhs = h->dalloc<double>(h->n); W.part = h->dalloc<double>(256);
+        HIPCHK(hipMemsetAsync(W.gy, 0, h->n * sizeof(double), W.stream)); HIPCHK(hipMemsetAsync(W.gx, 0, h->n * sizeof(double), W.stream));
+        HIPCHK(hipStreamSynchronize(W.stream));
+        h->ws.push_back(W);
+    }
+    return h->ws[k];
+}
+
 static void substitute(gfs_handle* h, const double* rhs, double* x, int add) {
-    if (h->nd) { substitute_nd(h, rhs, x, add); return; }
+    if (h->nd) { substitute_nd(h, solve_ws(h, 0), rhs, x, add); return; }
     const unsigned g3 = (unsigned)((3 * h->ncp + 255) / 256), gp = (unsigned)((h->npad + 255) / 256);
     HIPCHK(hipMemsetAsync(h->vb, 0, h->npad * sizeof(double), h->stream));
     hipLaunchKernelGGL(permute_in_kernel, dim3(g3), dim3(256), 0, h->stream, h->ncp, h->newi, rhs, h->vb);
@@ -1136,6 +1168,7 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
             for (int s_ = 0; s_ < NS; ++s_) { HIPCHK(hipStreamCreate(&h->st[s_])); HIPCHK(hipEventCreateWithFlags(&h->ev[s_], hipEventDisableTiming)); }
             HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
             const size_t fl_ = (size_t)maxb * NB;
+            h->ws_front_len = (long long)fl_;
             for (int s_ = 0; s_ <= NS; ++s_) {
                 h->s_wbuf[s_] = h->dalloc<double>((size_t)std::max(maxb, 1) * NB2 * std::max(h->panel_w, 1));
                 h->s_b[s_] = h->dalloc<double>(fl_); h->s_y[s_] = h->dalloc<double>(fl_); h->s_z[s_] = h->dalloc<double>(fl_); h->s_x[s_] = h->dalloc<double>(fl_);
@@ -1198,6 +1231,7 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
             h->bwbuf = h->dalloc<double>((size_t)wmax * NB2);
         }
         h->fbnd = h->dalloc<double>((size_t)std::max<int64_t>(3 * nbnd, 1));
+        h->ws_bnd_len = (long long)std::max<int64_t>(3 * nbnd, 1);
         h->gy = h->dalloc<double>(h->n); h->gb = h->dalloc<double>(h->n); h->gx = h->dalloc<double>(h->n);
         h->vr = h->dalloc<double>(h->n); h->vsol = h->dalloc<double>(h->n); h->vrhs = h->dalloc<double>(h->n); h->part = h->dalloc<double>(256);
         HIPCHK(hipMemsetAsync(h->gy, 0, h->n * sizeof(double), h->stream)); HIPCHK(hipMemsetAsync(h->gx, 0, h->n * sizeof(double), h->stream));
@@ -1219,6 +1253,7 @@ void gfs_destroy(gfs_handle* h) {
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     if (h->g_factor) (void)hipGraphExecDestroy(h->g_factor);
     if (h->g_solve) (void)hipGraphExecDestroy(h->g_solve);
+    for (size_t k = 0; k < h->ws.size(); ++k) { if (h->ws[k].g_solve) (void)hipGraphExecDestroy(h->ws[k].g_solve); if (k > 0 && h->ws[k].stream) (void)hipStreamDestroy(h->ws[k].stream); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1283,38 +1318,89 @@ int gfs_set_general(gfs_handle* h, int nonsymmetric) {
     return 0;
 }
 
-static int solve_dev_impl(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual, int transpose) {
+// One or several right-hand sides (device pointers, [nrhs][n]).  The refinement runs in lockstep rounds: the substitutions and residuals of all right-hand
+// sides still being refined are issued on their own streams (workspace r), then the norms are read back in one synchronisation per round.  The sweeps are
+// chains of small dependent launches (latency, not bandwidth: the device is nearly idle during one), so k right-hand sides cost little more than one.
+static int solve_dev_impl(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual, int transpose, int nrhs = 1) {
     if (!h || !d_b || !d_x) return sfail("gfs_solve: null argument");
     if (!h->factored) return sfail("gfs_solve: no factorisation (call gfs_refactor)");
+    if (nrhs < 1 || nrhs > gfs_handle::MAX_RHS) return sfail("gfs_solve_multi: 1 .. " + std::to_string(gfs_handle::MAX_RHS) + " right-hand sides");
     transpose = transpose && h->general;                                  // symmetric K: the same system
     try {
         HIPCHK(hipSetDevice(h->device));
+        const bool conc = h->nd && nrhs > 1;                              // skyline mode: one after the other on the handle's stream (small models)
         const unsigned gcp = (unsigned)((h->ncp * 64 + 255) / 256);
-        substitute(h, d_b, h->vsol, 0);
-        const double nb_ = norm2(h, d_b, h->n);
-        double best = -1.0;
-        for (int itr = 0; itr <= max_refine; ++itr) {
-            if (transpose) hipLaunchKernelGGL(residual_t_kernel, dim3(gcp), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->d_rev, h->valK, d_b, h->vsol, h->vr);
-            else hipLaunchKernelGGL(residual_kernel, dim3(gcp), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->valK, d_b, h->vsol, h->vr);
-            const double nr = norm2(h, h->vr, h->n);
-            // symmetric mode: refinement only polishes round-off, so a step that does not halve the residual ends it; general mode: the refinement IS the solver
-            // for the skew part and contracts by |S^-1 (K - S)|, which may be anything below one -- it goes on while the residual drops at all
-            if (best >= 0.0 && !(nr < (h->general ? 0.95 : 0.5) * best)) {            // the last correction did not help: keep the previous iterate
-                if (nr >= best) HIPCHK(hipMemcpyAsync(h->vsol, h->vrhs, h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream)); else best = nr;
-                break;
+        const int nblk = 240;
+        std::vector<double> nb_(nrhs, 0.0), best(nrhs, -1.0), nx(nrhs, 0.0);
+        std::vector<char> active(nrhs, 1);
+        std::vector<double> host((size_t)nrhs * 256, 0.0);
+        auto W = [&](int r) -> gfs_handle::SolveWs& { return solve_ws(h, conc ? r : 0); };
+        if (conc) { HIPCHK(hipStreamSynchronize(h->stream)); for (int r = 1; r < nrhs; ++r) (void)W(r); }
+        auto sumsq_async = [&](int r, const double* v) {
+            gfs_handle::SolveWs& w = W(r);
+            hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, w.stream, h->n, v, w.part);
+            HIPCHK(hipMemcpyAsync(host.data() + (size_t)r * 256, w.part, nblk * sizeof(double), hipMemcpyDeviceToHost, w.stream));
+        };
+        auto sumsq_get = [&](int r) { long double a = 0; for (int k = 0; k < nblk; ++k) a += host[(size_t)r * 256 + k]; return std::sqrt((double)a); };
+        auto sync_all = [&]() { if (conc) { for (int r = 0; r < nrhs; ++r) HIPCHK(hipStreamSynchronize(W(r).stream)); } else HIPCHK(hipStreamSynchronize(h->stream)); };
+        auto subst = [&](int r, const double* rhs, double* x, int add) { if (h->nd) substitute_nd(h, W(r), rhs, x, add); else substitute(h, rhs, x, add); };
+        if (!conc && nrhs > 1) {                                          // sequential fall-back: each right-hand side through the single-vector path
+            double bw = 0.0;
+            for (int r = 0; r < nrhs; ++r) {
+                double rr = 0.0;
+                if (solve_dev_impl(h, d_b + (size_t)r * h->n, d_x + (size_t)r * h->n, max_refine, &rr, transpose, 1)) return 1;
+                if (rel_residual) rel_residual[r] = rr;
+                bw = std::max(bw, h->backward_error);
             }
-            best = nr;
-            if (itr == max_refine || nr == 0.0) break;
-            HIPCHK(hipMemcpyAsync(h->vrhs, h->vsol, h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));     // previous iterate
-            substitute(h, h->vr, h->vsol, 1);
+            h->backward_error = bw;
+            return 0;
         }
-        HIPCHK(hipMemcpyAsync(d_x, h->vsol, h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (rel_residual) *rel_residual = nb_ > 0.0 ? best / nb_ : best;
+        for (int r = 0; r < nrhs; ++r) { subst(r, d_b + (size_t)r * h->n, W(r).vsol, 0); sumsq_async(r, d_b + (size_t)r * h->n); }
+        sync_all();
+        for (int r = 0; r < nrhs; ++r) nb_[r] = sumsq_get(r);
+        for (int itr = 0; itr <= max_refine; ++itr) {
+            bool any = false;
+            for (int r = 0; r < nrhs; ++r) if (active[r]) {
+                gfs_handle::SolveWs& w = W(r);
+                const double* b = d_b + (size_t)r * h->n;
+                if (transpose) hipLaunchKernelGGL(residual_t_kernel, dim3(gcp), dim3(256), 0, w.stream, h->ncp, h->nb_ptr, h->nb, h->d_rev, h->valK, b, w.vsol, w.vr);
+                else hipLaunchKernelGGL(residual_kernel, dim3(gcp), dim3(256), 0, w.stream, h->ncp, h->nb_ptr, h->nb, h->valK, b, w.vsol, w.vr);
+                sumsq_async(r, w.vr);
+                any = true;
+            }
+            if (!any) break;
+            sync_all();
+            for (int r = 0; r < nrhs; ++r) if (active[r]) {
+                gfs_handle::SolveWs& w = W(r);
+                const double nr = sumsq_get(r);
+                // symmetric mode: refinement only polishes round-off, so a step that does not halve the residual ends it; general mode: the refinement IS the solver
+                // for the skew part and contracts by |S^-1 (K - S)|, which may be anything below one -- it goes on while the residual drops at all
+                if (best[r] >= 0.0 && !(nr < (h->general ? 0.95 : 0.5) * best[r])) {      // the last correction did not help: keep the previous iterate
+                    if (nr >= best[r]) HIPCHK(hipMemcpyAsync(w.vsol, w.vrhs, h->n * sizeof(double), hipMemcpyDeviceToDevice, w.stream)); else best[r] = nr;
+                    active[r] = 0;
+                    continue;
+                }
+                best[r] = nr;
+                if (itr == max_refine || nr == 0.0) { active[r] = 0; continue; }
+                HIPCHK(hipMemcpyAsync(w.vrhs, w.vsol, h->n * sizeof(double), hipMemcpyDeviceToDevice, w.stream));     // previous iterate
+                subst(r, w.vr, w.vsol, 1);
+            }
+        }
+        for (int r = 0; r < nrhs; ++r) {
+            HIPCHK(hipMemcpyAsync(d_x + (size_t)r * h->n, W(r).vsol, h->n * sizeof(double), hipMemcpyDeviceToDevice, W(r).stream));
+            sumsq_async(r, d_x + (size_t)r * h->n);
+        }
+        sync_all();
         // normwise backward error |b - K x| / (|K|_F |x| + |b|): the measure a backward-stable solve keeps at round-off level whatever
-        // the conditioning (|b - K x| / |b| alone has a floor of eps cond(K))
-        const double nx = norm2(h, d_x, h->n), den = h->normK * nx + nb_;
-        h->backward_error = den > 0.0 ? best / den : best;
+        // the conditioning (|b - K x| / |b| alone has a floor of eps cond(K)); several right-hand sides: the largest
+        double bw = 0.0;
+        for (int r = 0; r < nrhs; ++r) {
+            nx[r] = sumsq_get(r);
+            if (rel_residual) rel_residual[r] = nb_[r] > 0.0 ? best[r] / nb_[r] : best[r];
+            const double den = h->normK * nx[r] + nb_[r];
+            bw = std::max(bw, den > 0.0 ? best[r] / den : best[r]);
+        }
+        h->backward_error = bw;
     } catch (const std::exception& ex) { return sfail(ex.what()); }
     return 0;
 }
@@ -1322,17 +1408,19 @@ static int solve_dev_impl(gfs_handle* h, const double* d_b, double* d_x, int max
 int gfs_solve_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual) { return solve_dev_impl(h, d_b, d_x, max_refine, rel_residual, 0); }
 int gfs_solve_transposed_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual) { return solve_dev_impl(h, d_b, d_x, max_refine, rel_residual, 1); }
 
-static int solve_host_impl(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual, int transpose) {
+static int solve_host_impl(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual, int transpose, int nrhs = 1) {
     if (!h || !b || !x) return sfail("gfs_solve: null argument");
+    if (nrhs < 1 || nrhs > gfs_handle::MAX_RHS) return sfail("gfs_solve_multi: 1 .. " + std::to_string(gfs_handle::MAX_RHS) + " right-hand sides");
     try {
         HIPCHK(hipSetDevice(h->device));
         double *db = nullptr, *dx = nullptr;
-        HIPCHK(hipMalloc(&db, h->n * sizeof(double)));
-        if (hipMalloc(&dx, h->n * sizeof(double)) != hipSuccess) { (void)hipFree(db); throw std::runtime_error("gfs_solve: out of device memory"); }
+        const size_t nb_ = (size_t)nrhs * h->n * sizeof(double);
+        HIPCHK(hipMalloc(&db, nb_));
+        if (hipMalloc(&dx, nb_) != hipSuccess) { (void)hipFree(db); throw std::runtime_error("gfs_solve: out of device memory"); }
         int rc = 1;
-        if (hipMemcpy(db, b, h->n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess) {
-            rc = solve_dev_impl(h, db, dx, max_refine, rel_residual, transpose);
-            if (!rc && hipMemcpy(x, dx, h->n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = sfail("gfs_solve: copy to the host failed");
+        if (hipMemcpy(db, b, nb_, hipMemcpyHostToDevice) == hipSuccess) {
+            rc = solve_dev_impl(h, db, dx, max_refine, rel_residual, transpose, nrhs);
+            if (!rc && hipMemcpy(x, dx, nb_, hipMemcpyDeviceToHost) != hipSuccess) rc = sfail("gfs_solve: copy to the host failed");
         } else rc = sfail("gfs_solve: copy to the device failed");
         (void)hipFree(db); (void)hipFree(dx);
         return rc;
@@ -1341,6 +1429,9 @@ static int solve_host_impl(gfs_handle* h, const double* b, double* x, int max_re
 
 int gfs_solve(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual) { return solve_host_impl(h, b, x, max_refine, rel_residual, 0); }
 int gfs_solve_transposed(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual) { return solve_host_impl(h, b, x, max_refine, rel_residual, 1); }
+
+int gfs_solve_multi(gfs_handle* h, int nrhs, const double* b, double* x, int max_refine, double* rel_residual, int transpose) { return solve_host_impl(h, b, x, max_refine, rel_residual, transpose, nrhs); }
+int gfs_solve_multi_dev(gfs_handle* h, int nrhs, const double* d_b, double* d_x, int max_refine, double* rel_residual, int transpose) { return solve_dev_impl(h, d_b, d_x, max_refine, rel_residual, transpose, nrhs); }
 
 int gfs_info(gfs_handle* h, double info[8]) {
     if (!h || !info) return sfail("gfs_info: null argument");

@@ -496,6 +496,8 @@ class NonMatchingOpt:
         from scipy.sparse.linalg import splu
         if getattr(self, "_hlu", None) is None or self._hlu_version != ver:
             self._hlu, self._hlu_version = splu(self.dev.csr(_lib.MAT_K).tocsc()), ver
+        if np.ndim(rhs) == 2:                           # rows = right-hand sides
+            return np.ascontiguousarray(self._hlu.solve(np.ascontiguousarray(np.asarray(rhs, float).T), trans="T" if transpose else "N").T)
         return self._hlu.solve(rhs, trans="T" if transpose else "N")
 
     @property
@@ -516,6 +518,7 @@ class NonMatchingOpt:
         to the host path for this K.  A non-symmetric K (follower pressure) is solved on the device too: factors of its symmetric
         part, refinement against K / K^T; the same backward-error check decides whether that converged.
         ``"host"``: scipy SuperLU on a host copy of K (what MUMPS does in the reference; kept as the cross-check of the tests).
+        ``rhs`` may hold several right-hand sides as rows (shape (k, ndof)): they are solved in one call (DeviceSolver.solve_multi).
         Replaces GOLDFISH/utils/opt_utils.py:156-209 (MUMPS on a copy of K per call)."""
         rhs = np.asarray(rhs, float)
         ver = getattr(self, "_k_version", 0)
@@ -533,7 +536,10 @@ class NonMatchingOpt:
                 elif self._dsolver_version != ver:
                     self._dsolver.refactor()
                     self._dsolver_version = ver
-                x = self._dsolver.solve(rhs, transpose=transpose and not self.symmetric_K)
+                if rhs.ndim == 2:                           # several right-hand sides (adjoints of several functionals): one call, sweeps next to each other
+                    x = self._dsolver.solve_multi(rhs, transpose=transpose and not self.symmetric_K)
+                else:
+                    x = self._dsolver.solve(rhs, transpose=transpose and not self.symmetric_K)
                 rr, be = self._dsolver.rel_residual, self._dsolver.backward_error
                 self.linear_solve_relative_residual, self.linear_solve_backward_error = rr, be
                 small = bool(getattr(self._dsolver, "small_pivot", False))

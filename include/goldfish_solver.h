@@ -55,6 +55,13 @@ int gfs_solve_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine,
 int gfs_set_general(gfs_handle* h, int nonsymmetric);
 int gfs_solve_transposed(gfs_handle* h, const double* b, double* x, int max_refine, double* rel_residual);
 int gfs_solve_transposed_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual);
+/* Several right-hand sides in one call (the adjoints of several functionals -- internal energy, volume, aggregated stress -- share K^T): b, x hold nrhs
+ * vectors of 3 * ncp doubles one after the other; nrhs <= 8; rel_residual (may be NULL): nrhs values; transpose != 0: K^T x = b (general mode).  In the
+ * nested-dissection mode the substitution sweeps of the right-hand sides run next to each other on their own streams (the sweeps are chains of small dependent
+ * launches: latency, not bandwidth), the refinement in lockstep rounds; in the skyline mode (small models) they run one after the other.  gfs_info's backward
+ * error is then the largest of the nrhs solves. */
+int gfs_solve_multi(gfs_handle* h, int nrhs, const double* b, double* x, int max_refine, double* rel_residual, int transpose);
+int gfs_solve_multi_dev(gfs_handle* h, int nrhs, const double* d_b, double* d_x, int max_refine, double* rel_residual, int transpose);
 /* info[0] = half bandwidth (dofs), [1] = block columns, [2] = band tiles per block row, [3] = device bytes,
  * [4] = flops of one factorisation, [5] = 1 if the last factorisation met a pivot below 1e-14 * max |diag|, else 0,
  * [6] = normwise backward error |b - K x| / (|K|_F |x| + |b|) of the last solve (what a backward-stable solve keeps at round-off

@@ -30,6 +30,12 @@ for name, spec in cases:
     fmt = ("%s [" + S.method + "]: %d dofs, half bandwidth %d, factor storage %.2f GB; device: ordering + first factorisation %.3f s, re-factorisation %.4f s (%.1f TFLOP/s), "
            "Newton solve %.4f s (residual %.1e, backward error %.1e), adjoint solve %.4f s (residual %.1e, backward error %.1e)")
     line = fmt % (name, A.ndof, info["half_bandwidth"], info["device_bytes"] / 1e9, t_first, t_f, info["factor_flops"] / t_f / 1e12, t_s, rr, be, t_a, ra, bea)
+    # several right-hand sides in one call (gfs_solve_multi: the sweeps next to each other on their own streams in the nested-dissection mode)
+    B3 = np.stack([g, b, np.random.default_rng(1).standard_normal(A.ndof)])
+    S.solve_multi(B3)                                                     # first call: creates the extra workspaces / graphs
+    t = time.perf_counter(); X3 = S.solve_multi(B3); t_m = time.perf_counter() - t
+    line += "; 3 right-hand sides in one call %.4f s (largest residual %.1e, backward error %.1e; max difference to the single solves %.1e)" % (
+        t_m, S.rel_residual, S.backward_error, max(np.abs(X3[0] - lam).max() / np.abs(lam).max(), np.abs(X3[1] - x).max() / np.abs(x).max()))
     if host and A.ndof < 150000:
         K = D.csr(_lib.MAT_K).tocsc()
         t = time.perf_counter(); lu = spla.splu(K, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True)); t_h = time.perf_counter() - t
