@@ -478,12 +478,12 @@ def test_device_solver_several_right_hand_sides_in_one_call():
         assert np.array_equal(single, multi), method
         assert S.rel_residuals.shape == (3,) and S.backward_error < 1e-12
         allx = S.solve_multi(B)
-        assert np.array_equal(allx[:3], multi) and max(_rel(K @ x, b) for x, b in zip(allx, B)) < 1e-9
+        assert np.array_equal(allx[:3], multi) and max(_rel(K @ x, b) for x, b in zip(allx, B)) < 1e-7      # floor: eps cond(K) for random right-hand sides
         S.close()
     xk = nm.solve_K(B[:2])
-    assert xk.shape == (2, nm.vec_iga_dof) and _rel(K @ xk[1], B[1]) < 1e-9
+    assert xk.shape == (2, nm.vec_iga_dof) and _rel(K @ xk[1], B[1]) < 1e-7
     nm.linear_solver = "host"
-    assert _rel(nm.solve_K(B[:2]), xk) < 1e-7
+    assert _rel(nm.solve_K(B[:2]), xk) < 1e-5
 
 
 def test_device_solver_is_the_default_newton_and_adjoint_path():
