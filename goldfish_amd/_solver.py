@@ -171,14 +171,16 @@ class DeviceSolver:
         if lib().gfs_refactor(self.h):
             raise RuntimeError(lib().gfs_last_error().decode())
 
-    def solve(self, b, transpose=False):
+    def solve(self, b, transpose=False, max_refine=None):
+        """``max_refine``: refinement sweeps for this call (default: the solver's; 0 = substitutions only -- a Newton correction does not need the last decade of the
+        linear residual, and every sweep reads the factors twice: C4 0.048 s instead of 0.13 s)."""
         b = np.ascontiguousarray(b, float)
         if b.size != self.n:
             raise ValueError("DeviceSolver.solve: expected %d values, got %d" % (self.n, b.size))
         x, rr = np.empty(self.n), C.c_double(0.0)
         dp = C.POINTER(C.c_double)
         fn = lib().gfs_solve_transposed if transpose else lib().gfs_solve
-        if fn(self.h, b.ctypes.data_as(dp), x.ctypes.data_as(dp), int(self.max_refine), C.byref(rr)):
+        if fn(self.h, b.ctypes.data_as(dp), x.ctypes.data_as(dp), int(self.max_refine if max_refine is None else max_refine), C.byref(rr)):
             raise RuntimeError(lib().gfs_last_error().decode())
         self.rel_residual = rr.value
         inf = self.info()

@@ -1333,7 +1333,7 @@ static int solve_dev_impl(gfs_handle* h, const double* d_b, double* d_x, int max
         const int nblk = 240;
         std::vector<double> nb_(nrhs, 0.0), best(nrhs, -1.0), nx(nrhs, 0.0);
         std::vector<char> active(nrhs, 1);
-        std::vector<double> host((size_t)nrhs * 256, 0.0);
+        std::vector<double> host((size_t)nrhs * 256, 0.0), hostx((size_t)nrhs * 256, 0.0);
         auto W = [&](int r) -> gfs_handle::SolveWs& { return solve_ws(h, conc ? r : 0); };
         if (conc) { HIPCHK(hipStreamSynchronize(h->stream)); for (int r = 1; r < nrhs; ++r) (void)W(r); }
         auto sumsq_async = [&](int r, const double* v) {
@@ -1366,6 +1366,10 @@ static int solve_dev_impl(gfs_handle* h, const double* d_b, double* d_x, int max
                 if (transpose) hipLaunchKernelGGL(residual_t_kernel, dim3(gcp), dim3(256), 0, w.stream, h->ncp, h->nb_ptr, h->nb, h->d_rev, h->valK, b, w.vsol, w.vr);
                 else hipLaunchKernelGGL(residual_kernel, dim3(gcp), dim3(256), 0, w.stream, h->ncp, h->nb_ptr, h->nb, h->valK, b, w.vsol, w.vr);
                 sumsq_async(r, w.vr);
+                if (itr == 0) {                                           // |x| of the unrefined solution: is it already at round-off?
+                    hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, w.stream, h->n, w.vsol, w.vrhs);       // vrhs is free until the first correction
+                    HIPCHK(hipMemcpyAsync(hostx.data() + (size_t)r * 256, w.vrhs, nblk * sizeof(double), hipMemcpyDeviceToHost, w.stream));
+                }
                 any = true;
             }
             if (!any) break;
@@ -1373,6 +1377,15 @@ static int solve_dev_impl(gfs_handle* h, const double* d_b, double* d_x, int max
             for (int r = 0; r < nrhs; ++r) if (active[r]) {
                 gfs_handle::SolveWs& w = W(r);
                 const double nr = sumsq_get(r);
+                if (itr == 0) {
+                    // a solve whose normwise backward error |b - K x| / (|K|_F |x| + |b|) is already a tenth of the unit round-off cannot be improved by refinement
+                    // in working precision: every further sweep would read the factors twice for nothing (C4: 73 GB per sweep -- the solves are bound by that,
+                    // and the stopping rule below needs two more sweeps to find out that nothing halves any more)
+                    long double a = 0; for (int k = 0; k < nblk; ++k) a += hostx[(size_t)r * 256 + k];
+                    const double nx0 = std::sqrt((double)a);
+                    static const double early = getenv("GF_SOLVER_EARLY_STOP") ? atof(getenv("GF_SOLVER_EARLY_STOP")) : 0.0;      // off by default: at C4 the sweeps after the first still gain a decade of residual (profiles/r04_device_solver_bench.txt); callers that do not need it pass max_refine = 0
+                    if (nr <= early * (h->normK * nx0 + nb_[r])) { best[r] = nr; active[r] = 0; continue; }
+                }
                 // symmetric mode: refinement only polishes round-off, so a step that does not halve the residual ends it; general mode: the refinement IS the solver
                 // for the skew part and contracts by |S^-1 (K - S)|, which may be anything below one -- it goes on while the residual drops at all
                 if (best[r] >= 0.0 && !(nr < (h->general ? 0.95 : 0.5) * best[r])) {      // the last correction did not help: keep the previous iterate

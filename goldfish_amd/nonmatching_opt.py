@@ -507,7 +507,7 @@ class NonMatchingOpt:
         self.dev
         return bool(getattr(getattr(self, "_arrays_cache", None), "symmetric_K", True))
 
-    def solve_K(self, rhs, transpose=False):
+    def solve_K(self, rhs, transpose=False, refine=None):
         """x = K^{-1} rhs, or K^{-T} rhs with ``transpose`` (the same thing unless a follower pressure makes K non-symmetric), with the
         tangent currently assembled on the device.
         ``linear_solver == "device"`` (default): bandwidth-reducing ordering once on the host, then every call after a new
@@ -519,6 +519,8 @@ class NonMatchingOpt:
         part, refinement against K / K^T; the same backward-error check decides whether that converged.
         ``"host"``: scipy SuperLU on a host copy of K (what MUMPS does in the reference; kept as the cross-check of the tests).
         ``rhs`` may hold several right-hand sides as rows (shape (k, ndof)): they are solved in one call (DeviceSolver.solve_multi).
+        ``refine``: refinement sweeps of a device solve (default: the solver's; the Newton loop passes 0 -- its corrections do not need the last decade of the linear
+        residual and every sweep reads the factors twice; adjoint solves keep the full refinement).
         Replaces GOLDFISH/utils/opt_utils.py:156-209 (MUMPS on a copy of K per call)."""
         rhs = np.asarray(rhs, float)
         ver = getattr(self, "_k_version", 0)
@@ -539,7 +541,7 @@ class NonMatchingOpt:
                 if rhs.ndim == 2:                           # several right-hand sides (adjoints of several functionals): one call, sweeps next to each other
                     x = self._dsolver.solve_multi(rhs, transpose=transpose and not self.symmetric_K)
                 else:
-                    x = self._dsolver.solve(rhs, transpose=transpose and not self.symmetric_K)
+                    x = self._dsolver.solve(rhs, transpose=transpose and not self.symmetric_K, max_refine=None if (refine is None or not self.symmetric_K) else refine)
                 rr, be = self._dsolver.rel_residual, self._dsolver.backward_error
                 self.linear_solve_relative_residual, self.linear_solve_backward_error = rr, be
                 small = bool(getattr(self._dsolver, "small_pivot", False))
@@ -735,7 +737,7 @@ class NonMatchingOpt:
         converged, by_step, stagnated, it = nrm / ref_error < rtol, False, False, 0
         while not converged and it < max_it:
             u0 = self.u_iga.copy()
-            du = self.solve_K(-R)
+            du = self.solve_K(-R, refine=0)
             ndu = float(np.linalg.norm(du))
             lam = 1.0
             while True:

@@ -923,6 +923,100 @@ def test_volume_of_a_patch_subset_and_wint_regu_terms(oracle_lib):
     assert max(prob.check_partials(compact_print=False, free_mask=free).values()) < 5e-5      # central differences of the component's run_model
 
 
+def test_shape_opt_mint_group_wired_like_the_reference_demo():
+    """The reference's moving-intersection ShapeOptGroup (demos_om/shape_opt_mint/T-beam/T_beam_2patch_shopt_mi.py:18-305): IndepVarComp -> CPSurfAlignComp ->
+    CPSurfOrderElevationComp -> CPSurfKnotRefinementComp -> CPIGA2XiComp -> DispMintStatesComp -> IntEnergyComp, connected by absolute names, with the demo's
+    design (a bilinear net for the x coordinate of the web, aligned in both directions: ONE design variable, the position of the web under the flange) -- through
+    om.Problem (the protocol stand-in where OpenMDAO is not installed).  The total derivative of the internal energy (states xi(CP) and u(CP, xi), dR/dxi in the
+    adjoint) against central differences of run_model; the optimum of the symmetric load case is the centred web (round-3 verdict, missing 4)."""
+    from goldfish_amd.nonmatching_opt import NonMatchingOpt
+    from goldfish_amd.om_comps import CPIGA2XiComp, DispMintStatesComp, IntEnergyComp, om
+    from goldfish_amd.om_comps.surf_comps import CPSurfAlignComp, CPSurfOrderElevationComp, CPSurfKnotRefinementComp
+    from goldfish_amd.utils.bsp_utils import CPSurfDesign2Analysis
+
+    class ShapeOptGroup(om.Group):
+
+        def initialize(self):
+            self.options.declare('nonmatching_opt')
+            self.options.declare('cpdesign2analysis')
+            for name, default in (('cp_design_name_pre', 'CP_design'), ('cp_coarse_name_pre', 'CP_coarse'), ('cp_order_ele_name_pre', 'CP_order_ele'),
+                                  ('cp_analysis_name_pre', 'CP_analysis'), ('int_name', 'int_para'), ('disp_name', 'displacements'), ('int_energy_name', 'int_E')):
+                self.options.declare(name, default=default)
+
+        def init_parameters(self):
+            for k in ('nonmatching_opt', 'cpdesign2analysis', 'cp_design_name_pre', 'cp_coarse_name_pre', 'cp_order_ele_name_pre', 'cp_analysis_name_pre',
+                      'int_name', 'disp_name', 'int_energy_name'):
+                setattr(self, k, self.options[k])
+            self.opt_field = self.nonmatching_opt.opt_field
+            self.init_cp_design = self.cpdesign2analysis.init_cp_design
+            self.names = {pre: [getattr(self, pre) + str(f) for f in self.opt_field]
+                          for pre in ('cp_design_name_pre', 'cp_coarse_name_pre', 'cp_order_ele_name_pre', 'cp_analysis_name_pre')}
+
+        def setup(self):
+            nm, d2a = self.nonmatching_opt, self.cpdesign2analysis
+            inputs_comp = om.IndepVarComp()
+            for i in range(len(self.opt_field)):
+                inputs_comp.add_output(self.names['cp_design_name_pre'][i], shape=len(self.init_cp_design[i]), val=self.init_cp_design[i])
+            self.add_subsystem('inputs_comp', inputs_comp)
+            comps = [('CP_design_align_comp', CPSurfAlignComp(cpdesign2analysis=d2a, input_cp_design_name_pre=self.cp_design_name_pre, output_cp_coarse_name_pre=self.cp_coarse_name_pre)),
+                     ('CP_order_ele_comp', CPSurfOrderElevationComp(cpdesign2analysis=d2a, input_cp_coarse_name_pre=self.cp_coarse_name_pre, output_cp_order_ele_name_pre=self.cp_order_ele_name_pre)),
+                     ('CP_knot_refine_comp', CPSurfKnotRefinementComp(cpdesign2analysis=d2a, input_cp_order_ele_name_pre=self.cp_order_ele_name_pre, output_cp_fine_name_pre=self.cp_analysis_name_pre)),
+                     ('CPIGA2Xi_comp', CPIGA2XiComp(nonmatching_opt=nm, input_cp_iga_name_pre=self.cp_analysis_name_pre, output_xi_name=self.int_name))]
+            for name, c in comps:
+                c.init_parameters()
+                self.add_subsystem(name, c)
+            disp = DispMintStatesComp(nonmatching_opt=nm, input_cp_iga_name_pre=self.cp_analysis_name_pre, input_xi_name=self.int_name, output_u_name=self.disp_name)
+            disp.init_parameters(save_files=False, nonlinear_solver_rtol=1e-9, nonlinear_solver_max_it=20)
+            self.add_subsystem('disp_states_comp', disp)
+            wint = IntEnergyComp(nonmatching_opt=nm, input_cp_iga_name_pre=self.cp_analysis_name_pre, input_u_name=self.disp_name, output_wint_name=self.int_energy_name)
+            wint.init_parameters()
+            self.add_subsystem('internal_energy_comp', wint)
+            for i in range(len(self.opt_field)):
+                d, c, o, a = (self.names[k][i] for k in ('cp_design_name_pre', 'cp_coarse_name_pre', 'cp_order_ele_name_pre', 'cp_analysis_name_pre'))
+                self.connect('inputs_comp.' + d, 'CP_design_align_comp.' + d)
+                self.connect('CP_design_align_comp.' + c, 'CP_order_ele_comp.' + c)
+                self.connect('CP_order_ele_comp.' + o, 'CP_knot_refine_comp.' + o)
+                for tgt in ('CPIGA2Xi_comp', 'disp_states_comp', 'internal_energy_comp'):
+                    self.connect('CP_knot_refine_comp.' + a, tgt + '.' + a)
+            self.connect('CPIGA2Xi_comp.' + self.int_name, 'disp_states_comp.' + self.int_name)
+            self.connect('disp_states_comp.' + self.disp_name, 'internal_energy_comp.' + self.disp_name)
+            self.add_design_var('inputs_comp.' + self.names['cp_design_name_pre'][0], lower=-1.0, upper=1.0)
+            self.add_objective('internal_energy_comp.' + self.int_energy_name, scaler=1e2)
+
+    spec = G.tbeam_2patch(4, load=(0.0, 0.0, -1.0), tip_load=0.0)
+    spec.body_force = [[0.0, 0.0, -1.0], [0.0, 0.0, 0.0]]               # the flange carries the load: symmetric about x = 0
+    nm = NonMatchingOpt.from_spec(spec)
+    nm.set_shopt_surf_inds(opt_field=[0], shopt_surf_inds=[[1]])
+    nm.create_diff_intersections()
+    d2a = CPSurfDesign2Analysis(nm.preprocessor, opt_field=[0], shopt_surf_inds=[[1]])
+    lin = [[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 1.0, 1.0]]
+    d2a.set_init_knots_by_field([[[1, 1]]], [[lin]])
+    web = spec.patches[1]
+    d2a.set_order_elevation_by_field([[[web.p, web.q]]], [[[[0.0] * (web.p + 1) + [1.0] * (web.p + 1), [0.0] * (web.q + 1) + [1.0] * (web.q + 1)]]])
+    d2a.set_knot_refinement()
+    d2a.get_init_cp_coarse()
+    d2a.set_cp_align(field=0, align_dir_list=[[0, 1]])
+    assert d2a.init_cp_design[0].shape == (1,)                              # one design variable: the web's x
+    A = d2a.knot_refine_operator_list[0].tocsr() @ d2a.order_ele_operator_list[0].tocsr() @ d2a.cp_coarse_align_deriv_list[0].tocsr()
+    assert A.shape == (web.ncp, 1) and np.abs(A.toarray() - 1.0).max() < 1e-12        # the whole chain moves every analysis control point of the web by the design value
+    model = ShapeOptGroup(nonmatching_opt=nm, cpdesign2analysis=d2a)
+    model.init_parameters()
+    prob = om.Problem(model=model)
+    prob.setup()
+    x0 = float(d2a.init_cp_design[0][0])
+    of, wrt = 'internal_energy_comp.int_E', 'inputs_comp.CP_design0'
+    vals = {}
+    for s in (0.3, 0.3 + 1e-5, 0.3 - 1e-5, -0.3, 0.0):
+        prob.set_val(wrt, [x0 + s])
+        prob.run_model()
+        vals[s] = float(np.ravel(prob.get_val(of))[0])
+        if s == 0.3:
+            tot = float(np.ravel(prob.compute_totals(of=[of], wrt=[wrt])[(of, wrt)])[0])
+    fd = (vals[0.3 + 1e-5] - vals[0.3 - 1e-5]) / 2e-5
+    assert abs(tot - fd) < 2e-5 * abs(fd), (tot, fd)
+    assert abs(vals[0.3] - vals[-0.3]) < 1e-6 * vals[0.3] and vals[0.0] < vals[0.3]      # symmetric load case: the centred web is the optimum
+
+
 def test_moving_intersection_optimisation_finds_the_symmetric_optimum():
     """examples/tbeam_moving_intersection.py (set-up of demos_om/shape_opt_mint/T-beam): the web starts 0.4 off centre under a
     load that is symmetric about the flange's centre line; with the intersection moving along (xi(CP), dR/dxi in the total

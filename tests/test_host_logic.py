@@ -947,3 +947,66 @@ def test_traffic_tool_counts_every_kernel_of_a_pass_once():
     out3 = T.build("r03_v4", 9421968, os.path.join(ROOT, "profiles"))
     assert "kl_gather_rec_kernel<3, true>" in out3["full_pass_kernels"] and "kl_gather_rec_kernel<3, false>" not in out3["full_pass_kernels"]
     assert 33e9 < out3["full_pass_bytes_per_step"] < 36e9
+
+
+def test_design_to_analysis_control_nets():
+    """utils/bsp_utils.py (N3, reference GOLDFISH/utils/bsp_utils.py:516-1230): order elevation and knot refinement are exact embeddings (the surface does not
+    change), alignment / pin / regularisation / distance operators against their definitions, and the surf components reproduce the analysis control net."""
+    from goldfish_amd.cpiga2xi import IntersectionData
+    from goldfish_amd.om_comps import om
+    from goldfish_amd.om_comps.surf_comps import CPSurfAlignComp, CPSurfOrderElevationComp, CPSurfKnotRefinementComp, CPSurfPinComp, CPSurfReguComp, CPSurfDistanceComp
+    from goldfish_amd.splines import NURBSPatch
+    from goldfish_amd.utils import bsp_utils as B
+    rng = np.random.default_rng(3)
+    # a random biquadratic 3 x 4 net elevated to bicubic and refined: same surface at random points
+    p_in, k_in = [2, 2], [np.array([0, 0, 0, 1, 1, 1.0]), np.array([0, 0, 0, 0.5, 1, 1, 1.0])]
+    p_out, k_el = [3, 3], [np.array([0, 0, 0, 0, 1, 1, 1, 1.0]), np.array([0, 0, 0, 0, 0.5, 0.5, 1, 1, 1, 1.0])]
+    E = B.surface_order_elevation_operator(p_in, k_in, p_out, k_el, coo=False)
+    ref = [np.array([0.25, 0.6]), np.array([0.3])]
+    R = B.surface_knot_refine_operator(k_el, ref, coo=False)
+    k_fine = [np.sort(np.concatenate([k_el[0], ref[0]])), np.sort(np.concatenate([k_el[1], ref[1]]))]
+    c = rng.standard_normal(3 * 4)
+    cf = R @ (E @ c)
+
+    def ev(p, k, cp, x):
+        Bu, Bv = B._collocation(p[0], k[0], [x[0]]), B._collocation(p[1], k[1], [x[1]])
+        return float(Bv[0] @ cp.reshape(Bv.shape[1], Bu.shape[1]) @ Bu[0])
+    for x in rng.uniform(0, 1, (20, 2)):
+        assert abs(ev(p_in, k_in, c, x) - ev(p_out, k_fine, cf, x)) < 1e-12
+    A0, free0 = B.surface_cp_align_operator([3, 4], 0)
+    A1, free1 = B.surface_cp_align_operator([3, 4], 1)
+    v = rng.standard_normal(4)
+    assert np.array_equal((A0 @ v).reshape(4, 3), np.repeat(v[:, None], 3, 1)) and free0 == [0, 3, 6, 9] and free1 == [0, 1, 2]
+    assert np.array_equal((A1 @ v[:3]).reshape(4, 3), np.repeat(v[None, :3], 4, 0))
+    G0 = B.surface_cp_regu_operator([3, 4], 0).toarray()
+    net = rng.standard_normal((4, 3))                                   # [j][i]
+    assert np.allclose((G0 @ net.ravel()).reshape(2, 4), (net[:, 1:] - net[:, :-1]).T)
+    # the class on two patches of the T-beam: both fields' chains reproduce the analysis control points
+    spec = G.tbeam_2patch(4)
+    pre = IntersectionData(patches=spec.patches, mapping_list=[[i.a, i.b] for i in spec.interfaces], intersections_para_coords=[[i.xi_a, i.xi_b] for i in spec.interfaces])
+    d2a = B.CPSurfDesign2Analysis(pre, opt_field=[0, 2], shopt_surf_inds=[[1], [0, 1]])
+    lin = [[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 1.0, 1.0]]
+    cub = [[0.0] * 4 + [1.0] * 4, [0.0] * 4 + [1.0] * 4]
+    d2a.set_init_knots([0, 1], [[1, 1], [1, 1]], [lin, lin])
+    d2a.set_order_elevation([0, 1], [[3, 3], [3, 3]], [cub, cub])
+    d2a.set_knot_refinement()
+    d2a.get_init_cp_coarse()
+    for f in range(2):                                                  # flat bilinear patches: the coarse nets reproduce them exactly
+        Aall = d2a.knot_refine_operator_list[f].tocsr() @ d2a.order_ele_operator_list[f].tocsr()
+        assert np.abs(Aall @ d2a.init_cp_coarse[f] - d2a.init_analysis_cp[f]).max() < 1e-10
+    d2a.set_cp_align(2, [None, 0])
+    assert d2a.init_cp_design[1].size == 4 + 2
+    pin = d2a.set_cp_pin(2, [1, None], [[0], None])
+    assert pin.shape == (2, 6) and np.abs(pin @ d2a.init_cp_design[1] - np.asarray(d2a.cp_coarse_pin_vals[1])).max() == 0.0
+    regu = d2a.set_cp_regu(2, [1, None])
+    assert regu.shape == (2, 6)
+    d2a.set_cp_align(0, [[0, 1]])
+    comps = [CPSurfAlignComp(cpdesign2analysis=d2a), CPSurfOrderElevationComp(cpdesign2analysis=d2a), CPSurfKnotRefinementComp(cpdesign2analysis=d2a, output_cp_fine_name_pre='CP_IGA'),
+             CPSurfPinComp(cpdesign2analysis=d2a, output_cp_pin_name_pre='CP_pin'), CPSurfReguComp(cpdesign2analysis=d2a)]
+    for c_ in comps:
+        c_.init_parameters()
+        prob = om.Problem(model=c_)
+        prob.setup(); prob.run_model()
+        assert max(prob.check_partials(compact_print=False).values()) < 1e-6
+    prob = om.Problem(model=comps[3]); prob.setup(); prob.run_model()
+    assert np.abs(np.ravel(prob.get_val('CP_pin2'))).max() == 0.0       # feasible at the initial design

@@ -36,7 +36,7 @@ class FakeNM(NonMatchingOpt):
     def _assemble(self, flags):
         self.n_assemblies += 1
 
-    def solve_K(self, rhs):
+    def solve_K(self, rhs, transpose=False, refine=None):
         return np.linalg.solve(self.jac(self.u_iga), rhs)
 
 
@@ -106,7 +106,7 @@ class _FakeSolver:
     def __init__(self, D, x, rr):
         self.D, self.x, self.rel_residual, self.backward_error, self.closed = D, x, rr, rr, False
 
-    def solve(self, b, transpose=False):
+    def solve(self, b, transpose=False, max_refine=None):
         return self.x(b)
 
     def refactor(self):
