@@ -20,7 +20,7 @@ BUF_CP, BUF_U, BUF_H, BUF_R, BUF_VAL_K, BUF_VAL_C0, BUF_VAL_C1, BUF_VAL_C2, BUF_
 EXPORTS = ["gf_device_count", "gf_last_error", "gf_create", "gf_destroy", "gf_total_cp", "gf_num_dofs",
            "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes", "gf_set_cp",
            "gf_set_thickness", "gf_set_u", "gf_nnz", "gf_pattern", "gf_assemble", "gf_sync", "gf_get_residual",
-           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_shape_regu", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms", "gf_assembly_path", "gf_stream", "gf_apply_many", "gf_get_functional_gradient", "gf_penalty_dxi_range", "gf_functionals_per_patch"]
+           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_shape_regu", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms", "gf_assembly_path", "gf_stream", "gf_apply_many", "gf_get_functional_gradient", "gf_penalty_dxi_range", "gf_functionals_per_patch", "gf_penalty_dxi_rev"]
 
 
 def lib():
@@ -43,7 +43,8 @@ def lib():
             "gf_stress_forms": ([vp, ci, C.c_double, dp, i64, ci, ci, dp, dp, dp, dp, dp, ci], None), "gf_device_ptr": ([vp, ci], vp),
             "gf_apply_dev": ([vp, ci, ci, vp, vp], None), "gf_kernel_ms": ([vp, C.POINTER(ci)], C.c_double), "gf_assembly_path": ([vp], None),
             "gf_get_functional_gradient": ([vp, ci, dp, i64], None), "gf_apply_many": ([vp, ci, ci, C.POINTER(ci), C.POINTER(dp), C.POINTER(dp)], None),
-            "gf_stream": ([vp], vp), "gf_functionals_per_patch": ([vp, dp, dp, i64], None)}
+            "gf_stream": ([vp], vp), "gf_functionals_per_patch": ([vp, dp, dp, i64], None),
+            "gf_penalty_dxi_rev": ([vp, i64, i64, dp, i64, dp, i64], None)}
         for name in ("gf_total_cp", "gf_num_dofs", "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes"):
             sig[name] = ([vp], i64)
         for name, (argtypes, restype) in sig.items():
@@ -275,6 +276,18 @@ class DeviceModel:
         win = np.zeros((npts, 2, 2), dtype=np.int32)
         _check(lib().gf_penalty_dxi_range(self.h, int(v_first), int(npts), _dp(blocks), blocks.size, win.ctypes.data_as(C.POINTER(C.c_int32)), win.size), ValueError)
         return blocks, win
+
+    def penalty_dxi_rev(self, npts, lam, v_first=0):
+        """(npts, 6): the reverse-mode product of the per-vertex dR/d(xi, tau) blocks with lam, formed on the device (gf_penalty_dxi_rev)."""
+        lam = np.ascontiguousarray(lam, dtype=np.float64).ravel()
+        out = np.zeros((int(npts), 6))
+        _check(lib().gf_penalty_dxi_rev(self.h, int(v_first), int(npts), _dp(lam), lam.size, _dp(out), out.size), ValueError)
+        return out
+
+    def penalty_dxi_rev_if(self, g, lam):
+        """penalty_dxi_rev for the mortar vertices of interface ``g`` of the model."""
+        off = self.arrays.if_off
+        return self.penalty_dxi_rev(int(off[g + 1] - off[g]), lam, v_first=int(off[g]))
 
     def k_values_ptr(self):
         """Device pointer of K's values (layout of pattern(MAT_K)): what goldfish_amd._solver.DeviceSolver factors in place."""

@@ -946,8 +946,12 @@ __global__ __launch_bounds__(64) void pen_point_kernel(DevModel M, DevPenalty Q,
 // curve tangent tau_d changes (a neighbouring vertex of side A moved).  One thread per (vertex, direction): forward-mode
 // pass of the vertex gradient in dual numbers, then the contraction with both sides' basis values:
 //   out[(v*6 + dir)][sd'][a][i] = sum_m nu_m,a^(sd') d(grad)[9 sd' + 3 m + i] + [sd' == sd] sum_m d(nu_m,a)/d(xi_d) grad[9 sd + 3 m + i]
-template <int P>
-__global__ __launch_bounds__(64) void pen_dxi_kernel(DevModel M, DevPenalty Q, const double* __restrict__ pt_nu2, double* __restrict__ out, long long v_first, long long v_count) {
+// REV = true: the blocks are not written -- each (vertex, direction) is contracted with lam over the rows this handle owns (control points below owned_cp,
+// Dirichlet rows skipped: the reference zeroes them, nonmatching_opt.py:1057-1062) and only that scalar goes out: out[t] = sum_{side', a, i} block lam[dof]:
+// the reverse-mode product (dR/dxi)^T lam without the blocks ever leaving the device (0.64 GB over PCIe at C4 for the 1.5 ms of this kernel).
+template <int P, bool REV = false>
+__global__ __launch_bounds__(64) void pen_dxi_kernel(DevModel M, DevPenalty Q, const double* __restrict__ pt_nu2, double* __restrict__ out, long long v_first, long long v_count,
+                                                     const double* __restrict__ lam = nullptr, long long owned_cp = 0) {
     constexpr int P1 = P + 1, NB = P1 * P1;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // (vertex of the range, direction)
     if (t >= v_count * 6) return;
@@ -979,19 +983,27 @@ __global__ __launch_bounds__(64) void pen_dxi_kernel(DevModel M, DevPenalty Q, c
     }
     tau[0] = {Q.pt_tau[2 * v], dir == 4 ? 1.0 : 0.0}; tau[1] = {Q.pt_tau[2 * v + 1], dir == 5 ? 1.0 : 0.0};
     penalty_grad_t<Dual>(y, Y, tau, Q.if_alpha[2 * itf], Q.if_alpha[2 * itf + 1], Q.pt_wt[v], gr);
-    double* o = out + (size_t)t * (2 * NB * 3);
+    double* o = REV ? nullptr : out + (size_t)t * (2 * NB * 3);
+    double acc = 0.0;
     for (int sd = 0; sd < 2; ++sd) {
         const double* nu = Q.pt_nu + ((size_t)v * 2 + sd) * 3 * NB;
         const double* n2 = pt_nu2 + ((size_t)v * 2 + sd) * 3 * NB;
         const bool seed = dir < 4 && sd == sdd;
+        const PatchDev& Pt = M.patches[Q.if_patch[2 * itf + sd]];
+        const int iu0 = Q.pt_base[4 * v + 2 * sd], iv0 = Q.pt_base[4 * v + 2 * sd + 1];
         for (int a = 0; a < NB; ++a) {
             const double r0 = nu[a], r1 = nu[NB + a], r2 = nu[2 * NB + a];
             const double s0 = seed ? (d == 0 ? r1 : r2) : 0.0, s1 = seed ? (d == 0 ? n2[a] : n2[2 * NB + a]) : 0.0, s2 = seed ? (d == 0 ? n2[2 * NB + a] : n2[NB + a]) : 0.0;
-            for (int i = 0; i < 3; ++i)
-                o[(sd * NB + a) * 3 + i] = r0 * gr[9 * sd + i].d + r1 * gr[9 * sd + 3 + i].d + r2 * gr[9 * sd + 6 + i].d
-                                         + s0 * gr[9 * sd + i].v + s1 * gr[9 * sd + 3 + i].v + s2 * gr[9 * sd + 6 + i].v;
+            const long long g = Pt.cp_off + (iu0 + a % P1) + (long long)(iv0 + a / P1) * Pt.nu;
+            for (int i = 0; i < 3; ++i) {
+                const double b = r0 * gr[9 * sd + i].d + r1 * gr[9 * sd + 3 + i].d + r2 * gr[9 * sd + 6 + i].d
+                               + s0 * gr[9 * sd + i].v + s1 * gr[9 * sd + 3 + i].v + s2 * gr[9 * sd + 6 + i].v;
+                if constexpr (REV) { if (g < owned_cp && !M.zero[3 * g + i]) acc += b * lam[3 * g + i]; }
+                else o[(sd * NB + a) * 3 + i] = b;
+            }
         }
     }
+    if constexpr (REV) out[t] = acc;
 }
 
 // Penalty rows of one owned control point a (one wave each): residual entries and the coupling blocks

@@ -786,6 +786,38 @@ int gf_penalty_dxi_range(gf_handle* h, int64_t v_first, int64_t v_count, double*
     } catch (const std::exception& ex) { return fail(ex.what()); }
     return 0;
 }
+// reverse-mode product with dR/dxi on the device: out[v][dir] = sum over the owned, non-Dirichlet rows of block[v][dir] * lam (pen_dxi_kernel<P, true>)
+int gf_penalty_dxi_rev(gf_handle* h, int64_t v_first, int64_t v_count, const double* lam, int64_t nlam, double* out, int64_t nout) {
+    if (!h || !lam || !out) return fail("gf_penalty_dxi_rev: null argument");
+    const HostModel& H = h->H;
+    if (v_first < 0 || v_count < 0 || v_first + v_count > (int64_t)H.npts) return fail("gf_penalty_dxi_rev: vertex range outside the model's mortar vertices");
+    if (nlam != (int64_t)H.ndof || nout != 6 * v_count) return fail("gf_penalty_dxi_rev: lam must hold ndof values, out 6 per mortar vertex");
+    if (v_count == 0) return 0;
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        if (!h->d_pt_nu2) {
+            h->d_pt_nu2 = h->dalloc<double>(H.pt_nu2.size());
+            HIPCHK(hipMemcpy(h->d_pt_nu2, H.pt_nu2.data(), H.pt_nu2.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        if (!h->d_many) h->d_many = h->dalloc<double>(5 * (size_t)H.ndof);      // d_many: >= 6 * npts doubles?  (npts * 6 <= 5 ndof is checked below)
+        if (6 * v_count > 5 * (int64_t)H.ndof) return fail("gf_penalty_dxi_rev: more mortar vertices than the staging buffer holds");
+        HIPCHK(hipMemcpyAsync(h->d_x, lam, nlam * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        const long long nt = (long long)v_count * 6;
+        const dim3 grid((unsigned)((nt + 63) / 64));
+        switch (H.degree) {
+            case 2: hipLaunchKernelGGL((pen_dxi_kernel<2, true>), grid, dim3(64), 0, h->stream, h->M, h->Q, h->d_pt_nu2, h->d_many, (long long)v_first, (long long)v_count, h->d_x, (long long)H.owned_cp); break;
+            case 3: hipLaunchKernelGGL((pen_dxi_kernel<3, true>), grid, dim3(64), 0, h->stream, h->M, h->Q, h->d_pt_nu2, h->d_many, (long long)v_first, (long long)v_count, h->d_x, (long long)H.owned_cp); break;
+            case 4: hipLaunchKernelGGL((pen_dxi_kernel<4, true>), grid, dim3(64), 0, h->stream, h->M, h->Q, h->d_pt_nu2, h->d_many, (long long)v_first, (long long)v_count, h->d_x, (long long)H.owned_cp); break;
+            default: throw std::runtime_error("gf_penalty_dxi_rev: unsupported degree");
+        }
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out, h->d_many, nout * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) throw std::runtime_error(std::string("gf_penalty_dxi_rev: ") + hipGetErrorString(e));
+    } catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
+}
+
 int gf_penalty_dxi(gf_handle* h, double* blocks, int64_t n, int32_t* windows, int64_t nw) {
     if (!h) return fail("gf_penalty_dxi: null argument");
     return gf_penalty_dxi_range(h, 0, (int64_t)h->H.npts, blocks, n, windows, nw);

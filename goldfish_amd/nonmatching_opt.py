@@ -683,6 +683,24 @@ class NonMatchingOpt:
         keep[self.zero_dofs] = 0.0
         return sp.diags(keep) @ J
 
+    def dRIGAdxi_rev(self, lam):
+        """(dR/dxi)^T lam without forming dR/dxi: the per-vertex blocks are contracted with lam on the device (gf_penalty_dxi_rev: no 0.64 GB host copy at
+        C4) and only 6 doubles per mortar vertex come back, chained here with d(tau)/d(xi_A).  Works on a sharded problem (the ranks' owned rows add up).
+        Reference: DispMintImOpeartion.apply_linear_rev, operations/disp_mi_imop.py:75-104."""
+        c2x, dev = self.cpiga2xi, self.dev
+        lam = np.ascontiguousarray(lam, float)
+        out = np.zeros(c2x.xi_size_global)
+        for i, g in enumerate(self.diff_int_inds):
+            n, base = c2x.diff_int_num_pts[i], c2x.xi_flat_inds[i]
+            T = dev.penalty_dxi_rev_if(g, lam)                                   # (n, 6)
+            k = np.arange(n)
+            for d in range(4):
+                out[base + (d // 2) * 2 * n + 2 * k + d % 2] += T[:, d]
+            Gm = np.gradient(np.eye(n), 1.0 / (n - 1), axis=0, edge_order=2 if n > 2 else 1)   # tau = Gm @ xi_A
+            for d in range(2):
+                out[base + 2 * k + d] += Gm.T @ T[:, 4 + d]
+        return out
+
     def dRIGAdxi_FD(self, xi_flat, h=1e-8):
         """Forward-difference check of dRIGAdxi (nonmatching_opt.py:1018-1040): one model rebuild per column."""
         xi0 = np.asarray(xi_flat, float).copy()
@@ -720,7 +738,7 @@ class NonMatchingOpt:
         zero_mortar_funcs).  Plain Newton as in the reference, with two safeguards it does not have:
 
         * backtracking: after the first step (the linear solution, whose residual legitimately exceeds |R_0| for a
-          geometrically nonlinear shell) a step that does not reduce |R| is halved, at most four times;
+          geometrically nonlinear shell) a step whose residual exceeds the largest of the last three (non-monotone rule) is halved, at most four times;
         * honesty about the end of the iteration: ``newton_converged`` is True when |R| / ref < rtol, or when the Newton
           correction has become negligible (|du| <= newton_step_rtol |u|) -- the residual of a thin, stiffly coupled shell
           has an evaluation floor of about eps E h |A| (strain = difference of metrics) that a tight rtol cannot pass.
@@ -752,7 +770,11 @@ class NonMatchingOpt:
                 # negligible against the state
                 contracted = min(hist) < 0.1 * hist[0]
                 near_floor = contracted and nn < 10.0 * min(hist) and lam * ndu <= 1e-4 * max(float(np.linalg.norm(self.u_iga)), 1e-300)
-                if (np.isfinite(nn) and (it == 0 or nn <= hist[-1] or near_floor)) or lam <= 1.0 / 16.0:
+                # NON-MONOTONE acceptance (Grippo-Lampariello-Lucidi): the full step stands unless its residual exceeds the largest of the last three.  The
+                # residual norm of a thin shell is a poor merit function -- the sliding-web T-beam goes 1, 208, 0.056, ~0.5, 1e-4, ... under plain Newton (the
+                # reference's iteration), and a monotone rule cuts its third step sixteen-fold and creeps (round 4; round 3 let that step through only by the
+                # overshoot bug the advisor flagged) --, while a diverging iteration (arctan from 3) still exceeds its recent history and is shortened.
+                if (np.isfinite(nn) and (it == 0 or nn <= max(hist[-3:]) or near_floor)) or lam <= 1.0 / 16.0:
                     break
                 lam *= 0.5
             rel_step = ndu / max(float(np.linalg.norm(self.u_iga)), 1e-300)    # the full correction: a shortened step says nothing

@@ -16,9 +16,16 @@ class DispMintImOpeartion(DispImOpeartion):
     def linearize(self):
         """disp_mi_imop.py:34-42: dR/du and dR/dCP_f in one device pass, dR/dxi from the mortar-vertex kernel."""
         self.nonmatching_opt._assemble(_lib.ASM_K | _lib.ASM_DRDCP)
-        self.dRigadxi = self.nonmatching_opt.dRIGAdxi()
+        self._dRigadxi = None                         # the matrix itself is built when somebody asks for it (forward products, tests): reverse products do not need it
         self._lin_dev = self.nonmatching_opt.dev
-        return self.dRigadxi
+        self._lin_state = getattr(self.nonmatching_opt, "_state_version", 0)
+
+    @property
+    def dRigadxi(self):
+        """d R_IGA / d xi as a sparse matrix (disp_mi_imop.py:40; one host copy of the per-vertex blocks)."""
+        if getattr(self, "_dRigadxi", None) is None:
+            self._dRigadxi = self.nonmatching_opt.dRIGAdxi()
+        return self._dRigadxi
 
     def stale(self):
         """True when update_transfer_matrices re-created the device model after the last linearize (its matrices are gone)."""
@@ -52,5 +59,5 @@ class DispMintImOpeartion(DispImOpeartion):
                     acc = np.zeros(nm.vec_scalar_iga_dof)
                     dev.apply(_lib.MAT_DRDCP0 + field, dres, acc, transpose=True)
                     d_inputs_array_list[i][:] += acc[nm._shopt_cols[i]]
-                d_inputs_array_list[-1][:] += self.dRigadxi.T @ dres
+                d_inputs_array_list[-1][:] += nm.dRIGAdxi_rev(dres)               # formed on the device: 6 doubles per mortar vertex come back
         return d_inputs_array_list, d_outputs_array

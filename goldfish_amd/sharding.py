@@ -110,6 +110,7 @@ class Shard:
     cp_off_global: np.ndarray    # global control-point offsets (all patches)
     cp_off_local: np.ndarray
     owned_by_rank: list = None   # owned global patch ids of every rank (ascending)
+    if_global: list = None       # global interface id of every local interface (local order)
 
     @property
     def total_cp_global(self):
@@ -144,11 +145,12 @@ def shard_spec(spec, rank, world, part=None):
             ghosts.add(itf.a)
     order = own + sorted(ghosts)
     g2l = {g: l for l, g in enumerate(order)}
-    itfs = []
-    for itf in spec.interfaces:
+    itfs, if_global = [], []
+    for gi, itf in enumerate(spec.interfaces):
         if itf.a in mine or itf.b in mine:
             loc = Interface(g2l[itf.a], g2l[itf.b], itf.xi_a, itf.xi_b)   # keeps the (A, B) orientation
             itfs.append(loc)
+            if_global.append(gi)
     pls = [(g2l[s], xi, f, v) for (s, xi, f, v) in spec.point_loads if s in mine]
     def per_patch(v):                # a per-patch list follows the local patch order; a scalar is shared
         return [np.asarray(v).ravel()[g] for g in order] if np.ndim(v) > 0 and np.size(v) == len(spec.patches) else v
@@ -161,7 +163,7 @@ def shard_spec(spec, rank, world, part=None):
                         [(g2l[s], d, side, f) for (s, d, side, f) in spec.edge_traction if s in g2l])
     cpg = np.concatenate([[0], np.cumsum([p.ncp for p in spec.patches])]).astype(np.int64)
     cpl = np.concatenate([[0], np.cumsum([p.ncp for p in local.patches])]).astype(np.int64)
-    return Shard(rank, world, local, len(own), order, cpg, cpl, [[int(g) for g in np.flatnonzero(part == r)] for r in range(world)])
+    return Shard(rank, world, local, len(own), order, cpg, cpl, [[int(g) for g in np.flatnonzero(part == r)] for r in range(world)], if_global)
 
 
 def shard_arrays(shard, thickness_global=None):
@@ -261,6 +263,7 @@ class ShardedDeviceModel:
         self._own_rows = {w: self.shard.owned_rows_global(w) for w in (1, 3)}
         self._gpat = {}
         self._kglob = None
+        self._n_if_pts = [int(i.npts) for i in spec.interfaces]
 
     def close(self):
         if getattr(self, "D", None) is not None:
@@ -349,6 +352,18 @@ class ShardedDeviceModel:
         du[3 * n:] = 0.0
         dcp[:, n:] = 0.0
         return dict(C=float(self._allreduce(np.array([F["C"]]))[0]), dCdu=self._rows_to_global(du, 3), dCdcp=np.stack([self._rows_to_global(dcp[k], 1) for k in range(3)]))
+
+    def penalty_dxi_rev_if(self, g, lam):
+        """(n, 6) reverse-mode product of the dR/d(xi, tau) blocks of the mortar vertices of GLOBAL interface g with the replicated lam (moving intersections on
+        shards): every rank that holds the interface contracts the rows of its OWN patches on its device (gf_penalty_dxi_rev masks the ghost
+        rows), the ranks' results add up -- one all-reduce of 6 doubles per mortar vertex."""
+        itf_l = self.shard.if_global.index(g) if g in self.shard.if_global else None
+        n = int(self._n_if_pts[g])
+        out = np.zeros((n, 6))
+        if itf_l is not None:
+            off = self.A.if_off
+            out = self.D.penalty_dxi_rev(n, self.shard.to_local(np.asarray(lam, float), 3), v_first=int(off[itf_l]))
+        return self._allreduce(out.ravel()).reshape(n, 6)
 
     # -- replicated global K on this rank's device: what the direct solver factors (stage 1 of the sharded solve: every rank gathers the owned value rows
     #    of all ranks and factors the same matrix -- correct and redundant; the assembly is sharded, the factorisation is not)

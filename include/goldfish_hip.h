@@ -136,6 +136,11 @@ int gf_penalty_dxi(gf_handle* h, double* blocks, int64_t n, int32_t* windows, in
 /* the same for the mortar vertices v_first .. v_first + v_count - 1 only (blocks, windows sized for v_count vertices): the vertices
  * of the interfaces that actually move, instead of every vertex of the model (0.64 GB of blocks at C4) */
 int gf_penalty_dxi_range(gf_handle* h, int64_t v_first, int64_t v_count, double* blocks, int64_t n, int32_t* windows, int64_t nw);
+/* Reverse-mode product with those blocks WITHOUT moving them to the host (DispMintImOpeartion.apply_linear_rev, operations/disp_mi_imop.py:75-104:
+ * d_xi += (dR/dxi)^T d_res): out[v][dir] = sum over side', a, i of blocks[v][dir][side'][a][i] * lam[dof], the rows this handle owns (owned patches of a shard)
+ * with Dirichlet rows skipped (the reference zeroes them, nonmatching_opt.py:1057-1062); lam: ndof doubles (host), out: 6 per mortar vertex of the range (host).
+ * The caller chains dir 4, 5 with d(tau)/d(xi) as for gf_penalty_dxi.  On a shard the results of the ranks add up (a cut interface is evaluated by both). */
+int gf_penalty_dxi_rev(gf_handle* h, int64_t v_first, int64_t v_count, const double* lam, int64_t nlam, double* out, int64_t nout);
 
 /* borrowed device pointer to one of the GF_BUF_* buffers (for zero-copy users: bench, RCCL exchange) */
 void* gf_device_ptr(gf_handle* h, int which);

@@ -274,3 +274,14 @@ def test_stalled_general_mode_solve_and_small_pivot_fall_back(monkeypatch):
         warnings.simplefilter("error")
         assert np.allclose(K @ nm.solve_K(b), b)
     assert built == [1]
+
+
+def test_non_monotone_shell_history_is_not_cut_short():
+    """The sliding-web T-beam's residual history under plain Newton (the reference's iteration): 1, 208, 0.056, 0.5, 1e-4, 1e-9.  A monotone backtracking
+    rule shortens the step to 0.5 sixteen-fold and creeps at 0.05 (round 4, found by the shape_opt_mint group); the non-monotone rule lets it through."""
+    seq = [1.0, 208.0, 0.056, 0.5, 1e-4, 1e-9, 1e-14]
+    nm = FakeNM(lambda u: np.array([seq[min(int(round(u[0])), len(seq) - 1)]]), lambda u: np.array([[-seq[min(int(round(u[0])), len(seq) - 1)]]]), 1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        nm.solve_nonlinear_nonmatching_problem(rtol=1e-8, max_it=30)
+    assert nm.newton_converged and nm.newton_iterations == 5 and all(h[2] == 1.0 for h in nm.newton_history)
