@@ -23,8 +23,9 @@ class DispMintImOpeartion(DispImOpeartion):
     @property
     def dRigadxi(self):
         """d R_IGA / d xi as a sparse matrix (disp_mi_imop.py:40; one host copy of the per-vertex blocks)."""
-        if getattr(self, "_dRigadxi", None) is None:
-            self._dRigadxi = self.nonmatching_opt.dRIGAdxi()
+        sv = (getattr(self.nonmatching_opt, "_state_version", 0), id(self.nonmatching_opt.dev))
+        if getattr(self, "_dRigadxi", None) is None or getattr(self, "_dRigadxi_state", None) != sv:      # always the matrix of the CURRENT state, like the device-side reverse product
+            self._dRigadxi, self._dRigadxi_state = self.nonmatching_opt.dRIGAdxi(), sv
         return self._dRigadxi
 
     def stale(self):

@@ -658,6 +658,7 @@ def test_disp_states_with_moving_intersections_component():
     assert ("displacements", "int_para") in errs
     # reverse mode: <lam, J dx> == <J^T lam, dx> for the xi block
     op = comp.disp_mint_state_imop
+    op.linearize()                                                   # the products below are those of the current state
     lam, dxi = rng.standard_normal(nm.vec_iga_dof), rng.standard_normal(nm.xi_size)
     dres = np.zeros(nm.vec_iga_dof)
     din = [np.zeros(s) for s in comp.input_cp_shapes] + [dxi]
