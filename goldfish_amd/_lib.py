@@ -20,7 +20,7 @@ BUF_CP, BUF_U, BUF_H, BUF_R, BUF_VAL_K, BUF_VAL_C0, BUF_VAL_C1, BUF_VAL_C2, BUF_
 EXPORTS = ["gf_device_count", "gf_last_error", "gf_create", "gf_destroy", "gf_total_cp", "gf_num_dofs",
            "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes", "gf_set_cp",
            "gf_set_thickness", "gf_set_u", "gf_nnz", "gf_pattern", "gf_assemble", "gf_sync", "gf_get_residual",
-           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_shape_regu", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms", "gf_assembly_path", "gf_stream", "gf_apply_many", "gf_get_functional_gradient", "gf_penalty_dxi_range", "gf_functionals_per_patch", "gf_penalty_dxi_rev"]
+           "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_shape_regu", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms", "gf_assembly_path", "gf_stream", "gf_apply_many", "gf_get_functional_gradient", "gf_penalty_dxi_range", "gf_functionals_per_patch", "gf_penalty_dxi_rev", "gf_update_interface"]
 
 
 def lib():
@@ -44,7 +44,7 @@ def lib():
             "gf_apply_dev": ([vp, ci, ci, vp, vp], None), "gf_kernel_ms": ([vp, C.POINTER(ci)], C.c_double), "gf_assembly_path": ([vp], None),
             "gf_get_functional_gradient": ([vp, ci, dp, i64], None), "gf_apply_many": ([vp, ci, ci, C.POINTER(ci), C.POINTER(dp), C.POINTER(dp)], None),
             "gf_stream": ([vp], vp), "gf_functionals_per_patch": ([vp, dp, dp, i64], None),
-            "gf_penalty_dxi_rev": ([vp, i64, i64, dp, i64, dp, i64], None)}
+            "gf_penalty_dxi_rev": ([vp, i64, i64, dp, i64, dp, i64], None), "gf_update_interface": ([vp, ci, dp, dp, dp, i64], None)}
         for name in ("gf_total_cp", "gf_num_dofs", "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes"):
             sig[name] = ([vp], i64)
         for name, (argtypes, restype) in sig.items():
@@ -283,6 +283,21 @@ class DeviceModel:
         out = np.zeros((int(npts), 6))
         _check(lib().gf_penalty_dxi_rev(self.h, int(v_first), int(npts), _dp(lam), lam.size, _dp(out), out.size), ValueError)
         return out
+
+    def update_interface(self, g, itf):
+        """New parametric coordinates of interface ``g`` (a model.Interface): True when the vertex tables were patched in place (no vertex left its knot spans),
+        False -- nothing changed -- when the model has to be re-created (gf_update_interface)."""
+        xi = np.ascontiguousarray(np.hstack([itf.xi_a, itf.xi_b]), dtype=np.float64).ravel()
+        tau, wt = np.ascontiguousarray(itf.tau, dtype=np.float64).ravel(), np.ascontiguousarray(itf.wt, dtype=np.float64).ravel()
+        rc = lib().gf_update_interface(self.h, int(g), _dp(xi), _dp(tau), _dp(wt), wt.size)
+        if rc == 2:
+            return False
+        _check(rc, ValueError)
+        off = int(self.arrays.if_off[g])                      # keep the host copy of the model in step (a later re-creation starts from it)
+        self.arrays.if_xi[4 * off:4 * off + xi.size] = xi
+        self.arrays.if_tau[2 * off:2 * off + tau.size] = tau
+        self.arrays.if_wt[off:off + wt.size] = wt
+        return True
 
     def penalty_dxi_rev_if(self, g, lam):
         """penalty_dxi_rev for the mortar vertices of interface ``g`` of the model."""

@@ -786,6 +786,38 @@ int gf_penalty_dxi_range(gf_handle* h, int64_t v_first, int64_t v_count, double*
     } catch (const std::exception& ex) { return fail(ex.what()); }
     return 0;
 }
+// Moving intersections: new parametric coordinates of the mortar vertices of ONE interface.  When every vertex stays in its knot spans (same support windows:
+// the coupling pattern, the visit lists and every index table stay valid) only the vertex tables -- basis values / derivatives, curve tangents, quadrature
+// weights -- of that interface are re-evaluated and uploaded; returns 2, changing nothing, when a vertex crossed a knot line (the caller re-creates the model).
+int gf_update_interface(gf_handle* h, int iface, const double* xi, const double* tau, const double* wt, int64_t npts_if) {
+    if (!h || !xi || !tau || !wt) return fail("gf_update_interface: null argument");
+    HostModel& H = h->H;
+    if (iface < 0 || iface >= H.ni) return fail("gf_update_interface: interface index out of range");
+    const int64_t v0 = H.if_off[iface], n = H.if_off[iface + 1] - v0;
+    if (npts_if != n) return fail("gf_update_interface: the interface has " + std::to_string(n) + " mortar vertices, got " + std::to_string(npts_if));
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        const int NB = (H.degree + 1) * (H.degree + 1);
+        std::vector<double> nu((size_t)n * 2 * 3 * NB), nu2((size_t)n * 2 * 3 * NB);
+        for (int64_t k = 0; k < n; ++k) for (int sd = 0; sd < 2; ++sd) {
+            int win[2];
+            H.eval_mortar_vertex(H.if_patch[2 * iface + sd], xi[4 * k + 2 * sd], xi[4 * k + 2 * sd + 1], win, &nu[((size_t)k * 2 + sd) * 3 * NB], &nu2[((size_t)k * 2 + sd) * 3 * NB]);
+            if (win[0] != H.pt_base[4 * (v0 + k) + 2 * sd] || win[1] != H.pt_base[4 * (v0 + k) + 2 * sd + 1]) return 2;      // a vertex left its knot spans
+        }
+        std::copy(nu.begin(), nu.end(), H.pt_nu.begin() + (size_t)v0 * 2 * 3 * NB);
+        std::copy(nu2.begin(), nu2.end(), H.pt_nu2.begin() + (size_t)v0 * 2 * 3 * NB);
+        std::copy(tau, tau + 2 * n, H.pt_tau.begin() + 2 * v0);
+        std::copy(wt, wt + n, H.pt_wt.begin() + v0);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(const_cast<double*>(h->Q.pt_nu) + (size_t)v0 * 2 * 3 * NB, nu.data(), nu.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (h->d_pt_nu2) HIPCHK(hipMemcpy(h->d_pt_nu2 + (size_t)v0 * 2 * 3 * NB, nu2.data(), nu2.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(const_cast<double*>(h->Q.pt_tau) + 2 * v0, tau, 2 * n * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(const_cast<double*>(h->Q.pt_wt) + v0, wt, n * sizeof(double), hipMemcpyHostToDevice));
+        for (int w = 0; w < 5; ++w) h->assembled[w] = false;
+    } catch (const std::exception& ex) { return fail(ex.what()); }
+    return 0;
+}
+
 // reverse-mode product with dR/dxi on the device: out[v][dir] = sum over the owned, non-Dirichlet rows of block[v][dir] * lam (pen_dxi_kernel<P, true>)
 int gf_penalty_dxi_rev(gf_handle* h, int64_t v_first, int64_t v_count, const double* lam, int64_t nlam, double* out, int64_t nout) {
     if (!h || !lam || !out) return fail("gf_penalty_dxi_rev: null argument");

@@ -125,6 +125,7 @@ struct HostModel {
     std::vector<CpDesc> cp_desc;        // [total_cp]
     std::vector<WalkItem> rec_items; std::vector<RecPatch> rec_patch; std::vector<RecCp> rec_cp; std::vector<RecCp4> rec_cp4; int rec_rows = 0;   // row-record path
     void build_rec(int seg_len);
+    void eval_mortar_vertex(int patch, double xu, double xv, int win[2], double* nu, double* nu2) const;
     std::vector<int> cp_patch;          // [total_cp]
     std::vector<double> weights;
     std::vector<unsigned char> zero;    // [ndof]
@@ -143,6 +144,7 @@ struct HostModel {
     std::vector<int> nb_rev_s, nb_rev_c;   // per neighbour entry (a, k) with b = nb[k]: position of a in b's list (the relation is symmetric): fixed-order transposed products
     std::vector<unsigned short> nb_meta;   // per nb_c entry: bits 0-6 box slot of the neighbour (127: coupling-only column), 7-9 Dirichlet flags of its dofs, 10 self
     // mortar points
+    std::vector<double> knots; std::vector<int64_t> knot_off;   // copies of the desc's knot vectors (gf_update_interface re-evaluates mortar vertices)
     std::vector<int> pt_iface;          // [npts]
     std::vector<int> pt_base;           // [npts][2][2] (iu0, iv0) per side
     std::vector<double> pt_nu;          // [npts][2][3][NB] rational value/d1/d2
@@ -247,6 +249,7 @@ inline void HostModel::build(const gf_model_desc* D) {
     // ---- mortar points ------------------------------------------------------------
     ni = D->n_interfaces;
     const int NB = (degree + 1) * (degree + 1);
+    knot_off.assign(D->knot_off, D->knot_off + 2 * np + 1); knots.assign(D->knots, D->knots + knot_off[2 * np]);
     if (ni > 0 && (!D->if_patch || !D->if_off || !D->if_xi || !D->if_tau || !D->if_wt || !D->if_alpha)) throw std::runtime_error("gf_create: n_interfaces > 0 but an interface array is NULL");
     npts = ni > 0 ? D->if_off[ni] : 0;
     if_patch.assign(D->if_patch, D->if_patch + 2 * ni); if_alpha.assign(D->if_alpha, D->if_alpha + 2 * ni);
@@ -258,30 +261,9 @@ inline void HostModel::build(const gf_model_desc* D) {
         for (int64_t v = if_off[i]; v < if_off[i + 1]; ++v) {
             pt_iface[v] = i;
             for (int sd = 0; sd < 2; ++sd) {
-                const int s = if_patch[2 * i + sd]; const PatchDev& P = patches[s];
-                const double* Uu = D->knots + D->knot_off[2 * s]; const double* Uv = D->knots + D->knot_off[2 * s + 1];
-                const double xu = D->if_xi[4 * v + 2 * sd], xv = D->if_xi[4 * v + 2 * sd + 1];
-                const int su = find_span(P.nu, P.p, Uu, xu), sv = find_span(P.nv, P.q, Uv, xv);
-                double du[3][MAXP + 1], dv[3][MAXP + 1]; basis_ders(su, xu, P.p, Uu, du); basis_ders(sv, xv, P.q, Uv, dv);
-                double N[6][MAXNB], W[6] = {0, 0, 0, 0, 0, 0};
-                for (int jv = 0; jv <= P.q; ++jv) for (int ju = 0; ju <= P.p; ++ju) {
-                    const int a = ju + jv * (P.p + 1);
-                    const double w = weights[P.cp_off + (su - P.p + ju) + int64_t(sv - P.q + jv) * P.nu];
-                    N[0][a] = du[0][ju] * dv[0][jv]; N[1][a] = du[1][ju] * dv[0][jv]; N[2][a] = du[0][ju] * dv[1][jv];
-                    N[3][a] = du[2][ju] * dv[0][jv]; N[4][a] = du[0][ju] * dv[2][jv]; N[5][a] = du[1][ju] * dv[1][jv];
-                    for (int k = 0; k < 6; ++k) W[k] += N[k][a] * w;
-                }
-                pt_base[4 * v + 2 * sd] = su - P.p; pt_base[4 * v + 2 * sd + 1] = sv - P.q;
-                double* o = &pt_nu[(size_t(v) * 2 + sd) * 3 * NB];
-                for (int a = 0; a < NB; ++a) {
-                    const double R = N[0][a] / W[0];
-                    const double R1 = (N[1][a] - R * W[1]) / W[0], R2 = (N[2][a] - R * W[2]) / W[0];
-                    o[a] = R; o[NB + a] = R1; o[2 * NB + a] = R2;
-                    double* o2 = &pt_nu2[(size_t(v) * 2 + sd) * 3 * NB];
-                    o2[a] = (N[3][a] - 2 * R1 * W[1] - R * W[3]) / W[0];
-                    o2[NB + a] = (N[4][a] - 2 * R2 * W[2] - R * W[4]) / W[0];
-                    o2[2 * NB + a] = (N[5][a] - R1 * W[2] - R2 * W[1] - R * W[5]) / W[0];
-                }
+                int win[2];
+                eval_mortar_vertex(if_patch[2 * i + sd], D->if_xi[4 * v + 2 * sd], D->if_xi[4 * v + 2 * sd + 1], win, &pt_nu[(size_t(v) * 2 + sd) * 3 * NB], &pt_nu2[(size_t(v) * 2 + sd) * 3 * NB]);
+                pt_base[4 * v + 2 * sd] = win[0]; pt_base[4 * v + 2 * sd + 1] = win[1];
             }
         }
     }
@@ -463,6 +445,33 @@ inline void HostModel::build(const gf_model_desc* D) {
             }
             ent_ptr.push_back((int64_t)pen_entries.size()); row_cp.push_back(a);
         }
+    }
+}
+
+// Support window (first control-point indices) and rational basis values / first / second derivatives of patch `patch` at the parametric point (xu, xv):
+// nu [3][NB] = R, R_u, R_v; nu2 [3][NB] = R_uu, R_vv, R_uv (quotient rule on the tensor-product B-spline values)
+inline void HostModel::eval_mortar_vertex(int s, double xu, double xv, int win[2], double* o, double* o2) const {
+    const PatchDev& P = patches[s];
+    const int NB = (degree + 1) * (degree + 1);
+    const double* Uu = knots.data() + knot_off[2 * s]; const double* Uv = knots.data() + knot_off[2 * s + 1];
+    const int su = find_span(P.nu, P.p, Uu, xu), sv = find_span(P.nv, P.q, Uv, xv);
+    double du[3][MAXP + 1], dv[3][MAXP + 1]; basis_ders(su, xu, P.p, Uu, du); basis_ders(sv, xv, P.q, Uv, dv);
+    double N[6][MAXNB], W[6] = {0, 0, 0, 0, 0, 0};
+    for (int jv = 0; jv <= P.q; ++jv) for (int ju = 0; ju <= P.p; ++ju) {
+        const int a = ju + jv * (P.p + 1);
+        const double w = weights[P.cp_off + (su - P.p + ju) + int64_t(sv - P.q + jv) * P.nu];
+        N[0][a] = du[0][ju] * dv[0][jv]; N[1][a] = du[1][ju] * dv[0][jv]; N[2][a] = du[0][ju] * dv[1][jv];
+        N[3][a] = du[2][ju] * dv[0][jv]; N[4][a] = du[0][ju] * dv[2][jv]; N[5][a] = du[1][ju] * dv[1][jv];
+        for (int k = 0; k < 6; ++k) W[k] += N[k][a] * w;
+    }
+    win[0] = su - P.p; win[1] = sv - P.q;
+    for (int a = 0; a < NB; ++a) {
+        const double R = N[0][a] / W[0];
+        const double R1 = (N[1][a] - R * W[1]) / W[0], R2 = (N[2][a] - R * W[2]) / W[0];
+        o[a] = R; o[NB + a] = R1; o[2 * NB + a] = R2;
+        o2[a] = (N[3][a] - 2 * R1 * W[1] - R * W[3]) / W[0];
+        o2[NB + a] = (N[4][a] - 2 * R2 * W[2] - R * W[4]) / W[0];
+        o2[2 * NB + a] = (N[5][a] - R1 * W[2] - R2 * W[1] - R * W[5]) / W[0];
     }
 }
 

@@ -637,12 +637,23 @@ class NonMatchingOpt:
         tables (support windows, basis values, curve tangents, coupling pattern) live in the device model, which is
         re-created; control points, thickness and displacement are pushed again by ``dev``."""
         c2x = self.cpiga2xi
+        patched = self._dev is not None
         for i, g in enumerate(self.diff_int_inds):
             n = c2x.diff_int_num_pts[i]
             sub = self.xi_flat[c2x.xi_flat_inds[i]:c2x.xi_flat_inds[i + 1]]
             a, b = self.mapping_list[g]
-            self.interfaces[g] = Interface(a, b, sub[:2 * n].reshape(-1, 2), sub[2 * n:].reshape(-1, 2))
-        self._drop_device()                                    # factorisations belong to the old coupling pattern
+            new = Interface(a, b, sub[:2 * n].reshape(-1, 2), sub[2 * n:].reshape(-1, 2))
+            unchanged = np.array_equal(new.xi_a, self.interfaces[g].xi_a) and np.array_equal(new.xi_b, self.interfaces[g].xi_b)
+            self.interfaces[g] = new
+            # while every mortar vertex stays in its knot spans the coupling pattern and all index tables of the device model stay valid: only the vertex
+            # tables of the moved interface are re-evaluated (gf_update_interface), the direct solver keeps its symbolic phase; a vertex that crosses a knot
+            # line forces a new model (2.7 s at C4 size, DESIGN.md section 4)
+            if patched and not unchanged:
+                patched = bool(self._dev.update_interface(g, new))
+        if patched:
+            self._touch()                                      # same model, new coupling values: everything assembled is stale
+        else:
+            self._drop_device()                                # factorisations belong to the old coupling pattern
 
     def dRIGAdxi(self):
         """d RIGA / d xi_flat (nonmatching_opt.py:1042-1088), ndof x xi_size, Dirichlet rows zeroed: the device returns the

@@ -29,8 +29,10 @@ class DispMintImOpeartion(DispImOpeartion):
         return self._dRigadxi
 
     def stale(self):
-        """True when update_transfer_matrices re-created the device model after the last linearize (its matrices are gone)."""
-        return getattr(self, "_lin_dev", None) is not self.nonmatching_opt.dev
+        """True when the device model was re-created or its state changed (update_transfer_matrices patches the vertex tables of a moved interface in place) after
+        the last linearize: the matrices of that linearisation are gone."""
+        nm = self.nonmatching_opt
+        return getattr(self, "_lin_dev", None) is not nm.dev or getattr(self, "_lin_state", None) != getattr(nm, "_state_version", 0)
 
     def apply_linear_fwd(self, d_inputs_array_list=None, d_outputs_array=None, d_residuals_array=None):
         """disp_mi_imop.py:44-73."""

@@ -353,6 +353,16 @@ class ShardedDeviceModel:
         dcp[:, n:] = 0.0
         return dict(C=float(self._allreduce(np.array([F["C"]]))[0]), dCdu=self._rows_to_global(du, 3), dCdcp=np.stack([self._rows_to_global(dcp[k], 1) for k in range(3)]))
 
+    def update_interface(self, g, itf):
+        """DeviceModel.update_interface for GLOBAL interface g: patched on the ranks that hold it; the model is re-created everywhere when ANY rank reports a vertex
+        that crossed a knot line (one all-reduce of a flag)."""
+        ok = 1.0
+        if g in self.shard.if_global:
+            loc = self.shard.spec.interfaces[self.shard.if_global.index(g)]
+            from .model import Interface
+            ok = 1.0 if self.D.update_interface(self.shard.if_global.index(g), Interface(loc.a, loc.b, itf.xi_a, itf.xi_b)) else 0.0
+        return bool(self._allreduce(np.array([1.0 - ok]))[0] == 0.0)
+
     def penalty_dxi_rev_if(self, g, lam):
         """(n, 6) reverse-mode product of the dR/d(xi, tau) blocks of the mortar vertices of GLOBAL interface g with the replicated lam (moving intersections on
         shards): every rank that holds the interface contracts the rows of its OWN patches on its device (gf_penalty_dxi_rev masks the ghost

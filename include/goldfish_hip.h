@@ -136,6 +136,11 @@ int gf_penalty_dxi(gf_handle* h, double* blocks, int64_t n, int32_t* windows, in
 /* the same for the mortar vertices v_first .. v_first + v_count - 1 only (blocks, windows sized for v_count vertices): the vertices
  * of the interfaces that actually move, instead of every vertex of the model (0.64 GB of blocks at C4) */
 int gf_penalty_dxi_range(gf_handle* h, int64_t v_first, int64_t v_count, double* blocks, int64_t n, int32_t* windows, int64_t nw);
+/* NonMatchingOpt.update_transfer_matrices (nonmatching_opt.py:567-600 rebuilds the mortar transfer matrices at new parametric coordinates) for ONE interface
+ * without re-creating the model: xi [npts_if][2 sides][2], tau [npts_if][2], wt [npts_if] in gf_model_desc's layout (if_xi, if_tau, if_wt).  Returns 0 when
+ * the vertex tables were patched (every vertex stayed in its knot spans, so the coupling pattern and all index tables are unchanged; the assembled matrices are
+ * marked stale), 2 -- with nothing changed -- when a vertex crossed a knot line: the caller then creates a new handle; 1 on errors. */
+int gf_update_interface(gf_handle* h, int iface, const double* xi, const double* tau, const double* wt, int64_t npts_if);
 /* Reverse-mode product with those blocks WITHOUT moving them to the host (DispMintImOpeartion.apply_linear_rev, operations/disp_mi_imop.py:75-104:
  * d_xi += (dR/dxi)^T d_res): out[v][dir] = sum over side', a, i of blocks[v][dir][side'][a][i] * lam[dof], the rows this handle owns (owned patches of a shard)
  * with Dirichlet rows skipped (the reference zeroes them, nonmatching_opt.py:1057-1062); lam: ndof doubles (host), out: 6 per mortar vertex of the range (host).
