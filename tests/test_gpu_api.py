@@ -994,7 +994,7 @@ def test_update_transfer_matrices_patches_the_moved_interface_in_place():
     xi0 = nm.xi_flat.copy()
     xi = xi0.copy()
     n = nm.cpiga2xi.diff_int_num_pts[0]
-    xi[0:2 * n:2] += 0.01                                                # side A slides by 0.01 in u: inside its spans (4 elements per side: spans of 0.25, vertices at 0.5)
+    xi[0:2 * n:2] += 0.01                                                # side A slides by 0.01 in u: inside its span (the flange has two spans in u, [0, 0.5) and [0.5, 1]; the vertices sit at 0.5)
     nm.update_xi(xi)
     nm.update_transfer_matrices()
     assert nm.dev is dev0                                                 # patched in place
@@ -1011,7 +1011,7 @@ def test_update_transfer_matrices_patches_the_moved_interface_in_place():
     assert _rel(R1, R2) < 1e-13 and abs(K1 - K2).max() < 1e-13 * abs(K2).max()
     assert _rel(K2 @ x1, -R2) < 1e-8
     xi = xi0.copy()
-    xi[0:2 * n:2] += 0.3                                                  # across a knot line: new support windows
+    xi[0:2 * n:2] -= 0.3                                                  # across the knot line at 0.5: new support windows
     nm.update_xi(xi)
     nm.update_transfer_matrices()
     assert nm.dev is not dev0
