@@ -301,6 +301,31 @@ def test_chunked_scratch_gives_identical_results(oracle_lib, monkeypatch):
             assert np.array_equal(x, y)
 
 
+def test_p4_record_chunks_give_identical_results(monkeypatch):
+    """p = 4 row-record path: GF_SCRATCH_GB small enough to force one chunk of work items per patch (the walks and the gather of a chunk run before the next
+    chunk reuses the record buffer; the gather's record rows are relative to the chunk's first item) gives the same bits as the single-chunk run, for the full
+    pass and the Newton pass."""
+    from goldfish_amd import _lib
+    spec = G.synthetic_shell(3, 2, nel=6, p=4, jitter=1)
+    A, h, u = _state(spec, seed=5)
+    out = []
+    for gb in ("16", "0.0012"):
+        monkeypatch.setenv("GF_SCRATCH_GB", gb)
+        D = _lib.DeviceModel(A)
+        assert D.assembly_path == 5
+        D.set_thickness(h)
+        D.set_u(u)
+        D.assemble()
+        res = [D.residual()] + [D.values(w) for w in range(5)]
+        D.assemble(_lib.ASM_R | _lib.ASM_K)
+        res += [D.residual(), D.values(0)]
+        out.append(res)
+        D.close()
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+    assert np.array_equal(out[0][0], out[0][6]) and np.array_equal(out[0][1], out[0][7])       # Newton pass (9 values per pair) = full pass
+
+
 def test_single_patch_without_interfaces(oracle_lib):
     from goldfish_amd import _lib
     from oracle.oracle_py import Oracle
