@@ -167,7 +167,10 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         // doubles of scratch per element: element blocks, or (row-record paths) the residual entries + the element's share of the records
         const long long rec_sz = h->rec4 ? Rec4Cfg<21>::SZ : RecCfg<true>::SZ;
         const long long blk_doubles = recs ? (long long)ND : 2LL * ND * ND + (long long)ND * NB + ND;
-        double budget_gb = h->rec4 ? 16.0 : 40.0;         // p = 4 records: 16 GB of row records per chunk of patches (full C5: 8 chunks, 87 GB in all; one GPU's share of it: one chunk)
+        // p = 4 records: up to 120 GB of row records per chunk of patches, capped by half of the free device memory -- full C5 (117 GB of records) then runs as ONE chunk on
+        // an empty MI355X (288 GB): chunks cost launch tails (3 chunks: 468 ms per pass, 8 chunks: 486 ms, same lease); GF_SCRATCH_GB overrides
+        double budget_gb = 40.0;
+        if (h->rec4) { size_t fb = 0, tb = 0; budget_gb = 120.0; if (hipMemGetInfo(&fb, &tb) == hipSuccess) budget_gb = std::min(budget_gb, 0.5 * (double)fb / 1e9); }
         if (const char* s = getenv("GF_SCRATCH_GB")) budget_gb = atof(s);
         if (h->rec) budget_gb = 1e9;                      // p = 2, 3 records: one chunk
         // p = 4 records: ~rec_sz doubles per element (one record row per element row and strip); chunks of whole patches within the budget
