@@ -189,9 +189,10 @@ class DeviceSolver:
 
     MAX_RHS = 8
 
-    def solve_multi(self, B, transpose=False):
-        """X[k] = K^{-1} B[k] (or K^{-T} B[k]) for the rows of B in ONE call (gfs_solve_multi): in the nested-dissection mode the substitution sweeps of the
-        right-hand sides run next to each other on the device; ``rel_residuals`` holds one value per row, ``backward_error`` the largest."""
+    def solve_multi(self, B, transpose=False, max_refine=None):
+        """X[k] = K^{-1} B[k] (or K^{-T} B[k]) for the rows of B in ONE call (gfs_solve_multi): in the nested-dissection mode groups of three right-hand sides
+        share one pass over the factors (the sweeps are bound by the factor bytes) and the groups run next to each other on the device; the result of a row is
+        bitwise the one ``solve`` gives; ``rel_residuals`` holds one value per row, ``backward_error`` the largest."""
         B = np.ascontiguousarray(np.atleast_2d(B), float)
         if B.shape[1] != self.n:
             raise ValueError("DeviceSolver.solve_multi: expected rows of %d values, got %d" % (self.n, B.shape[1]))
@@ -201,7 +202,7 @@ class DeviceSolver:
         for k0 in range(0, B.shape[0], self.MAX_RHS):
             blk = np.ascontiguousarray(B[k0:k0 + self.MAX_RHS])
             out, rr = np.empty_like(blk), np.zeros(blk.shape[0])
-            if lib().gfs_solve_multi(self.h, blk.shape[0], blk.ctypes.data_as(dp), out.ctypes.data_as(dp), int(self.max_refine), rr.ctypes.data_as(dp), int(bool(transpose))):
+            if lib().gfs_solve_multi(self.h, blk.shape[0], blk.ctypes.data_as(dp), out.ctypes.data_as(dp), int(self.max_refine if max_refine is None else max_refine), rr.ctypes.data_as(dp), int(bool(transpose))):
                 raise RuntimeError(lib().gfs_last_error().decode())
             X[k0:k0 + blk.shape[0]] = out
             rr_all.append(rr)

@@ -301,8 +301,8 @@ template <int P> static int run_penalty(gf_handle* h, int flags) {
         const dim3 grid((unsigned)(((h->Q.nrow_groups + 7) / 8) * 8)), blk64(64);       // multiple of 8: XCD-contiguous group ranges
         if constexpr (P <= 3) {
             if (h->pen16 && h->Q.slots) {
-                const size_t lds = (size_t)h->pen_maxdeg * 18 * sizeof(double);
-#define GF_PEN16(WC, WK) hipLaunchKernelGGL((pen_row16_kernel<P, WC, WK>), grid, blk64, lds, st, h->M, h->Q, flags, h->d_pbuf, h->d_R, h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])
+                const size_t lds1 = (size_t)h->pen_maxdeg * 9 * sizeof(double);          // accumulators of one matrix per row
+#define GF_PEN16(WC, WK) hipLaunchKernelGGL((pen_row16_kernel<P, WC, WK>), grid, blk64, ((WC) && (WK)) ? 2 * lds1 : lds1, st, h->M, h->Q, flags, h->d_pbuf, h->d_R, h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])
                 if (!(flags & GF_ASM_DRDCP)) GF_PEN16(false, true);
                 else if (!(flags & GF_ASM_K)) GF_PEN16(true, false);
                 else GF_PEN16(true, true);

@@ -20,6 +20,9 @@
 // gave 384 instead of 426 us, so that layout is worth about 7 %).
 // Measured and dropped earlier: a second batch of data in flight (513 / 444 vs 487 / 426 us on the 8 x 8-patch slice before / after the bank fix); one
 // launch per class of neighbour counts (<= 64, <= 88, rest: more waves per CU for the narrow rows, but three tails: 463 vs 426 us).
+// Round 4: the one-matrix instances (Newton pass: K only; linearize after a solve: dR/dc only) allocate only their own accumulators -- half the LDS, twice
+// the waves per CU: 1.26 -> 0.84 ms at C4 for the K-only instance.  The full pass as TWO such launches (K rows, then dR/dc rows) is slower than the fused
+// instance (1.27 + 1.03 = 2.29 vs 1.80 ms at C4: the visit and vertex loads are issued twice, and those loads are what the kernel waits for).
 // The kernel WRITES the rows (the gather adds the shell part), like pen_owner_kernel<.., ADD = false>.
 // Reference path: nonmatching_opt.py:745-752, 789-801, 861-887 (penalty residual and its blocks of dR/du, dR/dCP).
 #pragma once
@@ -47,9 +50,9 @@ __global__ __launch_bounds__(64) void pen_row16_kernel(DevModel M, DevPenalty Q,
     // = 18 banks walks all 32 banks in 16 slots: the ds_add_f64 of a window (slots s .. s + 3, s + 7 .. in a box 7 wide) meet two-way
     // at most (with 18 doubles per slot, 36 banks, every eighth slot collided: five-way; the kernel is LDS bound)
     extern __shared__ double s_acc[];
-    double* const s_accK = s_acc; double* const s_accC = s_acc + 9 * (size_t)deg_c;
+    double* const s_accK = s_acc; double* const s_accC = (WITHK && WITHC) ? s_acc + 9 * (size_t)deg_c : s_acc;      // a one-matrix instance has only its own accumulators (half the LDS: twice the waves per CU)
     __shared__ double s_r[4][4];
-    if (mats) for (int k = lane; k < (int)deg_c * 18; k += 64) s_acc[k] = 0.0;
+    if (mats) for (int k = lane; k < (int)deg_c * ((WITHK && WITHC) ? 18 : 9); k += 64) s_acc[k] = 0.0;
 
     // the six w values of lane c: index c + 16 q of [wK (i, col) 54 | wC (i, col) 36]; offset of their Hessian row 0 in the vertex record
     // for side 0 and the stride between rows (the rows 9 s + 3 m + i, m = 0..2, are contracted with nu_a's value / d1 / d2)

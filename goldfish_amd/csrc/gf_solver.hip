@@ -320,69 +320,131 @@ __global__ __launch_bounds__(256) void bwd_kernel(const double* __restrict__ ban
 // ---- substitutions of a dense front, a GROUP of w <= 4 block columns per launch (one launch per block column is latency: 6 us each, 1 727 columns in the
 //      large fronts of C4).  Every workgroup solves the group's w x w block triangle itself (a few 64 x 64 matrix-vector products on tiles that sit in L2:
 //      cheaper than a second launch or a cross-workgroup hand-over), workgroup 0 keeps the result, workgroup g >= 1 applies it to one block row outside.
-__device__ __forceinline__ double mv_row(const double* __restrict__ L, const double* __restrict__ v, int r, int q4) {      // (L v)_r, four lanes per row
+//      NR right-hand sides per launch (round 4): the sweeps read the factors once for all of them -- every tile entry is loaded once and multiplied into NR
+//      sums (the sweeps are bound by the 73 GB of factors at C4, not by the arithmetic).  Vec<NR>: the NR vectors of one kind (one workspace per right-hand side).
+template <int NR> struct Vec { double* p[NR]; };
+template <int NR> __device__ __forceinline__ void mv_row(const double* __restrict__ L, const double (*v)[NB], int vs, int r, int q4, double (&out)[NR]) {      // (L v_j)_r, four lanes per row; v_j = v[j * vs]
     const double* Lr = L + r * NB + 16 * q4;
-    double part = 0.0;
+    double l[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) part += Lr[c] * v[16 * q4 + c];
-    part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
-    return part;
+    for (int c = 0; c < 16; ++c) l[c] = Lr[c];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        double part = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) part += l[c] * v[j * vs][16 * q4 + c];
+        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+        out[j] = part;
+    }
 }
-__global__ __launch_bounds__(256) void fwd_group_kernel(const double* __restrict__ band, const double* __restrict__ linv, double* __restrict__ b, double* __restrict__ y,
-                                                        const long long* __restrict__ tri, int k0, int w) {
-    __shared__ double sb[4][NB], sy[4][NB];
+template <int NR>
+__global__ __launch_bounds__(256) void fwd_group_kernel(const double* __restrict__ band, const double* __restrict__ linv, Vec<NR> b, Vec<NR> y, const long long* __restrict__ tri, int k0, int w) {
+    __shared__ double sb[NR * 4][NB], sy[NR * 4][NB];                  // [j][block column of the group]
     const int tid = threadIdx.x, r = tid >> 2, q4 = tid & 3, g = blockIdx.x;
-    for (int q = tid; q < w * NB; q += 256) sb[q >> 6][q & 63] = b[(size_t)k0 * NB + q];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) for (int q = tid; q < w * NB; q += 256) sb[4 * j + (q >> 6)][q & 63] = b.p[j][(size_t)k0 * NB + q];
     __syncthreads();
+    double out[NR];
     for (int c = 0; c < w; ++c) {
-        const double yv = mv_row(linv + (size_t)(k0 + c) * NB2, sb[c], r, q4);
-        if (q4 == 0) sy[c][r] = yv;
+        mv_row<NR>(linv + (size_t)(k0 + c) * NB2, sb + c, 4, r, q4, out);
+        if (q4 == 0) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) sy[4 * j + c][r] = out[j];
+        }
         __syncthreads();
         for (int c2 = c + 1; c2 < w; ++c2) {
-            const double part = mv_row(band + (size_t)(tri[k0 + c2] + (c2 - c)) * NB2, sy[c], r, q4);
-            if (q4 == 0) sb[c2][r] -= part;
+            mv_row<NR>(band + (size_t)(tri[k0 + c2] + (c2 - c)) * NB2, sy + c, 4, r, q4, out);
+            if (q4 == 0) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) sb[4 * j + c2][r] -= out[j];
+            }
         }
         __syncthreads();
     }
-    if (g == 0) { for (int q = tid; q < w * NB; q += 256) y[(size_t)k0 * NB + q] = sy[q >> 6][q & 63]; return; }
-    const int I = k0 + w + (g - 1);
-    double part = 0.0;
-    for (int c = 0; c < w; ++c) part += mv_row(band + (size_t)(tri[I] + (I - (k0 + c))) * NB2, sy[c], r, q4);
-    if (q4 == 0) b[(size_t)I * NB + r] -= part;
-}
-// (L^T v)_c over the 16 rows 16 rq .. 16 rq + 15 of a tile: partial sums of the four row quarters, to be added by the caller
-__device__ __forceinline__ double mvt_part(const double* __restrict__ L, const double* __restrict__ v, int c, int rq) {
-    const double* Lc = L + (16 * rq) * NB + c;
-    double part = 0.0;
+    if (g == 0) {
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) part += Lc[rr * NB] * v[16 * rq + rr];
-    return part;
+        for (int j = 0; j < NR; ++j) for (int q = tid; q < w * NB; q += 256) y.p[j][(size_t)k0 * NB + q] = sy[4 * j + (q >> 6)][q & 63];
+        return;
+    }
+    const int I = k0 + w + (g - 1);
+    double part[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) part[j] = 0.0;
+    for (int c = 0; c < w; ++c) {
+        mv_row<NR>(band + (size_t)(tri[I] + (I - (k0 + c))) * NB2, sy + c, 4, r, q4, out);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) part[j] += out[j];
+    }
+    if (q4 == 0) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) b.p[j][(size_t)I * NB + r] -= part[j];
+    }
 }
-__global__ __launch_bounds__(256) void bwd_group_kernel(const double* __restrict__ band, const double* __restrict__ linv, double* __restrict__ z, double* __restrict__ x,
-                                                        const long long* __restrict__ tri, int k0, int w) {
-    __shared__ double sz[4][NB], sx[4][NB], sp[4][NB];
+// (L^T v_j)_c over the 16 rows 16 rq .. 16 rq + 15 of a tile: partial sums of the four row quarters, to be added by the caller
+template <int NR> __device__ __forceinline__ void mvt_part(const double* __restrict__ L, const double (*v)[NB], int vs, int c, int rq, double (&out)[NR]) {
+    const double* Lc = L + (16 * rq) * NB + c;
+    double l[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) l[rr] = Lc[rr * NB];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        double part = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) part += l[rr] * v[j * vs][16 * rq + rr];
+        out[j] = part;
+    }
+}
+template <int NR>
+__global__ __launch_bounds__(256) void bwd_group_kernel(const double* __restrict__ band, const double* __restrict__ linv, Vec<NR> z, Vec<NR> x, const long long* __restrict__ tri, int k0, int w) {
+    __shared__ double sz[NR * 4][NB], sx[NR * 4][NB], sp[NR * 4][NB];  // sz, sx: [j][block column]; sp: [j][row quarter]
     const int tid = threadIdx.x, c = tid & 63, rq = tid >> 6, g = blockIdx.x;
-    for (int q = tid; q < w * NB; q += 256) sz[q >> 6][q & 63] = z[(size_t)k0 * NB + q];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) for (int q = tid; q < w * NB; q += 256) sz[4 * j + (q >> 6)][q & 63] = z.p[j][(size_t)k0 * NB + q];
     __syncthreads();
+    double out[NR];
     for (int cc = w - 1; cc >= 0; --cc) {
-        sp[rq][c] = mvt_part(linv + (size_t)(k0 + cc) * NB2, sz[cc], c, rq);
+        mvt_part<NR>(linv + (size_t)(k0 + cc) * NB2, sz + cc, 4, c, rq, out);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) sp[4 * j + rq][c] = out[j];
         __syncthreads();
-        if (tid < NB) sx[cc][tid] = sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+        if (tid < NB) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) sx[4 * j + cc][tid] = sp[4 * j][tid] + sp[4 * j + 1][tid] + sp[4 * j + 2][tid] + sp[4 * j + 3][tid];
+        }
         __syncthreads();
         for (int c2 = cc - 1; c2 >= 0; --c2) {
-            sp[rq][c] = mvt_part(band + (size_t)(tri[k0 + cc] + (cc - c2)) * NB2, sx[cc], c, rq);
+            mvt_part<NR>(band + (size_t)(tri[k0 + cc] + (cc - c2)) * NB2, sx + cc, 4, c, rq, out);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) sp[4 * j + rq][c] = out[j];
             __syncthreads();
-            if (tid < NB) sz[c2][tid] -= sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+            if (tid < NB) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) sz[4 * j + c2][tid] -= sp[4 * j][tid] + sp[4 * j + 1][tid] + sp[4 * j + 2][tid] + sp[4 * j + 3][tid];
+            }
             __syncthreads();
         }
     }
-    if (g == 0) { for (int q = tid; q < w * NB; q += 256) x[(size_t)k0 * NB + q] = sx[q >> 6][q & 63]; return; }
+    if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) for (int q = tid; q < w * NB; q += 256) x.p[j][(size_t)k0 * NB + q] = sx[4 * j + (q >> 6)][q & 63];
+        return;
+    }
     const int J = k0 - g;
-    double part = 0.0;
-    for (int cc = 0; cc < w; ++cc) part += mvt_part(band + (size_t)(tri[k0 + cc] + (k0 + cc - J)) * NB2, sx[cc], c, rq);
-    sp[rq][c] = part;
+    double part[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) part[j] = 0.0;
+    for (int cc = 0; cc < w; ++cc) {
+        mvt_part<NR>(band + (size_t)(tri[k0 + cc] + (k0 + cc - J)) * NB2, sx + cc, 4, c, rq, out);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) part[j] += out[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) sp[4 * j + rq][c] = part[j];
     __syncthreads();
-    if (tid < NB) z[(size_t)J * NB + tid] -= sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+    if (tid < NB) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) z.p[j][(size_t)J * NB + tid] -= sp[4 * j][tid] + sp[4 * j + 1][tid] + sp[4 * j + 2][tid] + sp[4 * j + 3][tid];
+    }
 }
 
 __global__ void permute_in_kernel(long long ncp, const int* __restrict__ newi, const double* __restrict__ src, double* __restrict__ dst) {
@@ -589,66 +651,105 @@ __global__ __launch_bounds__(256) void nd_extend_add_batch_kernel(const Front* _
     }
 }
 // front-local right-hand side: the eliminated dofs from the global vector (original numbering), zeros on the padding and the boundary part
-__global__ void nd_gather_rhs_kernel(Front F, const int* __restrict__ elim, const double* __restrict__ b, double* __restrict__ w) {
+template <int NR> __global__ void nd_gather_rhs_kernel(Front F, const int* __restrict__ elim, Vec<NR> b, Vec<NR> w) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 64 * F.nblk_t) return;
-    w[t] = t < 3 * F.ne_cp ? b[3 * (long long)elim[F.elim_off + t / 3] + t % 3] : 0.0;
+    const long long src = t < 3 * F.ne_cp ? 3 * (long long)elim[F.elim_off + t / 3] + t % 3 : -1;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) w.p[j][t] = src >= 0 ? b.p[j][src] : 0.0;
 }
 // the boundary updates a child left behind (fbnd, per front: 3 doubles per boundary control point) pulled into the parent's local vector: the
 // parent adds its children one after the other (fixed order, no two writers: bitwise reproducible, and sibling subtrees may run concurrently)
-__global__ void nd_pull_child_kernel(Front Fc, Front Fp, const int* __restrict__ pmap, const double* __restrict__ fbnd, double* __restrict__ w) {
+template <int NR> __global__ void nd_pull_child_kernel(Front Fc, Front Fp, const int* __restrict__ pmap, Vec<NR> fbnd, Vec<NR> w) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 3 * Fc.nb_cp) w[nd_dofpos(Fp, pmap[Fc.bnd_off + t / 3], t % 3)] += fbnd[3 * Fc.bnd_off + t];
+    if (t >= 3 * Fc.nb_cp) return;
+    const int dst = nd_dofpos(Fp, pmap[Fc.bnd_off + t / 3], t % 3);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) w.p[j][dst] += fbnd.p[j][3 * Fc.bnd_off + t];
 }
 // after the forward substitution of a front: y of the eliminated dofs to the global y, the updated boundary part to the front's own buffer
-__global__ void nd_scatter_fwd_kernel(Front F, const int* __restrict__ elim, const double* __restrict__ wy, const double* __restrict__ wb,
-                                      double* __restrict__ y, double* __restrict__ fbnd) {
+template <int NR> __global__ void nd_scatter_fwd_kernel(Front F, const int* __restrict__ elim, Vec<NR> wy, Vec<NR> wb, Vec<NR> y, Vec<NR> fbnd) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 3 * F.ne_cp) y[3 * (long long)elim[F.elim_off + t / 3] + t % 3] = wy[t];
-    if (t < 3 * F.nb_cp) fbnd[3 * F.bnd_off + t] = wb[F.ne_pad + t];
+    if (t < 3 * F.ne_cp) {
+        const long long dst = 3 * (long long)elim[F.elim_off + t / 3] + t % 3;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) y.p[j][dst] = wy.p[j][t];
+    }
+    if (t < 3 * F.nb_cp) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) fbnd.p[j][3 * F.bnd_off + t] = wb.p[j][F.ne_pad + t];
+    }
 }
 // before the backward substitution of a front: z = D^-1 y on the eliminated dofs, x of the boundary dofs (ancestors: already known)
-__global__ void nd_gather_bwd_kernel(Front F, const int* __restrict__ elim, const int* __restrict__ bnd, const double* __restrict__ y, const double* __restrict__ x,
-                                     const double* __restrict__ dval, double* __restrict__ wz, double* __restrict__ wx) {
+template <int NR> __global__ void nd_gather_bwd_kernel(Front F, const int* __restrict__ elim, const int* __restrict__ bnd, Vec<NR> y, Vec<NR> x,
+                                                       const double* __restrict__ dval, Vec<NR> wz, Vec<NR> wx) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 64 * F.nblk_t) return;
-    if (t < F.ne_pad) { wz[t] = t < 3 * F.ne_cp ? y[3 * (long long)elim[F.elim_off + t / 3] + t % 3] / dval[F.kbase * NB + t] : 0.0; wx[t] = 0.0; }
-    else { const int q = t - F.ne_pad; wx[t] = q < 3 * F.nb_cp ? x[3 * (long long)bnd[F.bnd_off + q / 3] + q % 3] : 0.0; wz[t] = 0.0; }
+    if (t < F.ne_pad) {
+        const bool in = t < 3 * F.ne_cp;
+        const long long src = in ? 3 * (long long)elim[F.elim_off + t / 3] + t % 3 : 0;
+        const double d = in ? dval[F.kbase * NB + t] : 1.0;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) { wz.p[j][t] = in ? y.p[j][src] / d : 0.0; wx.p[j][t] = 0.0; }
+    } else {
+        const int q = t - F.ne_pad; const bool in = q < 3 * F.nb_cp;
+        const long long src = in ? 3 * (long long)bnd[F.bnd_off + q / 3] + q % 3 : 0;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) { wx.p[j][t] = in ? x.p[j][src] : 0.0; wz.p[j][t] = 0.0; }
+    }
 }
 // z_J -= sum over the boundary block rows I of L_IJ^T x_I  (workgroup J < nblk_e)
-__global__ __launch_bounds__(256) void nd_bwd_bnd_kernel(const double* __restrict__ band, const long long* __restrict__ tri, int nblk_e, int nblk_t,
-                                                         const double* __restrict__ wx, double* __restrict__ wz) {
-    __shared__ double sx[NB], sp[4][NB];
+template <int NR>
+__global__ __launch_bounds__(256) void nd_bwd_bnd_kernel(const double* __restrict__ band, const long long* __restrict__ tri, int nblk_e, int nblk_t, Vec<NR> wx, Vec<NR> wz) {
+    __shared__ double sx[NR][NB], sp[NR * 4][NB];
     const int tid = threadIdx.x, c = tid & 63, rq = tid >> 6, J = blockIdx.x;
-    double acc = 0.0;
+    double acc[NR], out[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[j] = 0.0;
     for (int I = nblk_e; I < nblk_t; ++I) {
         __syncthreads();
-        if (tid < NB) sx[tid] = wx[(size_t)I * NB + tid];
-        __syncthreads();
-        const double* L = band + (size_t)(tri[I] + (I - J)) * NB2 + (16 * rq) * NB + c;
+        if (tid < NB) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc += L[r * NB] * sx[16 * rq + r];
+            for (int j = 0; j < NR; ++j) sx[j][tid] = wx.p[j][(size_t)I * NB + tid];
+        }
+        __syncthreads();
+        mvt_part<NR>(band + (size_t)(tri[I] + (I - J)) * NB2, sx, 1, c, rq, out);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[j] += out[j];
     }
-    sp[rq][c] = acc;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) sp[4 * j + rq][c] = acc[j];
     __syncthreads();
-    if (tid < NB) wz[(size_t)J * NB + tid] -= sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+    if (tid < NB) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) wz.p[j][(size_t)J * NB + tid] -= sp[4 * j][tid] + sp[4 * j + 1][tid] + sp[4 * j + 2][tid] + sp[4 * j + 3][tid];
+    }
 }
 // ---- whole-front substitutions for the small fronts (most block columns of a model sit in fronts of a few dozen blocks: one launch per block column
-//      makes a solve launch bound).  One workgroup per front, the front-local vector in LDS, the tiles streamed once; all fronts of one tree height in
-//      one launch (they are independent), heights in ascending (forward) / descending (backward) order on one stream.
+//      makes a solve launch bound).  One workgroup per front, the front-local vectors (NR right-hand sides) in LDS, the tiles streamed once; all fronts of one
+//      tree height in one launch (they are independent), heights in ascending (forward) / descending (backward) order on one stream.
+template <int NR>
 __global__ __launch_bounds__(256) void nd_fwd_front_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const int* __restrict__ kid_off, const int* __restrict__ kid,
                                                            const long long* __restrict__ tri, const double* __restrict__ arena, const double* __restrict__ linv, const int* __restrict__ elim,
-                                                           const int* __restrict__ pmap, const double* __restrict__ gb, double* __restrict__ gy, double* __restrict__ fbnd) {
-    extern __shared__ double sw[];                                  // [64 nblk_t] front-local right-hand side, then sy [64]
+                                                           const int* __restrict__ pmap, Vec<NR> gb, Vec<NR> gy, Vec<NR> fbnd) {
+    extern __shared__ double sw[];                                  // [NR][64 nblk_t] front-local right-hand sides, then sy [NR][64]
     const int t = list[blockIdx.x], tid = threadIdx.x;
     const Front F = fronts[t];
     const int nloc = 64 * F.nblk_t;
-    double* sy = sw + nloc;
-    for (int q = tid; q < nloc; q += 256) sw[q] = q < 3 * F.ne_cp ? gb[3 * (long long)elim[F.elim_off + q / 3] + q % 3] : 0.0;
+    double* sy = sw + NR * nloc;
+    for (int q = tid; q < nloc; q += 256) {
+        const long long src = q < 3 * F.ne_cp ? 3 * (long long)elim[F.elim_off + q / 3] + q % 3 : -1;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) sw[j * nloc + q] = src >= 0 ? gb.p[j][src] : 0.0;
+    }
     __syncthreads();
     for (int ci = kid_off[t]; ci < kid_off[t + 1]; ++ci) {           // children one after the other: fixed order
         const Front Fc = fronts[kid[ci]];
-        for (int q = tid; q < 3 * Fc.nb_cp; q += 256) sw[nd_dofpos(F, pmap[Fc.bnd_off + q / 3], q % 3)] += fbnd[3 * Fc.bnd_off + q];
+        for (int q = tid; q < 3 * Fc.nb_cp; q += 256) {
+            const int dst = nd_dofpos(F, pmap[Fc.bnd_off + q / 3], q % 3);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) sw[j * nloc + dst] += fbnd.p[j][3 * Fc.bnd_off + q];
+        }
         __syncthreads();
     }
     const double* band = arena + (size_t)F.tile_off * NB2;
@@ -656,72 +757,132 @@ __global__ __launch_bounds__(256) void nd_fwd_front_kernel(const Front* __restri
     for (int k = 0; k < F.nblk_e; ++k) {
         {
             const double* L = linv + (size_t)(F.kbase + k) * NB2 + r * NB + 16 * q4;
-            double part = 0.0;
+            double l[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) part += L[c] * sw[64 * k + 16 * q4 + c];
-            part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
-            if (q4 == 0) sy[r] = part;
+            for (int c = 0; c < 16; ++c) l[c] = L[c];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                double part = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) part += l[c] * sw[j * nloc + 64 * k + 16 * q4 + c];
+                part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+                if (q4 == 0) sy[64 * j + r] = part;
+            }
         }
         __syncthreads();
         for (int I = k + 1; I < F.nblk_t; ++I) {
             const double* L = band + (size_t)(tri[I] + (I - k)) * NB2 + r * NB + 16 * q4;
-            double part = 0.0;
+            double l[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) part += L[c] * sy[16 * q4 + c];
-            part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
-            if (q4 == 0) sw[64 * I + r] -= part;
+            for (int c = 0; c < 16; ++c) l[c] = L[c];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                double part = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) part += l[c] * sy[64 * j + 16 * q4 + c];
+                part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+                if (q4 == 0) sw[j * nloc + 64 * I + r] -= part;
+            }
         }
-        if (tid < NB) { const int q = 64 * k + tid; if (q < 3 * F.ne_cp) gy[3 * (long long)elim[F.elim_off + q / 3] + q % 3] = sy[tid]; }
+        if (tid < NB) {
+            const int q = 64 * k + tid;
+            if (q < 3 * F.ne_cp) {
+                const long long dst = 3 * (long long)elim[F.elim_off + q / 3] + q % 3;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) gy.p[j][dst] = sy[64 * j + tid];
+            }
+        }
         __syncthreads();
     }
-    for (int q = tid; q < 3 * F.nb_cp; q += 256) fbnd[3 * F.bnd_off + q] = sw[F.ne_pad + q];
+    for (int q = tid; q < 3 * F.nb_cp; q += 256) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) fbnd.p[j][3 * F.bnd_off + q] = sw[j * nloc + F.ne_pad + q];
+    }
 }
+template <int NR>
 __global__ __launch_bounds__(256) void nd_bwd_front_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ tri, const double* __restrict__ arena,
                                                            const double* __restrict__ linv, const double* __restrict__ dval, const int* __restrict__ elim, const int* __restrict__ bnd,
-                                                           const double* __restrict__ gy, double* __restrict__ gx) {
-    extern __shared__ double sw[];                                  // [64 nblk_t]: z on the eliminated blocks (becomes x), x on the boundary blocks; then sp [4][64]
+                                                           Vec<NR> gy, Vec<NR> gx) {
+    extern __shared__ double sw[];                                  // [NR][64 nblk_t]: z on the eliminated blocks (becomes x), x on the boundary blocks; then sp [NR][4][64]
     const int t = list[blockIdx.x], tid = threadIdx.x;
     const Front F = fronts[t];
     const int nloc = 64 * F.nblk_t;
-    double (*sp)[NB] = reinterpret_cast<double (*)[NB]>(sw + nloc);
+    double (*sp)[NB] = reinterpret_cast<double (*)[NB]>(sw + NR * nloc);
     for (int q = tid; q < nloc; q += 256) {
-        double v = 0.0;
-        if (q < F.ne_pad) { if (q < 3 * F.ne_cp) v = gy[3 * (long long)elim[F.elim_off + q / 3] + q % 3] / dval[F.kbase * NB + q]; }
-        else { const int qb = q - F.ne_pad; if (qb < 3 * F.nb_cp) v = gx[3 * (long long)bnd[F.bnd_off + qb / 3] + qb % 3]; }
-        sw[q] = v;
+        if (q < F.ne_pad) {
+            const bool in = q < 3 * F.ne_cp;
+            const long long src = in ? 3 * (long long)elim[F.elim_off + q / 3] + q % 3 : 0;
+            const double d = in ? dval[F.kbase * NB + q] : 1.0;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) sw[j * nloc + q] = in ? gy.p[j][src] / d : 0.0;
+        } else {
+            const int qb = q - F.ne_pad; const bool in = qb < 3 * F.nb_cp;
+            const long long src = in ? 3 * (long long)bnd[F.bnd_off + qb / 3] + qb % 3 : 0;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) sw[j * nloc + q] = in ? gx.p[j][src] : 0.0;
+        }
     }
     __syncthreads();
     const double* band = arena + (size_t)F.tile_off * NB2;
     const int c = tid & 63, rq = tid >> 6;
     // z_J -= sum over the rows I below (boundary rows, then the eliminated rows already solved) of L_IJ^T x_I, J descending; then x_J = L_JJ^-T z_J
     for (int J = F.nblk_e - 1; J >= 0; --J) {
-        double acc = 0.0;
+        double acc[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[j] = 0.0;
         for (int I = J + 1; I < F.nblk_t; ++I) {
             const double* L = band + (size_t)(tri[I] + (I - J)) * NB2 + (16 * rq) * NB + c;
+            double l[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc += L[r * NB] * sw[64 * I + 16 * rq + r];
+            for (int r = 0; r < 16; ++r) l[r] = L[r * NB];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j] += l[r] * sw[j * nloc + 64 * I + 16 * rq + r];
+            }
         }
-        sp[rq][c] = acc;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) sp[4 * j + rq][c] = acc[j];
         __syncthreads();
-        if (tid < NB) sw[64 * J + tid] -= sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+        if (tid < NB) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) sw[j * nloc + 64 * J + tid] -= sp[4 * j][tid] + sp[4 * j + 1][tid] + sp[4 * j + 2][tid] + sp[4 * j + 3][tid];
+        }
         __syncthreads();
         {
             const double* L = linv + (size_t)(F.kbase + J) * NB2 + (16 * rq) * NB + c;
-            double part = 0.0;
+            double l[16], part[NR];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part += L[r * NB] * sw[64 * J + 16 * rq + r];
+            for (int r = 0; r < 16; ++r) l[r] = L[r * NB];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                part[j] = 0.0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[j] += l[r] * sw[j * nloc + 64 * J + 16 * rq + r];
+            }
             __syncthreads();
-            sp[rq][c] = part;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) sp[4 * j + rq][c] = part[j];
         }
         __syncthreads();
-        if (tid < NB) sw[64 * J + tid] = sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+        if (tid < NB) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) sw[j * nloc + 64 * J + tid] = sp[4 * j][tid] + sp[4 * j + 1][tid] + sp[4 * j + 2][tid] + sp[4 * j + 3][tid];
+        }
         __syncthreads();
     }
-    for (int q = tid; q < 3 * F.ne_cp; q += 256) gx[3 * (long long)elim[F.elim_off + q / 3] + q % 3] = sw[q];
+    for (int q = tid; q < 3 * F.ne_cp; q += 256) {
+        const long long dst = 3 * (long long)elim[F.elim_off + q / 3] + q % 3;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) gx.p[j][dst] = sw[j * nloc + q];
+    }
 }
-__global__ void nd_scatter_bwd_kernel(Front F, const int* __restrict__ elim, const double* __restrict__ wx, double* __restrict__ x, int add) {
+template <int NR> __global__ void nd_scatter_bwd_kernel(Front F, const int* __restrict__ elim, Vec<NR> wx, Vec<NR> x) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 3 * F.ne_cp) { double* dst = x + 3 * (long long)elim[F.elim_off + t / 3] + t % 3; *dst = add ? *dst + wx[t] : wx[t]; }
+    if (t >= 3 * F.ne_cp) return;
+    const long long dst = 3 * (long long)elim[F.elim_off + t / 3] + t % 3;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) x.p[j][dst] = wx.p[j][t];
 }
 
 }  // namespace
@@ -763,7 +924,8 @@ struct gfs_handle {
     // substitution workspaces: [0] aliases the handle's own buffers and stream; [1 ..] are created by the first multi-right-hand-side solve, one stream each, so
     // that the sweeps of several right-hand sides (latency-bound chains of small launches) run next to each other (gfs_solve_multi)
     struct SolveWs { hipStream_t stream = nullptr; double *gb = nullptr, *gy = nullptr, *gx = nullptr, *fbnd = nullptr, *sb = nullptr, *sy = nullptr, *sz = nullptr, *sx = nullptr,
-                     *vr = nullptr, *vsol = nullptr, *vrhs = nullptr, *part = nullptr; hipGraphExec_t g_solve = nullptr; };
+                     *vr = nullptr, *vsol = nullptr, *vrhs = nullptr, *part = nullptr; hipGraphExec_t g_solve[3] = {nullptr, nullptr, nullptr}; };
+    static constexpr int RHS_BLOCK = 3;      // right-hand sides per pass over the factors (the front-local vectors of the small fronts sit in LDS: 3 x 48 KB)
     static constexpr int MAX_RHS = 8;
     std::vector<SolveWs> ws; long long ws_front_len = 0, ws_bnd_len = 0;
     template <class Tp> Tp* dalloc(size_t cnt) {
@@ -816,35 +978,39 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
             hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, h->s_wbuf[si], wstride, h->d_tri, k0, w, nrow);
     }
 }
-static void nd_forward_front(gfs_handle* h, int t, const gfs_handle::SolveWs& W) {
+// the NR vectors of one kind out of NR workspaces (one workspace per right-hand side)
+#define GF_VEC(member) ([&] { Vec<NR> v_; for (int j_ = 0; j_ < NR; ++j_) v_.p[j_] = W[j_]->member; return v_; }())
+template <int NR> static void nd_forward_front(gfs_handle* h, int t, const gfs_handle::SolveWs* const (&W)[NR]) {
     const Front& F = h->fronts[t];
-    hipStream_t st = W.stream;
+    hipStream_t st = W[0]->stream;
     const double* band = h->band + (size_t)F.tile_off * NB2;
     const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
-    hipLaunchKernelGGL(nd_gather_rhs_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, W.gb, W.sb);
+    const Vec<NR> gb = GF_VEC(gb), gy = GF_VEC(gy), fbnd = GF_VEC(fbnd), sb = GF_VEC(sb), sy = GF_VEC(sy);
+    hipLaunchKernelGGL(nd_gather_rhs_kernel<NR>, dim3(gl), dim3(256), 0, st, F, h->d_elim, gb, sb);
     for (int c : h->kids[t]) {
         const Front& Fc = h->fronts[c];
-        if (Fc.nb_cp > 0) hipLaunchKernelGGL(nd_pull_child_kernel, dim3((unsigned)((3 * Fc.nb_cp + 255) / 256)), dim3(256), 0, st, Fc, F, h->d_pmap, W.fbnd, W.sb);
+        if (Fc.nb_cp > 0) hipLaunchKernelGGL(nd_pull_child_kernel<NR>, dim3((unsigned)((3 * Fc.nb_cp + 255) / 256)), dim3(256), 0, st, Fc, F, h->d_pmap, fbnd, sb);
     }
     for (int k0 = 0; k0 < F.nblk_e; k0 += 4) {
         const int w = std::min(4, F.nblk_e - k0);
-        hipLaunchKernelGGL(fwd_group_kernel, dim3(1 + F.nblk_t - (k0 + w)), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, W.sb, W.sy, h->d_tri, k0, w);
+        hipLaunchKernelGGL(fwd_group_kernel<NR>, dim3(1 + F.nblk_t - (k0 + w)), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, sb, sy, h->d_tri, k0, w);
     }
-    hipLaunchKernelGGL(nd_scatter_fwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, W.sy, W.sb, W.gy, W.fbnd);
+    hipLaunchKernelGGL(nd_scatter_fwd_kernel<NR>, dim3(gl), dim3(256), 0, st, F, h->d_elim, sy, sb, gy, fbnd);
 }
-static void nd_backward_front(gfs_handle* h, int t, const gfs_handle::SolveWs& W) {
+template <int NR> static void nd_backward_front(gfs_handle* h, int t, const gfs_handle::SolveWs* const (&W)[NR]) {
     const Front& F = h->fronts[t];
-    hipStream_t st = W.stream;
+    hipStream_t st = W[0]->stream;
     const double* band = h->band + (size_t)F.tile_off * NB2;
     const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
-    hipLaunchKernelGGL(nd_gather_bwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->d_bnd, W.gy, W.gx, h->dval, W.sz, W.sx);
+    const Vec<NR> gy = GF_VEC(gy), gx = GF_VEC(gx), sz = GF_VEC(sz), sx = GF_VEC(sx);
+    hipLaunchKernelGGL(nd_gather_bwd_kernel<NR>, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->d_bnd, gy, gx, h->dval, sz, sx);
     if (F.nblk_t > F.nblk_e && F.nblk_e > 0)
-        hipLaunchKernelGGL(nd_bwd_bnd_kernel, dim3(F.nblk_e), dim3(256), 0, st, band, h->d_tri, F.nblk_e, F.nblk_t, W.sx, W.sz);
+        hipLaunchKernelGGL(nd_bwd_bnd_kernel<NR>, dim3(F.nblk_e), dim3(256), 0, st, band, h->d_tri, F.nblk_e, F.nblk_t, sx, sz);
     for (int k0 = ((F.nblk_e - 1) / 4) * 4; k0 >= 0; k0 -= 4) {
         const int w = std::min(4, F.nblk_e - k0);
-        hipLaunchKernelGGL(bwd_group_kernel, dim3(1 + k0), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, W.sz, W.sx, h->d_tri, k0, w);
+        hipLaunchKernelGGL(bwd_group_kernel<NR>, dim3(1 + k0), dim3(256), 0, st, band, h->linv + (size_t)F.kbase * NB2, sz, sx, h->d_tri, k0, w);
     }
-    hipLaunchKernelGGL(nd_scatter_bwd_kernel, dim3(gl), dim3(256), 0, st, F, h->d_elim, W.sx, W.gx, 0);
+    hipLaunchKernelGGL(nd_scatter_bwd_kernel<NR>, dim3(gl), dim3(256), 0, st, F, h->d_elim, sx, gx);
 }
 // bottom-up sweep: the independent subtrees on their streams (forked behind the main stream's earlier work), then the top fronts on the main stream
 template <class Fn> static void nd_sweep_up(gfs_handle* h, Fn&& fn) {
@@ -930,26 +1096,49 @@ template <class Body> static void nd_run_captured(gfs_handle* h, hipGraphExec_t*
     }
     HIPCHK(hipGraphLaunch(*exec, cs));
 }
-// multifrontal substitutions; vectors in the original numbering
-static void substitute_nd(gfs_handle* h, gfs_handle::SolveWs& W, const double* rhs, double* x, int add) {
-    HIPCHK(hipMemcpyAsync(W.gb, rhs, h->n * sizeof(double), hipMemcpyDeviceToDevice, W.stream));
-    nd_run_captured(h, &W.g_solve, [&] {
+// multifrontal substitutions of NR right-hand sides in one pass over the factors; vectors in the original numbering.  Workspace W[j] holds right-hand side j's vectors;
+// everything runs on W[0]'s stream; the captured graph (the sweeps are ~1e4 launches of fixed structure) belongs to W[0] and is keyed by NR -- the caller always
+// groups the same workspaces (solve_dev_impl: right-hand sides 3 c .. 3 c + NR - 1), so the pointers baked into the graph stay valid.
+// rhs[j] == nullptr: the right-hand side of workspace j is not refreshed and x[j] not written (a right-hand side of the group that has already converged rides along:
+// the sweeps are bound by the factor bytes, an idle slot costs nothing, and the group's graph stays the same).
+template <int NR> static void substitute_nd(gfs_handle* h, gfs_handle::SolveWs* const (&Wm)[NR], const double* const (&rhs)[NR], double* const (&x)[NR], int add) {
+    const gfs_handle::SolveWs* W[NR];
+    for (int j = 0; j < NR; ++j) W[j] = Wm[j];
+    hipStream_t st = W[0]->stream;
+    for (int j = 0; j < NR; ++j) if (rhs[j]) HIPCHK(hipMemcpyAsync(W[j]->gb, rhs[j], h->n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    const gfs_handle::SolveWs* const (&Wc)[NR] = W;
+    if (NR > 1) {                                                                 // NR front-local vectors of up to FUSE_MAX_BLK blocks: more than the 64 KB a launch gets by default
+        static bool raised = false;
+        if (!raised) {
+            const int lim = 160 * 1024;
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_fwd_front_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_bwd_front_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            raised = true;
+        }
+    }
+    nd_run_captured(h, &Wm[0]->g_solve[NR - 1], [&] {
+        const Vec<NR> gb = GF_VEC(gb), gy = GF_VEC(gy), gx = GF_VEC(gx), fbnd = GF_VEC(fbnd);
         for (const auto& L : h->levels) {                                         // forward: heights ascending
             if (L.n_small > 0)
-                hipLaunchKernelGGL(nd_fwd_front_kernel, dim3(L.n_small), dim3(256), (size_t)(64 * L.max_blk + 64) * sizeof(double), W.stream, h->d_fronts, h->d_lvl_list + L.off_small,
-                                   h->d_kid_off, h->d_kid, h->d_tri, h->band, h->linv, h->d_elim, h->d_pmap, W.gb, W.gy, W.fbnd);
-            for (int t : L.big) nd_forward_front(h, t, W);
+                hipLaunchKernelGGL(nd_fwd_front_kernel<NR>, dim3(L.n_small), dim3(256), (size_t)NR * (64 * L.max_blk + 64) * sizeof(double), st, h->d_fronts, h->d_lvl_list + L.off_small,
+                                   h->d_kid_off, h->d_kid, h->d_tri, h->band, h->linv, h->d_elim, h->d_pmap, gb, gy, fbnd);
+            for (int t : L.big) nd_forward_front<NR>(h, t, Wc);
         }
         for (auto it = h->levels.rbegin(); it != h->levels.rend(); ++it) {          // backward: heights descending
             const auto& L = *it;
-            for (auto b_ = L.big.rbegin(); b_ != L.big.rend(); ++b_) nd_backward_front(h, *b_, W);
+            for (auto b_ = L.big.rbegin(); b_ != L.big.rend(); ++b_) nd_backward_front<NR>(h, *b_, Wc);
             if (L.n_small > 0)
-                hipLaunchKernelGGL(nd_bwd_front_kernel, dim3(L.n_small), dim3(256), (size_t)(64 * L.max_blk + 4 * 64) * sizeof(double), W.stream, h->d_fronts, h->d_lvl_list + L.off_small,
-                                   h->d_tri, h->band, h->linv, h->dval, h->d_elim, h->d_bnd, W.gy, W.gx);
+                hipLaunchKernelGGL(nd_bwd_front_kernel<NR>, dim3(L.n_small), dim3(256), (size_t)NR * (64 * L.max_blk + 4 * 64) * sizeof(double), st, h->d_fronts, h->d_lvl_list + L.off_small,
+                                   h->d_tri, h->band, h->linv, h->dval, h->d_elim, h->d_bnd, gy, gx);
         }
-    }, W.stream);
-    hipLaunchKernelGGL(nd_out_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, W.stream, h->n, W.gx, x, add);
+    }, st);
+    for (int j = 0; j < NR; ++j) if (rhs[j]) hipLaunchKernelGGL(nd_out_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, st, h->n, W[j]->gx, x[j], add);
     HIPCHK(hipGetLastError());
+}
+#undef GF_VEC
+static void substitute_nd(gfs_handle* h, gfs_handle::SolveWs& W, const double* rhs, double* x, int add) {
+    gfs_handle::SolveWs* const Wm[1] = {&W}; const double* const r[1] = {rhs}; double* const xx[1] = {x};
+    substitute_nd<1>(h, Wm, r, xx, add);
 }
 
 // workspace k of the handle: 0 aliases the handle's own vectors and stream, the others are allocated on first use (nested-dissection mode only)
@@ -958,7 +1147,7 @@ static gfs_handle::SolveWs& solve_ws(gfs_handle* h, int k) {
     if (h->ws.empty()) {
         gfs_handle::SolveWs W;
         W.stream = h->stream; W.gb = h->gb; W.gy = h->gy; W.gx = h->gx; W.fbnd = h->fbnd; W.sb = h->s_b[NS]; W.sy = h->s_y[NS]; W.sz = h->s_z[NS]; W.sx = h->s_x[NS];
-        W.vr = h->vr; W.vsol = h->vsol; W.vrhs = h->vrhs; W.part = h->part; W.g_solve = nullptr;
+        W.vr = h->vr; W.vsol = h->vsol; W.vrhs = h->vrhs; W.part = h->part;
         h->ws.push_back(W);
     }
     while ((int)h->ws.size() <= k) {
@@ -1181,7 +1370,8 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
             int hmax = 0; for (int64_t t = 0; t < nfronts; ++t) hmax = std::max(hmax, height[t]);
             h->levels.assign(hmax + 1, {});
             std::vector<std::vector<int>> small(hmax + 1);
-            for (int64_t t = 0; t < nfronts; ++t) (h->fronts[t].nblk_t <= gfs_handle::FUSE_MAX_BLK ? small[height[t]] : h->levels[height[t]].big).push_back((int)t);
+            const int fuse_max = getenv("GF_SOLVER_FUSE_MAX_BLK") ? std::max(0, std::min(atoi(getenv("GF_SOLVER_FUSE_MAX_BLK")), (int)gfs_handle::FUSE_MAX_BLK)) : gfs_handle::FUSE_MAX_BLK;      // test switch: small models through the large-front kernels
+            for (int64_t t = 0; t < nfronts; ++t) (h->fronts[t].nblk_t <= fuse_max ? small[height[t]] : h->levels[height[t]].big).push_back((int)t);
             std::vector<int> flat;
             for (int l = 0; l <= hmax; ++l) {
                 auto& L = h->levels[l]; L.off_small = (int)flat.size(); L.n_small = (int)small[l].size(); L.max_blk = 1;
@@ -1253,7 +1443,7 @@ void gfs_destroy(gfs_handle* h) {
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     if (h->g_factor) (void)hipGraphExecDestroy(h->g_factor);
     if (h->g_solve) (void)hipGraphExecDestroy(h->g_solve);
-    for (size_t k = 0; k < h->ws.size(); ++k) { if (h->ws[k].g_solve) (void)hipGraphExecDestroy(h->ws[k].g_solve); if (k > 0 && h->ws[k].stream) (void)hipStreamDestroy(h->ws[k].stream); }
+    for (size_t k = 0; k < h->ws.size(); ++k) { for (auto& g : h->ws[k].g_solve) if (g) (void)hipGraphExecDestroy(g); if (k > 0 && h->ws[k].stream) (void)hipStreamDestroy(h->ws[k].stream); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1331,19 +1521,38 @@ static int solve_dev_impl(gfs_handle* h, const double* d_b, double* d_x, int max
         const bool conc = h->nd && nrhs > 1;                              // skyline mode: one after the other on the handle's stream (small models)
         const unsigned gcp = (unsigned)((h->ncp * 64 + 255) / 256);
         const int nblk = 240;
+        constexpr int RB = gfs_handle::RHS_BLOCK;
         std::vector<double> nb_(nrhs, 0.0), best(nrhs, -1.0), nx(nrhs, 0.0);
         std::vector<char> active(nrhs, 1);
         std::vector<double> host((size_t)nrhs * 256, 0.0), hostx((size_t)nrhs * 256, 0.0);
+        // several right-hand sides: groups of RB share one pass over the factors (substitute_nd<NR>), the groups run next to each other; everything of a group
+        // is issued on the stream of the group's first workspace
         auto W = [&](int r) -> gfs_handle::SolveWs& { return solve_ws(h, conc ? r : 0); };
+        auto S = [&](int r) -> hipStream_t { return conc ? solve_ws(h, (r / RB) * RB).stream : h->stream; };
         if (conc) { HIPCHK(hipStreamSynchronize(h->stream)); for (int r = 1; r < nrhs; ++r) (void)W(r); }
         auto sumsq_async = [&](int r, const double* v) {
             gfs_handle::SolveWs& w = W(r);
-            hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, w.stream, h->n, v, w.part);
-            HIPCHK(hipMemcpyAsync(host.data() + (size_t)r * 256, w.part, nblk * sizeof(double), hipMemcpyDeviceToHost, w.stream));
+            hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, S(r), h->n, v, w.part);
+            HIPCHK(hipMemcpyAsync(host.data() + (size_t)r * 256, w.part, nblk * sizeof(double), hipMemcpyDeviceToHost, S(r)));
         };
         auto sumsq_get = [&](int r) { long double a = 0; for (int k = 0; k < nblk; ++k) a += host[(size_t)r * 256 + k]; return std::sqrt((double)a); };
-        auto sync_all = [&]() { if (conc) { for (int r = 0; r < nrhs; ++r) HIPCHK(hipStreamSynchronize(W(r).stream)); } else HIPCHK(hipStreamSynchronize(h->stream)); };
-        auto subst = [&](int r, const double* rhs, double* x, int add) { if (h->nd) substitute_nd(h, W(r), rhs, x, add); else substitute(h, rhs, x, add); };
+        auto sync_all = [&]() { if (conc) { for (int r = 0; r < nrhs; r += RB) HIPCHK(hipStreamSynchronize(S(r))); } else HIPCHK(hipStreamSynchronize(h->stream)); };
+        // substitutions of the right-hand sides with want[r] != 0: x_r (+)= K^-1 rhs_r, rhs_r = first ? d_b_r : W(r).vr, x_r = W(r).vsol
+        auto subst_all = [&](const std::vector<char>& want, bool first) {
+            if (!h->nd) { substitute(h, first ? d_b : W(0).vr, W(0).vsol, first ? 0 : 1); return; }
+            for (int r0 = 0; r0 < nrhs; r0 += RB) {
+                const int nr = std::min(RB, nrhs - r0);
+                bool any = false; for (int j = 0; j < nr; ++j) any = any || want[r0 + j];
+                if (!any) continue;
+                auto rhs_of = [&](int r) -> const double* { return !want[r] ? nullptr : (first ? d_b + (size_t)r * h->n : W(r).vr); };
+                auto x_of = [&](int r) -> double* { return !want[r] ? nullptr : W(r).vsol; };
+                if (nr == 1) { gfs_handle::SolveWs* const Wm[1] = {&W(r0)}; const double* const rh[1] = {rhs_of(r0)}; double* const xx[1] = {x_of(r0)}; substitute_nd<1>(h, Wm, rh, xx, first ? 0 : 1); }
+                else if (nr == 2) { gfs_handle::SolveWs* const Wm[2] = {&W(r0), &W(r0 + 1)}; const double* const rh[2] = {rhs_of(r0), rhs_of(r0 + 1)}; double* const xx[2] = {x_of(r0), x_of(r0 + 1)};
+                                    substitute_nd<2>(h, Wm, rh, xx, first ? 0 : 1); }
+                else { gfs_handle::SolveWs* const Wm[3] = {&W(r0), &W(r0 + 1), &W(r0 + 2)}; const double* const rh[3] = {rhs_of(r0), rhs_of(r0 + 1), rhs_of(r0 + 2)};
+                       double* const xx[3] = {x_of(r0), x_of(r0 + 1), x_of(r0 + 2)}; substitute_nd<3>(h, Wm, rh, xx, first ? 0 : 1); }
+            }
+        };
         if (!conc && nrhs > 1) {                                          // sequential fall-back: each right-hand side through the single-vector path
             double bw = 0.0;
             for (int r = 0; r < nrhs; ++r) {
@@ -1355,7 +1564,8 @@ static int solve_dev_impl(gfs_handle* h, const double* d_b, double* d_x, int max
             h->backward_error = bw;
             return 0;
         }
-        for (int r = 0; r < nrhs; ++r) { subst(r, d_b + (size_t)r * h->n, W(r).vsol, 0); sumsq_async(r, d_b + (size_t)r * h->n); }
+        subst_all(active, true);
+        for (int r = 0; r < nrhs; ++r) sumsq_async(r, d_b + (size_t)r * h->n);
         sync_all();
         for (int r = 0; r < nrhs; ++r) nb_[r] = sumsq_get(r);
         for (int itr = 0; itr <= max_refine; ++itr) {
@@ -1363,17 +1573,18 @@ static int solve_dev_impl(gfs_handle* h, const double* d_b, double* d_x, int max
             for (int r = 0; r < nrhs; ++r) if (active[r]) {
                 gfs_handle::SolveWs& w = W(r);
                 const double* b = d_b + (size_t)r * h->n;
-                if (transpose) hipLaunchKernelGGL(residual_t_kernel, dim3(gcp), dim3(256), 0, w.stream, h->ncp, h->nb_ptr, h->nb, h->d_rev, h->valK, b, w.vsol, w.vr);
-                else hipLaunchKernelGGL(residual_kernel, dim3(gcp), dim3(256), 0, w.stream, h->ncp, h->nb_ptr, h->nb, h->valK, b, w.vsol, w.vr);
+                if (transpose) hipLaunchKernelGGL(residual_t_kernel, dim3(gcp), dim3(256), 0, S(r), h->ncp, h->nb_ptr, h->nb, h->d_rev, h->valK, b, w.vsol, w.vr);
+                else hipLaunchKernelGGL(residual_kernel, dim3(gcp), dim3(256), 0, S(r), h->ncp, h->nb_ptr, h->nb, h->valK, b, w.vsol, w.vr);
                 sumsq_async(r, w.vr);
                 if (itr == 0) {                                           // |x| of the unrefined solution: is it already at round-off?
-                    hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, w.stream, h->n, w.vsol, w.vrhs);       // vrhs is free until the first correction
-                    HIPCHK(hipMemcpyAsync(hostx.data() + (size_t)r * 256, w.vrhs, nblk * sizeof(double), hipMemcpyDeviceToHost, w.stream));
+                    hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, S(r), h->n, w.vsol, w.vrhs);       // vrhs is free until the first correction
+                    HIPCHK(hipMemcpyAsync(hostx.data() + (size_t)r * 256, w.vrhs, nblk * sizeof(double), hipMemcpyDeviceToHost, S(r)));
                 }
                 any = true;
             }
             if (!any) break;
             sync_all();
+            std::vector<char> correct(nrhs, 0);
             for (int r = 0; r < nrhs; ++r) if (active[r]) {
                 gfs_handle::SolveWs& w = W(r);
                 const double nr = sumsq_get(r);
@@ -1389,18 +1600,19 @@ static int solve_dev_impl(gfs_handle* h, const double* d_b, double* d_x, int max
                 // symmetric mode: refinement only polishes round-off, so a step that does not halve the residual ends it; general mode: the refinement IS the solver
                 // for the skew part and contracts by |S^-1 (K - S)|, which may be anything below one -- it goes on while the residual drops at all
                 if (best[r] >= 0.0 && !(nr < (h->general ? 0.95 : 0.5) * best[r])) {      // the last correction did not help: keep the previous iterate
-                    if (nr >= best[r]) HIPCHK(hipMemcpyAsync(w.vsol, w.vrhs, h->n * sizeof(double), hipMemcpyDeviceToDevice, w.stream)); else best[r] = nr;
+                    if (nr >= best[r]) HIPCHK(hipMemcpyAsync(w.vsol, w.vrhs, h->n * sizeof(double), hipMemcpyDeviceToDevice, S(r))); else best[r] = nr;
                     active[r] = 0;
                     continue;
                 }
                 best[r] = nr;
                 if (itr == max_refine || nr == 0.0) { active[r] = 0; continue; }
-                HIPCHK(hipMemcpyAsync(w.vrhs, w.vsol, h->n * sizeof(double), hipMemcpyDeviceToDevice, w.stream));     // previous iterate
-                subst(r, w.vr, w.vsol, 1);
+                HIPCHK(hipMemcpyAsync(w.vrhs, w.vsol, h->n * sizeof(double), hipMemcpyDeviceToDevice, S(r)));     // previous iterate
+                correct[r] = 1;
             }
+            subst_all(correct, false);                                    // the corrections of a group in one pass over the factors
         }
         for (int r = 0; r < nrhs; ++r) {
-            HIPCHK(hipMemcpyAsync(d_x + (size_t)r * h->n, W(r).vsol, h->n * sizeof(double), hipMemcpyDeviceToDevice, W(r).stream));
+            HIPCHK(hipMemcpyAsync(d_x + (size_t)r * h->n, W(r).vsol, h->n * sizeof(double), hipMemcpyDeviceToDevice, S(r)));
             sumsq_async(r, d_x + (size_t)r * h->n);
         }
         sync_all();

@@ -57,9 +57,10 @@ int gfs_solve_transposed(gfs_handle* h, const double* b, double* x, int max_refi
 int gfs_solve_transposed_dev(gfs_handle* h, const double* d_b, double* d_x, int max_refine, double* rel_residual);
 /* Several right-hand sides in one call (the adjoints of several functionals -- internal energy, volume, aggregated stress -- share K^T): b, x hold nrhs
  * vectors of 3 * ncp doubles one after the other; nrhs <= 8; rel_residual (may be NULL): nrhs values; transpose != 0: K^T x = b (general mode).  In the
- * nested-dissection mode the substitution sweeps of the right-hand sides run next to each other on their own streams (the sweeps are chains of small dependent
- * launches: latency, not bandwidth), the refinement in lockstep rounds; in the skyline mode (small models) they run one after the other.  gfs_info's backward
- * error is then the largest of the nrhs solves. */
+ * nested-dissection mode groups of three right-hand sides share ONE pass over the factors (the sweeps are bound by the factor bytes: every tile entry is loaded once
+ * and multiplied into three sums, each in the order of the single solve, so x is bitwise what gfs_solve returns), the groups run next to each other on their own
+ * streams, the refinement in lockstep rounds; in the skyline mode (small models) the right-hand sides run one after the other.  gfs_info's backward error is then
+ * the largest of the nrhs solves. */
 int gfs_solve_multi(gfs_handle* h, int nrhs, const double* b, double* x, int max_refine, double* rel_residual, int transpose);
 int gfs_solve_multi_dev(gfs_handle* h, int nrhs, const double* d_b, double* d_x, int max_refine, double* rel_residual, int transpose);
 /* info[0] = half bandwidth (dofs), [1] = block columns, [2] = band tiles per block row, [3] = device bytes,

@@ -460,8 +460,9 @@ def test_device_solver_general_mode_in_both_factorisations():
 
 def test_device_solver_several_right_hand_sides_in_one_call():
     """gfs_solve_multi (round-3 verdict, next 5): the adjoints of several functionals share K^T -- three right-hand sides in one call equal the three single solves
-    bit for bit in both factorisation modes (the same kernels on per-right-hand-side workspaces; nested dissection: on their own streams), through
-    NonMatchingOpt.solve_K with a (k, ndof) array, and more right-hand sides than workspaces (10 > 8) in two rounds."""
+    bit for bit in both factorisation modes (nested dissection: groups of three right-hand sides share one pass over the factors, every tile entry multiplied into
+    three sums in the order of the single solve; the groups on their own streams), through NonMatchingOpt.solve_K with a (k, ndof) array, and more right-hand sides
+    than workspaces (10 > 8) in two rounds."""
     from goldfish_amd import _solver
     from goldfish_amd.nonmatching_opt import NonMatchingOpt
     nm = NonMatchingOpt.from_spec(G.tbeam_4patch())
@@ -471,8 +472,14 @@ def test_device_solver_several_right_hand_sides_in_one_call():
     B = np.random.default_rng(9).standard_normal((10, nm.vec_iga_dof))
     w = np.concatenate([sp_.cp_hom_flat()[:, 3] for sp_ in nm.splines])
     X = np.stack([nm.cp_iga[f] / w for f in range(3)], 1)
-    for method, kw in (("skyline", {}), ("nd", dict(leaf=96))):
-        S = _solver.DeviceSolver(nm.dev, coords=X, method=method, **kw)
+    # "nd-large": the same fronts through the kernels of the LARGE fronts (per block-column group; GF_SOLVER_FUSE_MAX_BLK: test switch of the library)
+    for method, kw in (("skyline", {}), ("nd", dict(leaf=96)), ("nd-large", dict(leaf=96))):
+        if method == "nd-large":
+            os.environ["GF_SOLVER_FUSE_MAX_BLK"] = "2"
+        try:
+            S = _solver.DeviceSolver(nm.dev, coords=X, method=method.split("-")[0], **kw)
+        finally:
+            os.environ.pop("GF_SOLVER_FUSE_MAX_BLK", None)
         single = np.stack([S.solve(b) for b in B[:3]])
         multi = S.solve_multi(B[:3])
         assert np.array_equal(single, multi), method

@@ -36,6 +36,13 @@ for name, spec in cases:
     t = time.perf_counter(); X3 = S.solve_multi(B3); t_m = time.perf_counter() - t
     line += "; 3 right-hand sides in one call %.4f s (largest residual %.1e, backward error %.1e; max difference to the single solves %.1e)" % (
         t_m, S.rel_residual, S.backward_error, max(np.abs(X3[0] - lam).max() / np.abs(lam).max(), np.abs(X3[1] - x).max() / np.abs(x).max()))
+    # the sweeps alone (no refinement): one, two, three and six right-hand sides
+    ts = []
+    for k in (1, 2, 3, 6):
+        Bk = np.stack([g, b, B3[2], g[::-1].copy(), b[::-1].copy(), B3[2][::-1].copy()][:k])
+        S.solve_multi(Bk, max_refine=0)
+        t = time.perf_counter(); S.solve_multi(Bk, max_refine=0); ts.append(time.perf_counter() - t)
+    line += "; substitutions only (no refinement, host copies included): 1 / 2 / 3 / 6 right-hand sides %.4f / %.4f / %.4f / %.4f s" % tuple(ts)
     if host and A.ndof < 150000:
         K = D.csr(_lib.MAT_K).tocsc()
         t = time.perf_counter(); lu = spla.splu(K, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True)); t_h = time.perf_counter() - t
