@@ -45,10 +45,51 @@ class Symbolic:
                     largest_front_dofs=int((nb * bt).max()), eliminated_block_columns=int(be.sum()))
 
 
-def nested_dissection(nb_ptr, nb, coords, leaf=192):
+def _best_cuts(ncp, act, seg, rank, start, count, cut0, rows, cols, window):
+    """Per region the cut rank within ``window`` (fraction of the region's size) of the median that gives the SMALLEST separator (the control points of A coupled to
+    B).  A median cut of a patch grid falls on patch interfaces, where the penalty coupling reaches p + 1 control-point rows instead of the p rows inside a patch:
+    a separator there is a third wider, and the work of a front grows with the cube of that.  With M(v) = the largest rank among v's neighbours in its region, the
+    separator of a cut t is {v: rank(v) < t <= M(v)} -- its size for every t of the window comes from one difference array per level.  Only the edges that cross the
+    window matter (two byte-flag gathers over the edge list select them)."""
+    w = np.maximum((window * count).astype(np.int64), 0)
+    tmin, tmax = np.maximum(cut0 - w, 1), np.minimum(cut0 + w, count - 1)
+    tmax = np.maximum(tmax, tmin)
+    flag = np.zeros(ncp, np.int8)
+    flag[act] = (rank < tmax[seg]).astype(np.int8) | ((rank >= tmin[seg]).astype(np.int8) << 1)
+    fr, fc = flag[rows], flag[cols]
+    sel = ((fr & 1) & (fc >> 1) | (fc & 1) & (fr >> 1)).astype(bool)
+    gpos = np.zeros(ncp, np.int64)
+    gpos[act] = np.arange(act.size)                                     # position in the (region, coordinate) order: rank + start of the region
+    p1, p2 = gpos[rows[sel]], gpos[cols[sel]]
+    lo, hi = np.minimum(p1, p2), np.maximum(p1, p2)
+    M = np.arange(act.size, dtype=np.int64)
+    o = np.argsort(lo, kind="stable")
+    lo, hi = lo[o], hi[o]
+    if lo.size:
+        first = np.flatnonzero(np.concatenate([[True], lo[1:] != lo[:-1]]))
+        M[lo[first]] = np.maximum(np.maximum.reduceat(hi, first), lo[first])
+    # separator size of the cut at global position g (A = positions < g): #{v: v < g <= M(v)}
+    diff = np.zeros(act.size + 2, np.int64)
+    has = M > np.arange(act.size)
+    np.add.at(diff, np.flatnonzero(has) + 1, 1)
+    np.add.at(diff, M[has] + 1, -1)
+    size = np.cumsum(diff)[:act.size + 1]
+    cut = cut0.copy()
+    for r in range(count.size):                                        # regions of one level: at most a few thousand
+        a, b = start[r] + tmin[r], start[r] + tmax[r]
+        if b <= a:
+            continue
+        sz = size[a:b + 1]
+        best = np.flatnonzero(sz == sz.min())
+        cut[r] = tmin[r] + best[np.argmin(np.abs(best + tmin[r] - cut0[r]))]       # ties: the cut nearest to the median
+    return cut
+
+
+def nested_dissection(nb_ptr, nb, coords, leaf=192, cut_window=0.04):
     """Recursive coordinate bisection of the control-point graph (nb_ptr, nb: neighbour lists incl. the control point itself) with
     vertex separators; ``leaf``: regions of at most that many control points are not split further.  Level-synchronous: every pass
-    splits all regions of the current level with array operations over the edge list."""
+    splits all regions of the current level with array operations over the edge list.  ``cut_window``: the cut of a region is the one with the
+    smallest separator among the ranks within that fraction of the region's size around the median (0: the median itself)."""
     ncp = nb_ptr.size - 1
     X = np.asarray(coords, float).reshape(ncp, -1)
     rows = np.repeat(np.arange(ncp, dtype=np.int32), np.diff(nb_ptr))      # 32-bit indices: the passes below are gathers over the edge list (66 M edges at C4)
@@ -84,7 +125,10 @@ def nested_dissection(nb_ptr, nb, coords, leaf=192):
         o2 = np.lexsort((val, seg))
         act, seg = act[o2], seg[o2]
         rank = np.arange(act.size) - start[seg]
-        side = (rank >= (count[seg] + 1) // 2)                         # False: first half (A), True: second half (B)
+        cut = (count + 1) // 2                                         # per region: ranks below the cut form A, the others B
+        if cut_window > 0.0:
+            cut = _best_cuts(ncp, act, seg, rank, start, count, cut, rows, cols, cut_window)
+        side = (rank >= cut[seg])                                      # False: first part (A), True: second part (B)
         side_of = np.zeros(ncp, np.int8)
         side_of[act] = side.astype(np.int8) + 1                        # 1: A, 2: B, 0: not in a region that is being split
         # separator: control points of A coupled to a control point of B of the same region.  The edge list only holds edges whose ends are both

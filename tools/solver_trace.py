@@ -1,0 +1,34 @@
+"""Diagnostic: reads a rocprofv3 --kernel-trace CSV of tools/solver_bench.py (GF_SOLVER_GRAPH=0 GF_SOLVER_C4=1) and prints, for the LAST re-factorisation in the
+trace, the wall time, the union of kernel-busy time, the time during which only a given kernel kind runs, and the time by number of kernels in flight."""
+import csv, sys, collections
+rows = []
+for r in csv.DictReader(open(sys.argv[1])):
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]))
+rows.sort()
+# factorisations start with nd_scatter_kernel; take the last one and everything up to the first substitution kernel behind it
+starts = [i for i, r in enumerate(rows) if r[2].startswith("nd_scatter_kernel")]
+i0 = starts[-1]
+i1 = next((i for i in range(i0, len(rows)) if rows[i][2].startswith(("nd_fwd_front", "nd_gather_rhs", "residual"))), len(rows))
+F = rows[i0:i1]
+t0, t1 = F[0][0], max(r[1] for r in F)
+print("factorisation: %d launches, wall %.1f ms" % (len(F), (t1 - t0) / 1e6))
+ev = []
+for s, e, n in F:
+    ev.append((s, 1, n)); ev.append((e, -1, n))
+ev.sort()
+live = collections.Counter(); last = t0; by_n = collections.Counter(); only = collections.Counter(); idle = 0
+for t, d, n in ev:
+    dt = t - last
+    k = sum(live.values())
+    if k == 0: idle += dt
+    else:
+        by_n[min(k, 8)] += dt
+        kinds = [x for x, c in live.items() if c > 0]
+        if len(kinds) == 1: only[kinds[0]] += dt
+    live[n] += d; last = t
+print("idle (no kernel running) %.1f ms" % (idle / 1e6))
+print("time by kernels in flight:", {k: round(v / 1e6, 1) for k, v in sorted(by_n.items())})
+print("time with only one KIND of kernel running (ms):", {k: round(v / 1e6, 1) for k, v in only.most_common(8)})
+tot = collections.Counter(); cnt = collections.Counter()
+for s, e, n in F: tot[n] += e - s; cnt[n] += 1
+print("sum of durations (ms):", {k: (round(v / 1e6, 1), cnt[k]) for k, v in tot.most_common(10)})
