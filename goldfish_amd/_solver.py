@@ -119,7 +119,7 @@ class DeviceSolver:
     ``method``: "skyline" (block skyline after RCM: small and medium models), "nd" (nested-dissection multifrontal: goldfish_amd/_nd.py +
     gfs_create_nd; needs the control points' coordinates), "auto": nd above ND_MIN_CP control points."""
 
-    def __init__(self, dev_model, max_refine=None, coords=None, method="auto", leaf=256, general=False):
+    def __init__(self, dev_model, max_refine=None, coords=None, method="auto", leaf=128, general=False):
         from . import _lib
         self.general = bool(general)
         self.D, self.max_refine = dev_model, (40 if general else 3) if max_refine is None else max_refine
@@ -139,6 +139,7 @@ class DeviceSolver:
             from . import _nd
             if coords is None:
                 raise ValueError("DeviceSolver(method='nd') needs the control points' coordinates")
+            leaf = int(os.environ.get("GF_SOLVER_LEAF", leaf))            # measurement switch (tools/solver_bench.py)
             self.sym = sym = _nd.nested_dissection(self.nb_ptr, self.nb, coords, leaf=leaf)
             keep = [np.ascontiguousarray(a, np.int64) for a in (sym.elim, sym.elim_off, sym.bnd, sym.bnd_off, sym.parent, sym.order, sym.front_of, parent_positions(sym))]
             rc = lib().gfs_create_nd(int(dev_model.device), ncp, self.nb_ptr.ctypes.data_as(C.POINTER(C.c_int64)), self.nb.ctypes.data_as(C.POINTER(C.c_int32)),

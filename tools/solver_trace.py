@@ -3,7 +3,8 @@ trace, the wall time, the union of kernel-busy time, the time during which only 
 import csv, sys, collections
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]))
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0],
+                 int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1) // max(1, int(r["Workgroup_Size_X"]))))
 rows.sort()
 # factorisations start with nd_scatter_kernel; take the last one and everything up to the first substitution kernel behind it
 starts = [i for i, r in enumerate(rows) if r[2].startswith("nd_scatter_kernel")]
@@ -13,7 +14,7 @@ F = rows[i0:i1]
 t0, t1 = F[0][0], max(r[1] for r in F)
 print("factorisation: %d launches, wall %.1f ms" % (len(F), (t1 - t0) / 1e6))
 ev = []
-for s, e, n in F:
+for s, e, n, _ in F:
     ev.append((s, 1, n)); ev.append((e, -1, n))
 ev.sort()
 live = collections.Counter(); last = t0; by_n = collections.Counter(); only = collections.Counter(); idle = 0
@@ -30,5 +31,12 @@ print("idle (no kernel running) %.1f ms" % (idle / 1e6))
 print("time by kernels in flight:", {k: round(v / 1e6, 1) for k, v in sorted(by_n.items())})
 print("time with only one KIND of kernel running (ms):", {k: round(v / 1e6, 1) for k, v in only.most_common(8)})
 tot = collections.Counter(); cnt = collections.Counter()
-for s, e, n in F: tot[n] += e - s; cnt[n] += 1
+for s, e, n, _ in F: tot[n] += e - s; cnt[n] += 1
 print("sum of durations (ms):", {k: (round(v / 1e6, 1), cnt[k]) for k, v in tot.most_common(10)})
+# update_wide_kernel: one workgroup per 64 x 64 output tile, w = 4 panel columns per launch (the last group of a front may have fewer): 4 x 2 x 64^3 flop per workgroup
+bins = collections.defaultdict(lambda: [0, 0.0, 0.0])
+for s_, e, n, wg in F:
+    if n.startswith("update_wide_kernel"):
+        b = 1 << max(0, (wg - 1).bit_length())
+        bins[b][0] += 1; bins[b][1] += (e - s_) / 1e6; bins[b][2] += wg * 4 * 2 * 64.0 ** 3
+print("update_wide_kernel by launch size (workgroups <= bin: launches, ms, Tflop/s if w = 4):", {b: (v[0], round(v[1], 1), round(v[2] / v[1] / 1e9, 1)) for b, v in sorted(bins.items())})
