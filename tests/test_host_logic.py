@@ -109,6 +109,36 @@ def test_solver_library_exports_every_declared_symbol():
         assert rc != 0 and b"no HIP device" in L.gfs_last_error()
 
 
+def test_nested_dissection_cuts_avoid_the_wide_coupling_of_patch_interfaces():
+    """goldfish_amd/_nd.py: _best_cuts -- a median cut of a patch grid falls on the patch interfaces, where the coupling reaches one control-point row further than
+    inside a patch; the cut with the smallest separator within the window lies inside the patches: fewer flops, smaller fronts, still a valid elimination order
+    (every control point once; the boundaries checked by the test below on random points), and both sides of every split stay non-empty."""
+    from goldfish_amd import _nd
+    n, pw = 96, 24
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    idx = ii * n + jj
+    rows, cols = [], []
+    for di in range(-4, 5):
+        for dj in range(-4, 5):
+            i2, j2 = ii + di, jj + dj
+            ok = (i2 >= 0) & (i2 < n) & (j2 >= 0) & (j2 < n)
+            ok &= ((abs(di) <= 3) | ((ii // pw) != (i2 // pw))) & ((abs(dj) <= 3) | ((jj // pw) != (j2 // pw)))     # reach 3 inside a patch, 4 across an interface
+            rows.append(idx[ok]); cols.append((i2 * n + j2)[ok])
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    o = np.lexsort((cols, rows)); rows, cols = rows[o], cols[o]
+    nb_ptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n * n))]).astype(np.int64)
+    X = np.stack([ii.ravel(), jj.ravel()], 1).astype(float)
+    st = {}
+    for cw in (0.0, 0.04):
+        sym = _nd.nested_dissection(nb_ptr, cols.astype(np.int32), X, leaf=64, cut_window=cw)
+        assert sorted(sym.elim) == list(range(n * n)) and np.array_equal(sym.order[sym.elim], np.arange(n * n))
+        st[cw] = sym.stats()
+        if cw > 0:                       # the root separator: three grid lines inside a patch instead of four on an interface
+            root = int(np.flatnonzero(sym.parent < 0)[0])
+            assert sym.elim_off[root + 1] - sym.elim_off[root] == 3 * n
+    assert st[0.04]["flops"] < 0.9 * st[0.0]["flops"] and st[0.04]["largest_front_dofs"] <= st[0.0]["largest_front_dofs"]
+
+
 def test_nested_dissection_symbolic_phase_and_reference_multifrontal_solve():
     """goldfish_amd/_nd.py: the fronts of the nested-dissection order (what gfs_create_nd factors on the device) -- every control point
     eliminated once, boundaries lie outside the subtree and inside the parent's front, sibling subtrees are not coupled -- and the dense
