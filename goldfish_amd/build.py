@@ -1,6 +1,7 @@
 """Builds libgoldfish_hip.so (gfx950) in-tree with hipcc.  The .so is git-ignored but
 travels to the GPU box with the gpurun snapshot."""
 import os
+import sys
 import shutil
 import subprocess
 
@@ -22,7 +23,12 @@ def needs_build(lib=LIB, sources=SOURCES):
     return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in sources)
 
 
+REPORT = {}      # library -> "compiled" | "reused" of the last build() call (the driver's log shows whether the box compiled anything)
+
+
 def build(force=False, verbose=False):
+    REPORT.clear()
+    REPORT[os.path.basename(LIB)] = "compiled" if (force or needs_build()) else "reused"
     if force or needs_build():
         cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
                os.path.join(CSRC, "gf_lib.hip"), "-o", LIB]
@@ -34,6 +40,7 @@ def build(force=False, verbose=False):
         subprocess.check_call([_hipcc(), "-O2", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-x", "hip",
                                os.path.join(CSRC, "point_host_test.cpp"), "-o", host])
     solver = os.path.join(HERE, "libgoldfish_solver.so")      # block-banded L D L^T factorisation + solves on the device, include/goldfish_solver.h
+    REPORT[os.path.basename(solver)] = "compiled" if (force or needs_build(solver, ["gf_solver.hip", os.path.join("..", "..", "include", "goldfish_solver.h")])) else "reused"
     if force or needs_build(solver, ["gf_solver.hip", os.path.join("..", "..", "include", "goldfish_solver.h")]):
         # -amdgpu-mfma-vgpr-form: v_mfma_f64_16x16x4 with its accumulators in arch VGPRs issues every 64 cycles, with AGPR accumulators (the
         # compiler's default for these kernels) every 131 (tools/ubench_acc.hip, profiles/r03_ubench_fp64_mfma.txt); the tile kernels have registers to spare
@@ -43,6 +50,8 @@ def build(force=False, verbose=False):
         extra = os.environ.get("GF_SOLVER_CXXFLAGS", "").split()
         subprocess.check_call([_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form"] + extra +
                               [os.path.join(CSRC, "gf_solver.hip"), "-o", solver])
+    if verbose or os.environ.get("GF_BUILD_REPORT", "1") == "1":
+        print("goldfish_amd.build: " + ", ".join("%s %s" % kv for kv in REPORT.items()) + " (hipcc --offload-arch=gfx950; a library is reused when no source is newer than it)", file=sys.stderr, flush=True)
     return LIB
 
 
