@@ -30,7 +30,7 @@ def build(force=False, verbose=False):
     REPORT.clear()
     REPORT[os.path.basename(LIB)] = "compiled" if (force or needs_build()) else "reused"
     if force or needs_build():
-        cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
+        cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"] + os.environ.get("GF_LIB_CXXFLAGS", "").split() + [
                os.path.join(CSRC, "gf_lib.hip"), "-o", LIB]
         if verbose:
             print(" ".join(cmd))

@@ -591,6 +591,7 @@ __global__ void nd_scatter_kernel(long long ncp, const long long* __restrict__ n
     for (long long k = lane; k < deg; k += 64) {
         const int b = nb[ptr + k];
         const int t = order[b] < oa ? front_of[b] : front_of[a];
+        if (t < 0) continue;                        // partial handle (gfs_create_nd_partial): the entry belongs to a front of another handle
         const Front F = fronts[t];
         const int pa = nd_pos(F, t, (int)a, front_of, order, bnd), pb = nd_pos(F, t, b, front_of, order, bnd);
         if (pa < pb) continue;
@@ -605,6 +606,14 @@ __global__ void nd_scatter_kernel(long long ncp, const long long* __restrict__ n
     }
 }
 // identity on the padding of the eliminated part of every front (one workgroup per front)
+// the Schur complement of a front after its partial factorisation (the boundary x boundary tiles of its arena) packed as the lower triangle of (nblk_t - nblk_e)
+// block rows -- the layout of a stub front's arena: tile (I', J') at tri[I'] + (I' - J'); workgroup = one tile
+__global__ __launch_bounds__(256) void nd_export_schur_kernel(Front F, const long long* __restrict__ tri, const double* __restrict__ arena, double* __restrict__ dst) {
+    int gi, gj; tri_index((int)blockIdx.x, gi, gj);
+    const double* src = arena + (size_t)(F.tile_off + tri[gi + F.nblk_e] + (gi - gj)) * NB2;
+    double* out = dst + (size_t)(tri[gi] + (gi - gj)) * NB2;
+    for (int q = threadIdx.x; q < NB2; q += 256) out[q] = src[q];
+}
 __global__ void nd_pad_kernel(const Front* __restrict__ fronts, const long long* __restrict__ tri, double* __restrict__ arena) {
     const Front F = fronts[blockIdx.x];
     for (int r = 3 * F.ne_cp + threadIdx.x; r < F.ne_pad; r += blockDim.x) arena[nd_entry(F, tri, r, r)] = 1.0;
@@ -770,6 +779,7 @@ __global__ __launch_bounds__(256) void nd_fwd_front_kernel(const Front* __restri
     extern __shared__ double sw[];                                  // [NR][64 nblk_t] front-local right-hand sides, then sy [NR][64]
     const int t = list[blockIdx.x], tid = threadIdx.x;
     const Front F = fronts[t];
+    if (F.ne_cp == 0) return;                                       // stub front of a partial handle: its boundary contribution comes from outside (gfs_set_fbnd)
     const int nloc = 64 * F.nblk_t;
     double* sy = sw + NR * nloc;
     for (int q = tid; q < nloc; q += 256) {
@@ -841,6 +851,7 @@ __global__ __launch_bounds__(256) void nd_bwd_front_kernel(const Front* __restri
     extern __shared__ double sw[];                                  // [NR][64 nblk_t]: z on the eliminated blocks (becomes x), x on the boundary blocks; then sp [NR][4][64]
     const int t = list[blockIdx.x], tid = threadIdx.x;
     const Front F = fronts[t];
+    if (F.ne_cp == 0) return;                                       // stub front: nothing to solve for
     const int nloc = 64 * F.nblk_t;
     double (*sp)[NB] = reinterpret_cast<double (*)[NB]>(sw + NR * nloc);
     for (int q = tid; q < nloc; q += 256) {
@@ -947,6 +958,9 @@ struct gfs_handle {
     std::vector<int> top;                    // the remaining fronts, in post-order
     // the sweeps are ~1e5 small launches with a fixed structure: captured once into HIP graphs (all streams), replayed per factorisation / substitution
     hipGraphExec_t g_factor = nullptr, g_solve = nullptr; bool use_graph = true;
+    // partial handle (gfs_create_nd_partial: a sub-forest of the elimination tree -- a rank's own subtrees, or the top of the tree above stub fronts that stand for the
+    // subtrees of other ranks): Schur complements of stub fronts come from device buffers (stub_src, copied in by gfs_refactor), the sweeps run in halves
+    bool partial = false; std::vector<const double*> stub_src; hipGraphExec_t g_fwd = nullptr, g_bwd = nullptr;
     // substitutions: fronts by tree height; the small ones of a height in one launch (nd_fwd_front_kernel / nd_bwd_front_kernel), the large ones per block column
     static constexpr int FUSE_MAX_BLK = 96;  // 64 x 96 doubles = 48 KB of LDS for the front-local vector
     struct Level { int off_small, n_small, max_blk; std::vector<int> big; };
@@ -1017,6 +1031,7 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
 #define GF_VEC(member) ([&] { Vec<NR> v_; for (int j_ = 0; j_ < NR; ++j_) v_.p[j_] = W[j_]->member; return v_; }())
 template <int NR> static void nd_forward_front(gfs_handle* h, int t, const gfs_handle::SolveWs* const (&W)[NR]) {
     const Front& F = h->fronts[t];
+    if (F.ne_cp == 0) return;                                       // stub front of a partial handle
     hipStream_t st = W[0]->stream;
     const double* band = h->band + (size_t)F.tile_off * NB2;
     const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
@@ -1034,6 +1049,7 @@ template <int NR> static void nd_forward_front(gfs_handle* h, int t, const gfs_h
 }
 template <int NR> static void nd_backward_front(gfs_handle* h, int t, const gfs_handle::SolveWs* const (&W)[NR]) {
     const Front& F = h->fronts[t];
+    if (F.ne_cp == 0) return;
     hipStream_t st = W[0]->stream;
     const double* band = h->band + (size_t)F.tile_off * NB2;
     const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
@@ -1131,6 +1147,26 @@ template <class Body> static void nd_run_captured(gfs_handle* h, hipGraphExec_t*
     }
     HIPCHK(hipGraphLaunch(*exec, cs));
 }
+// the two halves of a substitution: forward over the tree heights ascending, backward descending (W: one workspace per right-hand side, st: the stream)
+template <int NR> static void nd_forward_all(gfs_handle* h, const gfs_handle::SolveWs* const (&W)[NR], hipStream_t st) {
+    const Vec<NR> gb = GF_VEC(gb), gy = GF_VEC(gy), fbnd = GF_VEC(fbnd);
+    for (const auto& L : h->levels) {
+        if (L.n_small > 0)
+            hipLaunchKernelGGL(nd_fwd_front_kernel<NR>, dim3(L.n_small), dim3(256), (size_t)NR * (64 * L.max_blk + 64) * sizeof(double), st, h->d_fronts, h->d_lvl_list + L.off_small,
+                               h->d_kid_off, h->d_kid, h->d_tri, h->band, h->linv, h->d_elim, h->d_pmap, gb, gy, fbnd);
+        for (int t : L.big) nd_forward_front<NR>(h, t, W);
+    }
+}
+template <int NR> static void nd_backward_all(gfs_handle* h, const gfs_handle::SolveWs* const (&W)[NR], hipStream_t st) {
+    const Vec<NR> gy = GF_VEC(gy), gx = GF_VEC(gx);
+    for (auto it = h->levels.rbegin(); it != h->levels.rend(); ++it) {
+        const auto& L = *it;
+        for (auto b_ = L.big.rbegin(); b_ != L.big.rend(); ++b_) nd_backward_front<NR>(h, *b_, W);
+        if (L.n_small > 0)
+            hipLaunchKernelGGL(nd_bwd_front_kernel<NR>, dim3(L.n_small), dim3(256), (size_t)NR * (64 * L.max_blk + 4 * 64) * sizeof(double), st, h->d_fronts, h->d_lvl_list + L.off_small,
+                               h->d_tri, h->band, h->linv, h->dval, h->d_elim, h->d_bnd, gy, gx);
+    }
+}
 // multifrontal substitutions of NR right-hand sides in one pass over the factors; vectors in the original numbering.  Workspace W[j] holds right-hand side j's vectors;
 // everything runs on W[0]'s stream; the captured graph (the sweeps are ~1e4 launches of fixed structure) belongs to W[0] and is keyed by NR -- the caller always
 // groups the same workspaces (solve_dev_impl: right-hand sides 3 c .. 3 c + NR - 1), so the pointers baked into the graph stay valid.
@@ -1151,22 +1187,7 @@ template <int NR> static void substitute_nd(gfs_handle* h, gfs_handle::SolveWs* 
             raised = true;
         }
     }
-    nd_run_captured(h, &Wm[0]->g_solve[NR - 1], [&] {
-        const Vec<NR> gb = GF_VEC(gb), gy = GF_VEC(gy), gx = GF_VEC(gx), fbnd = GF_VEC(fbnd);
-        for (const auto& L : h->levels) {                                         // forward: heights ascending
-            if (L.n_small > 0)
-                hipLaunchKernelGGL(nd_fwd_front_kernel<NR>, dim3(L.n_small), dim3(256), (size_t)NR * (64 * L.max_blk + 64) * sizeof(double), st, h->d_fronts, h->d_lvl_list + L.off_small,
-                                   h->d_kid_off, h->d_kid, h->d_tri, h->band, h->linv, h->d_elim, h->d_pmap, gb, gy, fbnd);
-            for (int t : L.big) nd_forward_front<NR>(h, t, Wc);
-        }
-        for (auto it = h->levels.rbegin(); it != h->levels.rend(); ++it) {          // backward: heights descending
-            const auto& L = *it;
-            for (auto b_ = L.big.rbegin(); b_ != L.big.rend(); ++b_) nd_backward_front<NR>(h, *b_, Wc);
-            if (L.n_small > 0)
-                hipLaunchKernelGGL(nd_bwd_front_kernel<NR>, dim3(L.n_small), dim3(256), (size_t)NR * (64 * L.max_blk + 4 * 64) * sizeof(double), st, h->d_fronts, h->d_lvl_list + L.off_small,
-                                   h->d_tri, h->band, h->linv, h->dval, h->d_elim, h->d_bnd, gy, gx);
-        }
-    }, st);
+    nd_run_captured(h, &Wm[0]->g_solve[NR - 1], [&] { nd_forward_all<NR>(h, Wc, st); nd_backward_all<NR>(h, Wc, st); }, st);
     for (int j = 0; j < NR; ++j) if (rhs[j]) hipLaunchKernelGGL(nd_out_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, st, h->n, W[j]->gx, x[j], add);
     HIPCHK(hipGetLastError());
 }
@@ -1290,8 +1311,8 @@ int gfs_create(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb
 //   elim [ncp], elim_off [nfronts + 1]: control points eliminated by every front (post-order); bnd, bnd_off: boundary control points per front (ascending
 //   elimination order); parent [nfronts] (-1: root); order [ncp]: position in the elimination order; front_of [ncp]; pmap [size of bnd]: position of every
 //   boundary control point of a front in its PARENT's numbering (eliminated control points first, then the parent's boundary).
-int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb, const double* d_valK, int64_t nfronts, const int64_t* elim, const int64_t* elim_off,
-                  const int64_t* bnd, const int64_t* bnd_off, const int64_t* parent, const int64_t* order, const int64_t* front_of, const int64_t* pmap, gfs_handle** out) {
+static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb, const double* d_valK, int64_t nfronts, const int64_t* elim, const int64_t* elim_off,
+                          const int64_t* bnd, const int64_t* bnd_off, const int64_t* parent, const int64_t* order, const int64_t* front_of, const int64_t* pmap, bool partial, gfs_handle** out) {
     if (!out || !nb_ptr || !nb || !d_valK || !elim || !elim_off || !bnd_off || !parent || !order || !front_of) return sfail("gfs_create_nd: null argument");
     *out = nullptr;
     if (ncp <= 0 || nfronts <= 0) return sfail("gfs_create_nd: empty model");
@@ -1300,10 +1321,11 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("gfs_create_nd: no HIP device visible (libgoldfish_solver has no CPU fallback)");
         if (device < 0 || device >= ndev) throw std::runtime_error("gfs_create_nd: device index out of range");
-        if (elim_off[nfronts] != ncp) throw std::runtime_error("gfs_create_nd: the fronts do not eliminate every control point exactly once");
+        const int64_t nelim = elim_off[nfronts];
+        if (nelim > ncp || (!partial && nelim != ncp)) throw std::runtime_error("gfs_create_nd: the fronts do not eliminate every control point exactly once");
         {
             std::vector<char> seen(ncp, 0);
-            for (int64_t q = 0; q < ncp; ++q) {
+            for (int64_t q = 0; q < nelim; ++q) {
                 const int64_t a = elim[q];
                 if (a < 0 || a >= ncp || seen[a] || order[a] != q) throw std::runtime_error("gfs_create_nd: elim / order are not a consistent permutation");
                 seen[a] = 1;
@@ -1320,12 +1342,12 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
             Front& F = h->fronts[t];
             F.elim_off = elim_off[t]; F.bnd_off = bnd_off[t];
             F.ne_cp = (int)(elim_off[t + 1] - elim_off[t]); F.nb_cp = (int)(bnd_off[t + 1] - bnd_off[t]);
-            if (F.ne_cp <= 0) throw std::runtime_error("gfs_create_nd: a front eliminates nothing");
+            if (F.ne_cp < 0 || (F.ne_cp == 0 && !partial)) throw std::runtime_error("gfs_create_nd: a front eliminates nothing");
             F.nblk_e = (3 * F.ne_cp + NB - 1) / NB; F.ne_pad = F.nblk_e * NB;
             F.nblk_t = F.nblk_e + (3 * F.nb_cp + NB - 1) / NB;
             F.parent = (int)parent[t]; F.pad0 = F.pad1 = 0;
             if (F.parent >= 0) { if (F.parent <= t || F.parent >= nfronts) throw std::runtime_error("gfs_create_nd: the fronts are not in post-order"); h->kids[F.parent].push_back((int)t); }
-            else if (F.nb_cp != 0) throw std::runtime_error("gfs_create_nd: a root front has a boundary");
+            else if (F.nb_cp != 0 && !partial) throw std::runtime_error("gfs_create_nd: a root front has a boundary");
             F.tile_off = tiles; F.kbase = kb;
             tiles += (long long)F.nblk_t * (F.nblk_t + 1) / 2; kb += F.nblk_e; maxb = std::max(maxb, F.nblk_t);
             for (int k = 0; k < F.nblk_e; ++k) { const double r = F.nblk_t - 1 - k; fl += 2.0 * NB * NB * NB * (r + r * (r + 1) / 2) + 2.0 * NB * NB * NB / 3; }
@@ -1336,7 +1358,9 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
         if (gbs * 1e9 > 0.92 * (double)freeb) throw std::runtime_error("gfs_create_nd: the fronts need " + std::to_string(gbs) + " GB, more than the free device memory");
         std::vector<long long> ptr(nb_ptr, nb_ptr + ncp + 1), tri(maxb + 1), ord(order, order + ncp);
         for (int I = 0; I <= maxb; ++I) tri[I] = (long long)I * (I + 1) / 2;
-        std::vector<int> e32(elim, elim + ncp), fo32(front_of, front_of + ncp), b32, pm32;
+        std::vector<int> e32(elim, elim + nelim), fo32(front_of, front_of + ncp), b32, pm32;
+        if (e32.empty()) e32.push_back(0);
+        h->partial = partial; h->stub_src.assign(nfronts, nullptr);
         const int64_t nbnd = bnd_off[nfronts];
         if (nbnd > 0) { if (!bnd || !pmap) throw std::runtime_error("gfs_create_nd: bnd / pmap missing"); b32.assign(bnd, bnd + nbnd); pm32.assign(pmap, pmap + nbnd); }
         for (int64_t t = 0; t < nfronts; ++t) {               // the map into the parent must be strictly increasing and inside the parent
@@ -1469,6 +1493,15 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
     return 0;
 }
 
+int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb, const double* d_valK, int64_t nfronts, const int64_t* elim, const int64_t* elim_off,
+                  const int64_t* bnd, const int64_t* bnd_off, const int64_t* parent, const int64_t* order, const int64_t* front_of, const int64_t* pmap, gfs_handle** out) {
+    return create_nd_impl(device, ncp, nb_ptr, nb, d_valK, nfronts, elim, elim_off, bnd, bnd_off, parent, order, front_of, pmap, false, out);
+}
+int gfs_create_nd_partial(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb, const double* d_valK, int64_t nfronts, const int64_t* elim, const int64_t* elim_off,
+                          const int64_t* bnd, const int64_t* bnd_off, const int64_t* parent, const int64_t* order, const int64_t* front_of, const int64_t* pmap, gfs_handle** out) {
+    return create_nd_impl(device, ncp, nb_ptr, nb, d_valK, nfronts, elim, elim_off, bnd, bnd_off, parent, order, front_of, pmap, true, out);
+}
+
 void gfs_destroy(gfs_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
@@ -1478,6 +1511,8 @@ void gfs_destroy(gfs_handle* h) {
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     if (h->g_factor) (void)hipGraphExecDestroy(h->g_factor);
     if (h->g_solve) (void)hipGraphExecDestroy(h->g_solve);
+    if (h->g_fwd) (void)hipGraphExecDestroy(h->g_fwd);
+    if (h->g_bwd) (void)hipGraphExecDestroy(h->g_bwd);
     for (size_t k = 0; k < h->ws.size(); ++k) { for (auto& g : h->ws[k].g_solve) if (g) (void)hipGraphExecDestroy(g); if (k > 0 && h->ws[k].stream) (void)hipStreamDestroy(h->ws[k].stream); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1494,6 +1529,10 @@ int gfs_refactor(gfs_handle* h) {
                                h->d_bnd, h->d_tri, h->band);
             const int nf = (int)h->fronts.size();
             hipLaunchKernelGGL(nd_pad_kernel, dim3(nf), dim3(64), 0, h->stream, h->d_fronts, h->d_tri, h->band);
+            if (h->partial) for (int t = 0; t < nf; ++t) if (h->stub_src[t]) {         // a stub front's tiles = the Schur complement another handle exported (one contiguous triangle)
+                const Front& F = h->fronts[t];
+                HIPCHK(hipMemcpyAsync(h->band + (size_t)F.tile_off * NB2, h->stub_src[t], (size_t)F.nblk_t * (F.nblk_t + 1) / 2 * NB2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            }
             if (h->batch_blk > 0) nd_run_captured(h, &h->g_factor, [&] { nd_factor_levels(h); });
             else nd_run_captured(h, &h->g_factor, [&] { nd_sweep_up(h, [](gfs_handle* hh, int t, hipStream_t st, int si) { nd_factor_front(hh, t, st, si); }); });
         } else {
@@ -1692,6 +1731,80 @@ int gfs_solve_transposed(gfs_handle* h, const double* b, double* x, int max_refi
 
 int gfs_solve_multi(gfs_handle* h, int nrhs, const double* b, double* x, int max_refine, double* rel_residual, int transpose) { return solve_host_impl(h, b, x, max_refine, rel_residual, transpose, nrhs); }
 int gfs_solve_multi_dev(gfs_handle* h, int nrhs, const double* d_b, double* d_x, int max_refine, double* rel_residual, int transpose) { return solve_dev_impl(h, d_b, d_x, max_refine, rel_residual, transpose, nrhs); }
+
+// ---- partial handles: the pieces a distributed factorisation is put together from (goldfish_amd/_dsolver.py)
+static int partial_front(gfs_handle* h, int64_t front, const char* who) {
+    if (!h || !h->nd) return sfail(std::string(who) + ": needs a nested-dissection handle");
+    if (front < 0 || front >= (int64_t)h->fronts.size()) return sfail(std::string(who) + ": front index out of range");
+    return 0;
+}
+int64_t gfs_schur_doubles(gfs_handle* h, int64_t front) {
+    if (partial_front(h, front, "gfs_schur_doubles")) return -1;
+    const Front& F = h->fronts[front]; const long long nbb = F.nblk_t - F.nblk_e;
+    return (int64_t)(nbb * (nbb + 1) / 2 * NB2);
+}
+int gfs_export_schur(gfs_handle* h, int64_t front, double* d_buf) {
+    if (partial_front(h, front, "gfs_export_schur")) return 1;
+    if (!h->factored) return sfail("gfs_export_schur: no factorisation (call gfs_refactor)");
+    if (!d_buf) return sfail("gfs_export_schur: null buffer");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        const Front& F = h->fronts[front]; const long long nbb = F.nblk_t - F.nblk_e;
+        if (nbb > 0) hipLaunchKernelGGL(nd_export_schur_kernel, dim3((unsigned)(nbb * (nbb + 1) / 2)), dim3(256), 0, h->stream, F, h->d_tri, h->band, d_buf);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+    } catch (const std::exception& ex) { return sfail(ex.what()); }
+    return 0;
+}
+int gfs_set_schur_source(gfs_handle* h, int64_t front, const double* d_buf) {
+    if (partial_front(h, front, "gfs_set_schur_source")) return 1;
+    if (!h->partial || h->fronts[front].ne_cp != 0) return sfail("gfs_set_schur_source: not a stub front of a partial handle");
+    h->stub_src[front] = d_buf; h->factored = false;
+    return 0;
+}
+int gfs_get_fbnd(gfs_handle* h, int64_t front, double* d_out) {
+    if (partial_front(h, front, "gfs_get_fbnd")) return 1;
+    const Front& F = h->fronts[front];
+    if (F.nb_cp > 0 && hipMemcpy(d_out, h->fbnd + 3 * F.bnd_off, (size_t)3 * F.nb_cp * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) return sfail("gfs_get_fbnd: copy failed");
+    return 0;
+}
+int gfs_set_fbnd(gfs_handle* h, int64_t front, const double* d_in) {
+    if (partial_front(h, front, "gfs_set_fbnd")) return 1;
+    const Front& F = h->fronts[front];
+    if (F.nb_cp > 0 && hipMemcpy(h->fbnd + 3 * F.bnd_off, d_in, (size_t)3 * F.nb_cp * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) return sfail("gfs_set_fbnd: copy failed");
+    return 0;
+}
+double* gfs_x_ptr(gfs_handle* h) { return (h && h->nd) ? h->gx : nullptr; }
+// forward half: y of this handle's eliminated dofs and the boundary contributions of its fronts from the right-hand side d_b (3 * ncp doubles, original numbering);
+// backward half: x of this handle's eliminated dofs into the vector gfs_x_ptr points at, whose entries at the boundary control points of the root fronts (eliminated by
+// another handle) must have been written before.  One right-hand side, the handle's own workspace and stream; both calls return when the device is done.
+int gfs_forward_dev(gfs_handle* h, const double* d_b) {
+    if (!h || !h->nd || !d_b) return sfail("gfs_forward_dev: needs a nested-dissection handle and a right-hand side");
+    if (!h->factored) return sfail("gfs_forward_dev: no factorisation (call gfs_refactor)");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        gfs_handle::SolveWs& W0 = solve_ws(h, 0);
+        const gfs_handle::SolveWs* const W[1] = {&W0};
+        HIPCHK(hipMemcpyAsync(W0.gb, d_b, h->n * sizeof(double), hipMemcpyDeviceToDevice, W0.stream));
+        nd_run_captured(h, &h->g_fwd, [&] { nd_forward_all<1>(h, W, W0.stream); }, W0.stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(W0.stream));
+    } catch (const std::exception& ex) { return sfail(ex.what()); }
+    return 0;
+}
+int gfs_backward_dev(gfs_handle* h) {
+    if (!h || !h->nd) return sfail("gfs_backward_dev: needs a nested-dissection handle");
+    if (!h->factored) return sfail("gfs_backward_dev: no factorisation (call gfs_refactor)");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        gfs_handle::SolveWs& W0 = solve_ws(h, 0);
+        const gfs_handle::SolveWs* const W[1] = {&W0};
+        nd_run_captured(h, &h->g_bwd, [&] { nd_backward_all<1>(h, W, W0.stream); }, W0.stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(W0.stream));
+    } catch (const std::exception& ex) { return sfail(ex.what()); }
+    return 0;
+}
 
 int gfs_info(gfs_handle* h, double info[8]) {
     if (!h || !info) return sfail("gfs_info: null argument");

@@ -533,7 +533,13 @@ class NonMatchingOpt:
                 if getattr(self, "_dsolver", None) is None or self._dsolver.D is not self.dev:
                     w = np.concatenate([sp_.cp_hom_flat()[:, 3] for sp_ in self.splines])
                     # a follower pressure's K is not symmetric: the device solver then factors its symmetric part and refines against K / K^T
-                    self._dsolver = _solver.DeviceSolver(self.dev, coords=np.stack([self.cp_iga[f] / w for f in range(3)], 1), general=not self.symmetric_K)
+                    coords = np.stack([self.cp_iga[f] / w for f in range(3)], 1)
+                    if self._use_distributed_solver():
+                        # sharded problem, stage 2 (goldfish_amd/_dsolver.py): every rank factors the subtrees dealt to it, the top of the elimination tree is replicated
+                        from . import _dsolver
+                        self._dsolver = _dsolver.DistributedSolver(self.dev, self._dist, self._group, coords=coords)
+                    else:
+                        self._dsolver = _solver.DeviceSolver(self.dev, coords=coords, general=not self.symmetric_K)
                     self._dsolver_version = ver
                 elif self._dsolver_version != ver:
                     self._dsolver.refactor()
@@ -564,6 +570,16 @@ class NonMatchingOpt:
             warnings.warn("solve_K: device L D L^T rejected for this tangent (%s); falling back to the host sparse LU" % why, RuntimeWarning)
             self._dsolver_failed_version = ver
         return self._host_solve(rhs, ver, transpose and not self.symmetric_K)
+
+    #: direct solves of a sharded problem: "distributed" (stage 2: subtrees of the elimination tree per rank, replicated top; symmetric K, models large enough
+    #: for the nested-dissection mode), "replicated" (stage 1: every rank factors the gathered K), "auto": distributed when it applies
+    sharded_solver = os.environ.get("GF_SHARDED_SOLVER", "auto")
+
+    def _use_distributed_solver(self):
+        from . import _solver
+        if getattr(self, "_dist", None) is None or self.sharded_solver == "replicated" or not self.symmetric_K:
+            return False
+        return self.sharded_solver == "distributed" or self.vec_iga_dof // 3 >= _solver.ND_MIN_CP
 
     def RIGA(self):
         """Non-matching residual in IGA dofs, Dirichlet rows zeroed (nonmatching_opt.py:941-948)."""

@@ -63,6 +63,27 @@ int gfs_solve_transposed_dev(gfs_handle* h, const double* d_b, double* d_x, int 
  * the largest of the nrhs solves. */
 int gfs_solve_multi(gfs_handle* h, int nrhs, const double* b, double* x, int max_refine, double* rel_residual, int transpose);
 int gfs_solve_multi_dev(gfs_handle* h, int nrhs, const double* d_b, double* d_x, int max_refine, double* rel_residual, int transpose);
+/* ---- Partial handles: the pieces of a factorisation distributed over several GPUs (goldfish_amd/_dsolver.py; one process per GPU, K's values replicated).
+ * gfs_create_nd_partial takes a SUB-FOREST of the elimination tree with the arguments of gfs_create_nd and these differences: elim / elim_off cover only the control
+ * points this handle eliminates; front_of[cp] = -1 for the others; order[cp] = position in elim for the handle's own control points, larger than all of those for
+ * control points eliminated LATER by another handle (the boundaries of this handle's root fronts), smaller than zero for control points eliminated EARLIER by another
+ * handle; a root front may have a boundary (its Schur complement is what gfs_export_schur packs); a front may eliminate nothing -- a STUB that stands for a subtree
+ * factored by another handle: its tiles are that subtree root's Schur complement, copied in by every gfs_refactor from the device buffer registered with
+ * gfs_set_schur_source (gfs_schur_doubles(h, front) doubles: the lower triangle of 64 x 64 tiles, row I at I (I + 1) / 2, tile (I, J) at offset I - J), its boundary
+ * contribution to the forward sweep is what gfs_set_fbnd stored (3 doubles per boundary control point, in the order of the front's boundary list).
+ * The sweeps of a partial handle run in halves: gfs_forward_dev (right-hand side -> y of the handle's dofs, boundary contributions of every front: gfs_get_fbnd of a
+ * root front is what the owner of the tree above needs), gfs_backward_dev (x of the handle's dofs into the vector at gfs_x_ptr, 3 * ncp doubles in the original
+ * numbering, whose entries at the root fronts' boundary control points the caller has written before). */
+int gfs_create_nd_partial(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb, const double* d_valK, int64_t nfronts, const int64_t* elim, const int64_t* elim_off,
+                          const int64_t* bnd, const int64_t* bnd_off, const int64_t* parent, const int64_t* order, const int64_t* front_of, const int64_t* pmap, gfs_handle** out);
+int64_t gfs_schur_doubles(gfs_handle* h, int64_t front);
+int gfs_export_schur(gfs_handle* h, int64_t front, double* d_buf);
+int gfs_set_schur_source(gfs_handle* h, int64_t front, const double* d_buf);
+int gfs_get_fbnd(gfs_handle* h, int64_t front, double* d_out);
+int gfs_set_fbnd(gfs_handle* h, int64_t front, const double* d_in);
+double* gfs_x_ptr(gfs_handle* h);
+int gfs_forward_dev(gfs_handle* h, const double* d_b);
+int gfs_backward_dev(gfs_handle* h);
 /* info[0] = half bandwidth (dofs), [1] = block columns, [2] = band tiles per block row, [3] = device bytes,
  * [4] = flops of one factorisation, [5] = 1 if the last factorisation met a pivot below 1e-14 * max |diag|, else 0,
  * [6] = normwise backward error |b - K x| / (|K|_F |x| + |b|) of the last solve (what a backward-stable solve keeps at round-off

@@ -1486,3 +1486,89 @@ def test_thickness_opt_group_on_a_sharded_problem_over_rccl():
     if n < 2:
         pytest.skip("one GPU visible: RCCL needs at least two")
     _check_sharded_group(_run_group_ranks(min(n, 3), "nccl"))
+
+
+def _dist_solver_worker(rank, world, port, q, backend):
+    import torch
+    import torch.distributed as dist
+    from goldfish_amd.nonmatching_opt import NonMatchingOpt
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = rank if backend == "nccl" else 0
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = G.synthetic_shell(4, 4, nel=10, p=3, jitter=2)
+    nm = NonMatchingOpt.from_spec(spec, comm=dist, device=dev)
+    nm.sharded_solver = "distributed"
+    nm.update_uIGA(G.smooth_displacement(spec, 0.5 * spec.h_th))
+    nm._assemble(3)
+    B = np.random.default_rng(4).standard_normal((2, nm.vec_iga_dof))
+    x0 = nm.solve_K(B[0])
+    ds = nm._dsolver
+    out = dict(x0=x0, rr0=nm.linear_solve_relative_residual, be0=nm.linear_solve_backward_error, method=ds.method, owner=ds.owner.copy(), nroots=len(ds.roots),
+               has_subtrees=ds.A is not None, failed=getattr(nm, "_dsolver_failed_version", None) is not None)
+    # a new tangent: refactor (collective), two right-hand sides in one call, a Newton solve of the sharded problem
+    nm.update_uIGA(G.smooth_displacement(spec, 0.8 * spec.h_th))
+    nm._assemble(3)
+    out["X"] = nm.solve_K(B)
+    out["K"] = nm.dRIGAduIGA()
+    _, u = nm.solve_nonlinear_nonmatching_problem(rtol=1e-8, max_it=30)
+    out["u"], out["newton_rr"] = u, nm.newton_relative_residual
+    res = [None] * world
+    dist.all_gather_object(res, (rank, out["has_subtrees"], out["method"]))
+    out["ranks"] = res
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_factorisation_over_rccl():
+    """The same on one GPU per rank over RCCL (Schur complements and boundary contributions by all_gather_into_tensor, x by all_reduce on device tensors): runs as
+    soon as two GPUs are visible."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one GPU visible: RCCL needs at least two")
+    test_distributed_factorisation_on_a_sharded_problem(min(n, 3), backend="nccl")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_factorisation_on_a_sharded_problem(world, backend="gloo"):
+    """goldfish_amd/_dsolver.py (SURVEY 8(e) + N1, stage 2): the subtrees of the nested-dissection tree are factored by the ranks that own them (partial handles of
+    libgoldfish_solver), their Schur complements all-gathered into stub fronts below the replicated top; forward / backward sweeps in halves with the boundary
+    contributions exchanged.  World 2 and 3 over gloo on the one GPU: the solutions solve K x = b of the unsharded matrix, a refactorisation after a new assembly,
+    several right-hand sides, and the Newton loop of the sharded problem on top of it."""
+    import torch.multiprocessing as mp
+    from goldfish_amd.nonmatching_opt import NonMatchingOpt
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_solver_worker, args=(r, world, port, q, backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    r = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert r["method"] == "nd-distributed" and not r["failed"] and all(m == "nd-distributed" for _, _, m in r["ranks"])
+    assert sum(1 for _, has, _ in r["ranks"] if has) == world                 # every rank factors subtrees of its own
+    assert r["nroots"] >= world and (r["owner"] == -1).sum() >= 1 and set(np.unique(r["owner"])) == set(range(-1, world))
+    # the unsharded problem in this process
+    spec = G.synthetic_shell(4, 4, nel=10, p=3, jitter=2)
+    nm = NonMatchingOpt.from_spec(spec)
+    B = np.random.default_rng(4).standard_normal((2, nm.vec_iga_dof))
+    nm.update_uIGA(G.smooth_displacement(spec, 0.5 * spec.h_th)); nm._assemble(3)
+    K0 = nm.dRIGAduIGA()
+    assert _rel(K0 @ r["x0"], B[0]) < 1e-7 and r["be0"] < 1e-12            # floor of the residual: eps cond(K) for a random right-hand side
+    assert _rel(r["x0"], nm.solve_K(B[0])) < 1e-6
+    nm.update_uIGA(G.smooth_displacement(spec, 0.8 * spec.h_th)); nm._assemble(3)
+    K1 = nm.dRIGAduIGA()
+    assert abs(K1 - r["K"]).max() < 1e-9 * abs(K1).max()
+    for k in range(2):
+        assert _rel(K1 @ r["X"][k], B[k]) < 1e-7
+    _, u = nm.solve_nonlinear_nonmatching_problem(rtol=1e-8, max_it=30)
+    # the Newton loop on top of it: the same path as the unsharded run, down to the same floor (this start is far from equilibrium: 26 iterations)
+    assert r["newton_rr"] < 2.0 * nm.newton_relative_residual + 1e-12 and _rel(r["u"], u) < 1e-6

@@ -183,6 +183,61 @@ def test_nested_dissection_symbolic_phase_and_reference_multifrontal_solve():
     assert np.abs(x - xd).max() < 1e-12 * np.abs(xd).max()
 
 
+def test_distributed_factorisation_tree_split_and_partial_symbolics():
+    """goldfish_amd/_dsolver.py (host side of the distributed factorisation): split_tree deals whole subtrees to the ranks and keeps the top replicated;
+    partial_symbolic gives gfs_create_nd_partial consistent pieces -- own control points numbered by their place in the handle's elimination list, the top's control
+    points behind them for a handle of subtrees, everything else in front (negative); boundary lists ascending in that order; a stub per subtree root below the top
+    with the root's boundary list; the boundary maps into the parents monotone."""
+    from goldfish_amd import _nd, _dsolver
+    rng = np.random.default_rng(5)
+    ncp = 1500
+    pts = rng.uniform(0, 1, (ncp, 3)) * [1.0, 0.8, 0.02]
+    adj = np.abs(pts[:, None, :2] - pts[None, :, :2]).max(-1) < 0.05
+    nb_lists = [np.flatnonzero(adj[a]) for a in range(ncp)]
+    nb_ptr = np.concatenate([[0], np.cumsum([len(x) for x in nb_lists])]).astype(np.int64)
+    sym = _nd.nested_dissection(nb_ptr, np.concatenate(nb_lists).astype(np.int32), pts, leaf=40)
+    for world in (2, 3, 5):
+        owner, roots = _dsolver.split_tree(sym, world)
+        assert set(np.unique(owner)) == set(range(-1, world)) and len(roots) >= world
+        for t in range(sym.nfronts):                                     # a subtree is owned as a whole; the parent of a subtree root is a top front
+            p = sym.parent[t]
+            if owner[t] == -1:
+                assert p < 0 or owner[p] == -1
+            elif t in roots:
+                assert p >= 0 and owner[p] == -1
+            else:
+                assert owner[p] == owner[t]
+        top_f = np.flatnonzero(owner == -1)
+        top_cp = np.concatenate([sym.elim[sym.elim_off[t]:sym.elim_off[t + 1]] for t in top_f])
+        seen = np.zeros(ncp, int)
+        for r in list(range(world)) + [-1]:
+            keep = np.flatnonzero(owner == r)
+            fronts, sub, pmap = _dsolver.partial_symbolic(sym, keep, roots if r < 0 else (), None if r < 0 else top_cp)
+            seen[sub.elim] += 1
+            assert np.array_equal(sub.order[sub.elim], np.arange(sub.elim.size)) and np.all(sub.front_of[sub.elim] >= 0)
+            foreign = np.ones(ncp, bool); foreign[sub.elim] = False
+            assert np.all(sub.front_of[foreign] == -1)
+            if r >= 0:
+                assert np.all(sub.order[top_cp] >= sub.elim.size) and np.all(sub.order[foreign & ~np.isin(np.arange(ncp), top_cp)] < 0)
+            else:
+                assert np.all(sub.order[foreign] < 0)
+            for i, t in enumerate(fronts):
+                bd = sub.bnd[sub.bnd_off[i]:sub.bnd_off[i + 1]]
+                assert np.array_equal(bd, sym.bnd[sym.bnd_off[t]:sym.bnd_off[t + 1]]) and np.all(np.diff(sub.order[bd]) > 0)
+                ne = sub.elim_off[i + 1] - sub.elim_off[i]
+                if r < 0 and t in roots:
+                    assert ne == 0 and sub.parent[i] >= 0                                   # stub below a top front
+                else:
+                    assert ne == sym.elim_off[t + 1] - sym.elim_off[t] and np.all(sub.order[bd] >= sub.elim_off[i + 1])
+                if sub.parent[i] >= 0:
+                    pm = pmap[sub.bnd_off[i]:sub.bnd_off[i + 1]]
+                    pi = sub.parent[i]
+                    assert np.all(np.diff(pm) > 0) and (pm.size == 0 or pm[-1] < (sub.elim_off[pi + 1] - sub.elim_off[pi]) + (sub.bnd_off[pi + 1] - sub.bnd_off[pi]))
+                elif r >= 0:
+                    assert t in roots
+        assert np.all(seen == 1)                                          # every control point is eliminated by exactly one handle
+
+
 def _lib_has_no_gpu():
     from goldfish_amd import _lib
     return _lib.lib().gf_device_count() == 0

@@ -1,0 +1,35 @@
+"""Measurement + model (not product): the distributed factorisation (goldfish_amd/_dsolver.py) of C4's K for 2, 4, 8 ranks from the symbolic phase alone -- work of
+the replicated top, largest per-rank share of the subtrees, bytes of the Schur-complement all-gather and of the boundary-contribution all-gather -- priced with the
+rates measured on one MI355X (profiles/r04_device_solver_bench.txt: 37 TFLOP/s for a factorisation; all-gather over xGMI taken as 300 GB/s per GPU)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from goldfish_amd import _lib, _nd, _solver, _dsolver, geometry as G
+from goldfish_amd.model import arrays_from_spec
+n = int(os.environ.get("GF_ND_PATCHES", "16"))
+spec = G.synthetic_shell(n, n, nel=48, p=3, jitter=2)
+A = arrays_from_spec(spec)
+D = _lib.DeviceModel(A)
+rowptr, col = D.pattern(_lib.MAT_K)
+nb_ptr, nb = _solver.control_point_graph(rowptr, col)
+del rowptr, col
+X = np.stack([A.cp_hom[f] / A.weights for f in range(3)], 1)
+sym = _nd.nested_dissection(nb_ptr, nb, X, leaf=128)
+ne, nbd, be, bb = sym.front_dofs()
+bt = be + bb
+flop = 2.0 * 64 ** 3 * _dsolver.front_work(sym)
+tiles = bt * (bt + 1) // 2
+RATE, XGMI = 37e12, 300e9
+print("C4: %d fronts, %.2f Tflop, %.1f GB of tiles; one GPU: %.0f ms per factorisation at %.0f TFLOP/s" % (sym.nfronts, flop.sum() / 1e12, tiles.sum() * 32768 / 1e9, flop.sum() / RATE * 1e3, RATE / 1e12))
+for world in (2, 4, 8):
+    owner, roots = _dsolver.split_tree(sym, world)
+    top = owner == -1
+    per = np.array([flop[owner == r].sum() for r in range(world)])
+    mem = np.array([tiles[owner == r].sum() for r in range(world)]) * 32768.0
+    schur = np.array([bb[t] * (bb[t] + 1) // 2 for t in roots]) * 32768.0
+    fb = np.array([nbd[t] for t in roots]) * 8.0
+    t_sub, t_top, t_ag = per.max() / RATE, flop[top].sum() / RATE, schur.sum() * (world - 1) / world / XGMI
+    print("%d ranks: %d subtrees below %d top fronts; subtrees %.2f Tflop (largest share %.2f, imbalance %.2f), top %.2f Tflop (replicated); Schur all-gather %.2f GB, boundary "
+          "contributions %.1f MB per solve; factor memory per rank %.1f GB (own) + %.1f GB (top) + %.1f GB (stubs); modelled factorisation %.0f + %.0f + %.0f = %.0f ms"
+          % (world, len(roots), int(top.sum()), per.sum() / 1e12, per.max() / 1e12, per.max() / per.mean(), flop[top].sum() / 1e12, schur.sum() / 1e9, fb.sum() / 1e6,
+             mem.max() / 1e9, tiles[top].sum() * 32768 / 1e9, schur.sum() / 1e9, t_sub * 1e3, t_ag * 1e3, t_top * 1e3, (t_sub + t_ag + t_top) * 1e3), flush=True)
