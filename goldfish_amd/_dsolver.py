@@ -255,10 +255,13 @@ class DistributedSolver:
     # -- numeric phase
     def refactor(self):
         """Collective: own subtrees, all-gather of their Schur complements, the replicated top."""
+        import time
         L, torch = self.L, self.torch
         self.D.sync()
+        t0 = time.perf_counter()
         if hasattr(self.D, "refresh_k_values"):
             self.D.refresh_k_values()
+        t1 = time.perf_counter()
         if self.A is not None:
             self._check(L.gfs_refactor(self.A.h))
             off = self.rank * self.schur_pad
@@ -266,9 +269,14 @@ class DistributedSolver:
                 self._check(L.gfs_export_schur(self.A.h, self.A.local[t], C.c_void_p(self.schur_all.data_ptr() + 8 * off)))
                 off += self.schur_len[t]
         torch.cuda.synchronize()
+        t2 = time.perf_counter()
         self._allgather(self.schur_all, self.schur_pad)
         torch.cuda.synchronize()
+        t3 = time.perf_counter()
         self._check(L.gfs_refactor(self.B.h))
+        t4 = time.perf_counter()
+        #: seconds of the last refactor() on this rank: K value gather, own subtrees (+ packing), Schur all-gather, replicated top
+        self.timings = {"k_values": t1 - t0, "own_subtrees": t2 - t1, "schur_allgather": t3 - t2, "top": t4 - t3}
         v = (C.c_double * 8)()
         small = False
         for p in (self.A, self.B):
