@@ -21,8 +21,9 @@
 // Measured and dropped earlier: a second batch of data in flight (513 / 444 vs 487 / 426 us on the 8 x 8-patch slice before / after the bank fix); one
 // launch per class of neighbour counts (<= 64, <= 88, rest: more waves per CU for the narrow rows, but three tails: 463 vs 426 us).
 // Round 4: the one-matrix instances (Newton pass: K only; linearize after a solve: dR/dc only) allocate only their own accumulators -- half the LDS, twice
-// the waves per CU: 1.26 -> 0.84 ms at C4 for the K-only instance.  The full pass as TWO such launches (K rows, then dR/dc rows) is slower than the fused
-// instance (1.27 + 1.03 = 2.29 vs 1.80 ms at C4: the visit and vertex loads are issued twice, and those loads are what the kernel waits for).
+// the waves per CU -- without effect on their time (K-only instance at C4: 1.26 -> 1.24 ms: the kernel is not short of waves).  The full pass as TWO such
+// launches (K rows, then dR/dc rows) is slower than the fused instance (1.27 + 1.03 = 2.29 vs 1.80 ms at C4: the visit and vertex loads are issued twice,
+// and those loads are what the kernel waits for).
 // The kernel WRITES the rows (the gather adds the shell part), like pen_owner_kernel<.., ADD = false>.
 // Reference path: nonmatching_opt.py:745-752, 789-801, 861-887 (penalty residual and its blocks of dR/du, dR/dCP).
 #pragma once
