@@ -11,6 +11,12 @@ operations of goldfish_amd instead of an OpenMDAO group:
 
 With openmdao installed the same problem is the reference's group wired from goldfish_amd.om_comps (HthMapComp,
 DispStatesComp, IntEnergyComp, VolumeComp) unchanged.  Usage: python examples/plate_thickness_opt.py
+
+Several GPUs (the reference runs its demos under mpirun with ``comm`` passed to NonMatchingOpt):
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 examples/plate_thickness_opt.py
+every rank runs this script on replicated design and state vectors; the patches, the assembly, the products and the functionals are sharded over the ranks
+(one GPU each over RCCL; with fewer GPUs than ranks -- a rehearsal -- all ranks share GPU 0 over gloo), the direct solves run on the device of every rank
+(GF_SHARDED_SOLVER=distributed: the distributed factorisation also for a model this small).
 """
 import os
 import sys
@@ -91,13 +97,13 @@ def problem_from_reference_files():
     return nm, 1.0e-2
 
 
-def run(p=3, maxiter=60, lower=4e-3, upper=5e-2, verbose=True, from_files=False):
+def run(p=3, maxiter=60, lower=4e-3, upper=5e-2, verbose=True, from_files=False, comm=None, device=0):
     if from_files:
         nm, h_init = problem_from_reference_files()
         spec = type("S", (), {"h_th": h_init})()
     else:
         spec = G.plate_6patch(p)
-        nm = NonMatchingOptFFD.from_spec(spec)
+        nm = NonMatchingOptFFD.from_spec(spec, comm=comm, device=device)
     prob = ReducedThicknessProblem(nm)
     h0 = np.full(nm.num_splines, spec.h_th)
     v0, w0 = prob.volume(h0), prob.objective(h0)
@@ -115,5 +121,27 @@ def run(p=3, maxiter=60, lower=4e-3, upper=5e-2, verbose=True, from_files=False)
     return dict(h=res.x, w0=w0, w1=w1, v0=v0, v1=prob.volume(res.x), problem=prob, result=res)
 
 
+def main():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        run()
+        return
+    import torch
+    import torch.distributed as dist
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if torch.cuda.device_count() >= world:                                # one GPU per rank: RCCL
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:                                                                 # rehearsal: every rank on GPU 0, exchanges through the host
+        local = 0
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        run(comm=dist, device=local, verbose=rank == 0)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 if __name__ == "__main__":
-    run()
+    main()

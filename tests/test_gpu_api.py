@@ -1572,3 +1572,22 @@ def test_distributed_factorisation_on_a_sharded_problem(world, backend="gloo"):
     _, u = nm.solve_nonlinear_nonmatching_problem(rtol=1e-8, max_it=30)
     # the Newton loop on top of it: the same path as the unsharded run, down to the same floor (this start is far from equilibrium: 26 iterations)
     assert r["newton_rr"] < 2.0 * nm.newton_relative_residual + 1e-12 and _rel(r["u"], u) < 1e-6
+
+
+def test_plate_thickness_example_under_torchrun_on_two_ranks():
+    """examples/plate_thickness_opt.py launched as the reference launches its demos under MPI: ``python -m torch.distributed.run --nproc-per-node 2`` (one-GPU box: both ranks
+    on GPU 0 over gloo), the distributed factorisation forced for this small model -- the optimum equals the one-process run's."""
+    import importlib.util, subprocess, sys, re
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, GF_SHARDED_SOLVER="distributed", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(here, "examples", "plate_thickness_opt.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    h = np.array([float(x) for x in re.findall(r"Thickness for patch\s+\d+:\s+([0-9.eE+-]+)", out.stdout)])
+    assert h.size == 6, out.stdout[-2000:]
+    spec_ = importlib.util.spec_from_file_location("plate_thickness_opt", os.path.join(here, "examples", "plate_thickness_opt.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    ref = mod.run(verbose=False)
+    assert np.abs(h - ref["h"]).max() < 2e-6, (h, ref["h"])
