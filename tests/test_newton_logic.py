@@ -285,3 +285,50 @@ def test_non_monotone_shell_history_is_not_cut_short():
         warnings.simplefilter("error")
         nm.solve_nonlinear_nonmatching_problem(rtol=1e-8, max_it=30)
     assert nm.newton_converged and nm.newton_iterations == 5 and all(h[2] == 1.0 for h in nm.newton_history)
+
+
+class ChordNM(FakeNM):
+    """FakeNM whose solve_K keeps 'factors': the Jacobian of the state it last factored (what the device solver does when solve_K is asked to reuse them)."""
+    newton_reuse_factors = True
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.J, self.n_factor, self.n_stale = None, 0, 0
+
+    def solve_K(self, rhs, transpose=False, refine=None, stale_factors=False):
+        if stale_factors and self.J is not None:
+            self.n_stale += 1
+        else:
+            self.J = self.jac(self.u_iga)
+            self.n_factor += 1
+        return np.linalg.solve(self.J, rhs)
+
+
+def test_chord_steps_reuse_the_factors_while_they_contract():
+    """Newton loop on large models: after a step that contracted the residual five-fold the next correction reuses the factorisation (chord step); the converged state is
+    the full Newton iteration's, with fewer factorisations; a chord step that does not halve the residual is thrown away and repeated with fresh factors."""
+    k, f = 1.0e4, 1.0
+    fun, jac = (lambda u: u + k * u ** 3 - f), (lambda u: np.diag(1.0 + 3.0 * k * u ** 2))
+    full = FakeNM(fun, jac, 1)
+    _, u_full = full.solve_nonlinear_nonmatching_problem(rtol=1e-12, max_it=40)
+    nm = ChordNM(fun, jac, 1)
+    _, u = nm.solve_nonlinear_nonmatching_problem(rtol=1e-12, max_it=40)
+    assert nm.newton_converged and abs(fun(u)[0]) < 1e-9 and abs(u[0] - u_full[0]) < 1e-9 * abs(u_full[0])      # both end at the same root (by residual or by a negligible correction)
+    assert nm.newton_chord_steps >= 1 and nm.n_stale >= nm.newton_chord_steps
+    assert nm.n_factor < full.newton_iterations                      # fewer factorisations than plain Newton needs
+    # a tangent that changes fast: chord steps get rejected (they do not halve the residual) and are redone as Newton steps -- same solution, never more than one
+    # wasted substitution per Newton step
+    fun2, jac2 = (lambda u: np.exp(3.0 * u) - 5.0), (lambda u: np.diag(3.0 * np.exp(3.0 * u)))
+    full2 = FakeNM(fun2, jac2, 1, u0=[2.0]); full2.solve_nonlinear_nonmatching_problem(rtol=1e-13, max_it=60, zero_mortar_funcs=False)
+    nm2 = ChordNM(fun2, jac2, 1, u0=[2.0])
+    _, u2 = nm2.solve_nonlinear_nonmatching_problem(rtol=1e-13, max_it=60, zero_mortar_funcs=False)
+    assert nm2.newton_converged and abs(u2[0] - np.log(5.0) / 3.0) < 1e-11
+    assert nm2.n_stale - nm2.newton_chord_steps <= nm2.n_factor       # rejected chord steps are bounded by the Newton steps
+    # the switch: off = the reference's iteration, "auto" = only large models on the device solver
+    off = ChordNM(fun, jac, 1); off.newton_reuse_factors = False
+    off.solve_nonlinear_nonmatching_problem(rtol=1e-12, max_it=40)
+    assert off.n_stale == 0 and off.newton_chord_steps == 0 and off.newton_iterations == full.newton_iterations
+    auto = ChordNM(fun, jac, 1); auto.newton_reuse_factors = "auto"; auto.linear_solver = "device"
+    assert not auto._newton_reuses_factors()
+    auto.vec_iga_dof = 10 ** 6
+    assert auto._newton_reuses_factors()
