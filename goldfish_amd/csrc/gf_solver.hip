@@ -109,16 +109,23 @@ __device__ __forceinline__ void diag_body(double* __restrict__ band, double* __r
     double a[16];
 #pragma unroll
     for (int c = 0; c < 16; c += 2) { const double2 v = *reinterpret_cast<const double2*>(A + i * NB + 16 * jg + c); a[c] = v.x; a[c + 1] = v.y; }
+    // Round 4: the 64 elimination steps as FOUR trips of a loop over 16 unrolled steps (the register index of the pivot column, p % 16, is compile-time inside a
+    // trip; which quarter of the threads owns the column, p / 16, is the trip counter).  Fully unrolled the kernel was 72 KB of straight-line code executed once per
+    // tile -- more than the instruction cache -- and took 94 us for ~25 us of dependent arithmetic; the same for the inverse below (16 unrolled rows per trip).
+#pragma unroll 1
+    for (int pb = 0; pb < 4; ++pb) {
 #pragma unroll
-    for (int p = 0; p < NB; ++p) {
-        double* cb = col[p & 1];
-        if (jg == p / 16) { cb[i] = i > p ? a[p % 16] : 0.0; if (i == p) sd[p] = a[p % 16]; }
-        __syncthreads();
-        const double lip = cb[i] / sd[p];
+        for (int pp = 0; pp < 16; ++pp) {
+            const int p = 16 * pb + pp;
+            double* cb = col[pp & 1];
+            if (jg == pb) { cb[i] = i > p ? a[pp] : 0.0; if (i == p) sd[p] = a[pp]; }
+            __syncthreads();
+            const double lip = cb[i] / sd[p];
 #pragma unroll
-        for (int c = 0; c < 16; c += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(cb + 16 * jg + c);
-            a[c] -= lip * v.x; a[c + 1] -= lip * v.y;
+            for (int c = 0; c < 16; c += 2) {
+                const double2 v = *reinterpret_cast<const double2*>(cb + 16 * jg + c);
+                a[c] -= lip * v.x; a[c + 1] -= lip * v.y;
+            }
         }
     }
     __syncthreads();
@@ -146,15 +153,23 @@ __device__ __forceinline__ void diag_body(double* __restrict__ band, double* __r
 #pragma unroll
     for (int t = 0; t < 16; ++t) xr[t] = 0.0;
     double* Li = linv + (size_t)k * NB2;
+#pragma unroll 1
+    for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
-    for (int r = 0; r < NB; ++r) {
-        double p0 = 0.0, p1 = 0.0;
+        for (int rr = 0; rr < 16; ++rr) {
+            const int r = 16 * rb + rr;
+            double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-        for (int t = 0; t < 16; t += 2) { p0 += sL[r * S1 + 4 * t + q4] * xr[t]; p1 += sL[r * S1 + 4 * (t + 1) + q4] * xr[t + 1]; }
-        double part = p0 + p1;
-        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
-        const double xv = (r == c ? 1.0 : 0.0) - part;         // rows above c: L's row is zero there and so are the x_m: xv = 0
-        if (q4 == r % 4) { xr[r / 4] = xv; Li[r * NB + c] = xv; }
+            for (int t = 0; t < 16; t += 2) { p0 += sL[r * S1 + 4 * t + q4] * xr[t]; p1 += sL[r * S1 + 4 * (t + 1) + q4] * xr[t + 1]; }
+            double part = p0 + p1;
+            part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+            const double xv = (r == c ? 1.0 : 0.0) - part;         // rows above c: L's row is zero there and so are the x_m: xv = 0
+            if (q4 == rr % 4) {
+                Li[r * NB + c] = xv;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) if (rb == g) xr[4 * g + rr / 4] = xv;      // x_r lives in register r / 4 = 4 rb + rr / 4: compile-time per (g, rr)
+            }
+        }
     }
 }
 __global__ __launch_bounds__(256) void diag_kernel(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
