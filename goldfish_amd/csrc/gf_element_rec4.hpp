@@ -264,6 +264,9 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
             }
         } else {
             constexpr int tb = PASS - 1;
+            // body force: sum_gp R_a (dJ/dZ . phi_b)_f per a tile, scaled by -f_i behind the group loop (3 + 3 MFMAs per group instead of 9 + 9 into the nine
+            // (i, f) tiles: f_i is a constant of the patch) -- as the p <= 3 kernels do (gauss_group: accB)
+            gf_d4 accB[2][3] = {{gf_d4{0, 0, 0, 0}, gf_d4{0, 0, 0, 0}, gf_d4{0, 0, 0, 0}}, {gf_d4{0, 0, 0, 0}, gf_d4{0, 0, 0, 0}, gf_d4{0, 0, 0, 0}}};
             for (int grp = 0; grp < NGRP; ++grp) {
                 const int gp = 4 * grp + kk, gpc = gp < NG ? gp : NG - 1;
                 const int gu = gpc % P1, gv = gpc / P1;
@@ -312,15 +315,20 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
 #pragma unroll
                         for (int f = 0; f < 3; ++f) {
                             const double jz = load_dz_dot(im, ppd, lg, f, pb[0], pb[1]);
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) {
-                                accC[0][3 * i + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pf[i] * R0[0], jz, accC[0][3 * i + f], 0, 0, 0);
-                                accC[1][3 * i + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pf[i] * R0[1], jz, accC[1][3 * i + f], 0, 0, 0);
-                            }
+                            accB[0][f] = __builtin_amdgcn_mfma_f64_16x16x4f64(R0[0], jz, accB[0][f], 0, 0, 0);
+                            accB[1][f] = __builtin_amdgcn_mfma_f64_16x16x4f64(R0[1], jz, accB[1][f], 0, 0, 0);
                         }
                     }
                 }
                 GF_STAMP(4, tstamp);
+            }
+            if (doC && has_bf) {
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int f = 0; f < 3; ++f) accC[ta][3 * i + f] -= pf[i] * accB[ta][f];
             }
         }
 
