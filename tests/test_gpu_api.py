@@ -1591,3 +1591,23 @@ def test_plate_thickness_example_under_torchrun_on_two_ranks():
     spec_.loader.exec_module(mod)
     ref = mod.run(verbose=False)
     assert np.abs(h - ref["h"]).max() < 2e-6, (h, ref["h"])
+
+
+def test_newton_chord_steps_on_the_device_solver():
+    """NonMatchingOpt.newton_reuse_factors: chord steps with the factors at hand (solve_K(..., stale_factors=True): substitutions only, no refactorisation, no acceptance
+    test of the linear solve) reach the state of the reference's iteration -- here on the 4 x 4-patch shell under a load that bends it by several thicknesses, with both
+    factorisation modes of the device solver."""
+    import dataclasses
+    from goldfish_amd.nonmatching_opt import NonMatchingOpt
+    spec0 = G.synthetic_shell(4, 4, nel=10, p=3, jitter=2)
+    spec = dataclasses.replace(spec0, body_force=[[0.0, 0.0, -100.0]] * len(spec0.patches))
+    out = {}
+    for reuse in (False, True):
+        nm = NonMatchingOpt.from_spec(spec)
+        nm.newton_reuse_factors = reuse
+        _, u = nm.solve_nonlinear_nonmatching_problem(rtol=1e-9, max_it=40)
+        assert nm.newton_converged and nm.linear_solver == "device" and getattr(nm, "_dsolver_failed_version", None) is None
+        out[reuse] = (u, nm.newton_iterations, nm.newton_chord_steps, nm.newton_relative_residual)
+    assert out[False][2] == 0 and out[True][2] >= 1                       # chord steps were taken, and only with the switch on
+    assert _rel(out[True][0], out[False][0]) < 1e-6
+    assert out[True][1] - out[True][2] < out[False][1]                     # fewer factorisations than the plain iteration
