@@ -183,7 +183,7 @@ class DistributedSolver:
         self.n = 3 * ncp
         if coords is None:
             raise ValueError("DistributedSolver needs the control points' coordinates")
-        sym = self.sym = _nd.nested_dissection(self.nb_ptr, self.nb, coords, leaf=leaf)
+        sym = self.sym = _nd.nested_dissection_native(self.nb_ptr, self.nb, coords, leaf=leaf)[0]      # deterministic (also across thread counts): the same tree on every rank
         self.owner, self.roots = split_tree(sym, self.world)
         dK = dev_model.k_values_ptr()
         mine = np.flatnonzero(self.owner == self.rank)

@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GF_SOLVER_LIB", os.path.join(_HERE, "libgoldfish_solver.so"))   # GF_SOLVER_LIB: A/B builds while tuning
 EXPORTS = ["gfs_last_error", "gfs_create", "gfs_create_nd", "gfs_destroy", "gfs_refactor", "gfs_solve", "gfs_solve_dev", "gfs_set_general", "gfs_solve_transposed",
            "gfs_solve_transposed_dev", "gfs_info", "gfs_solve_multi", "gfs_solve_multi_dev", "gfs_create_nd_partial", "gfs_schur_doubles", "gfs_export_schur",
-           "gfs_set_schur_source", "gfs_get_fbnd", "gfs_set_fbnd", "gfs_x_ptr", "gfs_forward_dev", "gfs_backward_dev"]
+           "gfs_set_schur_source", "gfs_get_fbnd", "gfs_set_fbnd", "gfs_x_ptr", "gfs_forward_dev", "gfs_backward_dev", "gfs_symbolic_create", "gfs_symbolic_sizes",
+           "gfs_symbolic_copy", "gfs_symbolic_destroy"]
 _L = None
 
 
@@ -141,8 +142,13 @@ class DeviceSolver:
             if coords is None:
                 raise ValueError("DeviceSolver(method='nd') needs the control points' coordinates")
             leaf = int(os.environ.get("GF_SOLVER_LEAF", leaf))            # measurement switch (tools/solver_bench.py)
-            self.sym = sym = _nd.nested_dissection(self.nb_ptr, self.nb, coords, leaf=leaf)
-            keep = [np.ascontiguousarray(a, np.int64) for a in (sym.elim, sym.elim_off, sym.bnd, sym.bnd_off, sym.parent, sym.order, sym.front_of, parent_positions(sym))]
+            if os.environ.get("GF_ND", "native") == "python":       # the NumPy statement of the symbolic phase (what the tests compare the native one against)
+                self.sym = sym = _nd.nested_dissection(self.nb_ptr, self.nb, coords, leaf=leaf)
+                pmap = parent_positions(sym)
+            else:
+                self.sym, pmap = _nd.nested_dissection_native(self.nb_ptr, self.nb, coords, leaf=leaf)
+                sym = self.sym
+            keep = [np.ascontiguousarray(a, np.int64) for a in (sym.elim, sym.elim_off, sym.bnd, sym.bnd_off, sym.parent, sym.order, sym.front_of, pmap)]
             rc = lib().gfs_create_nd(int(dev_model.device), ncp, self.nb_ptr.ctypes.data_as(C.POINTER(C.c_int64)), self.nb.ctypes.data_as(C.POINTER(C.c_int32)),
                                      C.c_void_p(dK), sym.nfronts, *[i64(a) for a in keep], C.byref(h))
         else:

@@ -40,15 +40,15 @@ def build(force=False, verbose=False):
         subprocess.check_call([_hipcc(), "-O2", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-x", "hip",
                                os.path.join(CSRC, "point_host_test.cpp"), "-o", host])
     solver = os.path.join(HERE, "libgoldfish_solver.so")      # block-banded L D L^T factorisation + solves on the device, include/goldfish_solver.h
-    REPORT[os.path.basename(solver)] = "compiled" if (force or needs_build(solver, ["gf_solver.hip", os.path.join("..", "..", "include", "goldfish_solver.h")])) else "reused"
-    if force or needs_build(solver, ["gf_solver.hip", os.path.join("..", "..", "include", "goldfish_solver.h")]):
+    REPORT[os.path.basename(solver)] = "compiled" if (force or needs_build(solver, ["gf_solver.hip", "gf_nd_symbolic.hpp", os.path.join("..", "..", "include", "goldfish_solver.h")])) else "reused"
+    if force or needs_build(solver, ["gf_solver.hip", "gf_nd_symbolic.hpp", os.path.join("..", "..", "include", "goldfish_solver.h")]):
         # -amdgpu-mfma-vgpr-form: v_mfma_f64_16x16x4 with its accumulators in arch VGPRs issues every 64 cycles, with AGPR accumulators (the
         # compiler's default for these kernels) every 131 (tools/ubench_acc.hip, profiles/r03_ubench_fp64_mfma.txt); the tile kernels have registers to spare
         # Measured without effect (round 4): -Xclang -target-feature -Xclang -load-store-opt, which keeps the MFMA operand reads as ds_read_b64 (the pass fuses two
         # k-steps into ds_read2_b64: half the LDS bandwidth, two-way conflicts on the 66-double row stride; SQ_LDS_BANK_CONFLICT 2.5 x SQ_ACTIVE_INST_LDS in
         # profiles/r04_solver_pmc_c4.txt) -- C4 factorisation 0.261 vs 0.257 s: the update kernels do not wait for the LDS.
         extra = os.environ.get("GF_SOLVER_CXXFLAGS", "").split()
-        subprocess.check_call([_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form"] + extra +
+        subprocess.check_call([_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-pthread", "-mllvm", "-amdgpu-mfma-vgpr-form"] + extra +
                               [os.path.join(CSRC, "gf_solver.hip"), "-o", solver])
     if verbose or os.environ.get("GF_BUILD_REPORT", "1") == "1":
         print("goldfish_amd.build: " + ", ".join("%s %s" % kv for kv in REPORT.items()) + " (hipcc --offload-arch=gfx950; a library is reused when no source is newer than it)", file=sys.stderr, flush=True)

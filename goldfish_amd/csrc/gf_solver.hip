@@ -12,6 +12,7 @@
 //   update_kernel   A_ij -= W_ik L_jk^T   for k < j <= i <= k + T       (one workgroup per tile, same product)
 // Solves: block forward / backward substitution with the inverted diagonal tiles (one launch per block column), then
 // iterative refinement with the block-CSR K.  Reference: the MUMPS solves of GOLDFISH/utils/opt_utils.py:156-209.
+#include "gf_nd_symbolic.hpp"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -1746,6 +1747,30 @@ int gfs_solve_transposed(gfs_handle* h, const double* b, double* x, int max_refi
 
 int gfs_solve_multi(gfs_handle* h, int nrhs, const double* b, double* x, int max_refine, double* rel_residual, int transpose) { return solve_host_impl(h, b, x, max_refine, rel_residual, transpose, nrhs); }
 int gfs_solve_multi_dev(gfs_handle* h, int nrhs, const double* d_b, double* d_x, int max_refine, double* rel_residual, int transpose) { return solve_dev_impl(h, d_b, d_x, max_refine, rel_residual, transpose, nrhs); }
+
+// ---- symbolic phase on the host (gf_nd_symbolic.hpp): no device needed
+struct gfs_symbolic { gfnd::Symbolic S; };
+int gfs_symbolic_create(int64_t ncp, const int64_t* nb_ptr, const int32_t* nb, const double* coords, int dim, int64_t leaf, double cut_window, int threads, gfs_symbolic** out) {
+    if (!out || !nb_ptr || !nb || !coords) return sfail("gfs_symbolic_create: null argument");
+    *out = nullptr;
+    try {
+        gfs_symbolic* s = new gfs_symbolic();
+        try { s->S = gfnd::nested_dissection(ncp, nb_ptr, nb, coords, dim, leaf, cut_window, threads); }
+        catch (...) { delete s; throw; }
+        *out = s;
+    } catch (const std::exception& ex) { return sfail(ex.what()); }
+    return 0;
+}
+void gfs_symbolic_sizes(const gfs_symbolic* s, int64_t* nfronts, int64_t* nbnd) {
+    if (nfronts) *nfronts = s ? s->S.nfronts : 0;
+    if (nbnd) *nbnd = s ? (int64_t)s->S.bnd.size() : 0;
+}
+void gfs_symbolic_copy(const gfs_symbolic* s, int64_t* elim, int64_t* elim_off, int64_t* bnd, int64_t* bnd_off, int64_t* parent, int64_t* order, int64_t* front_of, int64_t* pmap) {
+    if (!s) return;
+    auto cp = [](const std::vector<int64_t>& v, int64_t* dst) { if (dst && !v.empty()) std::copy(v.begin(), v.end(), dst); };
+    cp(s->S.elim, elim); cp(s->S.elim_off, elim_off); cp(s->S.bnd, bnd); cp(s->S.bnd_off, bnd_off); cp(s->S.parent, parent); cp(s->S.order, order); cp(s->S.front_of, front_of); cp(s->S.pmap, pmap);
+}
+void gfs_symbolic_destroy(gfs_symbolic* s) { delete s; }
 
 // ---- partial handles: the pieces a distributed factorisation is put together from (goldfish_amd/_dsolver.py)
 static int partial_front(gfs_handle* h, int64_t front, const char* who) {

@@ -63,6 +63,17 @@ int gfs_solve_transposed_dev(gfs_handle* h, const double* d_b, double* d_x, int 
  * the largest of the nrhs solves. */
 int gfs_solve_multi(gfs_handle* h, int nrhs, const double* b, double* x, int max_refine, double* rel_residual, int transpose);
 int gfs_solve_multi_dev(gfs_handle* h, int nrhs, const double* d_b, double* d_x, int max_refine, double* rel_residual, int transpose);
+/* ---- Symbolic phase on the host (no device call): nested dissection of the control-point graph by recursive coordinate bisection with vertex separators, every cut
+ * at the rank within cut_window (a fraction of the region's size) of the median that gives the smallest separator; the fronts in post-order with their boundaries and the
+ * extend-add maps -- the arguments gfs_create_nd takes.  nb_ptr / nb: neighbour lists as for gfs_create; coords: ncp x dim doubles; leaf: regions of at most that many
+ * control points are not split; threads: the two halves of the large regions run on up to that many threads.  The result is what goldfish_amd/_nd.py computes (the tests
+ * compare the two entry by entry).  gfs_symbolic_sizes gives the number of fronts and the length of bnd / pmap; gfs_symbolic_copy fills caller-allocated arrays: elim [ncp],
+ * elim_off [nfronts + 1], bnd [nbnd], bnd_off [nfronts + 1], parent [nfronts], order [ncp], front_of [ncp], pmap [nbnd] (any of them may be NULL). */
+typedef struct gfs_symbolic gfs_symbolic;
+int gfs_symbolic_create(int64_t ncp, const int64_t* nb_ptr, const int32_t* nb, const double* coords, int dim, int64_t leaf, double cut_window, int threads, gfs_symbolic** out);
+void gfs_symbolic_sizes(const gfs_symbolic* s, int64_t* nfronts, int64_t* nbnd);
+void gfs_symbolic_copy(const gfs_symbolic* s, int64_t* elim, int64_t* elim_off, int64_t* bnd, int64_t* bnd_off, int64_t* parent, int64_t* order, int64_t* front_of, int64_t* pmap);
+void gfs_symbolic_destroy(gfs_symbolic* s);
 /* ---- Partial handles: the pieces of a factorisation distributed over several GPUs (goldfish_amd/_dsolver.py; one process per GPU, K's values replicated).
  * gfs_create_nd_partial takes a SUB-FOREST of the elimination tree with the arguments of gfs_create_nd and these differences: elim / elim_off cover only the control
  * points this handle eliminates; front_of[cp] = -1 for the others; order[cp] = position in elim for the handle's own control points, larger than all of those for

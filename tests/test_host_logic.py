@@ -183,6 +183,41 @@ def test_nested_dissection_symbolic_phase_and_reference_multifrontal_solve():
     assert np.abs(x - xd).max() < 1e-12 * np.abs(xd).max()
 
 
+def test_native_symbolic_phase_equals_the_numpy_statement():
+    """csrc/gf_nd_symbolic.hpp (gfs_symbolic_create: host C++ in libgoldfish_solver.so, what DeviceSolver uses) against goldfish_amd/_nd.py entry by entry -- elimination
+    order, fronts, boundaries, parents, extend-add maps -- on scattered points and on a patch grid with wide interface coupling, for several cut windows, leaf sizes and
+    thread counts (the result does not depend on the threads)."""
+    from goldfish_amd import _nd
+    from goldfish_amd._solver import parent_positions
+    rng = np.random.default_rng(11)
+    ncp = 1800
+    pts = rng.uniform(0, 1, (ncp, 3)) * [1.0, 0.6, 0.03]
+    adj = np.abs(pts[:, None, :2] - pts[None, :, :2]).max(-1) < 0.045
+    nbl = [np.flatnonzero(adj[a]) for a in range(ncp)]
+    cases = [(np.concatenate([[0], np.cumsum([len(x) for x in nbl])]).astype(np.int64), np.concatenate(nbl).astype(np.int32), pts)]
+    n, pw = 72, 18
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    idx = ii * n + jj
+    rows, cols = [], []
+    for di in range(-4, 5):
+        for dj in range(-4, 5):
+            i2, j2 = ii + di, jj + dj
+            ok = (i2 >= 0) & (i2 < n) & (j2 >= 0) & (j2 < n)
+            ok &= ((abs(di) <= 3) | ((ii // pw) != (i2 // pw))) & ((abs(dj) <= 3) | ((jj // pw) != (j2 // pw)))
+            rows.append(idx[ok]); cols.append((i2 * n + j2)[ok])
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    o = np.lexsort((cols, rows)); rows, cols = rows[o], cols[o]
+    cases.append((np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n * n))]).astype(np.int64), cols.astype(np.int32), np.stack([ii.ravel(), jj.ravel()], 1).astype(float)))
+    for nb_ptr, nb, X in cases:
+        for leaf, cw in ((40, 0.0), (40, 0.04), (128, 0.1)):
+            a = _nd.nested_dissection(nb_ptr, nb, X, leaf=leaf, cut_window=cw)
+            for threads in (1, 3):
+                b, pmap = _nd.nested_dissection_native(nb_ptr, nb, X, leaf=leaf, cut_window=cw, threads=threads)
+                for k in ("elim", "elim_off", "bnd", "bnd_off", "parent", "order", "front_of"):
+                    assert np.array_equal(getattr(a, k), getattr(b, k)), (k, leaf, cw, threads)
+                assert np.array_equal(parent_positions(a), pmap)
+
+
 def test_distributed_factorisation_tree_split_and_partial_symbolics():
     """goldfish_amd/_dsolver.py (host side of the distributed factorisation): split_tree deals whole subtrees to the ranks and keeps the top replicated;
     partial_symbolic gives gfs_create_nd_partial consistent pieces -- own control points numbered by their place in the handle's elimination list, the top's control
