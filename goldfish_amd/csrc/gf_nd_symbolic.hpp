@@ -10,6 +10,8 @@
 // (GOLDFISH/utils/opt_utils.py:156-209).  Host code only: no HIP call in this file.
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <cstdint>
 #include <functional>
 #include <future>
@@ -27,13 +29,15 @@ struct Symbolic {
 struct Dissector {
     int64_t ncp; const int64_t* nb_ptr; const int32_t* nb; const double* X; int dim; int64_t leaf; double window;
     std::vector<int64_t> node_of;          // tree node (heap numbering: children of r are 2 r + 1, 2 r + 2) that owns the control point
-    std::vector<int64_t> tag;              // node of the region the control point currently lies in (-1: it has its final node)
+    // node of the region the control point currently lies in (-1: it has its final node).  A region's thread reads the tags of ITS vertices' neighbours, which may
+    // belong to a region another thread is splitting: relaxed atomics (a foreign tag never equals the reader's node, whatever moment it is read at)
+    std::unique_ptr<std::atomic<int64_t>[]> tag;
     std::vector<int32_t> pos;              // rank of the control point in its region's order along the region's axis
     int max_threads = 1;
 
     void split(int32_t* v, int64_t n, int64_t node, int depth) {
         if (n <= 0) return;
-        if (n <= leaf) { for (int64_t k = 0; k < n; ++k) { node_of[v[k]] = node; tag[v[k]] = -1; } return; }
+        if (n <= leaf) { for (int64_t k = 0; k < n; ++k) { node_of[v[k]] = node; tag[v[k]].store(-1, std::memory_order_relaxed); } return; }
         // longest axis of the bounding box (the first of equal ones), order along it (ties: control-point index)
         int axis = 0; double best = -1.0;
         for (int d = 0; d < dim; ++d) {
@@ -42,7 +46,7 @@ struct Dissector {
             if (hi - lo > best) { best = hi - lo; axis = d; }
         }
         std::sort(v, v + n, [&](int32_t a, int32_t b) { const double xa = X[(size_t)a * dim + axis], xb = X[(size_t)b * dim + axis]; return xa < xb || (xa == xb && a < b); });
-        for (int64_t k = 0; k < n; ++k) { pos[v[k]] = (int32_t)k; tag[v[k]] = node; }
+        for (int64_t k = 0; k < n; ++k) { pos[v[k]] = (int32_t)k; tag[v[k]].store(node, std::memory_order_relaxed); }
         const int64_t cut0 = (n + 1) / 2;
         int64_t w = (int64_t)(window * (double)n); if (w < 0) w = 0;
         int64_t tmin = std::max<int64_t>(cut0 - w, 1), tmax = std::min<int64_t>(cut0 + w, n - 1);
@@ -51,7 +55,7 @@ struct Dissector {
         std::vector<int32_t> M((size_t)tmax);
         for (int64_t k = 0; k < tmax; ++k) {
             const int32_t a = v[k]; int32_t m = (int32_t)k;
-            for (int64_t e = nb_ptr[a]; e < nb_ptr[a + 1]; ++e) { const int32_t b = nb[e]; if (tag[b] == node && pos[b] > m) m = pos[b]; }
+            for (int64_t e = nb_ptr[a]; e < nb_ptr[a + 1]; ++e) { const int32_t b = nb[e]; if (tag[b].load(std::memory_order_relaxed) == node && pos[b] > m) m = pos[b]; }
             M[(size_t)k] = m;
         }
         int64_t cut = cut0;
@@ -74,7 +78,7 @@ struct Dissector {
         A.reserve((size_t)cut); B.reserve((size_t)(n - cut));
         for (int64_t k = 0; k < n; ++k) {
             const int32_t a = v[k];
-            if (k < cut && M[(size_t)k] >= cut) { node_of[a] = node; tag[a] = -1; }
+            if (k < cut && M[(size_t)k] >= cut) { node_of[a] = node; tag[a].store(-1, std::memory_order_relaxed); }
             else (k < cut ? A : B).push_back(a);
         }
         std::vector<int32_t>().swap(M);
@@ -93,8 +97,10 @@ struct Dissector {
 inline Symbolic nested_dissection(int64_t ncp, const int64_t* nb_ptr, const int32_t* nb, const double* X, int dim, int64_t leaf, double window, int threads) {
     if (ncp <= 0 || dim <= 0 || leaf <= 0) throw std::runtime_error("gfs_symbolic_create: empty graph, no coordinates or leaf <= 0");
     if (ncp >= (int64_t)1 << 31) throw std::runtime_error("gfs_symbolic_create: more than 2^31 control points");
-    Dissector D{ncp, nb_ptr, nb, X, dim, leaf, window};
-    D.node_of.assign((size_t)ncp, -1); D.tag.assign((size_t)ncp, 0); D.pos.assign((size_t)ncp, 0); D.max_threads = std::max(1, threads);
+    Dissector D; D.ncp = ncp; D.nb_ptr = nb_ptr; D.nb = nb; D.X = X; D.dim = dim; D.leaf = leaf; D.window = window;
+    D.node_of.assign((size_t)ncp, -1); D.tag.reset(new std::atomic<int64_t>[(size_t)ncp]); D.pos.assign((size_t)ncp, 0);
+    for (int64_t a = 0; a < ncp; ++a) D.tag[(size_t)a].store(0, std::memory_order_relaxed);
+    D.max_threads = std::max(1, threads);
     {
         std::vector<int32_t> all((size_t)ncp);
         for (int64_t a = 0; a < ncp; ++a) all[(size_t)a] = (int32_t)a;

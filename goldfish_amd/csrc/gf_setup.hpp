@@ -16,6 +16,9 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <thread>
+#include <mutex>
+#include <cstdlib>
 #include "../../include/goldfish_model.h"
 
 namespace gf {
@@ -111,6 +114,28 @@ inline void basis_ders(int span, double xi, int p, const double* U, double ders[
     }
     double r = p;
     for (int k = 1; k <= nd; ++k) { for (int j = 0; j <= p; ++j) ders[k][j] *= r; r *= (p - k); }
+}
+
+
+// Index ranges [0, n) cut into contiguous chunks, one thread per chunk (GF_SETUP_THREADS, default: the hardware threads, at most 16); the first exception of any
+// chunk is rethrown on the caller's thread.  The set-up loops below write disjoint entries per index, so the result does not depend on the thread count.
+template <class Fn> inline void parallel_chunks(int64_t n, Fn&& fn, int64_t min_chunk = 1024) {
+    int nt = 1;
+    if (const char* e = std::getenv("GF_SETUP_THREADS")) nt = std::atoi(e);
+    else { nt = (int)std::thread::hardware_concurrency(); if (nt > 16) nt = 16; }
+    if (nt < 1) nt = 1;
+    if ((int64_t)nt > n / min_chunk) nt = (int)std::max<int64_t>(1, n / min_chunk);
+    if (nt <= 1) { fn((int64_t)0, n); return; }
+    std::vector<std::thread> th; std::mutex mu; std::string err; bool failed = false;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        th.emplace_back([&, lo, hi] {
+            try { fn(lo, hi); }
+            catch (const std::exception& ex) { std::lock_guard<std::mutex> g(mu); if (!failed) { failed = true; err = ex.what(); } }
+        });
+    }
+    for (auto& x : th) x.join();
+    if (failed) throw std::runtime_error(err);
 }
 
 struct HostModel {
@@ -300,55 +325,73 @@ inline void HostModel::build(const gf_model_desc* D) {
             if (in_window(v, itf, s, A.cp) && in_window(v, itf, t, B.cp)) return true;
         return false;
     };
+    // coupling lists: the control points of both sides whose windows share a mortar vertex.  The pairs of an interface are found in parallel (the test walks the
+    // common vertex range), then appended per control point in interface order (a corner control point lies on two interfaces)
     std::vector<std::vector<int>> extra(total_cp);
-    for (int i = 0; i < ni; ++i) for (int s = 0; s < 2; ++s) for (int t = 0; t < 2; ++t)
-        for (const CpRange& A : ranges[2 * i + s]) for (const CpRange& B : ranges[2 * i + t])
-            if (A.lo <= B.hi && B.lo <= A.hi && cosupport(i, s, A, t, B)) extra[A.cp].push_back(B.cp);
+    {
+        std::vector<std::vector<std::pair<int, int>>> found((size_t)ni);
+        parallel_chunks(ni, [&](int64_t i0, int64_t i1) {
+            for (int i = (int)i0; i < (int)i1; ++i) for (int s = 0; s < 2; ++s) for (int t = 0; t < 2; ++t)
+                for (const CpRange& A : ranges[2 * i + s]) for (const CpRange& B : ranges[2 * i + t])
+                    if (A.lo <= B.hi && B.lo <= A.hi && cosupport(i, s, A, t, B)) found[(size_t)i].push_back({(int)A.cp, (int)B.cp});
+        }, 1);
+        for (int i = 0; i < ni; ++i) for (const auto& ab : found[(size_t)i]) extra[(size_t)ab.first].push_back(ab.second);
+    }
+    tick("coupling pairs of the interfaces");
     nb_ptr_s.assign(total_cp + 1, 0); nb_ptr_c.assign(total_cp + 1, 0);
-    std::vector<int> box;
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1) { nb_s.resize(nb_ptr_s[total_cp]); nb_c.resize(nb_ptr_c[total_cp]); }
-        for (int s = 0; s < np; ++s) {
-            const PatchDev& P = patches[s];
-            const int *spu = &ints[P.spu], *spv = &ints[P.spv], *c2u = &ints[P.c2u], *c2v = &ints[P.c2v];
-            for (int j = 0; j < P.nv; ++j) for (int i = 0; i < P.nu; ++i) {
-                const int64_t a = P.cp_off + i + int64_t(j) * P.nu;
-                box.clear();
-                if (c2u[2 * i + 1] >= 0 && c2v[2 * j + 1] >= 0) {
-                    const int i0 = spu[c2u[2 * i]] - P.p, i1 = spu[c2u[2 * i + 1]], j0 = spv[c2v[2 * j]] - P.q, j1 = spv[c2v[2 * j + 1]];
-                    for (int jj = j0; jj <= j1; ++jj) for (int ii = i0; ii <= i1; ++ii) box.push_back(int(P.cp_off + ii + int64_t(jj) * P.nu));
-                }
-                if (pass == 0) {
-                    nb_ptr_s[a + 1] = nb_ptr_s[a] + (int64_t)box.size();
-                    std::vector<int>& ex = extra[a];
-                    if (!ex.empty()) {
-                        ex.insert(ex.end(), box.begin(), box.end());
-                        std::sort(ex.begin(), ex.end()); ex.erase(std::unique(ex.begin(), ex.end()), ex.end());
-                        nb_ptr_c[a + 1] = nb_ptr_c[a] + (int64_t)ex.size();
-                    } else nb_ptr_c[a + 1] = nb_ptr_c[a] + (int64_t)box.size();
-                } else {
-                    std::copy(box.begin(), box.end(), nb_s.begin() + nb_ptr_s[a]);
-                    const std::vector<int>& src = extra[a].empty() ? box : extra[a];
-                    std::copy(src.begin(), src.end(), nb_c.begin() + nb_ptr_c[a]);
+    // per control point: its box of shell neighbours (the control points of the elements it lies in), merged with the coupling lists; sizes first, then the
+    // prefix sums, then the lists -- both passes over the patches in parallel (every control point writes its own entries)
+    auto for_cps = [&](int pass) {
+        parallel_chunks(np, [&](int64_t s0, int64_t s1) {
+            std::vector<int> box;
+            for (int64_t s = s0; s < s1; ++s) {
+                const PatchDev& P = patches[s];
+                const int *spu = &ints[P.spu], *spv = &ints[P.spv], *c2u = &ints[P.c2u], *c2v = &ints[P.c2v];
+                for (int j = 0; j < P.nv; ++j) for (int i = 0; i < P.nu; ++i) {
+                    const int64_t a = P.cp_off + i + int64_t(j) * P.nu;
+                    box.clear();
+                    if (c2u[2 * i + 1] >= 0 && c2v[2 * j + 1] >= 0) {
+                        const int i0 = spu[c2u[2 * i]] - P.p, i1 = spu[c2u[2 * i + 1]], j0 = spv[c2v[2 * j]] - P.q, j1 = spv[c2v[2 * j + 1]];
+                        for (int jj = j0; jj <= j1; ++jj) for (int ii = i0; ii <= i1; ++ii) box.push_back(int(P.cp_off + ii + int64_t(jj) * P.nu));
+                    }
+                    if (pass == 0) {
+                        nb_ptr_s[a + 1] = (int64_t)box.size();
+                        std::vector<int>& ex = extra[a];
+                        if (!ex.empty()) {
+                            ex.insert(ex.end(), box.begin(), box.end());
+                            std::sort(ex.begin(), ex.end()); ex.erase(std::unique(ex.begin(), ex.end()), ex.end());
+                            nb_ptr_c[a + 1] = (int64_t)ex.size();
+                        } else nb_ptr_c[a + 1] = (int64_t)box.size();
+                    } else {
+                        std::copy(box.begin(), box.end(), nb_s.begin() + nb_ptr_s[a]);
+                        const std::vector<int>& src = extra[a].empty() ? box : extra[a];
+                        std::copy(src.begin(), src.end(), nb_c.begin() + nb_ptr_c[a]);
+                    }
                 }
             }
-        }
-    }
+        }, 1);
+    };
+    for_cps(0);
+    for (int64_t a = 0; a < total_cp; ++a) { nb_ptr_s[a + 1] += nb_ptr_s[a]; nb_ptr_c[a + 1] += nb_ptr_c[a]; }
+    nb_s.resize(nb_ptr_s[total_cp]); nb_c.resize(nb_ptr_c[total_cp]);
+    for_cps(1);
     {   // reverse indices (lists are sorted ascending)
         auto build_rev = [&](const std::vector<int64_t>& ptr, const std::vector<int>& nb, std::vector<int>& rev) {
             rev.assign(nb.size(), 0);
-            for (int64_t a = 0; a < total_cp; ++a) for (int64_t k = ptr[a]; k < ptr[a + 1]; ++k) {
-                const int b = nb[k];
-                const int* lo = nb.data() + ptr[b]; const int* hi = nb.data() + ptr[b + 1];
-                const int* it = std::lower_bound(lo, hi, (int)a);
-                if (it == hi || *it != (int)a) throw std::runtime_error("gf_create: neighbour relation is not symmetric");
-                rev[k] = int(it - lo);
-            }
+            parallel_chunks(total_cp, [&](int64_t a0, int64_t a1) {
+                for (int64_t a = a0; a < a1; ++a) for (int64_t k = ptr[a]; k < ptr[a + 1]; ++k) {
+                    const int b = nb[k];
+                    const int* lo = nb.data() + ptr[b]; const int* hi = nb.data() + ptr[b + 1];
+                    const int* it = std::lower_bound(lo, hi, (int)a);
+                    if (it == hi || *it != (int)a) throw std::runtime_error("gf_create: neighbour relation is not symmetric");
+                    rev[k] = int(it - lo);
+                }
+            });
         };
         build_rev(nb_ptr_s, nb_s, nb_rev_s); build_rev(nb_ptr_c, nb_c, nb_rev_c);
     }
     cp_desc.assign(total_cp, CpDesc{});
-    for (int s = 0; s < np; ++s) {
+    parallel_chunks(np, [&](int64_t s0_, int64_t s1_) { for (int s = (int)s0_; s < (int)s1_; ++s) {
         const PatchDev& P = patches[s];
         const int *spu = &ints[P.spu], *spv = &ints[P.spv], *c2u = &ints[P.c2u], *c2v = &ints[P.c2v];
         for (int j = 0; j < P.nv; ++j) for (int i = 0; i < P.nu; ++i) {
@@ -361,11 +404,11 @@ inline void HostModel::build(const gf_model_desc* D) {
             if (c.neu > 5 || c.nev > 5) throw std::runtime_error("gf_create: a control point lies in more than 5 knot spans per direction");
             for (int k = 0; k < 5; ++k) { c.bu[k] = k < c.neu ? spu[eu0 + k] - P.p : 0; c.bv[k] = k < c.nev ? spv[ev0 + k] - P.q : 0; }
         }
-    }
+    } }, 1);
     tick("neighbour lists (shell, coupling), reverse indices, control-point descriptors");
     // per-entry metadata of the coupling lists: what the gather's write phase would otherwise derive from dependent loads
     nb_meta.assign(nb_c.size(), 0);
-    for (int s = 0; s < np; ++s) {
+    parallel_chunks(np, [&](int64_t s0_, int64_t s1_) { for (int s = (int)s0_; s < (int)s1_; ++s) {
         const PatchDev& P = patches[s];
         const int *spu = &ints[P.spu], *spv = &ints[P.spv], *c2u = &ints[P.c2u], *c2v = &ints[P.c2v];
         for (int j = 0; j < P.nv; ++j) for (int i = 0; i < P.nu; ++i) {
@@ -384,7 +427,7 @@ inline void HostModel::build(const gf_model_desc* D) {
                 nb_meta[k] = (unsigned short)(slot | (zero[3 * b] ? 128 : 0) | (zero[3 * b + 1] ? 256 : 0) | (zero[3 * b + 2] ? 512 : 0) | (b == a ? 1024 : 0));
             }
         }
-    }
+    } }, 1);
     // control points of the loads that run behind the gather (gf_extra_loads.hpp): every control point of a pressurised patch, the
     // edge row of a loaded edge
     {
@@ -410,8 +453,11 @@ inline void HostModel::build(const gf_model_desc* D) {
         std::stable_sort(rows.begin(), rows.end(), [](const PenRowItem& x, const PenRowItem& y) { return x.a < y.a; });
         row_items = rows; row_ptr.clear(); row_ptr.push_back(0);
         for (size_t k = 1; k <= rows.size(); ++k) if (k == rows.size() || rows[k].a != rows[k - 1].a) row_ptr.push_back((int64_t)k);
-        pen_entries.clear(); pen_slots.clear(); ent_ptr.assign(1, 0); row_cp.clear();
-        for (size_t g = 0; g + 1 < row_ptr.size(); ++g) {
+        // the visits of a row group (an owned control point a): every mortar vertex of its ranges whose window holds a.  Two passes over the groups, both in
+        // parallel: count, prefix sums, fill (a visit costs 32 binary searches in a's neighbour list: 1.4 of the 2.7 s of gf_create at C4 when done serially)
+        const int64_t ngroups = (int64_t)row_ptr.size() - 1;
+        const bool slots = degree <= 3;
+        auto visits = [&](int64_t g, auto&& emit) {
             const int a = rows[row_ptr[g]].a;
             for (int64_t it = row_ptr[g]; it < row_ptr[g + 1]; ++it) {
                 const PenRowItem& I = rows[it];
@@ -421,31 +467,47 @@ inline void HostModel::build(const gf_model_desc* D) {
                 for (int v = I.lo; v <= I.hi; ++v) {
                     const int di = ia - pt_base[4 * v + 2 * sd], dj = ja - pt_base[4 * v + 2 * sd + 1];
                     if (di < 0 || di > P.p || dj < 0 || dj > P.q) continue;
+                    emit(a, itf, sd, v, di + dj * (P.p + 1));
+                }
+            }
+        };
+        ent_ptr.assign((size_t)ngroups + 1, 0); row_cp.assign((size_t)ngroups, 0);
+        parallel_chunks(ngroups, [&](int64_t g0, int64_t g1) {
+            for (int64_t g = g0; g < g1; ++g) {
+                int64_t n = 0;
+                visits(g, [&](int, int, int, int, int) { ++n; });
+                ent_ptr[(size_t)g + 1] = n; row_cp[(size_t)g] = rows[row_ptr[g]].a;
+            }
+        });
+        for (int64_t g = 0; g < ngroups; ++g) ent_ptr[(size_t)g + 1] += ent_ptr[(size_t)g];
+        pen_entries.assign((size_t)ent_ptr[(size_t)ngroups], PenEntry{});
+        pen_slots.assign(slots ? (size_t)ent_ptr[(size_t)ngroups] * 32 : 0, (unsigned short)0xFFFF);
+        parallel_chunks(ngroups, [&](int64_t g0, int64_t g1) {
+            for (int64_t g = g0; g < g1; ++g) {
+                int64_t e = ent_ptr[(size_t)g];
+                visits(g, [&](int a, int itf, int sd, int v, int al) {
                     for (int k = 0; k < 4; ++k) if (pt_base[4 * v + k] < 0 || pt_base[4 * v + k] > 32767) throw std::runtime_error("gf_create: patch too large for the packed mortar windows");
-                    pen_entries.push_back({v, (sd << 8) | (di + dj * (P.p + 1)), pt_base[4 * v] | (pt_base[4 * v + 1] << 16), pt_base[4 * v + 2] | (pt_base[4 * v + 3] << 16),
-                                           if_patch[2 * itf], if_patch[2 * itf + 1], 0, 0});
-                    if (degree <= 3) {                               // where the window's control points sit in a's coupled neighbour list (sorted by id)
+                    pen_entries[(size_t)e] = PenEntry{v, (sd << 8) | al, pt_base[4 * v] | (pt_base[4 * v + 1] << 16), pt_base[4 * v + 2] | (pt_base[4 * v + 3] << 16),
+                                                      if_patch[2 * itf], if_patch[2 * itf + 1], 0, 0};
+                    if (slots) {                                     // where the window's control points sit in a's coupled neighbour list (sorted by id)
                         const int p1 = degree + 1;
                         const int* nb0 = nb_c.data() + nb_ptr_c[a]; const int* nb1 = nb_c.data() + nb_ptr_c[a + 1];
                         for (int t = 0; t < 2; ++t) {
                             const PatchDev& Pt = patches[if_patch[2 * itf + t]];
-                            for (int c = 0; c < 16; ++c) {
-                                unsigned short k = 0xFFFF;
-                                if (c < p1 * p1) {
-                                    const int64_t b = Pt.cp_off + (pt_base[4 * v + 2 * t] + c % p1) + int64_t(pt_base[4 * v + 2 * t + 1] + c / p1) * Pt.nu;
-                                    const int* it2 = std::lower_bound(nb0, nb1, (int)b);
-                                    if (it2 == nb1 || *it2 != (int)b) throw std::runtime_error("gf_create: a mortar vertex couples control points that are not neighbours");
-                                    k = (unsigned short)(it2 - nb0);
-                                }
-                                pen_slots.push_back(k);
+                            for (int c = 0; c < p1 * p1; ++c) {
+                                const int64_t b = Pt.cp_off + (pt_base[4 * v + 2 * t] + c % p1) + int64_t(pt_base[4 * v + 2 * t + 1] + c / p1) * Pt.nu;
+                                const int* it2 = std::lower_bound(nb0, nb1, (int)b);
+                                if (it2 == nb1 || *it2 != (int)b) throw std::runtime_error("gf_create: a mortar vertex couples control points that are not neighbours");
+                                pen_slots[((size_t)e * 2 + t) * 16 + c] = (unsigned short)(it2 - nb0);
                             }
                         }
                     }
-                }
+                    ++e;
+                });
             }
-            ent_ptr.push_back((int64_t)pen_entries.size()); row_cp.push_back(a);
-        }
+        });
     }
+    tick("owner lists of the penalty rows, visit records, window slots");
 }
 
 // Support window (first control-point indices) and rational basis values / first / second derivatives of patch `patch` at the parametric point (xu, xv):
