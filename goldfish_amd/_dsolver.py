@@ -243,6 +243,12 @@ class DistributedSolver:
             self.dist.all_gather(parts, mine.cpu(), group=self.group)
             buf.copy_(self.torch.cat(parts).to(buf.device))
 
+    def _any(self, flag):
+        """Logical OR of ``flag`` over the ranks (collective)."""
+        t = self.torch.tensor([1.0 if flag else 0.0], dtype=self.torch.float64, device=self.torch.device("cuda", self.device) if self.cuda else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return bool(t.item() > 0.0)
+
     def close(self):
         for part in ("A", "B"):
             p = getattr(self, part, None)
@@ -262,13 +268,19 @@ class DistributedSolver:
         if hasattr(self.D, "refresh_k_values"):
             self.D.refresh_k_values()
         t1 = time.perf_counter()
+        err = None
         if self.A is not None:
-            self._check(L.gfs_refactor(self.A.h))
-            off = self.rank * self.schur_pad
-            for t in self.my_roots:
-                self._check(L.gfs_export_schur(self.A.h, self.A.local[t], C.c_void_p(self.schur_all.data_ptr() + 8 * off)))
-                off += self.schur_len[t]
+            try:
+                self._check(L.gfs_refactor(self.A.h))
+                off = self.rank * self.schur_pad
+                for t in self.my_roots:
+                    self._check(L.gfs_export_schur(self.A.h, self.A.local[t], C.c_void_p(self.schur_all.data_ptr() + 8 * off)))
+                    off += self.schur_len[t]
+            except RuntimeError as e:                          # e.g. a zero pivot in one rank's subtree: every rank must leave the collective phase the same way
+                err = str(e)
         torch.cuda.synchronize()
+        if self._any(err is not None):
+            raise RuntimeError("DistributedSolver.refactor: " + (err or "the factorisation of another rank's subtrees failed"))
         t2 = time.perf_counter()
         self._allgather(self.schur_all, self.schur_pad)
         torch.cuda.synchronize()
@@ -283,7 +295,7 @@ class DistributedSolver:
             if p is not None:
                 L.gfs_info(p.h, v)
                 small = small or bool(v[5])
-        self.small_pivot = small
+        self.small_pivot = self._any(small)                    # the same flag on every rank: solve_K's acceptance bar depends on it
         L.gfs_info(self.B.h, v)
         self.norm_K = float(v[7])
 
