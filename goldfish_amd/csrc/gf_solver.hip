@@ -985,7 +985,7 @@ struct gfs_handle {
     // the large fronts per block column on the side streams
     struct Round { int off, n; long long max_tiles; };
     struct FLevel { int off = 0, n = 0; std::vector<int> nk, max_ni; std::vector<Round> rounds; std::vector<int> big; };
-    std::vector<FLevel> flevels; int *d_flist = nullptr, *d_ealist = nullptr; long long* d_fwofs = nullptr; double* bwbuf = nullptr; int batch_blk = 96, panel_w = 8;       // panel_w: block columns per trailing update (C4: 4 -> 8: 0.257 -> 0.249 s, the target tile is read and written once per group)
+    std::vector<FLevel> flevels; int *d_flist = nullptr, *d_ealist = nullptr; long long* d_fwofs = nullptr; double* bwbuf = nullptr; int batch_blk = 96, batch_panel_w = 8, panel_w = 8;       // panel_w: block columns per trailing update (C4: 4 -> 8: 0.257 -> 0.249 s, the target tile is read and written once per group)
     // substitution workspaces: [0] aliases the handle's own buffers and stream; [1 ..] are created by the first multi-right-hand-side solve, one stream each, so
     // that the sweeps of several right-hand sides (latency-bound chains of small launches) run next to each other (gfs_solve_multi)
     struct SolveWs { hipStream_t stream = nullptr; double *gb = nullptr, *gy = nullptr, *gx = nullptr, *fbnd = nullptr, *sb = nullptr, *sy = nullptr, *sz = nullptr, *sx = nullptr,
@@ -1118,7 +1118,7 @@ static void nd_factor_levels(gfs_handle* h) {
             for (int s = 0; s < used; ++s) HIPCHK(hipStreamWaitEvent(h->st[s], h->ev_main, 0));
             for (size_t i = 0; i < L.big.size(); ++i) { const int s = (int)(i % NS); nd_factor_front(h, L.big[i], h->st[s], s, false); }
         }
-        const int WP = std::max(h->panel_w, 1), kmax = (int)L.nk.size();
+        const int WP = std::max(h->batch_panel_w, 1), kmax = (int)L.nk.size();
         for (int k0 = 0; k0 < kmax; k0 += WP) {                          // panel groups, as nd_factor_front does for one front
             for (int c = 0; c < WP && k0 + c < kmax; ++c) {
                 const int k = k0 + c, nk = L.nk[k], mni = L.max_ni[k];
@@ -1397,7 +1397,8 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
         h->band = h->dalloc<double>((size_t)tiles * NB2);
         h->linv = h->dalloc<double>((size_t)kb * NB2);
         h->dval = h->dalloc<double>((size_t)kb * NB); h->stat = h->dalloc<double>((size_t)2 * kb);
-        if (const char* e = std::getenv("GF_SOLVER_PANEL_W")) h->panel_w = std::max(1, std::min(8, std::atoi(e)));
+        if (const char* e = std::getenv("GF_SOLVER_PANEL_W")) h->panel_w = h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));
+        if (const char* e = std::getenv("GF_SOLVER_BATCH_PANEL_W")) h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));      // panel groups of the level-batched small fronts
         {   // independent subtrees for the side streams: split the largest subtree (by factorisation work) until there are enough of them
             constexpr int NS = gfs_handle::NS;
             std::vector<double> work(nfronts, 0.0); std::vector<int> cnt(nfronts, 1);
@@ -1473,7 +1474,7 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
                 std::stable_sort(small[l].begin(), small[l].end(), [&](int x, int y) { return h->fronts[x].nblk_e > h->fronts[y].nblk_e; });
                 L.off = (int)flist.size(); L.n = (int)small[l].size();
                 long long w = 0;
-                for (int t : small[l]) { flist.push_back(t); wofs.push_back(w); w += (long long)std::max(h->panel_w, 1) * std::max(h->fronts[t].nblk_t - 1, 1); }
+                for (int t : small[l]) { flist.push_back(t); wofs.push_back(w); w += (long long)std::max(h->batch_panel_w, 1) * std::max(h->fronts[t].nblk_t - 1, 1); }
                 wmax = std::max(wmax, w);
                 const int kmax = L.n ? h->fronts[small[l][0]].nblk_e : 0;
                 L.nk.assign(kmax, 0); L.max_ni.assign(kmax, 0);
