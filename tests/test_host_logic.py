@@ -218,6 +218,29 @@ def test_native_symbolic_phase_equals_the_numpy_statement():
                 assert np.array_equal(parent_positions(a), pmap)
 
 
+def test_native_symbolic_phase_on_degenerate_graphs():
+    """The same comparison where the bisection has nothing to hold on to: disconnected clusters and isolated points (empty separators: tree nodes that own nothing),
+    identical coordinates, a single front, a chain with a wide cut window, a complete graph."""
+    from goldfish_amd import _nd
+    from goldfish_amd._solver import parent_positions
+    rng = np.random.default_rng(5)
+
+    def csr(nbl):
+        return np.concatenate([[0], np.cumsum([len(x) for x in nbl])]).astype(np.int64), np.concatenate([np.asarray(x, np.int32) for x in nbl])
+    pts = np.concatenate([rng.uniform(0, 1, (250, 2)), rng.uniform(5, 6, (250, 2)), rng.uniform(10, 20, (100, 2))])
+    adj = np.abs(pts[:, None, :] - pts[None, :, :]).max(-1) < 0.12
+    chain = [np.unique(np.clip(np.arange(a - 3, a + 4), 0, 199)) for a in range(200)]
+    cases = [(csr([np.flatnonzero(adj[a]) for a in range(600)]), pts, 30, 0.04), (csr(chain), np.zeros((200, 3)), 20, 0.04),
+             (csr(chain), np.arange(200.0)[:, None] * np.ones((1, 3)), 500, 0.04), (csr(chain), np.arange(200.0)[:, None], 10, 0.3),
+             (csr([np.arange(60) for _ in range(60)]), rng.uniform(0, 1, (60, 3)), 8, 0.1)]
+    for (nb_ptr, nb), X, leaf, cw in cases:
+        a = _nd.nested_dissection(nb_ptr, nb, X, leaf=leaf, cut_window=cw)
+        b, pmap = _nd.nested_dissection_native(nb_ptr, nb, X, leaf=leaf, cut_window=cw, threads=4)
+        for k in ("elim", "elim_off", "bnd", "bnd_off", "parent", "order", "front_of"):
+            assert np.array_equal(getattr(a, k), getattr(b, k)), k
+        assert np.array_equal(parent_positions(a), pmap)
+
+
 def test_distributed_factorisation_tree_split_and_partial_symbolics():
     """goldfish_amd/_dsolver.py (host side of the distributed factorisation): split_tree deals whole subtrees to the ranks and keeps the top replicated;
     partial_symbolic gives gfs_create_nd_partial consistent pieces -- own control points numbered by their place in the handle's elimination list, the top's control
