@@ -19,7 +19,7 @@ BUF_CP, BUF_U, BUF_H, BUF_R, BUF_VAL_K, BUF_VAL_C0, BUF_VAL_C1, BUF_VAL_C2, BUF_
 
 EXPORTS = ["gf_device_count", "gf_last_error", "gf_create", "gf_destroy", "gf_total_cp", "gf_num_dofs",
            "gf_num_elements", "gf_num_gauss_points", "gf_num_mortar_points", "gf_device_bytes", "gf_set_cp",
-           "gf_set_thickness", "gf_set_u", "gf_nnz", "gf_pattern", "gf_assemble", "gf_sync", "gf_get_residual",
+           "gf_set_thickness", "gf_set_u", "gf_nnz", "gf_pattern", "gf_cp_graph_size", "gf_cp_graph", "gf_assemble", "gf_sync", "gf_get_residual",
            "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_shape_regu", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms", "gf_assembly_path", "gf_stream", "gf_apply_many", "gf_get_functional_gradient", "gf_penalty_dxi_range", "gf_functionals_per_patch", "gf_penalty_dxi_rev", "gf_update_interface"]
 
 
@@ -35,7 +35,7 @@ def lib():
         sig = {   # name: (argtypes, restype); restype None keeps ctypes' default int
             "gf_device_count": (None, ci), "gf_last_error": (None, C.c_char_p), "gf_create": ([C.POINTER(gf_model_desc), ci, C.POINTER(vp)], None),
             "gf_destroy": ([vp], "void"), "gf_set_cp": ([vp, ci, dp, i64], None), "gf_set_thickness": ([vp, dp, i64], None), "gf_set_u": ([vp, dp, i64], None),
-            "gf_nnz": ([vp, ci], i64), "gf_pattern": ([vp, ci, C.POINTER(C.c_int64), i32p], None), "gf_assemble": ([vp, ci], None), "gf_sync": ([vp], None),
+            "gf_nnz": ([vp, ci], i64), "gf_pattern": ([vp, ci, C.POINTER(C.c_int64), i32p], None), "gf_cp_graph_size": ([vp], i64), "gf_cp_graph": ([vp, C.POINTER(C.c_int64), i32p], None), "gf_assemble": ([vp, ci], None), "gf_sync": ([vp], None),
             "gf_get_residual": ([vp, dp, i64], None), "gf_get_values": ([vp, ci, dp, i64], None), "gf_apply": ([vp, ci, ci, dp, i64, dp, i64], None),
             "gf_functionals": ([vp, dp, dp, dp, dp, dp, dp, ci], None), "gf_compliance": ([vp, dp, i64, dp, dp, dp, ci], None),
             "gf_shape_regu": ([vp, ci, dp, i64, dp, i64, dp, dp], None), "gf_penalty_dxi": ([vp, dp, i64, i32p, i64], None),
@@ -164,6 +164,13 @@ class DeviceModel:
                                     col.ctypes.data_as(C.POINTER(C.c_int32))))
             self._pat[which] = (rowptr, col)
         return self._pat[which]
+
+    def cp_graph(self):
+        """(nb_ptr, nb): control-point-level pattern of K (gf_cp_graph) -- what the device solver's symbolic phase takes."""
+        n = lib().gf_cp_graph_size(self.h)
+        nb_ptr, nb = np.zeros(self.total_cp + 1, np.int64), np.zeros(n, np.int32)
+        _check(lib().gf_cp_graph(self.h, nb_ptr.ctypes.data_as(C.POINTER(C.c_int64)), nb.ctypes.data_as(C.POINTER(C.c_int32))))
+        return nb_ptr, nb
 
     def assemble(self, flags=ASM_ALL, sync=True):
         _check(lib().gf_assemble(self.h, int(flags)))

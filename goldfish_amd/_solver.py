@@ -125,9 +125,12 @@ class DeviceSolver:
         from . import _lib
         self.general = bool(general)
         self.D, self.max_refine = dev_model, (40 if general else 3) if max_refine is None else max_refine
-        rowptr, col = dev_model.pattern(_lib.MAT_K)
-        self.nb_ptr, self.nb = control_point_graph(rowptr, col)
-        del rowptr, col
+        if hasattr(dev_model, "cp_graph"):                      # the library's own control-point-level lists (a ninth of the dof-level pattern)
+            self.nb_ptr, self.nb = dev_model.cp_graph()
+        else:                                                   # sharded model: the global dof-level pattern gathered from the ranks
+            rowptr, col = dev_model.pattern(_lib.MAT_K)
+            self.nb_ptr, self.nb = control_point_graph(rowptr, col)
+            del rowptr, col
         ncp = self.nb_ptr.size - 1
         self.n = 3 * ncp
         if method == "auto":

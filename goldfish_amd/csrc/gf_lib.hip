@@ -268,6 +268,16 @@ int64_t gf_nnz(const gf_handle* h, int which) {
     if (which >= GF_MAT_DRDCP0 && which <= GF_MAT_DRDCP2) return 3 * H.nb_ptr_c[H.total_cp];
     return -1;
 }
+// control-point-level pattern of K (neighbour lists incl. the control point itself, ascending): what the solver's symbolic phase works on -- 9 times smaller than
+// gf_pattern(GF_MAT_K), from which goldfish_amd/_solver.py: control_point_graph would otherwise recover it
+int64_t gf_cp_graph_size(const gf_handle* h) { return h ? (int64_t)h->H.nb_c.size() : -1; }
+int gf_cp_graph(const gf_handle* h, int64_t* nb_ptr, int32_t* nb) {
+    if (!h || !nb_ptr || !nb) return fail("gf_cp_graph: null argument");
+    const HostModel& H = h->H;
+    std::copy(H.nb_ptr_c.begin(), H.nb_ptr_c.end(), nb_ptr);
+    std::copy(H.nb_c.begin(), H.nb_c.end(), nb);
+    return 0;
+}
 int gf_pattern(const gf_handle* h, int which, int64_t* rowptr, int32_t* col) {
     if (!h || !rowptr || !col) return fail("gf_pattern: null argument");
     if (which < 0 || which > 4) return fail("gf_pattern: unknown matrix id");

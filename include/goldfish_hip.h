@@ -65,6 +65,10 @@ int gf_set_u(gf_handle* h, const double* u, int64_t n);
 /* static CSR patterns (row = vector dof).  which: GF_MAT_* of goldfish_model.h */
 int64_t gf_nnz(const gf_handle* h, int which);
 int     gf_pattern(const gf_handle* h, int which, int64_t* rowptr, int32_t* col);
+/* control-point-level pattern of K: nb_ptr [total_cp + 1], nb [gf_cp_graph_size]: the control points coupled to control point a (itself included), ascending --
+ * the block pattern of K (every entry stands for a 3 x 3 block) that goldfish_solver.h's gfs_create / gfs_create_nd / gfs_symbolic_create take */
+int64_t gf_cp_graph_size(const gf_handle* h);
+int     gf_cp_graph(const gf_handle* h, int64_t* nb_ptr, int32_t* nb);
 
 /* One pass of the hot path over the current state, results left in HBM:
  *   GF_ASM_R     RIGA()          nonmatching_opt.py:941-948  (assemble_RFE :726-770 + BCs)
