@@ -13,6 +13,7 @@
 // Solves: block forward / backward substitution with the inverted diagonal tiles (one launch per block column), then
 // iterative refinement with the block-CSR K.  Reference: the MUMPS solves of GOLDFISH/utils/opt_utils.py:156-209.
 #include "gf_nd_symbolic.hpp"
+#include <map>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -974,6 +975,7 @@ struct gfs_handle {
     std::vector<int> top;                    // the remaining fronts, in post-order
     // the sweeps are ~1e5 small launches with a fixed structure: captured once into HIP graphs (all streams), replayed per factorisation / substitution
     hipGraphExec_t g_factor = nullptr, g_solve = nullptr; bool use_graph = true;
+    std::map<void*, int> graph_calls; int graph_after = 3;        // direct launches for the first graph_after calls of every sweep (GF_SOLVER_GRAPH_AFTER)
     // partial handle (gfs_create_nd_partial: a sub-forest of the elimination tree -- a rank's own subtrees, or the top of the tree above stub fronts that stand for the
     // subtrees of other ranks): Schur complements of stub fronts come from device buffers (stub_src, copied in by gfs_refactor), the sweeps run in halves
     bool partial = false; std::vector<const double*> stub_src; hipGraphExec_t g_fwd = nullptr, g_bwd = nullptr;
@@ -1142,6 +1144,9 @@ static void nd_factor_levels(gfs_handle* h) {
 template <class Body> static void nd_run_captured(gfs_handle* h, hipGraphExec_t* exec, Body&& body, hipStream_t cs = nullptr) {
     if (!cs) cs = h->stream;
     if (!h->use_graph) { body(); return; }
+    // the first calls of a sweep launch directly: capturing + instantiating a graph of a few thousand nodes costs 0.3 - 0.6 s per sweep at C4 and pays back 9 ms per
+    // factorisation -- a session of a handful of solves never gets there (C4: the first solve 2.6 -> 1.4 s)
+    if (!*exec && h->graph_calls[(void*)exec]++ < h->graph_after) { body(); return; }
     if (!*exec) {
         hipGraph_t g = nullptr;
         // thread-local capture: only this thread's calls are checked against the capture, and a failure inside body() must not leave the stream
@@ -1349,6 +1354,7 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
         }
         h = new gfs_handle(); h->device = device; h->nd = true;
         if (const char* e_ = getenv("GF_SOLVER_GRAPH")) h->use_graph = std::string(e_) != "0";
+        if (const char* e_ = getenv("GF_SOLVER_GRAPH_AFTER")) h->graph_after = std::max(0, atoi(e_));
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreate(&h->stream));
         h->ncp = ncp; h->n = 3 * ncp; h->npad = h->n; h->nblk = 0; h->bw = 0;
