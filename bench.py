@@ -100,7 +100,7 @@ def workload_name(args):
 
 def kname_of(D, p):
     """Name of the dominant kernel of the path the handle runs (gf_assembly_path)."""
-    return {5: "kl_element_rec4_kernel", 4: "kl_element_rec_kernel", 3: "kl_element_kernel"}.get(D.assembly_path, "kl_element_mfma4_kernel" if p == 4 else "kl_element_mfma_kernel")
+    return {5: "kl_element_rec4_kernel", 4: "kl_element_rec_kernel", 3: "kl_element_kernel"}.get(D.assembly_path, "kl_element_mfma4_kernel" if p == 4 else "kl_element_mfma_kernel")   # 6 (p = 4 hybrid): the full pass runs the block kernel
 
 
 def parse_args(argv=None):

@@ -46,6 +46,8 @@ struct gf_handle {
     double *d_fun = nullptr, *d_pen_en = nullptr, *d_ve = nullptr;    // functional gradients [11*total_cp], penalty energies [npts]
     long long* d_pl_dof = nullptr; double* d_pl_val = nullptr;
     std::vector<Chunk> chunks;
+    std::vector<Chunk> rchunks;                      // p = 4 row-record path: its own chunks of patches (== chunks unless hybrid)
+    bool hybrid4 = false;                            // p = 4 default: Newton passes (R, K) through the row records, passes with dR/dCP / dR/dh through element blocks
     std::vector<hipEvent_t> ev0, ev1; int ev_n = 0;   // element-kernel timing
     bool assembled[5] = {false, false, false, false, false};
     bool rec = false;                                 // p = 2, 3, MFMA path, default: walking kernel that stores row records + kl_gather_rec_kernel (gf_element_rec.hpp); GF_ASSEMBLY=block: one block per element + row gather
@@ -98,6 +100,12 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             if (const char* s = getenv("GF_REC_SEG")) seg = std::max(1, atoi(s));
             H.tick("penalty owner lists, visit records");
             if (want_rec) { H.build_rec(seg); h->rec = H.degree <= 3; h->rec4 = H.degree == 4; H.tick("row-record tables"); }
+            // p = 4: each pass kind on the path that is faster for it (same-lease A/B on one GPU's share of C5, profiles/r04_c5share_*: Newton pass 21.3 ms through
+            // the records against 24.2 through element blocks, full pass 60.0 against 54.4).  GF_ASSEMBLY=rec: records for every pass (least memory and traffic),
+            // =block: element blocks for every pass
+            h->hybrid4 = h->rec4;
+            if (const char* s = getenv("GF_ASSEMBLY")) h->hybrid4 = h->hybrid4 && std::string(s) != "rec";
+
         }
         std::vector<long long> nbs(H.nb_ptr_s.begin(), H.nb_ptr_s.end()), nbc(H.nb_ptr_c.begin(), H.nb_ptr_c.end());
         h->d_cp4 = h->dalloc<double>(4 * H.total_cp); h->d_u = h->dalloc<double>(H.ndof); h->d_h = h->dalloc<double>(H.total_cp); h->d_R = h->dalloc<double>(H.ndof);
@@ -165,32 +173,47 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         const int P = H.degree, NB = (P + 1) * (P + 1), ND = 3 * NB;
         const bool recs = h->rec || h->rec4;
         // doubles of scratch per element: element blocks, or (row-record paths) the residual entries + the element's share of the records
-        const long long rec_sz = h->rec4 ? Rec4Cfg<21>::SZ : RecCfg<true>::SZ;
-        const long long blk_doubles = recs ? (long long)ND : 2LL * ND * ND + (long long)ND * NB + ND;
+        const long long rec_sz = h->rec4 ? (h->hybrid4 ? Rec4Cfg<9>::SZ : Rec4Cfg<21>::SZ) : RecCfg<true>::SZ;
+        const long long full_blk = 2LL * ND * ND + (long long)ND * NB + ND;
+        const long long blk_doubles = (recs && !h->hybrid4) ? (long long)ND : full_blk;
         // p = 4 records: up to 120 GB of row records per chunk of patches, capped by half of the free device memory -- full C5 (117 GB of records) then runs as ONE chunk on
-        // an empty MI355X (288 GB): chunks cost launch tails (3 chunks: 468 ms per pass, 8 chunks: 486 ms, same lease); GF_SCRATCH_GB overrides
-        double budget_gb = 40.0;
-        if (h->rec4) { size_t fb = 0, tb = 0; budget_gb = 120.0; if (hipMemGetInfo(&fb, &tb) == hipSuccess) budget_gb = std::min(budget_gb, 0.5 * (double)fb / 1e9); }
-        if (const char* s = getenv("GF_SCRATCH_GB")) budget_gb = atof(s);
+        // an empty MI355X (288 GB): chunks cost launch tails (3 chunks: 468 ms per pass, 8 chunks: 486 ms, same lease); GF_SCRATCH_GB overrides.
+        // Hybrid: the Newton-pass records (9 of 21 values per pair: 50 GB at C5) within a quarter of the free memory, the element blocks of the full pass within 30 % of it
+        double budget_gb = 40.0, rec_budget_gb = 1e9;
+        if (h->rec4) {
+            size_t fb = 0, tb = 0; double free_gb = 240.0;
+            if (hipMemGetInfo(&fb, &tb) == hipSuccess) free_gb = (double)fb / 1e9;
+            if (h->hybrid4) { rec_budget_gb = std::min(60.0, 0.25 * free_gb); budget_gb = std::min(80.0, 0.30 * free_gb); }
+            else { rec_budget_gb = std::min(120.0, 0.5 * free_gb); budget_gb = rec_budget_gb; }
+        }
+        if (const char* s = getenv("GF_SCRATCH_GB")) { budget_gb = atof(s); if (h->rec4) rec_budget_gb = budget_gb; }
         if (h->rec) budget_gb = 1e9;                      // p = 2, 3 records: one chunk
-        // p = 4 records: ~rec_sz doubles per element (one record row per element row and strip); chunks of whole patches within the budget
-        const double per_elem = h->rec4 ? double(rec_sz + ND) : double(blk_doubles);
-        const long long max_elems = std::max<long long>(1, (long long)(budget_gb * 1e9 / (per_elem * 8.0)));
+        // chunks of whole patches within a budget of ``per_elem`` doubles per element
+        auto make_chunks = [&](double gb, double per_elem, std::vector<Chunk>& out, long long& biggest, long long& biggest_items) {
+            const long long max_elems = std::max<long long>(1, (long long)(gb * 1e9 / (per_elem * 8.0)));
+            biggest = 0; biggest_items = 0;
+            for (int s = 0; s < H.n_owned;) {
+                Chunk c; c.p0 = s; c.e0 = H.patches[s].elem_off; c.a0 = H.patches[s].cp_off;
+                long long ne = 0;
+                while (s < H.n_owned) {
+                    const long long pe = (long long)H.patches[s].nelu * H.patches[s].nelv;
+                    if (ne > 0 && ne + pe > max_elems) break;
+                    ne += pe; ++s;
+                }
+                c.p1 = s; c.e1 = c.e0 + ne; c.a1 = (s < H.np) ? H.patches[s].cp_off : H.total_cp;
+                out.push_back(c); biggest = std::max(biggest, ne);
+                if (recs) {
+                    const long long i0 = H.rec_patch[c.p0].item_off, i1 = c.p1 < H.n_owned ? H.rec_patch[c.p1].item_off : (long long)H.rec_items.size();
+                    biggest_items = std::max(biggest_items, i1 - i0);
+                }
+            }
+        };
         long long biggest = 0, biggest_items = 0;
-        for (int s = 0; s < H.n_owned;) {
-            Chunk c; c.p0 = s; c.e0 = H.patches[s].elem_off; c.a0 = H.patches[s].cp_off;
-            long long ne = 0;
-            while (s < H.n_owned) {
-                const long long pe = (long long)H.patches[s].nelu * H.patches[s].nelv;
-                if (ne > 0 && ne + pe > max_elems) break;
-                ne += pe; ++s;
-            }
-            c.p1 = s; c.e1 = c.e0 + ne; c.a1 = (s < H.np) ? H.patches[s].cp_off : H.total_cp;
-            h->chunks.push_back(c); biggest = std::max(biggest, ne);
-            if (recs) {
-                const long long i0 = H.rec_patch[c.p0].item_off, i1 = c.p1 < H.n_owned ? H.rec_patch[c.p1].item_off : (long long)H.rec_items.size();
-                biggest_items = std::max(biggest_items, i1 - i0);
-            }
+        // p = 4 records: ~rec_sz doubles per element (one record row per element row and strip)
+        if (h->rec4 && !h->hybrid4) { make_chunks(rec_budget_gb, double(rec_sz + ND), h->chunks, biggest, biggest_items); h->rchunks = h->chunks; }
+        else {
+            make_chunks(budget_gb, double(blk_doubles), h->chunks, biggest, biggest_items);
+            if (h->hybrid4) { long long b2 = 0; make_chunks(rec_budget_gb, double(rec_sz + ND), h->rchunks, b2, biggest_items); biggest = std::max(biggest, (b2 * ND + blk_doubles - 1) / blk_doubles); }
         }
         long long scratch_doubles = biggest * blk_doubles;
         if (recs) {
@@ -386,7 +409,7 @@ static void run_assemble_rec4(gf_handle* h, int flags) {
     const HostModel& H = h->H;
     const bool mats = (flags & ~GF_ASM_R) != 0, full = (flags & (GF_ASM_DRDCP | GF_ASM_DRDH)) != 0;
     const int pen = run_penalty<4>(h, flags);
-    for (const Chunk& c : h->chunks) {
+    for (const Chunk& c : h->rchunks) {
         const long long i0 = H.rec_patch[c.p0].item_off, i1 = c.p1 < H.n_owned ? H.rec_patch[c.p1].item_off : (long long)H.rec_items.size();
         const unsigned n = (unsigned)(i1 - i0);
         const Rec4Out O{h->d_rec, h->d_blk, H.rec_rows, c.e0};
@@ -427,7 +450,7 @@ template <int P> static void run_assemble(gf_handle* h, int flags) {
     // and dropped: next to the element kernel they cost it LDS occupancy (17.7 -> 22.8 ms), next to the gather both slow down
     // by what the overlap saves (profiles/r01_v8_*).
     if ((P == 2 || P == 3) && h->rec) { run_assemble_rec<P>(h, flags); return; }
-    if (P == 4 && h->rec4) { run_assemble_rec4(h, flags); return; }
+    if (P == 4 && h->rec4 && !(h->hybrid4 && (flags & (GF_ASM_DRDCP | GF_ASM_DRDH)))) { run_assemble_rec4(h, flags); return; }
     const int pen = run_penalty<P>(h, flags);
     for (size_t ci = 0; ci < h->chunks.size(); ++ci) {
         const Chunk& c = h->chunks[ci];
@@ -661,7 +684,7 @@ double gf_kernel_ms(gf_handle* h, int* n_launches) {
 
 void* gf_stream(gf_handle* h) { return h ? (void*)h->stream : nullptr; }
 
-int gf_assembly_path(const gf_handle* h) { return !h ? -1 : (h->rec4 ? 5 : (h->rec ? 4 : (h->mfma ? 0 : 3))); }
+int gf_assembly_path(const gf_handle* h) { return !h ? -1 : (h->rec4 ? (h->hybrid4 ? 6 : 5) : (h->rec ? 4 : (h->mfma ? 0 : 3))); }
 
 int gf_get_functional_gradient(gf_handle* h, int field, double* out, int64_t n) {
     if (!h || !out) return fail("gf_get_functional_gradient: null argument");

@@ -768,23 +768,66 @@ class NonMatchingOpt:
     newton_step_rtol = 1e-9          # |du| / |u| below which a residual stuck at its round-off floor counts as a converged state
     newton_raise_unconverged = False  # True: an unconverged Newton solve raises instead of warning
 
+    newton_load_steps = 1            # > 1: the dead loads are applied in that many equal increments (each a Newton solve started from the previous one's state)
+
     def solve_nonlinear_nonmatching_problem(self, solver="direct", ref_error=None, rtol=1e-3, max_it=30,
-                                            zero_mortar_funcs=True, iga_dofs=True, POINT_SOURCE=True):
+                                            zero_mortar_funcs=True, iga_dofs=True, POINT_SOURCE=True, load_steps=None):
         """Newton iteration on R(u) = 0 (PENGoLINS; used by DispImOpeartion.solve_nonlinear,
         GOLDFISH/operations/disp_imop.py:38-44: max_it=30, rtol=1e-3 relative to the first residual, start from zero when
         zero_mortar_funcs).  Plain Newton as in the reference, with two safeguards it does not have:
 
         * backtracking: after the first step (the linear solution, whose residual legitimately exceeds |R_0| for a
           geometrically nonlinear shell) a step whose residual exceeds the largest of the last three (non-monotone rule) is halved, at most four times;
-        * honesty about the end of the iteration: ``newton_converged`` is True when |R| / ref < rtol, or when the Newton
-          correction has become negligible (|du| <= newton_step_rtol |u|) -- the residual of a thin, stiffly coupled shell
-          has an evaluation floor of about eps E h |A| (strain = difference of metrics) that a tight rtol cannot pass.
-          Every solve that ends otherwise warns (RuntimeWarning) or raises (``newton_raise_unconverged``);
-          ``newton_history`` keeps (|R| / ref, |du| / |u|, step length) per iteration."""
+        * honesty about the end of the iteration: ``newton_converged`` is True when |R| / ref < rtol and ONLY then (the reference's
+          criterion, disp_imop.py:38-44).  The iteration also ends when the Newton correction has become negligible
+          (|du| <= newton_step_rtol |u|: ``newton_converged_by_step``) or when the residual stagnates (``newton_stagnated``) -- the residual
+          of a thin, stiffly coupled shell has an evaluation floor that a tight rtol cannot pass --, but neither is reported as convergence:
+          every solve that ends with |R| / ref >= rtol warns (RuntimeWarning) or raises (``newton_raise_unconverged``);
+          ``newton_history`` keeps (|R| / ref, |du| / |u|, step length) per iteration.
+
+        ``load_steps`` (default ``newton_load_steps`` = 1: the reference's single solve): the dead loads are applied in that many equal increments,
+        R_s(u) = R(u) - (1 - s) R(0) for s = 1/n ... 1 (R(0) = -F_ext: the internal and penalty forces vanish at u = 0 and a dead load does not depend
+        on u, so no kernel knows about s), each increment a Newton solve from the previous state with the tolerance measured against the FULL load's
+        first residual.  A geometrically nonlinear shell whose full load is beyond Newton's reach from u = 0 converges this way.  Not for follower
+        pressures (their load depends on u); starts from u = 0."""
+        n_steps = int(self.newton_load_steps if load_steps is None else load_steps)
+        self._newton_load_offset = None
+        if n_steps > 1:
+            if any(getattr(r, "pressure", 0.0) != 0.0 for r in getattr(self, "residuals", []) or []):
+                raise NotImplementedError("solve_nonlinear_nonmatching_problem: load_steps > 1 with a follower pressure (its load depends on u)")
+            self.update_uIGA(np.zeros(self.vec_iga_dof))
+            self._assemble(_lib.ASM_R)
+            R_full0 = self.dev.residual().copy()                       # R(0) = -F_ext
+            ref_full = ref_error if ref_error is not None else (float(np.linalg.norm(R_full0)) or 1.0)
+            history, iters = [], 0
+            try:
+                for k in range(1, n_steps + 1):
+                    self._newton_load_offset = (1.0 - k / n_steps) * R_full0 if k < n_steps else None
+                    # intermediate increments only need to stay on the path: the reference's default tolerance, never tighter than the caller's
+                    self._newton_solve(ref_full, max(rtol, 1e-3) if k < n_steps else rtol, max_it)
+                    history += self.newton_history
+                    iters += self.newton_iterations
+                    if not self.newton_converged and k < n_steps and not np.all(np.isfinite(self.u_iga)):
+                        break
+            finally:
+                self._newton_load_offset = None
+            self.newton_history, self.newton_iterations, self.newton_load_steps_done = history, iters, k
+            return None, self.u_iga.copy()
         if zero_mortar_funcs:
             self.update_uIGA(np.zeros(self.vec_iga_dof))
-        self._assemble(_lib.ASM_R | _lib.ASM_K)
+        self._newton_solve(ref_error, rtol, max_it)
+        return None, self.u_iga.copy()
+
+    def _newton_residual(self):
+        """R of the current state as the Newton loop sees it: the assembled residual, minus the part of the dead loads a load increment holds back."""
         R = self.dev.residual()
+        off = getattr(self, "_newton_load_offset", None)
+        return R if off is None else R - off
+
+    def _newton_solve(self, ref_error, rtol, max_it):
+        """The Newton iteration of solve_nonlinear_nonmatching_problem from the current state (one load increment)."""
+        self._assemble(_lib.ASM_R | _lib.ASM_K)
+        R = self._newton_residual()
         nrm = float(np.linalg.norm(R))
         if ref_error is None:
             ref_error = nrm if nrm > 0 else 1.0
@@ -808,7 +851,7 @@ class NonMatchingOpt:
                 # the full step is usually accepted: R and K in one pass; a shortened trial needs |R| only (R-only pass: a third of the R + K pass at C4),
                 # the tangent of the state that is finally accepted follows below (_assemble launches only what is not current)
                 self._assemble(_lib.ASM_R | _lib.ASM_K if (lam == 1.0 and not reuse) else _lib.ASM_R)
-                Rn = self.dev.residual()
+                Rn = self._newton_residual()
                 nn = float(np.linalg.norm(Rn))
                 if chord and not (np.isfinite(nn) and nn <= 0.5 * hist[-1]):
                     break                             # a chord step must contract by itself: no backtracking on stale factors
@@ -821,7 +864,11 @@ class NonMatchingOpt:
                 # residual norm of a thin shell is a poor merit function -- the sliding-web T-beam goes 1, 208, 0.056, ~0.5, 1e-4, ... under plain Newton (the
                 # reference's iteration), and a monotone rule cuts its third step sixteen-fold and creeps (round 4; round 3 let that step through only by the
                 # overshoot bug the advisor flagged) --, while a diverging iteration (arctan from 3) still exceeds its recent history and is shortened.
-                if (np.isfinite(nn) and (it == 0 or nn <= max(hist[-3:]) or near_floor)) or lam <= 1.0 / 16.0:
+                # The residual of an OVERSHOOTING first step (hist[1] > hist[0]: unconditionally accepted, the T-beam's is 208 |R_0|) counts only as the PREVIOUS
+                # residual (the step right after it has to come down from there), not as a member of the window of the step after that -- which otherwise
+                # accepts anything up to the overshoot at full length
+                window = [h for k, h in enumerate(hist) if k >= len(hist) - 3 and not (k == 1 and len(hist) > 2 and hist[1] > hist[0])]
+                if (np.isfinite(nn) and (it == 0 or nn <= max(window) or near_floor)) or lam <= 1.0 / 16.0:
                     break
                 lam *= 0.5
             if chord and not (np.isfinite(nn) and nn <= 0.5 * hist[-1]):
@@ -844,7 +891,8 @@ class NonMatchingOpt:
             if nrm / ref_error < rtol:
                 converged = True
             elif rel_step <= self.newton_step_rtol and nrm < hist[0] and not was_chord:
-                converged = by_step = True            # (a chord step converges linearly: its size is no measure of the remaining error)
+                by_step = True                        # the state no longer moves, the residual is at its evaluation floor ABOVE rtol: the end of the iteration, not
+                break                                 # convergence (reported as such below; a chord step converges linearly: its size is no measure of the remaining error)
             elif (len(hist) >= 5 and min(hist[:-3]) < 0.1 * hist[0] and max(hist[-3:]) < hist[0]
                   and min(hist[-3:]) > 0.5 * min(hist[:-3])):
                 stagnated = True                      # after a real contraction (below a tenth of the first residual), three iterations that did not halve the best residual: the evaluation floor
@@ -853,13 +901,13 @@ class NonMatchingOpt:
         self.newton_converged, self.newton_converged_by_step, self.newton_stagnated, self.newton_iterations = converged, by_step, stagnated, it
         if not converged:
             msg = ("solve_nonlinear_nonmatching_problem: not converged after %d iterations%s: relative residual %.3e >= rtol %.1e, last "
-                   "relative Newton correction %.3e" % (it, " (residual stagnates: round-off floor of its evaluation)" if stagnated else "",
+                   "relative Newton correction %.3e" % (it, " (residual stagnates: round-off floor of its evaluation)" if stagnated else
+                                                       (" (the Newton correction is negligible, the residual sits at its evaluation floor)" if by_step else ""),
                                                        nrm / ref_error, rtol, self.newton_history[-1][1] if self.newton_history else float("nan")))
             if self.newton_raise_unconverged:
                 raise RuntimeError(msg)
             import warnings
             warnings.warn(msg, RuntimeWarning)
-        return None, self.u_iga.copy()
 
     # ------------------------------------------------------------------ convenience
     @classmethod

@@ -170,8 +170,10 @@ double gf_kernel_ms(gf_handle* h, int* n_launches);
 void* gf_stream(gf_handle* h);
 
 /* which element path gf_assemble runs on this handle: 4 = walking MFMA kernel that stores row records + record gather (default for
- * p = 2, 3), 5 = the same for p = 4 (three walks per pass, gf_element_rec4.hpp; default for p = 4), 0 = MFMA element kernel, one block per
- * element + row gather (GF_ASSEMBLY=block: the cross-check path), 3 = FP64-VALU element kernel + gather (GF_ELEMENT=valu) */
+ * p = 2, 3), 6 = p = 4 default: Newton passes (R, K) through row records (one walk, gf_element_rec4.hpp), passes with dR/dCP / dR/dh through
+ * element blocks (each pass kind on the path that is faster for it), 5 = p = 4 with row records for every pass (three walks per full pass;
+ * GF_ASSEMBLY=rec: half the memory and traffic), 0 = MFMA element kernel, one block per element + row gather (GF_ASSEMBLY=block: the
+ * cross-check path), 3 = FP64-VALU element kernel + gather (GF_ELEMENT=valu) */
 int gf_assembly_path(const gf_handle* h);
 
 #ifdef __cplusplus

@@ -71,7 +71,9 @@ def test_assembly_parity(oracle_lib, case):
     A, h, u = _state(spec)
     O = Oracle(A, thickness=h, u=u)
     D = _lib.DeviceModel(A)
-    assert D.assembly_path == (5 if int(A.degree[0]) == 4 else 4)     # walking MFMA kernels + row records + record gather (p = 4: three walks per pass, gf_element_rec4.hpp)
+    # p = 2, 3: walking MFMA kernel + row records + record gather; p = 4: hybrid (Newton passes through the row records of gf_element_rec4.hpp, passes with
+    # dR/dCP / dR/dh through element blocks: each pass kind on its faster path)
+    assert D.assembly_path == (6 if int(A.degree[0]) == 4 else 4)
     D.set_thickness(h)
     D.set_u(u)
     D.assemble(_lib.ASM_ALL)
@@ -112,7 +114,7 @@ def test_row_record_path_segment_lengths_and_block_path(oracle_lib, monkeypatch,
         vals, Ro = O.assemble(), O.residual()
         out = {}
         for walk in ("2", "0"):
-            if walk == "2": monkeypatch.delenv("GF_ASSEMBLY", raising=False)      # the default path
+            if walk == "2": monkeypatch.setenv("GF_ASSEMBLY", "rec")              # row records for every pass (the default for p = 2, 3; p = 4: the low-memory path)
             else: monkeypatch.setenv("GF_ASSEMBLY", "block")                    # one block per element + row gather: the cross-check path
             monkeypatch.setenv("GF_REC_SEG", seg)
             D = _lib.DeviceModel(A)
@@ -309,6 +311,7 @@ def test_p4_record_chunks_give_identical_results(monkeypatch):
     spec = G.synthetic_shell(3, 2, nel=6, p=4, jitter=1)
     A, h, u = _state(spec, seed=5)
     out = []
+    monkeypatch.setenv("GF_ASSEMBLY", "rec")
     for gb in ("16", "0.0012"):
         monkeypatch.setenv("GF_SCRATCH_GB", gb)
         D = _lib.DeviceModel(A)
@@ -324,6 +327,41 @@ def test_p4_record_chunks_give_identical_results(monkeypatch):
     for x, y in zip(*out):
         assert np.array_equal(x, y)
     assert np.array_equal(out[0][0], out[0][6]) and np.array_equal(out[0][1], out[0][7])       # Newton pass (9 values per pair) = full pass
+
+
+def test_p4_hybrid_path_chunks_and_pass_kinds(oracle_lib, monkeypatch):
+    """p = 4 default (hybrid): a Newton pass (R, K) runs through the row records, a pass with dR/dCP / dR/dh through element blocks -- each on its own chunks of
+    patches.  Both against the oracle, K of the two pass kinds equal to round-off, and chunked scratch (one chunk per patch for either path) bitwise equal to one chunk."""
+    from goldfish_amd import _lib
+    from oracle.oracle_py import Oracle
+    spec = G.synthetic_shell(3, 2, nel=6, p=4, jitter=1)
+    A, h, u = _state(spec, seed=5)
+    O = Oracle(A, thickness=h, u=u)
+    vals, Ro = O.assemble(), O.residual()
+    out = []
+    for gb in (None, "0.004", "0.0012"):
+        if gb is None: monkeypatch.delenv("GF_SCRATCH_GB", raising=False)
+        else: monkeypatch.setenv("GF_SCRATCH_GB", gb)
+        D = _lib.DeviceModel(A)
+        assert D.assembly_path == 6
+        D.set_thickness(h)
+        D.set_u(u)
+        D.assemble(_lib.ASM_R | _lib.ASM_K)                       # records
+        res = [D.residual(), D.values(0)]
+        D.assemble()                                              # element blocks
+        res += [D.residual()] + [D.values(w) for w in range(5)]
+        D.assemble(_lib.ASM_K)                                    # records again: the full pass left nothing behind that they depend on
+        res += [D.values(0)]
+        out.append(res)
+        D.close()
+    for other in out[1:]:
+        for x, y in zip(out[0], other):
+            assert np.array_equal(x, y)
+    r = out[0]
+    assert _rel(r[0], Ro) < RTOL and _rel(r[2], Ro) < RTOL and _rel(r[1], vals[0]) < RTOL
+    for w in range(5):
+        assert _rel(r[3 + w], vals[w]) < RTOL
+    assert np.array_equal(r[1], r[8]) and _rel(r[1], r[3]) < 1e-13
 
 
 def test_single_patch_without_interfaces(oracle_lib):
