@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
     const RowLane L(x);                                  // lane constants of the row expansion (independent of the loads above)
     if (tid < NB) {
         s_c[tid][0] = c4.x; s_c[tid][1] = c4.y; s_c[tid][2] = c4.z; s_w[tid] = c4.w;
-        s_d[tid][0] = c4.x + ux; s_d[tid][1] = c4.y + uy; s_d[tid][2] = c4.z + uz;
+        s_d[tid][0] = ux; s_d[tid][1] = uy; s_d[tid][2] = uz;            // displacement coefficients (kl_strains)
         s_h[tid] = hh;
     }
     if (tid < P1 * 3 * P1) { s_tu[tid] = ttu; s_tv[tid] = ttv; }

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
         const double4 c4 = reinterpret_cast<const double4*>(M.cp4)[g];
         const double ux = M.u[3 * g], uy = M.u[3 * g + 1], uz = M.u[3 * g + 2];
         s_c[tid][0] = c4.x; s_c[tid][1] = c4.y; s_c[tid][2] = c4.z; s_w[tid] = c4.w;
-        s_d[tid][0] = c4.x + ux; s_d[tid][1] = c4.y + uy; s_d[tid][2] = c4.z + uz;
+        s_d[tid][0] = ux; s_d[tid][1] = uy; s_d[tid][2] = uz;            // displacement coefficients (kl_strains)
         s_h[tid] = M.h[g];
     }
     for (int k = tid; k < P1 * 3 * P1; k += 64) { s_tu[k] = M.tab[ed.tabu + k]; s_tv[k] = M.tab[ed.tabv + k]; }
@@ -81,15 +81,15 @@ __global__ __launch_bounds__(64) void kl_element_mfma4_kernel(DevModel M, int e_
             }
         }
         W[0] = 1.0 / W[0];
-        double z[15], Z[15], R[6];
+        double z[15], Z[15], dz[15], R[6];
         for (int i = 0; i < 3; ++i) {
             rationalize6(Ac[i], W, R);
             for (int m = 0; m < 5; ++m) Z[3 * m + i] = R[m + 1];
-            rationalize6(Ad[i], W, R);
-            for (int m = 0; m < 5; ++m) z[3 * m + i] = R[m + 1];
+            rationalize6(Ad[i], W, R);                       // s_d holds the displacement coefficients: dz = z - Z (kl_point.hpp: kl_strains)
+            for (int m = 0; m < 5; ++m) { dz[3 * m + i] = R[m + 1]; z[3 * m + i] = Z[3 * m + i] + R[m + 1]; }
         }
         double* im = s_im[tid];
-        shell_point(z, Z, t, s_pc[0], s_pc[1], im);
+        shell_point(z, Z, dz, t, s_pc[0], s_pc[1], im);
         for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
         im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
     }

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
         if (tid < NB) {
             const double* rw = s_raw[(iv0 + tid / P1) & 7][tid % P1];
             s_c[tid][0] = rw[0]; s_c[tid][1] = rw[1]; s_c[tid][2] = rw[2]; s_w[tid] = rw[3];
-            s_d[tid][0] = rw[0] + rw[4]; s_d[tid][1] = rw[1] + rw[5]; s_d[tid][2] = rw[2] + rw[6];
+            s_d[tid][0] = rw[4]; s_d[tid][1] = rw[5]; s_d[tid][2] = rw[6];      // displacement coefficients (kl_strains)
             s_h[tid] = rw[7];
         }
         wave_lds_sync();

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
             if (a < NB) {
                 if (pa_q == 0) { s_c[a][0] = F.cp[r].x; s_c[a][1] = F.cp[r].y; }
                 else if (pa_q == 1) { s_c[a][2] = F.cp[r].x; s_w[a] = F.cp[r].y; }
-                else if (pa_q == 2) { s_d[a][0] = F.cp[r].x; s_d[a][1] = F.cp[r].y; }     // displacements for now; c is added below
+                else if (pa_q == 2) { s_d[a][0] = F.cp[r].x; s_d[a][1] = F.cp[r].y; }     // displacement coefficients (the strains are evaluated from their derivatives: kl_strains)
                 else { s_d[a][2] = F.cp[r].x; s_h[a] = F.cp[r].y; }
             }
             const int k = tid + 64 * r;
@@ -117,7 +117,6 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
         }
         if (tid < P1) s_wg[P1 + tid] = F.wv;
         wave_lds_sync();
-        if (tid < NB) { s_d[tid][0] += s_c[tid][0]; s_d[tid][1] += s_c[tid][1]; s_d[tid][2] += s_c[tid][2]; }      // deformed control points c + u
     };
     {   // prologue: u table and weights of the strip, inputs of the first element
         for (int k = tid; k < TS; k += 64) s_tu[k] = M.tab[p_tabu + it.eu * TS + k];
@@ -178,15 +177,15 @@ __global__ __launch_bounds__(64) void kl_element_rec4_kernel(DevModel M, const W
                 }
             }
             W[0] = 1.0 / W[0];
-            double z[15], Z[15], R[6];
+            double z[15], Z[15], dz[15], R[6];
             for (int i = 0; i < 3; ++i) {
                 rationalize6(Ac[i], W, R);
                 for (int m = 0; m < 5; ++m) Z[3 * m + i] = R[m + 1];
-                rationalize6(Ad[i], W, R);
-                for (int m = 0; m < 5; ++m) z[3 * m + i] = R[m + 1];
+                rationalize6(Ad[i], W, R);                       // s_d holds the displacement coefficients: dz = z - Z (kl_point.hpp: kl_strains)
+                for (int m = 0; m < 5; ++m) { dz[3 * m + i] = R[m + 1]; z[3 * m + i] = Z[3 * m + i] + R[m + 1]; }
             }
             double* im = s_im[tid];
-            shell_point<PASS != 0>(z, Z, th, s_pc[0], s_pc[1], im);      // the K walk needs no reference-configuration derivatives
+            shell_point<PASS != 0>(z, Z, dz, th, s_pc[0], s_pc[1], im);      // the K walk needs no reference-configuration derivatives
             for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
             im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
         }

@@ -76,7 +76,7 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned off, d
 // per row jv of control points the three u-sums, then the six (du, dv) combinations; the rational derivatives follow by the
 // quotient rule, rationalize6 being linear in the B-spline values), the three lanes exchange their components through the Gauss
 // point's (not yet written) record, and each produces the record columns c = ic, 3 + ic (kl_point.hpp: shell_point_cols).
-// s_c / s_d: reference / deformed homogeneous control points of the element, s_w weights, s_h thickness; tu / tv: 1-D tables
+// s_c / s_d: reference homogeneous control points / displacement coefficients of the element, s_w weights, s_h thickness; tu / tv: 1-D tables
 // [gp][3][p+1]; wgu / wgv: Gauss weights x span length / 2; pc: E, nu of the patch.  Leaves s_im[gp] complete (one wave: in order).
 template <int P, bool WITHC>
 __device__ __forceinline__ void point_phase(int x, int kk, const double* tu, const double* tv, const double (*s_c)[3], const double (*s_d)[3],
@@ -120,12 +120,12 @@ __device__ __forceinline__ void point_phase(int x, int kk, const double* tu, con
         for (int mm = 0; mm < 5; ++mm) im[15 + 3 * mm + ic] = R[mm + 1];
     }
     wave_lds_sync();
-    double z[15], Z[15];
-    if (act) for (int k = 0; k < 15; ++k) { Z[k] = im[k]; z[k] = im[15 + k]; }
+    double z[15], Z[15], dz[15];                        // s_d holds the displacement coefficients: Ad sums to dz = z - Z (kl_point.hpp: kl_strains)
+    if (act) for (int k = 0; k < 15; ++k) { Z[k] = im[k]; dz[k] = im[15 + k]; z[k] = Z[k] + dz[k]; }
     wave_lds_sync();                                   // all three lanes hold z, Z before the record overwrites the exchange slots
     if (act) {
         const double dsel[3] = {ic == 0 ? 1.0 : 0.0, ic == 1 ? 1.0 : 0.0, ic == 2 ? 1.0 : 0.0};
-        shell_point_cols<WITHC>(z, Z, th, pc[0], pc[1], ic, dsel, kk == 0, im);
+        shell_point_cols<WITHC>(z, Z, dz, th, pc[0], pc[1], ic, dsel, kk == 0, im);
         if (kk == 0) {
             for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
             im[IM_WQ] = wgu[gu] * wgv[gv];

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, (P >= 4 ? 1 : ElemCfg<P>::NT / 64))
         const double4 c4 = reinterpret_cast<const double4*>(M.cp4)[g];
         const double ux = M.u[3 * g], uy = M.u[3 * g + 1], uz = M.u[3 * g + 2];
         s_c[tid][0] = c4.x; s_c[tid][1] = c4.y; s_c[tid][2] = c4.z; s_w[tid] = c4.w;
-        s_d[tid][0] = c4.x + ux; s_d[tid][1] = c4.y + uy; s_d[tid][2] = c4.z + uz;
+        s_d[tid][0] = ux; s_d[tid][1] = uy; s_d[tid][2] = uz;            // displacement coefficients: the strains are evaluated from their derivatives (kl_strains)
         s_h[tid] = M.h[g];
     }
     for (int k = tid; k < P1 * 3 * P1; k += NT) { s_tu[k] = M.tab[Pt.tabu + eu * P1 * 3 * P1 + k]; s_tv[k] = M.tab[Pt.tabv + ev * P1 * 3 * P1 + k]; }
@@ -117,15 +117,16 @@ __global__ __launch_bounds__(ElemCfg<P>::NT, (P >= 4 ? 1 : ElemCfg<P>::NT / 64))
         double W[6] = {0, 0, 0, 0, 0, 0}, Nb[6], R[6];
         for (int a = 0; a < NB; ++a) { bspline6<P>(s_tu, s_tv, gu, gv, a, Nb); for (int k = 0; k < 6; ++k) W[k] += Nb[k] * s_w[a]; }
         W[0] = 1.0 / W[0];
-        double z[15], Z[15], t = 0.0;
-        for (int k = 0; k < 15; ++k) { z[k] = 0.0; Z[k] = 0.0; }
+        double z[15], Z[15], dz[15], t = 0.0;
+        for (int k = 0; k < 15; ++k) { dz[k] = 0.0; Z[k] = 0.0; }
         for (int a = 0; a < NB; ++a) {
             bspline6<P>(s_tu, s_tv, gu, gv, a, Nb); rationalize6(Nb, W, R);
             t += Nb[0] * s_h[a];
-            for (int m = 0; m < 5; ++m) for (int i = 0; i < 3; ++i) { Z[3 * m + i] += R[m + 1] * s_c[a][i]; z[3 * m + i] += R[m + 1] * s_d[a][i]; }
+            for (int m = 0; m < 5; ++m) for (int i = 0; i < 3; ++i) { Z[3 * m + i] += R[m + 1] * s_c[a][i]; dz[3 * m + i] += R[m + 1] * s_d[a][i]; }
         }
+        for (int k = 0; k < 15; ++k) z[k] = Z[k] + dz[k];
         double* im = s_im[tid];
-        shell_point(z, Z, t, Pt.E, Pt.nu_, im);
+        shell_point(z, Z, dz, t, Pt.E, Pt.nu_, im);
         for (int k = 0; k < 6; ++k) im[IM_W + k] = W[k];
         im[IM_WQ] = s_wg[gu] * s_wg[P1 + gv];
     }
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KIND == 2 ? 
         const long long g = ed.g0 + (a % P1) + (long long)(a / P1) * ed.nu;
         const double4 c4 = reinterpret_cast<const double4*>(M.cp4)[g];
         s_c[el][a][0] = c4.x; s_c[el][a][1] = c4.y; s_c[el][a][2] = c4.z; s_w[el][a] = c4.w;
-        s_d[el][a][0] = c4.x + M.u[3 * g]; s_d[el][a][1] = c4.y + M.u[3 * g + 1]; s_d[el][a][2] = c4.z + M.u[3 * g + 2];
+        s_d[el][a][0] = M.u[3 * g]; s_d[el][a][1] = M.u[3 * g + 1]; s_d[el][a][2] = M.u[3 * g + 2];      // displacement coefficients (kl_strains)
         s_h[el][a] = M.h[g];
         if constexpr (KIND == 2) s_c0[el][a] = S.cp0[g];
     }
@@ -710,12 +711,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KIND == 2 ? 
                 }
             }
             W[0] = 1.0 / W[0];
-            double z[15], Z[15], R[6];
+            double z[15], Z[15], dz[15], R[6];
             for (int i = 0; i < 3; ++i) {
                 rationalize6(Ac[i], W, R);
                 for (int m = 0; m < 5; ++m) Z[3 * m + i] = R[m + 1];
                 rationalize6(Ad[i], W, R);
-                for (int m = 0; m < 5; ++m) z[3 * m + i] = R[m + 1];
+                for (int m = 0; m < 5; ++m) { dz[3 * m + i] = R[m + 1]; z[3 * m + i] = Z[3 * m + i] + R[m + 1]; }
             }
             double* fe = s_fe[el][gpi];
             if constexpr (KIND == 2) {
@@ -736,10 +737,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KIND == 2 ? 
                 fe[FE_J] = -cf * 2.0 * dot3(wv, Z) * iJ;                 // d/dD_,2
                 fe[FE_SIZE + 7] = 0.0;
             } else if constexpr (KIND == 0) {
-                shell_energy_point(z, Z, t, Pt.E, Pt.nu_, fe);
+                shell_energy_point(z, Z, dz, t, Pt.E, Pt.nu_, fe);
                 fe[FE_SIZE + 7] = t;
             } else {
-                shell_stress_point(z, Z, t, Pt.E, Pt.nu_, S.sgn, S.measure, fe);
+                shell_stress_point(z, Z, dz, t, Pt.E, Pt.nu_, S.sgn, S.measure, fe);
                 const double sig = fe[0], J = fe[1], ms = S.m_list[pid];
                 double g, gp;                                           // g(sigma), g'(sigma)
                 if (S.mode == 0) { g = exp(S.rho * (sig - ms)); gp = S.rho * g; }
@@ -918,9 +919,9 @@ __global__ __launch_bounds__(64) void pen_point_kernel(DevModel M, DevPenalty Q,
     const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= Q.npts) return;
     const int itf = Q.pt_iface[v];
-    double y[18], Y[12];
+    double y[18], Y[12], dY[12];
     for (int k = 0; k < 18; ++k) y[k] = 0.0;
-    for (int k = 0; k < 12; ++k) Y[k] = 0.0;
+    for (int k = 0; k < 12; ++k) { Y[k] = 0.0; dY[k] = 0.0; }
     for (int sd = 0; sd < 2; ++sd) {
         const PatchDev& Pt = M.patches[Q.if_patch[2 * itf + sd]];
         const int iu0 = Q.pt_base[4 * v + 2 * sd], iv0 = Q.pt_base[4 * v + 2 * sd + 1];
@@ -930,13 +931,14 @@ __global__ __launch_bounds__(64) void pen_point_kernel(DevModel M, DevPenalty Q,
             const double r0 = nu[a], r1 = nu[NB + a], r2 = nu[2 * NB + a];
             for (int k = 0; k < 3; ++k) {
                 const double c = M.cp4[4 * g + k], uu = M.u[3 * g + k];
-                y[9 * sd + k] += r0 * uu; y[9 * sd + 3 + k] += r1 * (c + uu); y[9 * sd + 6 + k] += r2 * (c + uu);
+                y[9 * sd + k] += r0 * uu; dY[6 * sd + k] += r1 * uu; dY[6 * sd + 3 + k] += r2 * uu;
                 Y[6 * sd + k] += r1 * c; Y[6 * sd + 3 + k] += r2 * c;
             }
         }
+        for (int k = 0; k < 6; ++k) y[9 * sd + 3 + k] = Y[6 * sd + k] + dY[6 * sd + k];      // deformed tangents = reference + displacement tangents
     }
     // grad_only: 0 = gradient + both Hessian blocks, 1 = gradient only, 2 = gradient + Hyy (Newton pass), 3 = gradient + HyC
-    penalty_point(y, Y, Q.pt_tau + 2 * v, Q.if_alpha[2 * itf], Q.if_alpha[2 * itf + 1], Q.pt_wt[v], pbuf + (size_t)v * PB_STRIDE, grad_only == 1,
+    penalty_point(y, Y, dY, Q.pt_tau + 2 * v, Q.if_alpha[2 * itf], Q.if_alpha[2 * itf + 1], Q.pt_wt[v], pbuf + (size_t)v * PB_STRIDE, grad_only == 1,
                   grad_only == 2 ? 1 : (grad_only == 3 ? 2 : 3));
 }
 

@@ -125,7 +125,10 @@ __device__ inline void penalty_tables(int role, const double* y, const double* Y
 // combine step (one lane, behind the six): e1, e2, the scaled constants, the gradient of the energy, the energy
 __device__ inline void penalty_combine(const double* y, double ad, double ar, double* T) {
     double* sc = T + PT_SC;
-    const double e1 = sc[0] - sc[3], e2 = sc[1] - sc[4], c0 = sc[2];
+    // e1 = s1 - S1, e2 = s2 - S2 evaluated from the displacement tangents (y + 30: dY; y + 18: Y) without the cancellation (kl_point.hpp: pen_rot_measures)
+    double e1, e2;
+    pen_rot_measures(y + 18, y + 30, sc + 6, e1, e2);
+    const double c0 = sc[2];
     const double d[3] = {y[0] - y[9], y[1] - y[10], y[2] - y[11]};
     const int tan[12] = {3, 4, 5, 6, 7, 8, 12, 13, 14, 15, 16, 17};
     for (int k = 0; k < 18; ++k) T[PT_GL + k] = 0.0;
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(64) void pen_point16_kernel(DevModel M, DevPenalty 
     const long long v = vok ? v0 : Q.npts - 1;
     // LDS: the partial sums of phase A and the tables of phases B / C share the space (the sums are consumed before the tables are written)
     __shared__ __attribute__((aligned(16))) double s_buf[4][PT_SIZE + 144 > 480 ? PT_SIZE + 144 : 480];
-    __shared__ __attribute__((aligned(16))) double s_y[4][32];
+    __shared__ __attribute__((aligned(16))) double s_y[4][44];            // y (18) | Y (12) | dY (12: the displacement tangents)
     const int itf = Q.pt_iface[v];
     // ---- A: kinematics
     {
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(64) void pen_point16_kernel(DevModel M, DevPenalty 
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const double cc = M.cp4[4 * gcp + k], uu = M.u[3 * gcp + k];
-                    part[9 * sd + k] = r0 * uu; part[9 * sd + 3 + k] = r1 * (cc + uu); part[9 * sd + 6 + k] = r2 * (cc + uu);
+                    part[9 * sd + k] = r0 * uu; part[9 * sd + 3 + k] = r1 * uu; part[9 * sd + 6 + k] = r2 * uu;       // displacement tangents for now
                     part[18 + 6 * sd + k] = r1 * cc; part[18 + 6 * sd + 3 + k] = r2 * cc;
                 }
             }
@@ -214,6 +217,12 @@ __global__ __launch_bounds__(64) void pen_point16_kernel(DevModel M, DevPenalty 
 #pragma unroll
         for (int q = 0; q < 16; ++q) s += s_buf[g][16 * k + q];               // fixed order
         s_y[g][k] = s;
+    }
+    wave_lds_sync();
+    if (c < 12) {                                                           // deformed tangents = reference + displacement tangents; the latter are kept (dY)
+        const int ys = c < 6 ? 3 + c : 6 + c;
+        const double dy = s_y[g][ys];
+        s_y[g][30 + c] = dy; s_y[g][ys] = s_y[g][18 + c] + dy;
     }
     wave_lds_sync();
     // ---- B: the small quantities (all 16 lanes of the row, by role), then the combine step

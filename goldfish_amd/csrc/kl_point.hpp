@@ -116,10 +116,36 @@ GF_HD __forceinline__ void symmv(const double* C, const double* x, double* y) {
     y[2] = C[2] * x[0] + C[4] * x[1] + C[5] * x[2];
 }
 
-// Everything a Gauss point contributes, in compact form.  z, Z: [15]; out: IM record (W slots untouched).
+
+// ---- strains from the DISPLACEMENT derivatives (round 5) ------------------------------------------------------------------------------------------
+// The reference's forms (ShNAPr surfaceEnergyDensitySVK) evaluate eps = (a - A) / 2 and kappa = B - b as differences of the metric / curvature coefficients
+// of the two configurations: an absolute error of eps_machine |A|^2 in a strain that is 1e-6 ... 1e-10 for the thin shells of the demos, i.e. a floor of the
+// residual of about eps_machine E h |A|^2 |grad N| per entry however small the load (Newton stalled above the reference's rtol = 1e-3 on C4).
+// With dz = z - Z formed from the displacement coefficients alone (the callers sum U instead of c + U: the rational basis is linear in the coefficients) the
+// same strains follow without cancellation:
+//     eps_ab   = (Z_a . dz_b + dz_a . Z_b + dz_a . dz_b) / 2
+//     n - N    = (delta - N s / (j + J)) / j,   delta = Z_1 x dz_2 + dz_1 x Z_2 + dz_1 x dz_2,   s = j^2 - J^2 = 2 J N . delta + delta . delta
+//     kappa_ab = H_ab . N - h_ab . n = -(H_ab . (n - N) + dh_ab . n)
+// Everything else of the closed forms (first / second derivatives) multiplies these and is evaluated as before.  oracle/kl_oracle.c has both evaluations
+// (gfo_set_strain_mode); tests/test_strain_evaluation.py compares them.
+GF_HD __forceinline__ void kl_strains(const double* Z, const double* dz, const double* n, const double* N, double j, double Jn, double* eps, double* kap) {
+    eps[0] = dot3(Z, dz) + 0.5 * dot3(dz, dz);
+    eps[1] = dot3(Z + 3, dz + 3) + 0.5 * dot3(dz + 3, dz + 3);
+    eps[2] = dot3(Z, dz + 3) + dot3(dz, Z + 3) + dot3(dz, dz + 3);
+    double a[3], b[3], c[3], dl[3], dn[3];
+    cross3(Z, dz + 3, a); cross3(dz, Z + 3, b); cross3(dz, dz + 3, c);
+    for (int k = 0; k < 3; ++k) dl[k] = a[k] + b[k] + c[k];
+    const double f = (2.0 * Jn * dot3(N, dl) + dot3(dl, dl)) / (j + Jn), ij = 1.0 / j;
+    for (int k = 0; k < 3; ++k) dn[k] = (dl[k] - N[k] * f) * ij;
+    kap[0] = -(dot3(Z + 6, dn) + dot3(dz + 6, n));
+    kap[1] = -(dot3(Z + 9, dn) + dot3(dz + 9, n));
+    kap[2] = -2.0 * (dot3(Z + 12, dn) + dot3(dz + 12, n));
+}
+
+// Everything a Gauss point contributes, in compact form.  z, Z: [15]; dz = z - Z from the displacement coefficients; out: IM record (W slots untouched).
 // REF = false (passes without dR/dCP: the K walk of gf_element_rec4.hpp): the reference-configuration derivatives (IM_JZJ, IM_JDNV, IM_JDMO) are not produced.
 template <bool REF = true>
-GF_HD inline void shell_point(const double* z, const double* Z, double t, double E, double nu, double* im) {
+GF_HD inline void shell_point(const double* z, const double* Z, const double* dz, double t, double E, double nu, double* im) {
     const double f3[3] = {1.0, 1.0, 2.0};
     double n[3], N[3], j, Jn, Dn[3][6], DN[3][6];
     normal_derivs(z, z + 3, n, j, Dn);
@@ -127,10 +153,7 @@ GF_HD inline void shell_point(const double* z, const double* Z, double t, double
     double C[6], dC[3][6], J;
     material(Z, Z + 3, E, nu, C, dC, J);
     double eps[3], kap[3];
-    eps[0] = 0.5 * (dot3(z, z) - dot3(Z, Z));
-    eps[1] = 0.5 * (dot3(z + 3, z + 3) - dot3(Z + 3, Z + 3));
-    eps[2] = dot3(z, z + 3) - dot3(Z, Z + 3);
-    for (int k = 0; k < 3; ++k) kap[k] = f3[k] * (dot3(Z + 6 + 3 * k, N) - dot3(z + 6 + 3 * k, n));
+    kl_strains(Z, dz, n, N, j, Jn, eps, kap);
     const double t3 = t * t * t / 12.0;
     double Ce[3], Ck[3], nv[3], mo[3];
     symmv(C, eps, Ce); symmv(C, kap, Ck);
@@ -195,7 +218,7 @@ GF_HD inline void shell_point(const double* z, const double* Z, double t, double
 // stream on the GPU) and written by the caller with lead = true.  Same formulas as shell_point above.
 // ref = false (Newton pass: no dR/dCP): the reference-configuration derivatives (IM_JDNV, IM_JDMO) are not produced.
 template <bool REF = true>
-GF_HD inline void shell_point_cols(const double* z, const double* Z, double t, double E, double nu, int ic, const double* d, bool lead, double* im) {
+GF_HD inline void shell_point_cols(const double* z, const double* Z, const double* dz, double t, double E, double nu, int ic, const double* d, bool lead, double* im) {
     const double f3[3] = {1.0, 1.0, 2.0};
     double nt[3], n[3], Nt[3], N[3];
     cross3(z, z + 3, nt); const double j = sqrt(dot3(nt, nt)), ij = 1.0 / j;
@@ -204,10 +227,7 @@ GF_HD inline void shell_point_cols(const double* z, const double* Z, double t, d
     double C[6], dC[3][6], J;
     material(Z, Z + 3, E, nu, C, dC, J);
     double eps[3], kap[3];
-    eps[0] = 0.5 * (dot3(z, z) - dot3(Z, Z));
-    eps[1] = 0.5 * (dot3(z + 3, z + 3) - dot3(Z + 3, Z + 3));
-    eps[2] = dot3(z, z + 3) - dot3(Z, Z + 3);
-    for (int k = 0; k < 3; ++k) kap[k] = f3[k] * (dot3(Z + 6 + 3 * k, N) - dot3(z + 6 + 3 * k, n));
+    kl_strains(Z, dz, n, N, j, Jn, eps, kap);
     const double t3 = t * t * t / 12.0;
     double Ce[3], Ck[3], nv[3], mo[3];
     symmv(C, eps, Ce); symmv(C, kap, Ck);
@@ -359,7 +379,7 @@ GF_HD __forceinline__ double load_dz_dot(const double* im, const double* pd, con
 // ---- energy functionals: first derivatives of Psi wrt z, Z, t and of the area Jacobian ----------
 // out: [0] Psi, [1] J, [2] dPsi/dt, [3..17] dPsi/dz, [18..32] dPsi/dZ, [33..38] dJ/d(G1,G2)
 enum : int { FE_PSI = 0, FE_J = 1, FE_PT = 2, FE_PZ = 3, FE_PZR = 18, FE_JZ = 33, FE_SIZE = 39 };
-GF_HD inline void shell_energy_point(const double* z, const double* Z, double t, double E, double nu, double* out) {
+GF_HD inline void shell_energy_point(const double* z, const double* Z, const double* dz, double t, double E, double nu, double* out) {
     const double f3[3] = {1.0, 1.0, 2.0};
     double n[3], N[3], j, Jn, Dn[3][6], DN[3][6];
     normal_derivs(z, z + 3, n, j, Dn);
@@ -367,10 +387,7 @@ GF_HD inline void shell_energy_point(const double* z, const double* Z, double t,
     double C[6], dC[3][6], J;
     material(Z, Z + 3, E, nu, C, dC, J);
     double eps[3], kap[3];
-    eps[0] = 0.5 * (dot3(z, z) - dot3(Z, Z));
-    eps[1] = 0.5 * (dot3(z + 3, z + 3) - dot3(Z + 3, Z + 3));
-    eps[2] = dot3(z, z + 3) - dot3(Z, Z + 3);
-    for (int k = 0; k < 3; ++k) kap[k] = f3[k] * (dot3(Z + 6 + 3 * k, N) - dot3(z + 6 + 3 * k, n));
+    kl_strains(Z, dz, n, N, j, Jn, eps, kap);
     const double t3 = t * t * t / 12.0;
     double Ce[3], Ck[3];
     symmv(C, eps, Ce); symmv(C, kap, Ck);
@@ -413,7 +430,7 @@ GF_HD inline void shell_energy_point(const double* z, const double* Z, double t,
 //   measure 1 (2nd Piola-Kirchhoff, metric A):   q = (s:A)^2 - 3 det s det A
 // out: [0] sigma_vM, [1] J, [2] d sigma/dt, [3..17] d sigma/dz, [18..32] d sigma/dZ, [33..38] dJ/d(G1,G2)
 // (same slots as shell_energy_point, so the functional kernels share their contraction code).
-GF_HD inline void shell_stress_point(const double* z, const double* Z, double t, double E, double nu, double sgn, int measure, double* out) {
+GF_HD inline void shell_stress_point(const double* z, const double* Z, const double* dz, double t, double E, double nu, double sgn, int measure, double* out) {
     const double f3[3] = {1.0, 1.0, 2.0};
     double n[3], N[3], j, Jn, Dn[3][6], DN[3][6];
     normal_derivs(z, z + 3, n, j, Dn);
@@ -423,8 +440,7 @@ GF_HD inline void shell_stress_point(const double* z, const double* Z, double t,
     const double A[3] = {dot3(Z, Z), dot3(Z + 3, Z + 3), dot3(Z, Z + 3)};
     const double a[3] = {dot3(z, z), dot3(z + 3, z + 3), dot3(z, z + 3)};
     double eps[3], kap[3], e[3], s[3];
-    eps[0] = 0.5 * (a[0] - A[0]); eps[1] = 0.5 * (a[1] - A[1]); eps[2] = a[2] - A[2];
-    for (int k = 0; k < 3; ++k) kap[k] = f3[k] * (dot3(Z + 6 + 3 * k, N) - dot3(z + 6 + 3 * k, n));
+    kl_strains(Z, dz, n, N, j, Jn, eps, kap);
     const double xi = 0.5 * sgn * t;
     for (int k = 0; k < 3; ++k) e[k] = eps[k] + xi * kap[k];
     symmv(C, e, s);
@@ -541,20 +557,52 @@ GF_HD inline void s_terms(const double* gA, const double* gB, const double* tau,
     for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H2[6 + r][6 + c] = H[r][c];
 }
 
+// The two rotation measures of the penalty energy, e1 = nA . nB - NA . NB and e2 = (at x nA) . nB - (At x NA) . NB, from the displacement tangents
+// dY = (dA1, dA2, dB1, dB2) = y_tangents - Y without cancellation (same idea as kl_strains: the measures are 1e-6 ... 1e-10, their terms O(1), and they are
+// multiplied by alpha_r ~ 1e8): with n = N + dn, at = At + dat (differences of unit vectors in closed form)
+//     e1 = NA . dnB + dnA . NB + dnA . dnB,     e2 = An . dnB + dan . NB + dan . dnB,  dan = At x dnA + dat x NA + dat x dnA,  An = At x NA
+GF_HD inline void unit_diff(const double* X, const double* dx, double* U, double* dU, double& L) {       // U = X / |X|, dU = (X + dx) / |X + dx| - U
+    L = sqrt(dot3(X, X));
+    const double xd[3] = {X[0] + dx[0], X[1] + dx[1], X[2] + dx[2]};
+    const double l = sqrt(dot3(xd, xd)), f = (2.0 * dot3(X, dx) + dot3(dx, dx)) / (l + L);
+    for (int k = 0; k < 3; ++k) { U[k] = X[k] / L; dU[k] = (dx[k] - U[k] * f) / l; }
+}
+GF_HD inline void pen_rot_measures(const double* Y, const double* dY, const double* tau, double& e1, double& e2) {
+    double N[2][3], dn[2][3];
+    for (int sd = 0; sd < 2; ++sd) {
+        const double *G1 = Y + 6 * sd, *G2 = G1 + 3, *d1 = dY + 6 * sd, *d2 = d1 + 3;
+        double Nt[3], a[3], b[3], c[3], dl[3], J;
+        cross3(G1, G2, Nt); cross3(G1, d2, a); cross3(d1, G2, b); cross3(d1, d2, c);
+        for (int k = 0; k < 3; ++k) dl[k] = a[k] + b[k] + c[k];
+        unit_diff(Nt, dl, N[sd], dn[sd], J);
+    }
+    double tr[3], dt_[3], At[3], dat[3], L;
+    for (int k = 0; k < 3; ++k) { tr[k] = tau[0] * Y[k] + tau[1] * Y[3 + k]; dt_[k] = tau[0] * dY[k] + tau[1] * dY[3 + k]; }
+    unit_diff(tr, dt_, At, dat, L);
+    e1 = dot3(N[0], dn[1]) + dot3(dn[0], N[1]) + dot3(dn[0], dn[1]);
+    double An[3], x0[3], x1[3], x2[3], dan[3];
+    cross3(At, N[0], An); cross3(At, dn[0], x0); cross3(dat, N[0], x1); cross3(dat, dn[0], x2);
+    for (int k = 0; k < 3; ++k) dan[k] = x0[k] + x1[k] + x2[k];
+    e2 = dot3(An, dn[1]) + dot3(dan, N[1]) + dot3(dan, dn[1]);
+}
+
 enum : int { PB_GRAD = 0, PB_HYY = 18, PB_HYY_END = 18 + 324, PB_HYC = 18 + 324, PB_SIZE = 18 + 324 + 216, PB_EN = PB_SIZE };
 constexpr int PB_STRIDE = PB_SIZE + 2;   // + energy + pad
 
-// One mortar vertex: y[18] = (uA, gA1, gA2, uB, gB1, gB2), Y[12] = (GA1, GA2, GB1, GB2).
+// One mortar vertex: y[18] = (uA, gA1, gA2, uB, gB1, gB2), Y[12] = (GA1, GA2, GB1, GB2), dY[12] = the displacement tangents (gA1 - GA1, ...) summed from the
+// displacement coefficients (the rotation measures e1, e2 are evaluated from them: pen_rot_measures).
 // out: grad[18], Hyy[18][18], HyC[18][12] where HyC = Hyy[:, tangent cols] + HyY (the dR/dCP operator).
 // grad_only: energy and gradient only (residual-only assemblies, functionals); the Hessian slots are left untouched.
 // want: bit 0 = store Hyy, bit 1 = store HyC (the Newton pass needs only Hyy, linearize right after it only HyC)
-GF_HD inline void penalty_point(const double* y, const double* Y, const double* tau, double ad, double ar, double dt, double* out, bool grad_only = false, int want = 3) {
+GF_HD inline void penalty_point(const double* y, const double* Y, const double* dY, const double* tau, double ad, double ar, double dt, double* out, bool grad_only = false, int want = 3) {
     const int tan[12] = {3, 4, 5, 6, 7, 8, 12, 13, 14, 15, 16, 17};
     double s1, s2, S1, S2, g1[12], g2[12], G1[12], G2[12], L, Lr, at[3], At[3];
     double H1[12][12], H2[12][12];
     s_terms(y + 3, y + 12, tau, s1, s2, g1, g2, grad_only ? nullptr : H1, grad_only ? nullptr : H2, L, at);
     s_terms(Y, Y + 6, tau, S1, S2, G1, G2, nullptr, nullptr, Lr, At);
-    const double e1 = s1 - S1, e2 = s2 - S2, c0 = dt * Lr;
+    double e1, e2;
+    pen_rot_measures(Y, dY, tau, e1, e2);                     // = s1 - S1, s2 - S2 without the cancellation
+    const double c0 = dt * Lr;
     double d[3] = {y[0] - y[9], y[1] - y[10], y[2] - y[11]};
     out[PB_EN] = c0 * (0.5 * ad * dot3(d, d) + 0.5 * ar * (e1 * e1 + e2 * e2));
     double* grad = out + PB_GRAD; double* Hyy = out + PB_HYY; double* HyC = out + PB_HYC;

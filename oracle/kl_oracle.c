@@ -382,13 +382,23 @@ static void first_var(const double g[5][3], const double n[3], double j, const d
     V->db[2] = 2 * (Ra[5] * n[i] + dot3(g[4], V->dn));
 }
 
+/* How the strains are EVALUATED (the quantities are the same): 0 = as differences of the metric / curvature coefficients of the deformed and the reference
+ * configuration, eps = (a - A) / 2, kappa = B - b -- the arithmetic of the reference's UFL forms (ShNAPr's surfaceEnergyDensitySVK via tIGAr) and the default;
+ * 1 = from the displacement derivatives d = x - X without cancellation: eps_ab = (A_a . d_b + d_a . A_b + d_a . d_b) / 2,
+ * kappa_ab = -(H_ab . (n - N) + d_ab . n) with n - N = (delta - N s / (j + J)) / j, delta = A_1 x d_2 + d_1 x A_2 + d_1 x d_2, s = 2 Nt . delta + delta . delta.
+ * Mode 0 loses eps_machine |A|^2 of absolute accuracy in the strain, i.e. a residual floor of about eps_machine E h |A|^2 |grad N| per entry, however small the
+ * load; mode 1 is what the HIP kernels evaluate since round 5 (tests/test_strain_evaluation.py compares the two where mode 0 is well conditioned). */
+static int g_strain_mode = 0;
+void gfo_set_strain_mode(int mode) { g_strain_mode = mode; }
+int gfo_get_strain_mode(void) { return g_strain_mode; }
+
 static void shell_element(const gfo_model* M, const patch_t* P, int eu, int ev, int want_mats, int want_fun, out_t* O) {
     const int p = P->p, q = P->q, nb = (p + 1) * (q + 1), nd = 3 * nb;
     const int iu0 = P->spanu[eu] - p, iv0 = P->spanv[ev] - q;
-    int64_t gid[MAXNB]; double c[MAXNB][3], d[MAXNB][3], hl[MAXNB], wl[MAXNB];
+    int64_t gid[MAXNB]; double c[MAXNB][3], d[MAXNB][3], ul[MAXNB][3], hl[MAXNB], wl[MAXNB];
     for (int jv = 0; jv <= q; ++jv) for (int ju = 0; ju <= p; ++ju) {
         int a = ju + jv * (p + 1); int64_t g = P->cp_off + (iu0 + ju) + (int64_t)(iv0 + jv) * P->nu; gid[a] = g;
-        for (int k = 0; k < 3; ++k) { c[a][k] = M->cp[3 * g + k]; d[a][k] = c[a][k] + M->u[3 * g + k]; }
+        for (int k = 0; k < 3; ++k) { c[a][k] = M->cp[3 * g + k]; ul[a][k] = M->u[3 * g + k]; d[a][k] = c[a][k] + ul[a][k]; }
         hl[a] = M->h[g]; wl[a] = M->w[g];
     }
     double* Re = (double*)calloc(nd, sizeof(double));
@@ -430,6 +440,19 @@ static void shell_element(const gfo_model* M, const patch_t* P, int eu, int ev, 
         double eps[3] = {0.5 * (dot3(g[0], g[0]) - A11), 0.5 * (dot3(g[1], g[1]) - A22), dot3(g[0], g[1]) - A12};
         double kap[3];
         for (int k = 0; k < 3; ++k) kap[k] = f3[k] * (dot3(G[2 + k], Nn) - dot3(g[2 + k], n));
+        if (g_strain_mode == 1) {                          /* displacement-based evaluation: the same strains without the cancellation */
+            double dg[5][3] = {{0}};
+            for (int a = 0; a < nb; ++a) for (int m = 0; m < 5; ++m) for (int k = 0; k < 3; ++k) dg[m][k] += Rb[m + 1][a] * ul[a][k];
+            eps[0] = dot3(G[0], dg[0]) + 0.5 * dot3(dg[0], dg[0]);
+            eps[1] = dot3(G[1], dg[1]) + 0.5 * dot3(dg[1], dg[1]);
+            eps[2] = dot3(G[0], dg[1]) + dot3(dg[0], G[1]) + dot3(dg[0], dg[1]);
+            double t1[3], t2[3], t3_[3], dl[3], dn[3];
+            cross3(G[0], dg[1], t1); cross3(dg[0], G[1], t2); cross3(dg[0], dg[1], t3_);
+            for (int k = 0; k < 3; ++k) dl[k] = t1[k] + t2[k] + t3_[k];
+            const double sdl = 2.0 * dot3(Nt, dl) + dot3(dl, dl);
+            for (int k = 0; k < 3; ++k) dn[k] = (dl[k] - Nn[k] * sdl / (jn + Jn)) / jn;      /* n - N */
+            for (int k = 0; k < 3; ++k) kap[k] = -f3[k] * (dot3(G[2 + k], dn) + dot3(dg[2 + k], n));
+        }
         double Ceps[3], Ckap[3]; mv3(C, eps, Ceps); mv3(C, kap, Ckap);
         double t3 = th * th * th / 12.0, nv[3], mo[3];
         for (int k = 0; k < 3; ++k) { nv[k] = th * Ceps[k]; mo[k] = t3 * Ckap[k]; }
@@ -535,8 +558,36 @@ static void normal_pullback(const cplx* g1, const cplx* g2, const cplx* n, cplx 
     cplx nv = cdot(n, v), w[3]; for (int k = 0; k < 3; ++k) w[k] = (v[k] - n[k] * nv) / j;
     ccross(g2, w, o1); ccross(w, g1, o2);
 }
-/* y = (uA, gA1, gA2, uB, gB1, gB2), Y = (GA1, GA2, GB1, GB2); returns energy, fills gradient wrt y */
-static cplx pen_grad(const cplx y[18], const cplx Y[12], const double tau[2], double ad, double ar, double dt, cplx gr[18]) {
+/* U = X / |X|, dU = (X + dx) / |X + dx| - U without cancellation (analytic in X, dx) */
+static void cunit_diff(const cplx* X, const cplx* dx, cplx* U, cplx* dU) {
+    cplx L = csqrt(cdot(X, X)), xd[3] = {X[0] + dx[0], X[1] + dx[1], X[2] + dx[2]};
+    cplx l = csqrt(cdot(xd, xd)), f = (2.0 * cdot(X, dx) + cdot(dx, dx)) / (l + L);
+    for (int k = 0; k < 3; ++k) { U[k] = X[k] / L; dU[k] = (dx[k] - U[k] * f) / l; }
+}
+/* strain mode 1: the rotation measures e1 = nA.nB - NA.NB, e2 = (at x nA).nB - (At x NA).NB from the displacement tangents dY = y_tangents - Y (real parts given
+ * separately, summed from the displacement coefficients; imaginary parts = the complex-step seeds of y and Y, which subtract exactly) */
+static void pen_rot_measures_c(const cplx y[18], const cplx Y[12], const double* dYre, const double tau[2], cplx* e1, cplx* e2) {
+    static const int tan_[12] = {3, 4, 5, 6, 7, 8, 12, 13, 14, 15, 16, 17};
+    cplx dY[12], N[2][3], dn[2][3];
+    for (int k = 0; k < 12; ++k) dY[k] = dYre[k] + I * (cimag(y[tan_[k]]) - cimag(Y[k]));
+    for (int sd = 0; sd < 2; ++sd) {
+        const cplx *G1 = Y + 6 * sd, *G2 = G1 + 3, *d1 = dY + 6 * sd, *d2 = d1 + 3;
+        cplx Nt[3], a[3], b[3], c[3], dl[3];
+        ccross(G1, G2, Nt); ccross(G1, d2, a); ccross(d1, G2, b); ccross(d1, d2, c);
+        for (int k = 0; k < 3; ++k) dl[k] = a[k] + b[k] + c[k];
+        cunit_diff(Nt, dl, N[sd], dn[sd]);
+    }
+    cplx tr[3], dt_[3], At[3], dat[3];
+    for (int k = 0; k < 3; ++k) { tr[k] = tau[0] * Y[k] + tau[1] * Y[3 + k]; dt_[k] = tau[0] * dY[k] + tau[1] * dY[3 + k]; }
+    cunit_diff(tr, dt_, At, dat);
+    *e1 = cdot(N[0], dn[1]) + cdot(dn[0], N[1]) + cdot(dn[0], dn[1]);
+    cplx An[3], x0[3], x1[3], x2[3], dan[3];
+    ccross(At, N[0], An); ccross(At, dn[0], x0); ccross(dat, N[0], x1); ccross(dat, dn[0], x2);
+    for (int k = 0; k < 3; ++k) dan[k] = x0[k] + x1[k] + x2[k];
+    *e2 = cdot(An, dn[1]) + cdot(dan, N[1]) + cdot(dan, dn[1]);
+}
+/* y = (uA, gA1, gA2, uB, gB1, gB2), Y = (GA1, GA2, GB1, GB2); dYre: NULL, or (strain mode 1) the displacement tangents; returns energy, fills gradient wrt y */
+static cplx pen_grad(const cplx y[18], const cplx Y[12], const double* dYre, const double tau[2], double ad, double ar, double dt, cplx gr[18]) {
     const cplx *uA = y, *gA1 = y + 3, *gA2 = y + 6, *uB = y + 9, *gB1 = y + 12, *gB2 = y + 15;
     const cplx *GA1 = Y, *GA2 = Y + 3, *GB1 = Y + 6, *GB2 = Y + 9;
     cplx tref[3], tdef[3], At[3], at[3];
@@ -547,6 +598,7 @@ static cplx pen_grad(const cplx y[18], const cplx Y[12], const double tau[2], do
     cunit_normal(gA1, gA2, nA, &jA); cunit_normal(gB1, gB2, nB, &jB); cunit_normal(GA1, GA2, NA, &JA); cunit_normal(GB1, GB2, NB, &JB);
     cplx an[3], An[3]; ccross(at, nA, an); ccross(At, NA, An);
     cplx e1 = cdot(nA, nB) - cdot(NA, NB), e2 = cdot(an, nB) - cdot(An, NB);
+    if (dYre && g_strain_mode == 1) pen_rot_measures_c(y, Y, dYre, tau, &e1, &e2);
     cplx dd[3] = {uA[0] - uB[0], uA[1] - uB[1], uA[2] - uB[2]}, c0 = dt * L;
     cplx en = c0 * (0.5 * ad * cdot(dd, dd) + 0.5 * ar * (e1 * e1 + e2 * e2));
     if (!gr) return en;
@@ -567,14 +619,18 @@ static cplx pen_grad(const cplx y[18], const cplx Y[12], const double tau[2], do
     return en;
 }
 /* exported for tests: energy, gradient, Hessians of one mortar vertex */
-void gfo_penalty_point(const double y[18], const double Y[12], const double tau[2], double ad, double ar, double dt,
-                       double* energy, double grad[18], double Hyy[18 * 18], double HyY[18 * 12]) {
+static void penalty_point_impl(const double y[18], const double Y[12], const double* dY, const double tau[2], double ad, double ar, double dt,
+                               double* energy, double grad[18], double Hyy[18 * 18], double HyY[18 * 12]) {
     cplx yc[18], Yc[12], g[18]; const double hstep = 1e-30;
     for (int k = 0; k < 18; ++k) yc[k] = y[k]; for (int k = 0; k < 12; ++k) Yc[k] = Y[k];
-    cplx en = pen_grad(yc, Yc, tau, ad, ar, dt, g);
+    cplx en = pen_grad(yc, Yc, dY, tau, ad, ar, dt, g);
     if (energy) *energy = creal(en); if (grad) for (int k = 0; k < 18; ++k) grad[k] = creal(g[k]);
-    if (Hyy) for (int c = 0; c < 18; ++c) { yc[c] = y[c] + hstep * I; pen_grad(yc, Yc, tau, ad, ar, dt, g); yc[c] = y[c]; for (int r = 0; r < 18; ++r) Hyy[r * 18 + c] = cimag(g[r]) / hstep; }
-    if (HyY) for (int c = 0; c < 12; ++c) { Yc[c] = Y[c] + hstep * I; pen_grad(yc, Yc, tau, ad, ar, dt, g); Yc[c] = Y[c]; for (int r = 0; r < 18; ++r) HyY[r * 12 + c] = cimag(g[r]) / hstep; }
+    if (Hyy) for (int c = 0; c < 18; ++c) { yc[c] = y[c] + hstep * I; pen_grad(yc, Yc, dY, tau, ad, ar, dt, g); yc[c] = y[c]; for (int r = 0; r < 18; ++r) Hyy[r * 18 + c] = cimag(g[r]) / hstep; }
+    if (HyY) for (int c = 0; c < 12; ++c) { Yc[c] = Y[c] + hstep * I; pen_grad(yc, Yc, dY, tau, ad, ar, dt, g); Yc[c] = Y[c]; for (int r = 0; r < 18; ++r) HyY[r * 12 + c] = cimag(g[r]) / hstep; }
+}
+void gfo_penalty_point(const double y[18], const double Y[12], const double tau[2], double ad, double ar, double dt,
+                       double* energy, double grad[18], double Hyy[18 * 18], double HyY[18 * 12]) {
+    penalty_point_impl(y, Y, NULL, tau, ad, ar, dt, energy, grad, Hyy, HyY);
 }
 
 static void penalty_all(const gfo_model* M, int want_mats, out_t* O, double* Wpen) {
@@ -582,7 +638,7 @@ static void penalty_all(const gfo_model* M, int want_mats, out_t* O, double* Wpe
         const iface_t* F = &M->ifs[ii]; const patch_t* PP[2] = {&M->P[F->pa], &M->P[F->pb]};
         for (int64_t v = 0; v < F->npts; ++v) {
             int nbs[2]; int64_t gid[2][MAXNB]; const double* Rv[2][3];
-            double y[18] = {0}, Y[12] = {0};
+            double y[18] = {0}, Y[12] = {0}, dY[12] = {0};
             for (int sd = 0; sd < 2; ++sd) {
                 const patch_t* P = PP[sd]; nbs[sd] = (P->p + 1) * (P->q + 1);
                 for (int k = 0; k < 3; ++k) Rv[sd][k] = F->R + ((v * 2 + sd) * 3 + k) * MAXNB;
@@ -593,11 +649,12 @@ static void penalty_all(const gfo_model* M, int want_mats, out_t* O, double* Wpe
                         y[9 * sd + k] += Rv[sd][0][a] * uu;
                         y[9 * sd + 3 + k] += Rv[sd][1][a] * (cc + uu); y[9 * sd + 6 + k] += Rv[sd][2][a] * (cc + uu);
                         Y[6 * sd + k] += Rv[sd][1][a] * cc; Y[6 * sd + 3 + k] += Rv[sd][2][a] * cc;
+                        dY[6 * sd + k] += Rv[sd][1][a] * uu; dY[6 * sd + 3 + k] += Rv[sd][2][a] * uu;
                     }
                 }
             }
             double en, gr[18], Hyy[18 * 18], HyY[18 * 12];
-            gfo_penalty_point(y, Y, F->tau + 2 * v, F->ad, F->ar, F->wt[v], &en, gr, want_mats ? Hyy : NULL, want_mats ? HyY : NULL);
+            penalty_point_impl(y, Y, dY, F->tau + 2 * v, F->ad, F->ar, F->wt[v], &en, gr, want_mats ? Hyy : NULL, want_mats ? HyY : NULL);
             if (Wpen) *Wpen += en;
             for (int sd = 0; sd < 2; ++sd) for (int a = 0; a < nbs[sd]; ++a) for (int i = 0; i < 3; ++i) {
                 double r = 0; for (int m = 0; m < 3; ++m) r += Rv[sd][m][a] * gr[9 * sd + 3 * m + i];

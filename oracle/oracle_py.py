@@ -54,12 +54,31 @@ def lib():
         L.gfo_set_quadrature.argtypes = [C.c_void_p, C.c_int, dp, dp, dp]
         L.gfo_num_threads.restype = C.c_int
         L.gfo_set_num_threads.argtypes = [C.c_int]
+        L.gfo_set_strain_mode.argtypes = [C.c_int]
+        L.gfo_get_strain_mode.restype = C.c_int
         _LIB = L
     return _LIB
 
 
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+class strain_mode:
+    """Context manager: how the oracle EVALUATES the strains and the penalty's rotation measures (process-wide switch of kl_oracle.c).  0 (default) = differences
+    of the two configurations' metric / curvature coefficients, the arithmetic of the reference's UFL forms; 1 = from the displacement derivatives without
+    cancellation, what the HIP kernels evaluate since round 5 (kl_point.hpp: kl_strains, pen_rot_measures).  Same quantities, different round-off."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        self.old = lib().gfo_get_strain_mode()
+        lib().gfo_set_strain_mode(self.mode)
+        return self
+
+    def __exit__(self, *a):
+        lib().gfo_set_strain_mode(self.old)
 
 
 def two_triangle_rule(quad_deg, scheme="fiat"):

@@ -137,7 +137,7 @@ def _nm_worker(rank, world, port, q):
     out["rev"] = (d_in, d_out)
     out["x"] = op.solve_linear_fwd(np.zeros(nm.vec_iga_dof), lam.copy())
     out["inputs"] = (du, lam, dcp, dh)
-    _, out["u_newton"] = nm.solve_nonlinear_nonmatching_problem(rtol=1e-9, max_it=20)
+    _, out["u_newton"] = nm.solve_nonlinear_nonmatching_problem(rtol=1e-6, max_it=20)
     out["newton_converged"] = nm.newton_converged
     if rank == 0:
         q.put(out)
