@@ -138,8 +138,8 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         run(comm=dist, device=local, verbose=rank == 0)
+        dist.barrier()                      # only on the way out of a run that finished: a barrier in ``finally`` turns one rank's exception into a hang of the others
     finally:
-        dist.barrier()
         dist.destroy_process_group()
 
 

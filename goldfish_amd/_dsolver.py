@@ -38,6 +38,8 @@ def _bind():
     L.gfs_schur_doubles.restype = C.c_int64
     for name in ("gfs_export_schur", "gfs_set_schur_source", "gfs_get_fbnd", "gfs_set_fbnd"):
         getattr(L, name).argtypes = [vp, C.c_int64, vp]
+    for name in ("gfs_get_fbnd_packed", "gfs_set_fbnd_packed"):
+        getattr(L, name).argtypes = [vp, C.c_int64, _i64p, vp]
     L.gfs_x_ptr.argtypes = [vp]
     L.gfs_x_ptr.restype = vp
     L.gfs_forward_dev.argtypes = [vp, vp]
@@ -185,6 +187,38 @@ class DistributedSolver:
             raise ValueError("DistributedSolver needs the control points' coordinates")
         sym = self.sym = _nd.nested_dissection_native(self.nb_ptr, self.nb, coords, leaf=leaf)[0]      # deterministic (also across thread counts): the same tree on every rank
         self.owner, self.roots = split_tree(sym, self.world)
+        self.A = self.B = None
+        self.rel_residual = self.backward_error = None
+        self.rel_residuals = None
+        self.small_pivot = False
+        # Everything from here to the first collective of refactor() can fail on ONE rank only (a rank's fronts are checked against that rank's free memory): the
+        # outcome is agreed on before anybody enters a collective, and every rank raises the same kind of error (a rank that fell back to the host
+        # solve alone met the others inside an all-gather)
+        err = None
+        try:
+            self._create(dev_model, sym)
+        except (RuntimeError, MemoryError) as e:
+            err = str(e) or type(e).__name__
+        self._raise_together(err, "DistributedSolver")
+        self.refactor()
+
+    _PERMANENT = ("device memory", "out of memory", "does not fit", "not symmetric", "hipMalloc", "OutOfMemory")
+
+    def _raise_together(self, err, where):
+        """Collective: every rank passes its local error text (or None); if any rank failed, ALL raise a RuntimeError whose text says whether the failure is permanent
+        (memory: the text contains "out of memory", which NonMatchingOpt.solve_K latches on) -- the same decision on every rank."""
+        code = 0 if err is None else (2 if any(k in err for k in self._PERMANENT) else 1)
+        worst = self._agree(code)
+        if worst == 0:
+            return
+        self.close()
+        mine = (": " + err) if err is not None else ""
+        if worst == 2:
+            raise RuntimeError("%s: out of memory on at least one rank (rank %d%s)" % (where, self.rank, mine))
+        raise RuntimeError("%s: failed on at least one rank (rank %d%s)" % (where, self.rank, mine))
+
+    def _create(self, dev_model, sym):
+        torch, L = self.torch, self.L
         dK = dev_model.k_values_ptr()
         mine = np.flatnonzero(self.owner == self.rank)
         self.my_roots = [t for t in self.roots if self.owner[t] == self.rank]
@@ -208,6 +242,9 @@ class DistributedSolver:
                 if L.gfs_set_schur_source(self.B.h, self.B.local[t], C.c_void_p(self.schur_all.data_ptr() + 8 * off)):
                     raise RuntimeError(L.gfs_last_error().decode())
                 off += self.schur_len[t]
+        # the roots of every rank in B's / A's local front numbers (the packed boundary copies of a substitution)
+        self._rootsB = [np.ascontiguousarray([self.B.local[t] for t in ts], np.int64) for ts in per_rank]
+        self._rootsA = np.ascontiguousarray([self.A.local[t] for t in self.my_roots], np.int64) if self.A else np.zeros(0, np.int64)
         # index sets of the exchange of x: the dofs this rank's subtrees eliminate, the dofs of the top
         def dofs(cps):
             return (3 * np.asarray(cps, np.int64)[:, None] + np.arange(3)).ravel()
@@ -217,10 +254,6 @@ class DistributedSolver:
         self.xA = self._view(L.gfs_x_ptr(self.A.h), self.n) if self.A else None
         self.xB = self._view(L.gfs_x_ptr(self.B.h), self.n)
         self.b_dev = torch.zeros(self.n, dtype=torch.float64, device=dev)
-        self.rel_residual = self.backward_error = None
-        self.rel_residuals = None
-        self.small_pivot = False
-        self.refactor()
 
     # -- helpers
     def _view(self, ptr, n):
@@ -243,11 +276,15 @@ class DistributedSolver:
             self.dist.all_gather(parts, mine.cpu(), group=self.group)
             buf.copy_(self.torch.cat(parts).to(buf.device))
 
+    def _agree(self, code):
+        """Largest ``code`` over the ranks (collective)."""
+        t = self.torch.tensor([float(code)], dtype=self.torch.float64, device=self.torch.device("cuda", self.device) if self.cuda else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
     def _any(self, flag):
         """Logical OR of ``flag`` over the ranks (collective)."""
-        t = self.torch.tensor([1.0 if flag else 0.0], dtype=self.torch.float64, device=self.torch.device("cuda", self.device) if self.cuda else "cpu")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        return bool(t.item() > 0.0)
+        return self._agree(1 if flag else 0) > 0
 
     def close(self):
         for part in ("A", "B"):
@@ -260,7 +297,8 @@ class DistributedSolver:
 
     # -- numeric phase
     def refactor(self):
-        """Collective: own subtrees, all-gather of their Schur complements, the replicated top."""
+        """Collective: own subtrees, all-gather of their Schur complements, the replicated top.  A failure on any rank is agreed on before the next collective
+        and raised on every rank."""
         import time
         L, torch = self.L, self.torch
         self.D.sync()
@@ -278,14 +316,17 @@ class DistributedSolver:
                     off += self.schur_len[t]
             except RuntimeError as e:                          # e.g. a zero pivot in one rank's subtree: every rank must leave the collective phase the same way
                 err = str(e)
-        torch.cuda.synchronize()
-        if self._any(err is not None):
-            raise RuntimeError("DistributedSolver.refactor: " + (err or "the factorisation of another rank's subtrees failed"))
+        self._raise_together(err, "DistributedSolver.refactor (subtrees)")
         t2 = time.perf_counter()
         self._allgather(self.schur_all, self.schur_pad)
-        torch.cuda.synchronize()
+        torch.cuda.current_stream(self.b_dev.device).synchronize()
         t3 = time.perf_counter()
-        self._check(L.gfs_refactor(self.B.h))
+        err = None
+        try:                                                   # the same arithmetic on every rank -- but a rank may still run out of memory alone
+            self._check(L.gfs_refactor(self.B.h))
+        except RuntimeError as e:
+            err = str(e)
+        self._raise_together(err, "DistributedSolver.refactor (top)")
         t4 = time.perf_counter()
         #: seconds of the last refactor() on this rank: K value gather, own subtrees (+ packing), Schur all-gather, replicated top
         self.timings = {"k_values": t1 - t0, "own_subtrees": t2 - t1, "schur_allgather": t3 - t2, "top": t4 - t3}
@@ -300,48 +341,58 @@ class DistributedSolver:
         self.norm_K = float(v[7])
 
     def _substitute(self, b_dev):
-        """x = (L D L^T)^-1 b for one right-hand side on the device (torch tensor, replicated); returns a new tensor (replicated)."""
+        """x = (L D L^T)^-1 b for one right-hand side on the device (torch tensor, replicated); returns a new device tensor (replicated).  The library calls return when
+        the device is done with them; torch's stream is drained only where the library consumes what torch wrote (no device-wide synchronisations).  A library error on
+        one rank does not leave the others waiting in a collective: the rank keeps taking part, the failure rides in an extra entry of the all-reduced x, and every
+        rank raises."""
         L, torch = self.L, self.torch
-        torch.cuda.synchronize()
-        if self.A is not None:
-            self._check(L.gfs_forward_dev(self.A.h, C.c_void_p(b_dev.data_ptr())))
-            off = self.rank * self.fb_pad
-            for t in self.my_roots:
-                self._check(L.gfs_get_fbnd(self.A.h, self.A.local[t], C.c_void_p(self.fb_all.data_ptr() + 8 * off)))
-                off += self.fb_len[t]
-        torch.cuda.synchronize()
+        st = torch.cuda.current_stream(b_dev.device)
+        err = None
+        st.synchronize()                                        # b_dev may have been written by torch
+        try:
+            if self.A is not None:
+                self._check(L.gfs_forward_dev(self.A.h, C.c_void_p(b_dev.data_ptr())))
+                self._check(L.gfs_get_fbnd_packed(self.A.h, self._rootsA.size, self._rootsA.ctypes.data_as(_i64p), C.c_void_p(self.fb_all.data_ptr() + 8 * self.rank * self.fb_pad)))
+        except RuntimeError as e:
+            err = str(e)
         self._allgather(self.fb_all, self.fb_pad)
-        for r, ts in enumerate(self.per_rank):
-            off = r * self.fb_pad
-            for t in ts:
-                self._check(L.gfs_set_fbnd(self.B.h, self.B.local[t], C.c_void_p(self.fb_all.data_ptr() + 8 * off)))
-                off += self.fb_len[t]
-        torch.cuda.synchronize()
-        self._check(L.gfs_forward_dev(self.B.h, C.c_void_p(b_dev.data_ptr())))
-        self._check(L.gfs_backward_dev(self.B.h))
-        x = torch.zeros(self.n, dtype=torch.float64, device=b_dev.device)
-        if self.A is not None:
-            self.xA[self.top_dofs] = self.xB[self.top_dofs]          # the top's x at the boundaries of the own subtrees
-            torch.cuda.synchronize()
-            self._check(L.gfs_backward_dev(self.A.h))
-            x[self.own_dofs] = self.xA[self.own_dofs]
-        if self.rank == 0:
-            x[self.top_dofs] = self.xB[self.top_dofs]
-        torch.cuda.synchronize()
+        x = torch.zeros(self.n + 1, dtype=torch.float64, device=b_dev.device)
+        try:
+            st.synchronize()
+            for r, rb in enumerate(self._rootsB):
+                if rb.size:
+                    self._check(L.gfs_set_fbnd_packed(self.B.h, rb.size, rb.ctypes.data_as(_i64p), C.c_void_p(self.fb_all.data_ptr() + 8 * r * self.fb_pad)))
+            self._check(L.gfs_forward_dev(self.B.h, C.c_void_p(b_dev.data_ptr())))
+            self._check(L.gfs_backward_dev(self.B.h))
+            if self.A is not None and err is None:
+                self.xA[self.top_dofs] = self.xB[self.top_dofs]          # the top's x at the boundaries of the own subtrees
+                st.synchronize()
+                self._check(L.gfs_backward_dev(self.A.h))
+                x[self.own_dofs] = self.xA[self.own_dofs]
+            if self.rank == 0:
+                x[self.top_dofs] = self.xB[self.top_dofs]
+        except RuntimeError as e:
+            err = err or str(e)
+        x[self.n] = 0.0 if err is None else 1.0
         if self.cuda:
             self.dist.all_reduce(x, group=self.group)
         else:
             xc = x.cpu()
             self.dist.all_reduce(xc, group=self.group)
             x = xc.to(b_dev.device)
-        return x
+        if float(x[self.n]) > 0.0:
+            raise RuntimeError("DistributedSolver: a substitution failed on at least one rank (rank %d%s)" % (self.rank, ": " + err if err else ""))
+        return x[:self.n]
 
-    def _residual(self, b, x):
-        """b - K x with the model's global K (collective on a sharded model); host arrays."""
-        return b - self.D.apply(0, x)
+    def _residual_dev(self, b, x):
+        """b - K x with the model's global K (collective on a sharded model); device tensors when the model exchanges on the device, else through the host."""
+        if getattr(self.D, "_tdev", None) is not None and hasattr(self.D, "apply_fwd_dev"):
+            return b - self.D.apply_fwd_dev(0, x)
+        return b - self.torch.from_numpy(self.D.apply(0, x.cpu().numpy())).to(b.device)
 
     def solve(self, b, transpose=False, max_refine=None):
-        """x = K^-1 b; refinement against K itself while a step halves the residual (gfs_solve's rule), ``max_refine`` steps at most."""
+        """x = K^-1 b; refinement against K itself while a step halves the residual (gfs_solve's rule), ``max_refine`` steps at most.  b comes in and x goes out as host
+        arrays (the problem surface's replicated vectors); in between everything stays on the device."""
         torch = self.torch
         if transpose:
             raise NotImplementedError("DistributedSolver: K is symmetric here (general mode is single-GPU)")
@@ -350,27 +401,29 @@ class DistributedSolver:
             raise ValueError("DistributedSolver.solve: expected %d values, got %d" % (self.n, b.size))
         steps = self.max_refine if max_refine is None else int(max_refine)
         dev = self.b_dev.device
-        x = self._substitute(torch.from_numpy(b).to(dev)).cpu().numpy()
-        nb_ = float(np.linalg.norm(b))
-        best, x_prev = None, None
-        for it in range(steps + 1):
-            r = self._residual(b, x)
-            nr = float(np.linalg.norm(r))
-            if best is not None and not nr < 0.5 * best:
-                if nr >= best:
-                    x = x_prev
-                else:
-                    best = nr
-                break
-            best = nr
-            if it == steps or nr == 0.0:
-                break
-            x_prev = x
-            x = x + self._substitute(torch.from_numpy(np.ascontiguousarray(r)).to(dev)).cpu().numpy()
-        self.rel_residual = best / nb_ if nb_ > 0 else best
-        den = self.norm_K * float(np.linalg.norm(x)) + nb_
-        self.backward_error = best / den if den > 0 else best
-        return x
+        with torch.cuda.device(dev):
+            bd = torch.from_numpy(b).to(dev)
+            x = self._substitute(bd)
+            nb_ = float(torch.linalg.vector_norm(bd))
+            best, x_prev = None, None
+            for it in range(steps + 1):
+                r = self._residual_dev(bd, x)
+                nr = float(torch.linalg.vector_norm(r))
+                if best is not None and not nr < 0.5 * best:
+                    if nr >= best:
+                        x = x_prev
+                    else:
+                        best = nr
+                    break
+                best = nr
+                if it == steps or nr == 0.0:
+                    break
+                x_prev = x
+                x = x + self._substitute(r.contiguous())
+            self.rel_residual = best / nb_ if nb_ > 0 else best
+            den = self.norm_K * float(torch.linalg.vector_norm(x)) + nb_
+            self.backward_error = best / den if den > 0 else best
+            return x.cpu().numpy()
 
     def solve_multi(self, B, transpose=False, max_refine=None):
         B = np.atleast_2d(np.asarray(B, float))

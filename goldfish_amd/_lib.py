@@ -23,12 +23,27 @@ EXPORTS = ["gf_device_count", "gf_last_error", "gf_create", "gf_destroy", "gf_to
            "gf_get_values", "gf_apply", "gf_functionals", "gf_compliance", "gf_stress_forms", "gf_penalty_dxi", "gf_shape_regu", "gf_device_ptr", "gf_apply_dev", "gf_kernel_ms", "gf_assembly_path", "gf_stream", "gf_apply_many", "gf_get_functional_gradient", "gf_penalty_dxi_range", "gf_functionals_per_patch", "gf_penalty_dxi_rev", "gf_update_interface"]
 
 
+def one_hip_runtime():
+    """PyTorch-ROCm bundles its own libamdhip64.so.  A process that loads the system runtime first (through libgoldfish_hip.so / libgoldfish_solver.so) and touches
+    torch.cuda later runs TWO HIP runtimes, and torch then reports "No HIP GPUs are available" (measured on the GPU box, round 5: /proc/self/maps shows
+    /opt/rocm/lib/libamdhip64.so.7 next to torch/lib/libamdhip64.so).  With torch imported first the loader binds the libraries to torch's copy (same SONAME) and there
+    is one runtime -- what the sharded exchange, the distributed solver and the device CG (all torch tensors on the library's buffers) need.  Importing torch does not
+    initialise the GPU.  GF_NO_TORCH_PRELOAD=1 skips this (processes that never use torch)."""
+    if os.environ.get("GF_NO_TORCH_PRELOAD") == "1":
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def lib():
     global _LIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libgoldfish_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                                "goldfish_amd has no CPU fallback")
+        one_hip_runtime()
         L = C.CDLL(LIB_PATH)
         dp, vp, i64, ci = C.POINTER(C.c_double), C.c_void_p, C.c_int64, C.c_int
         i32p = C.POINTER(C.c_int32)

@@ -1004,6 +1004,7 @@ struct gfs_handle {
     static constexpr int RHS_BLOCK = 3;      // right-hand sides per pass over the factors (the front-local vectors of the small fronts sit in LDS: 3 x 48 KB)
     static constexpr int MAX_RHS = 8;
     std::vector<SolveWs> ws; long long ws_front_len = 0, ws_bnd_len = 0;
+    bool lds_raised[3] = {false, false, false};   // hipFuncAttributeMaxDynamicSharedMemorySize of the NR-right-hand-side sweep kernels raised on this handle's device
     template <class Tp> Tp* dalloc(size_t cnt) {
         void* p = nullptr; const size_t nb_ = (cnt ? cnt : 1) * sizeof(Tp);
         HIPCHK(hipMalloc(&p, nb_)); allocs.push_back(p); bytes += (long long)nb_; return (Tp*)p;
@@ -1209,12 +1210,12 @@ template <int NR> static void substitute_nd(gfs_handle* h, gfs_handle::SolveWs* 
     for (int j = 0; j < NR; ++j) if (rhs[j]) HIPCHK(hipMemcpyAsync(W[j]->gb, rhs[j], h->n * sizeof(double), hipMemcpyDeviceToDevice, st));
     const gfs_handle::SolveWs* const (&Wc)[NR] = W;
     if (NR > 1) {                                                                 // NR front-local vectors of up to FUSE_MAX_BLK blocks: more than the 64 KB a launch gets by default
-        static bool raised = false;
-        if (!raised) {
+        // per handle, not per process: the attribute belongs to the CURRENT DEVICE's copy of the kernel, and a process may hold handles on several GPUs
+        if (!h->lds_raised[NR - 1]) {
             const int lim = 160 * 1024;
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_fwd_front_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_bwd_front_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-            raised = true;
+            h->lds_raised[NR - 1] = true;
         }
     }
     nd_run_captured(h, &Wm[0]->g_solve[NR - 1], [&] { nd_forward_all<NR>(h, Wc, st); nd_backward_all<NR>(h, Wc, st); }, st);
@@ -1231,6 +1232,7 @@ static void substitute_nd(gfs_handle* h, gfs_handle::SolveWs& W, const double* r
 static gfs_handle::SolveWs& solve_ws(gfs_handle* h, int k) {
     constexpr int NS = gfs_handle::NS;
     if (h->ws.empty()) {
+        h->ws.reserve(gfs_handle::MAX_RHS + 1);        // the graphs of a workspace are keyed by the address of its g_solve slots (graph_calls): the vector must never reallocate
         gfs_handle::SolveWs W;
         W.stream = h->stream; W.gb = h->gb; W.gy = h->gy; W.gx = h->gx; W.fbnd = h->fbnd; W.sb = h->s_b[NS]; W.sy = h->s_y[NS]; W.sz = h->s_z[NS]; W.sx = h->s_x[NS];
         W.vr = h->vr; W.vsol = h->vsol; W.vrhs = h->vrhs; W.part = h->part;
@@ -1818,18 +1820,35 @@ int gfs_set_schur_source(gfs_handle* h, int64_t front, const double* d_buf) {
     h->stub_src[front] = d_buf; h->factored = false;
     return 0;
 }
-int gfs_get_fbnd(gfs_handle* h, int64_t front, double* d_out) {
-    if (partial_front(h, front, "gfs_get_fbnd")) return 1;
-    const Front& F = h->fronts[front];
-    if (F.nb_cp > 0 && hipMemcpy(d_out, h->fbnd + 3 * F.bnd_off, (size_t)3 * F.nb_cp * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) return sfail("gfs_get_fbnd: copy failed");
+// boundary contributions of root fronts: `n` fronts packed one after the other (3 doubles per boundary control point, in the order of each front's boundary list);
+// asynchronous copies on the handle's sweep stream, one synchronisation per call
+static int fbnd_copy(gfs_handle* h, int64_t n, const int64_t* fronts, double* d_buf, bool get, const char* who) {
+    if (!h || !h->nd) return sfail(std::string(who) + ": needs a nested-dissection handle");
+    if (!h->partial) return sfail(std::string(who) + ": needs a partial handle (gfs_create_nd_partial)");
+    if (!d_buf || (n > 0 && !fronts)) return sfail(std::string(who) + ": null argument");
+    if (get && !h->factored) return sfail(std::string(who) + ": no factorisation (call gfs_refactor)");
+    for (int64_t k = 0; k < n; ++k) if (fronts[k] < 0 || fronts[k] >= (int64_t)h->fronts.size()) return sfail(std::string(who) + ": front index out of range");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        gfs_handle::SolveWs& W0 = solve_ws(h, 0);
+        size_t off = 0;
+        for (int64_t k = 0; k < n; ++k) {
+            const Front& F = h->fronts[fronts[k]];
+            const size_t len = (size_t)3 * F.nb_cp;
+            if (len) {
+                if (get) HIPCHK(hipMemcpyAsync(d_buf + off, W0.fbnd + 3 * F.bnd_off, len * sizeof(double), hipMemcpyDeviceToDevice, W0.stream));
+                else HIPCHK(hipMemcpyAsync(W0.fbnd + 3 * F.bnd_off, d_buf + off, len * sizeof(double), hipMemcpyDeviceToDevice, W0.stream));
+            }
+            off += len;
+        }
+        HIPCHK(hipStreamSynchronize(W0.stream));
+    } catch (const std::exception& ex) { return sfail(ex.what()); }
     return 0;
 }
-int gfs_set_fbnd(gfs_handle* h, int64_t front, const double* d_in) {
-    if (partial_front(h, front, "gfs_set_fbnd")) return 1;
-    const Front& F = h->fronts[front];
-    if (F.nb_cp > 0 && hipMemcpy(h->fbnd + 3 * F.bnd_off, d_in, (size_t)3 * F.nb_cp * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) return sfail("gfs_set_fbnd: copy failed");
-    return 0;
-}
+int gfs_get_fbnd(gfs_handle* h, int64_t front, double* d_out) { return fbnd_copy(h, 1, &front, d_out, true, "gfs_get_fbnd"); }
+int gfs_set_fbnd(gfs_handle* h, int64_t front, const double* d_in) { return fbnd_copy(h, 1, &front, const_cast<double*>(d_in), false, "gfs_set_fbnd"); }
+int gfs_get_fbnd_packed(gfs_handle* h, int64_t n, const int64_t* fronts, double* d_out) { return fbnd_copy(h, n, fronts, d_out, true, "gfs_get_fbnd_packed"); }
+int gfs_set_fbnd_packed(gfs_handle* h, int64_t n, const int64_t* fronts, const double* d_in) { return fbnd_copy(h, n, fronts, const_cast<double*>(d_in), false, "gfs_set_fbnd_packed"); }
 double* gfs_x_ptr(gfs_handle* h) { return (h && h->nd) ? h->gx : nullptr; }
 // forward half: y of this handle's eliminated dofs and the boundary contributions of its fronts from the right-hand side d_b (3 * ncp doubles, original numbering);
 // backward half: x of this handle's eliminated dofs into the vector gfs_x_ptr points at, whose entries at the boundary control points of the root fronts (eliminated by

@@ -129,10 +129,6 @@ GF_HD __forceinline__ void symmv(const double* C, const double* x, double* y) {
 // Everything else of the closed forms (first / second derivatives) multiplies these and is evaluated as before.  oracle/kl_oracle.c has both evaluations
 // (gfo_set_strain_mode); tests/test_strain_evaluation.py compares them.
 GF_HD __forceinline__ void kl_strains(const double* Z, const double* dz, const double* n, const double* N, double j, double Jn, double* eps, double* kap) {
-    // no FMA contraction in here: the template instances of the element kernels (Newton pass / full pass) inline this body into different surroundings, and with
-    // contraction left to the optimiser they fused different products -- K of a Newton pass and of a full pass then differed in the last bit
-    // (tests/test_gpu_api.py::test_incremental_assembly_and_functional_cache wants the same bits from either)
-#pragma clang fp contract(off)
     eps[0] = dot3(Z, dz) + 0.5 * dot3(dz, dz);
     eps[1] = dot3(Z + 3, dz + 3) + 0.5 * dot3(dz + 3, dz + 3);
     eps[2] = dot3(Z, dz + 3) + dot3(dz, Z + 3) + dot3(dz, dz + 3);

@@ -528,7 +528,7 @@ class NonMatchingOpt:
                 and getattr(self, "_dsolver_permanent_failure", None) is None):
             from . import _solver
             import warnings
-            why = None
+            why, x, permanent = None, None, False
             try:
                 if getattr(self, "_dsolver", None) is None or self._dsolver.D is not self.dev:
                     w = np.concatenate([sp_.cp_hom_flat()[:, 3] for sp_ in self.splines])
@@ -552,9 +552,9 @@ class NonMatchingOpt:
                 self.linear_solve_relative_residual, self.linear_solve_backward_error = rr, be
                 small = bool(getattr(self._dsolver, "small_pivot", False))
                 tol = min(self.linear_solve_rtol, self.linear_solve_rtol_small_pivot) if small else self.linear_solve_rtol
-                if np.all(np.isfinite(x)) and (be <= tol or (stale_factors and self._dsolver_version != ver)):
-                    return x                                # a chord step (factors of an earlier tangent, on purpose) is not an exact solve: its quality is the Newton loop's to judge
-                why = "backward error %.3e > %.1e after refinement (relative residual %.3e%s)" % (be, tol, rr, "; the factorisation met a small pivot" if small else "")
+                # a chord step (factors of an earlier tangent, on purpose) is not an exact solve: its quality is the Newton loop's to judge
+                if not (np.all(np.isfinite(x)) and (be <= tol or (stale_factors and self._dsolver_version != ver))):
+                    why = "backward error %.3e > %.1e after refinement (relative residual %.3e%s)" % (be, tol, rr, "; the factorisation met a small pivot" if small else "")
             except RuntimeError as e:
                 why = str(e)
                 ds, self._dsolver = getattr(self, "_dsolver", None), None
@@ -563,13 +563,37 @@ class NonMatchingOpt:
                 # a failure that another assembly cannot cure (the factors do not fit the device, the block pattern is not symmetric) is latched until
                 # the device model is dropped: otherwise every Newton iteration rebuilds the solver (pattern download, host nested dissection: seconds
                 # at C4) only to fail again
-                if any(k in why for k in ("device memory", "out of memory", "does not fit", "not symmetric", "hipMalloc")):
-                    self._dsolver_permanent_failure = why
-                    warnings.warn("solve_K: the device solver cannot be used for this model (%s); the host sparse LU is used until the model changes" % why, RuntimeWarning)
-                    return self._host_solve(rhs, ver, transpose and not self.symmetric_K)
+                permanent = any(k in why for k in ("device memory", "out of memory", "does not fit", "not symmetric", "hipMalloc"))
+            if getattr(self, "_dist", None) is not None:
+                # every rank takes the SAME way out: a failure that only one rank saw (its own GPU ran out of memory under the replicated factorisation)
+                # must not send that rank alone into the host solve, whose K gather is a collective the others would never join
+                n_fail, n_perm = (int(v) for v in self.dev._allreduce(np.array([float(why is not None), float(permanent)])))
+                if n_fail and why is None:
+                    why = "the device solve failed on another rank"
+                    ds, self._dsolver = getattr(self, "_dsolver", None), None
+                    if ds is not None:
+                        ds.close()
+                permanent = n_perm > 0
+            if why is None:
+                return x
+            if permanent:
+                self._dsolver_permanent_failure = why
+                self._refuse_host_solve_of_a_huge_model(why)
+                warnings.warn("solve_K: the device solver cannot be used for this model (%s); the host sparse LU is used until the model changes" % why, RuntimeWarning)
+                return self._host_solve(rhs, ver, transpose and not self.symmetric_K)
             warnings.warn("solve_K: device L D L^T rejected for this tangent (%s); falling back to the host sparse LU" % why, RuntimeWarning)
             self._dsolver_failed_version = ver
         return self._host_solve(rhs, ver, transpose and not self.symmetric_K)
+
+    #: above this many dofs the host sparse LU is not a fallback (C5: 10 M dofs -- SuperLU would need hundreds of GB and hours): solve_K raises instead, naming what does work
+    host_solve_max_dofs = int(os.environ.get("GF_HOST_SOLVE_MAX_DOFS", "3000000"))
+
+    def _refuse_host_solve_of_a_huge_model(self, why):
+        if int(getattr(self, "vec_iga_dof", 0)) > self.host_solve_max_dofs:
+            raise RuntimeError("solve_K: the device factorisation of this model is not possible on one GPU (%s) and a host sparse LU of %d dofs is not a path either "
+                               "(host_solve_max_dofs = %d).  Models of this size (C5: 708 GB of factors) need the distributed factorisation: "
+                               "NonMatchingOpt(..., comm=torch.distributed) on a multi-GPU node (goldfish_amd/_dsolver.py; C5 fits 8 x 288 GB); preconditioned CG was "
+                               "measured and does not converge on these tangents (goldfish_amd/_krylov.py, profiles/r05_krylov_study.txt)." % (why, self.vec_iga_dof, self.host_solve_max_dofs))
 
     #: direct solves of a sharded problem: "distributed" (stage 2: subtrees of the elimination tree per rank, replicated top; symmetric K, models large enough
     #: for the nested-dissection mode), "replicated" (stage 1: every rank factors the gathered K), "auto": distributed when it applies

@@ -178,7 +178,7 @@ def shard_arrays(shard, thickness_global=None):
     return A
 
 
-def allreduce_owned_rows(shard, local_rows, dist, width=3, out=None):
+def allreduce_owned_rows(shard, local_rows, dist, width=3, out=None, group=None):
     """Place this rank's owned rows into a zero-padded global vector and sum over ranks
     (torch.distributed; backend 'nccl' == RCCL over xGMI on the GPU box, 'gloo' in CPU tests).
     ``local_rows`` is a torch tensor holding at least the owned rows first."""
@@ -191,7 +191,7 @@ def allreduce_owned_rows(shard, local_rows, dist, width=3, out=None):
     idx = _rows_index(shard, width, local_rows.device)[shard.rank]
     out[idx] = local_rows[:idx.numel()]
     if shard.world > 1:
-        dist.all_reduce(out)
+        dist.all_reduce(out, group=group)
     return out
 
 
@@ -205,7 +205,7 @@ def _rows_index(shard, width, device):
     return cache[key]
 
 
-def allgather_owned_rows(shard, local_rows, dist, width=3, out=None):
+def allgather_owned_rows(shard, local_rows, dist, width=3, out=None, group=None):
     """Same result as allreduce_owned_rows with half the traffic: the owned row slices are disjoint and contiguous in the
     global vector, so they are exchanged by ONE all-gather of slices padded to the largest one ((N-1)/N of the vector per
     rank over xGMI instead of 2(N-1)/N for the ring all-reduce of a zero-padded vector) and copied into place."""
@@ -227,11 +227,11 @@ def allgather_owned_rows(shard, local_rows, dist, width=3, out=None):
     send, recv_buf = cache[key]
     send[:nown] = local_rows[:nown]                                        # the padding behind it stays zero
     recv = recv_buf
-    if dist.get_backend() == "nccl":
-        dist.all_gather_into_tensor(recv, send)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(recv, send, group=group)
     else:                                                       # gloo (tests, rehearsal): host tensors
         parts = [torch.empty(mx, dtype=torch.float64) for _ in range(shard.world)]
-        dist.all_gather(parts, send.cpu())
+        dist.all_gather(parts, send.cpu(), group=group)
         recv = torch.cat(parts).to(local_rows.device)
     # the owned patches of a rank need not be contiguous in the global numbering: one gather + one scatter for all ranks (two launches instead of two per rank: at
     # 8 ranks a step of the bench is ~3 ms, a dozen small launches are a few per cent of it)
@@ -269,6 +269,19 @@ class ShardedDeviceModel:
         self._gpat = {}
         self._kglob = None
         self._n_if_pts = [int(i.npts) for i in spec.interfaces]
+        # Device-resident exchange (round 5): with a real DeviceModel the products, the residual and their exchange stay on the GPU -- the replicated input is
+        # copied in ONCE, sliced to the local numbering by a device gather, multiplied by gf_apply_dev, the owned rows travel by ONE all-gather of device buffers
+        # (allgather_owned_rows: RCCL sees device pointers; gloo, in the tests, stages inside the collective wrapper only) and the replicated result is copied
+        # out ONCE.  The library's stream and torch's are ordered by events.  (The CPU stand-in of tests/test_distributed_cpu.py has no device: host path.)
+        self._tdev = None
+        if hasattr(self.D, "h") and hasattr(self.D, "stream_ptr"):
+            import torch
+            if torch.cuda.is_available():
+                self._tdev = torch.device("cuda", self.device)
+                self._lib_stream = torch.cuda.ExternalStream(self.D.stream_ptr, device=self._tdev)
+                cg = torch.from_numpy(self.cols_g).to(self._tdev)
+                self._loc_cp_g = cg                                                     # global control point of every local one (owned + ghost)
+                self._loc_dof_g = (3 * cg[:, None] + torch.arange(3, device=self._tdev)).reshape(-1)
 
     def close(self):
         if getattr(self, "D", None) is not None:
@@ -291,6 +304,7 @@ class ShardedDeviceModel:
         sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
         self.dist.all_gather(sizes, n, group=self.group)
         sizes = [int(x.item()) for x in sizes]
+        self._last_concat_sizes = sizes
         mx = max(sizes)
         send = torch.zeros(mx, dtype=torch.from_numpy(arr[:0]).dtype, device=dev)
         send[:arr.size] = torch.from_numpy(arr).to(dev)
@@ -315,6 +329,8 @@ class ShardedDeviceModel:
             grow = 3 * self.cols_g[rows_l // 3] + rows_l % 3
             gcol = bw * self.cols_g[col[:nnz] // bw] + col[:nnz] % bw
             R, Cc = self._allgather_concat(grow.astype(np.int64)), self._allgather_concat(gcol.astype(np.int64))
+            if kind == 0:
+                self._k_sizes = list(getattr(self, "_last_concat_sizes", [nnz]))      # owned K values per rank (the layout of the value all-gather)
             ncol = self.ndof if kind == 0 else self.total_cp
             Gm = sp.coo_matrix((np.arange(1, R.size + 1, dtype=np.float64), (R, Cc)), shape=(self.ndof, ncol)).tocsr()
             Gm.sort_indices()
@@ -338,14 +354,86 @@ class ShardedDeviceModel:
         ncol = self.ndof if which == self._lib.MAT_K else self.total_cp
         return sp.csr_matrix((self._allgather_concat(self.D.values(which)[:nnz])[perm], ix, ip), shape=(self.ndof, ncol))
 
+    # -- device-resident pieces
+    def _dev_view(self, which_buf, n):
+        import torch
+
+        class _Buf:
+            def __init__(self, p, k):
+                self.__cuda_array_interface__ = {"shape": (k,), "typestr": "<f8", "data": (int(p), False), "version": 2}
+        return torch.as_tensor(_Buf(self._lib.lib().gf_device_ptr(self.D.h, which_buf), n), device=self._tdev)
+
+    def _to_dev(self, v):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(v, float)).to(self._tdev)
+
+    def _apply_dev(self, which, transpose, x_dev, y_dev):
+        """y_dev += A x_dev on the library's stream, ordered behind torch's work on x_dev / y_dev and in front of torch's next use of y_dev."""
+        import ctypes as C
+        import torch
+        self._lib_stream.wait_stream(torch.cuda.current_stream(self._tdev))
+        if self._lib.lib().gf_apply_dev(self.D.h, int(which), int(bool(transpose)), C.c_void_p(x_dev.data_ptr()), C.c_void_p(y_dev.data_ptr())):
+            raise RuntimeError(self._lib.lib().gf_last_error().decode())
+        torch.cuda.current_stream(self._tdev).wait_stream(self._lib_stream)
+
+    def _allreduce_dev(self, t):
+        """Sum over the ranks of a device tensor: in place over RCCL, through the host under gloo (tests)."""
+        if self.world == 1:
+            return t
+        if self.dist.get_backend(self.group) == "nccl":
+            self.dist.all_reduce(t, group=self.group)
+            return t
+        h = t.cpu()
+        self.dist.all_reduce(h, group=self.group)
+        return h.to(t.device)
+
+    def apply_fwd_dev(self, which, xg):
+        """A x for a replicated global device tensor ``xg``: the replicated global result as a device tensor (local product of the owned rows, ONE all-gather; nothing
+        touches the host under RCCL).  What the distributed solver's refinement uses."""
+        import torch
+        _lib = self._lib
+        with torch.cuda.device(self._tdev):
+            y = torch.zeros(self.A.ndof, dtype=torch.float64, device=self._tdev)
+            self._apply_dev(which, False, xg[self._loc_dof_g if which == _lib.MAT_K else self._loc_cp_g].contiguous(), y)
+            return allgather_owned_rows(self.shard, y, self.dist, 3, group=self.group).clone()
+
     def apply_many(self, which, xs, ys, transpose=False):
-        """DeviceModel.apply_many with replicated global vectors: transpose=False: ys[0] += sum_m A_m xs[m]; transpose=True: ys[m] += A_m^T xs[0]."""
-        for m, w in enumerate(which):
-            if transpose:
-                ys[m][:] += self.apply(w, xs[0], transpose=True)
-            else:
-                ys[0][:] += self.apply(w, xs[m])
-        return ys
+        """DeviceModel.apply_many with replicated global vectors: transpose=False: ys[0] += sum_m A_m xs[m]; transpose=True: ys[m] += A_m^T xs[0].
+        ONE collective per call (DispImOpeartion.apply_linear_fwd / _rev, disp_imop.py:58-128): forward, the local products are summed on the device and the
+        owned rows all-gathered once; reverse, the m results share one all-reduce."""
+        if self._tdev is None:
+            for m, w in enumerate(which):
+                if transpose:
+                    ys[m][:] += self.apply(w, xs[0], transpose=True)
+                else:
+                    ys[0][:] += self.apply(w, xs[m])
+            return ys
+        import torch
+        _lib = self._lib
+        with torch.cuda.device(self._tdev):
+            if not transpose:
+                y = torch.zeros(self.A.ndof, dtype=torch.float64, device=self._tdev)
+                for m, w in enumerate(which):
+                    xg = self._to_dev(xs[m])
+                    self._apply_dev(w, False, xg[self._loc_dof_g if w == _lib.MAT_K else self._loc_cp_g].contiguous(), y)
+                ys[0][:] += allgather_owned_rows(self.shard, y, self.dist, 3, group=self.group).cpu().numpy()
+                return ys
+            xl = self._to_dev(xs[0])[self._loc_dof_g].contiguous()
+            xl[3 * self.n_owned_cp:] = 0.0                                  # ghost rows are not assembled here
+            sizes = [self.ndof if w == _lib.MAT_K else self.total_cp for w in which]
+            out = torch.zeros(int(sum(sizes)), dtype=torch.float64, device=self._tdev)
+            off = 0
+            for w, n in zip(which, sizes):
+                y = torch.zeros(self.A.ndof if w == _lib.MAT_K else self.A.total_cp, dtype=torch.float64, device=self._tdev)
+                self._apply_dev(w, True, xl, y)
+                out[off:off + n].index_add_(0, self._loc_dof_g if w == _lib.MAT_K else self._loc_cp_g, y)      # local columns (owned + ghost) -> global ids
+                off += n
+            out = self._allreduce_dev(out).cpu().numpy()
+            off = 0
+            for m, n in enumerate(sizes):
+                ys[m][:] += out[off:off + n]
+                off += n
+            return ys
 
     def compliance(self, forces, apply_bcs=True):
         """Global compliance functional (gf_compliance): owned patches per rank, value and owned gradient rows summed over the ranks."""
@@ -389,10 +477,36 @@ class ShardedDeviceModel:
         return int(self._kglob.data_ptr())
 
     def refresh_k_values(self):
+        """The replicated K of the direct solvers (stage 1 / the distributed factorisation's value source): ONE all-gather of the owned value rows as device buffers
+        and one device gather into the global CSR order.  (Round 4 went device -> host -> list all-gather -> host permutation of 3.5e8 doubles -> device: 3.2 s at C4
+        with two ranks; under gloo the collective itself is still staged through the host, the permutation is not.)"""
         import torch
         self.k_values_ptr()
-        self._kglob.copy_(torch.from_numpy(self.values(self._lib.MAT_K)))
-        torch.cuda.synchronize(self.device)
+        if self._tdev is None or self.world == 1:
+            self._kglob.copy_(torch.from_numpy(self.values(self._lib.MAT_K)))
+            torch.cuda.synchronize(self.device)
+            return
+        _, _, perm, nnz = self._global_pattern(self._lib.MAT_K)
+        sizes = self._k_sizes
+        mx = max(sizes)
+        with torch.cuda.device(self._tdev):
+            if getattr(self, "_k_place", None) is None:                    # CSR position -> place in the padded all-gather buffer [rank][mx]
+                cum = np.concatenate([[0], np.cumsum(sizes)])
+                r = np.searchsorted(cum, perm, side="right") - 1
+                place = r * mx + (perm - cum[r])
+                self._k_place = torch.from_numpy(place.astype(np.int32 if self.world * mx < 2 ** 31 else np.int64)).to(self._tdev)
+                self._k_recv = torch.empty(self.world * mx, dtype=torch.float64, device=self._tdev)
+                self._k_send = torch.zeros(mx, dtype=torch.float64, device=self._tdev)
+            torch.cuda.current_stream(self._tdev).wait_stream(self._lib_stream)
+            self._k_send[:nnz] = self._dev_view(self._lib.BUF_VAL_K, nnz)
+            if self.dist.get_backend(self.group) == "nccl":
+                self.dist.all_gather_into_tensor(self._k_recv, self._k_send, group=self.group)
+            else:
+                parts = [torch.empty(mx, dtype=torch.float64) for _ in range(self.world)]
+                self.dist.all_gather(parts, self._k_send.cpu(), group=self.group)
+                self._k_recv.copy_(torch.cat(parts))
+            torch.index_select(self._k_recv, 0, self._k_place, out=self._kglob)
+            torch.cuda.synchronize(self.device)
 
     # -- replicated inputs
     def set_cp(self, field, v):
@@ -430,7 +544,13 @@ class ShardedDeviceModel:
         return self._allreduce(out)
 
     def residual(self):
-        return self._rows_to_global(self.D.residual(), 3)
+        if self._tdev is None:
+            return self._rows_to_global(self.D.residual(), 3)
+        import torch
+        with torch.cuda.device(self._tdev):
+            torch.cuda.current_stream(self._tdev).wait_stream(self._lib_stream)         # the assembly that wrote the residual runs on the library's stream
+            R = allgather_owned_rows(self.shard, self._dev_view(self._lib.BUF_R, self.A.ndof), self.dist, 3, group=self.group)
+            return R.cpu().numpy()
 
     def apply(self, which, x, y=None, transpose=False):
         """A x (or A^T x) for the replicated global x as a replicated global vector; with ``y`` (DeviceModel.apply's signature) it is added to y in place."""
@@ -439,6 +559,10 @@ class ShardedDeviceModel:
             return y
         _lib = self._lib
         x = np.asarray(x, float)
+        if self._tdev is not None:                              # device-resident: one copy in, one collective, one copy out
+            out = [np.zeros(self.ndof if (which == _lib.MAT_K or not transpose) else self.total_cp)]
+            self.apply_many([which], [x], out, transpose=transpose)
+            return out[0]
         if not transpose:
             xl = self.shard.to_local(x, 3 if which == _lib.MAT_K else 1)
             y = np.zeros(self.A.ndof)
@@ -457,27 +581,45 @@ class ShardedDeviceModel:
         self.D.apply(which, xl, y, transpose=True)
         return self._cols_to_global(y)
 
+    def _allreduce_packed(self, parts):
+        """ONE all-reduce for several arrays (scalars, per-patch terms, gradient rows placed at their global ids): returns the summed arrays in the same shapes."""
+        flat = np.concatenate([np.ravel(p_) for p_ in parts])
+        flat = self._allreduce(flat)
+        out, off = [], 0
+        for p_ in parts:
+            n = int(np.size(p_))
+            out.append(flat[off:off + n].reshape(np.shape(p_)))
+            off += n
+        return out
+
+    def _own_rows_global(self, v, width):
+        """The owned rows of a local gradient field at their global ids, zeros elsewhere (the ranks' contributions add up)."""
+        out = np.zeros(width * self.total_cp)
+        n = width * self.n_owned_cp
+        out[self._own_rows[width]] = np.asarray(v, float)[:n]              # gradients are assembled for owned control points only
+        return out
+
     def functionals(self, apply_bcs=True):
+        """Global W_int, volume, penalty energy and their gradient fields: owned elements per rank; the scalars, the per-patch terms and the eleven gradient rows
+        per control point travel in ONE all-reduce (round 4: nine)."""
         F = self.D.functionals(apply_bcs=apply_bcs)
-        sc = self._allreduce(np.array([F["Wint"], F["volume"], F["Wpen"]]))
-        out = dict(Wint=sc[0], volume=sc[1], Wpen=sc[2])
-        if "volume_patch" in F:                              # per-patch terms (VolumeExOperation(vol_surf_inds = subset)): the owner reports its patches
+        parts = [np.array([F["Wint"], F["volume"], F["Wpen"]])]
+        has_pp = "volume_patch" in F
+        if has_pp:                                           # per-patch terms (VolumeExOperation(vol_surf_inds = subset)): the owner reports its patches
             order, no, npg = np.asarray(self.shard.order), self.shard.n_owned, len(self.shard.cp_off_global) - 1
             pp = np.zeros((2, npg))
             pp[0, order[:no]], pp[1, order[:no]] = F["Wint_patch"][:no], F["volume_patch"][:no]
-            pp = self._allreduce(pp.ravel()).reshape(2, npg)
+            parts.append(pp)
+        parts += [self._own_rows_global(F["dWdu"], 3), self._own_rows_global(F["dWdh"], 1), self._own_rows_global(F["dVdh"], 1)]
+        parts += [self._own_rows_global(F["dWdcp"][f], 1) for f in range(3)] + [self._own_rows_global(F["dVdcp"][f], 1) for f in range(3)]
+        res = self._allreduce_packed(parts)
+        sc = res.pop(0)
+        out = dict(Wint=sc[0], volume=sc[1], Wpen=sc[2])
+        if has_pp:
+            pp = res.pop(0)
             out["Wint_patch"], out["volume_patch"] = pp[0], pp[1]
-        n = self.n_owned_cp
-
-        def own(v, width=1):                                # gradients are assembled for owned control points only
-            w = np.array(v, float)
-            w[width * n:] = 0.0
-            return w
-        out["dWdu"] = self._rows_to_global(own(F["dWdu"], 3), 3)
-        out["dWdh"] = self._rows_to_global(own(F["dWdh"]), 1)
-        out["dVdh"] = self._rows_to_global(own(F["dVdh"]), 1)
-        out["dWdcp"] = [self._rows_to_global(own(F["dWdcp"][f]), 1) for f in range(3)]
-        out["dVdcp"] = [self._rows_to_global(own(F["dVdcp"][f]), 1) for f in range(3)]
+        out["dWdu"], out["dWdh"], out["dVdh"] = res[0], res[1], res[2]
+        out["dWdcp"], out["dVdcp"] = [res[3], res[4], res[5]], [res[6], res[7], res[8]]
         return out
 
     def stress_forms(self, mode, rho, m_list, surf=1, measure=0, apply_bcs=True, gradients=True):

@@ -92,6 +92,9 @@ int gfs_export_schur(gfs_handle* h, int64_t front, double* d_buf);
 int gfs_set_schur_source(gfs_handle* h, int64_t front, const double* d_buf);
 int gfs_get_fbnd(gfs_handle* h, int64_t front, double* d_out);
 int gfs_set_fbnd(gfs_handle* h, int64_t front, const double* d_in);
+/* the same for n fronts in one call: their boundary contributions packed one after the other in d_out / d_in (one synchronisation instead of one blocking copy per front) */
+int gfs_get_fbnd_packed(gfs_handle* h, int64_t n, const int64_t* fronts, double* d_out);
+int gfs_set_fbnd_packed(gfs_handle* h, int64_t n, const int64_t* fronts, const double* d_in);
 double* gfs_x_ptr(gfs_handle* h);
 int gfs_forward_dev(gfs_handle* h, const double* d_b);
 int gfs_backward_dev(gfs_handle* h);

@@ -725,11 +725,10 @@ def test_incremental_assembly_and_functional_cache():
     spec2, th2, ref = _problem()
     ref.update_uIGA(nm.u_iga)
     ref.dev.assemble(_lib.ASM_ALL)
-    # p = 2, 3: one path for every pass kind -- the separate passes give the fused pass's bits; p = 4 (hybrid: a pass without dR/dCP / dR/dh runs through the row
-    # records, one with them through element blocks -- each on its faster path) sums the same products in another order: equal to round-off
-    tol = 0.0 if ref.dev.assembly_path != 6 else 1e-13 * abs(K).max()
-    assert np.abs(ref.dev.residual() - R).max() <= tol
-    assert abs(ref.dev.csr(_lib.MAT_K) - K).max() <= tol
+    # the separate passes give the fused pass's matrices to round-off: a pass without dR/dCP / dR/dh runs leaner kernel instances (p = 4: another path altogether,
+    # row records instead of element blocks -- each pass kind on its faster path), whose compiler-scheduled FMA contractions / summation order differ in the last bits
+    assert np.abs(ref.dev.residual() - R).max() <= 1e-13 * np.abs(R).max()
+    assert abs(ref.dev.csr(_lib.MAT_K) - K).max() <= 1e-13 * abs(K).max()
     assert abs(ref.dRIGAdCPIGA(1) - C1).max() == 0.0 and abs(ref.dRIGAdh_th() - H).max() == 0.0
     n0 = len(calls)
     nm.update_uIGA(nm.u_iga * 1.01)                                       # new state: everything is stale again
