@@ -119,11 +119,15 @@ def parse_args(argv=None):
 
 
 def git_head():
+    """Commit of the tree this runs from: git where there is one, else the record goldfish_amd.build.build() wrote where it last ran WITH git (the driver's box has
+    no git; the record travels with the built libraries) -- marked as such."""
     try:
         import subprocess
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
-        return None
+        from goldfish_amd import build
+        bi = build.build_info()
+        return ("%s%s (goldfish_amd/_build_info.json)" % (bi["head"], "+uncommitted" if bi.get("dirty") else "")) if bi.get("head") else None
 
 
 def last_commit_of(path):

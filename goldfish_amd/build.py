@@ -23,6 +23,30 @@ def needs_build(lib=LIB, sources=SOURCES):
     return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in sources)
 
 
+BUILD_INFO = os.path.join(HERE, "_build_info.json")      # git-ignored like the libraries, travels with them to the GPU box (no git there): bench.py's "head"
+
+
+def _write_build_info():
+    """Where git is available (the build container), record the commit the libraries were built from; elsewhere (the GPU box) keep the file that came along."""
+    import json
+    try:
+        root = os.path.dirname(HERE)
+        head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        dirty = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"], stderr=subprocess.DEVNULL).decode().strip())
+        with open(BUILD_INFO, "w") as f:
+            json.dump({"head": head, "dirty": dirty, "libraries": dict(REPORT)}, f)
+    except Exception:
+        pass
+
+
+def build_info():
+    import json
+    try:
+        return json.load(open(BUILD_INFO))
+    except Exception:
+        return {}
+
+
 REPORT = {}      # library -> "compiled" | "reused" of the last build() call (the driver's log shows whether the box compiled anything)
 
 
@@ -50,6 +74,7 @@ def build(force=False, verbose=False):
         extra = os.environ.get("GF_SOLVER_CXXFLAGS", "").split()
         subprocess.check_call([_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-pthread", "-mllvm", "-amdgpu-mfma-vgpr-form"] + extra +
                               [os.path.join(CSRC, "gf_solver.hip"), "-o", solver])
+    _write_build_info()
     if verbose or os.environ.get("GF_BUILD_REPORT", "1") == "1":
         print("goldfish_amd.build: " + ", ".join("%s %s" % kv for kv in REPORT.items()) + " (hipcc --offload-arch=gfx950; a library is reused when no source is newer than it)", file=sys.stderr, flush=True)
     return LIB

@@ -710,8 +710,6 @@ class NonMatchingOpt:
         per-vertex blocks (gf_penalty_dxi -> pen_dxi_kernel); here they are scattered to dofs / coordinates, and the
         tangent blocks are chained with d(tau)/d(xi_A) of the vertex stencil (model.Interface: second-order differences)."""
         c2x, dev = self.cpiga2xi, self.dev
-        if self.sharded:
-            raise NotImplementedError("dRIGAdxi on a sharded model (moving intersections across ranks) is not implemented: run shape_opt_mint problems on one GPU")
         A = self._arrays_cache
         p = self.splines[0].p
         P1, nb = p + 1, (p + 1) ** 2
@@ -719,8 +717,9 @@ class NonMatchingOpt:
         al = np.arange(nb)
         for i, g in enumerate(self.diff_int_inds):
             n = c2x.diff_int_num_pts[i]
-            v0, base = int(A.if_off[g]), c2x.xi_flat_inds[i]
-            B, W = dev.penalty_dxi(n, p, v_first=v0)                                   # the vertices of this moving interface only: (n, 6, 2, nb, 3), (n, 2, 2)
+            base = c2x.xi_flat_inds[i]
+            # the vertices of this moving interface only: (n, 6, 2, nb, 3), (n, 2, 2); sharded: evaluated by the owner of side A, replicated (ShardedDeviceModel.penalty_dxi_if)
+            B, W = dev.penalty_dxi_if(g, p) if self.sharded else dev.penalty_dxi(n, p, v_first=int(A.if_off[g]))
             dof = np.zeros((n, 2, nb, 3), dtype=np.int64)
             for sd, s in enumerate(self.mapping_list[g]):
                 cp = self.cp_off[s] + (W[:, sd, 0][:, None] + al % P1) + (W[:, sd, 1][:, None] + al // P1) * self.splines[s].n_u

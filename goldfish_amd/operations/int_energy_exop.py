@@ -20,6 +20,34 @@ class ShapeRegu(object):
             raise ValueError("ShapeRegu: field must be 0, 1 or 2")
 
 
+def regu_fields(nm, terms, what):
+    """Per-patch list of None / ShapeRegu (the ``wint_regu`` of IntEnergyExOperation, the ``c_regu`` of ComplianceExOperation) -> {field: (per-patch coefficients,
+    initial coordinate field)}: what one gf_shape_regu evaluation per regularised field takes."""
+    terms = [None] * nm.num_splines if terms is None else list(terms)
+    if len(terms) != nm.num_splines:
+        raise ValueError("%s: one entry (None or a ShapeRegu) per patch" % what)
+    fields = {}
+    for s, r in enumerate(terms):
+        if r is None:
+            continue
+        if not isinstance(r, ShapeRegu):
+            raise TypeError("%s[%d]: the reference adds a UFL form here; the device path evaluates goldfish_amd.operations."
+                            "int_energy_exop.ShapeRegu terms (the regularisation of the reference's eVTOL demo), got %r" % (what, s, type(r)))
+        coef, cp0 = fields.setdefault(r.field, (np.zeros(nm.num_splines), nm.cp_iga[r.field].copy()))
+        coef[s] = r.coef
+        if r.cp0 is not None:
+            if r.cp0.size != nm.vec_scalar_iga_dof_list[s]:
+                raise ValueError("%s[%d].cp0: expected %d values" % (what, s, nm.vec_scalar_iga_dof_list[s]))
+            cp0[nm.cp_off[s]:nm.cp_off[s + 1]] = r.cp0
+    return terms, fields
+
+
+def regu_values(nm, fields, tag):
+    """[(value, dcp (3, total_cp))] of the regularisation terms, one device evaluation per regularised coordinate field and state."""
+    return [nm._cached((tag, f, coef.tobytes(), cp0.tobytes()), lambda f=f, coef=coef, cp0=cp0: nm.dev.shape_regu(f, cp0, coef))
+            for f, (coef, cp0) in sorted(fields.items())]
+
+
 class IntEnergyExOperation(object):
 
     def __init__(self, nonmatching_opt, wint_regu=None):
@@ -28,22 +56,7 @@ class IntEnergyExOperation(object):
         self.splines = nonmatching_opt.splines
         self.opt_shape = nonmatching_opt.opt_shape
         self.opt_thickness = nonmatching_opt.opt_thickness
-        self.wint_regu = [None] * self.num_splines if wint_regu is None else list(wint_regu)
-        if len(self.wint_regu) != self.num_splines:
-            raise ValueError("wint_regu: one entry (None or a ShapeRegu) per patch")
-        self._regu_fields = {}                  # field -> (per-patch coefficients, initial coordinate field)
-        for s, r in enumerate(self.wint_regu):
-            if r is None:
-                continue
-            if not isinstance(r, ShapeRegu):
-                raise TypeError("wint_regu[%d]: the reference adds a UFL form here; the device path evaluates goldfish_amd.operations."
-                                "int_energy_exop.ShapeRegu terms (the regularisation of the reference's eVTOL demo), got %r" % (s, type(r)))
-            coef, cp0 = self._regu_fields.setdefault(r.field, (np.zeros(self.num_splines), nm.cp_iga[r.field].copy()))
-            coef[s] = r.coef
-            if r.cp0 is not None:
-                if r.cp0.size != nm.vec_scalar_iga_dof_list[s]:
-                    raise ValueError("wint_regu[%d].cp0: expected %d values" % (s, nm.vec_scalar_iga_dof_list[s]))
-                cp0[nm.cp_off[s]:nm.cp_off[s + 1]] = r.cp0
+        self.wint_regu, self._regu_fields = regu_fields(nm, wint_regu, "wint_regu")
         if self.opt_shape:
             self.opt_field = nonmatching_opt.opt_field
             self.shopt_surf_inds = nonmatching_opt.shopt_surf_inds
@@ -53,9 +66,7 @@ class IntEnergyExOperation(object):
 
     def _regu(self):
         """[(value, dcp (3, total_cp))] of the regularisation terms, one device evaluation per regularised coordinate field and state."""
-        nm = self.nonmatching_opt
-        return [nm._cached(("wint_regu", f, coef.tobytes(), cp0.tobytes()), lambda f=f, coef=coef, cp0=cp0: nm.dev.shape_regu(f, cp0, coef))
-                for f, (coef, cp0) in sorted(self._regu_fields.items())]
+        return regu_values(self.nonmatching_opt, self._regu_fields, "wint_regu")
 
     def Wint(self):
         """int_energy_exop.py:55-59."""

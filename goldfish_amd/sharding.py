@@ -269,6 +269,7 @@ class ShardedDeviceModel:
         self._gpat = {}
         self._kglob = None
         self._n_if_pts = [int(i.npts) for i in spec.interfaces]
+        self._if_side_a = [int(i.a) for i in spec.interfaces]
         # Device-resident exchange (round 5): with a real DeviceModel the products, the residual and their exchange stay on the GPU -- the replicated input is
         # copied in ONCE, sliced to the local numbering by a device gather, multiplied by gf_apply_dev, the owned rows travel by ONE all-gather of device buffers
         # (allgather_owned_rows: RCCL sees device pointers; gloo, in the tests, stages inside the collective wrapper only) and the replicated result is copied
@@ -455,6 +456,22 @@ class ShardedDeviceModel:
             from .model import Interface
             ok = 1.0 if self.D.update_interface(self.shard.if_global.index(g), Interface(loc.a, loc.b, itf.xi_a, itf.xi_b)) else 0.0
         return bool(self._allreduce(np.array([1.0 - ok]))[0] == 0.0)
+
+    def penalty_dxi_if(self, g, degree):
+        """(blocks (n, 6, 2, nb, 3), windows (n, 2, 2)) of the mortar vertices of GLOBAL interface g, replicated: the rank that owns the interface's side A evaluates
+        them on its device (both patches are there, one possibly as a ghost: the per-vertex blocks need geometry and state only) and everybody receives them -- one
+        all-reduce to which the other ranks contribute zeros (58 k doubles for a 100-vertex bicubic interface).  The matrix form of dR/dxi on a sharded problem
+        (GOLDFISH/nonmatching_opt.py:1042-1341; the reference marks this path "doesn't work in parallel")."""
+        n, nb = int(self._n_if_pts[g]), (int(degree) + 1) ** 2
+        a_global = self._if_side_a[g]
+        owner = next(r for r, own in enumerate(self.shard.owned_by_rank) if a_global in own)
+        B, W = np.zeros((n, 6, 2, nb, 3)), np.zeros((n, 2, 2))
+        if owner == self.rank:
+            itf_l = self.shard.if_global.index(g)
+            Bl, Wl = self.D.penalty_dxi(n, degree, v_first=int(self.A.if_off[itf_l]))
+            B, W = np.asarray(Bl, float), np.asarray(Wl, float)
+        out = self._allreduce_packed([B, W]) if self.world > 1 else [B, W]
+        return out[0], np.rint(out[1]).astype(np.int32)
 
     def penalty_dxi_rev_if(self, g, lam):
         """(n, 6) reverse-mode product of the dR/d(xi, tau) blocks of the mortar vertices of GLOBAL interface g with the replicated lam (moving intersections on
