@@ -926,7 +926,8 @@ def test_volume_of_a_patch_subset_and_wint_regu_terms(oracle_lib):
     # ---- c_regu of ComplianceExOperation (compliance_exop.py:9-28: raised NotImplementedError until round 5): the same terms added to the compliance form
     from goldfish_amd.operations.compliance_exop import ComplianceExOperation
     forces = rng.standard_normal((nm.num_splines, 3))
-    c0, c1 = ComplianceExOperation(nm, forces), ComplianceExOperation(nm, forces, c_regu=[None, ShapeRegu(ref.regu_para_full[1], field=2)])
+    c0 = ComplianceExOperation(nm, forces)
+    c1 = ComplianceExOperation(nm, forces, c_regu=[None, ShapeRegu(ref.regu_para_full[1], field=2, cp0=cp2[nm.cp_off[1]:nm.cp_off[2]])])     # P^0 = the control net before the perturbation (as only1's)
     assert abs((c1.cpl() - c0.cpl()) - (only1.Wint() - base.Wint())) < 1e-10 * abs(only1.Wint())
     assert _rel(c1.dcpldCPIGA(2) - c0.dcpldCPIGA(2), g1) < 1e-10 and np.array_equal(c1.dcplduIGA(), c0.dcplduIGA())
     nm.update_CPIGA(cp2, 2)

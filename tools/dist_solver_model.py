@@ -1,6 +1,9 @@
 """Measurement + model (not product): the distributed factorisation (goldfish_amd/_dsolver.py) of C4's K for 2, 4, 8 ranks from the symbolic phase alone -- work of
 the replicated top, largest per-rank share of the subtrees, bytes of the Schur-complement all-gather and of the boundary-contribution all-gather -- priced with the
-rates measured on one MI355X (profiles/r04_device_solver_bench.txt: 37 TFLOP/s for a factorisation; all-gather over xGMI taken as 300 GB/s per GPU)."""
+rates measured on one MI355X (profiles/r04_device_solver_bench.txt: 37 TFLOP/s for a factorisation; all-gather over xGMI taken as 300 GB/s per GPU).
+Round 5: the K VALUE EXCHANGE is a term of the model -- this code replicates K's values on every rank before it factors
+(ShardedDeviceModel.refresh_k_values: one all-gather of the owned value rows as device buffers + one device gather into the global CSR order, 9 x 8 bytes per
+block of the pattern): (world - 1) / world of K's bytes in per rank over xGMI, and a pass over 2 x K's bytes at HBM rate for the permutation."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,7 +25,8 @@ ne, nbd, be, bb = sym.front_dofs()
 bt = be + bb
 flop = 2.0 * 64 ** 3 * _dsolver.front_work(sym)
 tiles = bt * (bt + 1) // 2
-RATE, XGMI = 37e12, 300e9
+RATE, XGMI, HBM = 37e12, 300e9, 4.5e12
+k_bytes = 9.0 * 8.0 * float(nb_ptr[-1])                  # K's values: 9 doubles per block of the control-point pattern
 print(name + ": %d fronts, %.2f Tflop, %.1f GB of tiles; one GPU: %.0f ms per factorisation at %.0f TFLOP/s" % (sym.nfronts, flop.sum() / 1e12, tiles.sum() * 32768 / 1e9, flop.sum() / RATE * 1e3, RATE / 1e12))
 for world in ((8, 16) if name == "C5" else (2, 4, 8)):
     owner, roots = _dsolver.split_tree(sym, world)
@@ -32,7 +36,8 @@ for world in ((8, 16) if name == "C5" else (2, 4, 8)):
     schur = np.array([bb[t] * (bb[t] + 1) // 2 for t in roots]) * 32768.0
     fb = np.array([nbd[t] for t in roots]) * 8.0
     t_sub, t_top, t_ag = per.max() / RATE, flop[top].sum() / RATE, schur.sum() * (world - 1) / world / XGMI
+    t_k = k_bytes * (world - 1) / world / XGMI + 2.0 * k_bytes / HBM
     print("%d ranks: %d subtrees below %d top fronts; subtrees %.2f Tflop (largest share %.2f, imbalance %.2f), top %.2f Tflop (replicated); Schur all-gather %.2f GB, boundary "
-          "contributions %.1f MB per solve; factor memory per rank %.1f GB (own) + %.1f GB (top) + %.1f GB (stubs); modelled factorisation %.0f + %.0f + %.0f = %.0f ms"
+          "contributions %.1f MB per solve; factor memory per rank %.1f GB (own) + %.1f GB (top) + %.1f GB (stubs); modelled factorisation: K value exchange (%.2f GB replicated) %.0f + subtrees %.0f + Schur all-gather %.0f + top %.0f = %.0f ms"
           % (world, len(roots), int(top.sum()), per.sum() / 1e12, per.max() / 1e12, per.max() / per.mean(), flop[top].sum() / 1e12, schur.sum() / 1e9, fb.sum() / 1e6,
-             mem.max() / 1e9, tiles[top].sum() * 32768 / 1e9, schur.sum() / 1e9, t_sub * 1e3, t_ag * 1e3, t_top * 1e3, (t_sub + t_ag + t_top) * 1e3), flush=True)
+             mem.max() / 1e9, tiles[top].sum() * 32768 / 1e9, schur.sum() / 1e9, k_bytes / 1e9, t_k * 1e3, t_sub * 1e3, t_ag * 1e3, t_top * 1e3, (t_k + t_sub + t_ag + t_top) * 1e3), flush=True)
