@@ -1,7 +1,9 @@
 """Builds profiles/traffic.json from the PMC passes of tools/profile_round.sh (FETCH_SIZE, WRITE_SIZE; KB units;
 gfx950 correction: FETCH_SIZE counts 64 B per 128-B request -> bytes = 2*FETCH + WRITE, MI355X_MICROARCH.md HBM section).
 
-usage: traffic_from_pmc.py <tag> <Gauss points of the profiled workload> [output]
+usage: traffic_from_pmc.py <tag> <Gauss points of the profiled workload> [output] [chunks]
+``chunks``: launches of the element kernel per pass (full C5 on one GPU runs its element blocks in chunks of patches: 5 launches per pass); the per-"launch" figures
+of the element kernel and the per-step sum are then per PASS (all chunks), which is what bench.py compares them with (its kernel time is the sum over a step's launches).
 
 Which launches belong to the full pass (R + K + dR/dCP + dR/dh):  bench.py first runs its warm-up + timed FULL passes, then (unless
 --full-pass-only) a few Newton passes (R + K).  A kernel whose template arguments carry the pass (WITHC / WITHK instances) is told apart
@@ -83,7 +85,7 @@ def split(rows):
     return out
 
 
-def build(tag, gps, prof_dir="profiles"):
+def build(tag, gps, prof_dir="profiles", chunks=1):
     f = split(read_counter(os.path.join(prof_dir, "%s_pmc_fetch.csv" % tag), "FETCH_SIZE"))
     w = split(read_counter(os.path.join(prof_dir, "%s_pmc_write.csv" % tag), "WRITE_SIZE"))
     kern = {}
@@ -103,7 +105,9 @@ def build(tag, gps, prof_dir="profiles"):
     full = sorted(k for k in kern if kern[k]["launches_full_pass"] and k.startswith(GF_PASS_KERNELS))
     el = sorted((k for k in full if k.startswith("kl_element")), key=lambda k: -kern[k]["hbm_side_bytes_corrected_per_launch"])
     n_full = max((kern[k]["launches_full_pass"] for k in el), default=0)
-    out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_*.csv), bench.py (workload of %d Gauss points); averages per launch. "
+    if chunks > 1:
+        n_full = max(1, n_full // chunks)              # passes, not launches
+    out = {"launches_of_the_element_kernel_per_pass": chunks, "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_*.csv), bench.py (workload of %d Gauss points); averages per launch. "
                    "Counters are KB at the L2<->fabric interface (Infinity-Cache hits included); corrected = 2*FETCH + WRITE "
                    "(gfx950: FETCH_SIZE counts 64 B per 128-B request).  Kernels launched under one name by full and Newton passes are split by launch order "
                    "(tools/traffic_from_pmc.py)." % (tag, gps),
@@ -142,7 +146,7 @@ def build(tag, gps, prof_dir="profiles"):
 if __name__ == "__main__":
     tag, gps = sys.argv[1], int(sys.argv[2])
     outfile = sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json"
-    out = build(tag, gps)
+    out = build(tag, gps, chunks=int(sys.argv[4]) if len(sys.argv) > 4 else 1)
     try:
         import subprocess
         out["generated_at_commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
