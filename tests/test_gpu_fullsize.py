@@ -128,11 +128,13 @@ def test_c4_rigid_body_and_reproducibility(c4):
 
 @pytest.mark.parametrize("size", ["32 patches", "C5 share of one GPU", "C5 (1024 patches) on one GPU"])
 def test_c5_family_p4_properties(size):
-    """p = 4 (BASELINE.json configs[4]: synthetic fuselage, MFMA 2x2-tile element kernel) at sizes the oracle does not run in
-    seconds -- 32 patches (0.3 M dofs) and one GPU's share of C5 at 8 GPUs (128 patches of 53 spans a side, 1.04 M dofs,
-    7.35 M Gauss points; the element blocks take two scratch chunks): K x and (dR/dCP) x against residual differences,
-    symmetry of K, and bitwise agreement of two assemblies.  The full C5 (1024 patches, 10.0 M dofs, 72 M Gauss points, 100 GB of
-    device memory, eight scratch chunks) runs the same checks with the matrices compared through products instead of 45 GB of host copies."""
+    """p = 4 (BASELINE.json configs[4]: synthetic fuselage; default path since round 5: hybrid -- Newton passes through the row records of
+    gf_element_rec4.hpp, passes with dR/dCP / dR/dh through the element blocks of kl_element_mfma4_kernel) at sizes the oracle does not run in
+    seconds -- 32 patches (0.3 M dofs) and one GPU's share of C5 at 8 GPUs (128 patches of 53 spans a side, 1.25 M dofs,
+    9.0 M Gauss points; one chunk of records, one of element blocks): K x and (dR/dCP) x against residual differences,
+    symmetry of K, and bitwise agreement of two assemblies.  The full C5 (1024 patches, 10.0 M dofs, 72 M Gauss points, 187 GB of
+    device memory: 45 GB of CSR values, 50 GB of Newton-pass records in one chunk, element blocks in five chunks) runs the same checks with the
+    matrices compared through products instead of 45 GB of host copies."""
     from goldfish_amd import _lib
     full = size.startswith("C5 (1024")
     spec = (G.synthetic_fuselage(8, 4, nel=24, p=4, jitter=2) if size == "32 patches" else
