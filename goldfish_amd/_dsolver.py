@@ -13,8 +13,10 @@ and a solve is: forward sweep of the own subtrees (A), all-gather of the root fr
 backward sweep of the top (B, replicated), backward sweep of the own subtrees with the top's x at their boundaries, all-reduce of the pieces of x.  Iterative
 refinement runs against K itself (the replicated values: the same ``residual`` on every rank), like gfs_solve.
 
-What is distributed: the subtree factorisations and sweeps (C4 on 8 ranks: 7.2 of the 9.3 Tflop, 1/8 each).  What is replicated: the top fronts (2.1 Tflop), K's
-values (stage 1's all-gather of the owned value rows), the refinement residuals.  Factor memory per rank: own subtrees + top + the stubs' Schur complements.
+What is distributed: the subtree factorisations and sweeps (C4 on 8 ranks: 7.2 of the 9.3 Tflop, 1/8 each) AND K itself (round 5): the elimination tree follows
+the patch partition (partition_tree below), a rank's handle lives in that rank's LOCAL numbering on the K it assembled (owned rows + ghost columns; blocks whose later
+control point is a ghost are read transposed from the owned row: gfs_set_row_mask), and only the rows of the rank separators (a few per cent of K) are gathered
+for the replicated top.  What is replicated: the top fronts, the refinement residuals.  Factor memory per rank: own subtrees + top + the stubs' Schur complements.
 
 K must be symmetric (the general mode of the single-GPU solver is not distributed).  ``dist`` is torch.distributed ('nccl' == RCCL on a multi-GPU node; 'gloo' in
 the tests, where the buffers travel through the host)."""
@@ -40,6 +42,7 @@ def _bind():
         getattr(L, name).argtypes = [vp, C.c_int64, vp]
     for name in ("gfs_get_fbnd_packed", "gfs_set_fbnd_packed"):
         getattr(L, name).argtypes = [vp, C.c_int64, _i64p, vp]
+    L.gfs_set_row_mask.argtypes = [vp, vp]
     L.gfs_x_ptr.argtypes = [vp]
     L.gfs_x_ptr.restype = vp
     L.gfs_forward_dev.argtypes = [vp, vp]
@@ -148,25 +151,41 @@ def partial_symbolic(sym, keep, stub_roots=(), later_cp=None):
 
 
 class _Part:
-    """One partial handle of libgoldfish_solver (gfs_create_nd_partial) over partial_symbolic(...)."""
+    """One partial handle of libgoldfish_solver (gfs_create_nd_partial) over partial_symbolic(...), created in its OWN numbering of the control points:
+    ``to_own`` maps a global control point to that numbering (-1: not there), ``own_ids`` the other way; nb_ptr / nb: the control-point graph in that numbering;
+    dK: the K values in the layout of that graph; ``row_ok``: rows that hold values (None: all)."""
 
-    def __init__(self, L, sym, nb_ptr, nb, dK, device, keep, stub_roots=(), later_cp=None):
+    def __init__(self, L, sym, keep, stub_roots, later_cp, own_ids, nb_ptr, nb, dK, device, row_ok=None):
         fronts, sub, pmap = partial_symbolic(sym, keep, stub_roots, later_cp)
-        self.fronts, self.local, self.sym = fronts, {int(t): i for i, t in enumerate(fronts)}, sub
+        self.fronts, self.local = fronts, {int(t): i for i, t in enumerate(fronts)}
         self.nbnd = np.diff(sub.bnd_off)
-        self._keep = [np.ascontiguousarray(a, np.int64) for a in (sub.elim, sub.elim_off, sub.bnd, sub.bnd_off, sub.parent, sub.order, sub.front_of, pmap)]
+        own_ids = np.asarray(own_ids, np.int64)
+        to_own = np.full(sym.order.size, -1, np.int64)
+        to_own[own_ids] = np.arange(own_ids.size)
+        elim, bnd = to_own[sub.elim], to_own[sub.bnd]
+        if (elim < 0).any() or (bnd < 0).any():
+            raise RuntimeError("DistributedSolver: a control point of this handle's fronts is not in its numbering (the partition's ghosts do not cover a boundary)")
+        order, front_of = sub.order[own_ids], sub.front_of[own_ids]
+        self.nb_ptr, self.nb = np.ascontiguousarray(nb_ptr, np.int64), np.ascontiguousarray(nb, np.int32)
+        self._keep = [np.ascontiguousarray(a, np.int64) for a in (elim, sub.elim_off, bnd, sub.bnd_off, sub.parent, order, front_of, pmap)]
+        self.ncp = int(own_ids.size)
         h = C.c_void_p()
         i64 = lambda a: a.ctypes.data_as(_i64p)
-        rc = L.gfs_create_nd_partial(int(device), sym.order.size, nb_ptr.ctypes.data_as(_i64p), nb.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(dK), fronts.size,
+        rc = L.gfs_create_nd_partial(int(device), self.ncp, self.nb_ptr.ctypes.data_as(_i64p), self.nb.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(dK), fronts.size,
                                      *[i64(a) for a in self._keep], C.byref(h))
         if rc:
             raise RuntimeError(L.gfs_last_error().decode())
         self.h = h
+        if row_ok is not None:
+            self._mask = np.ascontiguousarray(row_ok, np.uint8)
+            if L.gfs_set_row_mask(h, self._mask.ctypes.data_as(C.c_void_p)):
+                raise RuntimeError(L.gfs_last_error().decode())
 
 
 class DistributedSolver:
-    """K x = b over the ranks of ``dist`` (see the module docstring).  ``dev_model``: the sharded device model (goldfish_amd/sharding.py: ShardedDeviceModel) -- its
-    ``pattern`` / ``k_values_ptr`` / ``refresh_k_values`` give the GLOBAL K with replicated values on this rank's GPU, as the stage-1 DeviceSolver uses them."""
+    """K x = b over the ranks of ``dist`` (see the module docstring).  ``dev_model``: the sharded device model (goldfish_amd/sharding.py: ShardedDeviceModel): its
+    ``pattern`` gives the GLOBAL control-point graph (symbolic phase only), its local device model (``dev_model.D``) the K this rank assembled, which the rank's
+    handle reads in place."""
 
     method = "nd-distributed"
 
@@ -185,8 +204,15 @@ class DistributedSolver:
         self.n = 3 * ncp
         if coords is None:
             raise ValueError("DistributedSolver needs the control points' coordinates")
-        sym = self.sym = _nd.nested_dissection_native(self.nb_ptr, self.nb, coords, leaf=leaf)[0]      # deterministic (also across thread counts): the same tree on every rank
-        self.owner, self.roots = split_tree(sym, self.world)
+        # owner rank of every control point (the patch partition), then the elimination tree that follows it: deterministic, the same on every rank
+        sh = dev_model.shard
+        owner_cp = np.empty(ncp, np.int64)
+        for r, own in enumerate(sh.owned_by_rank):
+            for g in own:
+                owner_cp[sh.cp_off_global[g]:sh.cp_off_global[g + 1]] = r
+        self.owner_cp = owner_cp
+        sym, self.owner, self.roots = partition_tree(self.nb_ptr, self.nb, coords, owner_cp, self.world, leaf=leaf)
+        self.sym = sym
         self.A = self.B = None
         self.rel_residual = self.backward_error = None
         self.rel_residuals = None
@@ -219,14 +245,28 @@ class DistributedSolver:
 
     def _create(self, dev_model, sym):
         torch, L = self.torch, self.L
-        dK = dev_model.k_values_ptr()
+        ncp = self.ncp
+        dev = torch.device("cuda", self.device)
         mine = np.flatnonzero(self.owner == self.rank)
         self.my_roots = [t for t in self.roots if self.owner[t] == self.rank]
         top_f = np.flatnonzero(self.owner == -1)
         top_cp = np.concatenate([sym.elim[sym.elim_off[t]:sym.elim_off[t + 1]] for t in top_f]) if top_f.size else np.zeros(0, np.int64)
-        self.A = _Part(L, sym, self.nb_ptr, self.nb, dK, self.device, mine, later_cp=top_cp) if mine.size else None
-        self.B = _Part(L, sym, self.nb_ptr, self.nb, dK, self.device, top_f, self.roots)
-        dev = torch.device("cuda", self.device)
+        # ---- handle A: this rank's subtrees in its LOCAL numbering, on the K it assembled (no gather)
+        loc = dev_model.D                                        # the rank's own DeviceModel
+        cols_g = np.asarray(dev_model.cols_g, np.int64)          # local control point -> global
+        if mine.size:
+            lptr, lnb = loc.cp_graph()
+            row_ok = np.arange(cols_g.size) < int(dev_model.n_owned_cp)
+            self.A = _Part(L, sym, mine, (), top_cp, cols_g, lptr, lnb, loc.k_values_ptr(), self.device, row_ok=row_ok)
+        # ---- handle B: the separator fronts in the numbering of S = their control points (ascending global ids), on the gathered rows of S
+        S = np.sort(top_cp)
+        self.S = S
+        s_index = np.full(ncp, -1, np.int64)
+        s_index[S] = np.arange(S.size)
+        sptr, snb = _induced(self.nb_ptr, np.asarray(self.nb, np.int64), S, ncp) if S.size else (np.zeros(1, np.int64), np.zeros(0, np.int32))
+        self._valB = torch.zeros(max(1, 9 * int(sptr[-1])), dtype=torch.float64, device=dev)
+        self._build_top_value_exchange(dev_model, S, s_index, sptr, snb, cols_g, dev)
+        self.B = _Part(L, sym, top_f, self.roots, None, S, sptr, snb, int(self._valB.data_ptr()), self.device)
         # exchange buffers: Schur complements (doubles per subtree root, padded to the largest per rank) and boundary contributions
         self.schur_len = {t: int(L.gfs_schur_doubles(self.B.h, self.B.local[t])) for t in self.roots}
         self.fb_len = {t: 3 * int(self.B.nbnd[self.B.local[t]]) for t in self.roots}
@@ -242,18 +282,95 @@ class DistributedSolver:
                 if L.gfs_set_schur_source(self.B.h, self.B.local[t], C.c_void_p(self.schur_all.data_ptr() + 8 * off)):
                     raise RuntimeError(L.gfs_last_error().decode())
                 off += self.schur_len[t]
-        # the roots of every rank in B's / A's local front numbers (the packed boundary copies of a substitution)
         self._rootsB = [np.ascontiguousarray([self.B.local[t] for t in ts], np.int64) for ts in per_rank]
         self._rootsA = np.ascontiguousarray([self.A.local[t] for t in self.my_roots], np.int64) if self.A else np.zeros(0, np.int64)
-        # index sets of the exchange of x: the dofs this rank's subtrees eliminate, the dofs of the top
+
+        # ---- index sets between the replicated global vectors and the handles' numberings
         def dofs(cps):
             return (3 * np.asarray(cps, np.int64)[:, None] + np.arange(3)).ravel()
+        t64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int64)).to(dev)
+        self.loc_dof_g = t64(dofs(cols_g))                       # global dof of every local dof (right-hand side of A)
         own_cp = np.concatenate([sym.elim[sym.elim_off[t]:sym.elim_off[t + 1]] for t in mine]) if mine.size else np.zeros(0, np.int64)
-        self.own_dofs = torch.from_numpy(dofs(own_cp)).to(dev)
-        self.top_dofs = torch.from_numpy(dofs(top_cp)).to(dev)
-        self.xA = self._view(L.gfs_x_ptr(self.A.h), self.n) if self.A else None
-        self.xB = self._view(L.gfs_x_ptr(self.B.h), self.n)
+        g2l = np.full(ncp, -1, np.int64)
+        g2l[cols_g] = np.arange(cols_g.size)
+        self.own_dofs_g, self.own_dofs_l = t64(dofs(own_cp)), t64(dofs(g2l[own_cp]))
+        self.S_dofs_g = t64(dofs(S))
+        here = np.flatnonzero(s_index[cols_g] >= 0)              # local control points that lie in S: the top's x at the boundaries of the own subtrees
+        self.S_here_l, self.S_here_s = t64(dofs(here)), t64(dofs(s_index[cols_g[here]]))
+        self.xA = self._view(L.gfs_x_ptr(self.A.h), 3 * self.A.ncp) if self.A else None
+        self.xB = self._view(L.gfs_x_ptr(self.B.h), 3 * self.B.ncp)
         self.b_dev = torch.zeros(self.n, dtype=torch.float64, device=dev)
+        # |K|_F from the owned rows of all ranks (the backward error's norm)
+        nnz_owned = 9 * int(loc.cp_graph()[0][int(dev_model.n_owned_cp)])
+        self._k_owned = self._view(loc.k_values_ptr(), nnz_owned) if nnz_owned else None
+
+    def _build_top_value_exchange(self, dev_model, S, s_index, sptr, snb, cols_g, dev):
+        """The rows of S (K restricted to the separators' control points) for the replicated top handle: every rank packs the blocks of the S rows it owns in the
+        canonical order (S ascending; per row its S neighbours ascending; per block i, j), ONE all-gather of the packed values, one device gather into the block-CSR
+        layout of B.  Source indices into this rank's own K and the placement of every rank's packet are built here once."""
+        torch = self.torch
+        deg = np.diff(sptr)
+        own_of_S = self.owner_cp[S]
+        rows_S = np.repeat(np.arange(S.size), deg)                       # row of every block of the S graph
+        k_in_row = np.arange(snb.size) - np.repeat(sptr[:-1], deg)
+        # destination of (block, i, j) in B's value layout: 9 ptr[a] + i 3 deg(a) + 3 k + j
+        dst_blk = 9 * sptr[rows_S] + 3 * k_in_row
+        ij_i, ij_j = np.repeat(np.arange(3), 3), np.tile(np.arange(3), 3)
+        dst = (dst_blk[:, None] + ij_i[None, :] * 3 * deg[rows_S][:, None] + ij_j[None, :])         # [block][9]
+        counts = [int(9 * (own_of_S[rows_S] == r).sum()) for r in range(self.world)]
+        self._top_pad = max(1, max(counts))
+        place = np.zeros(max(1, 9 * snb.size), np.int64)
+        for r in range(self.world):
+            sel = np.flatnonzero(own_of_S[rows_S] == r)
+            place[dst[sel].ravel()] = r * self._top_pad + np.arange(9 * sel.size)
+        self._top_place = torch.from_numpy(place).to(dev)
+        # source: this rank's blocks in ITS K (local numbering: the neighbour lists are in local ids, another order than the global one)
+        mine = np.flatnonzero(own_of_S[rows_S] == self.rank)
+        self._top_send = torch.zeros(self._top_pad, dtype=torch.float64, device=dev)
+        self._top_recv = torch.empty(self.world * self._top_pad, dtype=torch.float64, device=dev)
+        if mine.size:
+            lptr, lnb = dev_model.D.cp_graph()
+            g2l = np.full(self.ncp, -1, np.int64)
+            g2l[cols_g] = np.arange(cols_g.size)
+            a_l, b_g = g2l[S[rows_S[mine]]], S[snb[mine]]
+            # slot of neighbour b in the local list of a: search the (row, global neighbour) key in the sorted keys of the local lists of the needed rows
+            rows_need = np.unique(a_l)
+            ldeg = np.diff(lptr)[rows_need]
+            lrow = np.repeat(rows_need, ldeg)
+            lpos = np.concatenate([np.arange(lptr[a], lptr[a + 1]) for a in rows_need]) if rows_need.size < 64 else (np.repeat(lptr[rows_need], ldeg) + np.arange(ldeg.sum()) - np.repeat(np.cumsum(ldeg) - ldeg, ldeg))
+            lkey = lrow * np.int64(self.ncp) + cols_g[lnb[lpos]]
+            o = np.argsort(lkey, kind="stable")
+            want = a_l * np.int64(self.ncp) + b_g
+            at = np.searchsorted(lkey[o], want)
+            if (at >= o.size).any() or (lkey[o][np.minimum(at, o.size - 1)] != want).any():
+                raise RuntimeError("DistributedSolver: a block of the separator rows is missing from this rank's K")
+            slot = lpos[o][at] - lptr[a_l]                               # k of b in a's local list
+            ld = np.diff(lptr)[a_l]
+            src = (9 * lptr[a_l] + 3 * slot)[:, None] + ij_i[None, :] * 3 * ld[:, None] + ij_j[None, :]
+            self._top_src = torch.from_numpy(src.ravel()).to(dev)
+        else:
+            self._top_src = None
+
+    def _gather_top_values(self):
+        """Collective: the rows of S from their owners into B's value buffer (device buffers; the all-gather is the only exchange of K values there is)."""
+        torch = self.torch
+        if self._top_src is not None:
+            kloc = self._view(self.D.D.k_values_ptr(), 9 * int(self.D.D.cp_graph()[0][-1])) if not hasattr(self, "_k_all") else self._k_all
+            self._k_all = kloc
+            self._top_send[:self._top_src.numel()] = kloc[self._top_src]
+        if self.world > 1:
+            self._allgather_into(self._top_recv, self._top_send)
+            torch.index_select(self._top_recv, 0, self._top_place, out=self._valB)
+        else:
+            torch.index_select(self._top_send, 0, self._top_place, out=self._valB)
+
+    def _allgather_into(self, recv, send):
+        if self.cuda:
+            self.dist.all_gather_into_tensor(recv, send, group=self.group)
+        else:                                               # gloo: through the host
+            parts = [self.torch.empty(send.numel(), dtype=self.torch.float64) for _ in range(self.world)]
+            self.dist.all_gather(parts, send.cpu(), group=self.group)
+            recv.copy_(self.torch.cat(parts))
 
     # -- helpers
     def _view(self, ptr, n):
@@ -303,8 +420,8 @@ class DistributedSolver:
         L, torch = self.L, self.torch
         self.D.sync()
         t0 = time.perf_counter()
-        if hasattr(self.D, "refresh_k_values"):
-            self.D.refresh_k_values()
+        self._gather_top_values()                              # the rows of the rank separators: the only K values that travel
+        torch.cuda.current_stream(self.b_dev.device).synchronize()
         t1 = time.perf_counter()
         err = None
         if self.A is not None:
@@ -337,8 +454,15 @@ class DistributedSolver:
                 L.gfs_info(p.h, v)
                 small = small or bool(v[5])
         self.small_pivot = self._any(small)                    # the same flag on every rank: solve_K's acceptance bar depends on it
-        L.gfs_info(self.B.h, v)
-        self.norm_K = float(v[7])
+        ss = torch.zeros(1, dtype=torch.float64, device=self.b_dev.device)
+        if self._k_owned is not None:
+            ss += (self._k_owned * self._k_owned).sum()
+        if self.world > 1:
+            if self.cuda:
+                self.dist.all_reduce(ss, group=self.group)
+            else:
+                h_ = ss.cpu(); self.dist.all_reduce(h_, group=self.group); ss = h_
+        self.norm_K = float(ss.sqrt())
 
     def _substitute(self, b_dev):
         """x = (L D L^T)^-1 b for one right-hand side on the device (torch tensor, replicated); returns a new device tensor (replicated).  The library calls return when
@@ -348,10 +472,12 @@ class DistributedSolver:
         L, torch = self.L, self.torch
         st = torch.cuda.current_stream(b_dev.device)
         err = None
-        st.synchronize()                                        # b_dev may have been written by torch
+        bS = b_dev[self.S_dofs_g].contiguous()
         try:
             if self.A is not None:
-                self._check(L.gfs_forward_dev(self.A.h, C.c_void_p(b_dev.data_ptr())))
+                bl = b_dev[self.loc_dof_g].contiguous()            # the right-hand side in this rank's local numbering
+                st.synchronize()
+                self._check(L.gfs_forward_dev(self.A.h, C.c_void_p(bl.data_ptr())))
                 self._check(L.gfs_get_fbnd_packed(self.A.h, self._rootsA.size, self._rootsA.ctypes.data_as(_i64p), C.c_void_p(self.fb_all.data_ptr() + 8 * self.rank * self.fb_pad)))
         except RuntimeError as e:
             err = str(e)
@@ -362,15 +488,15 @@ class DistributedSolver:
             for r, rb in enumerate(self._rootsB):
                 if rb.size:
                     self._check(L.gfs_set_fbnd_packed(self.B.h, rb.size, rb.ctypes.data_as(_i64p), C.c_void_p(self.fb_all.data_ptr() + 8 * r * self.fb_pad)))
-            self._check(L.gfs_forward_dev(self.B.h, C.c_void_p(b_dev.data_ptr())))
+            self._check(L.gfs_forward_dev(self.B.h, C.c_void_p(bS.data_ptr())))
             self._check(L.gfs_backward_dev(self.B.h))
             if self.A is not None and err is None:
-                self.xA[self.top_dofs] = self.xB[self.top_dofs]          # the top's x at the boundaries of the own subtrees
+                self.xA[self.S_here_l] = self.xB[self.S_here_s]          # the top's x at the boundaries of the own subtrees
                 st.synchronize()
                 self._check(L.gfs_backward_dev(self.A.h))
-                x[self.own_dofs] = self.xA[self.own_dofs]
+                x[self.own_dofs_g] = self.xA[self.own_dofs_l]
             if self.rank == 0:
-                x[self.top_dofs] = self.xB[self.top_dofs]
+                x[self.S_dofs_g] = self.xB
         except RuntimeError as e:
             err = err or str(e)
         x[self.n] = 0.0 if err is None else 1.0
@@ -446,3 +572,137 @@ class DistributedSolver:
                 out["factor_flops"] += float(v[4])
         out["small_pivot"], out["backward_error"], out["norm_K"] = self.small_pivot, self.backward_error, self.norm_K
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------------------------
+# Round 5: an elimination tree that FOLLOWS THE PATCH PARTITION (VERDICT r04 missing 2 / next 2b).  split_tree above deals the subtrees of the global nested
+# dissection to the ranks by work -- whoever factors a subtree needs the K rows of its control points, hence the replicated K (2.8 GB all-gathered per
+# factorisation at C4).  MUMPS on ``comm`` (GOLDFISH/utils/opt_utils.py:156-209) does not replicate the matrix.  Here the leaves of the tree are the ranks' own
+# control points: with S = the lower-rank end of every edge of the control-point graph that joins control points of two ranks (a vertex separator: no edge joins
+# owned(r) \ S and owned(r') \ S), rank r dissects owned(r) \ S by itself, and S is eliminated along the hierarchy of the rank bisection
+# (sharding.partition_patches splits the ranks [r0, r0 + n) into [r0, r0 + n // 2) and the rest): a control point of S belongs to the shallowest node of that
+# hierarchy at which one of its edges crosses -- one separator front per node, exactly the top of a nested dissection whose first cuts are the partition's.
+def rank_tree_nodes(world):
+    """Internal nodes of the rank bisection as (r0, n, depth), parents before children."""
+    out, stack = [], [(0, world, 0)]
+    while stack:
+        r0, n, d = stack.pop(0)
+        if n <= 1:
+            continue
+        out.append((r0, n, d))
+        stack += [(r0, n // 2, d + 1), (r0 + n // 2, n - n // 2, d + 1)]
+    return out
+
+
+def _lca_node(world, ra, rb):
+    """Index (in rank_tree_nodes) of the node at which ranks ra != rb part."""
+    nodes = rank_tree_nodes(world)
+    index = {(r0, n): i for i, (r0, n, _) in enumerate(nodes)}
+    r0, n = 0, world
+    while True:
+        nl = n // 2
+        la, lb = ra < r0 + nl, rb < r0 + nl
+        if la != lb:
+            return index[(r0, n)]
+        r0, n = (r0, nl) if la else (r0 + nl, n - nl)
+
+
+def _induced(nb_ptr, nb, ids, ncp):
+    """Subgraph induced by the control points ``ids`` (ascending): (ptr, nb) in local numbers; the lists keep the control point itself."""
+    loc = np.full(ncp, -1, np.int64)
+    loc[ids] = np.arange(ids.size)
+    deg = np.diff(nb_ptr)[ids]
+    rows = np.repeat(np.arange(ids.size), deg)
+    cols = loc[np.concatenate([nb[nb_ptr[a]:nb_ptr[a + 1]] for a in ids])] if ids.size < 64 else loc[nb[np.repeat(nb_ptr[ids], deg) + (np.arange(deg.sum()) - np.repeat(np.cumsum(deg) - deg, deg))]]
+    keep = cols >= 0
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=ids.size))]).astype(np.int64)
+    return ptr, cols[keep].astype(np.int32)
+
+
+def partition_tree(nb_ptr, nb, coords, owner_cp, world, leaf=128, native=True):
+    """(Symbolic, owner, roots) of the partition-following elimination tree: ``owner[t]`` = the rank whose control points front t eliminates (-1: a separator front
+    of the rank hierarchy, replicated), ``roots`` = the fronts of rank subtrees whose parent is a separator front (or none).  Boundaries and parents come from one
+    pass over the fronts in elimination order (bnd(t) = later neighbours of t's own control points + the boundaries of its children, parent(t) = the front of the
+    first boundary control point), then the fronts are renumbered in post-order (what the numeric phase expects: a subtree is a contiguous range ending at its root)."""
+    nb_ptr, nb = np.asarray(nb_ptr, np.int64), np.asarray(nb, np.int64)
+    ncp = nb_ptr.size - 1
+    owner_cp = np.asarray(owner_cp, np.int64)
+    X = np.asarray(coords, float).reshape(ncp, -1)
+    rows = np.repeat(np.arange(ncp, dtype=np.int64), np.diff(nb_ptr))
+    cut = owner_cp[rows] < owner_cp[nb]                      # the lower-rank end of an edge between two ranks goes into S ...
+    node_of = np.full(ncp, -1, np.int64)                     # ... at the shallowest node of the rank hierarchy one of its edges crosses
+    if cut.any():
+        pair = owner_cp[rows[cut]] * world + owner_cp[nb[cut]]
+        nodes = rank_tree_nodes(world)
+        depth_of = np.array([d for (_, _, d) in nodes])
+        up, inv = np.unique(pair, return_inverse=True)
+        lca = np.array([_lca_node(world, int(p // world), int(p % world)) for p in up])[inv]
+        # shallowest node per control point: sort by (cp, depth) and keep the first
+        o = np.lexsort((depth_of[lca], rows[cut]))
+        cp_s, lca_s = rows[cut][o], lca[o]
+        first = np.concatenate([[True], cp_s[1:] != cp_s[:-1]])
+        node_of[cp_s[first]] = lca_s[first]
+    in_S = node_of >= 0
+    # ---- the fronts in a first elimination order: every rank's own nested dissection, then the separator nodes deepest first
+    elim_parts, owner_parts = [], []
+    for r in range(world):
+        ids = np.flatnonzero((owner_cp == r) & ~in_S)
+        if ids.size == 0:
+            continue
+        ptr, nbs = _induced(nb_ptr, nb, ids, ncp)
+        sym_r = (_nd.nested_dissection_native(ptr, nbs, X[ids], leaf=leaf)[0] if native else _nd.nested_dissection(ptr, nbs, X[ids], leaf=leaf))
+        for t in range(sym_r.nfronts):
+            elim_parts.append(ids[sym_r.elim[sym_r.elim_off[t]:sym_r.elim_off[t + 1]]])
+            owner_parts.append(r)
+    if in_S.any():
+        nodes = rank_tree_nodes(world)
+        for i in sorted(range(len(nodes)), key=lambda i: (-nodes[i][2], i)):        # deepest first
+            ids = np.flatnonzero(node_of == i)
+            if ids.size:
+                elim_parts.append(ids[np.argsort(X[ids, 0], kind="stable")])
+                owner_parts.append(-1)
+    nf = len(elim_parts)
+    elim = np.concatenate(elim_parts).astype(np.int64)
+    assert elim.size == ncp and np.unique(elim).size == ncp
+    elim_off = np.concatenate([[0], np.cumsum([e.size for e in elim_parts])]).astype(np.int64)
+    order = np.empty(ncp, np.int64); order[elim] = np.arange(ncp)
+    front_of = np.repeat(np.arange(nf), np.diff(elim_off))[order]
+    # later neighbours of every front's own control points (outside the front), sorted by elimination position
+    later = (order[nb] > order[rows]) & (front_of[nb] != front_of[rows])
+    key = np.unique(front_of[rows[later]] * np.int64(ncp) + order[nb[later]])
+    ef, eb = key // ncp, elim[key % ncp]
+    own_off = np.concatenate([[0], np.cumsum(np.bincount(ef, minlength=nf))]).astype(np.int64)
+    parent = np.full(nf, -1, np.int64)
+    kids = [[] for _ in range(nf)]
+    bnds = [None] * nf
+    for t in range(nf):
+        cand = eb[own_off[t]:own_off[t + 1]]
+        if kids[t]:
+            cand = np.unique(np.concatenate([cand] + [bnds[c] for c in kids[t]]))
+            cand = cand[front_of[cand] != t]
+            cand = cand[np.argsort(order[cand], kind="stable")]
+        bnds[t] = cand
+        if cand.size:
+            parent[t] = front_of[cand[0]]
+            kids[parent[t]].append(t)
+    # ---- post-order renumbering
+    post, stack = [], [(t, False) for t in reversed([t for t in range(nf) if parent[t] < 0])]
+    while stack:
+        t, seen = stack.pop()
+        if seen:
+            post.append(t)
+        else:
+            stack.append((t, True))
+            stack += [(c, False) for c in reversed(kids[t])]
+    new = np.empty(nf, np.int64); new[post] = np.arange(nf)
+    elim2 = np.concatenate([elim_parts[t] for t in post]).astype(np.int64)
+    elim_off2 = np.concatenate([[0], np.cumsum([elim_parts[t].size for t in post])]).astype(np.int64)
+    order2 = np.empty(ncp, np.int64); order2[elim2] = np.arange(ncp)
+    front_of2 = new[front_of]
+    b2 = [bnds[t][np.argsort(order2[bnds[t]], kind="stable")] for t in post]
+    bnd_off2 = np.concatenate([[0], np.cumsum([b.size for b in b2])]).astype(np.int64)
+    parent2 = np.array([new[parent[t]] if parent[t] >= 0 else -1 for t in post], np.int64)
+    sym = _nd.Symbolic(elim2, elim_off2, np.concatenate(b2).astype(np.int64) if nf else np.zeros(0, np.int64), bnd_off2, parent2, order2, front_of2)
+    owner = np.array([owner_parts[t] for t in post], np.int64)
+    roots = [t for t in range(nf) if owner[t] >= 0 and (parent2[t] < 0 or owner[parent2[t]] < 0)]
+    return sym, owner, roots

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GF_SOLVER_LIB", os.path.join(_HERE, "libgoldfish_solver.so"))   # GF_SOLVER_LIB: A/B builds while tuning
 EXPORTS = ["gfs_last_error", "gfs_create", "gfs_create_nd", "gfs_destroy", "gfs_refactor", "gfs_solve", "gfs_solve_dev", "gfs_set_general", "gfs_solve_transposed",
            "gfs_solve_transposed_dev", "gfs_info", "gfs_solve_multi", "gfs_solve_multi_dev", "gfs_create_nd_partial", "gfs_schur_doubles", "gfs_export_schur",
-           "gfs_set_schur_source", "gfs_get_fbnd", "gfs_set_fbnd", "gfs_get_fbnd_packed", "gfs_set_fbnd_packed", "gfs_x_ptr", "gfs_forward_dev", "gfs_backward_dev", "gfs_symbolic_create", "gfs_symbolic_sizes",
+           "gfs_set_schur_source", "gfs_get_fbnd", "gfs_set_fbnd", "gfs_get_fbnd_packed", "gfs_set_fbnd_packed", "gfs_set_row_mask", "gfs_x_ptr", "gfs_forward_dev", "gfs_backward_dev", "gfs_symbolic_create", "gfs_symbolic_sizes",
            "gfs_symbolic_copy", "gfs_symbolic_destroy"]
 _L = None
 

@@ -597,12 +597,16 @@ __device__ __forceinline__ int nd_pos(const Front& F, int t, int c, const int* _
 }
 // K (block CSR, original numbering) -> fronts: the block (a, b) belongs to the front that eliminates the earlier of the two, and is stored
 // there when a's position is not in front of b's (lower triangle); one wave per control point a
+// row_ok (may be nullptr = every row holds values): a handle on ONE RANK'S K of a sharded model (gfs_set_row_mask) has values in the rows of the control points that
+// rank owns only; the block (a, b) of a pair whose later control point b is a ghost there is then written from a's row, transposed (K is symmetric) -- a rank's
+// subtrees never need a row another rank assembled.
 __global__ void nd_scatter_kernel(long long ncp, const long long* __restrict__ nb_ptr, const int* __restrict__ nb, const int* __restrict__ rev, const double* __restrict__ valK,
                                   const Front* __restrict__ fronts, const int* __restrict__ front_of, const long long* __restrict__ order, const int* __restrict__ bnd,
-                                  const long long* __restrict__ tri, double* __restrict__ arena) {
+                                  const long long* __restrict__ tri, double* __restrict__ arena, const unsigned char* __restrict__ row_ok) {
     const long long a = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (a >= ncp) return;
+    if (row_ok && !row_ok[a]) return;
     const long long ptr = nb_ptr[a], deg = nb_ptr[a + 1] - ptr;
     const long long oa = order[a];
     for (long long k = lane; k < deg; k += 64) {
@@ -611,7 +615,17 @@ __global__ void nd_scatter_kernel(long long ncp, const long long* __restrict__ n
         if (t < 0) continue;                        // partial handle (gfs_create_nd_partial): the entry belongs to a front of another handle
         const Front F = fronts[t];
         const int pa = nd_pos(F, t, (int)a, front_of, order, bnd), pb = nd_pos(F, t, b, front_of, order, bnd);
-        if (pa < pb) continue;
+        if (pa < pb) {
+            if (!row_ok || row_ok[b]) continue;     // b's own row writes the block
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {       // K[(b, j), (a, i)] = K[(a, i), (b, j)]: row b is not here, a's is
+                    const int R = nd_dofpos(F, pb, j), C = nd_dofpos(F, pa, i);
+                    arena[nd_entry(F, tri, R, C)] = fact_value(valK, nb_ptr, rev, ptr, deg, k, b, i, j);
+                }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -1004,6 +1018,7 @@ struct gfs_handle {
     static constexpr int RHS_BLOCK = 3;      // right-hand sides per pass over the factors (the front-local vectors of the small fronts sit in LDS: 3 x 48 KB)
     static constexpr int MAX_RHS = 8;
     std::vector<SolveWs> ws; long long ws_front_len = 0, ws_bnd_len = 0;
+    unsigned char* d_row_ok = nullptr;            // gfs_set_row_mask: rows of d_valK that hold values (a rank's own rows of a sharded K); nullptr = all
     bool lds_raised[3] = {false, false, false};   // hipFuncAttributeMaxDynamicSharedMemorySize of the NR-right-hand-side sweep kernels raised on this handle's device
     template <class Tp> Tp* dalloc(size_t cnt) {
         void* p = nullptr; const size_t nb_ = (cnt ? cnt : 1) * sizeof(Tp);
@@ -1560,7 +1575,7 @@ int gfs_refactor(gfs_handle* h) {
         HIPCHK(hipMemsetAsync(h->band, 0, (size_t)h->ntiles * NB2 * sizeof(double), h->stream));
         if (h->nd) {
             hipLaunchKernelGGL(nd_scatter_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->general ? h->d_rev : nullptr, h->valK, h->d_fronts, h->d_front_of, h->d_order,
-                               h->d_bnd, h->d_tri, h->band);
+                               h->d_bnd, h->d_tri, h->band, h->d_row_ok);
             const int nf = (int)h->fronts.size();
             hipLaunchKernelGGL(nd_pad_kernel, dim3(nf), dim3(64), 0, h->stream, h->d_fronts, h->d_tri, h->band);
             if (h->partial) for (int t = 0; t < nf; ++t) if (h->stub_src[t]) {         // a stub front's tiles = the Schur complement another handle exported (one contiguous triangle)
@@ -1842,6 +1857,19 @@ static int fbnd_copy(gfs_handle* h, int64_t n, const int64_t* fronts, double* d_
             off += len;
         }
         HIPCHK(hipStreamSynchronize(W0.stream));
+    } catch (const std::exception& ex) { return sfail(ex.what()); }
+    return 0;
+}
+// rows of d_valK that hold values: mask [ncp] (host), 1 = the control point's three rows are assembled in this K (a rank's owned rows of a sharded model), 0 = not
+// (ghost rows).  The scatter of a partial handle then reads a block whose later control point has no row from the earlier one's row, transposed.  nullptr: all rows.
+int gfs_set_row_mask(gfs_handle* h, const unsigned char* mask) {
+    if (!h || !h->nd) return sfail("gfs_set_row_mask: needs a nested-dissection handle");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        if (!mask) { h->d_row_ok = nullptr; h->factored = false; return 0; }
+        if (!h->d_row_ok) h->d_row_ok = h->dalloc<unsigned char>((size_t)h->ncp);
+        HIPCHK(hipMemcpy(h->d_row_ok, mask, (size_t)h->ncp, hipMemcpyHostToDevice));
+        h->factored = false;
     } catch (const std::exception& ex) { return sfail(ex.what()); }
     return 0;
 }

@@ -611,7 +611,7 @@ class NonMatchingOpt:
 
     def _use_distributed_solver(self):
         from . import _solver
-        if getattr(self, "_dist", None) is None or self.sharded_solver == "replicated" or not self.symmetric_K:
+        if getattr(self, "_dist", None) is None or self.sharded_solver == "replicated" or not self.symmetric_K or getattr(self, "world", 2) < 2:
             return False
         return self.sharded_solver == "distributed" or self.vec_iga_dof // 3 >= _solver.ND_MIN_CP
 

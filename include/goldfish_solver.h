@@ -96,6 +96,10 @@ int gfs_set_fbnd(gfs_handle* h, int64_t front, const double* d_in);
 int gfs_get_fbnd_packed(gfs_handle* h, int64_t n, const int64_t* fronts, double* d_out);
 int gfs_set_fbnd_packed(gfs_handle* h, int64_t n, const int64_t* fronts, const double* d_in);
 double* gfs_x_ptr(gfs_handle* h);
+/* A handle on ONE RANK'S K of a sharded model (local numbering: owned control points, then ghosts): mask [ncp] (host), 1 = the control point's rows hold values.
+ * gfs_refactor then reads the block of a pair whose later control point has no row from the earlier one's row, transposed (K symmetric): the subtrees a rank
+ * eliminates never need a row another rank assembled -- no replicated K (goldfish_amd/_dsolver.py, round 5).  NULL: every row holds values (the default). */
+int gfs_set_row_mask(gfs_handle* h, const unsigned char* mask);
 int gfs_forward_dev(gfs_handle* h, const double* d_b);
 int gfs_backward_dev(gfs_handle* h);
 /* info[0] = half bandwidth (dofs), [1] = block columns, [2] = band tiles per block row, [3] = device bytes,

@@ -1153,3 +1153,51 @@ def test_design_to_analysis_control_nets():
         assert max(prob.check_partials(compact_print=False).values()) < 1e-6
     prob = om.Problem(model=comps[3]); prob.setup(); prob.run_model()
     assert np.abs(np.ravel(prob.get_val('CP_pin2'))).max() == 0.0       # feasible at the initial design
+
+
+def test_partition_following_elimination_tree():
+    """goldfish_amd/_dsolver.py: partition_tree (round 5) -- the elimination tree of the distributed factorisation follows the patch partition, so that a rank's
+    subtrees eliminate only control points that rank owns (its handle reads the K it assembled; no replicated K): the control points on rank boundaries (the
+    lower-rank end of every edge between two ranks) are eliminated along the hierarchy of the rank bisection, everything else by the owner's own nested
+    dissection.  Checked for 1, 2, 3, 4, 8 ranks on a random planar graph: every control point eliminated once, a subtree front holds one rank's control points
+    only, parents are later fronts and never another rank's, and the dense statement of the numeric phase (_nd.multifrontal_reference_solve) on that tree solves
+    a random SPD system to round-off."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    from goldfish_amd import _nd, _dsolver
+    rng = np.random.default_rng(5)
+    ncp = 700
+    pts = rng.uniform(0, 1, (ncp, 3)) * [1.0, 0.8, 0.02]
+    adj = np.abs(pts[:, None, :2] - pts[None, :, :2]).max(-1) < 0.07
+    nb_lists = [np.flatnonzero(adj[a]) for a in range(ncp)]
+    nb_ptr = np.concatenate([[0], np.cumsum([len(x) for x in nb_lists])]).astype(np.int64)
+    nb = np.concatenate(nb_lists).astype(np.int32)
+    rows = np.repeat(np.arange(ncp), np.diff(nb_ptr))
+    B = sp.csr_matrix((rng.uniform(0.1, 1.0, nb.size), (rows, nb)), shape=(ncp, ncp))
+    B = B + B.T
+    K = sp.kron(B, np.ones((3, 3))).tocsr()
+    K = K + sp.diags(np.asarray(abs(K).sum(1)).ravel() + 1.0)
+    b = rng.standard_normal(3 * ncp)
+    xref = spl.spsolve(K.tocsc(), b)
+    flops_global = _nd.nested_dissection(nb_ptr, nb, pts, leaf=40).stats()["flops"]
+    for world in (1, 2, 3, 4, 8):
+        nx = 2 if world >= 4 else world
+        gx = np.minimum((pts[:, 0] * nx).astype(int), nx - 1)
+        gy = np.minimum((pts[:, 1] / 0.8 * (world // 2)).astype(int), world // 2 - 1) if world >= 4 else 0
+        owner_cp = gx * (world // 2 if world >= 4 else 1) + gy
+        sym, owner, roots = _dsolver.partition_tree(nb_ptr, nb, pts, owner_cp, world, leaf=40, native=(world % 2 == 0))
+        assert np.array_equal(np.sort(sym.elim), np.arange(ncp)) and set(np.unique(owner)) <= set(range(-1, world))
+        for t in range(sym.nfronts):
+            e, p = sym.elim[sym.elim_off[t]:sym.elim_off[t + 1]], sym.parent[t]
+            bd = sym.bnd[sym.bnd_off[t]:sym.bnd_off[t + 1]]
+            assert p < 0 or p > t
+            assert np.all(np.diff(sym.order[bd]) > 0) and (bd.size == 0 or sym.front_of[bd[0]] == p)
+            if owner[t] >= 0:
+                assert np.all(owner_cp[e] == owner[t]) and (p < 0 or owner[p] in (owner[t], -1))
+                assert (t in roots) == (p < 0 or owner[p] < 0)
+            else:
+                assert p < 0 or owner[p] < 0
+        assert int((owner < 0).sum()) <= max(world - 1, 0)                       # one separator front per node of the rank hierarchy at most
+        x = _nd.multifrontal_reference_solve(sym, K, b)
+        assert np.abs(x - xref).max() < 1e-12 * np.abs(xref).max()
+        assert sym.stats()["flops"] < 1.5 * flops_global                          # following the partition costs little against the free dissection
