@@ -18,6 +18,8 @@ else:
 A = arrays_from_spec(spec)
 D = _lib.DeviceModel(A)
 nb_ptr, nb = D.cp_graph()
+from goldfish_amd import sharding
+cp_off = np.concatenate([[0], np.cumsum([p_.ncp for p_ in spec.patches])])
 X = np.stack([A.cp_hom[f] / A.weights for f in range(3)], 1)
 D.close()
 sym = _nd.nested_dissection_native(nb_ptr, nb, X, leaf=128)[0]
@@ -29,6 +31,28 @@ RATE, XGMI, HBM = 37e12, 300e9, 4.5e12
 k_bytes = 9.0 * 8.0 * float(nb_ptr[-1])                  # K's values: 9 doubles per block of the control-point pattern
 print(name + ": %d fronts, %.2f Tflop, %.1f GB of tiles; one GPU: %.0f ms per factorisation at %.0f TFLOP/s" % (sym.nfronts, flop.sum() / 1e12, tiles.sum() * 32768 / 1e9, flop.sum() / RATE * 1e3, RATE / 1e12))
 for world in ((8, 16) if name == "C5" else (2, 4, 8)):
+    # round 5: the tree the distributed solver uses follows the patch partition (partition_tree); K is not replicated, only the separator rows travel
+    part = sharding.partition_patches(spec, world)
+    owner_cp = np.repeat(part, np.diff(cp_off))
+    symp, ownerp, rootsp = _dsolver.partition_tree(nb_ptr, nb, X, owner_cp, world, leaf=128)
+    nep, nbdp, bep, bbp = symp.front_dofs()
+    btp = bep + bbp
+    flopp = 2.0 * 64 ** 3 * _dsolver.front_work(symp)
+    tilesp = btp * (btp + 1) // 2
+    topp = ownerp == -1
+    perp = np.array([flopp[ownerp == r].sum() for r in range(world)])
+    memp = np.array([tilesp[ownerp == r].sum() for r in range(world)]) * 32768.0
+    schurp = np.array([bbp[t] * (bbp[t] + 1) // 2 for t in rootsp]) * 32768.0
+    S_cps = int(sum(symp.elim_off[t + 1] - symp.elim_off[t] for t in np.flatnonzero(topp)))
+    rows_S = float(sum(nb_ptr[a + 1] - nb_ptr[a] for t in np.flatnonzero(topp) for a in symp.elim[symp.elim_off[t]:symp.elim_off[t + 1]])) * 72.0
+    t_subp, t_topp, t_agp, t_kp = perp.max() / RATE, flopp[topp].sum() / RATE, schurp.sum() * (world - 1) / world / XGMI, rows_S * (world - 1) / world / XGMI
+    print("%d ranks, partition-following tree (what _dsolver.py runs): %d subtree roots below %d separator fronts (%d control points = %.1f %% of the model); %.2f Tflop in all "
+          "(free dissection: %.2f); subtrees %.2f Tflop (largest share %.2f, imbalance %.2f), separators %.2f Tflop (replicated); K values that travel: <= %.2f GB (the separators' rows; "
+          "replicated K: %.2f GB); Schur all-gather %.2f GB; factor memory per rank %.1f GB (own) + %.1f GB (top) + %.1f GB (stubs); modelled factorisation: K rows %.1f + subtrees %.0f "
+          "+ Schur all-gather %.0f + top %.0f = %.0f ms"
+          % (world, len(rootsp), int(topp.sum()), S_cps, 100.0 * S_cps / (nb_ptr.size - 1), flopp.sum() / 1e12, flop.sum() / 1e12, perp.sum() / 1e12, perp.max() / 1e12, perp.max() / perp.mean(),
+             flopp[topp].sum() / 1e12, rows_S / 1e9, k_bytes / 1e9, schurp.sum() / 1e9, memp.max() / 1e9, tilesp[topp].sum() * 32768 / 1e9, schurp.sum() / 1e9,
+             t_kp * 1e3, t_subp * 1e3, t_agp * 1e3, t_topp * 1e3, (t_kp + t_subp + t_agp + t_topp) * 1e3), flush=True)
     owner, roots = _dsolver.split_tree(sym, world)
     top = owner == -1
     per = np.array([flop[owner == r].sum() for r in range(world)])
@@ -37,7 +61,7 @@ for world in ((8, 16) if name == "C5" else (2, 4, 8)):
     fb = np.array([nbd[t] for t in roots]) * 8.0
     t_sub, t_top, t_ag = per.max() / RATE, flop[top].sum() / RATE, schur.sum() * (world - 1) / world / XGMI
     t_k = k_bytes * (world - 1) / world / XGMI + 2.0 * k_bytes / HBM
-    print("%d ranks: %d subtrees below %d top fronts; subtrees %.2f Tflop (largest share %.2f, imbalance %.2f), top %.2f Tflop (replicated); Schur all-gather %.2f GB, boundary "
+    print("%d ranks, round 4's scheme (subtrees of the free dissection dealt by work, K replicated): %d subtrees below %d top fronts; subtrees %.2f Tflop (largest share %.2f, imbalance %.2f), top %.2f Tflop (replicated); Schur all-gather %.2f GB, boundary "
           "contributions %.1f MB per solve; factor memory per rank %.1f GB (own) + %.1f GB (top) + %.1f GB (stubs); modelled factorisation: K value exchange (%.2f GB replicated) %.0f + subtrees %.0f + Schur all-gather %.0f + top %.0f = %.0f ms"
           % (world, len(roots), int(top.sum()), per.sum() / 1e12, per.max() / 1e12, per.max() / per.mean(), flop[top].sum() / 1e12, schur.sum() / 1e9, fb.sum() / 1e6,
              mem.max() / 1e9, tiles[top].sum() * 32768 / 1e9, schur.sum() / 1e9, k_bytes / 1e9, t_k * 1e3, t_sub * 1e3, t_ag * 1e3, t_top * 1e3, (t_k + t_sub + t_ag + t_top) * 1e3), flush=True)
