@@ -11,5 +11,6 @@ for k, c in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0)):
     line = "%-34s launches %6d" % (k[:34], n[k])
     for name in sorted(c): line += "  %s %.3g" % (name.replace("SQ_", ""), c[name])
     if c.get("SQ_WAVE_CYCLES"): line += "  | MFMA busy / (4 x wave cycles) %.3f" % (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4 * c["SQ_WAVE_CYCLES"]))
-    if c.get("SQ_BUSY_CYCLES"): line += "  MFMA busy / busy cycles %.3f" % (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / c["SQ_BUSY_CYCLES"])
+    # (no "MFMA busy / busy cycles": SQ_VALU_MFMA_BUSY_CYCLES is summed per SIMD, SQ_BUSY_CYCLES per shader engine -- their quotient (~20 in profiles/r04_solver_pmc_c4.txt)
+    #  is not a utilisation)
     print(line)
