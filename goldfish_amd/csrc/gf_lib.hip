@@ -153,8 +153,8 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             Q.pt_iface = h->upload(H.pt_iface); Q.pt_base = h->upload(H.pt_base); Q.pt_nu = h->upload(H.pt_nu);
             Q.pt_tau = h->upload(H.pt_tau); Q.pt_wt = h->upload(H.pt_wt); Q.if_patch = h->upload(H.if_patch); Q.if_alpha = h->upload(H.if_alpha);
             Q.entries = h->upload(H.pen_entries); Q.ent_ptr = h->upload(ep); Q.row_cp = h->upload(H.row_cp);
-            Q.slots = H.degree <= 3 ? h->upload(H.pen_slots) : nullptr;
-            h->pen16 = H.degree <= 3;
+            Q.slots = H.degree <= 4 ? h->upload(H.pen_slots) : nullptr;
+            h->pen16 = H.degree <= 4;                      // p = 4: the vertex records by pen_point_kernel, the rows by the 32-lane form of pen_row16_kernel (round 5)
             if (const char* s = getenv("GF_PENALTY")) h->pen16 = h->pen16 && std::string(s) != "owner";
             Q.nrow_groups = (long long)rp.size() - 1;
             for (long long g = 0; g + 1 < (long long)rp.size(); ++g) if (rp[g + 1] > rp[g]) pen_row[H.row_items[rp[g]].a] = 1;
@@ -332,7 +332,7 @@ template <int P> static int run_penalty(gf_handle* h, int flags) {
     }
     if (pen) {
         const dim3 grid((unsigned)(((h->Q.nrow_groups + 7) / 8) * 8)), blk64(64);       // multiple of 8: XCD-contiguous group ranges
-        if constexpr (P <= 3) {
+        if constexpr (P <= 4) {
             if (h->pen16 && h->Q.slots) {
                 const size_t lds1 = (size_t)h->pen_maxdeg * 9 * sizeof(double);          // accumulators of one matrix per row
 #define GF_PEN16(WC, WK) hipLaunchKernelGGL((pen_row16_kernel<P, WC, WK>), grid, blk64, ((WC) && (WK)) ? 2 * lds1 : lds1, st, h->M, h->Q, flags, h->d_pbuf, h->d_R, h->d_val[0], h->d_val[1], h->d_val[2], h->d_val[3])

@@ -31,19 +31,22 @@
 
 namespace gf {
 
+// p = 4 (round 5): the 5 x 5 window takes a 32-lane row = two DPP rows of 16; both halves compute the visit's 90 w values (six per lane position c % 16), so that
+// every broadcast stays inside its DPP row; two visits in flight per wave instead of four.  (pen_owner_kernel was the p = 4 path until round 5: 3.4 ms on one
+// GPU's share of C5 for < 1 % of the quadrature points.)
 template <int P, bool WITHC, bool WITHK>
 __global__ __launch_bounds__(64) void pen_row16_kernel(DevModel M, DevPenalty Q, int flags, const double* __restrict__ pbuf, double* __restrict__ R,
                                                         double* __restrict__ valK, double* __restrict__ valC0, double* __restrict__ valC1, double* __restrict__ valC2) {
-    static_assert(P == 2 || P == 3, "the support window must fit a 16-lane row");
-    constexpr int P1 = P + 1, NB = P1 * P1;
+    static_assert(P >= 2 && P <= 4, "the support window must fit a 32-lane row");
+    constexpr int P1 = P + 1, NB = P1 * P1, LW = NB <= 16 ? 16 : 32, NV = 64 / LW;      // lanes per visit, visits in flight per wave
     const long long chunk = (Q.nrow_groups + 7) / 8;                           // XCD-contiguous ranges of row groups (see pen_owner_kernel)
     const long long gidx = (long long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if ((long long)(blockIdx.x >> 3) >= chunk || gidx >= Q.nrow_groups) return;
-    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int lane = threadIdx.x, g = lane / LW, c = lane % LW, c16 = lane & 15;      // c16: position in the DPP row (which of the 90 w values this lane computes)
     const long long e0 = Q.ent_ptr[gidx], e1 = Q.ent_ptr[gidx + 1];
     // row g takes the g-th quarter of the visit list: the four visits of a batch then lie ~n / 4 vertices apart and mostly hit
     // different slots (neighbouring vertices share their windows: the same addresses in one ds_add_f64)
-    const long long nq = (e1 - e0 + 3) / 4, eq0 = e0 + g * nq, eq1 = eq0 + nq < e1 ? eq0 + nq : e1;
+    const long long nq = (e1 - e0 + NV - 1) / NV, eq0 = e0 + g * nq, eq1 = eq0 + nq < e1 ? eq0 + nq : e1;
     const int a = Q.row_cp[gidx];
     const long long ptr_c = M.nb_ptr_c[a], deg_c = M.nb_ptr_c[a + 1] - ptr_c;
     const bool mats = (flags & (GF_ASM_K_BIT | GF_ASM_C_BIT)) != 0;
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(64) void pen_row16_kernel(DevModel M, DevPenalty Q,
     // at most (with 18 doubles per slot, 36 banks, every eighth slot collided: five-way; the kernel is LDS bound)
     extern __shared__ double s_acc[];
     double* const s_accK = s_acc; double* const s_accC = (WITHK && WITHC) ? s_acc + 9 * (size_t)deg_c : s_acc;      // a one-matrix instance has only its own accumulators (half the LDS: twice the waves per CU)
-    __shared__ double s_r[4][4];
+    __shared__ double s_r[NV][4];
     if (mats) for (int k = lane; k < (int)deg_c * ((WITHK && WITHC) ? 18 : 9); k += 64) s_acc[k] = 0.0;
 
     // the six w values of lane c: index c + 16 q of [wK (i, col) 54 | wC (i, col) 36]; offset of their Hessian row 0 in the vertex record
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(64) void pen_row16_kernel(DevModel M, DevPenalty Q,
     int woff[6], wstr[6]; bool wok[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-        const int idx = c + 16 * q;
+        const int idx = c16 + 16 * q;
         if (idx < 54) { woff[q] = PB_HYY + (idx / 18) * 18 + idx % 18; wstr[q] = 18; wok[q] = WITHK && mats; }
         else if (idx < 90) { const int j = idx - 54; woff[q] = PB_HYC + (j / 12) * 12 + j % 12; wstr[q] = 12; wok[q] = WITHC && mats; }
         else { woff[q] = 0; wstr[q] = 0; wok[q] = false; }
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(64) void pen_row16_kernel(DevModel M, DevPenalty Q,
             const double* nb = Q.pt_nu + ((size_t)v * 2 + t) * 3 * NB + (c < NB ? c : 0);
 #pragma unroll
             for (int m = 0; m < 3; ++m) B.bv[t][m] = (c < NB && B.ok && mats) ? nb[m * NB] : 0.0;
-            B.slot[t] = (c < NB && B.ok && mats) ? (int)Q.slots[((size_t)H.ee * 2 + t) * 16 + c] : 0xFFFF;
+            B.slot[t] = (c < NB && B.ok && mats) ? (int)Q.slots[((size_t)H.ee * 2 + t) * LW + c] : 0xFFFF;
         }
         return B;
     };
@@ -169,7 +172,10 @@ __global__ __launch_bounds__(64) void pen_row16_kernel(DevModel M, DevPenalty Q,
     // ---- residual: the four rows' sums in fixed order; blocks: every entry of the rows is written (the gather adds the shell part)
     if (c < 3) s_r[g][c] = racc;
     wave_lds_sync();
-    if ((flags & GF_ASM_R_BIT) && lane < 3) R[3 * (long long)a + lane] = ((s_r[0][lane] + s_r[1][lane]) + s_r[2][lane]) + s_r[3][lane];
+    if ((flags & GF_ASM_R_BIT) && lane < 3) {
+        if constexpr (NV == 4) R[3 * (long long)a + lane] = ((s_r[0][lane] + s_r[1][lane]) + s_r[2][lane]) + s_r[3][lane];
+        else R[3 * (long long)a + lane] = s_r[0][lane] + s_r[1][lane];
+    }
     if (!mats) return;
     for (int k = lane; k < (int)deg_c; k += 64) {
         const double* srcK = s_accK + k * 9; const double* srcC = s_accC + k * 9;

@@ -179,7 +179,7 @@ struct HostModel {
     // deterministic owner lists
     std::vector<PenRowItem> row_items; std::vector<int64_t> row_ptr;      // groups by CP a
     std::vector<PenEntry> pen_entries; std::vector<int64_t> ent_ptr; std::vector<int> row_cp;   // per group: its visits in fixed order
-    std::vector<unsigned short> pen_slots;   // p <= 3: [visit][side][16] index of the window's control points in the row's coupled neighbour list
+    std::vector<unsigned short> pen_slots;   // [visit][side][LW] (LW = 16 for p <= 3, 32 for p = 4) index of the window's control points in the row's coupled neighbour list
 
     void build(const gf_model_desc* D);
 };
@@ -456,7 +456,8 @@ inline void HostModel::build(const gf_model_desc* D) {
         // the visits of a row group (an owned control point a): every mortar vertex of its ranges whose window holds a.  Two passes over the groups, both in
         // parallel: count, prefix sums, fill (a visit costs 32 binary searches in a's neighbour list: 1.4 of the 2.7 s of gf_create at C4 when done serially)
         const int64_t ngroups = (int64_t)row_ptr.size() - 1;
-        const bool slots = degree <= 3;
+        const bool slots = degree <= 4;
+        const int slot_w = degree <= 3 ? 16 : 32;               // lanes of a visit's row in pen_row16_kernel
         auto visits = [&](int64_t g, auto&& emit) {
             const int a = rows[row_ptr[g]].a;
             for (int64_t it = row_ptr[g]; it < row_ptr[g + 1]; ++it) {
@@ -481,7 +482,7 @@ inline void HostModel::build(const gf_model_desc* D) {
         });
         for (int64_t g = 0; g < ngroups; ++g) ent_ptr[(size_t)g + 1] += ent_ptr[(size_t)g];
         pen_entries.assign((size_t)ent_ptr[(size_t)ngroups], PenEntry{});
-        pen_slots.assign(slots ? (size_t)ent_ptr[(size_t)ngroups] * 32 : 0, (unsigned short)0xFFFF);
+        pen_slots.assign(slots ? (size_t)ent_ptr[(size_t)ngroups] * 2 * slot_w : 0, (unsigned short)0xFFFF);
         parallel_chunks(ngroups, [&](int64_t g0, int64_t g1) {
             for (int64_t g = g0; g < g1; ++g) {
                 int64_t e = ent_ptr[(size_t)g];
@@ -498,7 +499,7 @@ inline void HostModel::build(const gf_model_desc* D) {
                                 const int64_t b = Pt.cp_off + (pt_base[4 * v + 2 * t] + c % p1) + int64_t(pt_base[4 * v + 2 * t + 1] + c / p1) * Pt.nu;
                                 const int* it2 = std::lower_bound(nb0, nb1, (int)b);
                                 if (it2 == nb1 || *it2 != (int)b) throw std::runtime_error("gf_create: a mortar vertex couples control points that are not neighbours");
-                                pen_slots[((size_t)e * 2 + t) * 16 + c] = (unsigned short)(it2 - nb0);
+                                pen_slots[((size_t)e * 2 + t) * slot_w + c] = (unsigned short)(it2 - nb0);
                             }
                         }
                     }
