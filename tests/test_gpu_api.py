@@ -1534,6 +1534,60 @@ def _dist_solver_worker(rank, world, port, q, backend):
     dist.destroy_process_group()
 
 
+def _dist_failure_worker(rank, world, port, q):
+    import warnings
+    import torch.distributed as dist
+    from goldfish_amd import _dsolver
+    from goldfish_amd.nonmatching_opt import NonMatchingOpt
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank == 1:                                     # this rank's subtree handle "does not fit": the others' do
+        orig = _dsolver._Part.__init__
+
+        def failing(self, *a, **k):
+            if k.get("row_ok") is not None:
+                raise RuntimeError("gfs_create_nd_partial: hipMalloc failed: out of memory (forced by the test)")
+            return orig(self, *a, **k)
+        _dsolver._Part.__init__ = failing
+    spec = G.synthetic_shell(4, 4, nel=10, p=3, jitter=2)
+    nm = NonMatchingOpt.from_spec(spec, comm=dist, device=0)
+    nm.sharded_solver = "distributed"
+    nm.update_uIGA(G.smooth_displacement(spec, 0.5 * spec.h_th))
+    nm._assemble(3)
+    b = np.random.default_rng(4).standard_normal(nm.vec_iga_dof)
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        x = nm.solve_K(b)                              # both ranks must come back: the failing one and the one whose own handle was fine
+    out = (rank, [str(w.message)[:120] for w in wl], nm._dsolver is None, getattr(nm, "_dsolver_permanent_failure", None), float(np.abs(nm.dRIGAduIGA() @ x - b).max() / np.abs(b).max()))
+    res = [None] * world
+    dist.all_gather_object(res, out)
+    if rank == 0:
+        q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failure_of_the_distributed_solver_on_one_rank_is_every_ranks_failure():
+    """a rank whose partial handle cannot be created (its GPU is out of memory) used to fall back to the host solve ALONE and met the other ranks
+    inside their all-gather.  Two ranks on the one GPU, rank 1's handle creation forced to fail: the outcome is agreed on before the first collective
+    (DistributedSolver._raise_together), both ranks latch the permanent failure and solve through the (collective) host path, with the right answer."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_failure_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for rank, msgs, dropped, latched, err in res:
+        assert dropped and latched is not None and "out of memory" in latched, (rank, latched)
+        assert any("cannot be used for this model" in m for m in msgs), (rank, msgs)
+        assert err < 1e-7
+
+
 def test_distributed_factorisation_over_rccl():
     """The same on one GPU per rank over RCCL (Schur complements and boundary contributions by all_gather_into_tensor, x by all_reduce on device tensors): runs as
     soon as two GPUs are visible."""
