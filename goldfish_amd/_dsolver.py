@@ -197,9 +197,16 @@ class DistributedSolver:
         self.device = int(dev_model.device)
         self.cuda = dist.get_backend(group) == "nccl"
         L = self.L = _bind()
-        rowptr, col = dev_model.pattern(0)
-        self.nb_ptr, self.nb = control_point_graph(rowptr, col)
-        del rowptr, col
+        import os, time
+        _t = [time.perf_counter()]
+        _lap = lambda: (_t.append(time.perf_counter()), _t[-1] - _t[-2])[1]
+        if hasattr(dev_model, "cp_graph_global"):              # the control-point-level graph from the ranks' own lists (a ninth of the dof-level pattern)
+            self.nb_ptr, self.nb = dev_model.cp_graph_global()
+        else:
+            rowptr, col = dev_model.pattern(0)
+            self.nb_ptr, self.nb = control_point_graph(rowptr, col)
+            del rowptr, col
+        self.setup_timings = {"global_pattern": _lap()}
         ncp = self.ncp = self.nb_ptr.size - 1
         self.n = 3 * ncp
         if coords is None:
@@ -213,6 +220,7 @@ class DistributedSolver:
         self.owner_cp = owner_cp
         sym, self.owner, self.roots = partition_tree(self.nb_ptr, self.nb, coords, owner_cp, self.world, leaf=leaf)
         self.sym = sym
+        self.setup_timings["partition_tree"] = _lap()
         self.A = self.B = None
         self.rel_residual = self.backward_error = None
         self.rel_residuals = None
@@ -226,7 +234,11 @@ class DistributedSolver:
         except (RuntimeError, MemoryError) as e:
             err = str(e) or type(e).__name__
         self._raise_together(err, "DistributedSolver")
+        self.setup_timings["handles"] = _lap()
         self.refactor()
+        self.setup_timings["first_factorisation"] = _lap()
+        if os.environ.get("GF_DSOLVER_TIMING") == "1" and self.rank == 0:
+            print("DistributedSolver set-up (s): " + ", ".join("%s %.2f" % kv for kv in self.setup_timings.items()), flush=True)
 
     _PERMANENT = ("device memory", "out of memory", "does not fit", "not symmetric", "hipMalloc", "OutOfMemory")
 

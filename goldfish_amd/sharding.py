@@ -344,6 +344,24 @@ class ShardedDeviceModel:
         ip, ix, _, _ = self._global_pattern(which)
         return ip, ix
 
+    def cp_graph_global(self):
+        """(nb_ptr, nb) of the GLOBAL control-point graph of K (lists ascending, the control point itself included) from the ranks' own lists: the owned rows of every
+        rank in global numbers, one all-gather of two index arrays -- a ninth of the dof-level ``pattern(MAT_K)`` (11 s at C4), which the distributed solver's symbolic
+        phase used to be built from.  Collective, built once."""
+        import scipy.sparse as sp
+        if getattr(self, "_cpg", None) is None:
+            lptr, lnb = self.D.cp_graph()
+            n_own = self.n_owned_cp
+            rows_l = np.repeat(np.arange(n_own, dtype=np.int64), np.diff(lptr[:n_own + 1]))
+            grow, gcol = self.cols_g[rows_l], self.cols_g[np.asarray(lnb[:lptr[n_own]], np.int64)]
+            R, Cc = self._allgather_concat(grow.astype(np.int64)), self._allgather_concat(gcol.astype(np.int64))
+            Gm = sp.csr_matrix((np.ones(R.size, np.int8), (R, Cc)), shape=(self.total_cp, self.total_cp))
+            Gm.sort_indices()
+            if Gm.nnz != R.size:
+                raise RuntimeError("sharded control-point graph: a row is owned by two ranks")
+            self._cpg = (Gm.indptr.astype(np.int64), Gm.indices.astype(np.int32))
+        return self._cpg
+
     def values(self, which):
         """Values of the global matrix in the order of ``pattern`` (all ranks' owned rows: one all-gather of the owned values)."""
         _, _, perm, nnz = self._global_pattern(which)
