@@ -270,7 +270,10 @@ class DistributedSolver:
             lptr, lnb = loc.cp_graph()
             row_ok = np.arange(cols_g.size) < int(dev_model.n_owned_cp)
             self.A = _Part(L, sym, mine, (), top_cp, cols_g, lptr, lnb, loc.k_values_ptr(), self.device, row_ok=row_ok)
-        # ---- handle B: the separator fronts in the numbering of S = their control points (ascending global ids), on the gathered rows of S
+        # ---- the separator fronts: ONE RANK EACH (tree-parallel top, round 5).  The fronts of one level of the rank hierarchy are independent, so they are factored side by
+        #      side by different ranks (front t by the lowest rank below it) instead of all of them by every rank: the critical path of the top is one front per level
+        #      (C4, 8 ranks: 1.84 of 4.07 Tflop; tools/dist_solver_model.py).  Every such front is its own partial handle (the front + stubs for its children) in the
+        #      numbering of S = the separators' control points (ascending global ids), on the gathered rows of S (a few per cent of K, replicated).
         S = np.sort(top_cp)
         self.S = S
         s_index = np.full(ncp, -1, np.int64)
@@ -278,23 +281,68 @@ class DistributedSolver:
         sptr, snb = _induced(self.nb_ptr, np.asarray(self.nb, np.int64), S, ncp) if S.size else (np.zeros(1, np.int64), np.zeros(0, np.int32))
         self._valB = torch.zeros(max(1, 9 * int(sptr[-1])), dtype=torch.float64, device=dev)
         self._build_top_value_exchange(dev_model, S, s_index, sptr, snb, cols_g, dev)
-        self.B = _Part(L, sym, top_f, self.roots, None, S, sptr, snb, int(self._valB.data_ptr()), self.device)
-        # exchange buffers: Schur complements (doubles per subtree root, padded to the largest per rank) and boundary contributions
-        self.schur_len = {t: int(L.gfs_schur_doubles(self.B.h, self.B.local[t])) for t in self.roots}
-        self.fb_len = {t: 3 * int(self.B.nbnd[self.B.local[t]]) for t in self.roots}
-        per_rank = [[t for t in self.roots if self.owner[t] == r] for r in range(self.world)]
-        self.per_rank = per_rank
-        self.schur_pad = max(1, max(sum(self.schur_len[t] for t in ts) for ts in per_rank))
-        self.fb_pad = max(1, max(sum(self.fb_len[t] for t in ts) for ts in per_rank))
-        self.schur_all = torch.zeros(self.world * self.schur_pad, dtype=torch.float64, device=dev)      # [rank][its roots one after the other]: B's stubs read from here
-        self.fb_all = torch.zeros(self.world * self.fb_pad, dtype=torch.float64, device=dev)
-        for r, ts in enumerate(per_rank):
-            off = r * self.schur_pad
-            for t in ts:
-                if L.gfs_set_schur_source(self.B.h, self.B.local[t], C.c_void_p(self.schur_all.data_ptr() + 8 * off)):
+        nf = sym.nfronts
+        kids = [[] for _ in range(nf)]
+        for t in range(nf):
+            if sym.parent[t] >= 0:
+                kids[sym.parent[t]].append(t)
+        depth = np.zeros(nf, np.int64)
+        for t in range(nf - 1, -1, -1):
+            if sym.parent[t] >= 0:
+                depth[t] = depth[sym.parent[t]] + 1
+        low = np.full(nf, self.world, np.int64)                     # lowest rank with a subtree below every front
+        for t in range(nf):
+            if self.owner[t] >= 0:
+                low[t] = self.owner[t]
+            for c in kids[t]:
+                low[t] = min(low[t], low[c])
+        maxd = int(depth[top_f].max()) if top_f.size else -1
+        # stages of the exchange: 0 = the ranks' subtree roots, s >= 1 = the separator fronts at depth maxd + 1 - s (deepest first, the root last)
+        self.stage_of = {int(t): 0 for t in self.roots}
+        self.prod_of = {int(t): int(self.owner[t]) for t in self.roots}
+        for t in top_f:
+            self.stage_of[int(t)] = maxd - int(depth[t]) + 1
+            self.prod_of[int(t)] = int(low[t]) if low[t] < self.world else 0
+        self.nstage = maxd + 2 if top_f.size else 1
+        _, _, be_, bb_ = sym.front_dofs()
+        self.schur_len = {t: int(bb_[t] * (bb_[t] + 1) // 2) * 4096 for t in self.stage_of}
+        self.fb_len = {t: 3 * int(sym.bnd_off[t + 1] - sym.bnd_off[t]) for t in self.stage_of}
+        self.stage_fronts = [[[t for t in sorted(self.stage_of) if self.stage_of[t] == st and self.prod_of[t] == r] for r in range(self.world)] for st in range(self.nstage)]
+        self.schur_pad = [max(1, max(sum(self.schur_len[t] for t in ts) for ts in per)) for per in self.stage_fronts]
+        self.fb_pad = [max(1, max(sum(self.fb_len[t] for t in ts) for ts in per)) for per in self.stage_fronts]
+        needs_up = [any(sym.parent[t] >= 0 for per in [self.stage_fronts[st]] for ts in per for t in ts) for st in range(self.nstage)]
+        self.stage_exchanges = needs_up                              # a stage whose fronts have no parents (the root) sends nothing up
+        self.schur_buf = [torch.zeros(self.world * self.schur_pad[st] if needs_up[st] else 1, dtype=torch.float64, device=dev) for st in range(self.nstage)]
+        self.fb_buf = [torch.zeros(self.world * self.fb_pad[st] if needs_up[st] else 1, dtype=torch.float64, device=dev) for st in range(self.nstage)]
+        self.schur_off, self.fb_off = {}, {}                         # front -> offset (doubles) of its slot in its stage's buffer
+        for st in range(self.nstage):
+            for r, ts in enumerate(self.stage_fronts[st]):
+                o1, o2 = r * self.schur_pad[st], r * self.fb_pad[st]
+                for t in ts:
+                    self.schur_off[t], self.fb_off[t] = o1, o2
+                    o1 += self.schur_len[t]; o2 += self.fb_len[t]
+        # this rank's separator fronts: handle = the front + stubs for its children, whose Schur complements it reads from the stage buffers
+        self.T = {}                                                  # front -> _Part
+        self.top_kids = {int(t): list(kids[t]) for t in top_f}
+        self.top_elim_s = {}
+        for t in top_f:
+            t = int(t)
+            if self.prod_of[t] != self.rank:
+                continue
+            anc, q = [], sym.parent[t]
+            while q >= 0:
+                anc.append(q); q = sym.parent[q]
+            later = np.concatenate([sym.elim[sym.elim_off[a]:sym.elim_off[a + 1]] for a in anc]) if anc else None
+            part = _Part(L, sym, [t], kids[t], later, S, sptr, snb, int(self._valB.data_ptr()), self.device)
+            for c in kids[t]:
+                stc = self.stage_of[c]
+                if L.gfs_set_schur_source(part.h, part.local[c], C.c_void_p(self.schur_buf[stc].data_ptr() + 8 * self.schur_off[c])):
                     raise RuntimeError(L.gfs_last_error().decode())
-                off += self.schur_len[t]
-        self._rootsB = [np.ascontiguousarray([self.B.local[t] for t in ts], np.int64) for ts in per_rank]
+            part.x = self._view(L.gfs_x_ptr(part.h), 3 * part.ncp)
+            self.T[t] = part
+            self.top_elim_s[t] = torch.from_numpy((3 * s_index[sym.elim[sym.elim_off[t]:sym.elim_off[t + 1]]][:, None] + np.arange(3)).ravel()).to(dev)
+        self.B = None
+        self.my_top = sorted(self.T, key=lambda t: self.stage_of[t])
         self._rootsA = np.ascontiguousarray([self.A.local[t] for t in self.my_roots], np.int64) if self.A else np.zeros(0, np.int64)
 
         # ---- index sets between the replicated global vectors and the handles' numberings
@@ -310,7 +358,6 @@ class DistributedSolver:
         here = np.flatnonzero(s_index[cols_g] >= 0)              # local control points that lie in S: the top's x at the boundaries of the own subtrees
         self.S_here_l, self.S_here_s = t64(dofs(here)), t64(dofs(s_index[cols_g[here]]))
         self.xA = self._view(L.gfs_x_ptr(self.A.h), 3 * self.A.ncp) if self.A else None
-        self.xB = self._view(L.gfs_x_ptr(self.B.h), 3 * self.B.ncp)
         self.b_dev = torch.zeros(self.n, dtype=torch.float64, device=dev)
         # |K|_F from the owned rows of all ranks (the backward error's norm)
         nnz_owned = 9 * int(loc.cp_graph()[0][int(dev_model.n_owned_cp)])
@@ -415,56 +462,74 @@ class DistributedSolver:
         """Logical OR of ``flag`` over the ranks (collective)."""
         return self._agree(1 if flag else 0) > 0
 
+    def _parts(self):
+        return [p for p in [getattr(self, "A", None)] + list(getattr(self, "T", {}).values()) if p is not None]
+
     def close(self):
-        for part in ("A", "B"):
-            p = getattr(self, part, None)
-            if p is not None and getattr(p, "h", None):
+        for p in self._parts():
+            if getattr(p, "h", None):
                 lib().gfs_destroy(p.h)
                 p.h = None
 
     __del__ = close
 
     # -- numeric phase
+    def _stage_allgather(self, bufs, pads, st):
+        if self.stage_exchanges[st] and self.world > 1:
+            self._allgather(bufs[st], pads[st])
+
     def refactor(self):
-        """Collective: own subtrees, all-gather of their Schur complements, the replicated top.  A failure on any rank is agreed on before the next collective
-        and raised on every rank."""
+        """Collective: own subtrees, then the separator fronts level by level (every front by one rank, the Schur complements of a level all-gathered before the next).
+        A failure on any rank is agreed on before the next collective and raised on every rank."""
         import time
         L, torch = self.L, self.torch
+        st_ = torch.cuda.current_stream(self.b_dev.device)
         self.D.sync()
         t0 = time.perf_counter()
         self._gather_top_values()                              # the rows of the rank separators: the only K values that travel
-        torch.cuda.current_stream(self.b_dev.device).synchronize()
+        st_.synchronize()
         t1 = time.perf_counter()
         err = None
         if self.A is not None:
             try:
                 self._check(L.gfs_refactor(self.A.h))
-                off = self.rank * self.schur_pad
                 for t in self.my_roots:
-                    self._check(L.gfs_export_schur(self.A.h, self.A.local[t], C.c_void_p(self.schur_all.data_ptr() + 8 * off)))
-                    off += self.schur_len[t]
+                    self._check(L.gfs_export_schur(self.A.h, self.A.local[t], C.c_void_p(self.schur_buf[0].data_ptr() + 8 * self.schur_off[t])))
             except RuntimeError as e:                          # e.g. a zero pivot in one rank's subtree: every rank must leave the collective phase the same way
                 err = str(e)
         self._raise_together(err, "DistributedSolver.refactor (subtrees)")
         t2 = time.perf_counter()
-        self._allgather(self.schur_all, self.schur_pad)
-        torch.cuda.current_stream(self.b_dev.device).synchronize()
-        t3 = time.perf_counter()
-        err = None
-        try:                                                   # the same arithmetic on every rank -- but a rank may still run out of memory alone
-            self._check(L.gfs_refactor(self.B.h))
-        except RuntimeError as e:
-            err = str(e)
-        self._raise_together(err, "DistributedSolver.refactor (top)")
-        t4 = time.perf_counter()
-        #: seconds of the last refactor() on this rank: K value gather, own subtrees (+ packing), Schur all-gather, replicated top
-        self.timings = {"k_values": t1 - t0, "own_subtrees": t2 - t1, "schur_allgather": t3 - t2, "top": t4 - t3}
+        t_ag = t_top = 0.0
+        ta = time.perf_counter()
+        self._stage_allgather(self.schur_buf, self.schur_pad, 0)
+        st_.synchronize()
+        t_ag += time.perf_counter() - ta
+        for stg in range(1, self.nstage):
+            ta = time.perf_counter()
+            err = None
+            try:
+                for t in self.my_top:
+                    if self.stage_of[t] != stg:
+                        continue
+                    P = self.T[t]
+                    self._check(L.gfs_refactor(P.h))
+                    if self.sym.parent[t] >= 0:
+                        self._check(L.gfs_export_schur(P.h, P.local[t], C.c_void_p(self.schur_buf[stg].data_ptr() + 8 * self.schur_off[t])))
+            except RuntimeError as e:
+                err = str(e)
+            self._raise_together(err, "DistributedSolver.refactor (separator fronts)")
+            t_top += time.perf_counter() - ta
+            ta = time.perf_counter()
+            self._stage_allgather(self.schur_buf, self.schur_pad, stg)
+            st_.synchronize()
+            t_ag += time.perf_counter() - ta
+        #: seconds of the last refactor() on this rank: separator rows of K, own subtrees (+ packing), Schur all-gathers, separator fronts (incl. waiting for their levels)
+        self.timings = {"k_values": t1 - t0, "own_subtrees": t2 - t1, "schur_allgather": t_ag, "top": t_top}
         v = (C.c_double * 8)()
         small = False
-        for p in (self.A, self.B):
-            if p is not None:
-                L.gfs_info(p.h, v)
-                small = small or bool(v[5])
+        for p in self._parts():
+            L.gfs_info(p.h, v)
+            small = small or bool(v[5])
         self.small_pivot = self._any(small)                    # the same flag on every rank: solve_K's acceptance bar depends on it
         ss = torch.zeros(1, dtype=torch.float64, device=self.b_dev.device)
         if self._k_owned is not None:
@@ -477,10 +542,11 @@ class DistributedSolver:
         self.norm_K = float(ss.sqrt())
 
     def _substitute(self, b_dev):
-        """x = (L D L^T)^-1 b for one right-hand side on the device (torch tensor, replicated); returns a new device tensor (replicated).  The library calls return when
-        the device is done with them; torch's stream is drained only where the library consumes what torch wrote (no device-wide synchronisations).  A library error on
-        one rank does not leave the others waiting in a collective: the rank keeps taking part, the failure rides in an extra entry of the all-reduced x, and every
-        rank raises."""
+        """x = (L D L^T)^-1 b for one right-hand side on the device (torch tensor, replicated); returns a new device tensor (replicated).  Forward: the own subtrees, then
+        the separator fronts level by level upwards (boundary contributions all-gathered per level); backward: the levels downwards (the x of a level summed over the
+        ranks into the replicated x of S), then the own subtrees.  The library calls return when the device is done with them; torch's stream is drained only where the
+        library consumes what torch wrote.  A library error on one rank does not leave the others waiting in a collective: the rank keeps taking part, the failure rides
+        in an extra entry of the all-reduced x, and every rank raises."""
         L, torch = self.L, self.torch
         st = torch.cuda.current_stream(b_dev.device)
         err = None
@@ -490,25 +556,57 @@ class DistributedSolver:
                 bl = b_dev[self.loc_dof_g].contiguous()            # the right-hand side in this rank's local numbering
                 st.synchronize()
                 self._check(L.gfs_forward_dev(self.A.h, C.c_void_p(bl.data_ptr())))
-                self._check(L.gfs_get_fbnd_packed(self.A.h, self._rootsA.size, self._rootsA.ctypes.data_as(_i64p), C.c_void_p(self.fb_all.data_ptr() + 8 * self.rank * self.fb_pad)))
+                if self._rootsA.size:
+                    t0 = self.my_roots[0]
+                    self._check(L.gfs_get_fbnd_packed(self.A.h, self._rootsA.size, self._rootsA.ctypes.data_as(_i64p), C.c_void_p(self.fb_buf[0].data_ptr() + 8 * self.fb_off[t0])))
         except RuntimeError as e:
             err = str(e)
-        self._allgather(self.fb_all, self.fb_pad)
+        self._stage_allgather(self.fb_buf, self.fb_pad, 0)
+        for stg in range(1, self.nstage):
+            try:
+                st.synchronize()
+                for t in self.my_top:
+                    if self.stage_of[t] != stg or err is not None:
+                        continue
+                    P = self.T[t]
+                    for c in self.top_kids[t]:
+                        self._check(L.gfs_set_fbnd(P.h, P.local[c], C.c_void_p(self.fb_buf[self.stage_of[c]].data_ptr() + 8 * self.fb_off[c])))
+                    self._check(L.gfs_forward_dev(P.h, C.c_void_p(bS.data_ptr())))
+                    if self.sym.parent[t] >= 0:
+                        self._check(L.gfs_get_fbnd(P.h, P.local[t], C.c_void_p(self.fb_buf[stg].data_ptr() + 8 * self.fb_off[t])))
+            except RuntimeError as e:
+                err = err or str(e)
+            self._stage_allgather(self.fb_buf, self.fb_pad, stg)
+        # backward: the separator levels from the root down; xS = the replicated x of S
+        xS = torch.zeros(3 * self.S.size, dtype=torch.float64, device=b_dev.device)
+        for stg in range(self.nstage - 1, 0, -1):
+            delta = torch.zeros_like(xS)
+            try:
+                for t in self.my_top:
+                    if self.stage_of[t] != stg or err is not None:
+                        continue
+                    P = self.T[t]
+                    P.x.copy_(xS)                                       # x of the ancestors' control points at this front's boundary
+                    st.synchronize()
+                    self._check(L.gfs_backward_dev(P.h))
+                    delta[self.top_elim_s[t]] = P.x[self.top_elim_s[t]]
+            except RuntimeError as e:
+                err = err or str(e)
+            if self.world > 1:
+                if self.cuda:
+                    self.dist.all_reduce(delta, group=self.group)
+                else:
+                    dc = delta.cpu(); self.dist.all_reduce(dc, group=self.group); delta = dc.to(xS.device)
+            xS += delta
         x = torch.zeros(self.n + 1, dtype=torch.float64, device=b_dev.device)
         try:
-            st.synchronize()
-            for r, rb in enumerate(self._rootsB):
-                if rb.size:
-                    self._check(L.gfs_set_fbnd_packed(self.B.h, rb.size, rb.ctypes.data_as(_i64p), C.c_void_p(self.fb_all.data_ptr() + 8 * r * self.fb_pad)))
-            self._check(L.gfs_forward_dev(self.B.h, C.c_void_p(bS.data_ptr())))
-            self._check(L.gfs_backward_dev(self.B.h))
             if self.A is not None and err is None:
-                self.xA[self.S_here_l] = self.xB[self.S_here_s]          # the top's x at the boundaries of the own subtrees
+                self.xA[self.S_here_l] = xS[self.S_here_s]              # the separators' x at the boundaries of the own subtrees
                 st.synchronize()
                 self._check(L.gfs_backward_dev(self.A.h))
                 x[self.own_dofs_g] = self.xA[self.own_dofs_l]
             if self.rank == 0:
-                x[self.S_dofs_g] = self.xB
+                x[self.S_dofs_g] = xS
         except RuntimeError as e:
             err = err or str(e)
         x[self.n] = 0.0 if err is None else 1.0
@@ -577,11 +675,10 @@ class DistributedSolver:
     def info(self):
         v = (C.c_double * 8)()
         out = {"device_bytes": 0, "factor_flops": 0.0}
-        for p in (self.A, self.B):
-            if p is not None:
-                self.L.gfs_info(p.h, v)
-                out["device_bytes"] += int(v[3])
-                out["factor_flops"] += float(v[4])
+        for p in self._parts():
+            self.L.gfs_info(p.h, v)
+            out["device_bytes"] += int(v[3])
+            out["factor_flops"] += float(v[4])
         out["small_pivot"], out["backward_error"], out["norm_K"] = self.small_pivot, self.backward_error, self.norm_K
         return out
 

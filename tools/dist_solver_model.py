@@ -45,14 +45,22 @@ for world in ((8, 16) if name == "C5" else (2, 4, 8)):
     schurp = np.array([bbp[t] * (bbp[t] + 1) // 2 for t in rootsp]) * 32768.0
     S_cps = int(sum(symp.elim_off[t + 1] - symp.elim_off[t] for t in np.flatnonzero(topp)))
     rows_S = float(sum(nb_ptr[a + 1] - nb_ptr[a] for t in np.flatnonzero(topp) for a in symp.elim[symp.elim_off[t]:symp.elim_off[t + 1]])) * 72.0
+    # if every separator front were factored by ONE rank instead of all of them (tree-parallel top: fronts of one level of the rank hierarchy side by side):
+    # the critical path = the largest front of every level
+    depth = np.zeros(symp.nfronts, np.int64)
+    for t in range(symp.nfronts - 1, -1, -1):
+        if symp.parent[t] >= 0:
+            depth[t] = depth[symp.parent[t]] + 1
+    crit = sum(flopp[(topp) & (depth == d)].max() for d in np.unique(depth[topp])) if topp.any() else 0.0
     t_subp, t_topp, t_agp, t_kp = perp.max() / RATE, flopp[topp].sum() / RATE, schurp.sum() * (world - 1) / world / XGMI, rows_S * (world - 1) / world / XGMI
     print("%d ranks, partition-following tree (what _dsolver.py runs): %d subtree roots below %d separator fronts (%d control points = %.1f %% of the model); %.2f Tflop in all "
           "(free dissection: %.2f); subtrees %.2f Tflop (largest share %.2f, imbalance %.2f), separators %.2f Tflop (replicated); K values that travel: <= %.2f GB (the separators' rows; "
           "replicated K: %.2f GB); Schur all-gather %.2f GB; factor memory per rank %.1f GB (own) + %.1f GB (top) + %.1f GB (stubs); modelled factorisation: K rows %.1f + subtrees %.0f "
-          "+ Schur all-gather %.0f + top %.0f = %.0f ms"
+          "+ Schur all-gather %.0f + top %.0f = %.0f ms (top fronts one rank each, levels side by side: critical path %.2f Tflop = %.0f ms -> %.0f ms in all)"
           % (world, len(rootsp), int(topp.sum()), S_cps, 100.0 * S_cps / (nb_ptr.size - 1), flopp.sum() / 1e12, flop.sum() / 1e12, perp.sum() / 1e12, perp.max() / 1e12, perp.max() / perp.mean(),
              flopp[topp].sum() / 1e12, rows_S / 1e9, k_bytes / 1e9, schurp.sum() / 1e9, memp.max() / 1e9, tilesp[topp].sum() * 32768 / 1e9, schurp.sum() / 1e9,
-             t_kp * 1e3, t_subp * 1e3, t_agp * 1e3, t_topp * 1e3, (t_kp + t_subp + t_agp + t_topp) * 1e3), flush=True)
+             t_kp * 1e3, t_subp * 1e3, t_agp * 1e3, t_topp * 1e3, (t_kp + t_subp + t_agp + t_topp) * 1e3, crit / 1e12, crit / RATE * 1e3,
+             (t_kp + t_subp + t_agp + crit / RATE) * 1e3), flush=True)
     owner, roots = _dsolver.split_tree(sym, world)
     top = owner == -1
     per = np.array([flop[owner == r].sum() for r in range(world)])
