@@ -55,8 +55,9 @@ for world in ((8, 16) if name == "C5" else (2, 4, 8)):
     t_subp, t_topp, t_agp, t_kp = perp.max() / RATE, flopp[topp].sum() / RATE, schurp.sum() * (world - 1) / world / XGMI, rows_S * (world - 1) / world / XGMI
     print("%d ranks, partition-following tree (what _dsolver.py runs): %d subtree roots below %d separator fronts (%d control points = %.1f %% of the model); %.2f Tflop in all "
           "(free dissection: %.2f); subtrees %.2f Tflop (largest share %.2f, imbalance %.2f), separators %.2f Tflop (replicated); K values that travel: <= %.2f GB (the separators' rows; "
-          "replicated K: %.2f GB); Schur all-gather %.2f GB; factor memory per rank %.1f GB (own) + %.1f GB (top) + %.1f GB (stubs); modelled factorisation: K rows %.1f + subtrees %.0f "
-          "+ Schur all-gather %.0f + top %.0f = %.0f ms (top fronts one rank each, levels side by side: critical path %.2f Tflop = %.0f ms -> %.0f ms in all)"
+          "replicated K: %.2f GB); Schur all-gather %.2f GB; factor memory per rank %.1f GB (own) + %.1f GB (top) + %.1f GB (stubs); if every rank repeated the separator fronts: K rows %.1f + subtrees %.0f "
+          "+ Schur all-gather %.0f + top %.0f = %.0f ms; AS BUILT (every separator front by one rank, the fronts of a level side by side): critical path of the top %.2f Tflop = %.0f ms -> "
+          "modelled factorisation %.0f ms"
           % (world, len(rootsp), int(topp.sum()), S_cps, 100.0 * S_cps / (nb_ptr.size - 1), flopp.sum() / 1e12, flop.sum() / 1e12, perp.sum() / 1e12, perp.max() / 1e12, perp.max() / perp.mean(),
              flopp[topp].sum() / 1e12, rows_S / 1e9, k_bytes / 1e9, schurp.sum() / 1e9, memp.max() / 1e9, tilesp[topp].sum() * 32768 / 1e9, schurp.sum() / 1e9,
              t_kp * 1e3, t_subp * 1e3, t_agp * 1e3, t_topp * 1e3, (t_kp + t_subp + t_agp + t_topp) * 1e3, crit / 1e12, crit / RATE * 1e3,
