@@ -1,22 +1,24 @@
-"""Direct solves with K over several GPUs (SURVEY.md 8(e) + 8(f) N1, stage 2): one process per GPU, the nested-dissection elimination tree cut below its top.
+"""Direct solves with K over several GPUs (SURVEY.md 8(e) + 8(f) N1, stage 2): one process per GPU, an elimination tree that follows the patch partition.
 
 Replaces, on a sharded problem, the replicated factorisation of stage 1 (every rank factors all of K: goldfish_amd/_solver.py with the gathered values) -- the
-reference's counterpart is MUMPS on ``comm`` (GOLDFISH/utils/opt_utils.py:156-209).  The symbolic phase (goldfish_amd/_nd.py) is deterministic, so every rank
-computes the same tree.  The subtrees hanging below the top ``depth`` levels are dealt to the ranks (largest first, by factorisation work); every rank
+reference's counterpart is MUMPS on ``comm`` (GOLDFISH/utils/opt_utils.py:156-209), which replicates neither the matrix nor the root fronts.  The symbolic phase
+(partition_tree below; deterministic, the same on every rank): the control points on rank boundaries S (the lower-rank end of every edge between two ranks' control
+points) are eliminated along the hierarchy of the rank bisection -- one SEPARATOR front per node --, everything else by its owner's own nested dissection.  Then
 
-  1. factors its own subtrees (handle A: gfs_create_nd_partial over the sub-forest; the root fronts keep their Schur complements),
-  2. packs the Schur complements of its subtree roots (gfs_export_schur) -- one all-gather of padded buffers,
-  3. factors the top of the tree (handle B: the top fronts above STUB fronts that stand for the subtrees and carry the gathered Schur complements) -- the same
-     arithmetic on every rank: the top factors are replicated, nothing else is exchanged,
+  1. every rank factors ITS subtrees (handle A: gfs_create_nd_partial in the rank's LOCAL numbering, on the K that rank assembled; a block whose later control point is
+     a ghost row is read transposed from the owned row: gfs_set_row_mask; the subtree roots keep their Schur complements),
+  2. the rows of S (a few per cent of K) are gathered once per factorisation -- the only K values that travel --,
+  3. the separator fronts are factored level by level from the deepest, every front by ONE rank (the lowest rank below it; its own partial handle: the front above STUB
+     fronts that carry its children's Schur complements), the fronts of a level side by side; after every level one all-gather of the new Schur complements,
 
-and a solve is: forward sweep of the own subtrees (A), all-gather of the root fronts' boundary contributions (3 doubles per boundary control point), forward and
-backward sweep of the top (B, replicated), backward sweep of the own subtrees with the top's x at their boundaries, all-reduce of the pieces of x.  Iterative
-refinement runs against K itself (the replicated values: the same ``residual`` on every rank), like gfs_solve.
+and a solve is: forward sweep of the own subtrees, then of the separator fronts level by level upwards (the boundary contributions, 3 doubles per boundary control
+point, all-gathered per level); backward sweep down the levels (the x of a level summed over the ranks into the replicated x of S), then of the own subtrees; one
+all-reduce of the pieces of x.  Iterative refinement runs against K itself with the sharded product (device-resident).  Every outcome -- handle creation, every
+level of the factorisation, every substitution -- is agreed on by all ranks before the next collective (_raise_together).
 
-What is distributed: the subtree factorisations and sweeps (C4 on 8 ranks: 7.2 of the 9.3 Tflop, 1/8 each) AND K itself (round 5): the elimination tree follows
-the patch partition (partition_tree below), a rank's handle lives in that rank's LOCAL numbering on the K it assembled (owned rows + ghost columns; blocks whose later
-control point is a ghost are read transposed from the owned row: gfs_set_row_mask), and only the rows of the rank separators (a few per cent of K) are gathered
-for the replicated top.  What is replicated: the top fronts, the refinement residuals.  Factor memory per rank: own subtrees + top + the stubs' Schur complements.
+Distributed: the subtree factorisations and sweeps, the separator fronts (one rank each: the critical path of the top is one front per level), K.  Replicated: the
+rows of S, the x of S, the refinement residuals.  split_tree (round 4's scheme: subtrees of the free dissection dealt by work, K and the top replicated) is kept for
+tools/dist_solver_model.py, which prices both.
 
 K must be symmetric (the general mode of the single-GPU solver is not distributed).  ``dist`` is torch.distributed ('nccl' == RCCL on a multi-GPU node; 'gloo' in
 the tests, where the buffers travel through the host)."""
