@@ -461,9 +461,8 @@ class ShardedDeviceModel:
         F = self.D.compliance(f, apply_bcs=apply_bcs)
         n = self.n_owned_cp
         du, dcp = np.array(F["dCdu"], float), np.array(F["dCdcp"], float)
-        du[3 * n:] = 0.0
-        dcp[:, n:] = 0.0
-        return dict(C=float(self._allreduce(np.array([F["C"]]))[0]), dCdu=self._rows_to_global(du, 3), dCdcp=np.stack([self._rows_to_global(dcp[k], 1) for k in range(3)]))
+        res = self._allreduce_packed([np.array([F["C"]]), self._own_rows_global(du, 3)] + [self._own_rows_global(dcp[k], 1) for k in range(3)])      # one all-reduce
+        return dict(C=float(res[0][0]), dCdu=res[1], dCdcp=np.stack(res[2:5]))
 
     def update_interface(self, g, itf):
         """DeviceModel.update_interface for GLOBAL interface g: patched on the ranks that hold it; the model is re-created everywhere when ANY rank reports a vertex
@@ -666,30 +665,18 @@ class ShardedDeviceModel:
         no, npg = self.shard.n_owned, ml.size
         I, vmax = np.zeros(npg), np.zeros(npg)
         I[order[:no]], vmax[order[:no]] = F["I"][:no], F["vmax"][:no]
-        sc = self._allreduce(np.concatenate([I, vmax]))
-        out = dict(I=sc[:npg], vmax=sc[npg:])
+        parts = [np.concatenate([I, vmax])]
         if gradients:
-            n = self.n_owned_cp
-
-            def own(v, width=1):
-                w = np.array(v, float)
-                w[width * n:] = 0.0
-                return w
-            out["dIdu"] = self._rows_to_global(own(F["dIdu"], 3), 3)
-            out["dIdh"] = self._rows_to_global(own(F["dIdh"]), 1)
-            out["dIdcp"] = np.stack([self._rows_to_global(own(F["dIdcp"][f]), 1) for f in range(3)])
+            parts += [self._own_rows_global(F["dIdu"], 3), self._own_rows_global(F["dIdh"], 1)] + [self._own_rows_global(F["dIdcp"][f], 1) for f in range(3)]
+        res = self._allreduce_packed(parts)                                  # one all-reduce for the per-patch values and the owned gradient rows
+        out = dict(I=res[0][:npg], vmax=res[0][npg:])
+        if gradients:
+            out["dIdu"], out["dIdh"], out["dIdcp"] = res[1], res[2], np.stack(res[3:6])
         return out
 
     def shape_regu(self, field, cp0_global, coef_global):
         """Global shape regularisation term (gf_shape_regu): owned elements per rank, value and owned gradient rows summed."""
         order = np.asarray(self.shard.order)
         F = self.D.shape_regu(field, self.shard.to_local(np.asarray(cp0_global, float)), np.asarray(coef_global, float)[order])
-        n = self.n_owned_cp
-        out = dict(value=float(self._allreduce(np.array([F["value"]]))[0]))
-        dcp = []
-        for f in range(3):
-            w = np.array(F["dcp"][f], float)
-            w[n:] = 0.0
-            dcp.append(self._rows_to_global(w, 1))
-        out["dcp"] = np.stack(dcp)
-        return out
+        res = self._allreduce_packed([np.array([F["value"]])] + [self._own_rows_global(F["dcp"][f], 1) for f in range(3)])
+        return dict(value=float(res[0][0]), dcp=np.stack(res[1:4]))
