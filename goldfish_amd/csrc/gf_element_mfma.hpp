@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64) void kl_element_mfma_kernel(DevModel M, int e_f
         const int gp = 4 * grp + kk, gpc = gp < NG ? gp : NG - 1, gu = gpc % P1, gv = gpc / P1;   // Gauss point of this lane's group
         const double* im = s_im[gpc];
         const double wq = gp < NG ? im[IM_WQ] : 0.0;        // padded Gauss-point slots contribute nothing
-        gauss_group<P, WITHC>(L, im, wq, s_tu, s_tv, gu, gv, ju, jv, bval, doK, doC, doH, has_bf, pf, ppd, accK, accC, accH, accB, accR GF_GROUP_STAMP_ARGS);
+        gauss_group<P, WITHC>(L, im, wq, s_tu, s_tv, gu, gv, ju, jv, bval, doK, doC, doH, has_bf, pf, ppd, accK, accC, accH, accB, accR, SfLane{} GF_GROUP_STAMP_ARGS);
     }
     GF_STAMP(4, tstamp);
     if (has_bf && doC) {

@@ -26,8 +26,24 @@ template <bool WITHC> struct RecCfg { static constexpr int NT = WITHC ? 18 : 9, 
 
 struct RecOut { double* rec; double* rblk; int rec_rows; };
 
-template <int P, bool WITHC = true, bool ALLF = false>      // ALLF: flags = R + K + dR/dCP + dR/dh known at compile time (gauss_group)
-__global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const WalkItem* __restrict__ items, int flags, RecOut O) {
+#ifndef GF_SUMFACT_BUILD
+#define GF_SUMFACT_BUILD 1                    // p = 3: row-side sum factorisation of the contraction (gf_gauss_loop.hpp: SfLane); 0: the 16 x 16 x 4 products of rounds 2 - 4
+#endif
+// LDS of one walking wave (one struct, so that the two instances of the walk below -- polynomial / rational patch -- share it)
+template <int P> struct RecShared {
+    static constexpr int P1 = P + 1, NB = P1 * P1, TS = P1 * 3 * P1;
+    int iv[REC_MAX_NEL + 1];                            // first control-point row of every element of the item (+ one behind)
+    double pc[8];                                       // patch constants E, nu, f[3], pd[3]
+    double tu[TS], tv[2][TS], wgu[P1], wgv[2][P1];      // v tables double buffered (the next element's are parked while this one's are in use)
+    __attribute__((aligned(16))) double g[4 * 3 * 16];  // control-point staging (phases 0-1), residual reduction at the end
+    __attribute__((aligned(16))) double im[NB][IM_SIZE];
+    __attribute__((aligned(16))) double raw[8][4][8];   // control points of the windows, ring over the row index: c_x, c_y, c_z, w, u_x, u_y, u_z, h
+};
+
+// SF: 0 the accumulator register is the u index of the row function (lane / 16 = slot of its row), 1 / 2 row-side sum factorisation on a polynomial / rational
+// patch: the register is the SLOT of the row, lane / 16 the u index (gf_gauss_loop.hpp)
+template <int P, bool WITHC, bool ALLF, int SF>
+__device__ __forceinline__ void rec_walk(const DevModel& M, const WalkItem* __restrict__ items, int item, int flags, const RecOut& O, RecShared<P>& S) {
     static_assert(P == 2 || P == 3, "one 16 x 16 tile: p <= 3");
     using RC = RecCfg<WITHC>;
     constexpr int P1 = P + 1, NB = P1 * P1, NG = NB, ND = 3 * NB, NGRP = (NG + 3) / 4, TS = P1 * 3 * P1;
@@ -37,27 +53,27 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
     // stores of the previous element.  They are read ONCE here into scalar registers, the items' span indices go to LDS.
     auto uni = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
     auto uni64 = [&](long long x) { return (long long)(((unsigned long long)(unsigned)uni((int)((unsigned long long)x >> 32)) << 32) | (unsigned)uni((int)(unsigned long long)x)); };
-    WalkItem it = items[blockIdx.x];
+    WalkItem it = items[item];
     it.patch = uni(it.patch); it.eu = uni(it.eu); it.ev0 = uni(it.ev0); it.nel = uni(it.nel); it.iu0 = uni(it.iu0);
     const PatchDev& Pt = M.patches[it.patch];
     const int p_nu = uni(Pt.nu), p_nelu = uni(Pt.nelu), p_tabu = uni(Pt.tabu), p_tabv = uni(Pt.tabv), p_wu = uni(Pt.wu), p_wv = uni(Pt.wv), p_spv = uni(Pt.spv);
     const long long p_cp_off = uni64(Pt.cp_off), p_elem_off = uni64(Pt.elem_off);
-    __shared__ int s_iv[REC_MAX_NEL + 1];               // first control-point row of every element of the item (+ one behind)
+    int* const s_iv = S.iv;
     for (int k = threadIdx.x; k <= it.nel && k <= REC_MAX_NEL; k += 64) s_iv[k] = M.ints[p_spv + it.ev0 + (k < it.nel ? k : it.nel - 1)] - P + (k < it.nel ? 0 : 4);
     // patch constants (E, nu, f[3], pd[3]: contiguous in PatchDev) staged in LDS: read from memory inside the Gauss-point loop they
     // are vector loads behind a vmcnt wait each (the compiler cannot move them across stores), held in registers they cost 16 VGPRs
-    __shared__ double s_pc[8];
+    double* const s_pc = S.pc;
     if (threadIdx.x < 8) s_pc[threadIdx.x] = (&Pt.E)[threadIdx.x];
     const double* const pf = s_pc + 2; const double* const ppd = s_pc + 5;
     wave_lds_sync();
 
-    __shared__ __attribute__((aligned(16))) double s_g[4 * 3 * 16];  // control-point staging (phases 0-1), residual reduction at the end
+    double* const s_g = S.g;
     double (*s_c)[3] = reinterpret_cast<double (*)[3]>(s_g);
     double (*s_d)[3] = reinterpret_cast<double (*)[3]>(s_g + 3 * NB);
     double* s_h = s_g + 6 * NB; double* s_w = s_g + 7 * NB;
-    __shared__ double s_tu[TS], s_tv[2][TS], s_wgu[P1], s_wgv[2][P1];            // v tables double buffered (the next element's are parked while this one's are in use)
-    __shared__ __attribute__((aligned(16))) double s_im[NG][IM_SIZE];
-    __shared__ __attribute__((aligned(16))) double s_raw[8][4][8];               // control points of the windows, ring over the row index: c_x, c_y, c_z, w, u_x, u_y, u_z, h
+    double* const s_tu = S.tu; double (*s_tv)[TS] = S.tv; double* const s_wgu = S.wgu; double (*s_wgv)[P1] = S.wgv;
+    double (*s_im)[IM_SIZE] = S.im;
+    double (*s_raw)[4][8] = S.raw;
 
     const RowLane L(x);                                  // lane constants of the row expansion
 
@@ -66,10 +82,25 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
     const int jub = x >> 2, sb = x & 3;                   // this lane's basis function: u index, v slot
     const int jubc = jub < P1 ? jub : 0;
 
-    gf_d4 accK[6], accC[9], accH[3];
+    gf_d4 accK[6], accC[9], accH[3];                       // SF = 0: the walking accumulators (MFMA destinations)
     for (int q = 0; q < 6; ++q) accK[q] = gf_d4{0, 0, 0, 0};
     for (int q = 0; q < 9; ++q) accC[q] = gf_d4{0, 0, 0, 0};
     for (int q = 0; q < 3; ++q) accH[q] = gf_d4{0, 0, 0, 0};
+    // SF != 0, passes with dR/dCP: the walking accumulators are FMA destinations (arch VGPRs) but 72 doubles of them next to phase 1 and the group step do not fit --
+    // they are parked in AGPRs (AccReg) and every component's update reads, adds and writes back its four values (16 moves per component and group)
+    // (the six K tiles stay in arch VGPRs; GF_SF_PARK_K=1 parks them too: 16 more moves per K component and group, 48 registers more for everything else)
+#ifndef GF_SF_PARK_K
+#define GF_SF_PARK_K 0
+#endif
+    constexpr bool AGP = SF != 0 && WITHC, AGPK = AGP && GF_SF_PARK_K != 0;
+    AccReg aK[6][4], aC[9][4];
+    if constexpr (AGP) {
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            if constexpr (AGPK) for (int q = 0; q < 6; ++q) acc_init(aK[q][sl]);
+            for (int q = 0; q < 9; ++q) acc_init(aC[q][sl]);
+        }
+    }
 
     // ---- input fetch of one element: 16 bytes per lane of the window's control points (lane = 4 * local index + quarter:
     //      c_xy | c_zw | u_xy | u_z, h), the v table and v weights; requested behind phase 1, parked in LDS behind the group loop
@@ -100,11 +131,18 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
         const Fetch F = fetch(it.ev0, iv_first);
         park(F, iv_first, 0);
     }
+    SfLane sfl; sfl.au[0] = sfl.au[1] = sfl.au[2] = 0.0; sfl.rot = 0;
+    if constexpr (SF != 0) {                             // the lane's row-side u index a1 = x & 3 at its Gauss point g1 = kk: constants of the strip
+        wave_lds_sync();
+        for (int k1 = 0; k1 < 3; ++k1) sfl.au[k1] = s_tu[(kk * 3 + k1) * P1 + (x & 3)];
+    }
 
     // ---- flush: the pairs whose lower row leaves the window (first row iv0f, next element's first row iv0nf) are complete for
     //      this item; every lane holds pairs of exactly one lower row rho and stores its registers into that row's record.
-    const __amdgpu_buffer_rsrc_t rR = buf_rsrc(O.rec + (size_t)blockIdx.x * O.rec_rows * RC::SZ, (unsigned)(O.rec_rows * RC::SZ * 8));
-    auto flush = [&](int iv0f, int iv0nf) {
+    const __amdgpu_buffer_rsrc_t rR = buf_rsrc(O.rec + (size_t)item * O.rec_rows * RC::SZ, (unsigned)(O.rec_rows * RC::SZ * 8));
+    // (KCH: which tiles -- the SF instances flush K and dR/dCP with their own addressing and the three dR/dh tiles, which every instance accumulates with the
+    //  16 x 16 x 4 product, with the SF = 0 addressing)
+    auto flush16 = [&](int iv0f, int iv0nf, bool fK, bool fC, bool fH) {
         const int rowa = iv0f + ((kk - iv0f) & 3), rowb = iv0f + ((sb - iv0f) & 3);       // control-point rows of this lane's slots
         const bool live = (rowa - iv0f) < P1 && (rowb - iv0f) < P1 && jub < P1;
         const int rho = rowa < rowb ? rowa : rowb;
@@ -116,23 +154,49 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
             unsigned off = 8u * (unsigned)((rho - iv_first) * RC::SZ + (own ? x : RC::A2 + rk * RC::NT * 4 + jub));
 #pragma unroll
             for (int rr = 0; rr < P1; ++rr, off += sr) {
-                if (doK) {
+                if (fK) {
 #pragma unroll
                     for (int q = 0; q < 6; ++q) buf_st(rR, off + (RC::QK + q) * sq, accK[q][rr]);
                 }
-                if (doH) {
+                if (fH) {
 #pragma unroll
                     for (int q = 0; q < 3; ++q) buf_st(rR, off + (RC::QH + q) * sq, accH[q][rr]);
                 }
-                if constexpr (WITHC) if (doC) {
+                if constexpr (WITHC) if (fC) {
 #pragma unroll
                     for (int q = 0; q < 9; ++q) buf_st(rR, off + (RC::QC + q) * sq, accC[q][rr]);
                 }
             }
-            for (int q = 0; q < 6; ++q) accK[q] = gf_d4{0, 0, 0, 0};
-            for (int q = 0; q < 9; ++q) accC[q] = gf_d4{0, 0, 0, 0};
-            for (int q = 0; q < 3; ++q) accH[q] = gf_d4{0, 0, 0, 0};
+            if (fK) for (int q = 0; q < 6; ++q) accK[q] = gf_d4{0, 0, 0, 0};
+            if (fC) for (int q = 0; q < 9; ++q) accC[q] = gf_d4{0, 0, 0, 0};
+            if (fH) for (int q = 0; q < 3; ++q) accH[q] = gf_d4{0, 0, 0, 0};
         }
+    };
+    auto flush = [&](int iv0f, int iv0nf) {
+        if constexpr (SF != 0) {
+            // register sl holds the pairs whose row function lies in control-point row rowa (the same for every lane), lane / 16 is its u index
+            const int rowb = iv0f + ((sb - iv0f) & 3);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int rowa = iv0f + ((sl - iv0f) & 3);
+                const int rho = rowa < rowb ? rowa : rowb;
+                if (rho < iv0nf) {
+                    const bool own = rowa <= rowb;                        // A's row is the lower one: area 1, else area 2 (A's row = rho + 1 + rk)
+                    const int rk = rowa - rho - 1;
+                    const unsigned sq = 8u * (own ? 16 : 4);
+                    const unsigned off = 8u * (unsigned)((rho - iv_first) * RC::SZ + (own ? x : RC::A2 + rk * RC::NT * 4 + jub) + kk * (own ? RC::NT * 16 : 3 * RC::NT * 4));
+                    if (doK) {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) { if constexpr (AGPK) { buf_st(rR, off + (RC::QK + q) * sq, acc_get(aK[q][sl])); acc_zero(aK[q][sl]); } else { buf_st(rR, off + (RC::QK + q) * sq, accK[q][sl]); accK[q][sl] = 0.0; } }
+                    }
+                    if constexpr (WITHC) if (doC) {
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) { if constexpr (AGP) { buf_st(rR, off + (RC::QC + q) * sq, acc_get(aC[q][sl])); acc_zero(aC[q][sl]); } else { buf_st(rR, off + (RC::QC + q) * sq, accC[q][sl]); accC[q][sl] = 0.0; } }
+                    }
+                }
+            }
+            if (doH) flush16(iv0f, iv0nf, false, false, true);
+        } else flush16(iv0f, iv0nf, doK, doC, doH);
     };
 
 #if defined(GF_STAMPS) && defined(GF_STAMPS_FINE)
@@ -179,16 +243,18 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
         const bool bok = jub < P1 && jvb < P1;
         const int jvc = jvb < P1 ? jvb : 0;
         const double bval = bok ? 1.0 : 0.0;                 // lanes beyond the basis functions contribute zero rows / columns
+        sfl.rot = iv0 & 3;
         double accR[3] = {0.0, 0.0, 0.0};
         gf_d4 accB[3] = {gf_d4{0, 0, 0, 0}, gf_d4{0, 0, 0, 0}, gf_d4{0, 0, 0, 0}};   // body force: sum_gp R_a (dJ/dZ . phi_b)_f, scaled by -f_i behind the loop
-
         for (int grp = 0; grp < NGRP; ++grp) {
             const int gp = 4 * grp + kk, gpc = gp < NG ? gp : NG - 1, gu = gpc % P1, gv = gpc / P1;   // Gauss point of this lane's group
             const double* im = s_im[gpc];
             const double wq = gp < NG ? im[IM_WQ] : 0.0;        // padded Gauss-point slots contribute nothing
-            gauss_group<P, WITHC, ALLF>(L, im, wq, s_tu, tv, gu, gv, jubc, jvc, bval, doK, doC, doH, has_bf, pf, ppd, accK, accC, accH, accB, accR GF_GROUP_STAMP_ARGS);
+            if constexpr (AGPK) gauss_group<P, WITHC, ALLF, SF>(L, im, wq, s_tu, tv, gu, gv, jubc, jvc, bval, doK, doC, doH, has_bf, pf, ppd, aK, aC, accH, accB, accR, sfl GF_GROUP_STAMP_ARGS);
+            else if constexpr (AGP) gauss_group<P, WITHC, ALLF, SF>(L, im, wq, s_tu, tv, gu, gv, jubc, jvc, bval, doK, doC, doH, has_bf, pf, ppd, accK, aC, accH, accB, accR, sfl GF_GROUP_STAMP_ARGS);
+            else gauss_group<P, WITHC, ALLF, SF>(L, im, wq, s_tu, tv, gu, gv, jubc, jvc, bval, doK, doC, doH, has_bf, pf, ppd, accK, accC, accH, accB, accR, sfl GF_GROUP_STAMP_ARGS);
         }
-        if (has_bf && doC) {
+        if (SF == 0 && has_bf && doC) {          // (the SF instances carry the body-force term inside their dR/dCP components)
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -217,6 +283,14 @@ __global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const Wa
 #endif
 }
 
+// SF = 1 / 2: the work items order[0 .. grid) -- the items of the polynomial / of the rational patches (HostModel::rec_order); one kernel per kind, so that each
+// instance has the register file to itself.  order = nullptr: item = workgroup.
+template <int P, bool WITHC = true, bool ALLF = false, int SF = 0>      // ALLF: flags = R + K + dR/dCP + dR/dh known at compile time (gauss_group)
+__global__ __launch_bounds__(64) void kl_element_rec_kernel(DevModel M, const WalkItem* __restrict__ items, const int* __restrict__ order, int flags, RecOut O) {
+    __shared__ RecShared<P> S;
+    const int item = order ? __builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int)blockIdx.x;
+    rec_walk<P, WITHC, ALLF, SF>(M, items, item, flags, O, S);
+}
 
 // Record gather: ONE wave per control point a = (ia, ja) sums, strip by strip and segment by segment (a fixed order), what the row
 // records hold for its three dof rows, then writes the rows (gather_write_rows: Dirichlet entries, coupling-only columns, penalty

@@ -47,6 +47,27 @@ template <int LANE, int J> __device__ __forceinline__ double row_dot2(double t0,
     fmac_bcast<LANE>(t, g[3 + J], p[1]);
     return t;
 }
+// The same dot products with their START tied to four values d (inline assembly that names them as inputs and does not read them): the chain cannot be scheduled
+// in front of whatever produces d.  The SF contraction uses it to put the T formation of component q + 1 between the 4 x 4 x 4 products of component q and the FMAs
+// that read their results -- the products' result latency is then covered by useful work instead of wait states (mfma4_result_gap).
+struct Dep4 { double a, b, c, d; };
+template <int LANE, int J> __device__ __forceinline__ double row_dot_dep(const double (&g)[15], const double (&p)[5], const Dep4& D) {
+    double t;
+    asm("v_mov_b64 %0, 0" : "=v"(t) : "v"(D.a), "v"(D.b), "v"(D.c), "v"(D.d));
+    fmac_bcast<LANE>(t, g[J], p[0]);
+    fmac_bcast<LANE>(t, g[3 + J], p[1]);
+    fmac_bcast<LANE>(t, g[6 + J], p[2]);
+    fmac_bcast<LANE>(t, g[9 + J], p[3]);
+    fmac_bcast<LANE>(t, g[12 + J], p[4]);
+    return t;
+}
+template <int LANE, int J> __device__ __forceinline__ double row_dot2_dep(double a, double b, const double (&g)[15], const double (&p)[5], const Dep4& D) {
+    double t;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(t) : "v"(a), "v"(b), "v"(D.a), "v"(D.b), "v"(D.c), "v"(D.d));
+    fmac_bcast<LANE>(t, g[J], p[0]);
+    fmac_bcast<LANE>(t, g[3 + J], p[1]);
+    return t;
+}
 // The row registers are written by VALU instructions and read through DPP by inline assembly the hazard recogniser cannot
 // see: tying them to a 2-wait-state nop keeps every producer in front of it and every DPP read behind it.
 __device__ __forceinline__ void dpp_source_fence(double (&g)[15]) {
@@ -63,6 +84,9 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 // (the operands are tied to the nop so that it stays between the last FMA and the first MFMA of a batch)
 __device__ __forceinline__ void mfma_hazard_gap(double (&t)[6]) {
     asm volatile("s_nop 1" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]));
+}
+__device__ __forceinline__ void mfma_hazard_gap(double (&t)[5]) {
+    asm volatile("s_nop 1" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]));
 }
 __device__ __forceinline__ void mfma_hazard_gap(double (&t)[9]) {
     asm volatile("s_nop 1" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]));
@@ -249,19 +273,104 @@ struct RowLane {
 #if defined(GF_STAMPS) && defined(GF_STAMPS_FINE)
 #define GF_GROUP_STAMP_PARAMS , unsigned long long* stamp_acc, unsigned long long& tstamp
 #define GF_GROUP_STAMP_ARGS , stamp_acc, tstamp
+#ifdef GF_STAMPS_SFDBG       // diagnostic of the SF contraction: slots 2 / 3 / 4 = T formation / products / accumulation of the dR/dCP components, the front part of the group in slot 7
+#define GF_GROUP_STAMP(slot) GF_STAMP(((slot) >= 2 && (slot) <= 4) ? 7 : (slot), tstamp)
+#define GF_SFDBG_STAMP(slot) GF_STAMP(slot, tstamp)
+#else
 #define GF_GROUP_STAMP(slot) GF_STAMP(slot, tstamp)
+#define GF_SFDBG_STAMP(slot) do { } while (0)
+#endif
 #else
 #define GF_GROUP_STAMP_PARAMS
 #define GF_GROUP_STAMP_ARGS
 #define GF_GROUP_STAMP(slot) do { } while (0)
+#define GF_SFDBG_STAMP(slot) do { } while (0)
 #endif
+// ---- row-side sum factorisation (SF; round 5, p = 3 walking kernel).  A group of the bicubic element is the four Gauss points g1 = kk of ONE v index g2 = grp,
+//      and the row-side basis function factorises, phi_a[m](g1, g2) = sum_k2 F_{a1}[m][k2](g1, g2) B^(k2)_{a2}(g2)  (F: the part of rationalize6 that multiplies
+//      the k2-th v derivative; B: the v table).  So the contraction over a group needs the 16 x 16 x 4 product  phi_a[m] x T_b[m]  only for the FOUR u indices a1:
+//          X[k2][a1][b]    = sum_g1 sum_m F_{a1}[m][k2] T_b[m]     v_mfma_f64_4x4x4: A operand F at lane (a1 = lane & 3, g1 = lane >> 4), B operand T_b of the lane
+//                                                                  (b = lane & 15, g1 = lane >> 4), result at lane b + 16 a1 -- 16.5 cycles instead of 64
+//          K[(a1,a2)][b]  += sum_k2 B^(k2)_{a2}(g2) X[k2][a1][b]   12 FMAs with wave-uniform factors (the accumulator register is the SLOT of the row a2, gf_element_rec.hpp)
+//      A polynomial patch (all weights equal, SF = 1) has one k2 per m (5 MFMAs per component), a rational one (SF = 2) nine (m, k2) pairs:
+//      82 / 148 + 48 cycles on the FP64 pipe per component and group instead of 320.  The T formation, the expansions and the residual are unchanged.
+// a value every lane holds, moved to scalar registers (an FMA takes one scalar operand: the twelve factors of a group cost no vector registers)
+__device__ __forceinline__ double uniform_double(double v) {
+    const gf_u2 w = __builtin_bit_cast(gf_u2, v);
+    return __builtin_bit_cast(double, gf_u2{(unsigned)__builtin_amdgcn_readfirstlane((int)w.x), (unsigned)__builtin_amdgcn_readfirstlane((int)w.y)});
+}
+// A double parked in two accumulation registers: the asm statements that define and read it constrain both halves to AGPRs, so the value never occupies
+// arch VGPRs between its uses (the walking accumulators of the SF instances: touched once per element).
+struct AccReg { int lo, hi; };
+__device__ __forceinline__ void acc_init(AccReg& a) { asm("v_accvgpr_write_b32 %0, 0" : "=a"(a.lo)); asm("v_accvgpr_write_b32 %0, 0" : "=a"(a.hi)); }
+__device__ __forceinline__ void acc_zero(AccReg& a) { asm("v_accvgpr_write_b32 %0, 0" : "+a"(a.lo)); asm("v_accvgpr_write_b32 %0, 0" : "+a"(a.hi)); }
+__device__ __forceinline__ double acc_get(const AccReg& a) {
+    int lo, hi;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(a.lo)); asm("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(a.hi));
+    return __builtin_bit_cast(double, gf_u2{(unsigned)lo, (unsigned)hi});
+}
+__device__ __forceinline__ void acc_put(AccReg& a, double v) {
+    const gf_u2 w = __builtin_bit_cast(gf_u2, v);
+    // "+a": the new value takes the register of the old one (a fresh "=a" value is copied back into the loop-carried register: one v_accvgpr_mov each)
+    asm("v_accvgpr_write_b32 %0, %1" : "+a"(a.lo) : "v"((int)w.x)); asm("v_accvgpr_write_b32 %0, %1" : "+a"(a.hi) : "v"((int)w.y));
+}
+struct SfLane { double au[3]; int rot; };            // A^(k1)_{a1 = lane & 3}(g1 = lane >> 4) of the strip's u table; first control-point row of the element mod 4
+template <int SF> __host__ __device__ constexpr bool sf_nz(int m, int k2) {
+    return SF == 1 ? k2 == ((m == 0 || m == 2) ? 0 : (m == 3 ? 2 : 1)) : (k2 == 0 || (k2 == 1 && (m == 1 || m == 3 || m == 4)) || (k2 == 2 && m == 3));
+}
+// v_mfma_f64_4x4x4 with EVERY operand in arch VGPRs.  The builtin lets the compiler choose, and in a function that may use AGPRs it puts the results there: two
+// v_accvgpr_read per product before the FMAs can use them, and the AGPRs are where the walking accumulators of the SF instances live (AccReg).  As inline
+// assembly the instruction is opaque to the hazard recogniser, so the two software interlocks are spelled out: operands written by VALU need two wait states
+// (mfma_hazard_gap, as for the 16 x 16 x 4 form), and a result needs the instruction's four passes + write-back before a VALU reads it (mfma4_result_gap: ten
+// wait states against the six LLVM's table lists for the 4 x 4 x 4 DGEMM form).  Dependent products (the same X) are kept two products apart.
+__device__ __forceinline__ double mfma4_first(double a, double b) { double d; asm("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ void mfma4_acc(double& x, double a, double b) { asm("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(x) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void mfma4_result_gap(double& a, double& b, double& c) { asm volatile("s_nop 7\n\ts_nop 1" : "+v"(a), "+v"(b), "+v"(c)); }
+__device__ __forceinline__ void mfma4_result_gap(double& a, double& b, double& c, double& d) { asm volatile("s_nop 7\n\ts_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void mfma4_result_gap(double& x) { asm volatile("s_nop 7\n\ts_nop 1" : "+v"(x)); }
+__device__ __forceinline__ void mfma_hazard_gap(double& a, double& b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
+// the operand gap of component q + 1 that also holds back the readers of component q's products (Dep4 above): everything that reads X comes behind it
+__device__ __forceinline__ void mfma_pipeline_gap(double (&t)[5], double (&x)[4]) {
+    asm volatile("s_nop 1" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+}
+
 // ALLF: the full pass (R + K + dR/dCP + dR/dh) as a compile-time fact -- the flags then fold away and the whole group step is ONE basic block, which lets the
 // scheduler move the plain FP64 work (residual / dR/dh prefactors, issued behind the first K batch) in between the MFMAs, into the unused part of their issue slots
-template <int P, bool WITHC, bool ALLF = false>
+// SF: acc[sl] += b0[sl] x0 + b1[sl] x1 + b2[sl] x2 for the four row slots -- on accumulators in arch VGPRs (gf_d4) or parked in AGPRs (AccReg[4]: read, FMAs, write back)
+__device__ __forceinline__ void sf_accumulate(gf_d4& acc, const double (&bs)[3][4], double x0, double x1, double x2) {
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_fma(bs[2][sl], x2, __builtin_fma(bs[1][sl], x1, __builtin_fma(bs[0][sl], x0, acc[sl])));
+}
+__device__ __forceinline__ void sf_accumulate(AccReg (&acc)[4], const double (&bs)[3][4], double x0, double x1, double x2) {
+    // the four slots side by side (four independent chains of three FMAs): slot by slot, every instruction would wait for the one in front of it
+    double v[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) v[sl] = acc_get(acc[sl]);
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) v[sl] = __builtin_fma(bs[0][sl], x0, v[sl]);
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) v[sl] = __builtin_fma(bs[1][sl], x1, v[sl]);
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) v[sl] = __builtin_fma(bs[2][sl], x2, v[sl]);
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) acc_put(acc[sl], v[sl]);
+}
+__device__ __forceinline__ void sf_accumulate1(gf_d4& acc, const double (&b)[4], double x) {
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_fma(b[sl], x, acc[sl]);
+}
+__device__ __forceinline__ void sf_accumulate1(AccReg (&acc)[4], const double (&b)[4], double x) {
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) acc_put(acc[sl], __builtin_fma(b[sl], x, acc_get(acc[sl])));
+}
+
+// accumulators: gf_d4 arrays (SF = 0: MFMA destinations, register = u index of the row function; SF != 0: register = row slot), or AccReg[.][4] (SF != 0, parked in AGPRs)
+template <int P, bool WITHC, bool ALLF = false, int SF = 0, class AK, class AC>
 __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, double wq, const double* tu, const double* tv, int gu, int gv,
                                             int ju, int jv, double bval, bool doK_, bool doC_, bool doH_, bool has_bf, const double* pf, const double* ppd,
-                                            gf_d4 (&accK)[6], gf_d4 (&accC)[9], gf_d4 (&accH)[3], gf_d4 (&accB)[3], double (&accR)[3] GF_GROUP_STAMP_PARAMS) {
+                                            AK& accK, AC& accC, gf_d4 (&accH)[3], gf_d4 (&accB)[3], double (&accR)[3], const SfLane& sf GF_GROUP_STAMP_PARAMS) {
     constexpr int P1 = P + 1;
+    static_assert(SF == 0 || P == 3, "row-side sum factorisation: the groups of a bicubic element are its four v indices");
     const bool doK = ALLF || doK_, doC = (ALLF && WITHC) || doC_, doH = ALLF || doH_;
     // -- every load the basis function and the row expansion start from, in one batch (RowLane::load)
     const double u0 = tu[(gu * 3 + 0) * P1 + ju], u1 = tu[(gu * 3 + 1) * P1 + ju], u2 = tu[(gu * 3 + 2) * P1 + ju];
@@ -269,7 +378,30 @@ __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, 
     const double Wl[6] = {im[IM_W], im[IM_W + 1], im[IM_W + 2], im[IM_W + 3], im[IM_W + 4], im[IM_W + 5]};
     RowLane::Pre pre;
     if (doK || doC) pre = L.load(im);
+    double bs[3][4];                                     // SF: B^(k2)_{a2}(g2) of the row slots s (a2 = (s - first row) mod 4): the same for every lane
+    if constexpr (SF != 0) {
+#pragma unroll
+        for (int k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) bs[k2][sl] = uniform_double(tv[(gv * 3 + k2) * P1 + ((sl - sf.rot) & 3)]);
+    }
     __builtin_amdgcn_sched_barrier(0);
+    // SF: the row-side factors F[m][k2] of the lane's (a1, g1) at this group's g2 and the value kind Fv (k2 = 0 only)
+    double F[5][3], Fv = 0.0;
+    if constexpr (SF != 0) {
+        for (int m = 0; m < 5; ++m) for (int k2 = 0; k2 < 3; ++k2) F[m][k2] = 0.0;
+        const double iW = Wl[0];
+        if constexpr (SF == 1) {
+            const double f0 = iW * sf.au[0], f1 = iW * sf.au[1], f2 = iW * sf.au[2];
+            F[0][0] = f1; F[1][1] = f0; F[2][0] = f2; F[3][2] = f0; F[4][1] = f1; Fv = f0;
+        } else {                                         // rationalize6 applied to the products with v0 = 1 / v1 = 1 / v2 = 1 alone
+            const double r0 = sf.au[0] * iW, r1 = (sf.au[1] - r0 * Wl[1]) * iW, r2 = -r0 * Wl[2] * iW;
+            F[0][0] = r1; F[1][0] = r2; F[2][0] = (sf.au[2] - 2 * r1 * Wl[1] - r0 * Wl[3]) * iW;
+            F[3][0] = (-2 * r2 * Wl[2] - r0 * Wl[4]) * iW; F[4][0] = (-r1 * Wl[2] - r2 * Wl[1] - r0 * Wl[5]) * iW; Fv = r0;
+            F[1][1] = r0; F[3][1] = -2 * r0 * Wl[2] * iW; F[4][1] = (sf.au[1] - r0 * Wl[1]) * iW;
+            F[3][2] = r0;
+        }
+    }
     // -- basis function of the lane at this Gauss point (registers)
     double phi[5], R0, n0;
     {
@@ -306,6 +438,9 @@ __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, 
             accR[i] += wq * (rz - ls * pf[i] * R0);
         }
     }
+    // dR/dh: a rank-one tile per component -- ONE 16 x 16 x 4 product in every instance (the SF instances would need three 4 x 4 x 4 products, their operands, two
+    // interlocks and the parked accumulators' moves: measured 2.0 k against 0.85 k cycles per group).  Its accumulators keep the layout of that product
+    // (lane / 16 = slot of the row function's row, register = its u index): the walking kernel flushes the three dR/dh tiles with the SF = 0 addressing.
     if (doH) {
         double nn = 0.0;
         for (int k = 0; k < 3; ++k) nn += phi[2 + k] * im[IM_JCK4 + k] * (k == 2 ? 2.0 : 1.0);
@@ -326,22 +461,117 @@ __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, 
     // chain -> MFMA -> chain sequence serialises on the shared FP64 pipe).
     constexpr int QI[6] = {0, 0, 0, 1, 1, 2}, QJ[6] = {0, 1, 2, 1, 2, 2};
     // curvature rows: psi_k = f_k sum_c f_c (J t^3 C)_kc w phi_b,2+c (f = 1, 1, 2) and the products of the normals, per lane
-    double psi[3], nn[6], nnb[9];
+    double psi[3], nn[6], nnb[9], nv[3] = {0.0, 0.0, 0.0}, dn[3] = {0.0, 0.0, 0.0};
     if (doK || doC) {
         const double ct[6] = {im[IM_CT3], im[IM_CT3 + 1], im[IM_CT3 + 2], im[IM_CT3 + 3], im[IM_CT3 + 4], im[IM_CT3 + 5]};
-        const double nv[3] = {im[IM_N], im[IM_N + 1], im[IM_N + 2]};
+        for (int k = 0; k < 3; ++k) nv[k] = im[IM_N + k];
         const double p4 = 2.0 * pb[4];
 #pragma unroll
         for (int k = 0; k < 3; ++k) psi[k] = (k == 2 ? 2.0 : 1.0) * (ct[sym3(k, 0)] * pb[2] + ct[sym3(k, 1)] * pb[3] + ct[sym3(k, 2)] * p4);
+        if constexpr (WITHC) for (int k = 0; k < 3; ++k) dn[k] = nv[k] - im[IM_NB + k];
+        if constexpr (SF == 0) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) nn[q] = nv[QI[q]] * nv[QJ[q]];
-        if constexpr (WITHC) {
-            const double dn[3] = {nv[0] - im[IM_NB], nv[1] - im[IM_NB + 1], nv[2] - im[IM_NB + 2]};
+            for (int q = 0; q < 6; ++q) nn[q] = nv[QI[q]] * nv[QJ[q]];
+            if constexpr (WITHC) {
 #pragma unroll
-            for (int q = 0; q < 9; ++q) nnb[q] = nv[q / 3] * dn[q % 3];
+                for (int q = 0; q < 9; ++q) nnb[q] = nv[q / 3] * dn[q % 3];
+            }
         }
     }
     GF_GROUP_STAMP(4);
+    if constexpr (SF != 0) {
+        // Row-side sum factorisation (see SfLane): COMPONENT by component -- the five B operands of a component, its five (nine) 4 x 4 x 4 products into X[k2],
+        // the twelve FMAs into the accumulators.  The accumulators are FMA destinations here (arch VGPRs, 144 of the 256), so what a component keeps live is
+        // kept small: X is three registers, the products of the normals are formed per component.
+        // order of the products: consecutive ones write different X (a dependent pair would wait for the first one's four passes)
+        // order of the products: two products into the same partial sum are at least two products apart (a dependent product reads its accumulator while the
+        // previous one is still in its four passes; nothing interlocks inline assembly).  The rational instance splits its five k2 = 0 products over X[0] and X[3].
+        constexpr int NPR = SF == 1 ? 5 : 9, NX = SF == 1 ? 3 : 4;
+        constexpr int PM[9] = {0, 1, 3, SF == 1 ? 2 : 3, SF == 1 ? 4 : 1, 3, 4, 2, 4}, PK[9] = {0, 1, 2, 0, SF == 1 ? 1 : 0, 1, 0, 0, 1}, PX[9] = {0, 1, 2, SF == 1 ? 0 : 3, SF == 1 ? 1 : 0, 1, 3, 0, 1};
+        // (m, k2) -> X:  SF = 1: (0,0)->0 (1,1)->1 (3,2)->2 (2,0)->0 (4,1)->1;   SF = 2: (0,0)->0 (1,1)->1 (3,2)->2 (3,0)->3 (1,0)->0 (3,1)->1 (4,0)->3 (2,0)->0 (4,1)->1
+        // tb: the B operand of the body-force term of a dR/dCP component (its row side is the VALUE kind: Fv, k2 = 0) -- one more product, into X[3]
+        auto products = [&](const double (&tq)[5], double (&X)[4], auto withb_, double tb) {
+            constexpr bool WITHB = decltype(withb_)::value;
+            if constexpr (NX == 3 && !WITHB) X[3] = 0.0;
+            if constexpr (NX == 3 && WITHB) X[3] = mfma4_first(Fv, tb);
+            static_for<NPR>([&](auto n_) {
+                constexpr int n = decltype(n_)::value, m = PM[n], k2 = PK[n], xi = PX[n];
+                static_assert(sf_nz<SF>(m, k2) && (xi == k2 || (xi == 3 && k2 == 0)), "product list of the row-side factors");
+                if constexpr (n < NX) X[xi] = mfma4_first(F[m][k2], tq[m]);      // the list starts with one product per partial sum
+                else mfma4_acc(X[xi], F[m][k2], tq[m]);
+            });
+            if constexpr (NX == 4 && WITHB) mfma4_acc(X[3], Fv, tb);          // (the previous product into X[3] lies three products back)
+        };
+        auto settle = [&](double (&X)[4], auto& acc, auto withb_) {
+            constexpr bool WITHB = decltype(withb_)::value;
+            if constexpr (NX == 4 || WITHB) X[0] += X[3];
+            sf_accumulate(acc, bs, X[0], X[1], X[2]);
+        };
+        constexpr std::false_type NOB{}; constexpr std::true_type WB{};
+        // software pipeline over the components of a stage: T formation of q (tied behind the products of q - 1), ONE gap, the FMAs of q - 1, the products of q
+        if (doK) {
+            double Xp[4] = {0.0, 0.0, 0.0, 0.0};
+            static_for<6>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                const double nq = nv[QI[q]] * nv[QJ[q]];
+                const Dep4 D = {Xp[0], Xp[1], Xp[2], Xp[3]};
+                double tq[5];
+                static_for<5>([&](auto m_) {
+                    constexpr int m = decltype(m_)::value;
+                    if constexpr (q == 0) {
+                        if constexpr (m < 2) tq[m] = row_dot<3 * m + QI[q], QJ[q]>(gR, pb);
+                        else tq[m] = row_dot2<3 * m + QI[q], QJ[q]>(nq * psi[m - 2], gR, pb);
+                    } else {
+                        if constexpr (m < 2) tq[m] = row_dot_dep<3 * m + QI[q], QJ[q]>(gR, pb, D);
+                        else tq[m] = row_dot2_dep<3 * m + QI[q], QJ[q]>(nq, psi[m - 2], gR, pb, D);
+                    }
+                });
+                if constexpr (q == 0) mfma_hazard_gap(tq);
+                else { mfma_pipeline_gap(tq, Xp); settle(Xp, accK[q - 1], NOB); }
+                products(tq, Xp, NOB, 0.0);
+                if constexpr (ALLF && q == 0) prefactors();
+                if constexpr (ALLF && WITHC && q == 2) { L.expand_h(im, mid, gR, hR); dpp_source_fence(hR); }
+            });
+            mfma4_result_gap(Xp[0], Xp[1], Xp[2], Xp[3]);
+            settle(Xp, accK[5], NOB);
+        }
+        GF_GROUP_STAMP(5);
+        if (doC) {
+            // body force, d(-f . u dA)/dc: -w f_i R_a (dJ/dZ . phi_b)_f with R_a = Fv B^(0)_{a2} -- one more product per (i, f) component (no tiles of its own)
+            double jzf[3];
+            const double pfu[3] = {uniform_double(pf[0]), uniform_double(pf[1]), uniform_double(pf[2])};
+            {
+                LoadGeom lg = {1.0, 0.0, 0.0};
+                if (has_bf) lg = load_geom(im, ppd);
+#pragma unroll
+                for (int f = 0; f < 3; ++f) jzf[f] = has_bf ? -load_dz_dot(im, ppd, lg, f, pb[0], pb[1]) : 0.0;
+            }
+            double Xp[4] = {0.0, 0.0, 0.0, 0.0};
+            static_for<9>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                const double nq = nv[q / 3] * dn[q % 3];
+                const Dep4 D = {Xp[0], Xp[1], Xp[2], Xp[3]};
+                double tq[5];
+                static_for<5>([&](auto m_) {
+                    constexpr int m = decltype(m_)::value;
+                    if constexpr (q == 0) {
+                        if constexpr (m < 2) tq[m] = row_dot<3 * m + q / 3, q % 3>(hR, pb);
+                        else tq[m] = row_dot2<3 * m + q / 3, q % 3>(nq * psi[m - 2], hR, pb);
+                    } else {
+                        if constexpr (m < 2) tq[m] = row_dot_dep<3 * m + q / 3, q % 3>(hR, pb, D);
+                        else tq[m] = row_dot2_dep<3 * m + q / 3, q % 3>(nq, psi[m - 2], hR, pb, D);
+                    }
+                });
+                double tbq = pfu[q / 3] * jzf[q % 3];
+                if constexpr (q == 0) asm volatile("s_nop 1" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tbq));
+                else { asm volatile("s_nop 1" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tbq), "+v"(Xp[0]), "+v"(Xp[1]), "+v"(Xp[2]), "+v"(Xp[3])); settle(Xp, accC[q - 1], WB); }
+                products(tq, Xp, WB, tbq);
+            });
+            mfma4_result_gap(Xp[0], Xp[1], Xp[2], Xp[3]);
+            settle(Xp, accC[8], WB);
+        }
+        GF_GROUP_STAMP(6);
+    } else {
     if (doK) {
         static_for<5>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
@@ -382,6 +612,7 @@ __device__ __forceinline__ void gauss_group(const RowLane& L, const double* im, 
         }
     }
     GF_GROUP_STAMP(6);
+    }
 }
 
 }  // namespace gf

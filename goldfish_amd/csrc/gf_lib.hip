@@ -51,7 +51,8 @@ struct gf_handle {
     std::vector<hipEvent_t> ev0, ev1; int ev_n = 0;   // element-kernel timing
     bool assembled[5] = {false, false, false, false, false};
     bool rec = false;                                 // p = 2, 3, MFMA path, default: walking kernel that stores row records + kl_gather_rec_kernel (gf_element_rec.hpp); GF_ASSEMBLY=block: one block per element + row gather
-    const WalkItem* d_rec_items = nullptr; const RecCp* d_rec_cp = nullptr; double* d_rec = nullptr; long long rec_doubles = 0;
+    int sumfact = 2;                // p = 3 walking kernel (GF_SUMFACT): 0 the 16 x 16 x 4 products for every item, 1 row-side sum factorisation on polynomial patches, 2 on rational ones too
+    const WalkItem* d_rec_items = nullptr; const int* d_rec_order = nullptr; const RecCp* d_rec_cp = nullptr; double* d_rec = nullptr; long long rec_doubles = 0;
     bool rec4 = false; const RecCp4* d_rec_cp4 = nullptr;   // p = 4, default: three walks that store row records + kl_gather_rec4_kernel (gf_element_rec4.hpp); GF_ASSEMBLY=block: element blocks
     bool mfma = true;                                 // p = 3: contraction on the FP64 matrix pipe (GF_ELEMENT=valu selects the VALU kernel)
     const int *d_rev_s = nullptr, *d_rev_c = nullptr;
@@ -98,6 +99,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
             if (const char* s = getenv("GF_ASSEMBLY")) want_rec = want_rec && std::string(s) != "block";
             int seg = 0;                                      // whole strips unless the model is small (HostModel::build_rec); GF_REC_SEG: elements per work item
             if (const char* s = getenv("GF_REC_SEG")) seg = std::max(1, atoi(s));
+            if (const char* s = getenv("GF_SUMFACT")) h->sumfact = std::max(0, std::min(2, atoi(s)));
             H.tick("penalty owner lists, visit records");
             if (want_rec) { H.build_rec(seg); h->rec = H.degree <= 3; h->rec4 = H.degree == 4; H.tick("row-record tables"); }
             // p = 4: each pass kind on the path that is faster for it (same-lease A/B on one GPU's share of C5, profiles/r04_c5share_*: Newton pass 21.3 ms through
@@ -219,6 +221,7 @@ int gf_create(const gf_model_desc* desc, int device, gf_handle** out) {
         if (recs) {
             scratch_doubles = std::max<long long>(scratch_doubles, H.nelem * (long long)(11 * NB + 2));   // the functionals' element blocks (FunCfg::STRIDE) share the scratch
             h->d_rec_items = h->upload(H.rec_items);
+            h->d_rec_order = h->upload(H.rec_order);
             if (h->rec4) h->d_rec_cp4 = h->upload(H.rec_cp4); else h->d_rec_cp = h->upload(H.rec_cp);
             h->rec_doubles = biggest_items * H.rec_rows * rec_sz;
             h->d_rec = h->dalloc<double>((size_t)h->rec_doubles);
@@ -381,9 +384,23 @@ template <int P> static void run_assemble_rec(gf_handle* h, int flags) {
     const int slot = h->ev_n % 64, n = (int)H.rec_items.size();
     HIPCHK(hipEventRecord(h->ev0[slot], h->stream));
     constexpr int ALL_BITS = GF_ASM_R | GF_ASM_K | GF_ASM_DRDCP | GF_ASM_DRDH;
-    if ((flags & ALL_BITS) == ALL_BITS) hipLaunchKernelGGL((kl_element_rec_kernel<PW, true, true>), dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_rec_items, flags, O);
-    else if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_rec_kernel<PW, true>), dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_rec_items, flags, O);
-    else hipLaunchKernelGGL((kl_element_rec_kernel<PW, false>), dim3((unsigned)n), dim3(64), 0, h->stream, h->M, h->d_rec_items, flags, O);
+    // p = 3: the row-side sum-factorised walk (gf_gauss_loop.hpp: SfLane), one launch per kind of patch (polynomial: one product per derivative, rational: nine
+    // (m, k2) pairs); p = 2 and GF_SUMFACT = 0: the 16 x 16 x 4 products of rounds 2 - 4, one launch over all items
+    auto walk = [&](auto sf_, const int* order, int cnt) {
+        constexpr int SF = decltype(sf_)::value;
+        if (cnt <= 0) return;
+        if ((flags & ALL_BITS) == ALL_BITS) hipLaunchKernelGGL((kl_element_rec_kernel<PW, true, true, SF>), dim3((unsigned)cnt), dim3(64), 0, h->stream, h->M, h->d_rec_items, order, flags, O);
+        else if (flags & GF_ASM_DRDCP) hipLaunchKernelGGL((kl_element_rec_kernel<PW, true, false, SF>), dim3((unsigned)cnt), dim3(64), 0, h->stream, h->M, h->d_rec_items, order, flags, O);
+        else hipLaunchKernelGGL((kl_element_rec_kernel<PW, false, false, SF>), dim3((unsigned)cnt), dim3(64), 0, h->stream, h->M, h->d_rec_items, order, flags, O);
+    };
+    if constexpr (PW == 3 && GF_SUMFACT_BUILD != 0) {
+        if (h->sumfact == 0) walk(std::integral_constant<int, 0>{}, nullptr, n);
+        else {
+            walk(std::integral_constant<int, 1>{}, h->d_rec_order, H.rec_npoly);
+            if (h->sumfact == 2) walk(std::integral_constant<int, 2>{}, h->d_rec_order + H.rec_npoly, n - H.rec_npoly);
+            else walk(std::integral_constant<int, 0>{}, h->d_rec_order + H.rec_npoly, n - H.rec_npoly);
+        }
+    } else walk(std::integral_constant<int, 0>{}, nullptr, n);
     HIPCHK(hipEventRecord(h->ev1[slot], h->stream));
     h->ev_n++;
     const Chunk& c = h->chunks[0];

@@ -150,6 +150,7 @@ struct HostModel {
     std::vector<CpDesc> cp_desc;        // [total_cp]
     std::vector<WalkItem> rec_items; std::vector<RecPatch> rec_patch; std::vector<RecCp> rec_cp; std::vector<RecCp4> rec_cp4; int rec_rows = 0;   // row-record path
     void build_rec(int seg_len);
+    std::vector<int> rec_order; int rec_npoly = 0;      // work items of the polynomial patches first, then those of the rational ones (WalkItem::pad), each in natural order
     void eval_mortar_vertex(int patch, double xu, double xv, int win[2], double* nu, double* nu2) const;
     std::vector<int> cp_patch;          // [total_cp]
     std::vector<double> weights;
@@ -573,12 +574,18 @@ inline void HostModel::build_rec(int seg_len) {
         R.ev0_of = (int)ints.size(); ints.resize(ints.size() + nseg + 1);
         for (int g = 0; g <= nseg; ++g) ints[R.ev0_of + g] = int(int64_t(g) * P.nelv / nseg);
         for (int g = 0; g < nseg; ++g) for (int ev = ints[R.ev0_of + g]; ev < ints[R.ev0_of + g + 1]; ++ev) ints[R.seg_of + ev] = g;
+        int rat = 0;                                                   // WalkItem::pad: non-constant weights (the walking kernel's polynomial instance needs W,alpha = 0)
+        for (int64_t a = P.cp_off + 1; a < P.cp_off + int64_t(P.nu) * P.nv; ++a) if (weights[a] != weights[P.cp_off]) { rat = 1; break; }
         for (int eu = 0; eu < P.nelu; ++eu) for (int g = 0; g < nseg; ++g) {
             const int e0 = ints[R.ev0_of + g], e1 = ints[R.ev0_of + g + 1];
-            rec_items.push_back({s, eu, e0, e1 - e0, g, 0, ints[P.spu + eu] - P.p, 0});
+            rec_items.push_back({s, eu, e0, e1 - e0, g, 0, ints[P.spu + eu] - P.p, rat});
             rec_rows = std::max(rec_rows, (ints[P.spv + e1 - 1] + 1) - (ints[P.spv + e0] - P.q));     // rows first .. last of the item's windows
         }
     }
+    rec_order.clear();
+    for (int k = 0; k < (int)rec_items.size(); ++k) if (!rec_items[k].pad) rec_order.push_back(k);
+    rec_npoly = (int)rec_order.size();
+    for (int k = 0; k < (int)rec_items.size(); ++k) if (rec_items[k].pad) rec_order.push_back(k);
     if (degree == 4) rec_cp4.assign(total_cp, RecCp4{}); else rec_cp.assign(total_cp, RecCp{});
     for (int s = 0; s < n_owned; ++s) {
         const PatchDev& P = patches[s];

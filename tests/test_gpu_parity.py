@@ -172,6 +172,38 @@ def test_penalty_kernel_variants(oracle_lib, monkeypatch):
             D.close()
 
 
+def test_p3_contraction_variants(oracle_lib, monkeypatch):
+    """The p = 3 walking kernel contracts either with the 16 x 16 x 4 products of rounds 2 - 4 (GF_SUMFACT=0) or with the row-side sum factorisation
+    (v_mfma_f64_4x4x4 as inline assembly with hand-placed interlocks, accumulators parked in AGPRs): on polynomial patches only (=1) or on rational
+    patches too (=2, default).  Every variant against the oracle, for every pass kind, on models with polynomial patches, rational patches, both,
+    repeated knots, a projected load, follower pressure -- and bitwise reproducible run to run."""
+    from goldfish_amd import _lib
+    from oracle.oracle_py import Oracle
+    for case in ("shell3x2_p3", "C3_wing16_refdata", "slr9_nurbs_p3_projected_load", "shell3x2_p3_double_knots_pressure_edge"):
+        A, h, u = _state(CASES[case](), seed=11)
+        O = Oracle(A, thickness=h, u=u)
+        vals, Ro = O.assemble(), O.residual()
+        for variant in ("0", "1", "2"):
+            monkeypatch.setenv("GF_SUMFACT", variant)
+            D = _lib.DeviceModel(A)
+            D.set_thickness(h)
+            D.set_u(u)
+            D.assemble(_lib.ASM_ALL)
+            first = [D.residual().copy()] + [D.values(w).copy() for w in range(5)]
+            assert _rel(first[0], Ro) < RTOL, (case, variant)
+            for w in range(5):
+                assert _rel(first[1 + w], vals[w]) < RTOL, (case, variant, w)
+            D.assemble(_lib.ASM_ALL)
+            for w in range(5):
+                assert np.array_equal(first[1 + w], D.values(w)), (case, variant, w)
+            for flags, which in ((_lib.ASM_R | _lib.ASM_K, (0,)), (_lib.ASM_DRDCP | _lib.ASM_DRDH, (1, 2, 3, 4)), (_lib.ASM_K | _lib.ASM_DRDCP, (0, 1, 2, 3))):
+                D.assemble(flags)
+                for w in which:
+                    assert _rel(D.values(w), vals[w]) < RTOL, (case, variant, flags, w)
+            D.close()
+    monkeypatch.delenv("GF_SUMFACT", raising=False)
+
+
 def test_valu_element_kernel_still_matches(oracle_lib, monkeypatch):
     """The FP64-VALU element kernel (GF_ELEMENT=valu) stays a supported path for every degree."""
     from goldfish_amd import _lib

@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["GF_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "goldfish_amd", "libgoldfish_hip_stamps.so")
+os.environ["GF_LIB"] = os.environ.get("GF_STAMPS_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "goldfish_amd", "libgoldfish_hip_stamps.so")
 from goldfish_amd import _lib, geometry as G
 from goldfish_amd.model import arrays_from_spec
 P = int(os.environ.get("GF_P", "3"))
