@@ -34,8 +34,10 @@ def pass_tag(name):
     if name.startswith(("kl_element_rec4_kernel", "kl_gather_rec4_kernel")):      # <PASS, NC> / <NC>: NC = 21 is the full record layout (full pass), 9 the Newton pass
         return "full" if a and a[-1] == "21" else "other"
     if name.startswith(("kl_element_rec_kernel", "kl_gather_rec_kernel", "kl_element_mfma_kernel", "kl_element_mfma4_kernel", "kl_gather1_kernel")):
-        if name.startswith("kl_element_rec_kernel") and len(a) == 2 and a[1] == "true":
-            return "other"              # <P, true> without ALLF: a partial pass with dR/dCP (linearize after a Newton solve); the full pass runs <P, true, true>
+        if name.startswith("kl_element_rec_kernel"):
+            # <P, WITHC, ALLF, SF>: the full pass runs the ALLF instances (round 5: one per kind of patch, SF = 1 polynomial / 2 rational; their bytes add up);
+            # <P, true, false, .> is a partial pass with dR/dCP (linearize after a Newton solve), <P, false, ...> the Newton pass
+            return "full" if a[1:3] == ["true", "true"] else "other"
         return "full" if a and a[-1] == "true" else ("other" if a else None)
     if name.startswith("pen_owner_kernel"):
         return "full" if a[-2:] == ["true", "true"] else "other"
