@@ -2,6 +2,8 @@
 // FP64 pipe?  Per component (15 per Gauss-point group of the full pass): T formation (19 v_fmac_f64_dpp + 3 products), 5 v_mfma_f64_4x4x4 into X[3], 12 FMAs into
 // the accumulators (72 doubles in arch VGPRs).  MODE bit 0: T formation, bit 1: the products, bit 2: the accumulation; MODE 8: the 16 x 16 x 4 form of rounds 2 - 4
 // (T formation + 5 v_mfma_f64_16x16x4 per component).  Output: cycles per component (s_memtime of wave 0) and the time of a grid that fills every SIMD once.
+// sf_asm_kernel: the same step with the products as inline assembly (VGPR results, explicit result gap) and with the accumulators parked in AGPRs -- what the
+// product kernel runs (gf_gauss_loop.hpp); mfma_order_kernel: does the ORDER of v_mfma_f64_16x16x4 with AGPR accumulators matter (it does not: 78.5 cycles).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -90,6 +92,62 @@ __global__ __launch_bounds__(64) void sf_kernel(const double* __restrict__ in, d
     double s = pad[(l * 7) & 63];
     for (int q = 0; q < 15; ++q) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
     out[blockIdx.x * 64 + l] = s;
+}
+
+// The ORDER of v_mfma_f64_16x16x4 with AGPR accumulators: ORD 0 five products in a row into the same accumulator (component outer, m inner: a dependent chain),
+// ORD 1 the products of one m for NQ accumulators in a row (m outer: independent accumulators, what gauss_group's SF = 0 form and the p = 4 kernels issue),
+// ORD 2 component outer over PAIRS of accumulators (two interleaved chains).
+template <int ORD, int NQ>
+__global__ __launch_bounds__(64) void mfma_order_kernel(const double* __restrict__ in, double* __restrict__ out, int ngroups, long long* __restrict__ cyc) {
+    __shared__ double pad[4800];
+    const int l = threadIdx.x;
+    pad[l] = in[l];
+    double a[5], b[5];
+    for (int k = 0; k < 5; ++k) { a[k] = in[64 + 5 * l + k]; b[k] = in[700 + 5 * l + k]; }
+    d4 acc[NQ];
+    for (int q = 0; q < NQ; ++q) acc[q] = d4{0, 0, 0, 0};
+    __syncthreads();
+    const long long t0 = clock64();
+    for (int g = 0; g < ngroups; ++g) {
+        if constexpr (ORD == 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int m = 0; m < 5; ++m) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[(m + q) % 5], acc[q], 0, 0, 0);
+        } else if constexpr (ORD == 1) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[(m + q) % 5], acc[q], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; q += 2)
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[(m + q) % 5], acc[q], 0, 0, 0);
+                    if (q + 1 < NQ) acc[q + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[(m + q + 1) % 5], acc[q + 1], 0, 0, 0);
+                }
+        }
+        a[g & 3] += 1e-9;
+    }
+    const long long t1 = clock64();
+    if (l == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+    double s = pad[(l * 7) & 63];
+    for (int q = 0; q < NQ; ++q) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+    out[blockIdx.x * 64 + l] = s;
+}
+template <int ORD, int NQ> void run_order(const char* what, const double* din, double* dout, long long* dc) {
+    const int NG = 2000, NWG = 1024;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((mfma_order_kernel<ORD, NQ>), dim3(NWG), dim3(64), 0, 0, din, dout, NG, dc);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    long long c = 0; hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
+    printf("%-78s %7.1f cycles per v_mfma_f64_16x16x4 (wave 0), %6.1f ns per product and SIMD (grid)\n", what, (double)c / NG / (5.0 * NQ), 1e6 * ms / NG / (5.0 * NQ));
 }
 
 // VAR 0: asm products (VGPR results), result gap GAP, accumulators in VGPRs.  VAR 1: accumulators parked in AGPRs, slot by slot (read, 3 FMAs, write back).
@@ -200,6 +258,10 @@ int main() {
     run_asm<1, 10>("SF step, accumulators parked in AGPRs, slot by slot, gap 10", din, dout, dc);
     run_asm<2, 10>("SF step, accumulators parked in AGPRs, four slots together, gap 10", din, dout, dc);
     run_asm<2, 6>("   ... gap 6", din, dout, dc);
+    run_order<0, 18>("v_mfma_f64_16x16x4, 18 AGPR accumulators: five products in a row per accumulator", din, dout, dc);
+    run_order<1, 18>("   ... the 18 accumulators in turn (one m at a time)", din, dout, dc);
+    run_order<1, 6>("   ... 6 accumulators in turn", din, dout, dc);
+    run_order<2, 18>("   ... two accumulators alternating, five products each", din, dout, dc);
     run<8>("5 v_mfma_f64_16x16x4 alone", din, dout, dc);
     run<9>("T formation + 5 v_mfma_f64_16x16x4 (the step of rounds 2 - 4)", din, dout, dc);
     return 0;
