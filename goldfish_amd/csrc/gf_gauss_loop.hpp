@@ -323,8 +323,9 @@ template <int SF> __host__ __device__ constexpr bool sf_nz(int m, int k2) {
 // assembly the instruction is opaque to the hazard recogniser, so the two software interlocks are spelled out: operands written by VALU need two wait states
 // (mfma_hazard_gap, as for the 16 x 16 x 4 form), and a result needs the instruction's four passes + write-back before a VALU reads it (mfma4_result_gap: ten
 // wait states against the six LLVM's table lists for the 4 x 4 x 4 DGEMM form).  Dependent products (the same X) are kept two products apart.
-__device__ __forceinline__ double mfma4_first(double a, double b) { double d; asm("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ void mfma4_acc(double& x, double a, double b) { asm("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(x) : "v"(a), "v"(b)); }
+// (volatile: the products and the gaps keep the order they are written in -- the spacing of dependent products is a property of the source, not of the scheduler's mood)
+__device__ __forceinline__ double mfma4_first(double a, double b) { double d; asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ void mfma4_acc(double& x, double a, double b) { asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(x) : "v"(a), "v"(b)); }
 __device__ __forceinline__ void mfma4_result_gap(double& a, double& b, double& c) { asm volatile("s_nop 7\n\ts_nop 1" : "+v"(a), "+v"(b), "+v"(c)); }
 __device__ __forceinline__ void mfma4_result_gap(double& a, double& b, double& c, double& d) { asm volatile("s_nop 7\n\ts_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 __device__ __forceinline__ void mfma4_result_gap(double& x) { asm volatile("s_nop 7\n\ts_nop 1" : "+v"(x)); }
