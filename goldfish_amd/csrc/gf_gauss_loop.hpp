@@ -13,6 +13,8 @@
 // (v_fmac_f64_dpp) -- no T tile, no expanded Hessian in LDS, no cross-wave barrier (one wave per workgroup), 300 MFMAs instead
 // of 4800 FMA instructions per element.  tools/ubench_mfma_loop.hip measures this loop at 68 cycles per (component, m) unit and
 // checks the operand layout:  A[i][k]: lane = i + 16 k    B[k][j]: lane = j + 16 k    D[i][j]: lane = j + 16 (i % 4), register i / 4.
+// Round 5, p = 3 walking kernel (template argument SF of gauss_group): the ROW side of that product sum-factorised -- per u index on v_mfma_f64_4x4x4, the v
+// direction by twelve FMAs per component (see SfLane below); the column side (T formation) is the one described here in every instance.
 // Reference path: GOLDFISH/nonmatching_opt.py:941-1015 (RIGA, dRIGAduIGA, dRIGAdCPIGA, dRIGAdh_th) via PENGoLINS' assembly.
 #pragma once
 #include <type_traits>
