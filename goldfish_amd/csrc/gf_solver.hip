@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include "../../include/goldfish_solver.h"
 
@@ -101,7 +102,7 @@ __global__ void band_fill_kernel(long long ncp, const long long* __restrict__ nb
 // the rows above need no predicate), one barrier, 16 FMAs; the steps are unrolled (register indices are compile-time).  The inverse of the unit lower
 // factor: column c by the four lanes 4 c .. 4 c + 3 (lane q4 keeps x_m, m = q4 mod 4, in registers), row by row with a full-width dot product against
 // the row of L in LDS (zeros above the diagonal: no run-time bounds), rows unrolled.
-__device__ __forceinline__ void diag_body(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
+__device__ __forceinline__ void diag_body_rows(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
     constexpr int S1 = NB + 1;
     __shared__ double sL[NB * S1];
     __shared__ __attribute__((aligned(16))) double col[2][NB];
@@ -173,6 +174,162 @@ __device__ __forceinline__ void diag_body(double* __restrict__ band, double* __r
             }
         }
     }
+}
+
+// ---- Round 5: the same tile BLOCKED by 16, block updates on the matrix pipe.  The row-per-thread kernel above spends its time in 64 + 64 dependent steps that each cross
+//      the workgroup (LDS publish, barrier, an IEEE division, 16 FMAs): ~ 500 cycles per step.  Here the 64 steps are four 16 x 16 diagonal blocks factored INSIDE A WAVE
+//      (lane = row, the pivot column reaches the other rows through v_fmac_f64_dpp row_newbcast: no LDS, no barrier, 120 DPP FMAs; the block's inverse by substitution with
+//      lane = column, another 120; all four waves do it redundantly, so nobody waits for a broadcast), the panel below a block is one 16^3 product per wave with the block's
+//      inverse (W = A M^T, L = W D^-1), the trailing blocks are 16^3 products (A_ij -= W_i L_j^T), two barriers per block step.  The inverse of the unit lower factor is
+//      block substitution per block column, one wave per column, and stays in registers: the accumulator layout of v_mfma_f64_16x16x4 (D[i][j]: lane j + 16 (i % 4), register
+//      i / 4) IS its B-operand layout for k-step register (B[k][j]: lane j + 16 (k % 4)), so S = sum_k L_ik M_kj feeds M_ij = -M_ii S directly and M_ij feeds the next block row.
+//      Results differ from the row kernel's in the last bits (other summation order, reciprocal by v_rcp_f64 + two Newton steps); deterministic.
+template <int I, int N, class F> __device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+// t += (value of g in lane LANE of this lane's 16-lane row) * p.  The DPP source must not have been written by a VALU instruction in the two preceding wait states
+// (dpp_fence; tools/check_dpp_hazard.py checks the code object)
+template <int LANE> __device__ __forceinline__ void fmac_bcast16(double& t, double g, double p) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(g), "v"(p), "n"(LANE));
+}
+__device__ __forceinline__ void dpp_fence(double& g) { asm volatile("s_nop 1" : "+v"(g)); }
+constexpr int MS = 17;        // row stride of the 16 x 16 blocks kept in LDS
+// diagonal block pb of the tile in sT: negL[m] = -l_im (lane = row i; 0 for i <= m), x[i] = (L^-1)_ic (lane = column c), myd / mydinv = d_i, 1 / d_i of the lane's row
+__device__ __forceinline__ void diag16(const double* __restrict__ sT, int pb, int l16, double (&negL)[16], double (&x)[16], double& myd, double& mydinv) {
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { const double v = sT[(16 * pb + l16) * LS + 16 * pb + c]; a[c] = c <= l16 ? v : 0.0; }
+    const double one = 1.0;
+    sfor<0, 16>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        dpp_fence(a[p]);
+        double dp = 0.0;
+        fmac_bcast16<p>(dp, a[p], one);                         // the pivot, from lane p
+        double r = __builtin_amdgcn_rcp(dp);
+        double e = __builtin_fma(-dp, r, 1.0); r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-dp, r, 1.0); r = __builtin_fma(r, e, r);
+        if (l16 == p) { myd = dp; mydinv = r; }
+        const double nl = -(a[p] * r);                          // -l_ip for the rows below the pivot
+        negL[p] = l16 > p ? nl : 0.0;
+        sfor<p + 1, 16>([&](auto C) { constexpr int c = decltype(C)::value; fmac_bcast16<c>(a[c], a[p], nl); });      // a_ic -= l_ip a_cp (a_cp from lane c)
+    });
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = l16 == i ? 1.0 : 0.0;
+    asm volatile("s_nop 1" : "+v"(negL[0]), "+v"(negL[1]), "+v"(negL[2]), "+v"(negL[3]), "+v"(negL[4]), "+v"(negL[5]), "+v"(negL[6]), "+v"(negL[7]),
+                             "+v"(negL[8]), "+v"(negL[9]), "+v"(negL[10]), "+v"(negL[11]), "+v"(negL[12]), "+v"(negL[13]), "+v"(negL[14]));
+    sfor<0, 15>([&](auto M_) {
+        constexpr int m = decltype(M_)::value;
+        sfor<m + 1, 16>([&](auto I_) { constexpr int i = decltype(I_)::value; fmac_bcast16<i>(x[i], negL[m], x[m]); });                // x_i -= l_im x_m (l_im from lane i)
+    });
+}
+// block column J of the inverse of the unit lower factor (one wave): M_JJ from sMb, M_iJ = -M_ii sum_{k = J}^{i - 1} L_ik M_kJ, written to Li (64 x 64, row-major; zero blocks above)
+template <int J> __device__ __forceinline__ void inv_block_column(const double* __restrict__ sT, const double (*sMb)[16 * MS], double* __restrict__ Li, int l16, int kq) {
+    d4 Mk[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) Mk[J][ks] = sMb[J][(4 * ks + kq) * MS + l16];
+    sfor<J + 1, 4>([&](auto I_) {
+        constexpr int i = decltype(I_)::value;
+        d4 S = {0, 0, 0, 0};
+        sfor<J, i>([&](auto K_) {
+            constexpr int kk = decltype(K_)::value;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f64_16x16x4f64(sT[(16 * i + l16) * LS + 16 * kk + 4 * ks + kq], Mk[kk][ks], S, 0, 0, 0);
+        });
+        d4 R = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) R = __builtin_amdgcn_mfma_f64_16x16x4f64(-sMb[i][l16 * MS + 4 * ks + kq], S[ks], R, 0, 0, 0);
+        Mk[i] = R;
+    });
+    sfor<0, 4>([&](auto I_) {
+        constexpr int i = decltype(I_)::value;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Li[(16 * i + 4 * t + kq) * NB + 16 * J + l16] = i < J ? 0.0 : Mk[i < J ? J : i][t];
+    });
+}
+__device__ __forceinline__ void diag_body_blocked(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
+    __shared__ __attribute__((aligned(16))) double sT[NB * LS];
+    __shared__ double sMw[4][16 * MS], sMb[4][16 * MS], sW[3][16 * MS], sd[NB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
+    double* A = band + (size_t)rowoff[k] * NB2;
+    {
+        const int i = tid >> 2, jg = tid & 3;
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) { const double2 v = *reinterpret_cast<const double2*>(A + i * NB + 16 * jg + c); sT[i * LS + 16 * jg + c] = v.x; sT[i * LS + 16 * jg + c + 1] = v.y; }
+    }
+    __syncthreads();
+    double negL[16], x[16], myd = 0.0, mydinv = 0.0;
+#pragma unroll 1
+    for (int pb = 0; pb < 4; ++pb) {
+        diag16(sT, pb, l16, negL, x, myd, mydinv);
+        if (kq == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sMw[wave][i * MS + l16] = x[i];
+            if (wave == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sMb[pb][i * MS + l16] = x[i];
+                sd[16 * pb + l16] = myd;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int ib = pb + 1 + wave;
+        if (ib < 4) {                                            // panel block (ib, pb): W = A M^T (kept for the trailing update), L = W D^-1 (in place)
+            d4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sT[(16 * ib + l16) * LS + 16 * pb + 4 * ks + kq], sMw[wave][l16 * MS + 4 * ks + kq], acc, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const int r = 4 * t + kq; sW[wave][r * MS + l16] = acc[t]; sT[(16 * ib + r) * LS + 16 * pb + l16] = acc[t] * mydinv; }
+        }
+        __syncthreads();
+        if (wave == 0 && kq == 0) {                              // what the band keeps of the diagonal block: d on the diagonal, L below, zero above (nobody reads the block again)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sT[(16 * pb + l16) * LS + 16 * pb + c] = c < l16 ? -negL[c] : (c == l16 ? myd : 0.0);
+        }
+        const int nrem = 3 - pb, npairs = nrem * (nrem + 1) / 2;
+        for (int n = wave; n < npairs; n += 4) {                 // trailing blocks (ib2 >= jb > pb): A -= W_ib2 L_jb^T
+            int gi = 0, gj = n;
+            while (gj > gi) { gj -= gi + 1; ++gi; }
+            const int ib2 = pb + 1 + gi, jb = pb + 1 + gj;
+            d4 acc;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = sT[(16 * ib2 + 4 * t + kq) * LS + 16 * jb + l16];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sW[gi][l16 * MS + 4 * ks + kq], sT[(16 * jb + l16) * LS + 16 * pb + 4 * ks + kq], acc, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sT[(16 * ib2 + 4 * t + kq) * LS + 16 * jb + l16] = acc[t];
+        }
+        __syncthreads();
+    }
+    double* Li = linv + (size_t)k * NB2;
+    if (wave == 0) inv_block_column<0>(sT, sMb, Li, l16, kq);
+    else if (wave == 1) inv_block_column<1>(sT, sMb, Li, l16, kq);
+    else if (wave == 2) inv_block_column<2>(sT, sMb, Li, l16, kq);
+    else inv_block_column<3>(sT, sMb, Li, l16, kq);
+    if (tid < NB) dval[(size_t)k * NB + tid] = sd[tid];
+    if (tid == 64) {                                             // smallest / largest |d| of the tile (singularity report)
+        double mn = 1e300, mx = 0.0;
+        for (int p = 0; p < NB; ++p) { const double d = fabs(sd[p]); mn = fmin(mn, d); mx = fmax(mx, d); }
+        stat[2 * k] = mn; stat[2 * k + 1] = mx;
+    }
+    {
+        const int i = tid >> 2, jg = tid & 3;
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) {
+            const bool up = jg > (i >> 4);
+            *reinterpret_cast<double2*>(A + i * NB + 16 * jg + c) = double2{up ? 0.0 : sT[i * LS + 16 * jg + c], up ? 0.0 : sT[i * LS + 16 * jg + c + 1]};
+        }
+    }
+}
+#ifndef GF_DIAG_BLOCKED
+#define GF_DIAG_BLOCKED 1
+#endif
+__device__ __forceinline__ void diag_body(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
+#if GF_DIAG_BLOCKED
+    diag_body_blocked(band, linv, dval, rowoff, k, stat);
+#else
+    diag_body_rows(band, linv, dval, rowoff, k, stat);
+#endif
 }
 __global__ __launch_bounds__(256) void diag_kernel(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
     diag_body(band, linv, dval, rowoff, k, stat);

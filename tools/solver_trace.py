@@ -40,3 +40,28 @@ for s_, e, n, wg in F:
         b = 1 << max(0, (wg - 1).bit_length())
         bins[b][0] += 1; bins[b][1] += (e - s_) / 1e6; bins[b][2] += wg * 4 * 2 * 64.0 ** 3
 print("update_wide_kernel by launch size (workgroups <= bin: launches, ms, Tflop/s if w = 4):", {b: (v[0], round(v[1], 1), round(v[2] / v[1] / 1e9, 1)) for b, v in sorted(bins.items())})
+# per tree height: a level of the factorisation starts with its extend-add rounds (nd_extend_add_batch_kernel; the leaves' level has none) -- wall time of the level,
+# launches of the large fronts' chain kernels in it, summed durations of its wide updates, and how long NO wide update (batched or not) was running
+lv = []
+cur = None
+for s, e, n, wg in F[1:]:
+    if n.startswith("nd_extend_add_batch_kernel") and (cur is None or cur["seen_other"]):
+        cur = {"t0": s, "t1": e, "rows": [], "seen_other": False}; lv.append(cur)
+    if cur is None:
+        cur = {"t0": s, "t1": e, "rows": [], "seen_other": False}; lv.append(cur)
+    if not n.startswith("nd_extend_add_batch_kernel"): cur["seen_other"] = True
+    cur["rows"].append((s, e, n, wg)); cur["t1"] = max(cur["t1"], e)
+print("per level (height ascending): wall ms | diag_kernel launches (mean us) | panel us | narrow us | wide: launches, summed ms | batched kernels summed ms | time without any wide update running ms")
+for i, L in enumerate(lv):
+    R = L["rows"]; d = [r for r in R if r[2] == "diag_kernel"]; w = [r for r in R if r[2].startswith("update_wide_kernel")]
+    pk = [r for r in R if r[2] == "panel_kernel"]; nk = [r for r in R if r[2].startswith("update_narrow_kernel")]
+    b = [r for r in R if r[2].startswith("nd_")]
+    ev2 = sorted([(r[0], 1) for r in R if "update_wide" in r[2]] + [(r[1], -1) for r in R if "update_wide" in r[2]])
+    live2 = 0; last2 = L["t0"]; nowide = 0
+    for t, dd in ev2:
+        if live2 == 0: nowide += t - last2
+        live2 += dd; last2 = t
+    nowide += L["t1"] - last2 if live2 == 0 else 0
+    mean = lambda rows: sum(r[1] - r[0] for r in rows) / max(1, len(rows)) / 1e3
+    print("  level %2d: %7.2f | %4d (%5.1f) | %5.1f | %5.1f | %3d, %6.2f | %6.2f | %6.2f" % (i, (L["t1"] - L["t0"]) / 1e6, len(d), mean(d), mean(pk), mean(nk), len(w),
+          sum(r[1] - r[0] for r in w) / 1e6, sum(r[1] - r[0] for r in b) / 1e6, nowide / 1e6))
