@@ -223,7 +223,7 @@ __device__ __forceinline__ void diag16(const double* __restrict__ sT, int pb, in
     });
 }
 // block column J of the inverse of the unit lower factor (one wave): M_JJ from sMb, M_iJ = -M_ii sum_{k = J}^{i - 1} L_ik M_kJ, written to Li (64 x 64, row-major; zero blocks above)
-template <int J> __device__ __forceinline__ void inv_block_column(const double* __restrict__ sT, const double (*sMb)[16 * MS], double* __restrict__ Li, int l16, int kq) {
+template <int J> __device__ __forceinline__ void inv_block_column(const double* __restrict__ sT, double (*sMb)[16 * MS], double* __restrict__ Li, int l16, int kq) {
     d4 Mk[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) Mk[J][ks] = sMb[J][(4 * ks + kq) * MS + l16];
@@ -246,9 +246,16 @@ template <int J> __device__ __forceinline__ void inv_block_column(const double* 
         for (int t = 0; t < 4; ++t) Li[(16 * i + 4 * t + kq) * NB + 16 * J + l16] = i < J ? 0.0 : Mk[i < J ? J : i][t];
     });
 }
-__device__ __forceinline__ void diag_body_blocked(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
-    __shared__ __attribute__((aligned(16))) double sT[NB * LS];
-    __shared__ double sMw[4][16 * MS], sMb[4][16 * MS], sW[3][16 * MS], sd[NB];
+constexpr int SMEM_DOUBLES = 2 * NB * LS;      // LDS of every tile kernel: two operand tiles (67 584 B); the blocked diagonal tile needs 58 240 B of it
+constexpr int DIAG_LDS_DOUBLES = NB * LS + (4 + 4 + 3) * 16 * MS + NB;
+static_assert(DIAG_LDS_DOUBLES <= SMEM_DOUBLES, "diag_body_blocked lives in the tile kernels' LDS");
+__device__ __forceinline__ void diag_body_blocked(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat,
+                                                  double* __restrict__ smem) {
+    double* sT = smem;
+    double (*sMw)[16 * MS] = reinterpret_cast<double (*)[16 * MS]>(smem + NB * LS);
+    double (*sMb)[16 * MS] = sMw + 4;
+    double (*sW)[16 * MS] = sMb + 4;
+    double* sd = smem + NB * LS + 11 * 16 * MS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
     double* A = band + (size_t)rowoff[k] * NB2;
     {
@@ -324,20 +331,27 @@ __device__ __forceinline__ void diag_body_blocked(double* __restrict__ band, dou
 #ifndef GF_DIAG_BLOCKED
 #define GF_DIAG_BLOCKED 1
 #endif
-__device__ __forceinline__ void diag_body(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
+__device__ __forceinline__ void diag_body(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat,
+                                          double* __restrict__ smem) {
 #if GF_DIAG_BLOCKED
-    diag_body_blocked(band, linv, dval, rowoff, k, stat);
+    diag_body_blocked(band, linv, dval, rowoff, k, stat, smem);
 #else
     diag_body_rows(band, linv, dval, rowoff, k, stat);
 #endif
 }
+#define GF_TILE_SMEM __shared__ __attribute__((aligned(16))) double smem[SMEM_DOUBLES]
 __global__ __launch_bounds__(256) void diag_kernel(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
-    diag_body(band, linv, dval, rowoff, k, stat);
+    GF_TILE_SMEM;
+    diag_body(band, linv, dval, rowoff, k, stat, smem);
 }
+// Round 5: the workgroup that applies the LAST update to a diagonal tile factors it on the spot (its update is in global memory, the tile kernels' LDS is free again) --
+// the chain of a block column is panel -> narrow update (+ next diagonal tile) instead of diagonal tile -> panel -> narrow update: one dependent launch less per column.
+struct DiagNext { double* linv; double* dval; double* stat; int on; };
 
 // panel tile i = k + 1 + blockIdx.x: W = A_ik L_kk^-T (to wbuf), L_ik = W D_k^-1 (in place)
-__device__ __forceinline__ void panel_body(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, int g) {
-    __shared__ __attribute__((aligned(16))) double sA[NB * LS], sB[NB * LS];
+__device__ __forceinline__ void panel_body(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, int g,
+                                           double* __restrict__ smem) {
+    double *sA = smem, *sB = smem + NB * LS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double* A = band + (size_t)(rowoff[k + 1 + g] + (g + 1)) * NB2;
     load_tile(A, sA, tid); load_tile(linv + (size_t)k * NB2, sB, tid);
@@ -357,7 +371,8 @@ __device__ __forceinline__ void panel_body(double* __restrict__ band, const doub
     }
 }
 __global__ __launch_bounds__(256) void panel_kernel(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k) {
-    panel_body(band, linv, dval, wbuf, rowoff, k, (int)blockIdx.x);
+    GF_TILE_SMEM;
+    panel_body(band, linv, dval, wbuf, rowoff, k, (int)blockIdx.x, smem);
 }
 
 // trailing tile (i, j), k < j <= i: A_ij -= W_ik L_jk^T
@@ -368,8 +383,8 @@ __device__ __forceinline__ void tri_index(int bidx, int& gi, int& gj) {
     while (gi * (gi + 1) / 2 > bidx) --gi;
     gj = bidx - gi * (gi + 1) / 2;
 }
-__device__ __forceinline__ void update_tile(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, int gi, int gj) {
-    __shared__ __attribute__((aligned(16))) double sA[NB * LS], sB[NB * LS];
+__device__ __forceinline__ void update_tile(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, int gi, int gj, double* __restrict__ smem) {
+    double *sA = smem, *sB = smem + NB * LS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = k + 1 + gi, j = k + 1 + gj;
     load_tile(wbuf + (size_t)gi * NB2, sA, tid);
@@ -387,15 +402,24 @@ __device__ __forceinline__ void update_tile(double* __restrict__ band, const dou
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) C[(16 * wave + 4 * rg + (lane >> 4)) * NB + 16 * nj + (lane & 15)] = acc[nj][rg];
 }
-__global__ __launch_bounds__(256) void update_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, int ni) {
+// the diagonal tile of block column kn has had its last update (by this workgroup, in global memory): factor it
+__device__ __forceinline__ void diag_next(double* __restrict__ band, const long long* __restrict__ rowoff, int kn, const DiagNext& dn, double* __restrict__ smem) {
+    __syncthreads();                                              // the update's stores (this workgroup's) are visible to all its threads; its LDS operands are dead
+    diag_body(band, dn.linv, dn.dval, rowoff, kn, dn.stat, smem);
+}
+__global__ __launch_bounds__(256) void update_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, int ni, DiagNext dn) {
+    GF_TILE_SMEM;
     int gi, gj; tri_index((int)blockIdx.x, gi, gj);
     if (gi >= ni) return;
-    update_tile(band, wbuf, rowoff, k, gi, gj);
+    update_tile(band, wbuf, rowoff, k, gi, gj, smem);
+    if (dn.on && blockIdx.x == 0) diag_next(band, rowoff, k + 1, dn, smem);
 }
 // the same update restricted to the trailing columns k + 1 .. k + nin (the rest of a panel group): blockIdx = (row gi, column gj < nin)
-__global__ __launch_bounds__(256) void update_narrow_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k) {
+__global__ __launch_bounds__(256) void update_narrow_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, DiagNext dn) {
+    GF_TILE_SMEM;
     if (blockIdx.x < blockIdx.y) return;
-    update_tile(band, wbuf, rowoff, k, (int)blockIdx.x, (int)blockIdx.y);
+    update_tile(band, wbuf, rowoff, k, (int)blockIdx.x, (int)blockIdx.y, smem);
+    if (dn.on && blockIdx.x == 0 && blockIdx.y == 0) diag_next(band, rowoff, k + 1, dn, smem);       // tile (k + 1, k + 1): block column k was its last update inside the panel group
 }
 // trailing update behind a GROUP of w block columns k0 .. k0 + w - 1 (all factored, panels W_c in wbuf + c wstride tiles): tile (i, j), i >= j >= k0 + w,
 //     A_ij -= sum_c W_i,k0+c L_j,k0+c^T
@@ -409,8 +433,9 @@ __device__ __forceinline__ void park_tile(const double2 (&r)[8], double* __restr
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const int idx = 2 * (tid + 256 * q), rr = idx >> 6, c = idx & 63; s[rr * LS + c] = r[q].x; s[rr * LS + c + 1] = r[q].y; }
 }
-__device__ __forceinline__ void update_wide_tile(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int gi, int gj) {
-    __shared__ __attribute__((aligned(16))) double sA[NB * LS], sB[NB * LS];
+__device__ __forceinline__ void update_wide_tile(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int gi, int gj,
+                                                 double* __restrict__ smem) {
+    double *sA = smem, *sB = smem + NB * LS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = k0 + w + gi, j = k0 + w + gj;
     double* C = band + (size_t)(rowoff[i] + (gi - gj)) * NB2;
@@ -470,10 +495,13 @@ __device__ __forceinline__ void update_wide_tile(double* __restrict__ band, cons
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) C[(16 * wave + 4 * rg + (lane >> 4)) * NB + 16 * nj + (lane & 15)] = acc[nj][rg];
 }
-__global__ __launch_bounds__(256) void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow) {
+__global__ __launch_bounds__(256) void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow,
+                                                          DiagNext dn) {
+    GF_TILE_SMEM;
     int gi, gj; tri_index((int)blockIdx.x, gi, gj);
     if (gi >= nrow) return;
-    update_wide_tile(band, wbuf, wstride, rowoff, k0, w, gi, gj);
+    update_wide_tile(band, wbuf, wstride, rowoff, k0, w, gi, gj, smem);
+    if (dn.on && blockIdx.x == 0) diag_next(band, rowoff, k0 + w, dn, smem);          // the first block column of the next panel group
 }
 
 // forward substitution, block column k: y_k = L_kk^-1 b_k (every workgroup; workgroup 0 keeps it), b_{k+g} -= L_{k+g,k} y_k (workgroup g >= 1)
@@ -830,34 +858,45 @@ __global__ __launch_bounds__(256) void nd_extend_add_kernel(const Front* __restr
 //      blockIdx.x beyond a front's own panel / trailing block exits) -- the diagonal tile's serial chain is paid per (height, k) instead of per (front, k).
 __global__ __launch_bounds__(256) void nd_diag_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ tri, double* __restrict__ arena,
                                                             double* __restrict__ linv, double* __restrict__ dval, double* __restrict__ stat, int k) {
+    GF_TILE_SMEM;
     const Front F = fronts[list[blockIdx.x]];
-    diag_body(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, tri, k, stat + 2 * F.kbase);
+    diag_body(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, tri, k, stat + 2 * F.kbase, smem);
 }
 // wofs: tile offset of the front's panel scratch (WP slots of nblk_t - 1 tiles each); c = k - k0: slot of block column k inside its panel group
 __global__ __launch_bounds__(256) void nd_panel_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs, const long long* __restrict__ tri,
                                                              double* __restrict__ arena, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, int k, int c) {
+    GF_TILE_SMEM;
     const Front F = fronts[list[blockIdx.y]];
     if ((int)blockIdx.x >= F.nblk_t - 1 - k) return;
     panel_body(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, wbuf + (size_t)(wofs[blockIdx.y] + (long long)c * (F.nblk_t - 1)) * NB2, tri, k,
-               (int)blockIdx.x);
+               (int)blockIdx.x, smem);
 }
 // block column k updates the remaining columns of its panel group (k0 .. k0 + w - 1, w = min(WP, nblk_e - k0) per front): blockIdx = (row gi, column gj, front)
 __global__ __launch_bounds__(256) void nd_update_narrow_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs,
-                                                                     const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k, int k0, int WP) {
+                                                                     const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k, int k0, int WP,
+                                                                     DiagNext dn) {
+    GF_TILE_SMEM;
     const Front F = fronts[list[blockIdx.z]];
     const int ni = F.nblk_t - 1 - k, w = min(WP, F.nblk_e - k0), nin = k0 + w - 1 - k;
     if ((int)blockIdx.x >= ni || (int)blockIdx.y >= nin || blockIdx.x < blockIdx.y) return;
-    update_tile(arena + (size_t)F.tile_off * NB2, wbuf + (size_t)(wofs[blockIdx.z] + (long long)(k - k0) * (F.nblk_t - 1)) * NB2, tri, k, (int)blockIdx.x, (int)blockIdx.y);
+    double* band = arena + (size_t)F.tile_off * NB2;
+    update_tile(band, wbuf + (size_t)(wofs[blockIdx.z] + (long long)(k - k0) * (F.nblk_t - 1)) * NB2, tri, k, (int)blockIdx.x, (int)blockIdx.y, smem);
+    if (dn.on && blockIdx.x == 0 && blockIdx.y == 0)
+        diag_next(band, tri, k + 1, DiagNext{dn.linv + (size_t)F.kbase * NB2, dn.dval + (size_t)F.kbase * NB, dn.stat + 2 * F.kbase, 1}, smem);
 }
 // trailing update behind the panel group that starts at k0, all its block columns at once (update_wide_tile): one read-modify-write of a target tile per group
 // instead of per column -- the single-column batched update was HBM bound (64 KB per 64^3 product: 143 of the 406 ms of a C4 factorisation)
 __global__ __launch_bounds__(256) void nd_update_wide_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs,
-                                                                   const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k0, int WP) {
+                                                                   const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k0, int WP, DiagNext dn) {
+    GF_TILE_SMEM;
     const Front F = fronts[list[blockIdx.y]];
     const int w = min(WP, F.nblk_e - k0), nrow = F.nblk_t - (k0 + w);
     if ((long long)blockIdx.x >= (long long)nrow * (nrow + 1) / 2) return;
     int gi, gj; tri_index((int)blockIdx.x, gi, gj);
-    update_wide_tile(arena + (size_t)F.tile_off * NB2, wbuf + (size_t)wofs[blockIdx.y] * NB2, F.nblk_t - 1, tri, k0, w, gi, gj);
+    double* band = arena + (size_t)F.tile_off * NB2;
+    update_wide_tile(band, wbuf + (size_t)wofs[blockIdx.y] * NB2, F.nblk_t - 1, tri, k0, w, gi, gj, smem);
+    if (dn.on && blockIdx.x == 0 && k0 + w < F.nblk_e)
+        diag_next(band, tri, k0 + w, DiagNext{dn.linv + (size_t)F.kbase * NB2, dn.dval + (size_t)F.kbase * NB, dn.stat + 2 * F.kbase, 1}, smem);
 }
 // Schur complements of a list of children (no two of the same parent in one launch: one writer per entry) added into their parents
 __global__ __launch_bounds__(256) void nd_extend_add_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const int* __restrict__ pmap, const long long* __restrict__ tri,
@@ -1176,6 +1215,7 @@ struct gfs_handle {
     static constexpr int MAX_RHS = 8;
     std::vector<SolveWs> ws; long long ws_front_len = 0, ws_bnd_len = 0;
     unsigned char* d_row_ok = nullptr;            // gfs_set_row_mask: rows of d_valK that hold values (a rank's own rows of a sharded K); nullptr = all
+    bool fuse_diag = true;                        // GF_SOLVER_FUSE_DIAG=0: every diagonal tile in a launch of its own (the chain before round 5)
     bool lds_raised[3] = {false, false, false};   // hipFuncAttributeMaxDynamicSharedMemorySize of the NR-right-hand-side sweep kernels raised on this handle's device
     template <class Tp> Tp* dalloc(size_t cnt) {
         void* p = nullptr; const size_t nb_ = (cnt ? cnt : 1) * sizeof(Tp);
@@ -1207,7 +1247,7 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
         if (nbb > 0) hipLaunchKernelGGL(nd_extend_add_kernel, dim3((unsigned)(nbb * (nbb + 1) / 2)), dim3(256), 0, st, h->d_fronts, c, h->d_pmap, h->d_tri, h->band);
     }
     double* band = h->band + (size_t)F.tile_off * NB2;
-    double* linv = h->linv + (size_t)F.kbase * NB2; double* dval = h->dval + (size_t)F.kbase * NB;
+    double* linv = h->linv + (size_t)F.kbase * NB2; double* dval = h->dval + (size_t)F.kbase * NB; double* stat = h->stat + 2 * F.kbase;
     const int WP = std::max(h->panel_w, 1); const long long wstride = h->max_blk;
     // (Measured and dropped, round 3: look-ahead -- the bulk of a group's wide update on a partner stream while this stream goes on with the next group's
     //  diag / panel / narrow chain: 0.473 instead of 0.407 s at C4.  The chain's one-workgroup diagonal tile runs at a third of its speed next to the
@@ -1217,14 +1257,17 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
         for (int c = 0; c < w; ++c) {
             const int k = k0 + c, ni = F.nblk_t - 1 - k, nin = k0 + w - 1 - k;
             double* wb = h->s_wbuf[si] + (size_t)c * wstride * NB2;
-            hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, st, band, linv, dval, h->d_tri, k, h->stat + 2 * F.kbase);
+            // the diagonal tile of every block column but the front's first has been factored by the workgroup that applied its last update (DiagNext)
+            if (k == 0 || !h->fuse_diag) hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, st, band, linv, dval, h->d_tri, k, stat);
             if (ni > 0) hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, st, band, linv, dval, wb, h->d_tri, k);
-            if (w == 1 && ni > 0) hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, st, band, wb, h->d_tri, k, ni);
-            else if (nin > 0) hipLaunchKernelGGL(update_narrow_kernel, dim3(ni, nin), dim3(256), 0, st, band, wb, h->d_tri, k);
+            if (w == 1 && ni > 0) hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, st, band, wb, h->d_tri, k, ni,
+                                                     DiagNext{linv, dval, stat, h->fuse_diag && k + 1 < F.nblk_e ? 1 : 0});
+            else if (nin > 0) hipLaunchKernelGGL(update_narrow_kernel, dim3(ni, nin), dim3(256), 0, st, band, wb, h->d_tri, k, DiagNext{linv, dval, stat, h->fuse_diag ? 1 : 0});
         }
         const int nrow = F.nblk_t - (k0 + w);
         if (w > 1 && nrow > 0)
-            hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, h->s_wbuf[si], wstride, h->d_tri, k0, w, nrow);
+            hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, h->s_wbuf[si], wstride, h->d_tri, k0, w, nrow,
+                               DiagNext{linv, dval, stat, h->fuse_diag && k0 + w < F.nblk_e ? 1 : 0});
     }
 }
 // the NR vectors of one kind out of NR workspaces (one workspace per right-hand side)
@@ -1306,18 +1349,19 @@ static void nd_factor_levels(gfs_handle* h) {
         for (int k0 = 0; k0 < kmax; k0 += WP) {                          // panel groups, as nd_factor_front does for one front
             for (int c = 0; c < WP && k0 + c < kmax; ++c) {
                 const int k = k0 + c, nk = L.nk[k], mni = L.max_ni[k];
-                hipLaunchKernelGGL(nd_diag_batch_kernel, dim3(nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_tri, h->band, h->linv, h->dval, h->stat, k);
+                if (k == 0 || !h->fuse_diag)
+                    hipLaunchKernelGGL(nd_diag_batch_kernel, dim3(nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_tri, h->band, h->linv, h->dval, h->stat, k);
                 if (mni <= 0) continue;
                 hipLaunchKernelGGL(nd_panel_batch_kernel, dim3(mni, nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off, h->d_tri, h->band, h->linv, h->dval,
                                    h->bwbuf, k, c);
                 if (c + 1 < WP)
                     hipLaunchKernelGGL(nd_update_narrow_batch_kernel, dim3(mni, WP - 1 - c, nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off, h->d_tri,
-                                       h->band, h->bwbuf, k, k0, WP);
+                                       h->band, h->bwbuf, k, k0, WP, DiagNext{h->linv, h->dval, h->stat, h->fuse_diag ? 1 : 0});
             }
             const int mni0 = L.max_ni[k0];                                // >= the trailing rows of every front of the group
             if (mni0 > 0)
                 hipLaunchKernelGGL(nd_update_wide_batch_kernel, dim3((unsigned)((long long)mni0 * (mni0 + 1) / 2), L.nk[k0]), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off,
-                                   h->d_fwofs + L.off, h->d_tri, h->band, h->bwbuf, k0, WP);
+                                   h->d_fwofs + L.off, h->d_tri, h->band, h->bwbuf, k0, WP, DiagNext{h->linv, h->dval, h->stat, h->fuse_diag ? 1 : 0});
         }
         for (int s = 0; s < used; ++s) { HIPCHK(hipEventRecord(h->ev[s], h->st[s])); HIPCHK(hipStreamWaitEvent(h->stream, h->ev[s], 0)); }
     }
@@ -1464,6 +1508,7 @@ int gfs_create(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t* nb
             bwcp = std::max<long long>(bwcp, std::llabs((long long)new_index[a] - new_index[nb[k]]));
         }
         h = new gfs_handle(); h->device = device;
+        if (const char* e_ = getenv("GF_SOLVER_FUSE_DIAG")) h->fuse_diag = atoi(e_) != 0;
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreate(&h->stream));
         h->ncp = ncp; h->n = 3 * ncp; h->nblk = (h->n + NB - 1) / NB; h->npad = h->nblk * NB;
@@ -1587,6 +1632,7 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
         h->linv = h->dalloc<double>((size_t)kb * NB2);
         h->dval = h->dalloc<double>((size_t)kb * NB); h->stat = h->dalloc<double>((size_t)2 * kb);
         if (const char* e = std::getenv("GF_SOLVER_PANEL_W")) h->panel_w = h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));
+        if (const char* e = std::getenv("GF_SOLVER_FUSE_DIAG")) h->fuse_diag = std::atoi(e) != 0;
         if (const char* e = std::getenv("GF_SOLVER_BATCH_PANEL_W")) h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));      // panel groups of the level-batched small fronts
         {   // independent subtrees for the side streams: split the largest subtree (by factorisation work) until there are enough of them
             constexpr int NS = gfs_handle::NS;
@@ -1743,12 +1789,16 @@ int gfs_refactor(gfs_handle* h) {
             else nd_run_captured(h, &h->g_factor, [&] { nd_sweep_up(h, [](gfs_handle* hh, int t, hipStream_t st, int si) { nd_factor_front(hh, t, st, si); }); });
         } else {
         hipLaunchKernelGGL(band_fill_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->newi, h->general ? h->d_rev : nullptr, h->valK, h->band, h->rowoff, h->n, h->npad);
+        bool have_diag = false;                                          // the diagonal tile of this block column was factored by the update that completed it
         for (long long k = 0; k < h->nblk; ++k) {
             const int ni = h->nik[k];
-            hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, h->stream, h->band, h->linv, h->dval, h->rowoff, (int)k, h->stat);
+            if (!have_diag) hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, h->stream, h->band, h->linv, h->dval, h->rowoff, (int)k, h->stat);
+            have_diag = false;
             if (ni > 0) {
                 hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, h->stream, h->band, h->linv, h->dval, h->wbuf, h->rowoff, (int)k);
-                hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, h->stream, h->band, h->wbuf, h->rowoff, (int)k, ni);
+                have_diag = h->fuse_diag && k + 1 < h->nblk;              // block column k is the last one that reaches tile (k + 1, k + 1)
+                hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, h->stream, h->band, h->wbuf, h->rowoff, (int)k, ni,
+                                   DiagNext{h->linv, h->dval, h->stat, have_diag ? 1 : 0});
             }
         }
         }
