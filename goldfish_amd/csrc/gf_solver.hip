@@ -340,8 +340,9 @@ __device__ __forceinline__ void diag_body(double* __restrict__ band, double* __r
 #endif
 }
 #define GF_TILE_SMEM __shared__ __attribute__((aligned(16))) double smem[SMEM_DOUBLES]
+#define GF_DIAG_SMEM __shared__ __attribute__((aligned(16))) double smem[DIAG_LDS_DOUBLES]
 __global__ __launch_bounds__(256) void diag_kernel(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, const long long* __restrict__ rowoff, int k, double* __restrict__ stat) {
-    GF_TILE_SMEM;
+    GF_DIAG_SMEM;
     diag_body(band, linv, dval, rowoff, k, stat, smem);
 }
 // Round 5: the workgroup that applies the LAST update to a diagonal tile factors it on the spot (its update is in global memory, the tile kernels' LDS is free again) --
@@ -370,10 +371,6 @@ __device__ __forceinline__ void panel_body(double* __restrict__ band, const doub
         }
     }
 }
-__global__ __launch_bounds__(256) void panel_kernel(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k) {
-    GF_TILE_SMEM;
-    panel_body(band, linv, dval, wbuf, rowoff, k, (int)blockIdx.x, smem);
-}
 
 // trailing tile (i, j), k < j <= i: A_ij -= W_ik L_jk^T
 // linear index -> (gi >= gj) over a lower triangle of tiles
@@ -401,25 +398,6 @@ __device__ __forceinline__ void update_tile(double* __restrict__ band, const dou
     for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) C[(16 * wave + 4 * rg + (lane >> 4)) * NB + 16 * nj + (lane & 15)] = acc[nj][rg];
-}
-// the diagonal tile of block column kn has had its last update (by this workgroup, in global memory): factor it
-__device__ __forceinline__ void diag_next(double* __restrict__ band, const long long* __restrict__ rowoff, int kn, const DiagNext& dn, double* __restrict__ smem) {
-    __syncthreads();                                              // the update's stores (this workgroup's) are visible to all its threads; its LDS operands are dead
-    diag_body(band, dn.linv, dn.dval, rowoff, kn, dn.stat, smem);
-}
-__global__ __launch_bounds__(256) void update_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, int ni, DiagNext dn) {
-    GF_TILE_SMEM;
-    int gi, gj; tri_index((int)blockIdx.x, gi, gj);
-    if (gi >= ni) return;
-    update_tile(band, wbuf, rowoff, k, gi, gj, smem);
-    if (dn.on && blockIdx.x == 0) diag_next(band, rowoff, k + 1, dn, smem);
-}
-// the same update restricted to the trailing columns k + 1 .. k + nin (the rest of a panel group): blockIdx = (row gi, column gj < nin)
-__global__ __launch_bounds__(256) void update_narrow_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, DiagNext dn) {
-    GF_TILE_SMEM;
-    if (blockIdx.x < blockIdx.y) return;
-    update_tile(band, wbuf, rowoff, k, (int)blockIdx.x, (int)blockIdx.y, smem);
-    if (dn.on && blockIdx.x == 0 && blockIdx.y == 0) diag_next(band, rowoff, k + 1, dn, smem);       // tile (k + 1, k + 1): block column k was its last update inside the panel group
 }
 // trailing update behind a GROUP of w block columns k0 .. k0 + w - 1 (all factored, panels W_c in wbuf + c wstride tiles): tile (i, j), i >= j >= k0 + w,
 //     A_ij -= sum_c W_i,k0+c L_j,k0+c^T
@@ -495,13 +473,162 @@ __device__ __forceinline__ void update_wide_tile(double* __restrict__ band, cons
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) C[(16 * wave + 4 * rg + (lane >> 4)) * NB + 16 * nj + (lane & 15)] = acc[nj][rg];
 }
-__global__ __launch_bounds__(256) void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow,
-                                                          DiagNext dn) {
-    GF_TILE_SMEM;
+// ---- Round 5: the same update with the operand tiles brought in by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write parking), in HALF tiles
+//      of 32 k (two buffers of 32 KB: the same 64 KB of LDS, two workgroups per CU) so that the loads of stage s + 1 are in flight under the products of stage s and
+//      a stage costs ONE barrier.  The DMA writes a wave's 64 x 16 bytes linearly (four rows of 256 B), so the bank-conflict-free image is made on the SOURCE side:
+//      the lane that fills 16-byte slot p of row r fetches chunk p ^ (r & 15) of that row, and the operand reads apply the same XOR.  A lane reads both k of a chunk
+//      with one ds_read_b128 (k-step t of a round takes component t: the k order inside a stage is permuted identically for both operands).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+// rows 16 wave .. 16 wave + 15 of one operand's part tile (k = HKT h .. HKT h + HKT - 1 of the 64 x 64 row-major tile g) -> dst (64 rows x HKT doubles): HKT / 8 pieces of 1 KB per wave
+template <int HKT> __device__ __forceinline__ void glds_part(const double* __restrict__ g, double* __restrict__ dst, int h, int wave, int lane) {
+    constexpr int CPR = HKT / 2, RPP = 64 / CPR, NP = 16 / RPP;   // 16-byte chunks per row, rows per piece, pieces per wave
+    const int rr = lane / CPR, p = lane % CPR;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int r = 16 * wave + RPP * q + rr;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(g + r * NB + HKT * h + 2 * (p ^ (r & (CPR - 1)))), (lds_void_t*)(dst + (16 * wave + RPP * q) * HKT), 16, 0, 0);
+    }
+}
+// acc (+ / -)= sum over ncol pairs of 64 x 64 tiles (A_c, B_c) of A_c B_c^T; src(c, gA, gB) names pair c.  Stage s = (pair s / SPC, part s % SPC) lives in buffer s % 2.
+template <int HKT, bool NEG, class Src> __device__ __forceinline__ void mma_pairs_dma(Src&& src, int ncol, d4 (&acc)[4], double* __restrict__ smem) {
+    constexpr int PART = NB * HKT, STAGE = 2 * PART, CPR = HKT / 2, SPC = NB / HKT;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
+    auto issue = [&](int s) {
+        const double *gA, *gB; src(s / SPC, gA, gB);
+        double* buf = smem + (s & 1) * STAGE;
+        glds_part<HKT>(gA, buf, s % SPC, wave, lane);
+        glds_part<HKT>(gB, buf + PART, s % SPC, wave, lane);
+    };
+    issue(0);
+    const int ns = SPC * ncol;
+    for (int s = 0; s < ns; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of stage s have landed (and whatever the caller loaded before)
+        __builtin_amdgcn_s_barrier();                             // ... everybody's; and everybody is done with stage s - 1, whose buffer the next loads overwrite
+        asm volatile("" ::: "memory");
+        if (s + 1 < ns) issue(s + 1);
+        const double* bufA = smem + (s & 1) * STAGE + (16 * wave + l16) * HKT;
+        const double* bufB = smem + (s & 1) * STAGE + PART + l16 * HKT;
+#pragma unroll
+        for (int rd = 0; rd < HKT / 8; ++rd) {
+            const int off = 2 * ((4 * rd + kq) ^ (l16 & (CPR - 1)));
+            const double2 a = *reinterpret_cast<const double2*>(bufA + off);
+            double2 b[4];
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) b[nj] = *reinterpret_cast<const double2*>(bufB + nj * 16 * HKT + off);
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) acc[nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -a.x : a.x, b[nj].x, acc[nj], 0, 0, 0);
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) acc[nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -a.y : a.y, b[nj].y, acc[nj], 0, 0, 0);
+        }
+    }
+}
+template <int HKT> __device__ __forceinline__ void update_wide_tile_dma(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w,
+                                                                        int gi, int gj, double* __restrict__ smem) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
+    const int i = k0 + w + gi, j = k0 + w + gj;
+    double* C = band + (size_t)(rowoff[i] + (gi - gj)) * NB2;
+    d4 acc[4];
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) acc[nj][rg] = C[(16 * wave + 4 * rg + kq) * NB + 16 * nj + l16];
+    mma_pairs_dma<HKT, true>([&](int c, const double*& gA, const double*& gB) {
+        const int k = k0 + c;
+        gA = wbuf + (size_t)((long long)c * wstride + (i - (k + 1))) * NB2;
+        gB = band + (size_t)(rowoff[j] + (j - k)) * NB2;
+    }, w, acc, smem);
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) C[(16 * wave + 4 * rg + kq) * NB + 16 * nj + l16] = acc[nj][rg];
+}
+// panel tile in the same form: W = A_ik L_kk^-T (to wbuf), L_ik = W D_k^-1 (in place: the tile's last part has landed in LDS before anything is stored)
+template <int HKT> __device__ __forceinline__ void panel_body_dma(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf,
+                                                                  const long long* __restrict__ rowoff, int k, int g, double* __restrict__ smem) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double* A = band + (size_t)(rowoff[k + 1 + g] + (g + 1)) * NB2;
+    d4 acc[4] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+    mma_pairs_dma<HKT, false>([&](int, const double*& gA, const double*& gB) { gA = A; gB = linv + (size_t)k * NB2; }, 1, acc, smem);
+    double* W = wbuf + (size_t)g * NB2;
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) {
+        const int c = 16 * nj + (lane & 15);
+        const double di = 1.0 / dval[(size_t)k * NB + c];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int r = 16 * wave + 4 * rg + (lane >> 4);
+            W[r * NB + c] = acc[nj][rg]; A[r * NB + c] = acc[nj][rg] * di;
+        }
+    }
+}
+// parts of 16 k: two buffers of 16 KB -- FOUR workgroups per CU (the kernels that call this keep their LDS and registers small: no fused diagonal tile).  One MI355X, 150 block
+// rows behind 8 block columns, random operands (tools/ubench_update.hip, profiles/r05_ubench_update.txt): through registers 48.6 TFLOP/s; LDS-DMA with parts of 32 k (64 KB,
+// two workgroups per CU) 56.0, parts of 16 k 62.9; whole tiles (128 KB, one workgroup per CU) 47.1
+constexpr int HK = 16;
+#ifndef GF_UPDATE_DMA
+#define GF_UPDATE_DMA 1        // 0: operand tiles through registers (update_wide_tile), the form of rounds 3 - 4
+#endif
+#ifndef GF_WIDE_WAVES
+#define GF_WIDE_WAVES 4        // workgroups of a wide update per CU.  Three would leave 64 KB of LDS and a third of the registers of every CU free for the chain kernels of the
+#endif                         // other fronts (panel 32 KB; narrow update + diagonal tile 58 KB): their launches then take 15 / 30 us instead of 65 - 190 us beside the wide updates, but the
+                               // wide updates lose more than the chains gain -- C4, same box, median of 7: 0.2238 s with three, 0.2210 s with four (profiles/r05_solver_variants_ab.txt)
+#if GF_UPDATE_DMA
+#define GF_UPDATE_WIDE_TILE update_wide_tile_dma<HK>
+#define GF_WIDE_SMEM __shared__ __attribute__((aligned(16))) double smem[4 * NB * HK]
+#define GF_WIDE_ATTR __attribute__((amdgpu_waves_per_eu(1, GF_WIDE_WAVES)))
+#ifndef GF_LEAN_CHAIN
+#define GF_LEAN_CHAIN 1        // 0: panel and narrow update through registers with two whole operand tiles in LDS (67.6 KB), the form of rounds 3 - 4
+#endif
+#if GF_LEAN_CHAIN
+#define GF_PANEL_SMEM __shared__ __attribute__((aligned(16))) double smem[4 * NB * HK]
+#define GF_PANEL_BODY panel_body_dma<HK>
+#define GF_NARROW_SMEM __shared__ __attribute__((aligned(16))) double smem[DIAG_LDS_DOUBLES > 4 * NB * HK ? DIAG_LDS_DOUBLES : 4 * NB * HK]
+#define GF_UPDATE_TILE(band, wbuf, rowoff, k, gi, gj, smem) update_wide_tile_dma<HK>(band, wbuf, 0, rowoff, k, 1, gi, gj, smem)
+#else
+#define GF_PANEL_SMEM GF_TILE_SMEM
+#define GF_PANEL_BODY panel_body
+#define GF_NARROW_SMEM GF_TILE_SMEM
+#define GF_UPDATE_TILE update_tile
+#endif
+#else
+#define GF_UPDATE_WIDE_TILE update_wide_tile
+#define GF_WIDE_SMEM GF_TILE_SMEM
+#define GF_WIDE_ATTR
+#define GF_PANEL_SMEM GF_TILE_SMEM
+#define GF_PANEL_BODY panel_body
+#define GF_NARROW_SMEM GF_TILE_SMEM
+#define GF_UPDATE_TILE update_tile
+#endif
+__global__ __launch_bounds__(256) void panel_kernel(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k) {
+    GF_PANEL_SMEM;
+    GF_PANEL_BODY(band, linv, dval, wbuf, rowoff, k, (int)blockIdx.x, smem);
+}
+
+// the diagonal tile of block column kn has had its last update (by this workgroup, in global memory): factor it
+__device__ __forceinline__ void diag_next(double* __restrict__ band, const long long* __restrict__ rowoff, int kn, const DiagNext& dn, double* __restrict__ smem) {
+    __syncthreads();                                              // the update's stores (this workgroup's) are visible to all its threads; its LDS operands are dead
+    diag_body(band, dn.linv, dn.dval, rowoff, kn, dn.stat, smem);
+}
+__global__ __launch_bounds__(256) void update_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, int ni, DiagNext dn) {
+    GF_NARROW_SMEM;
+    int gi, gj; tri_index((int)blockIdx.x, gi, gj);
+    if (gi >= ni) return;
+    GF_UPDATE_TILE(band, wbuf, rowoff, k, gi, gj, smem);
+    if (dn.on && blockIdx.x == 0) diag_next(band, rowoff, k + 1, dn, smem);
+}
+// the same update restricted to the trailing columns k + 1 .. k + nin (the rest of a panel group): blockIdx = (row gi, column gj < nin)
+__global__ __launch_bounds__(256) void update_narrow_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, DiagNext dn) {
+    GF_NARROW_SMEM;
+    if (blockIdx.x < blockIdx.y) return;
+    GF_UPDATE_TILE(band, wbuf, rowoff, k, (int)blockIdx.x, (int)blockIdx.y, smem);
+    if (dn.on && blockIdx.x == 0 && blockIdx.y == 0) diag_next(band, rowoff, k + 1, dn, smem);       // tile (k + 1, k + 1): block column k was its last update inside the panel group
+}
+__global__ __launch_bounds__(256) GF_WIDE_ATTR void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow) {
+    GF_WIDE_SMEM;
     int gi, gj; tri_index((int)blockIdx.x, gi, gj);
     if (gi >= nrow) return;
-    update_wide_tile(band, wbuf, wstride, rowoff, k0, w, gi, gj, smem);
-    if (dn.on && blockIdx.x == 0) diag_next(band, rowoff, k0 + w, dn, smem);          // the first block column of the next panel group
+    GF_UPDATE_WIDE_TILE(band, wbuf, wstride, rowoff, k0, w, gi, gj, smem);
 }
 
 // forward substitution, block column k: y_k = L_kk^-1 b_k (every workgroup; workgroup 0 keeps it), b_{k+g} -= L_{k+g,k} y_k (workgroup g >= 1)
@@ -858,45 +985,43 @@ __global__ __launch_bounds__(256) void nd_extend_add_kernel(const Front* __restr
 //      blockIdx.x beyond a front's own panel / trailing block exits) -- the diagonal tile's serial chain is paid per (height, k) instead of per (front, k).
 __global__ __launch_bounds__(256) void nd_diag_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ tri, double* __restrict__ arena,
                                                             double* __restrict__ linv, double* __restrict__ dval, double* __restrict__ stat, int k) {
-    GF_TILE_SMEM;
+    GF_DIAG_SMEM;
     const Front F = fronts[list[blockIdx.x]];
     diag_body(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, tri, k, stat + 2 * F.kbase, smem);
 }
 // wofs: tile offset of the front's panel scratch (WP slots of nblk_t - 1 tiles each); c = k - k0: slot of block column k inside its panel group
 __global__ __launch_bounds__(256) void nd_panel_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs, const long long* __restrict__ tri,
                                                              double* __restrict__ arena, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, int k, int c) {
-    GF_TILE_SMEM;
+    GF_PANEL_SMEM;
     const Front F = fronts[list[blockIdx.y]];
     if ((int)blockIdx.x >= F.nblk_t - 1 - k) return;
-    panel_body(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, wbuf + (size_t)(wofs[blockIdx.y] + (long long)c * (F.nblk_t - 1)) * NB2, tri, k,
+    GF_PANEL_BODY(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, wbuf + (size_t)(wofs[blockIdx.y] + (long long)c * (F.nblk_t - 1)) * NB2, tri, k,
                (int)blockIdx.x, smem);
 }
 // block column k updates the remaining columns of its panel group (k0 .. k0 + w - 1, w = min(WP, nblk_e - k0) per front): blockIdx = (row gi, column gj, front)
 __global__ __launch_bounds__(256) void nd_update_narrow_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs,
                                                                      const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k, int k0, int WP,
                                                                      DiagNext dn) {
-    GF_TILE_SMEM;
+    GF_NARROW_SMEM;
     const Front F = fronts[list[blockIdx.z]];
     const int ni = F.nblk_t - 1 - k, w = min(WP, F.nblk_e - k0), nin = k0 + w - 1 - k;
     if ((int)blockIdx.x >= ni || (int)blockIdx.y >= nin || blockIdx.x < blockIdx.y) return;
     double* band = arena + (size_t)F.tile_off * NB2;
-    update_tile(band, wbuf + (size_t)(wofs[blockIdx.z] + (long long)(k - k0) * (F.nblk_t - 1)) * NB2, tri, k, (int)blockIdx.x, (int)blockIdx.y, smem);
+    GF_UPDATE_TILE(band, wbuf + (size_t)(wofs[blockIdx.z] + (long long)(k - k0) * (F.nblk_t - 1)) * NB2, tri, k, (int)blockIdx.x, (int)blockIdx.y, smem);
     if (dn.on && blockIdx.x == 0 && blockIdx.y == 0)
         diag_next(band, tri, k + 1, DiagNext{dn.linv + (size_t)F.kbase * NB2, dn.dval + (size_t)F.kbase * NB, dn.stat + 2 * F.kbase, 1}, smem);
 }
 // trailing update behind the panel group that starts at k0, all its block columns at once (update_wide_tile): one read-modify-write of a target tile per group
 // instead of per column -- the single-column batched update was HBM bound (64 KB per 64^3 product: 143 of the 406 ms of a C4 factorisation)
-__global__ __launch_bounds__(256) void nd_update_wide_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs,
-                                                                   const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k0, int WP, DiagNext dn) {
-    GF_TILE_SMEM;
+__global__ __launch_bounds__(256) GF_WIDE_ATTR void nd_update_wide_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs,
+                                                                   const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k0, int WP) {
+    GF_WIDE_SMEM;
     const Front F = fronts[list[blockIdx.y]];
     const int w = min(WP, F.nblk_e - k0), nrow = F.nblk_t - (k0 + w);
     if ((long long)blockIdx.x >= (long long)nrow * (nrow + 1) / 2) return;
     int gi, gj; tri_index((int)blockIdx.x, gi, gj);
     double* band = arena + (size_t)F.tile_off * NB2;
-    update_wide_tile(band, wbuf + (size_t)wofs[blockIdx.y] * NB2, F.nblk_t - 1, tri, k0, w, gi, gj, smem);
-    if (dn.on && blockIdx.x == 0 && k0 + w < F.nblk_e)
-        diag_next(band, tri, k0 + w, DiagNext{dn.linv + (size_t)F.kbase * NB2, dn.dval + (size_t)F.kbase * NB, dn.stat + 2 * F.kbase, 1}, smem);
+    GF_UPDATE_WIDE_TILE(band, wbuf + (size_t)wofs[blockIdx.y] * NB2, F.nblk_t - 1, tri, k0, w, gi, gj, smem);
 }
 // Schur complements of a list of children (no two of the same parent in one launch: one writer per entry) added into their parents
 __global__ __launch_bounds__(256) void nd_extend_add_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const int* __restrict__ pmap, const long long* __restrict__ tri,
@@ -1252,22 +1377,28 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
     // (Measured and dropped, round 3: look-ahead -- the bulk of a group's wide update on a partner stream while this stream goes on with the next group's
     //  diag / panel / narrow chain: 0.473 instead of 0.407 s at C4.  The chain's one-workgroup diagonal tile runs at a third of its speed next to the
     //  MFMA-heavy update workgroups it shares a CU with, so the chain does not get shorter and the split update costs a launch more per group.)
+    bool have_diag = false;
     for (int k0 = 0; k0 < F.nblk_e; k0 += WP) {                       // groups of WP block columns: one wide trailing update per group
         const int w = std::min(WP, F.nblk_e - k0);
         for (int c = 0; c < w; ++c) {
             const int k = k0 + c, ni = F.nblk_t - 1 - k, nin = k0 + w - 1 - k;
             double* wb = h->s_wbuf[si] + (size_t)c * wstride * NB2;
-            // the diagonal tile of every block column but the front's first has been factored by the workgroup that applied its last update (DiagNext)
-            if (k == 0 || !h->fuse_diag) hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, st, band, linv, dval, h->d_tri, k, stat);
+            // inside a panel group the diagonal tile of a block column has been factored by the workgroup that applied its last update (DiagNext); the group's first
+            // column gets a launch (the wide update stays small: 32 KB of LDS, four workgroups per CU)
+            if (!have_diag) hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, st, band, linv, dval, h->d_tri, k, stat);
+            have_diag = false;
             if (ni > 0) hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, st, band, linv, dval, wb, h->d_tri, k);
-            if (w == 1 && ni > 0) hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, st, band, wb, h->d_tri, k, ni,
-                                                     DiagNext{linv, dval, stat, h->fuse_diag && k + 1 < F.nblk_e ? 1 : 0});
-            else if (nin > 0) hipLaunchKernelGGL(update_narrow_kernel, dim3(ni, nin), dim3(256), 0, st, band, wb, h->d_tri, k, DiagNext{linv, dval, stat, h->fuse_diag ? 1 : 0});
+            if (w == 1 && ni > 0) {
+                have_diag = h->fuse_diag && k + 1 < F.nblk_e;
+                hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, st, band, wb, h->d_tri, k, ni, DiagNext{linv, dval, stat, have_diag ? 1 : 0});
+            } else if (nin > 0) {
+                have_diag = h->fuse_diag;
+                hipLaunchKernelGGL(update_narrow_kernel, dim3(ni, nin), dim3(256), 0, st, band, wb, h->d_tri, k, DiagNext{linv, dval, stat, have_diag ? 1 : 0});
+            }
         }
         const int nrow = F.nblk_t - (k0 + w);
         if (w > 1 && nrow > 0)
-            hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, h->s_wbuf[si], wstride, h->d_tri, k0, w, nrow,
-                               DiagNext{linv, dval, stat, h->fuse_diag && k0 + w < F.nblk_e ? 1 : 0});
+            hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, h->s_wbuf[si], wstride, h->d_tri, k0, w, nrow);
     }
 }
 // the NR vectors of one kind out of NR workspaces (one workspace per right-hand side)
@@ -1349,7 +1480,7 @@ static void nd_factor_levels(gfs_handle* h) {
         for (int k0 = 0; k0 < kmax; k0 += WP) {                          // panel groups, as nd_factor_front does for one front
             for (int c = 0; c < WP && k0 + c < kmax; ++c) {
                 const int k = k0 + c, nk = L.nk[k], mni = L.max_ni[k];
-                if (k == 0 || !h->fuse_diag)
+                if (c == 0 || !h->fuse_diag)
                     hipLaunchKernelGGL(nd_diag_batch_kernel, dim3(nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_tri, h->band, h->linv, h->dval, h->stat, k);
                 if (mni <= 0) continue;
                 hipLaunchKernelGGL(nd_panel_batch_kernel, dim3(mni, nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off, h->d_tri, h->band, h->linv, h->dval,
@@ -1361,7 +1492,7 @@ static void nd_factor_levels(gfs_handle* h) {
             const int mni0 = L.max_ni[k0];                                // >= the trailing rows of every front of the group
             if (mni0 > 0)
                 hipLaunchKernelGGL(nd_update_wide_batch_kernel, dim3((unsigned)((long long)mni0 * (mni0 + 1) / 2), L.nk[k0]), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off,
-                                   h->d_fwofs + L.off, h->d_tri, h->band, h->bwbuf, k0, WP, DiagNext{h->linv, h->dval, h->stat, h->fuse_diag ? 1 : 0});
+                                   h->d_fwofs + L.off, h->d_tri, h->band, h->bwbuf, k0, WP);
         }
         for (int s = 0; s < used; ++s) { HIPCHK(hipEventRecord(h->ev[s], h->st[s])); HIPCHK(hipStreamWaitEvent(h->stream, h->ev[s], 0)); }
     }

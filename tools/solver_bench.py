@@ -25,12 +25,15 @@ for name, spec in cases:
     t = time.perf_counter(); S = _solver.DeviceSolver(D, coords=X, method=os.environ.get("GF_SOLVER_METHOD", "auto")); t_first = time.perf_counter() - t
     info = S.info()
     for _ in range(3): S.refactor(); S.solve(b)           # the library launches the first three sweeps of a kind directly and captures its HIP graph at the fourth
-    t = time.perf_counter(); S.refactor(); t_f = time.perf_counter() - t
+    tfs = []
+    for _ in range(int(os.environ.get("GF_SOLVER_REFACTOR_SAMPLES", "7"))):
+        t = time.perf_counter(); S.refactor(); tfs.append(time.perf_counter() - t)
+    t_f = float(np.median(tfs)); t_fmin = min(tfs)
     t = time.perf_counter(); x = S.solve(b); t_s = time.perf_counter() - t; rr, be = S.rel_residual, S.backward_error
     t = time.perf_counter(); lam = S.solve(g); t_a = time.perf_counter() - t; ra, bea = S.rel_residual, S.backward_error
-    fmt = ("%s [" + S.method + "]: %d dofs, half bandwidth %d, factor storage %.2f GB; device: ordering + first factorisation %.3f s, re-factorisation %.4f s (%.1f TFLOP/s), "
+    fmt = ("%s [" + S.method + "]: %d dofs, half bandwidth %d, factor storage %.2f GB; device: ordering + first factorisation %.3f s, re-factorisation %.4f s (median of %d; fastest %.4f s; %.1f TFLOP/s), "
            "Newton solve %.4f s (residual %.1e, backward error %.1e), adjoint solve %.4f s (residual %.1e, backward error %.1e)")
-    line = fmt % (name, A.ndof, info["half_bandwidth"], info["device_bytes"] / 1e9, t_first, t_f, info["factor_flops"] / t_f / 1e12, t_s, rr, be, t_a, ra, bea)
+    line = fmt % (name, A.ndof, info["half_bandwidth"], info["device_bytes"] / 1e9, t_first, t_f, len(tfs), t_fmin, info["factor_flops"] / t_f / 1e12, t_s, rr, be, t_a, ra, bea)
     # several right-hand sides in one call (gfs_solve_multi: the sweeps next to each other on their own streams in the nested-dissection mode)
     B3 = np.stack([g, b, np.random.default_rng(1).standard_normal(A.ndof)])
     for _ in range(4): S.solve_multi(B3)                                  # first calls: create the extra workspaces / graphs

@@ -5,7 +5,7 @@
 #include <random>
 namespace {
 __global__ __launch_bounds__(256) void diag_rows_kernel(double* band, double* linv, double* dval, const long long* rowoff, double* stat) { diag_body_rows(band, linv, dval, rowoff, (int)blockIdx.x, stat); }
-__global__ __launch_bounds__(256) void diag_blocked_kernel(double* band, double* linv, double* dval, const long long* rowoff, double* stat) { diag_body_blocked(band, linv, dval, rowoff, (int)blockIdx.x, stat); }
+__global__ __launch_bounds__(256) void diag_blocked_kernel(double* band, double* linv, double* dval, const long long* rowoff, double* stat) { GF_TILE_SMEM; diag_body_blocked(band, linv, dval, rowoff, (int)blockIdx.x, stat, smem); }
 }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main() {

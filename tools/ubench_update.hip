@@ -40,6 +40,32 @@ __global__ __launch_bounds__(256) void ub_kernel(double* __restrict__ band, cons
 }
 }
 
+namespace {
+template <int DMA>
+__global__ __launch_bounds__(256) void wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow) {
+    GF_TILE_SMEM;
+    int gi, gj; tri_index((int)blockIdx.x, gi, gj);
+    if (gi >= nrow) return;
+    if (DMA) update_wide_tile_dma<HK>(band, wbuf, wstride, rowoff, k0, w, gi, gj, smem);
+    else update_wide_tile(band, wbuf, wstride, rowoff, k0, w, gi, gj, smem);
+}
+// the DMA form with parts of HKT k and only its own LDS (4 x 64 x HKT doubles: HKT = 16 -> 32 KB, four workgroups per CU; 64 -> 128 KB, one)
+template <int HKT>
+__global__ __launch_bounds__(256) void wide_dma_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow) {
+    __shared__ __attribute__((aligned(16))) double smem[4 * NB * HKT];
+    int gi, gj; tri_index((int)blockIdx.x, gi, gj);
+    if (gi >= nrow) return;
+    update_wide_tile_dma<HKT>(band, wbuf, wstride, rowoff, k0, w, gi, gj, smem);
+}
+}
+namespace {
+__global__ void fill_kernel(double* p, size_t n, unsigned seed) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long x = (t + 1) * 0x9E3779B97F4A7C15ull + seed; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        p[t] = (double)(x & 0xFFFFF) / 524288.0 - 1.0;
+    }
+}
+}
 int main(int argc, char** argv) {
     const int nrow = argc > 1 ? atoi(argv[1]) : 150, w = argc > 2 ? atoi(argv[2]) : 8, reps = 10;
     const int nblk = nrow + w;
@@ -48,7 +74,8 @@ int main(int argc, char** argv) {
     const size_t ntiles = (size_t)tri[nblk] + nblk;
     double *band, *wbuf; long long* d_tri;
     hipMalloc(&band, ntiles * NB2 * sizeof(double)); hipMalloc(&wbuf, (size_t)w * nblk * NB2 * sizeof(double)); hipMalloc(&d_tri, tri.size() * sizeof(long long));
-    hipMemset(band, 0, ntiles * NB2 * sizeof(double)); hipMemset(wbuf, 0, (size_t)w * nblk * NB2 * sizeof(double));
+    // random operands (zero-filled ones read high: the matrix pipe draws less power on zeros)
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, band, ntiles * NB2, 1u); hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, wbuf, (size_t)w * nblk * NB2, 2u);
     hipMemcpy(d_tri, tri.data(), tri.size() * sizeof(long long), hipMemcpyHostToDevice);
     const unsigned grid = (unsigned)((long long)nrow * (nrow + 1) / 2);
     const double flop = (double)grid * w * 2.0 * 64 * 64 * 64;
@@ -60,6 +87,27 @@ int main(int argc, char** argv) {
         printf("%-60s %8.3f ms  %6.1f TFLOP/s\n", name, ms, flop / ms / 1e9);
     };
     printf("front: %d block rows behind a group of %d block columns, %u workgroups, %.2f Gflop per launch\n", nrow, w, grid, flop / 1e9);
+    {   // the forms of the update on the same operands (products and sums of these 20-bit values are exact in FP64: any difference is an indexing error)
+        std::vector<double> r0(ntiles * NB2), r1(ntiles * NB2);
+        hipLaunchKernelGGL(wide_kernel<0>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); hipMemcpy(r0.data(), band, r0.size() * 8, hipMemcpyDeviceToHost);
+        auto check = [&](const char* name, auto launch) {
+            hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, band, ntiles * NB2, 1u);
+            launch(); hipMemcpy(r1.data(), band, r1.size() * 8, hipMemcpyDeviceToHost);
+            double e = 0, m = 0; for (size_t q = 0; q < r0.size(); ++q) { e = std::max(e, std::fabs(r0[q] - r1[q])); m = std::max(m, std::fabs(r0[q])); }
+            printf("register-staged against %s: max difference %.2e of %.2e (%s)\n", name, e, m, e <= 1e-12 * m ? "ok" : "MISMATCH");
+        };
+        check("LDS-DMA, parts of 32 k (library form)", [&] { hipLaunchKernelGGL(wide_kernel<1>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
+        check("LDS-DMA, parts of 16 k", [&] { hipLaunchKernelGGL(wide_dma_kernel<16>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
+        check("LDS-DMA, parts of 8 k", [&] { hipLaunchKernelGGL(wide_dma_kernel<8>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
+        check("LDS-DMA, whole tiles", [&] { hipLaunchKernelGGL(wide_dma_kernel<64>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
+        hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, band, ntiles * NB2, 1u);
+    }
+    time("V0r update_wide_tile through registers", [&] { hipLaunchKernelGGL(wide_kernel<0>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
+    time("V4 update_wide_tile_dma (LDS-DMA, half stages, one barrier per stage)", [&] { hipLaunchKernelGGL(wide_kernel<1>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
+    time("V5 LDS-DMA, parts of 16 k, 32 KB of LDS (four workgroups per CU)", [&] { hipLaunchKernelGGL(wide_dma_kernel<16>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
+    time("V5b LDS-DMA, parts of 8 k, 16 KB of LDS (eight workgroups per CU)", [&] { hipLaunchKernelGGL(wide_dma_kernel<8>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
+    time("V6 LDS-DMA, parts of 32 k, 64 KB of LDS (two workgroups per CU)", [&] { hipLaunchKernelGGL(wide_dma_kernel<32>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
+    time("V7 LDS-DMA, whole tiles, 128 KB of LDS (one workgroup per CU)", [&] { hipLaunchKernelGGL(wide_dma_kernel<64>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
     time("V0 update_wide_kernel (library)", [&] { hipLaunchKernelGGL(update_wide_kernel, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
     time("V1 no operand loads in the loop", [&] { hipLaunchKernelGGL(ub_kernel<1>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
     time("V2 no parking, no barriers (MFMA + LDS operand reads)", [&] { hipLaunchKernelGGL(ub_kernel<2>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
