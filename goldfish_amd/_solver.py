@@ -14,7 +14,7 @@ from scipy.sparse.csgraph import reverse_cuthill_mckee
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GF_SOLVER_LIB", os.path.join(_HERE, "libgoldfish_solver.so"))   # GF_SOLVER_LIB: A/B builds while tuning
-EXPORTS = ["gfs_last_error", "gfs_create", "gfs_create_nd", "gfs_destroy", "gfs_refactor", "gfs_solve", "gfs_solve_dev", "gfs_set_general", "gfs_solve_transposed",
+EXPORTS = ["gfs_last_error", "gfs_create", "gfs_create_nd", "gfs_destroy", "gfs_refactor", "gfs_prepare_refactor", "gfs_solve", "gfs_solve_dev", "gfs_set_general", "gfs_solve_transposed",
            "gfs_solve_transposed_dev", "gfs_info", "gfs_solve_multi", "gfs_solve_multi_dev", "gfs_create_nd_partial", "gfs_schur_doubles", "gfs_export_schur",
            "gfs_set_schur_source", "gfs_get_fbnd", "gfs_set_fbnd", "gfs_get_fbnd_packed", "gfs_set_fbnd_packed", "gfs_set_row_mask", "gfs_x_ptr", "gfs_forward_dev", "gfs_backward_dev", "gfs_symbolic_create", "gfs_symbolic_sizes",
            "gfs_symbolic_copy", "gfs_symbolic_destroy"]
@@ -36,6 +36,7 @@ def lib():
         L.gfs_destroy.argtypes = [vp]
         L.gfs_destroy.restype = None
         L.gfs_refactor.argtypes = [vp]
+        L.gfs_prepare_refactor.argtypes = [vp]
         L.gfs_solve.argtypes = [vp, dp, dp, C.c_int, dp]
         L.gfs_solve_dev.argtypes = [vp, vp, vp, C.c_int, dp]
         L.gfs_set_general.argtypes = [vp, C.c_int]
@@ -175,6 +176,12 @@ class DeviceSolver:
             self.h = None
 
     __del__ = close
+
+    def prepare(self):
+        """The factors at hand will not be used again and a new K is about to be assembled: start clearing the factor storage now (gfs_prepare_refactor: 11.5 ms of
+        HBM writes at C4 that run under the assembly pass instead of in front of the factorisation)."""
+        if lib().gfs_prepare_refactor(self.h):
+            raise RuntimeError(lib().gfs_last_error().decode())
 
     def refactor(self):
         """Numeric factorisation of the values of K currently on the device (after a new assembly)."""

@@ -624,6 +624,14 @@ __global__ __launch_bounds__(256) void update_narrow_kernel(double* __restrict__
     GF_UPDATE_TILE(band, wbuf, rowoff, k, (int)blockIdx.x, (int)blockIdx.y, smem);
     if (dn.on && blockIdx.x == 0 && blockIdx.y == 0) diag_next(band, rowoff, k + 1, dn, smem);       // tile (k + 1, k + 1): block column k was its last update inside the panel group
 }
+// the same update restricted to the first ncol trailing block columns (blockIdx = (row gi, column gj < ncol)): before a SUB-GROUP of a panel group starts, its columns
+// receive the products of all earlier panels of the group in one read-modify-write; the narrow updates then stay inside the sub-group.  A tile of the group's j-th column
+// is rewritten 1 + (j mod 4) times instead of j times (groups of 8, sub-groups of 4): the narrow updates are bound by exactly that traffic.
+__global__ __launch_bounds__(256) GF_WIDE_ATTR void update_mid_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w) {
+    GF_WIDE_SMEM;
+    if (blockIdx.x < blockIdx.y) return;
+    GF_UPDATE_WIDE_TILE(band, wbuf, wstride, rowoff, k0, w, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
 __global__ __launch_bounds__(256) GF_WIDE_ATTR void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow) {
     GF_WIDE_SMEM;
     int gi, gj; tri_index((int)blockIdx.x, gi, gj);
@@ -1001,10 +1009,10 @@ __global__ __launch_bounds__(256) void nd_panel_batch_kernel(const Front* __rest
 // block column k updates the remaining columns of its panel group (k0 .. k0 + w - 1, w = min(WP, nblk_e - k0) per front): blockIdx = (row gi, column gj, front)
 __global__ __launch_bounds__(256) void nd_update_narrow_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs,
                                                                      const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k, int k0, int WP,
-                                                                     DiagNext dn) {
+                                                                     int send, DiagNext dn) {       // send: end of the sub-group of k, relative to k0
     GF_NARROW_SMEM;
     const Front F = fronts[list[blockIdx.z]];
-    const int ni = F.nblk_t - 1 - k, w = min(WP, F.nblk_e - k0), nin = k0 + w - 1 - k;
+    const int ni = F.nblk_t - 1 - k, w = min(min(WP, F.nblk_e - k0), send), nin = k0 + w - 1 - k;
     if ((int)blockIdx.x >= ni || (int)blockIdx.y >= nin || blockIdx.x < blockIdx.y) return;
     double* band = arena + (size_t)F.tile_off * NB2;
     GF_UPDATE_TILE(band, wbuf + (size_t)(wofs[blockIdx.z] + (long long)(k - k0) * (F.nblk_t - 1)) * NB2, tri, k, (int)blockIdx.x, (int)blockIdx.y, smem);
@@ -1013,6 +1021,15 @@ __global__ __launch_bounds__(256) void nd_update_narrow_batch_kernel(const Front
 }
 // trailing update behind the panel group that starts at k0, all its block columns at once (update_wide_tile): one read-modify-write of a target tile per group
 // instead of per column -- the single-column batched update was HBM bound (64 KB per 64^3 product: 143 of the 406 ms of a C4 factorisation)
+// sub-group start inside the panel group at k0 (update_mid_kernel): wprev panels are done, the next ncol block columns get their products; blockIdx = (row gi, column gj, front)
+__global__ __launch_bounds__(256) GF_WIDE_ATTR void nd_update_mid_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs,
+                                                                               const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k0, int wprev, int ncol, int WP) {
+    GF_WIDE_SMEM;
+    const Front F = fronts[list[blockIdx.z]];
+    const int w = min(WP, F.nblk_e - k0), nc = min(ncol, w - wprev), nrow = F.nblk_t - (k0 + wprev);
+    if ((int)blockIdx.y >= nc || (int)blockIdx.x >= nrow || blockIdx.x < blockIdx.y) return;
+    GF_UPDATE_WIDE_TILE(arena + (size_t)F.tile_off * NB2, wbuf + (size_t)wofs[blockIdx.z] * NB2, F.nblk_t - 1, tri, k0, wprev, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
 __global__ __launch_bounds__(256) GF_WIDE_ATTR void nd_update_wide_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs,
                                                                    const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k0, int WP) {
     GF_WIDE_SMEM;
@@ -1313,7 +1330,7 @@ struct gfs_handle {
     // independent subtrees run on their own streams (their fronts are small: a single stream leaves the device idle); the fronts above
     // them ("top") follow on the main stream.  Per stream: W tiles of a panel, front-local vectors
     static constexpr int NS = 8;
-    hipStream_t st[NS] = {}; hipEvent_t ev[NS] = {}, ev_main = nullptr;
+    hipStream_t st[NS] = {}; hipEvent_t ev[NS] = {}, ev_main = nullptr, ev_norm = nullptr; double* part_k = nullptr;
     double *s_wbuf[NS + 1] = {}, *s_b[NS + 1] = {}, *s_y[NS + 1] = {}, *s_z[NS + 1] = {}, *s_x[NS + 1] = {};
     std::vector<std::vector<int>> sub;       // sub[s]: fronts of the subtrees assigned to stream s, in post-order
     std::vector<int> top;                    // the remaining fronts, in post-order
@@ -1340,6 +1357,8 @@ struct gfs_handle {
     static constexpr int MAX_RHS = 8;
     std::vector<SolveWs> ws; long long ws_front_len = 0, ws_bnd_len = 0;
     unsigned char* d_row_ok = nullptr;            // gfs_set_row_mask: rows of d_valK that hold values (a rank's own rows of a sharded K); nullptr = all
+    bool prepared = false;                        // gfs_prepare_refactor has cleared the factor storage for the next gfs_refactor
+    int subgroup = 4;                             // GF_SOLVER_SUBGROUP: block columns per sub-group of a panel group (0: none)
     bool fuse_diag = true;                        // GF_SOLVER_FUSE_DIAG=0: every diagonal tile in a launch of its own (the chain before round 5)
     bool lds_raised[3] = {false, false, false};   // hipFuncAttributeMaxDynamicSharedMemorySize of the NR-right-hand-side sweep kernels raised on this handle's device
     template <class Tp> Tp* dalloc(size_t cnt) {
@@ -1380,9 +1399,13 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
     bool have_diag = false;
     for (int k0 = 0; k0 < F.nblk_e; k0 += WP) {                       // groups of WP block columns: one wide trailing update per group
         const int w = std::min(WP, F.nblk_e - k0);
+        const int SG = h->subgroup > 0 ? h->subgroup : WP;
         for (int c = 0; c < w; ++c) {
-            const int k = k0 + c, ni = F.nblk_t - 1 - k, nin = k0 + w - 1 - k;
+            const int send = std::min((c / SG + 1) * SG, w);              // the sub-group of column c ends here (relative to k0)
+            const int k = k0 + c, ni = F.nblk_t - 1 - k, nin = k0 + send - 1 - k;
             double* wb = h->s_wbuf[si] + (size_t)c * wstride * NB2;
+            if (c > 0 && c % SG == 0)                                     // a sub-group starts: its columns get the products of the group's earlier panels in one pass
+                hipLaunchKernelGGL(update_mid_kernel, dim3(F.nblk_t - k, send - c), dim3(256), 0, st, band, h->s_wbuf[si], wstride, h->d_tri, k0, c);
             // inside a panel group the diagonal tile of a block column has been factored by the workgroup that applied its last update (DiagNext); the group's first
             // column gets a launch (the wide update stays small: 32 KB of LDS, four workgroups per CU)
             if (!have_diag) hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, st, band, linv, dval, h->d_tri, k, stat);
@@ -1478,16 +1501,20 @@ static void nd_factor_levels(gfs_handle* h) {
         }
         const int WP = std::max(h->batch_panel_w, 1), kmax = (int)L.nk.size();
         for (int k0 = 0; k0 < kmax; k0 += WP) {                          // panel groups, as nd_factor_front does for one front
+            const int SG = h->subgroup > 0 ? h->subgroup : WP;
             for (int c = 0; c < WP && k0 + c < kmax; ++c) {
                 const int k = k0 + c, nk = L.nk[k], mni = L.max_ni[k];
-                if (c == 0 || !h->fuse_diag)
+                if (c > 0 && c % SG == 0)                                // a sub-group starts (nd_factor_front)
+                    hipLaunchKernelGGL(nd_update_mid_batch_kernel, dim3(mni + 1, std::min(SG, WP - c), nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off,
+                                       h->d_tri, h->band, h->bwbuf, k0, c, SG, WP);
+                if (c % SG == 0 || !h->fuse_diag)
                     hipLaunchKernelGGL(nd_diag_batch_kernel, dim3(nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_tri, h->band, h->linv, h->dval, h->stat, k);
                 if (mni <= 0) continue;
                 hipLaunchKernelGGL(nd_panel_batch_kernel, dim3(mni, nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off, h->d_tri, h->band, h->linv, h->dval,
                                    h->bwbuf, k, c);
-                if (c + 1 < WP)
-                    hipLaunchKernelGGL(nd_update_narrow_batch_kernel, dim3(mni, WP - 1 - c, nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off, h->d_tri,
-                                       h->band, h->bwbuf, k, k0, WP, DiagNext{h->linv, h->dval, h->stat, h->fuse_diag ? 1 : 0});
+                if (c + 1 < WP && (c + 1) % SG != 0)
+                    hipLaunchKernelGGL(nd_update_narrow_batch_kernel, dim3(mni, std::min(SG - 1 - c % SG, WP - 1 - c), nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off,
+                                       h->d_fwofs + L.off, h->d_tri, h->band, h->bwbuf, k, k0, WP, (c / SG + 1) * SG, DiagNext{h->linv, h->dval, h->stat, h->fuse_diag ? 1 : 0});
             }
             const int mni0 = L.max_ni[k0];                                // >= the trailing rows of every front of the group
             if (mni0 > 0)
@@ -1764,6 +1791,7 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
         h->dval = h->dalloc<double>((size_t)kb * NB); h->stat = h->dalloc<double>((size_t)2 * kb);
         if (const char* e = std::getenv("GF_SOLVER_PANEL_W")) h->panel_w = h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));
         if (const char* e = std::getenv("GF_SOLVER_FUSE_DIAG")) h->fuse_diag = std::atoi(e) != 0;
+        if (const char* e = std::getenv("GF_SOLVER_SUBGROUP")) h->subgroup = std::max(0, std::min(8, std::atoi(e)));
         if (const char* e = std::getenv("GF_SOLVER_BATCH_PANEL_W")) h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));      // panel groups of the level-batched small fronts
         {   // independent subtrees for the side streams: split the largest subtree (by factorisation work) until there are enough of them
             constexpr int NS = gfs_handle::NS;
@@ -1798,6 +1826,7 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
             for (int64_t t = 0; t < nfronts; ++t) if (is_top[t]) h->top.push_back((int)t);
             for (int s_ = 0; s_ < NS; ++s_) { HIPCHK(hipStreamCreate(&h->st[s_])); HIPCHK(hipEventCreateWithFlags(&h->ev[s_], hipEventDisableTiming)); }
             HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_norm, hipEventDisableTiming)); h->part_k = h->dalloc<double>(256);
             const size_t fl_ = (size_t)maxb * NB;
             h->ws_front_len = (long long)fl_;
             for (int s_ = 0; s_ <= NS; ++s_) {
@@ -1892,6 +1921,7 @@ void gfs_destroy(gfs_handle* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (int s_ = 0; s_ < gfs_handle::NS; ++s_) { if (h->ev[s_]) (void)hipEventDestroy(h->ev[s_]); if (h->st[s_]) (void)hipStreamDestroy(h->st[s_]); }
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+    if (h->ev_norm) (void)hipEventDestroy(h->ev_norm);
     if (h->g_factor) (void)hipGraphExecDestroy(h->g_factor);
     if (h->g_solve) (void)hipGraphExecDestroy(h->g_solve);
     if (h->g_fwd) (void)hipGraphExecDestroy(h->g_fwd);
@@ -1901,12 +1931,31 @@ void gfs_destroy(gfs_handle* h) {
     delete h;
 }
 
+int gfs_prepare_refactor(gfs_handle* h) {
+    if (!h) return sfail("gfs_prepare_refactor: null handle");
+    try {
+        HIPCHK(hipSetDevice(h->device));
+        h->factored = false;
+        HIPCHK(hipMemsetAsync(h->band, 0, (size_t)h->ntiles * NB2 * sizeof(double), h->stream));
+        h->prepared = true;
+    } catch (const std::exception& ex) { return sfail(ex.what()); }
+    return 0;
+}
 int gfs_refactor(gfs_handle* h) {
     if (!h) return sfail("gfs_refactor: null handle");
     try {
         HIPCHK(hipSetDevice(h->device));
         h->factored = false;
-        HIPCHK(hipMemsetAsync(h->band, 0, (size_t)h->ntiles * NB2 * sizeof(double), h->stream));
+        // |K|_F (the backward errors' denominator) reads K's 9 nnz doubles once: on a side stream under the factorisation instead of behind it (2.1 ms at C4)
+        const bool norm_aside = h->nd && h->st[0] && h->ev_norm && h->part_k;
+        if (norm_aside) {
+            HIPCHK(hipEventRecord(h->ev_norm, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->st[0], h->ev_norm, 0));
+            hipLaunchKernelGGL(sumsq_kernel, dim3(240), dim3(256), 0, h->st[0], h->nnz9, h->valK, h->part_k);
+            HIPCHK(hipEventRecord(h->ev_norm, h->st[0]));
+        }
+        if (!h->prepared) HIPCHK(hipMemsetAsync(h->band, 0, (size_t)h->ntiles * NB2 * sizeof(double), h->stream));
+        h->prepared = false;
         if (h->nd) {
             hipLaunchKernelGGL(nd_scatter_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->general ? h->d_rev : nullptr, h->valK, h->d_fronts, h->d_front_of, h->d_order,
                                h->d_bnd, h->d_tri, h->band, h->d_row_ok);
@@ -1936,13 +1985,19 @@ int gfs_refactor(gfs_handle* h) {
         HIPCHK(hipGetLastError());
         const long long ncol = h->nd ? h->nbe_tot : h->nblk;
         std::vector<double> st(2 * ncol);
+        double pk[240];
         HIPCHK(hipMemcpyAsync(st.data(), h->stat, st.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (norm_aside) {
+            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_norm, 0));
+            HIPCHK(hipMemcpyAsync(pk, h->part_k, sizeof(pk), hipMemcpyDeviceToHost, h->stream));
+        }
         HIPCHK(hipStreamSynchronize(h->stream));
         double mn = 1e300, mx = 0.0;
         for (long long k = 0; k < ncol; ++k) { mn = std::min(mn, st[2 * k]); mx = std::max(mx, st[2 * k + 1]); }
         if (!(mn == mn) || !(mx == mx) || !std::isfinite(mx) || mn == 0.0) throw std::runtime_error("gfs_refactor: zero or non-finite pivot (K is singular for this ordering without pivoting)");
         h->small_pivot = mn < 1e-14 * mx;
-        h->normK = norm2(h, h->valK, h->nnz9);
+        if (norm_aside) { long double a = 0; for (int q = 0; q < 240; ++q) a += pk[q]; h->normK = std::sqrt((double)a); }      // the same partial sums in the same order as norm2
+        else h->normK = norm2(h, h->valK, h->nnz9);
         h->factored = true;
     } catch (const std::exception& ex) { return sfail(ex.what()); }
     return 0;

@@ -41,6 +41,11 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
 void gfs_destroy(gfs_handle* h);
 /* numeric factorisation of the values currently in d_valK */
 int gfs_refactor(gfs_handle* h);
+/* Optional, before a gfs_refactor: start clearing the factor storage now (asynchronously, on the handle's stream; C4: 57 GB, 11.5 ms of pure HBM writes, 5 % of a
+ * factorisation).  The factors at hand are gone from this call on.  The caller that knows a new K is coming -- the Newton loop, right after the solve that used the
+ * old factors (reference: GOLDFISH/operations/disp_imop.py:38-44, utils/opt_utils.py:156-209: a factorisation per step) -- calls it BEFORE it launches the assembly
+ * pass, which is bound by the FP64 pipe and leaves the memory system idle: the clearing then costs nothing.  gfs_refactor skips its own clearing once. */
+int gfs_prepare_refactor(gfs_handle* h);
 /* x = K^{-1} b with the current factors and up to max_refine steps of iterative refinement (stops when the residual no longer
  * decreases); b, x: 3 * ncp doubles, host pointers (gfs_solve) or device pointers (gfs_solve_dev).
  * rel_residual (may be NULL): |b - K x| / |b| of the returned solution (2-norm). */

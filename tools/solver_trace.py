@@ -13,6 +13,8 @@ i1 = next((i for i in range(i0, len(rows)) if rows[i][2].startswith(("nd_fwd_fro
 F = rows[i0:i1]
 t0, t1 = F[0][0], max(r[1] for r in F)
 print("factorisation: %d launches, wall %.1f ms" % (len(F), (t1 - t0) / 1e6))
+pre = [r for r in rows[max(0, i0 - 6):i0] if "fillBuffer" in r[2] or "sumsq" in r[2]]
+if pre: print("in front of it: " + ", ".join("%s %.2f ms" % (r[2][:40], (r[1] - r[0]) / 1e6) for r in pre) + "; from the start of the first of them to the scatter kernel %.2f ms" % ((t0 - pre[0][0]) / 1e6))
 ev = []
 for s, e, n, _ in F:
     ev.append((s, 1, n)); ev.append((e, -1, n))
