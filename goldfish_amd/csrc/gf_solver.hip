@@ -1363,11 +1363,15 @@ struct gfs_handle {
     // substitution workspaces: [0] aliases the handle's own buffers and stream; [1 ..] are created by the first multi-right-hand-side solve, one stream each, so
     // that the sweeps of several right-hand sides (latency-bound chains of small launches) run next to each other (gfs_solve_multi)
     struct SolveWs { hipStream_t stream = nullptr; double *gb = nullptr, *gy = nullptr, *gx = nullptr, *fbnd = nullptr, *sb = nullptr, *sy = nullptr, *sz = nullptr, *sx = nullptr,
-                     *vr = nullptr, *vsol = nullptr, *vrhs = nullptr, *part = nullptr; hipGraphExec_t g_solve[3] = {nullptr, nullptr, nullptr}; };
+                     *vr = nullptr, *vsol = nullptr, *vrhs = nullptr, *part = nullptr; hipGraphExec_t g_solve[3] = {nullptr, nullptr, nullptr};
+                     // round 5: the large fronts of one tree height run side by side on the handle's side streams -- front-local vectors per side stream, fork / join events
+                     double* big = nullptr; long long big_len = 0; hipEvent_t ev_fork = nullptr, ev_join[8] = {};
+                     double* scratch(int set, int which) const { return set < 0 ? (which == 0 ? sb : which == 1 ? sy : which == 2 ? sz : sx) : big + (size_t)(4 * set + which) * (size_t)big_len; } };
     static constexpr int RHS_BLOCK = 3;      // right-hand sides per pass over the factors (the front-local vectors of the small fronts sit in LDS: 3 x 48 KB)
     static constexpr int MAX_RHS = 8;
     std::vector<SolveWs> ws; long long ws_front_len = 0, ws_bnd_len = 0;
     unsigned char* d_row_ok = nullptr;            // gfs_set_row_mask: rows of d_valK that hold values (a rank's own rows of a sharded K); nullptr = all
+    bool sweep_streams = true;                    // GF_SOLVER_SWEEP_STREAMS=0: the large fronts of a substitution one after the other on the sweep's stream
     bool prepared = false;                        // gfs_prepare_refactor has cleared the factor storage for the next gfs_refactor
     int fuse_max_fronts = 2;                      // GF_SOLVER_FUSE_MAXF: tree heights with more large fronts than this run the lean narrow update + diagonal-tile launches
     int subgroup = 4;                             // GF_SOLVER_SUBGROUP: block columns per sub-group of a panel group (0: none)
@@ -1468,13 +1472,13 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
 }
 // the NR vectors of one kind out of NR workspaces (one workspace per right-hand side)
 #define GF_VEC(member) ([&] { Vec<NR> v_; for (int j_ = 0; j_ < NR; ++j_) v_.p[j_] = W[j_]->member; return v_; }())
-template <int NR> static void nd_forward_front(gfs_handle* h, int t, const gfs_handle::SolveWs* const (&W)[NR]) {
+#define GF_VECS(which) ([&] { Vec<NR> v_; for (int j_ = 0; j_ < NR; ++j_) v_.p[j_] = W[j_]->scratch(set, which); return v_; }())
+template <int NR> static void nd_forward_front(gfs_handle* h, int t, const gfs_handle::SolveWs* const (&W)[NR], hipStream_t st, int set) {
     const Front& F = h->fronts[t];
     if (F.ne_cp == 0) return;                                       // stub front of a partial handle
-    hipStream_t st = W[0]->stream;
     const double* band = h->band + (size_t)F.tile_off * NB2;
     const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
-    const Vec<NR> gb = GF_VEC(gb), gy = GF_VEC(gy), fbnd = GF_VEC(fbnd), sb = GF_VEC(sb), sy = GF_VEC(sy);
+    const Vec<NR> gb = GF_VEC(gb), gy = GF_VEC(gy), fbnd = GF_VEC(fbnd), sb = GF_VECS(0), sy = GF_VECS(1);
     hipLaunchKernelGGL(nd_gather_rhs_kernel<NR>, dim3(gl), dim3(256), 0, st, F, h->d_elim, gb, sb);
     for (int c : h->kids[t]) {
         const Front& Fc = h->fronts[c];
@@ -1486,13 +1490,12 @@ template <int NR> static void nd_forward_front(gfs_handle* h, int t, const gfs_h
     }
     hipLaunchKernelGGL(nd_scatter_fwd_kernel<NR>, dim3(gl), dim3(256), 0, st, F, h->d_elim, sy, sb, gy, fbnd);
 }
-template <int NR> static void nd_backward_front(gfs_handle* h, int t, const gfs_handle::SolveWs* const (&W)[NR]) {
+template <int NR> static void nd_backward_front(gfs_handle* h, int t, const gfs_handle::SolveWs* const (&W)[NR], hipStream_t st, int set) {
     const Front& F = h->fronts[t];
     if (F.ne_cp == 0) return;
-    hipStream_t st = W[0]->stream;
     const double* band = h->band + (size_t)F.tile_off * NB2;
     const unsigned gl = (unsigned)((64 * F.nblk_t + 255) / 256);
-    const Vec<NR> gy = GF_VEC(gy), gx = GF_VEC(gx), sz = GF_VEC(sz), sx = GF_VEC(sx);
+    const Vec<NR> gy = GF_VEC(gy), gx = GF_VEC(gx), sz = GF_VECS(2), sx = GF_VECS(3);
     hipLaunchKernelGGL(nd_gather_bwd_kernel<NR>, dim3(gl), dim3(256), 0, st, F, h->d_elim, h->d_bnd, gy, gx, h->dval, sz, sx);
     if (F.nblk_t > F.nblk_e && F.nblk_e > 0)
         hipLaunchKernelGGL(nd_bwd_bnd_kernel<NR>, dim3(F.nblk_e), dim3(256), 0, st, band, h->d_tri, F.nblk_e, F.nblk_t, sx, sz);
@@ -1601,24 +1604,50 @@ template <class Body> static void nd_run_captured(gfs_handle* h, hipGraphExec_t*
     }
     HIPCHK(hipGraphLaunch(*exec, cs));
 }
+// the large fronts of one tree height (independent of each other): side by side on the handle's side streams, each with the front-local vectors of its stream, forked
+// from and joined to the sweep's stream (round 5: their group kernels are chains of dependent 20 us launches -- 16.3 of a sweep's 37 ms at C4 ran one after the other)
+// returns the number of side streams to join (nd_big_join, behind whatever the caller runs on st beside them: the small fronts of the same height)
+template <int NR> static int nd_big_fronts(gfs_handle* h, const std::vector<int>& big, const gfs_handle::SolveWs* const (&W)[NR], hipStream_t st, bool backward) {
+    constexpr int NS = gfs_handle::NS;
+    const int nb = (int)big.size();
+    const bool side = h->sweep_streams && nb >= 2 && W[0]->ev_fork && h->st[0];
+    for (int j = 0; side && j < NR; ++j) if (!W[j]->big) throw std::runtime_error("substitution workspace without side-stream vectors");
+    if (!side) {
+        for (int i = 0; i < nb; ++i) { const int t = backward ? big[nb - 1 - i] : big[i]; if (backward) nd_backward_front<NR>(h, t, W, st, -1); else nd_forward_front<NR>(h, t, W, st, -1); }
+        return 0;
+    }
+    const int used = std::min(NS, nb);
+    HIPCHK(hipEventRecord(W[0]->ev_fork, st));
+    for (int s = 0; s < used; ++s) HIPCHK(hipStreamWaitEvent(h->st[s], W[0]->ev_fork, 0));
+    for (int i = 0; i < nb; ++i) {
+        const int t = backward ? big[nb - 1 - i] : big[i], s = i % NS;
+        if (backward) nd_backward_front<NR>(h, t, W, h->st[s], s); else nd_forward_front<NR>(h, t, W, h->st[s], s);
+    }
+    return used;
+}
+static void nd_big_join(gfs_handle* h, const gfs_handle::SolveWs* W0, hipStream_t st, int used) {
+    for (int s = 0; s < used; ++s) { HIPCHK(hipEventRecord(W0->ev_join[s], h->st[s])); HIPCHK(hipStreamWaitEvent(st, W0->ev_join[s], 0)); }
+}
 // the two halves of a substitution: forward over the tree heights ascending, backward descending (W: one workspace per right-hand side, st: the stream)
 template <int NR> static void nd_forward_all(gfs_handle* h, const gfs_handle::SolveWs* const (&W)[NR], hipStream_t st) {
     const Vec<NR> gb = GF_VEC(gb), gy = GF_VEC(gy), fbnd = GF_VEC(fbnd);
     for (const auto& L : h->levels) {
+        const int used = nd_big_fronts<NR>(h, L.big, W, st, false);
         if (L.n_small > 0)
             hipLaunchKernelGGL(nd_fwd_front_kernel<NR>, dim3(L.n_small), dim3(256), (size_t)NR * (64 * L.max_blk + 64) * sizeof(double), st, h->d_fronts, h->d_lvl_list + L.off_small,
                                h->d_kid_off, h->d_kid, h->d_tri, h->band, h->linv, h->d_elim, h->d_pmap, gb, gy, fbnd);
-        for (int t : L.big) nd_forward_front<NR>(h, t, W);
+        nd_big_join(h, W[0], st, used);
     }
 }
 template <int NR> static void nd_backward_all(gfs_handle* h, const gfs_handle::SolveWs* const (&W)[NR], hipStream_t st) {
     const Vec<NR> gy = GF_VEC(gy), gx = GF_VEC(gx);
     for (auto it = h->levels.rbegin(); it != h->levels.rend(); ++it) {
         const auto& L = *it;
-        for (auto b_ = L.big.rbegin(); b_ != L.big.rend(); ++b_) nd_backward_front<NR>(h, *b_, W);
+        const int used = nd_big_fronts<NR>(h, L.big, W, st, true);
         if (L.n_small > 0)
             hipLaunchKernelGGL(nd_bwd_front_kernel<NR>, dim3(L.n_small), dim3(256), (size_t)NR * (64 * L.max_blk + 4 * 64) * sizeof(double), st, h->d_fronts, h->d_lvl_list + L.off_small,
                                h->d_tri, h->band, h->linv, h->dval, h->d_elim, h->d_bnd, gy, gx);
+        nd_big_join(h, W[0], st, used);
     }
 }
 // multifrontal substitutions of NR right-hand sides in one pass over the factors; vectors in the original numbering.  Workspace W[j] holds right-hand side j's vectors;
@@ -1646,11 +1675,19 @@ template <int NR> static void substitute_nd(gfs_handle* h, gfs_handle::SolveWs* 
     HIPCHK(hipGetLastError());
 }
 #undef GF_VEC
+#undef GF_VECS
 static void substitute_nd(gfs_handle* h, gfs_handle::SolveWs& W, const double* rhs, double* x, int add) {
     gfs_handle::SolveWs* const Wm[1] = {&W}; const double* const r[1] = {rhs}; double* const xx[1] = {x};
     substitute_nd<1>(h, Wm, r, xx, add);
 }
 
+// front-local vectors per side stream and the fork / join events of a workspace (nested-dissection handles)
+static void solve_ws_side(gfs_handle* h, gfs_handle::SolveWs& W) {
+    if (!h->nd || !h->st[0] || h->ws_front_len <= 0) return;
+    W.big_len = h->ws_front_len; W.big = h->dalloc<double>((size_t)4 * gfs_handle::NS * (size_t)W.big_len);
+    HIPCHK(hipEventCreateWithFlags(&W.ev_fork, hipEventDisableTiming));
+    for (int s = 0; s < gfs_handle::NS; ++s) HIPCHK(hipEventCreateWithFlags(&W.ev_join[s], hipEventDisableTiming));
+}
 // workspace k of the handle: 0 aliases the handle's own vectors and stream, the others are allocated on first use (nested-dissection mode only)
 static gfs_handle::SolveWs& solve_ws(gfs_handle* h, int k) {
     constexpr int NS = gfs_handle::NS;
@@ -1659,6 +1696,7 @@ static gfs_handle::SolveWs& solve_ws(gfs_handle* h, int k) {
         gfs_handle::SolveWs W;
         W.stream = h->stream; W.gb = h->gb; W.gy = h->gy; W.gx = h->gx; W.fbnd = h->fbnd; W.sb = h->s_b[NS]; W.sy = h->s_y[NS]; W.sz = h->s_z[NS]; W.sx = h->s_x[NS];
         W.vr = h->vr; W.vsol = h->vsol; W.vrhs = h->vrhs; W.part = h->part;
+        solve_ws_side(h, W);
         h->ws.push_back(W);
     }
     while ((int)h->ws.size() <= k) {
@@ -1671,6 +1709,7 @@ static gfs_handle::SolveWs& solve_ws(gfs_handle* h, int k) {
         W.vr = h->dalloc<double>(h->n); W.vsol = h->dalloc<double>(h->n); W.vrhs = h->dalloc<double>(h->n); W.part = h->dalloc<double>(256);
         HIPCHK(hipMemsetAsync(W.gy, 0, h->n * sizeof(double), W.stream)); HIPCHK(hipMemsetAsync(W.gx, 0, h->n * sizeof(double), W.stream));
         HIPCHK(hipStreamSynchronize(W.stream));
+        solve_ws_side(h, W);
         h->ws.push_back(W);
     }
     return h->ws[k];
@@ -1841,6 +1880,7 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
         if (const char* e = std::getenv("GF_SOLVER_PANEL_W")) h->panel_w = h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));
         if (const char* e = std::getenv("GF_SOLVER_FUSE_DIAG")) h->fuse_diag = std::atoi(e) != 0;
         if (const char* e = std::getenv("GF_SOLVER_SUBGROUP")) h->subgroup = std::max(0, std::min(8, std::atoi(e)));
+        if (const char* e = std::getenv("GF_SOLVER_SWEEP_STREAMS")) h->sweep_streams = std::atoi(e) != 0;
         if (const char* e = std::getenv("GF_SOLVER_FUSE_MAXF")) h->fuse_max_fronts = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("GF_SOLVER_BATCH_PANEL_W")) h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));      // panel groups of the level-batched small fronts
         {   // independent subtrees for the side streams: split the largest subtree (by factorisation work) until there are enough of them
@@ -1986,7 +2026,12 @@ void gfs_destroy(gfs_handle* h) {
     if (h->g_solve) (void)hipGraphExecDestroy(h->g_solve);
     if (h->g_fwd) (void)hipGraphExecDestroy(h->g_fwd);
     if (h->g_bwd) (void)hipGraphExecDestroy(h->g_bwd);
-    for (size_t k = 0; k < h->ws.size(); ++k) { for (auto& g : h->ws[k].g_solve) if (g) (void)hipGraphExecDestroy(g); if (k > 0 && h->ws[k].stream) (void)hipStreamDestroy(h->ws[k].stream); }
+    for (size_t k = 0; k < h->ws.size(); ++k) {
+        for (auto& g : h->ws[k].g_solve) if (g) (void)hipGraphExecDestroy(g);
+        if (k > 0 && h->ws[k].stream) (void)hipStreamDestroy(h->ws[k].stream);
+        if (h->ws[k].ev_fork) (void)hipEventDestroy(h->ws[k].ev_fork);
+        for (auto& e : h->ws[k].ev_join) if (e) (void)hipEventDestroy(e);
+    }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

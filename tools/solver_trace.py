@@ -67,3 +67,23 @@ for i, L in enumerate(lv):
     mean = lambda rows: sum(r[1] - r[0] for r in rows) / max(1, len(rows)) / 1e3
     print("  level %2d: %7.2f | %4d (%5.1f) | %5.1f | %5.1f | %3d, %6.2f | %6.2f | %6.2f" % (i, (L["t1"] - L["t0"]) / 1e6, len(d), mean(d), mean(pk), mean(nk), len(w),
           sum(r[1] - r[0] for r in w) / 1e6, sum(r[1] - r[0] for r in b) / 1e6, nowide / 1e6))
+# substitution sweeps behind the last factorisation: a sweep ends with nd_out_kernel; the last sweep with ONE right-hand side (kernel names "<1>") and the last with three
+rest = rows[i1:]
+sweeps, cur = [], []
+for r in rest:
+    cur.append(r)
+    if r[2].startswith("nd_out_kernel"):
+        sweeps.append(cur); cur = []
+for tag in ("<1>", "<3>"):
+    sel = [sw for sw in sweeps if any(tag in r[2] for r in sw) and any("nd_fwd_front" in r[2] for r in sw)]
+    if not sel: continue
+    sw = [r for r in sel[-1] if "residual" not in r[2] and "sumsq" not in r[2]]
+    a, b = min(r[0] for r in sw), max(r[1] for r in sw)
+    tot = collections.Counter(); cnt = collections.Counter()
+    for s_, e, n, _ in sw: tot[n.split("(")[0]] += e - s_; cnt[n.split("(")[0]] += 1
+    ev3 = sorted([(r[0], 1) for r in sw] + [(r[1], -1) for r in sw]); live3 = 0; last3 = a; idle3 = 0
+    for t, d in ev3:
+        if live3 == 0: idle3 += t - last3
+        live3 += d; last3 = t
+    print("last substitution sweep %s: %d launches, wall %.2f ms, no kernel running %.2f ms; sum of durations (ms, launches): %s" % (
+        tag, len(sw), (b - a) / 1e6, idle3 / 1e6, {k: (round(v / 1e6, 2), cnt[k]) for k, v in tot.most_common(12)}))
