@@ -178,8 +178,8 @@ class DeviceSolver:
     __del__ = close
 
     def prepare(self):
-        """The factors at hand will not be used again and a new K is about to be assembled: start clearing the factor storage now (gfs_prepare_refactor: 11.5 ms of
-        HBM writes at C4 that run under the assembly pass instead of in front of the factorisation)."""
+        """The factors at hand will not be used again: start clearing the factor storage now (gfs_prepare_refactor: 9 - 11 ms of HBM writes at C4 that the next refactor()
+        then skips).  Pays when the device is idle until then; beside an assembly pass it does not (include/goldfish_solver.h has the measurement)."""
         if lib().gfs_prepare_refactor(self.h):
             raise RuntimeError(lib().gfs_last_error().decode())
 

@@ -847,17 +847,6 @@ class NonMatchingOpt:
         off = getattr(self, "_newton_load_offset", None)
         return R if off is None else R - off
 
-    def _prepare_refactor(self):
-        """The device solver's factors will not be used again (the state is about to move and K to be assembled anew): let it clear its factor storage now, beside the
-        assembly pass (gfs_prepare_refactor: 11.5 ms of HBM writes at C4 that otherwise sit in front of every factorisation)."""
-        ds = getattr(self, "_dsolver", None)
-        if self.linear_solver == "device" and ds is not None and hasattr(ds, "prepare"):
-            try:
-                ds.prepare()
-                self._dsolver_version = None          # whatever comes next factors first
-            except RuntimeError:
-                pass
-
     def _newton_solve(self, ref_error, rtol, max_it):
         """The Newton iteration of solve_nonlinear_nonmatching_problem from the current state (one load increment)."""
         self._assemble(_lib.ASM_R | _lib.ASM_K)
@@ -878,8 +867,6 @@ class NonMatchingOpt:
             if not chord:
                 self._assemble(_lib.ASM_K)            # tangent of the current state (already there unless the last steps were chord steps)
             du = self.solve_K(-R, refine=0, stale_factors=True) if chord else self.solve_K(-R, refine=0)
-            if not reuse:
-                self._prepare_refactor()              # these factors are done (a factorisation per step, as the reference): their storage is cleared under the next assembly pass
             ndu = float(np.linalg.norm(du))
             lam = 1.0
             while True:

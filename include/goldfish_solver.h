@@ -41,10 +41,10 @@ int gfs_create_nd(int device, int64_t ncp, const int64_t* nb_ptr, const int32_t*
 void gfs_destroy(gfs_handle* h);
 /* numeric factorisation of the values currently in d_valK */
 int gfs_refactor(gfs_handle* h);
-/* Optional, before a gfs_refactor: start clearing the factor storage now (asynchronously, on the handle's stream; C4: 57 GB, 11.5 ms of pure HBM writes, 5 % of a
- * factorisation).  The factors at hand are gone from this call on.  The caller that knows a new K is coming -- the Newton loop, right after the solve that used the
- * old factors (reference: GOLDFISH/operations/disp_imop.py:38-44, utils/opt_utils.py:156-209: a factorisation per step) -- calls it BEFORE it launches the assembly
- * pass, which is bound by the FP64 pipe and leaves the memory system idle: the clearing then costs nothing.  gfs_refactor skips its own clearing once. */
+/* Optional, before a gfs_refactor: start clearing the factor storage now (asynchronously, on the handle's stream; C4: 57 GB, 9.4 - 11.5 ms of pure HBM writes, 5 % of a
+ * factorisation).  The factors at hand are gone from this call on; gfs_refactor skips its own clearing once.  For a caller whose device is IDLE before the next
+ * factorisation (host-side work between two solves).  Measured and NOT used by the Newton loop (tools/time_prepare_overlap.py, profiles/r05_prepare_overlap.txt): beside the
+ * assembly pass the fill kernel takes the element kernel's issue slots -- the pass takes 21.3 instead of 11.5 ms, the factorisation 208.7 instead of 218.9 ms, the step the same. */
 int gfs_prepare_refactor(gfs_handle* h);
 /* x = K^{-1} b with the current factors and up to max_refine steps of iterative refinement (stops when the residual no longer
  * decreases); b, x: 3 * ncp doubles, host pointers (gfs_solve) or device pointers (gfs_solve_dev).
