@@ -13,6 +13,8 @@ ends with the RCCL all-gather of the owned residual rows.  C5 (configs[4]: 32x32
 reports it as the `secondary` record of the same JSON line (own roofline / roofline_fp64; skipped, with the reason, when the device
 has less than 110 GB free or with --no-secondary).  By hand: `--geometry fuselage --patches 32 32 --nel 53 --degree 4`; one GPU's
 share of it: `--geometry fuselage --patches 16 8 --nel 53 --degree 4`.
+At N = 1 the default run also adds `device_solver` (not part of `value`): the factorisation and the solves of the K it has just assembled -- the other nine tenths of a Newton
+step (`--no-solver` skips it).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--geometry shell|fuselage] [--patches NX NY] [--nel E] [--degree P]
 N > 1:  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -114,6 +116,7 @@ def parse_args(argv=None):
     ap.add_argument("--degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1, default workload: do not add the C5 record")
+    ap.add_argument("--no-solver", action="store_true", help="N = 1, default workload: do not add the device_solver record (factorisation / solves of this K)")
     ap.add_argument("--full-pass-only", action="store_true", help="skip the apply_linear and Newton-pass legs (PMC passes: every launch belongs to a full pass)")
     return ap.parse_args(argv)
 
@@ -349,8 +352,43 @@ def measure(args, torch, dist, rank, local_rank, world):
             out["roofline_fp64"]["counter_flop_per_launch"] = counter_flop
             out["roofline_fp64"]["counter_flop_source"] = traffic_source
             out["roofline_fp64"]["frac_counters"] = counter_flop / (kern_ms_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+        if world == 1 and workload_name(args) == "C4" and not args.full_pass_only and not args.no_solver:
+            try:
+                out["device_solver"] = solver_record(D, A, np)
+            except Exception as ex:
+                out["device_solver"] = {"error": str(ex)}
     D.close()
     return out if rank == 0 else None
+
+
+def solver_record(D, A, np):
+    """SURVEY 8(f) N1 beside the headline: the linear solves of a Newton step / an adjoint on the K this run assembled (DispImOpeartion.solve_nonlinear / solve_linear,
+    GOLDFISH/operations/disp_imop.py:38-44, 130-142; MUMPS in the reference).  Not part of `value`: its own record, measured live."""
+    from goldfish_amd import _lib, _solver
+    D.assemble(_lib.ASM_R | _lib.ASM_K); D.sync()
+    b = -D.residual()
+    X = np.stack([A.cp_hom[f] / A.weights for f in range(3)], 1)
+    t = time.perf_counter(); S = _solver.DeviceSolver(D, coords=X); t_first = time.perf_counter() - t
+    try:
+        info = S.info()
+        for _ in range(3):
+            S.refactor(); S.solve(b)                      # the library captures its HIP graphs at the fourth call of a sweep
+        tf = []
+        for _ in range(5):
+            t = time.perf_counter(); S.refactor(); tf.append(time.perf_counter() - t)
+        t = time.perf_counter(); S.solve(b); t_solve = time.perf_counter() - t
+        rr, be = S.rel_residual, S.backward_error
+        for _ in range(4):
+            S.solve(b, max_refine=0)
+        t = time.perf_counter(); S.solve(b, max_refine=0); t_sweep = time.perf_counter() - t
+        f = float(np.median(tf))
+        return {"what": "K x = -R of this model on the device: nested-dissection multifrontal L D L^T on 64 x 64 FP64-MFMA tiles (goldfish_amd/csrc/gf_solver.hip), K read in place",
+                "method": S.method, "dofs": int(A.ndof), "factor_bytes": int(info["device_bytes"]), "factor_flop": float(info["factor_flops"]),
+                "ordering_and_first_factorisation_s": t_first, "factorisation_s": f, "factorisation_samples": len(tf), "factorisation_tflops": info["factor_flops"] / f / 1e12,
+                "frac_of_fp64_matrix_peak": info["factor_flops"] / f / 1e12 / FP64_PEAK_TFLOPS, "solve_with_refinement_s": t_solve, "relative_residual": rr, "backward_error": be,
+                "substitution_sweep_s": t_sweep, "timing": "host wall clock around synchronous calls of the C ABI (host copies of b and x included in the solves), this run"}
+    finally:
+        S.close()
 
 
 if __name__ == "__main__":
