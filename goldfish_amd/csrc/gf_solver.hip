@@ -624,13 +624,6 @@ __global__ __launch_bounds__(256) void update_narrow_kernel(double* __restrict__
     GF_UPDATE_TILE(band, wbuf, rowoff, k, (int)blockIdx.x, (int)blockIdx.y, smem);
     if (dn.on && blockIdx.x == 0 && blockIdx.y == 0) diag_next(band, rowoff, k + 1, dn, smem);       // tile (k + 1, k + 1): block column k was its last update inside the panel group
 }
-// the narrow update without the diagonal tile: 32 KB of LDS and a third of the registers -- its workgroups start beside the wide updates of other fronts at once, where the
-// 58 KB form waits for slots to drain (75 - 120 us per launch at the crowded levels of C4 against 19 us alone)
-__global__ __launch_bounds__(256) GF_WIDE_ATTR void update_narrow_lean_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k) {
-    GF_WIDE_SMEM;
-    if (blockIdx.x < blockIdx.y) return;
-    GF_UPDATE_WIDE_TILE(band, wbuf, 0, rowoff, k, 1, (int)blockIdx.x, (int)blockIdx.y, smem);
-}
 // the same update restricted to the first ncol trailing block columns (blockIdx = (row gi, column gj < ncol)): before a SUB-GROUP of a panel group starts, its columns
 // receive the products of all earlier panels of the group in one read-modify-write; the narrow updates then stay inside the sub-group.  A tile of the group's j-th column
 // is rewritten 1 + (j mod 4) times instead of j times (groups of 8, sub-groups of 4): the narrow updates are bound by exactly that traffic.
@@ -639,13 +632,11 @@ __global__ __launch_bounds__(256) GF_WIDE_ATTR void update_mid_kernel(double* __
     if (blockIdx.x < blockIdx.y) return;
     GF_UPDATE_WIDE_TILE(band, wbuf, wstride, rowoff, k0, w, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
-// off: the triangle starts off block rows / columns behind the group (look-ahead: the first off trailing columns are updated by update_mid_kernel on the chain's stream)
-__global__ __launch_bounds__(256) GF_WIDE_ATTR void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow,
-                                                                       int off) {
+__global__ __launch_bounds__(256) GF_WIDE_ATTR void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow) {
     GF_WIDE_SMEM;
     int gi, gj; tri_index((int)blockIdx.x, gi, gj);
     if (gi >= nrow) return;
-    GF_UPDATE_WIDE_TILE(band, wbuf, wstride, rowoff, k0, w, gi + off, gj + off, smem);
+    GF_UPDATE_WIDE_TILE(band, wbuf, wstride, rowoff, k0, w, gi, gj, smem);
 }
 
 // forward substitution, block column k: y_k = L_kk^-1 b_k (every workgroup; workgroup 0 keeps it), b_{k+g} -= L_{k+g,k} y_k (workgroup g >= 1)
@@ -1340,8 +1331,6 @@ struct gfs_handle {
     // them ("top") follow on the main stream.  Per stream: W tiles of a panel, front-local vectors
     static constexpr int NS = 8;
     hipStream_t st[NS] = {}; hipEvent_t ev[NS] = {}, ev_main = nullptr, ev_norm = nullptr; double* part_k = nullptr;
-    // look-ahead in the large fronts (round 5): the bulk of a panel group's wide update runs on a partner stream under the next group's chain
-    hipStream_t st2[NS] = {}; hipEvent_t evA[NS] = {}, evB[NS] = {}; double* s_wbuf2[NS + 1] = {}; bool lookahead = false;
     double *s_wbuf[NS + 1] = {}, *s_b[NS + 1] = {}, *s_y[NS + 1] = {}, *s_z[NS + 1] = {}, *s_x[NS + 1] = {};
     std::vector<std::vector<int>> sub;       // sub[s]: fronts of the subtrees assigned to stream s, in post-order
     std::vector<int> top;                    // the remaining fronts, in post-order
@@ -1373,7 +1362,6 @@ struct gfs_handle {
     unsigned char* d_row_ok = nullptr;            // gfs_set_row_mask: rows of d_valK that hold values (a rank's own rows of a sharded K); nullptr = all
     bool sweep_streams = true;                    // GF_SOLVER_SWEEP_STREAMS=0: the large fronts of a substitution one after the other on the sweep's stream
     bool prepared = false;                        // gfs_prepare_refactor has cleared the factor storage for the next gfs_refactor
-    int fuse_max_fronts = 2;                      // GF_SOLVER_FUSE_MAXF: tree heights with more large fronts than this run the lean narrow update + diagonal-tile launches
     int subgroup = 4;                             // GF_SOLVER_SUBGROUP: block columns per sub-group of a panel group (0: none)
     bool fuse_diag = true;                        // GF_SOLVER_FUSE_DIAG=0: every diagonal tile in a launch of its own (the chain before round 5)
     bool lds_raised[3] = {false, false, false};   // hipFuncAttributeMaxDynamicSharedMemorySize of the NR-right-hand-side sweep kernels raised on this handle's device
@@ -1400,7 +1388,7 @@ __global__ void nd_out_kernel(long long n, const double* __restrict__ src, doubl
     if (t < n) dst[t] = add ? dst[t] + src[t] : src[t];
 }
 // ---- multifrontal mode: work of one front on a stream with that stream's scratch (index NS = the main stream's)
-static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool extend_add = true, bool crowded = false, bool allow_look = false) {
+static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool extend_add = true) {
     const Front& F = h->fronts[t];
     if (extend_add) for (int c : h->kids[t]) {
         const long long nbb = h->fronts[c].nblk_t - h->fronts[c].nblk_e;
@@ -1412,17 +1400,15 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
     // (Measured and dropped, round 3: look-ahead -- the bulk of a group's wide update on a partner stream while this stream goes on with the next group's
     //  diag / panel / narrow chain: 0.473 instead of 0.407 s at C4.  The chain's one-workgroup diagonal tile runs at a third of its speed next to the
     //  MFMA-heavy update workgroups it shares a CU with, so the chain does not get shorter and the split update costs a launch more per group.)
-    // Look-ahead (round 5, optional: GF_SOLVER_LOOKAHEAD; measured and dropped in round 3, when the wide update ran at half its present rate and the chain at a third of its own beside it): behind the
-    // chain of group g the trailing update is split -- the columns of group g + 1 on this stream (update_mid_kernel: the next chain needs them), the rest on the partner
-    // stream (update_wide_kernel with an offset), under the chain of group g + 1.  Every tile receives the same products in the same order: the factors do not change.
-    // Two sets of panel buffers (the partner still reads W of group g while the chain writes W of group g + 1).  si == NS (the main stream) has no partner.
-    // (allow_look: the caller has forked the partner stream from the main stream itself and joins it there -- a graph capture did not survive a partner forked from a fork)
-    const bool look = allow_look && h->lookahead && si < gfs_handle::NS && h->st2[si] && h->s_wbuf2[si] && F.nblk_e > WP;
-    hipStream_t sb = look ? h->st2[si] : nullptr;
-    bool have_diag = false, partner_busy = false; int g = 0;
-    for (int k0 = 0; k0 < F.nblk_e; k0 += WP, ++g) {                  // groups of WP block columns: one wide trailing update per group
+    // (Look-ahead -- the bulk of a group's wide update on a partner stream under the next group's chain -- was measured twice and dropped twice.  Round 3: 0.473 against 0.407 s, the
+    //  chain's diagonal tile ran at a third of its speed beside the update workgroups.  Round 5, with the 13 us tile and the LDS-DMA update: same products in the same order through
+    //  update_mid_kernel for the next group's columns + an offset wide update on the partner, two sets of panel buffers: direct launches 0.2198 s without, 0.2189 s with it, the captured
+    //  graph 0.2158 s -- and the ladder of dependencies between the two streams cannot be captured: hipGraphInstantiate of ROCm 7.2 walks every path through it (stack overflow; 270 GB
+    //  of host memory with an unlimited stack).  profiles/r05_solver_lookahead_ab.txt; the code is in the history.)
+    bool have_diag = false;
+    for (int k0 = 0; k0 < F.nblk_e; k0 += WP) {                       // groups of WP block columns: one wide trailing update per group
         const int w = std::min(WP, F.nblk_e - k0);
-        double* wset = (look && (g & 1)) ? h->s_wbuf2[si] : h->s_wbuf[si];
+        double* wset = h->s_wbuf[si];
         const int SG = h->subgroup > 0 ? h->subgroup : WP;
         for (int c = 0; c < w; ++c) {
             const int send = std::min((c / SG + 1) * SG, w);              // the sub-group of column c ends here (relative to k0)
@@ -1430,45 +1416,24 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
             double* wb = wset + (size_t)c * wstride * NB2;
             if (c > 0 && c % SG == 0)                                     // a sub-group starts: its columns get the products of the group's earlier panels in one pass
                 hipLaunchKernelGGL(update_mid_kernel, dim3(F.nblk_t - k, send - c), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, c);
-            // inside a panel group the diagonal tile of a block column has been factored by the workgroup that applied its last update (DiagNext); the group's first
-            // column gets a launch (the wide update stays small: 32 KB of LDS, four workgroups per CU)
+            // inside a sub-group the diagonal tile of a block column has been factored by the workgroup that applied its last update (DiagNext); the sub-group's first
+            // column gets a launch (the wide and mid updates stay small: 32 KB of LDS, four workgroups per CU).  A lean narrow update (32 KB, no fused tile) at the tree
+            // heights where several large fronts run side by side was measured without effect (profiles/r05_solver_fuse_maxf_ab.txt) and removed.
             if (!have_diag) hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, st, band, linv, dval, h->d_tri, k, stat);
             have_diag = false;
             if (ni > 0) hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, st, band, linv, dval, wb, h->d_tri, k);
             if (w == 1 && ni > 0) {
-                if (partner_busy) { HIPCHK(hipStreamWaitEvent(st, h->evB[si], 0)); partner_busy = false; }       // the partner's update wrote these tiles
                 have_diag = h->fuse_diag && k + 1 < F.nblk_e;
                 hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, st, band, wb, h->d_tri, k, ni, DiagNext{linv, dval, stat, have_diag ? 1 : 0});
             } else if (nin > 0) {
-                have_diag = h->fuse_diag && !crowded;             // crowded level: the lean narrow update and a diagonal-tile launch
-                if (have_diag || !GF_UPDATE_DMA) hipLaunchKernelGGL(update_narrow_kernel, dim3(ni, nin), dim3(256), 0, st, band, wb, h->d_tri, k, DiagNext{linv, dval, stat, have_diag ? 1 : 0});
-                else hipLaunchKernelGGL(update_narrow_lean_kernel, dim3(ni, nin), dim3(256), 0, st, band, wb, h->d_tri, k);
+                have_diag = h->fuse_diag;
+                hipLaunchKernelGGL(update_narrow_kernel, dim3(ni, nin), dim3(256), 0, st, band, wb, h->d_tri, k, DiagNext{linv, dval, stat, have_diag ? 1 : 0});
             }
         }
         const int nrow = F.nblk_t - (k0 + w);
-        if (w > 1 && nrow > 0) {
-            const int wnext = std::min(WP, F.nblk_e - (k0 + w));          // block columns of the next group (<= 0: this was the last one)
-            if (look && wnext > 0) {
-                const int nrow2 = nrow - wnext;
-                if (nrow2 > 0) {
-                    HIPCHK(hipEventRecord(h->evA[si], st));                                   // the chain of this group is done
-                    HIPCHK(hipStreamWaitEvent(sb, h->evA[si], 0));
-                }
-                if (partner_busy) HIPCHK(hipStreamWaitEvent(st, h->evB[si], 0));           // the partner's update of the previous group wrote the next group's columns too
-                partner_busy = false;
-                hipLaunchKernelGGL(update_mid_kernel, dim3(nrow, wnext), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w);
-                if (nrow2 > 0) {
-                    hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow2 * (nrow2 + 1) / 2)), dim3(256), 0, sb, band, wset, wstride, h->d_tri, k0, w, nrow2, wnext);
-                    HIPCHK(hipEventRecord(h->evB[si], sb));
-                    partner_busy = true;
-                }
-            } else {
-                if (partner_busy) { HIPCHK(hipStreamWaitEvent(st, h->evB[si], 0)); partner_busy = false; }
-                hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow, 0);
-            }
-        }
+        if (w > 1 && nrow > 0)
+            hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow);
     }
-    if (partner_busy) HIPCHK(hipStreamWaitEvent(st, h->evB[si], 0));                       // join: whatever follows on this stream sees the whole front
 }
 // the NR vectors of one kind out of NR workspaces (one workspace per right-hand side)
 #define GF_VEC(member) ([&] { Vec<NR> v_; for (int j_ = 0; j_ < NR; ++j_) v_.p[j_] = W[j_]->member; return v_; }())
@@ -1541,12 +1506,8 @@ static void nd_factor_levels(gfs_handle* h) {
         if (!L.big.empty()) {
             HIPCHK(hipEventRecord(h->ev_main, h->stream));
             used = std::min<int>(NS, (int)L.big.size());
-            for (int s = 0; s < used; ++s) {
-                HIPCHK(hipStreamWaitEvent(h->st[s], h->ev_main, 0));
-                if (h->lookahead) HIPCHK(hipStreamWaitEvent(h->st2[s], h->ev_main, 0));
-            }
-            const bool crowded = (int)L.big.size() > h->fuse_max_fronts;       // several large fronts side by side: their chains run beside each other's wide updates
-            for (size_t i = 0; i < L.big.size(); ++i) { const int s = (int)(i % NS); nd_factor_front(h, L.big[i], h->st[s], s, false, crowded, true); }
+            for (int s = 0; s < used; ++s) HIPCHK(hipStreamWaitEvent(h->st[s], h->ev_main, 0));
+            for (size_t i = 0; i < L.big.size(); ++i) { const int s = (int)(i % NS); nd_factor_front(h, L.big[i], h->st[s], s, false); }
         }
         const int WP = std::max(h->batch_panel_w, 1), kmax = (int)L.nk.size();
         for (int k0 = 0; k0 < kmax; k0 += WP) {                          // panel groups, as nd_factor_front does for one front
@@ -1570,10 +1531,7 @@ static void nd_factor_levels(gfs_handle* h) {
                 hipLaunchKernelGGL(nd_update_wide_batch_kernel, dim3((unsigned)((long long)mni0 * (mni0 + 1) / 2), L.nk[k0]), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off,
                                    h->d_fwofs + L.off, h->d_tri, h->band, h->bwbuf, k0, WP);
         }
-        for (int s = 0; s < used; ++s) {
-            HIPCHK(hipEventRecord(h->ev[s], h->st[s])); HIPCHK(hipStreamWaitEvent(h->stream, h->ev[s], 0));
-            if (h->lookahead) { HIPCHK(hipEventRecord(h->evB[s], h->st2[s])); HIPCHK(hipStreamWaitEvent(h->stream, h->evB[s], 0)); }
-        }
+        for (int s = 0; s < used; ++s) { HIPCHK(hipEventRecord(h->ev[s], h->st[s])); HIPCHK(hipStreamWaitEvent(h->stream, h->ev[s], 0)); }
     }
 }
 // run `body` (kernel launches, event record / wait on h->stream and the side streams) through a graph captured at the first call
@@ -1881,7 +1839,6 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
         if (const char* e = std::getenv("GF_SOLVER_FUSE_DIAG")) h->fuse_diag = std::atoi(e) != 0;
         if (const char* e = std::getenv("GF_SOLVER_SUBGROUP")) h->subgroup = std::max(0, std::min(8, std::atoi(e)));
         if (const char* e = std::getenv("GF_SOLVER_SWEEP_STREAMS")) h->sweep_streams = std::atoi(e) != 0;
-        if (const char* e = std::getenv("GF_SOLVER_FUSE_MAXF")) h->fuse_max_fronts = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("GF_SOLVER_BATCH_PANEL_W")) h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));      // panel groups of the level-batched small fronts
         {   // independent subtrees for the side streams: split the largest subtree (by factorisation work) until there are enough of them
             constexpr int NS = gfs_handle::NS;
@@ -1915,21 +1872,12 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
             }
             for (int64_t t = 0; t < nfronts; ++t) if (is_top[t]) h->top.push_back((int)t);
             for (int s_ = 0; s_ < NS; ++s_) { HIPCHK(hipStreamCreate(&h->st[s_])); HIPCHK(hipEventCreateWithFlags(&h->ev[s_], hipEventDisableTiming)); }
-            // GF_SOLVER_LOOKAHEAD=1 (off by default; measured at C4, same box, profiles/r05_solver_lookahead_ab.txt: direct launches 0.2198 s without, 0.2189 s with it; the
-            // HIP graph of the sweep 0.2158 s -- and the graph cannot be had together with it: capturing the ladder of dependencies between a chain stream and its
-            // partner makes hipGraphInstantiate of ROCm 7.2 walk every path through the ladder (it ran out of stack, and with an unlimited stack out of 270 GB of host memory),
-            // so the switch also turns the factorisation's graph off)
-            if (const char* e = std::getenv("GF_SOLVER_LOOKAHEAD")) h->lookahead = std::atoi(e) != 0;
-            if (h->lookahead) for (int s_ = 0; s_ < NS; ++s_) {
-                HIPCHK(hipStreamCreate(&h->st2[s_])); HIPCHK(hipEventCreateWithFlags(&h->evA[s_], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->evB[s_], hipEventDisableTiming));
-            }
             HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&h->ev_norm, hipEventDisableTiming)); h->part_k = h->dalloc<double>(256);
             const size_t fl_ = (size_t)maxb * NB;
             h->ws_front_len = (long long)fl_;
             for (int s_ = 0; s_ <= NS; ++s_) {
                 h->s_wbuf[s_] = h->dalloc<double>((size_t)std::max(maxb, 1) * NB2 * std::max(h->panel_w, 1));
-                if (h->lookahead && s_ < NS) h->s_wbuf2[s_] = h->dalloc<double>((size_t)std::max(maxb, 1) * NB2 * std::max(h->panel_w, 1));
                 h->s_b[s_] = h->dalloc<double>(fl_); h->s_y[s_] = h->dalloc<double>(fl_); h->s_z[s_] = h->dalloc<double>(fl_); h->s_x[s_] = h->dalloc<double>(fl_);
             }
             h->wbuf = h->s_wbuf[NS];
@@ -2019,7 +1967,6 @@ void gfs_destroy(gfs_handle* h) {
     (void)hipDeviceSynchronize();
     for (void* p : h->allocs) (void)hipFree(p);
     for (int s_ = 0; s_ < gfs_handle::NS; ++s_) { if (h->ev[s_]) (void)hipEventDestroy(h->ev[s_]); if (h->st[s_]) (void)hipStreamDestroy(h->st[s_]); }
-    for (int s_ = 0; s_ < gfs_handle::NS; ++s_) { if (h->evA[s_]) (void)hipEventDestroy(h->evA[s_]); if (h->evB[s_]) (void)hipEventDestroy(h->evB[s_]); if (h->st2[s_]) (void)hipStreamDestroy(h->st2[s_]); }
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     if (h->ev_norm) (void)hipEventDestroy(h->ev_norm);
     if (h->g_factor) (void)hipGraphExecDestroy(h->g_factor);
@@ -2070,8 +2017,7 @@ int gfs_refactor(gfs_handle* h) {
                 const Front& F = h->fronts[t];
                 HIPCHK(hipMemcpyAsync(h->band + (size_t)F.tile_off * NB2, h->stub_src[t], (size_t)F.nblk_t * (F.nblk_t + 1) / 2 * NB2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
             }
-            if (h->batch_blk > 0 && h->lookahead) nd_factor_levels(h);                 // direct launches: see GF_SOLVER_LOOKAHEAD
-            else if (h->batch_blk > 0) nd_run_captured(h, &h->g_factor, [&] { nd_factor_levels(h); });
+            if (h->batch_blk > 0) nd_run_captured(h, &h->g_factor, [&] { nd_factor_levels(h); });
             else nd_run_captured(h, &h->g_factor, [&] { nd_sweep_up(h, [](gfs_handle* hh, int t, hipStream_t st, int si) { nd_factor_front(hh, t, st, si); }); });
         } else {
         hipLaunchKernelGGL(band_fill_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->newi, h->general ? h->d_rev : nullptr, h->valK, h->band, h->rowoff, h->n, h->npad);
