@@ -566,6 +566,7 @@ template <int HKT> __device__ __forceinline__ void panel_body_dma(double* __rest
 // rows behind 8 block columns, random operands (tools/ubench_update.hip, profiles/r05_ubench_update.txt): through registers 48.6 TFLOP/s; LDS-DMA with parts of 32 k (64 KB,
 // two workgroups per CU) 56.0, parts of 16 k 62.9; whole tiles (128 KB, one workgroup per CU) 47.1
 constexpr int HK = 16;
+static_assert(4 * NB * HK * sizeof(double) <= 65536, "the LDS-DMA destination (M0 base + lane offset) reaches 64 KB: the whole-tile variant (128 KB) failed the index check of tools/ubench_update.hip");
 #ifndef GF_UPDATE_DMA
 #define GF_UPDATE_DMA 1        // 0: operand tiles through registers (update_wide_tile), the form of rounds 3 - 4
 #endif
