@@ -543,6 +543,78 @@ template <int HKT> __device__ __forceinline__ void update_wide_tile_dma(double* 
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) C[(16 * wave + 4 * rg + kq) * NB + 16 * nj + l16] = acc[nj][rg];
 }
+// ---- 128 x 128 macro tiles: one workgroup updates the 2 x 2 target tiles (2 mi + {0, 1}, 2 mj + {0, 1}), one tile per WAVE (64 accumulator doubles per lane), from two W panels and two L
+//      panels staged by LDS-DMA as above (parts of 16 k: 2 x 128 rows x 16 k per stage, two stages = 64 KB, two workgroups per CU).  Per tile product that is half the operand
+//      bytes across the L2 <-> fabric interface (the wide updates move 368 KB per 64 KB target tile, profiles/r05_solver_traffic_before_xcd.txt), 8 instead of 20 ds_read_b128 and one
+//      barrier instead of four per 32 MFMAs of a wave.  Tiles above the diagonal and beyond the last block row are not computed (their wave still loads and synchronises).
+template <int HKT> __device__ __forceinline__ void update_wide_macro_dma(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w,
+                                                                         int mi, int mj, int nrow, double* __restrict__ smem) {
+    constexpr int PART = 2 * NB * HKT, STAGE = 2 * PART, CPR = HKT / 2, RPP = 64 / CPR, NP = 32 / RPP, SPC = NB / HKT;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kq = lane >> 4, wi = wave >> 1, wj = wave & 1;
+    const int gi = 2 * mi + wi, gj = 2 * mj + wj;
+    const bool valid = gi < nrow && gj <= gi;
+    int it[2], jt[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { it[t] = k0 + w + min(2 * mi + t, nrow - 1); jt[t] = k0 + w + min(2 * mj + t, nrow - 1); }
+    double* C = band + (size_t)(rowoff[k0 + w + min(gi, nrow - 1)] + (valid ? gi - gj : 0)) * NB2;
+    auto issue = [&](int s) {                                    // this wave's rows 32 wave .. 32 wave + 31 of the two 128-row operand parts of stage s
+        const int c = s / SPC, h = s % SPC, k = k0 + c;
+        double* buf = smem + (s & 1) * STAGE;
+        const int rr = lane / CPR, p = lane % CPR;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int r = 32 * wave + RPP * q + rr, t = r >> 6, tr = r & 63;
+            const double* gA = wbuf + (size_t)((long long)c * wstride + (it[t] - (k + 1))) * NB2;
+            const double* gB = band + (size_t)(rowoff[jt[t]] + (jt[t] - k)) * NB2;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(gA + tr * NB + HKT * h + 2 * (p ^ (r & (CPR - 1)))), (lds_void_t*)(buf + (32 * wave + RPP * q) * HKT), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(gB + tr * NB + HKT * h + 2 * (p ^ (r & (CPR - 1)))), (lds_void_t*)(buf + PART + (32 * wave + RPP * q) * HKT), 16, 0, 0);
+        }
+    };
+    issue(0);
+    d4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[a][b][t] = valid ? C[(16 * a + 4 * t + kq) * NB + 16 * b + l16] : 0.0;
+    const int ns = SPC * w;
+    for (int s = 0; s < ns; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 1 < ns) issue(s + 1);
+        if (valid) {
+            const double* bufA = smem + (s & 1) * STAGE + (64 * wi + l16) * HKT;
+            const double* bufB = smem + (s & 1) * STAGE + PART + (64 * wj + l16) * HKT;
+#pragma unroll
+            for (int rd = 0; rd < HKT / 8; ++rd) {
+                const int off = 2 * ((4 * rd + kq) ^ (l16 & (CPR - 1)));
+                double2 av[4], bv[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) av[a] = *reinterpret_cast<const double2*>(bufA + a * 16 * HKT + off);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bv[b] = *reinterpret_cast<const double2*>(bufB + b * 16 * HKT + off);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[a].x, bv[b].x, acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[a].y, bv[b].y, acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) C[(16 * a + 4 * t + kq) * NB + 16 * b + l16] = acc[a][b][t];
+    }
+}
 // panel tile in the same form: W = A_ik L_kk^-T (to wbuf), L_ik = W D_k^-1 (in place: the tile's last part has landed in LDS before anything is stored)
 template <int HKT> __device__ __forceinline__ void panel_body_dma(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf,
                                                                   const long long* __restrict__ rowoff, int k, int g, double* __restrict__ smem) {
@@ -632,6 +704,12 @@ __global__ __launch_bounds__(256) GF_WIDE_ATTR void update_mid_kernel(double* __
     GF_WIDE_SMEM;
     if (blockIdx.x < blockIdx.y) return;
     GF_UPDATE_WIDE_TILE(band, wbuf, wstride, rowoff, k0, w, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void update_wide_macro_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride,
+                                                                                                      const long long* __restrict__ rowoff, int k0, int w, int nrow) {
+    __shared__ __attribute__((aligned(16))) double smem[8 * NB * HK];
+    int mi, mj; tri_index((int)blockIdx.x, mi, mj);
+    update_wide_macro_dma<HK>(band, wbuf, wstride, rowoff, k0, w, mi, mj, nrow, smem);
 }
 __global__ __launch_bounds__(256) GF_WIDE_ATTR void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow) {
     GF_WIDE_SMEM;
@@ -1363,6 +1441,8 @@ struct gfs_handle {
     unsigned char* d_row_ok = nullptr;            // gfs_set_row_mask: rows of d_valK that hold values (a rank's own rows of a sharded K); nullptr = all
     bool sweep_streams = true;                    // GF_SOLVER_SWEEP_STREAMS=0: the large fronts of a substitution one after the other on the sweep's stream
     bool prepared = false;                        // gfs_prepare_refactor has cleared the factor storage for the next gfs_refactor
+    int macro_min_rows = 64;                      // GF_SOLVER_MACRO_ROWS: wide updates of the large fronts with at least this many block rows run in 128 x 128 macro tiles (alone the
+                                                  // two forms are equal from 100 block rows on and the macro form loses below 60; C4: 0.2178 -> 0.2152 s; profiles/r05_solver_macro_ab.txt)
     int subgroup = 4;                             // GF_SOLVER_SUBGROUP: block columns per sub-group of a panel group (0: none)
     bool fuse_diag = true;                        // GF_SOLVER_FUSE_DIAG=0: every diagonal tile in a launch of its own (the chain before round 5)
     bool lds_raised[3] = {false, false, false};   // hipFuncAttributeMaxDynamicSharedMemorySize of the NR-right-hand-side sweep kernels raised on this handle's device
@@ -1432,7 +1512,10 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
             }
         }
         const int nrow = F.nblk_t - (k0 + w);
-        if (w > 1 && nrow > 0)
+        if (w > 1 && nrow >= h->macro_min_rows) {
+            const long long nm = (nrow + 1) / 2;
+            hipLaunchKernelGGL(update_wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow);
+        } else if (w > 1 && nrow > 0)
             hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow);
     }
 }
@@ -1839,6 +1922,7 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
         if (const char* e = std::getenv("GF_SOLVER_PANEL_W")) h->panel_w = h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));
         if (const char* e = std::getenv("GF_SOLVER_FUSE_DIAG")) h->fuse_diag = std::atoi(e) != 0;
         if (const char* e = std::getenv("GF_SOLVER_SUBGROUP")) h->subgroup = std::max(0, std::min(8, std::atoi(e)));
+        if (const char* e = std::getenv("GF_SOLVER_MACRO_ROWS")) h->macro_min_rows = std::max(2, std::atoi(e));
         if (const char* e = std::getenv("GF_SOLVER_SWEEP_STREAMS")) h->sweep_streams = std::atoi(e) != 0;
         if (const char* e = std::getenv("GF_SOLVER_BATCH_PANEL_W")) h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));      // panel groups of the level-batched small fronts
         {   // independent subtrees for the side streams: split the largest subtree (by factorisation work) until there are enough of them

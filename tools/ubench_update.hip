@@ -59,6 +59,13 @@ __global__ __launch_bounds__(256) void wide_dma_kernel(double* __restrict__ band
 }
 }
 namespace {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void wide_macro_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow) {
+    __shared__ __attribute__((aligned(16))) double smem[8 * NB * 16];
+    int mi, mj; tri_index((int)blockIdx.x, mi, mj);
+    update_wide_macro_dma<16>(band, wbuf, wstride, rowoff, k0, w, mi, mj, nrow, smem);
+}
+}
+namespace {
 __global__ void fill_kernel(double* p, size_t n, unsigned seed) {
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         unsigned long long x = (t + 1) * 0x9E3779B97F4A7C15ull + seed; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
@@ -99,6 +106,7 @@ int main(int argc, char** argv) {
         check("LDS-DMA, parts of 32 k (library form)", [&] { hipLaunchKernelGGL(wide_kernel<1>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
         check("LDS-DMA, parts of 16 k", [&] { hipLaunchKernelGGL(wide_dma_kernel<16>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
         check("LDS-DMA, parts of 8 k", [&] { hipLaunchKernelGGL(wide_dma_kernel<8>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
+        { const int nm = (nrow + 1) / 2; check("LDS-DMA, 128 x 128 macro tiles", [&] { hipLaunchKernelGGL(wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); }); }
         check("LDS-DMA, whole tiles", [&] { hipLaunchKernelGGL(wide_dma_kernel<64>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
         hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, band, ntiles * NB2, 1u);
     }
@@ -106,6 +114,7 @@ int main(int argc, char** argv) {
     time("V4 update_wide_tile_dma (LDS-DMA, half stages, one barrier per stage)", [&] { hipLaunchKernelGGL(wide_kernel<1>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
     time("V5 LDS-DMA, parts of 16 k, 32 KB of LDS (four workgroups per CU)", [&] { hipLaunchKernelGGL(wide_dma_kernel<16>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
     time("V5b LDS-DMA, parts of 8 k, 16 KB of LDS (eight workgroups per CU)", [&] { hipLaunchKernelGGL(wide_dma_kernel<8>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
+    { const int nm = (nrow + 1) / 2; time("V10 LDS-DMA, 128 x 128 macro tiles (one tile per wave), parts of 16 k, 64 KB, two workgroups per CU", [&] { hipLaunchKernelGGL(wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); }); }
     time("V6 LDS-DMA, parts of 32 k, 64 KB of LDS (two workgroups per CU)", [&] { hipLaunchKernelGGL(wide_dma_kernel<32>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
     time("V7 LDS-DMA, whole tiles, 128 KB of LDS (one workgroup per CU)", [&] { hipLaunchKernelGGL(wide_dma_kernel<64>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
     time("V0 update_wide_kernel (library)", [&] { hipLaunchKernelGGL(update_wide_kernel, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
