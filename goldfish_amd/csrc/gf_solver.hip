@@ -1512,7 +1512,7 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
             }
         }
         const int nrow = F.nblk_t - (k0 + w);
-        if (w > 1 && nrow >= h->macro_min_rows) {
+        if (GF_UPDATE_DMA && w > 1 && nrow >= h->macro_min_rows) {
             const long long nm = (nrow + 1) / 2;
             hipLaunchKernelGGL(update_wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow);
         } else if (w > 1 && nrow > 0)
