@@ -697,6 +697,48 @@ __global__ __launch_bounds__(256) void update_narrow_kernel(double* __restrict__
     GF_UPDATE_TILE(band, wbuf, rowoff, k, (int)blockIdx.x, (int)blockIdx.y, smem);
     if (dn.on && blockIdx.x == 0 && blockIdx.y == 0) diag_next(band, rowoff, k + 1, dn, smem);       // tile (k + 1, k + 1): block column k was its last update inside the panel group
 }
+// ---- Round 5, last step: a SUB-GROUP of a panel group (sg <= 4 block columns ks .. ks + sg - 1) in TWO launches instead of two or three per block column.
+//      subgroup_block (one workgroup per front): the sg x sg block triangle on the diagonal -- diagonal tile, the panels below it inside the triangle, their updates of the
+//      triangle's remaining tiles, next diagonal tile, ... (right-looking, one tile operation after the other: with the 13 us diagonal tile that chain is ~ 90 us for four
+//      columns; in round 3, with the 93 us tile, the same idea lost).  subgroup_row (one workgroup per block row below the triangle): the row's sg panels, each behind the
+//      row's own lazy update from the sub-group's earlier columns (left-looking: W_i,c' is this workgroup's, L_k,c' the triangle's) -- a row's tiles are read once and its W / L
+//      written once, where panel + narrow updates re-read and re-wrote them per column.  Both use the tile kernels' device functions; a workgroup sees its own global writes
+//      behind __syncthreads().
+__device__ __forceinline__ void subgroup_block(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, double* __restrict__ stat, const long long* __restrict__ tri,
+                                               double* __restrict__ wbuf, long long wstride, int k0, int ks, int sg, int nblk_t, double* __restrict__ smem) {
+    for (int c = 0; c < sg; ++c) {
+        const int k = ks + c;
+        diag_body(band, linv, dval, tri, k, stat, smem);
+        __syncthreads();
+        double* wb = wbuf + (size_t)(k - k0) * wstride * NB2;
+        const int rin = min(ks + sg, nblk_t) - (k + 1);           // rows of the triangle below block column k
+        for (int g = 0; g < rin; ++g) { GF_PANEL_BODY(band, linv, dval, wb, tri, k, g, smem); __syncthreads(); }
+        for (int gj = 0; gj < rin; ++gj)
+            for (int gi = gj; gi < rin; ++gi) { GF_UPDATE_TILE(band, wb, tri, k, gi, gj, smem); __syncthreads(); }
+    }
+}
+__device__ __forceinline__ void subgroup_row(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, const long long* __restrict__ tri,
+                                             double* __restrict__ wbuf, long long wstride, int k0, int ks, int sg, int i, double* __restrict__ smem) {
+    for (int c = 0; c < sg; ++c) {
+        const int k = ks + c;
+        if (c > 0) {                                              // A_ik -= sum over the sub-group's earlier columns k' of W_ik' L_kk'^T
+            GF_UPDATE_WIDE_TILE(band, wbuf + (size_t)(ks - k0) * wstride * NB2, wstride, tri, ks, c, i - k, 0, smem);
+            __syncthreads();
+        }
+        GF_PANEL_BODY(band, linv, dval, wbuf + (size_t)(k - k0) * wstride * NB2, tri, k, i - (k + 1), smem);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void subgroup_block_kernel(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, double* __restrict__ stat, const long long* __restrict__ tri,
+                                                             double* __restrict__ wbuf, long long wstride, int k0, int ks, int sg, int nblk_t) {
+    GF_NARROW_SMEM;
+    subgroup_block(band, linv, dval, stat, tri, wbuf, wstride, k0, ks, sg, nblk_t, smem);
+}
+__global__ __launch_bounds__(256) GF_WIDE_ATTR void subgroup_row_kernel(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, const long long* __restrict__ tri,
+                                                                        double* __restrict__ wbuf, long long wstride, int k0, int ks, int sg) {
+    GF_WIDE_SMEM;
+    subgroup_row(band, linv, dval, tri, wbuf, wstride, k0, ks, sg, ks + sg + (int)blockIdx.x, smem);
+}
 // the same update restricted to the first ncol trailing block columns (blockIdx = (row gi, column gj < ncol)): before a SUB-GROUP of a panel group starts, its columns
 // receive the products of all earlier panels of the group in one read-modify-write; the narrow updates then stay inside the sub-group.  A tile of the group's j-th column
 // is rewritten 1 + (j mod 4) times instead of j times (groups of 8, sub-groups of 4): the narrow updates are bound by exactly that traffic.
@@ -1109,6 +1151,26 @@ __global__ __launch_bounds__(256) GF_WIDE_ATTR void nd_update_mid_batch_kernel(c
     if ((int)blockIdx.y >= nc || (int)blockIdx.x >= nrow || blockIdx.x < blockIdx.y) return;
     GF_UPDATE_WIDE_TILE(arena + (size_t)F.tile_off * NB2, wbuf + (size_t)wofs[blockIdx.z] * NB2, F.nblk_t - 1, tri, k0, wprev, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
+// the sub-group kernels over the fronts of a tree height (blockIdx.x of the block kernel / blockIdx.y of the row kernel = front of the level's list)
+__global__ __launch_bounds__(256) void nd_subgroup_block_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs, const long long* __restrict__ tri,
+                                                                      double* __restrict__ arena, double* __restrict__ linv, double* __restrict__ dval, double* __restrict__ stat, double* __restrict__ wbuf,
+                                                                      int k0, int cs, int SG, int WP) {
+    GF_NARROW_SMEM;
+    const Front F = fronts[list[blockIdx.x]];
+    const int sg = min(SG, min(WP, F.nblk_e - k0) - cs);
+    if (sg <= 0) return;
+    subgroup_block(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, stat + 2 * F.kbase, tri, wbuf + (size_t)wofs[blockIdx.x] * NB2, F.nblk_t - 1,
+                   k0, k0 + cs, sg, F.nblk_t, smem);
+}
+__global__ __launch_bounds__(256) GF_WIDE_ATTR void nd_subgroup_row_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs,
+                                                                                 const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ linv,
+                                                                                 const double* __restrict__ dval, double* __restrict__ wbuf, int k0, int cs, int SG, int WP) {
+    GF_WIDE_SMEM;
+    const Front F = fronts[list[blockIdx.y]];
+    const int sg = min(SG, min(WP, F.nblk_e - k0) - cs), i = k0 + cs + sg + (int)blockIdx.x;
+    if (sg <= 0 || i >= F.nblk_t) return;
+    subgroup_row(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, tri, wbuf + (size_t)wofs[blockIdx.y] * NB2, F.nblk_t - 1, k0, k0 + cs, sg, i, smem);
+}
 __global__ __launch_bounds__(256) GF_WIDE_ATTR void nd_update_wide_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs,
                                                                    const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k0, int WP) {
     GF_WIDE_SMEM;
@@ -1441,6 +1503,9 @@ struct gfs_handle {
     unsigned char* d_row_ok = nullptr;            // gfs_set_row_mask: rows of d_valK that hold values (a rank's own rows of a sharded K); nullptr = all
     bool sweep_streams = true;                    // GF_SOLVER_SWEEP_STREAMS=0: the large fronts of a substitution one after the other on the sweep's stream
     bool prepared = false;                        // gfs_prepare_refactor has cleared the factor storage for the next gfs_refactor
+    int block_chain = 2;                      // GF_SOLVER_BLOCKCHAIN (bit 0: large fronts, bit 1: level-batched small fronts): two launches per sub-group (subgroup_block / subgroup_row) instead of diagonal tile / panel /
+                                                  // narrow update per block column.  C4, same box: none 0.2133 s, small fronts only 0.2115 s (default), large fronts only 0.2172 s (their triangle's sixteen tile
+                                                  // operations run one after the other in one workgroup, where the per-column launches spread them over the device): profiles/r05_solver_blockchain_ab.txt
     int macro_min_rows = 64;                      // GF_SOLVER_MACRO_ROWS: wide updates of the large fronts with at least this many block rows run in 128 x 128 macro tiles (alone the
                                                   // two forms are equal from 100 block rows on and the macro form loses below 60; C4: 0.2178 -> 0.2152 s; profiles/r05_solver_macro_ab.txt)
     int subgroup = 4;                             // GF_SOLVER_SUBGROUP: block columns per sub-group of a panel group (0: none)
@@ -1486,6 +1551,26 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
     //  update_mid_kernel for the next group's columns + an offset wide update on the partner, two sets of panel buffers: direct launches 0.2198 s without, 0.2189 s with it, the captured
     //  graph 0.2158 s -- and the ladder of dependencies between the two streams cannot be captured: hipGraphInstantiate of ROCm 7.2 walks every path through it (stack overflow; 270 GB
     //  of host memory with an unlimited stack).  profiles/r05_solver_lookahead_ab.txt; the code is in the history.)
+    if ((h->block_chain & 1) && GF_UPDATE_DMA && GF_LEAN_CHAIN && h->subgroup > 0 && h->subgroup <= 4) {     // two launches per sub-group (subgroup_block / subgroup_row)
+        const int SG = h->subgroup;
+        double* wset = h->s_wbuf[si];
+        for (int k0 = 0; k0 < F.nblk_e; k0 += WP) {
+            const int w = std::min(WP, F.nblk_e - k0);
+            for (int cs = 0; cs < w; cs += SG) {
+                const int ks = k0 + cs, sg = std::min(SG, w - cs), nbelow = F.nblk_t - (ks + sg);
+                if (cs > 0) hipLaunchKernelGGL(update_mid_kernel, dim3(F.nblk_t - ks, sg), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, cs);
+                hipLaunchKernelGGL(subgroup_block_kernel, dim3(1), dim3(256), 0, st, band, linv, dval, stat, h->d_tri, wset, wstride, k0, ks, sg, F.nblk_t);
+                if (nbelow > 0) hipLaunchKernelGGL(subgroup_row_kernel, dim3(nbelow), dim3(256), 0, st, band, linv, dval, h->d_tri, wset, wstride, k0, ks, sg);
+            }
+            const int nrow = F.nblk_t - (k0 + w);
+            if (nrow >= h->macro_min_rows) {
+                const long long nm = (nrow + 1) / 2;
+                hipLaunchKernelGGL(update_wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow);
+            } else if (nrow > 0)
+                hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow);
+        }
+        return;
+    }
     bool have_diag = false;
     for (int k0 = 0; k0 < F.nblk_e; k0 += WP) {                       // groups of WP block columns: one wide trailing update per group
         const int w = std::min(WP, F.nblk_e - k0);
@@ -1594,7 +1679,26 @@ static void nd_factor_levels(gfs_handle* h) {
             for (size_t i = 0; i < L.big.size(); ++i) { const int s = (int)(i % NS); nd_factor_front(h, L.big[i], h->st[s], s, false); }
         }
         const int WP = std::max(h->batch_panel_w, 1), kmax = (int)L.nk.size();
-        for (int k0 = 0; k0 < kmax; k0 += WP) {                          // panel groups, as nd_factor_front does for one front
+        const bool blockchain = (h->block_chain & 2) && GF_UPDATE_DMA && GF_LEAN_CHAIN && h->subgroup > 0 && h->subgroup <= 4;
+        for (int k0 = 0; blockchain && k0 < kmax; k0 += WP) {            // panel groups in sub-groups of two launches each (subgroup_block / subgroup_row), as nd_factor_front
+            const int SG = h->subgroup;
+            for (int cs = 0; cs < WP && k0 + cs < kmax; cs += SG) {
+                const int ks = k0 + cs, nk = L.nk[ks], mni = L.max_ni[ks];
+                if (cs > 0)
+                    hipLaunchKernelGGL(nd_update_mid_batch_kernel, dim3(mni + 1, std::min(SG, WP - cs), nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off,
+                                       h->d_tri, h->band, h->bwbuf, k0, cs, SG, WP);
+                hipLaunchKernelGGL(nd_subgroup_block_batch_kernel, dim3(nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off, h->d_tri, h->band, h->linv, h->dval,
+                                   h->stat, h->bwbuf, k0, cs, SG, WP);
+                if (mni > 0)
+                    hipLaunchKernelGGL(nd_subgroup_row_batch_kernel, dim3(mni, nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off, h->d_tri, h->band, h->linv,
+                                       h->dval, h->bwbuf, k0, cs, SG, WP);
+            }
+            const int mni0 = L.max_ni[k0];
+            if (mni0 > 0)
+                hipLaunchKernelGGL(nd_update_wide_batch_kernel, dim3((unsigned)((long long)mni0 * (mni0 + 1) / 2), L.nk[k0]), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off,
+                                   h->d_fwofs + L.off, h->d_tri, h->band, h->bwbuf, k0, WP);
+        }
+        for (int k0 = 0; !blockchain && k0 < kmax; k0 += WP) {           // panel groups, as nd_factor_front does for one front
             const int SG = h->subgroup > 0 ? h->subgroup : WP;
             for (int c = 0; c < WP && k0 + c < kmax; ++c) {
                 const int k = k0 + c, nk = L.nk[k], mni = L.max_ni[k];
@@ -1922,6 +2026,7 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
         if (const char* e = std::getenv("GF_SOLVER_PANEL_W")) h->panel_w = h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));
         if (const char* e = std::getenv("GF_SOLVER_FUSE_DIAG")) h->fuse_diag = std::atoi(e) != 0;
         if (const char* e = std::getenv("GF_SOLVER_SUBGROUP")) h->subgroup = std::max(0, std::min(8, std::atoi(e)));
+        if (const char* e = std::getenv("GF_SOLVER_BLOCKCHAIN")) h->block_chain = std::atoi(e);
         if (const char* e = std::getenv("GF_SOLVER_MACRO_ROWS")) h->macro_min_rows = std::max(2, std::atoi(e));
         if (const char* e = std::getenv("GF_SOLVER_SWEEP_STREAMS")) h->sweep_streams = std::atoi(e) != 0;
         if (const char* e = std::getenv("GF_SOLVER_BATCH_PANEL_W")) h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));      // panel groups of the level-batched small fronts
