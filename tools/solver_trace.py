@@ -87,3 +87,8 @@ for tag in ("<1>", "<3>"):
         live3 += d; last3 = t
     print("last substitution sweep %s: %d launches, wall %.2f ms, no kernel running %.2f ms; sum of durations (ms, launches): %s" % (
         tag, len(sw), (b - a) / 1e6, idle3 / 1e6, {k: (round(v / 1e6, 2), cnt[k]) for k, v in tot.most_common(12)}))
+# the whole-front substitution kernels of the last one-right-hand-side sweep, launch by launch (tree height ascending for the forward kernel, descending for the backward one)
+sel = [sw for sw in sweeps if any("<1>" in r[2] for r in sw) and any("nd_fwd_front" in r[2] for r in sw)]
+if sel:
+    for nm in ("nd_fwd_front_kernel<1>", "nd_bwd_front_kernel<1>"):
+        print(nm + " per launch (ms, workgroups):", [(round((r[1] - r[0]) / 1e6, 2), r[3]) for r in sel[-1] if r[2].startswith(nm)])
