@@ -2080,6 +2080,15 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
             std::vector<std::vector<int>> small(hmax + 1);
             const int fuse_max = getenv("GF_SOLVER_FUSE_MAX_BLK") ? std::max(0, std::min(atoi(getenv("GF_SOLVER_FUSE_MAX_BLK")), (int)gfs_handle::FUSE_MAX_BLK)) : gfs_handle::FUSE_MAX_BLK;      // test switch: small models through the large-front kernels
             for (int64_t t = 0; t < nfronts; ++t) (h->fronts[t].nblk_t <= fuse_max ? small[height[t]] : h->levels[height[t]].big).push_back((int)t);
+            // A whole-front kernel streams its front with ONE workgroup: fine while a height has hundreds of fronts, not near the top of the small fronts' heights -- at C4 the
+            // three heights with 61 / 21 / 4 fronts of up to 96 blocks took 4.7 of the forward kernel's 8.3 ms (profiles/r05_solver_c4_timeline.txt).  Where a height has few small
+            // fronts, the larger of them go with the large fronts (group kernels: a workgroup per block row, side by side on the side streams).
+            const int few_max = getenv("GF_SOLVER_FEW_FRONTS") ? atoi(getenv("GF_SOLVER_FEW_FRONTS")) : 24, few_blk = getenv("GF_SOLVER_FEW_BLK") ? atoi(getenv("GF_SOLVER_FEW_BLK")) : 32;
+            for (int l = 0; l <= hmax; ++l) if ((int)small[l].size() <= few_max) {
+                std::vector<int> keep;
+                for (int t : small[l]) (h->fronts[t].nblk_t > few_blk ? h->levels[l].big : keep).push_back(t);
+                small[l].swap(keep);
+            }
             std::vector<int> flat;
             for (int l = 0; l <= hmax; ++l) {
                 auto& L = h->levels[l]; L.off_small = (int)flat.size(); L.n_small = (int)small[l].size(); L.max_blk = 1;
