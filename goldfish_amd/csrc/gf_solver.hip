@@ -523,8 +523,9 @@ template <int HKT, bool NEG, class Src> __device__ __forceinline__ void mma_pair
         }
     }
 }
+// assign: the target tile holds nothing yet (a Schur-block tile at the front's first wide update, "lazy S" below): C = - sum instead of C -= sum, the tile is not read
 template <int HKT> __device__ __forceinline__ void update_wide_tile_dma(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w,
-                                                                        int gi, int gj, double* __restrict__ smem) {
+                                                                        int gi, int gj, double* __restrict__ smem, bool assign = false) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
     const int i = k0 + w + gi, j = k0 + w + gj;
     double* C = band + (size_t)(rowoff[i] + (gi - gj)) * NB2;
@@ -532,7 +533,7 @@ template <int HKT> __device__ __forceinline__ void update_wide_tile_dma(double* 
 #pragma unroll
     for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) acc[nj][rg] = C[(16 * wave + 4 * rg + kq) * NB + 16 * nj + l16];
+        for (int rg = 0; rg < 4; ++rg) acc[nj][rg] = assign ? 0.0 : C[(16 * wave + 4 * rg + kq) * NB + 16 * nj + l16];
     mma_pairs_dma<HKT, true>([&](int c, const double*& gA, const double*& gB) {
         const int k = k0 + c;
         gA = wbuf + (size_t)((long long)c * wstride + (i - (k + 1))) * NB2;
@@ -548,7 +549,7 @@ template <int HKT> __device__ __forceinline__ void update_wide_tile_dma(double* 
 //      bytes across the L2 <-> fabric interface (the wide updates move 368 KB per 64 KB target tile, profiles/r05_solver_traffic_before_xcd.txt), 8 instead of 20 ds_read_b128 and one
 //      barrier instead of four per 32 MFMAs of a wave.  Tiles above the diagonal and beyond the last block row are not computed (their wave still loads and synchronises).
 template <int HKT> __device__ __forceinline__ void update_wide_macro_dma(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w,
-                                                                         int mi, int mj, int nrow, double* __restrict__ smem) {
+                                                                         int mi, int mj, int nrow, double* __restrict__ smem, int jassign = 0x7fffffff) {
     constexpr int PART = 2 * NB * HKT, STAGE = 2 * PART, CPR = HKT / 2, RPP = 64 / CPR, NP = 32 / RPP, SPC = NB / HKT;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kq = lane >> 4, wi = wave >> 1, wj = wave & 1;
     const int gi = 2 * mi + wi, gj = 2 * mj + wj;
@@ -577,7 +578,7 @@ template <int HKT> __device__ __forceinline__ void update_wide_macro_dma(double*
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[a][b][t] = valid ? C[(16 * a + 4 * t + kq) * NB + 16 * b + l16] : 0.0;
+            for (int t = 0; t < 4; ++t) acc[a][b][t] = (valid && k0 + w + gj < jassign) ? C[(16 * a + 4 * t + kq) * NB + 16 * b + l16] : 0.0;
     const int ns = SPC * w;
     for (int s = 0; s < ns; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -747,17 +748,23 @@ __global__ __launch_bounds__(256) GF_WIDE_ATTR void update_mid_kernel(double* __
     if (blockIdx.x < blockIdx.y) return;
     GF_UPDATE_WIDE_TILE(band, wbuf, wstride, rowoff, k0, w, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
+// jassign: target tiles in block columns >= jassign are ASSIGNED (the front's Schur block at its first wide update; INT_MAX: none)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void update_wide_macro_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride,
-                                                                                                      const long long* __restrict__ rowoff, int k0, int w, int nrow) {
+                                                                                                      const long long* __restrict__ rowoff, int k0, int w, int nrow, int jassign) {
     __shared__ __attribute__((aligned(16))) double smem[8 * NB * HK];
     int mi, mj; tri_index((int)blockIdx.x, mi, mj);
-    update_wide_macro_dma<HK>(band, wbuf, wstride, rowoff, k0, w, mi, mj, nrow, smem);
+    update_wide_macro_dma<HK>(band, wbuf, wstride, rowoff, k0, w, mi, mj, nrow, smem, jassign);
 }
-__global__ __launch_bounds__(256) GF_WIDE_ATTR void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow) {
+__global__ __launch_bounds__(256) GF_WIDE_ATTR void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow,
+                                                                       int jassign) {
     GF_WIDE_SMEM;
     int gi, gj; tri_index((int)blockIdx.x, gi, gj);
     if (gi >= nrow) return;
+#if GF_UPDATE_DMA
+    update_wide_tile_dma<HK>(band, wbuf, wstride, rowoff, k0, w, gi, gj, smem, k0 + w + gj >= jassign);
+#else
     GF_UPDATE_WIDE_TILE(band, wbuf, wstride, rowoff, k0, w, gi, gj, smem);
+#endif
 }
 
 // forward substitution, block column k: y_k = L_kk^-1 b_k (every workgroup; workgroup 0 keeps it), b_{k+g} -= L_{k+g,k} y_k (workgroup g >= 1)
@@ -1172,18 +1179,24 @@ __global__ __launch_bounds__(256) GF_WIDE_ATTR void nd_subgroup_row_batch_kernel
     subgroup_row(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, tri, wbuf + (size_t)wofs[blockIdx.y] * NB2, F.nblk_t - 1, k0, k0 + cs, sg, i, smem);
 }
 __global__ __launch_bounds__(256) GF_WIDE_ATTR void nd_update_wide_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs,
-                                                                   const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k0, int WP) {
+                                                                   const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k0, int WP, int lazy) {
     GF_WIDE_SMEM;
     const Front F = fronts[list[blockIdx.y]];
     const int w = min(WP, F.nblk_e - k0), nrow = F.nblk_t - (k0 + w);
     if ((long long)blockIdx.x >= (long long)nrow * (nrow + 1) / 2) return;
     int gi, gj; tri_index((int)blockIdx.x, gi, gj);
     double* band = arena + (size_t)F.tile_off * NB2;
+#if GF_UPDATE_DMA
+    update_wide_tile_dma<HK>(band, wbuf + (size_t)wofs[blockIdx.y] * NB2, F.nblk_t - 1, tri, k0, w, gi, gj, smem, lazy && k0 == 0 && k0 + w + gj >= F.nblk_e);
+#else
     GF_UPDATE_WIDE_TILE(band, wbuf + (size_t)wofs[blockIdx.y] * NB2, F.nblk_t - 1, tri, k0, w, gi, gj, smem);
+#endif
 }
 // Schur complements of a list of children (no two of the same parent in one launch: one writer per entry) added into their parents
+// part: 0 = every entry; 1 = the entries that land in the parent's ELIMINATED block columns (before the parent is factored); 2 = those that land in its Schur block
+// (behind the parent's wide updates: "lazy S")
 __global__ __launch_bounds__(256) void nd_extend_add_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const int* __restrict__ pmap, const long long* __restrict__ tri,
-                                                                  double* __restrict__ arena) {
+                                                                  double* __restrict__ arena, int part) {
     const int c = list[blockIdx.y];
     const Front Fc = fronts[c]; const Front Fp = fronts[Fc.parent];
     const long long nbb = Fc.nblk_t - Fc.nblk_e;
@@ -1206,12 +1219,30 @@ __global__ __launch_bounds__(256) void nd_extend_add_batch_kernel(const Front* _
         else sC[t] = pos;
     }
     __syncthreads();
+    const int nep = Fp.ne_pad;
+    if (part) {                                                        // does any column of this tile land in the wanted part?  (the map is monotone in the tile's columns)
+        int lo = 0x7fffffff, hi = -1;
+        for (int cc = 0; cc < NB; ++cc) { const int C = sC[cc]; if (C >= 0) { lo = min(lo, C); hi = max(hi, C); } }
+        if (part == 1 ? lo >= nep : hi < nep) return;
+    }
     for (int q = threadIdx.x; q < NB2; q += 256) {
         const int rr = q >> 6, cc = q & 63;
         const int R = sR[rr], C = sC[cc];
         if (R < 0 || C < 0 || (gi == gj && rr < cc)) continue;          // the map is monotone: R >= C for an entry of the lower triangle
+        if (part && (part == 1) != (C < nep)) continue;
         arena[sRow[rr] - (long long)(C >> 6) * NB2 + (C & 63)] += src[q];
     }
+}
+// "lazy S": the factor storage is cleared only where something is ADDED before it is written -- the tiles of a front's eliminated block columns (K's entries, the
+// children's contributions); its Schur block is first written by its first wide update (assign) and receives the children's contributions behind it.  One workgroup per
+// (front, block row): the row's tiles in eliminated columns are the LAST min(I + 1, nblk_e) of the row (tile (I, J) sits at tri[I] + I - J).
+__global__ __launch_bounds__(256) void nd_zero_lpart_kernel(const Front* __restrict__ fronts, const int2* __restrict__ rows, const long long* __restrict__ tri, double* __restrict__ arena) {
+    const int2 fr = rows[blockIdx.x];
+    const Front F = fronts[fr.x];
+    const int I = fr.y, nt = min(I + 1, F.nblk_e);
+    double2* p = reinterpret_cast<double2*>(arena + (size_t)(F.tile_off + tri[I] + (I + 1 - nt)) * NB2);
+    const long long n2 = (long long)nt * NB2 / 2;
+    for (long long q = threadIdx.x; q < n2; q += 256) p[q] = double2{0.0, 0.0};
 }
 // front-local right-hand side: the eliminated dofs from the global vector (original numbering), zeros on the padding and the boundary part
 template <int NR> __global__ void nd_gather_rhs_kernel(Front F, const int* __restrict__ elim, Vec<NR> b, Vec<NR> w) {
@@ -1503,6 +1534,7 @@ struct gfs_handle {
     unsigned char* d_row_ok = nullptr;            // gfs_set_row_mask: rows of d_valK that hold values (a rank's own rows of a sharded K); nullptr = all
     bool sweep_streams = true;                    // GF_SOLVER_SWEEP_STREAMS=0: the large fronts of a substitution one after the other on the sweep's stream
     bool prepared = false;                        // gfs_prepare_refactor has cleared the factor storage for the next gfs_refactor
+    bool lazy_s = true; int2* d_zrows = nullptr; long long n_zrows = 0;      // GF_SOLVER_LAZY_S=0: the whole factor storage is cleared and every Schur block is read-modified-written from the start
     int block_chain = 2;                      // GF_SOLVER_BLOCKCHAIN (bit 0: large fronts, bit 1: level-batched small fronts): two launches per sub-group (subgroup_block / subgroup_row) instead of diagonal tile / panel /
                                                   // narrow update per block column.  C4, same box: none 0.2133 s, small fronts only 0.2115 s (default), large fronts only 0.2172 s (their triangle's sixteen tile
                                                   // operations run one after the other in one workgroup, where the per-column launches spread them over the device): profiles/r05_solver_blockchain_ab.txt
@@ -1534,7 +1566,7 @@ __global__ void nd_out_kernel(long long n, const double* __restrict__ src, doubl
     if (t < n) dst[t] = add ? dst[t] + src[t] : src[t];
 }
 // ---- multifrontal mode: work of one front on a stream with that stream's scratch (index NS = the main stream's)
-static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool extend_add = true) {
+static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool extend_add = true, bool lazy = false) {
     const Front& F = h->fronts[t];
     if (extend_add) for (int c : h->kids[t]) {
         const long long nbb = h->fronts[c].nblk_t - h->fronts[c].nblk_e;
@@ -1562,12 +1594,12 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
                 hipLaunchKernelGGL(subgroup_block_kernel, dim3(1), dim3(256), 0, st, band, linv, dval, stat, h->d_tri, wset, wstride, k0, ks, sg, F.nblk_t);
                 if (nbelow > 0) hipLaunchKernelGGL(subgroup_row_kernel, dim3(nbelow), dim3(256), 0, st, band, linv, dval, h->d_tri, wset, wstride, k0, ks, sg);
             }
-            const int nrow = F.nblk_t - (k0 + w);
+            const int nrow = F.nblk_t - (k0 + w), jassign = (lazy && k0 == 0) ? F.nblk_e : 0x7fffffff;
             if (nrow >= h->macro_min_rows) {
                 const long long nm = (nrow + 1) / 2;
-                hipLaunchKernelGGL(update_wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow);
+                hipLaunchKernelGGL(update_wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow, jassign);
             } else if (nrow > 0)
-                hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow);
+                hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow, jassign);
         }
         return;
     }
@@ -1588,7 +1620,7 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
             if (!have_diag) hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, st, band, linv, dval, h->d_tri, k, stat);
             have_diag = false;
             if (ni > 0) hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, st, band, linv, dval, wb, h->d_tri, k);
-            if (w == 1 && ni > 0) {
+            if (w == 1 && ni > 0 && !(lazy && k0 == 0)) {
                 have_diag = h->fuse_diag && k + 1 < F.nblk_e;
                 hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, st, band, wb, h->d_tri, k, ni, DiagNext{linv, dval, stat, have_diag ? 1 : 0});
             } else if (nin > 0) {
@@ -1596,12 +1628,13 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
                 hipLaunchKernelGGL(update_narrow_kernel, dim3(ni, nin), dim3(256), 0, st, band, wb, h->d_tri, k, DiagNext{linv, dval, stat, have_diag ? 1 : 0});
             }
         }
-        const int nrow = F.nblk_t - (k0 + w);
-        if (GF_UPDATE_DMA && w > 1 && nrow >= h->macro_min_rows) {
+        const int nrow = F.nblk_t - (k0 + w), jassign = (lazy && k0 == 0) ? F.nblk_e : 0x7fffffff;
+        const bool wide = w > 1 || (lazy && k0 == 0);                     // (a single-column group is otherwise served by update_kernel above)
+        if (GF_UPDATE_DMA && wide && nrow >= h->macro_min_rows) {
             const long long nm = (nrow + 1) / 2;
-            hipLaunchKernelGGL(update_wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow);
-        } else if (w > 1 && nrow > 0)
-            hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow);
+            hipLaunchKernelGGL(update_wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow, jassign);
+        } else if (wide && nrow > 0)
+            hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow, jassign);
     }
 }
 // the NR vectors of one kind out of NR workspaces (one workspace per right-hand side)
@@ -1669,14 +1702,16 @@ template <class Fn> static void nd_sweep_down(gfs_handle* h, Fn&& fn) {
 static void nd_factor_levels(gfs_handle* h) {
     constexpr int NS = gfs_handle::NS;
     for (const auto& L : h->flevels) {
+        const bool lazy = h->lazy_s && GF_UPDATE_DMA;
         for (const auto& R : L.rounds)
-            hipLaunchKernelGGL(nd_extend_add_batch_kernel, dim3((unsigned)R.max_tiles, (unsigned)R.n), dim3(256), 0, h->stream, h->d_fronts, h->d_ealist + R.off, h->d_pmap, h->d_tri, h->band);
+            hipLaunchKernelGGL(nd_extend_add_batch_kernel, dim3((unsigned)R.max_tiles, (unsigned)R.n), dim3(256), 0, h->stream, h->d_fronts, h->d_ealist + R.off, h->d_pmap, h->d_tri, h->band,
+                               lazy ? 1 : 0);
         int used = 0;
         if (!L.big.empty()) {
             HIPCHK(hipEventRecord(h->ev_main, h->stream));
             used = std::min<int>(NS, (int)L.big.size());
             for (int s = 0; s < used; ++s) HIPCHK(hipStreamWaitEvent(h->st[s], h->ev_main, 0));
-            for (size_t i = 0; i < L.big.size(); ++i) { const int s = (int)(i % NS); nd_factor_front(h, L.big[i], h->st[s], s, false); }
+            for (size_t i = 0; i < L.big.size(); ++i) { const int s = (int)(i % NS); nd_factor_front(h, L.big[i], h->st[s], s, false, lazy); }
         }
         const int WP = std::max(h->batch_panel_w, 1), kmax = (int)L.nk.size();
         const bool blockchain = (h->block_chain & 2) && GF_UPDATE_DMA && GF_LEAN_CHAIN && h->subgroup > 0 && h->subgroup <= 4;
@@ -1696,7 +1731,7 @@ static void nd_factor_levels(gfs_handle* h) {
             const int mni0 = L.max_ni[k0];
             if (mni0 > 0)
                 hipLaunchKernelGGL(nd_update_wide_batch_kernel, dim3((unsigned)((long long)mni0 * (mni0 + 1) / 2), L.nk[k0]), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off,
-                                   h->d_fwofs + L.off, h->d_tri, h->band, h->bwbuf, k0, WP);
+                                   h->d_fwofs + L.off, h->d_tri, h->band, h->bwbuf, k0, WP, lazy ? 1 : 0);
         }
         for (int k0 = 0; !blockchain && k0 < kmax; k0 += WP) {           // panel groups, as nd_factor_front does for one front
             const int SG = h->subgroup > 0 ? h->subgroup : WP;
@@ -1717,9 +1752,11 @@ static void nd_factor_levels(gfs_handle* h) {
             const int mni0 = L.max_ni[k0];                                // >= the trailing rows of every front of the group
             if (mni0 > 0)
                 hipLaunchKernelGGL(nd_update_wide_batch_kernel, dim3((unsigned)((long long)mni0 * (mni0 + 1) / 2), L.nk[k0]), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off,
-                                   h->d_fwofs + L.off, h->d_tri, h->band, h->bwbuf, k0, WP);
+                                   h->d_fwofs + L.off, h->d_tri, h->band, h->bwbuf, k0, WP, lazy ? 1 : 0);
         }
         for (int s = 0; s < used; ++s) { HIPCHK(hipEventRecord(h->ev[s], h->st[s])); HIPCHK(hipStreamWaitEvent(h->stream, h->ev[s], 0)); }
+        if (lazy) for (const auto& R : L.rounds)                         // the children's contributions to the Schur blocks of this height's fronts, behind their wide updates
+            hipLaunchKernelGGL(nd_extend_add_batch_kernel, dim3((unsigned)R.max_tiles, (unsigned)R.n), dim3(256), 0, h->stream, h->d_fronts, h->d_ealist + R.off, h->d_pmap, h->d_tri, h->band, 2);
     }
 }
 // run `body` (kernel launches, event record / wait on h->stream and the side streams) through a graph captured at the first call
@@ -2019,6 +2056,12 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
         h->d_elim = h->up(e32.data(), e32.size()); h->d_front_of = h->up(fo32.data(), fo32.size());
         h->d_bnd = h->up(b32.data(), b32.size()); h->d_pmap = h->up(pm32.data(), pm32.size());
         h->d_fronts = h->up(h->fronts.data(), h->fronts.size());
+        {   // (front, block row) pairs whose tiles in eliminated block columns are cleared before a factorisation ("lazy S": clear_factor_storage)
+            std::vector<int2> zr;
+            for (size_t t = 0; t < h->fronts.size(); ++t) if (h->fronts[t].nblk_e > 0) for (int I = 0; I < h->fronts[t].nblk_t; ++I) zr.push_back(int2{(int)t, I});
+            h->n_zrows = (long long)zr.size();
+            if (!zr.empty()) h->d_zrows = h->up(zr.data(), zr.size());
+        }
         h->valK = d_valK; h->nnz9 = 9 * (long long)nb_ptr[ncp];
         h->band = h->dalloc<double>((size_t)tiles * NB2);
         h->linv = h->dalloc<double>((size_t)kb * NB2);
@@ -2026,6 +2069,7 @@ static int create_nd_impl(int device, int64_t ncp, const int64_t* nb_ptr, const 
         if (const char* e = std::getenv("GF_SOLVER_PANEL_W")) h->panel_w = h->batch_panel_w = std::max(1, std::min(8, std::atoi(e)));
         if (const char* e = std::getenv("GF_SOLVER_FUSE_DIAG")) h->fuse_diag = std::atoi(e) != 0;
         if (const char* e = std::getenv("GF_SOLVER_SUBGROUP")) h->subgroup = std::max(0, std::min(8, std::atoi(e)));
+        if (const char* e = std::getenv("GF_SOLVER_LAZY_S")) h->lazy_s = std::atoi(e) != 0;
         if (const char* e = std::getenv("GF_SOLVER_BLOCKCHAIN")) h->block_chain = std::atoi(e);
         if (const char* e = std::getenv("GF_SOLVER_MACRO_ROWS")) h->macro_min_rows = std::max(2, std::atoi(e));
         if (const char* e = std::getenv("GF_SOLVER_SWEEP_STREAMS")) h->sweep_streams = std::atoi(e) != 0;
@@ -2182,12 +2226,18 @@ void gfs_destroy(gfs_handle* h) {
     delete h;
 }
 
+// what a factorisation adds into before it writes it: everything, or ("lazy S", nested dissection through nd_factor_levels) the fronts' eliminated block columns only
+static void clear_factor_storage(gfs_handle* h) {
+    if (h->nd && h->lazy_s && GF_UPDATE_DMA && h->batch_blk > 0 && h->d_zrows) {
+        if (h->n_zrows > 0) hipLaunchKernelGGL(nd_zero_lpart_kernel, dim3((unsigned)h->n_zrows), dim3(256), 0, h->stream, h->d_fronts, h->d_zrows, h->d_tri, h->band);
+    } else HIPCHK(hipMemsetAsync(h->band, 0, (size_t)h->ntiles * NB2 * sizeof(double), h->stream));
+}
 int gfs_prepare_refactor(gfs_handle* h) {
     if (!h) return sfail("gfs_prepare_refactor: null handle");
     try {
         HIPCHK(hipSetDevice(h->device));
         h->factored = false;
-        HIPCHK(hipMemsetAsync(h->band, 0, (size_t)h->ntiles * NB2 * sizeof(double), h->stream));
+        clear_factor_storage(h);
         h->prepared = true;
     } catch (const std::exception& ex) { return sfail(ex.what()); }
     return 0;
@@ -2205,7 +2255,7 @@ int gfs_refactor(gfs_handle* h) {
             hipLaunchKernelGGL(sumsq_kernel, dim3(240), dim3(256), 0, h->st[0], h->nnz9, h->valK, h->part_k);
             HIPCHK(hipEventRecord(h->ev_norm, h->st[0]));
         }
-        if (!h->prepared) HIPCHK(hipMemsetAsync(h->band, 0, (size_t)h->ntiles * NB2 * sizeof(double), h->stream));
+        if (!h->prepared) clear_factor_storage(h);
         h->prepared = false;
         if (h->nd) {
             hipLaunchKernelGGL(nd_scatter_kernel, dim3((unsigned)((h->ncp * 64 + 255) / 256)), dim3(256), 0, h->stream, h->ncp, h->nb_ptr, h->nb, h->general ? h->d_rev : nullptr, h->valK, h->d_fronts, h->d_front_of, h->d_order,

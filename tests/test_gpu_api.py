@@ -460,7 +460,7 @@ def test_device_solver_general_mode_in_both_factorisations():
 
 def test_device_solver_chain_variants_and_prepared_storage():
     """Round 5: the factorisation's chain in its forms -- diagonal tiles factored by the workgroup that completes them or in launches of their own (GF_SOLVER_FUSE_DIAG),
-    panel groups with and without sub-groups (GF_SOLVER_SUBGROUP), sub-groups in two launches or per block column (GF_SOLVER_BLOCKCHAIN), wide updates in 64 x 64 tiles or 128 x 128 macro tiles (GF_SOLVER_MACRO_ROWS) -- gives the same solution to round-off in the skyline, the level-batched and the large-front paths; and
+    panel groups with and without sub-groups (GF_SOLVER_SUBGROUP), sub-groups in two launches or per block column (GF_SOLVER_BLOCKCHAIN), Schur blocks first written by the wide update or cleared and accumulated (GF_SOLVER_LAZY_S), wide updates in 64 x 64 tiles or 128 x 128 macro tiles (GF_SOLVER_MACRO_ROWS) -- gives the same solution to round-off in the skyline, the level-batched and the large-front paths; and
     gfs_prepare_refactor: the factors are gone at once (a solve refuses), the next factorisation finds its storage cleared and returns the same bits."""
     from goldfish_amd import _solver
     from goldfish_amd.nonmatching_opt import NonMatchingOpt
@@ -473,7 +473,7 @@ def test_device_solver_chain_variants_and_prepared_storage():
     X = np.stack([nm.cp_iga[f] / w for f in range(3)], 1)
     for method, kw in (("skyline", {}), ("nd", dict(leaf=96)), ("nd", dict(leaf=400)), ("nd-large", dict(leaf=96)), ("nd-large", dict(leaf=400))):
         ref = None
-        for env in ({}, {"GF_SOLVER_BLOCKCHAIN": "3"}, {"GF_SOLVER_BLOCKCHAIN": "3", "GF_SOLVER_SUBGROUP": "3", "GF_SOLVER_PANEL_W": "7"}, {"GF_SOLVER_BLOCKCHAIN": "0"},
+        for env in ({}, {"GF_SOLVER_LAZY_S": "0"}, {"GF_SOLVER_LAZY_S": "0", "GF_SOLVER_BLOCKCHAIN": "0"}, {"GF_SOLVER_BLOCKCHAIN": "3"}, {"GF_SOLVER_BLOCKCHAIN": "3", "GF_SOLVER_SUBGROUP": "3", "GF_SOLVER_PANEL_W": "7"}, {"GF_SOLVER_BLOCKCHAIN": "0"},
                     {"GF_SOLVER_BLOCKCHAIN": "0", "GF_SOLVER_FUSE_DIAG": "0"}, {"GF_SOLVER_BLOCKCHAIN": "0", "GF_SOLVER_SUBGROUP": "2"}, {"GF_SOLVER_SUBGROUP": "0"}, {"GF_SOLVER_SUBGROUP": "2"}, {"GF_SOLVER_SUBGROUP": "3", "GF_SOLVER_PANEL_W": "7"},
                     {"GF_SOLVER_MACRO_ROWS": "2"}, {"GF_SOLVER_MACRO_ROWS": "3", "GF_SOLVER_PANEL_W": "5"}):      # the large fronts' wide updates in 128 x 128 macro tiles (odd and even numbers of block rows)
             if method == "nd-large":                         # every front through the large fronts' kernels (factorisation: per front on streams; substitutions: per block-column group)
