@@ -1,6 +1,6 @@
 """Measurement + model (not product): the distributed factorisation (goldfish_amd/_dsolver.py) of C4's K for 2, 4, 8 ranks from the symbolic phase alone -- work of
 the replicated top, largest per-rank share of the subtrees, bytes of the Schur-complement all-gather and of the boundary-contribution all-gather -- priced with the
-rates measured on one MI355X (profiles/r05_device_solver_bench.txt: 40 TFLOP/s for a factorisation; all-gather over xGMI taken as 300 GB/s per GPU).
+rates measured on one MI355X (profiles/r05_v7_bench.json: 43 TFLOP/s for a factorisation; all-gather over xGMI taken as 300 GB/s per GPU).
 Round 5: the K VALUE EXCHANGE is a term of the model -- this code replicates K's values on every rank before it factors
 (ShardedDeviceModel.refresh_k_values: one all-gather of the owned value rows as device buffers + one device gather into the global CSR order, 9 x 8 bytes per
 block of the pattern): (world - 1) / world of K's bytes in per rank over xGMI, and a pass over 2 x K's bytes at HBM rate for the permutation."""
@@ -27,7 +27,7 @@ ne, nbd, be, bb = sym.front_dofs()
 bt = be + bb
 flop = 2.0 * 64 ** 3 * _dsolver.front_work(sym)
 tiles = bt * (bt + 1) // 2
-RATE, XGMI, HBM = 40e12, 300e9, 4.5e12       # round 5: 40.4 TFLOP/s per factorisation (profiles/r05_device_solver_bench.txt)
+RATE, XGMI, HBM = 43e12, 300e9, 4.5e12       # end of round 5: 43.3 - 43.8 TFLOP/s per factorisation (profiles/r05_v7_bench.json)
 k_bytes = 9.0 * 8.0 * float(nb_ptr[-1])                  # K's values: 9 doubles per block of the control-point pattern
 print(name + ": %d fronts, %.2f Tflop, %.1f GB of tiles; one GPU: %.0f ms per factorisation at %.0f TFLOP/s" % (sym.nfronts, flop.sum() / 1e12, tiles.sum() * 32768 / 1e9, flop.sum() / RATE * 1e3, RATE / 1e12))
 for world in ((8, 16) if name == "C5" else (2, 4, 8)):
