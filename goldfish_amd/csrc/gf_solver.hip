@@ -666,6 +666,8 @@ static_assert(4 * NB * HK * sizeof(double) <= 65536, "the LDS-DMA destination (M
 #define GF_UPDATE_TILE update_tile
 #endif
 #else
+#undef GF_LEAN_CHAIN
+#define GF_LEAN_CHAIN 0
 #define GF_UPDATE_WIDE_TILE update_wide_tile
 #define GF_WIDE_SMEM GF_TILE_SMEM
 #define GF_WIDE_ATTR
