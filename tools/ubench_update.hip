@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
     { const int nm = (nrow + 1) / 2; time("V10 LDS-DMA, 128 x 128 macro tiles (one tile per wave), parts of 16 k, 64 KB, two workgroups per CU", [&] { hipLaunchKernelGGL(wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); }); }
     time("V6 LDS-DMA, parts of 32 k, 64 KB of LDS (two workgroups per CU)", [&] { hipLaunchKernelGGL(wide_dma_kernel<32>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
     time("V7 LDS-DMA, whole tiles, 128 KB of LDS (one workgroup per CU)", [&] { hipLaunchKernelGGL(wide_dma_kernel<64>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
-    time("V0 update_wide_kernel (library)", [&] { hipLaunchKernelGGL(update_wide_kernel, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
+    time("V0 update_wide_kernel (library)", [&] { hipLaunchKernelGGL(update_wide_kernel, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow, 0x7fffffff); });
     time("V1 no operand loads in the loop", [&] { hipLaunchKernelGGL(ub_kernel<1>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
     time("V2 no parking, no barriers (MFMA + LDS operand reads)", [&] { hipLaunchKernelGGL(ub_kernel<2>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
     time("V3 MFMAs on register operands only", [&] { hipLaunchKernelGGL(ub_kernel<3>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
