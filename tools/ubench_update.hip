@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
             double e = 0, m = 0; for (size_t q = 0; q < r0.size(); ++q) { e = std::max(e, std::fabs(r0[q] - r1[q])); m = std::max(m, std::fabs(r0[q])); }
             printf("register-staged against %s: max difference %.2e of %.2e (%s)\n", name, e, m, e <= 1e-12 * m ? "ok" : "MISMATCH");
         };
-        check("LDS-DMA, parts of 32 k (library form)", [&] { hipLaunchKernelGGL(wide_kernel<1>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
+        check("LDS-DMA through the tile function of the library (parts of HK k)", [&] { hipLaunchKernelGGL(wide_kernel<1>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
         check("LDS-DMA, parts of 16 k", [&] { hipLaunchKernelGGL(wide_dma_kernel<16>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
         check("LDS-DMA, parts of 8 k", [&] { hipLaunchKernelGGL(wide_dma_kernel<8>, dim3(grid), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); });
         { const int nm = (nrow + 1) / 2; check("LDS-DMA, 128 x 128 macro tiles", [&] { hipLaunchKernelGGL(wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, 0, band, wbuf, (long long)nblk, d_tri, 0, w, nrow); }); }
