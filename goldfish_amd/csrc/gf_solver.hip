@@ -491,7 +491,8 @@ template <int HKT> __device__ __forceinline__ void glds_part(const double* __res
     }
 }
 // acc (+ / -)= sum over ncol pairs of 64 x 64 tiles (A_c, B_c) of A_c B_c^T; src(c, gA, gB) names pair c.  Stage s = (pair s / SPC, part s % SPC) lives in buffer s % 2.
-template <int HKT, bool NEG, class Src> __device__ __forceinline__ void mma_pairs_dma(Src&& src, int ncol, d4 (&acc)[4], double* __restrict__ smem) {
+// SCALE: the A operand of pair c is multiplied by sdv[64 c + k] on its way into the product (W = L D formed on the fly from the L tiles: "W-less" updates below)
+template <int HKT, bool NEG, bool SCALE = false, class Src> __device__ __forceinline__ void mma_pairs_dma(Src&& src, int ncol, d4 (&acc)[4], double* __restrict__ smem, const double* __restrict__ sdv = nullptr) {
     constexpr int PART = NB * HKT, STAGE = 2 * PART, CPR = HKT / 2, SPC = NB / HKT;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
     auto issue = [&](int s) {
@@ -512,7 +513,11 @@ template <int HKT, bool NEG, class Src> __device__ __forceinline__ void mma_pair
 #pragma unroll
         for (int rd = 0; rd < HKT / 8; ++rd) {
             const int off = 2 * ((4 * rd + kq) ^ (l16 & (CPR - 1)));
-            const double2 a = *reinterpret_cast<const double2*>(bufA + off);
+            double2 a = *reinterpret_cast<const double2*>(bufA + off);
+            if constexpr (SCALE) {
+                const double2 dv = *reinterpret_cast<const double2*>(sdv + 64 * (s / SPC) + HKT * (s % SPC) + 2 * (4 * rd + kq));
+                a.x *= dv.x; a.y *= dv.y;
+            }
             double2 b[4];
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) b[nj] = *reinterpret_cast<const double2*>(bufB + nj * 16 * HKT + off);
@@ -524,7 +529,10 @@ template <int HKT, bool NEG, class Src> __device__ __forceinline__ void mma_pair
     }
 }
 // assign: the target tile holds nothing yet (a Schur-block tile at the front's first wide update, "lazy S" below): C = - sum instead of C -= sum, the tile is not read
-template <int HKT> __device__ __forceinline__ void update_wide_tile_dma(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w,
+// WL ("W-less"): wbuf is the front's dval (d of block column k at wbuf + 64 k); the A operand of column k is the tile L_ik itself, scaled by d on its way into the
+// product, instead of the copy W_ik = L_ik D_k the panel kernels otherwise keep -- the panels write one tile less, and A and B operands come from the same tiles
+// (smem: the two stage buffers + 8 x 64 doubles for the d of the group's columns)
+template <int HKT, bool WL = false> __device__ __forceinline__ void update_wide_tile_dma(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w,
                                                                         int gi, int gj, double* __restrict__ smem, bool assign = false) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
     const int i = k0 + w + gi, j = k0 + w + gj;
@@ -534,11 +542,13 @@ template <int HKT> __device__ __forceinline__ void update_wide_tile_dma(double* 
     for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) acc[nj][rg] = assign ? 0.0 : C[(16 * wave + 4 * rg + kq) * NB + 16 * nj + l16];
-    mma_pairs_dma<HKT, true>([&](int c, const double*& gA, const double*& gB) {
+    double* sdv = smem + 4 * NB * HKT;
+    if constexpr (WL) for (int q = tid; q < 64 * w; q += 256) sdv[q] = wbuf[(size_t)64 * k0 + q];           // visible behind the first stage's barrier
+    mma_pairs_dma<HKT, true, WL>([&](int c, const double*& gA, const double*& gB) {
         const int k = k0 + c;
-        gA = wbuf + (size_t)((long long)c * wstride + (i - (k + 1))) * NB2;
+        gA = WL ? band + (size_t)(rowoff[i] + (i - k)) * NB2 : wbuf + (size_t)((long long)c * wstride + (i - (k + 1))) * NB2;
         gB = band + (size_t)(rowoff[j] + (j - k)) * NB2;
-    }, w, acc, smem);
+    }, w, acc, smem, sdv);
 #pragma unroll
     for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
@@ -617,13 +627,13 @@ template <int HKT> __device__ __forceinline__ void update_wide_macro_dma(double*
     }
 }
 // panel tile in the same form: W = A_ik L_kk^-T (to wbuf), L_ik = W D_k^-1 (in place: the tile's last part has landed in LDS before anything is stored)
-template <int HKT> __device__ __forceinline__ void panel_body_dma(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf,
+template <int HKT, bool WL = false> __device__ __forceinline__ void panel_body_dma(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf,
                                                                   const long long* __restrict__ rowoff, int k, int g, double* __restrict__ smem) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double* A = band + (size_t)(rowoff[k + 1 + g] + (g + 1)) * NB2;
     d4 acc[4] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
     mma_pairs_dma<HKT, false>([&](int, const double*& gA, const double*& gB) { gA = A; gB = linv + (size_t)k * NB2; }, 1, acc, smem);
-    double* W = wbuf + (size_t)g * NB2;
+    double* W = WL ? nullptr : wbuf + (size_t)g * NB2;
 #pragma unroll
     for (int nj = 0; nj < 4; ++nj) {
         const int c = 16 * nj + (lane & 15);
@@ -631,7 +641,8 @@ template <int HKT> __device__ __forceinline__ void panel_body_dma(double* __rest
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             const int r = 16 * wave + 4 * rg + (lane >> 4);
-            W[r * NB + c] = acc[nj][rg]; A[r * NB + c] = acc[nj][rg] * di;
+            if constexpr (!WL) W[r * NB + c] = acc[nj][rg];
+            A[r * NB + c] = acc[nj][rg] * di;
         }
     }
 }
@@ -643,13 +654,16 @@ static_assert(4 * NB * HK * sizeof(double) <= 65536, "the LDS-DMA destination (M
 #ifndef GF_UPDATE_DMA
 #define GF_UPDATE_DMA 1        // 0: operand tiles through registers (update_wide_tile), the form of rounds 3 - 4
 #endif
+#ifndef GF_WLESS_BATCH
+#define GF_WLESS_BATCH 1       // the level-batched small fronts (two-launch sub-groups, GF_SOLVER_BLOCKCHAIN bit 1) keep no W = L D panels: their updates scale L by d on the fly
+#endif
 #ifndef GF_WIDE_WAVES
 #define GF_WIDE_WAVES 4        // workgroups of a wide update per CU.  Three would leave 64 KB of LDS and a third of the registers of every CU free for the chain kernels of the
 #endif                         // other fronts (panel 32 KB; narrow update + diagonal tile 58 KB): their launches then take 15 / 30 us instead of 65 - 190 us beside the wide updates, but the
                                // wide updates lose more than the chains gain -- C4, same box, median of 7: 0.2238 s with three, 0.2210 s with four (profiles/r05_solver_variants_ab.txt)
 #if GF_UPDATE_DMA
 #define GF_UPDATE_WIDE_TILE update_wide_tile_dma<HK>
-#define GF_WIDE_SMEM __shared__ __attribute__((aligned(16))) double smem[4 * NB * HK]
+#define GF_WIDE_SMEM __shared__ __attribute__((aligned(16))) double smem[4 * NB * HK + 8 * NB]
 #define GF_WIDE_ATTR __attribute__((amdgpu_waves_per_eu(1, GF_WIDE_WAVES)))
 #ifndef GF_LEAN_CHAIN
 #define GF_LEAN_CHAIN 1        // 0: panel and narrow update through registers with two whole operand tiles in LDS (67.6 KB), the form of rounds 3 - 4
@@ -707,7 +721,7 @@ __global__ __launch_bounds__(256) void update_narrow_kernel(double* __restrict__
 //      row's own lazy update from the sub-group's earlier columns (left-looking: W_i,c' is this workgroup's, L_k,c' the triangle's) -- a row's tiles are read once and its W / L
 //      written once, where panel + narrow updates re-read and re-wrote them per column.  Both use the tile kernels' device functions; a workgroup sees its own global writes
 //      behind __syncthreads().
-__device__ __forceinline__ void subgroup_block(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, double* __restrict__ stat, const long long* __restrict__ tri,
+template <bool WL> __device__ __forceinline__ void subgroup_block(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, double* __restrict__ stat, const long long* __restrict__ tri,
                                                double* __restrict__ wbuf, long long wstride, int k0, int ks, int sg, int nblk_t, double* __restrict__ smem) {
     for (int c = 0; c < sg; ++c) {
         const int k = ks + c;
@@ -715,32 +729,40 @@ __device__ __forceinline__ void subgroup_block(double* __restrict__ band, double
         __syncthreads();
         double* wb = wbuf + (size_t)(k - k0) * wstride * NB2;
         const int rin = min(ks + sg, nblk_t) - (k + 1);           // rows of the triangle below block column k
-        for (int g = 0; g < rin; ++g) { GF_PANEL_BODY(band, linv, dval, wb, tri, k, g, smem); __syncthreads(); }
-        for (int gj = 0; gj < rin; ++gj)
-            for (int gi = gj; gi < rin; ++gi) { GF_UPDATE_TILE(band, wb, tri, k, gi, gj, smem); __syncthreads(); }
+        if constexpr (WL) {                                       // (the d of block column k: dval + 64 k, written by diag_body above)
+            for (int g = 0; g < rin; ++g) { panel_body_dma<HK, true>(band, linv, dval, nullptr, tri, k, g, smem); __syncthreads(); }
+            for (int gj = 0; gj < rin; ++gj)
+                for (int gi = gj; gi < rin; ++gi) { update_wide_tile_dma<HK, true>(band, dval, 0, tri, k, 1, gi, gj, smem); __syncthreads(); }
+        } else {
+            for (int g = 0; g < rin; ++g) { GF_PANEL_BODY(band, linv, dval, wb, tri, k, g, smem); __syncthreads(); }
+            for (int gj = 0; gj < rin; ++gj)
+                for (int gi = gj; gi < rin; ++gi) { GF_UPDATE_TILE(band, wb, tri, k, gi, gj, smem); __syncthreads(); }
+        }
     }
 }
-__device__ __forceinline__ void subgroup_row(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, const long long* __restrict__ tri,
+template <bool WL> __device__ __forceinline__ void subgroup_row(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, const long long* __restrict__ tri,
                                              double* __restrict__ wbuf, long long wstride, int k0, int ks, int sg, int i, double* __restrict__ smem) {
     for (int c = 0; c < sg; ++c) {
         const int k = ks + c;
         if (c > 0) {                                              // A_ik -= sum over the sub-group's earlier columns k' of W_ik' L_kk'^T
-            GF_UPDATE_WIDE_TILE(band, wbuf + (size_t)(ks - k0) * wstride * NB2, wstride, tri, ks, c, i - k, 0, smem);
+            if constexpr (WL) update_wide_tile_dma<HK, true>(band, dval, 0, tri, ks, c, i - k, 0, smem);
+            else GF_UPDATE_WIDE_TILE(band, wbuf + (size_t)(ks - k0) * wstride * NB2, wstride, tri, ks, c, i - k, 0, smem);
             __syncthreads();
         }
-        GF_PANEL_BODY(band, linv, dval, wbuf + (size_t)(k - k0) * wstride * NB2, tri, k, i - (k + 1), smem);
+        if constexpr (WL) panel_body_dma<HK, true>(band, linv, dval, nullptr, tri, k, i - (k + 1), smem);
+        else GF_PANEL_BODY(band, linv, dval, wbuf + (size_t)(k - k0) * wstride * NB2, tri, k, i - (k + 1), smem);
         __syncthreads();
     }
 }
 __global__ __launch_bounds__(256) void subgroup_block_kernel(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, double* __restrict__ stat, const long long* __restrict__ tri,
                                                              double* __restrict__ wbuf, long long wstride, int k0, int ks, int sg, int nblk_t) {
     GF_NARROW_SMEM;
-    subgroup_block(band, linv, dval, stat, tri, wbuf, wstride, k0, ks, sg, nblk_t, smem);
+    subgroup_block<false>(band, linv, dval, stat, tri, wbuf, wstride, k0, ks, sg, nblk_t, smem);
 }
 __global__ __launch_bounds__(256) GF_WIDE_ATTR void subgroup_row_kernel(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, const long long* __restrict__ tri,
                                                                         double* __restrict__ wbuf, long long wstride, int k0, int ks, int sg) {
     GF_WIDE_SMEM;
-    subgroup_row(band, linv, dval, tri, wbuf, wstride, k0, ks, sg, ks + sg + (int)blockIdx.x, smem);
+    subgroup_row<false>(band, linv, dval, tri, wbuf, wstride, k0, ks, sg, ks + sg + (int)blockIdx.x, smem);
 }
 // the same update restricted to the first ncol trailing block columns (blockIdx = (row gi, column gj < ncol)): before a SUB-GROUP of a panel group starts, its columns
 // receive the products of all earlier panels of the group in one read-modify-write; the narrow updates then stay inside the sub-group.  A tile of the group's j-th column
@@ -1158,7 +1180,11 @@ __global__ __launch_bounds__(256) GF_WIDE_ATTR void nd_update_mid_batch_kernel(c
     const Front F = fronts[list[blockIdx.z]];
     const int w = min(WP, F.nblk_e - k0), nc = min(ncol, w - wprev), nrow = F.nblk_t - (k0 + wprev);
     if ((int)blockIdx.y >= nc || (int)blockIdx.x >= nrow || blockIdx.x < blockIdx.y) return;
+#if GF_UPDATE_DMA && GF_WLESS_BATCH
+    update_wide_tile_dma<HK, true>(arena + (size_t)F.tile_off * NB2, wbuf + (size_t)F.kbase * NB, 0, tri, k0, wprev, (int)blockIdx.x, (int)blockIdx.y, smem);      // wbuf: the handle's dval here
+#else
     GF_UPDATE_WIDE_TILE(arena + (size_t)F.tile_off * NB2, wbuf + (size_t)wofs[blockIdx.z] * NB2, F.nblk_t - 1, tri, k0, wprev, (int)blockIdx.x, (int)blockIdx.y, smem);
+#endif
 }
 // the sub-group kernels over the fronts of a tree height (blockIdx.x of the block kernel / blockIdx.y of the row kernel = front of the level's list)
 __global__ __launch_bounds__(256) void nd_subgroup_block_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs, const long long* __restrict__ tri,
@@ -1168,8 +1194,8 @@ __global__ __launch_bounds__(256) void nd_subgroup_block_batch_kernel(const Fron
     const Front F = fronts[list[blockIdx.x]];
     const int sg = min(SG, min(WP, F.nblk_e - k0) - cs);
     if (sg <= 0) return;
-    subgroup_block(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, stat + 2 * F.kbase, tri, wbuf + (size_t)wofs[blockIdx.x] * NB2, F.nblk_t - 1,
-                   k0, k0 + cs, sg, F.nblk_t, smem);
+    subgroup_block<GF_WLESS_BATCH != 0>(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, stat + 2 * F.kbase, tri, wbuf + (size_t)wofs[blockIdx.x] * NB2,
+                                        F.nblk_t - 1, k0, k0 + cs, sg, F.nblk_t, smem);
 }
 __global__ __launch_bounds__(256) GF_WIDE_ATTR void nd_subgroup_row_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs,
                                                                                  const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ linv,
@@ -1178,7 +1204,8 @@ __global__ __launch_bounds__(256) GF_WIDE_ATTR void nd_subgroup_row_batch_kernel
     const Front F = fronts[list[blockIdx.y]];
     const int sg = min(SG, min(WP, F.nblk_e - k0) - cs), i = k0 + cs + sg + (int)blockIdx.x;
     if (sg <= 0 || i >= F.nblk_t) return;
-    subgroup_row(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, tri, wbuf + (size_t)wofs[blockIdx.y] * NB2, F.nblk_t - 1, k0, k0 + cs, sg, i, smem);
+    subgroup_row<GF_WLESS_BATCH != 0>(arena + (size_t)F.tile_off * NB2, linv + (size_t)F.kbase * NB2, dval + (size_t)F.kbase * NB, tri, wbuf + (size_t)wofs[blockIdx.y] * NB2, F.nblk_t - 1, k0, k0 + cs, sg, i,
+                                      smem);
 }
 __global__ __launch_bounds__(256) GF_WIDE_ATTR void nd_update_wide_batch_kernel(const Front* __restrict__ fronts, const int* __restrict__ list, const long long* __restrict__ wofs,
                                                                    const long long* __restrict__ tri, double* __restrict__ arena, const double* __restrict__ wbuf, int k0, int WP, int lazy) {
@@ -1189,7 +1216,11 @@ __global__ __launch_bounds__(256) GF_WIDE_ATTR void nd_update_wide_batch_kernel(
     int gi, gj; tri_index((int)blockIdx.x, gi, gj);
     double* band = arena + (size_t)F.tile_off * NB2;
 #if GF_UPDATE_DMA
+#if GF_WLESS_BATCH
+    update_wide_tile_dma<HK, true>(band, wbuf + (size_t)F.kbase * NB, 0, tri, k0, w, gi, gj, smem, lazy && k0 == 0 && k0 + w + gj >= F.nblk_e);                        // wbuf: the handle's dval here
+#else
     update_wide_tile_dma<HK>(band, wbuf + (size_t)wofs[blockIdx.y] * NB2, F.nblk_t - 1, tri, k0, w, gi, gj, smem, lazy && k0 == 0 && k0 + w + gj >= F.nblk_e);
+#endif
 #else
     GF_UPDATE_WIDE_TILE(band, wbuf + (size_t)wofs[blockIdx.y] * NB2, F.nblk_t - 1, tri, k0, w, gi, gj, smem);
 #endif
@@ -1701,6 +1732,12 @@ template <class Fn> static void nd_sweep_down(gfs_handle* h, Fn&& fn) {
     }
 }
 // factorisation sweep by tree height
+// what the batched mid / wide updates get in their W slot: the W panels, or (W-less build) the handle's dval
+#if GF_UPDATE_DMA && GF_WLESS_BATCH
+#define GF_BATCH_WSRC(h) ((const double*)(h)->dval)
+#else
+#define GF_BATCH_WSRC(h) ((const double*)(h)->bwbuf)
+#endif
 static void nd_factor_levels(gfs_handle* h) {
     constexpr int NS = gfs_handle::NS;
     for (const auto& L : h->flevels) {
@@ -1723,7 +1760,7 @@ static void nd_factor_levels(gfs_handle* h) {
                 const int ks = k0 + cs, nk = L.nk[ks], mni = L.max_ni[ks];
                 if (cs > 0)
                     hipLaunchKernelGGL(nd_update_mid_batch_kernel, dim3(mni + 1, std::min(SG, WP - cs), nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off,
-                                       h->d_tri, h->band, h->bwbuf, k0, cs, SG, WP);
+                                       h->d_tri, h->band, GF_BATCH_WSRC(h), k0, cs, SG, WP);
                 hipLaunchKernelGGL(nd_subgroup_block_batch_kernel, dim3(nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off, h->d_tri, h->band, h->linv, h->dval,
                                    h->stat, h->bwbuf, k0, cs, SG, WP);
                 if (mni > 0)
@@ -1733,7 +1770,7 @@ static void nd_factor_levels(gfs_handle* h) {
             const int mni0 = L.max_ni[k0];
             if (mni0 > 0)
                 hipLaunchKernelGGL(nd_update_wide_batch_kernel, dim3((unsigned)((long long)mni0 * (mni0 + 1) / 2), L.nk[k0]), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off,
-                                   h->d_fwofs + L.off, h->d_tri, h->band, h->bwbuf, k0, WP, lazy ? 1 : 0);
+                                   h->d_fwofs + L.off, h->d_tri, h->band, GF_BATCH_WSRC(h), k0, WP, lazy ? 1 : 0);
         }
         for (int k0 = 0; !blockchain && k0 < kmax; k0 += WP) {           // panel groups, as nd_factor_front does for one front
             const int SG = h->subgroup > 0 ? h->subgroup : WP;
@@ -1741,7 +1778,7 @@ static void nd_factor_levels(gfs_handle* h) {
                 const int k = k0 + c, nk = L.nk[k], mni = L.max_ni[k];
                 if (c > 0 && c % SG == 0)                                // a sub-group starts (nd_factor_front)
                     hipLaunchKernelGGL(nd_update_mid_batch_kernel, dim3(mni + 1, std::min(SG, WP - c), nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_fwofs + L.off,
-                                       h->d_tri, h->band, h->bwbuf, k0, c, SG, WP);
+                                       h->d_tri, h->band, GF_BATCH_WSRC(h), k0, c, SG, WP);
                 if (c % SG == 0 || !h->fuse_diag)
                     hipLaunchKernelGGL(nd_diag_batch_kernel, dim3(nk), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off, h->d_tri, h->band, h->linv, h->dval, h->stat, k);
                 if (mni <= 0) continue;
@@ -1754,7 +1791,7 @@ static void nd_factor_levels(gfs_handle* h) {
             const int mni0 = L.max_ni[k0];                                // >= the trailing rows of every front of the group
             if (mni0 > 0)
                 hipLaunchKernelGGL(nd_update_wide_batch_kernel, dim3((unsigned)((long long)mni0 * (mni0 + 1) / 2), L.nk[k0]), dim3(256), 0, h->stream, h->d_fronts, h->d_flist + L.off,
-                                   h->d_fwofs + L.off, h->d_tri, h->band, h->bwbuf, k0, WP, lazy ? 1 : 0);
+                                   h->d_fwofs + L.off, h->d_tri, h->band, GF_BATCH_WSRC(h), k0, WP, lazy ? 1 : 0);
         }
         for (int s = 0; s < used; ++s) { HIPCHK(hipEventRecord(h->ev[s], h->st[s])); HIPCHK(hipStreamWaitEvent(h->stream, h->ev[s], 0)); }
         if (lazy) for (const auto& R : L.rounds)                         // the children's contributions to the Schur blocks of this height's fronts, behind their wide updates
