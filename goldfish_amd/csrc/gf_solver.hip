@@ -558,7 +558,7 @@ template <int HKT, bool WL = false> __device__ __forceinline__ void update_wide_
 //      panels staged by LDS-DMA as above (parts of 16 k: 2 x 128 rows x 16 k per stage, two stages = 64 KB, two workgroups per CU).  Per tile product that is half the operand
 //      bytes across the L2 <-> fabric interface (the wide updates move 368 KB per 64 KB target tile, profiles/r05_solver_traffic_before_xcd.txt), 8 instead of 20 ds_read_b128 and one
 //      barrier instead of four per 32 MFMAs of a wave.  Tiles above the diagonal and beyond the last block row are not computed (their wave still loads and synchronises).
-template <int HKT> __device__ __forceinline__ void update_wide_macro_dma(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w,
+template <int HKT, bool WL = false> __device__ __forceinline__ void update_wide_macro_dma(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w,
                                                                          int mi, int mj, int nrow, double* __restrict__ smem, int jassign = 0x7fffffff) {
     constexpr int PART = 2 * NB * HKT, STAGE = 2 * PART, CPR = HKT / 2, RPP = 64 / CPR, NP = 32 / RPP, SPC = NB / HKT;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kq = lane >> 4, wi = wave >> 1, wj = wave & 1;
@@ -575,12 +575,14 @@ template <int HKT> __device__ __forceinline__ void update_wide_macro_dma(double*
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int r = 32 * wave + RPP * q + rr, t = r >> 6, tr = r & 63;
-            const double* gA = wbuf + (size_t)((long long)c * wstride + (it[t] - (k + 1))) * NB2;
+            const double* gA = WL ? band + (size_t)(rowoff[it[t]] + (it[t] - k)) * NB2 : wbuf + (size_t)((long long)c * wstride + (it[t] - (k + 1))) * NB2;
             const double* gB = band + (size_t)(rowoff[jt[t]] + (jt[t] - k)) * NB2;
             __builtin_amdgcn_global_load_lds((glb_void_t*)(gA + tr * NB + HKT * h + 2 * (p ^ (r & (CPR - 1)))), (lds_void_t*)(buf + (32 * wave + RPP * q) * HKT), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_void_t*)(gB + tr * NB + HKT * h + 2 * (p ^ (r & (CPR - 1)))), (lds_void_t*)(buf + PART + (32 * wave + RPP * q) * HKT), 16, 0, 0);
         }
     };
+    double* sdv = smem + 2 * STAGE;                               // W-less: the d of the group's block columns (update_wide_tile_dma)
+    if constexpr (WL) for (int q = tid; q < 64 * w; q += 256) sdv[q] = wbuf[(size_t)64 * k0 + q];
     issue(0);
     d4 acc[4][4];
 #pragma unroll
@@ -604,6 +606,11 @@ template <int HKT> __device__ __forceinline__ void update_wide_macro_dma(double*
                 double2 av[4], bv[4];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) av[a] = *reinterpret_cast<const double2*>(bufA + a * 16 * HKT + off);
+                if constexpr (WL) {
+                    const double2 dv = *reinterpret_cast<const double2*>(sdv + 64 * (s / SPC) + HKT * (s % SPC) + 2 * (4 * rd + kq));
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) { av[a].x *= dv.x; av[a].y *= dv.y; }
+                }
 #pragma unroll
                 for (int b = 0; b < 4; ++b) bv[b] = *reinterpret_cast<const double2*>(bufB + b * 16 * HKT + off);
 #pragma unroll
@@ -657,6 +664,10 @@ static_assert(4 * NB * HK * sizeof(double) <= 65536, "the LDS-DMA destination (M
 #ifndef GF_WLESS_BATCH
 #define GF_WLESS_BATCH 1       // the level-batched small fronts (two-launch sub-groups, GF_SOLVER_BLOCKCHAIN bit 1) keep no W = L D panels: their updates scale L by d on the fly
 #endif
+#ifndef GF_WLESS_BIG
+#define GF_WLESS_BIG 0         // 1: the large fronts too (panel_kernel is handed no W buffer, narrow / mid / wide / macro updates get the front's dval in the W slot): correct
+                               // (same tests), and measured without gain -- C4, same box: 0.1968 s with, 0.1955 s without (profiles/r05_solver_wless_ab.txt): their panels are 4.6 GB
+#endif
 #ifndef GF_WIDE_WAVES
 #define GF_WIDE_WAVES 4        // workgroups of a wide update per CU.  Three would leave 64 KB of LDS and a third of the registers of every CU free for the chain kernels of the
 #endif                         // other fronts (panel 32 KB; narrow update + diagonal tile 58 KB): their launches then take 15 / 30 us instead of 65 - 190 us beside the wide updates, but the
@@ -692,6 +703,9 @@ static_assert(4 * NB * HK * sizeof(double) <= 65536, "the LDS-DMA destination (M
 #endif
 __global__ __launch_bounds__(256) void panel_kernel(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k) {
     GF_PANEL_SMEM;
+#if GF_UPDATE_DMA && GF_LEAN_CHAIN
+    if (!wbuf) { panel_body_dma<HK, true>(band, linv, dval, nullptr, rowoff, k, (int)blockIdx.x, smem); return; }       // W-less front (the skyline keeps its W)
+#endif
     GF_PANEL_BODY(band, linv, dval, wbuf, rowoff, k, (int)blockIdx.x, smem);
 }
 
@@ -711,7 +725,11 @@ __global__ __launch_bounds__(256) void update_kernel(double* __restrict__ band, 
 __global__ __launch_bounds__(256) void update_narrow_kernel(double* __restrict__ band, const double* __restrict__ wbuf, const long long* __restrict__ rowoff, int k, DiagNext dn) {
     GF_NARROW_SMEM;
     if (blockIdx.x < blockIdx.y) return;
+#if GF_UPDATE_DMA && GF_LEAN_CHAIN && GF_WLESS_BIG
+    update_wide_tile_dma<HK, true>(band, wbuf, 0, rowoff, k, 1, (int)blockIdx.x, (int)blockIdx.y, smem);                  // wbuf: the front's dval
+#else
     GF_UPDATE_TILE(band, wbuf, rowoff, k, (int)blockIdx.x, (int)blockIdx.y, smem);
+#endif
     if (dn.on && blockIdx.x == 0 && blockIdx.y == 0) diag_next(band, rowoff, k + 1, dn, smem);       // tile (k + 1, k + 1): block column k was its last update inside the panel group
 }
 // ---- Round 5, last step: a SUB-GROUP of a panel group (sg <= 4 block columns ks .. ks + sg - 1) in TWO launches instead of two or three per block column.
@@ -770,14 +788,18 @@ __global__ __launch_bounds__(256) GF_WIDE_ATTR void subgroup_row_kernel(double* 
 __global__ __launch_bounds__(256) GF_WIDE_ATTR void update_mid_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w) {
     GF_WIDE_SMEM;
     if (blockIdx.x < blockIdx.y) return;
+#if GF_UPDATE_DMA && GF_LEAN_CHAIN && GF_WLESS_BIG
+    update_wide_tile_dma<HK, true>(band, wbuf, 0, rowoff, k0, w, (int)blockIdx.x, (int)blockIdx.y, smem);
+#else
     GF_UPDATE_WIDE_TILE(band, wbuf, wstride, rowoff, k0, w, (int)blockIdx.x, (int)blockIdx.y, smem);
+#endif
 }
 // jassign: target tiles in block columns >= jassign are ASSIGNED (the front's Schur block at its first wide update; INT_MAX: none)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void update_wide_macro_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride,
                                                                                                       const long long* __restrict__ rowoff, int k0, int w, int nrow, int jassign) {
-    __shared__ __attribute__((aligned(16))) double smem[8 * NB * HK];
+    __shared__ __attribute__((aligned(16))) double smem[8 * NB * HK + 8 * NB];
     int mi, mj; tri_index((int)blockIdx.x, mi, mj);
-    update_wide_macro_dma<HK>(band, wbuf, wstride, rowoff, k0, w, mi, mj, nrow, smem, jassign);
+    update_wide_macro_dma<HK, GF_LEAN_CHAIN && GF_WLESS_BIG>(band, wbuf, wstride, rowoff, k0, w, mi, mj, nrow, smem, jassign);
 }
 __global__ __launch_bounds__(256) GF_WIDE_ATTR void update_wide_kernel(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w, int nrow,
                                                                        int jassign) {
@@ -785,7 +807,7 @@ __global__ __launch_bounds__(256) GF_WIDE_ATTR void update_wide_kernel(double* _
     int gi, gj; tri_index((int)blockIdx.x, gi, gj);
     if (gi >= nrow) return;
 #if GF_UPDATE_DMA
-    update_wide_tile_dma<HK>(band, wbuf, wstride, rowoff, k0, w, gi, gj, smem, k0 + w + gj >= jassign);
+    update_wide_tile_dma<HK, GF_LEAN_CHAIN && GF_WLESS_BIG>(band, wbuf, wstride, rowoff, k0, w, gi, gj, smem, k0 + w + gj >= jassign);
 #else
     GF_UPDATE_WIDE_TILE(band, wbuf, wstride, rowoff, k0, w, gi, gj, smem);
 #endif
@@ -1599,6 +1621,7 @@ __global__ void nd_out_kernel(long long n, const double* __restrict__ src, doubl
     if (t < n) dst[t] = add ? dst[t] + src[t] : src[t];
 }
 // ---- multifrontal mode: work of one front on a stream with that stream's scratch (index NS = the main stream's)
+#define GF_BIG_WLESS (GF_UPDATE_DMA && GF_LEAN_CHAIN && GF_WLESS_BIG)
 static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool extend_add = true, bool lazy = false) {
     const Front& F = h->fronts[t];
     if (extend_add) for (int c : h->kids[t]) {
@@ -1619,20 +1642,21 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
     if ((h->block_chain & 1) && GF_UPDATE_DMA && GF_LEAN_CHAIN && h->subgroup > 0 && h->subgroup <= 4) {     // two launches per sub-group (subgroup_block / subgroup_row)
         const int SG = h->subgroup;
         double* wset = h->s_wbuf[si];
+        const double* wsrc = GF_BIG_WLESS ? (const double*)dval : (const double*)wset;      // the W-less mid / wide / macro kernels read L and d; the sub-group kernels of this path keep their W
         for (int k0 = 0; k0 < F.nblk_e; k0 += WP) {
             const int w = std::min(WP, F.nblk_e - k0);
             for (int cs = 0; cs < w; cs += SG) {
                 const int ks = k0 + cs, sg = std::min(SG, w - cs), nbelow = F.nblk_t - (ks + sg);
-                if (cs > 0) hipLaunchKernelGGL(update_mid_kernel, dim3(F.nblk_t - ks, sg), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, cs);
+                if (cs > 0) hipLaunchKernelGGL(update_mid_kernel, dim3(F.nblk_t - ks, sg), dim3(256), 0, st, band, wsrc, wstride, h->d_tri, k0, cs);
                 hipLaunchKernelGGL(subgroup_block_kernel, dim3(1), dim3(256), 0, st, band, linv, dval, stat, h->d_tri, wset, wstride, k0, ks, sg, F.nblk_t);
                 if (nbelow > 0) hipLaunchKernelGGL(subgroup_row_kernel, dim3(nbelow), dim3(256), 0, st, band, linv, dval, h->d_tri, wset, wstride, k0, ks, sg);
             }
             const int nrow = F.nblk_t - (k0 + w), jassign = (lazy && k0 == 0) ? F.nblk_e : 0x7fffffff;
             if (nrow >= h->macro_min_rows) {
                 const long long nm = (nrow + 1) / 2;
-                hipLaunchKernelGGL(update_wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow, jassign);
+                hipLaunchKernelGGL(update_wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, st, band, wsrc, wstride, h->d_tri, k0, w, nrow, jassign);
             } else if (nrow > 0)
-                hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow, jassign);
+                hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, wsrc, wstride, h->d_tri, k0, w, nrow, jassign);
         }
         return;
     }
@@ -1640,34 +1664,36 @@ static void nd_factor_front(gfs_handle* h, int t, hipStream_t st, int si, bool e
     for (int k0 = 0; k0 < F.nblk_e; k0 += WP) {                       // groups of WP block columns: one wide trailing update per group
         const int w = std::min(WP, F.nblk_e - k0);
         double* wset = h->s_wbuf[si];
+        const double* wsrc = GF_BIG_WLESS ? (const double*)dval : (const double*)wset;      // what the updates get in their W slot
         const int SG = h->subgroup > 0 ? h->subgroup : WP;
         for (int c = 0; c < w; ++c) {
             const int send = std::min((c / SG + 1) * SG, w);              // the sub-group of column c ends here (relative to k0)
             const int k = k0 + c, ni = F.nblk_t - 1 - k, nin = k0 + send - 1 - k;
             double* wb = wset + (size_t)c * wstride * NB2;
             if (c > 0 && c % SG == 0)                                     // a sub-group starts: its columns get the products of the group's earlier panels in one pass
-                hipLaunchKernelGGL(update_mid_kernel, dim3(F.nblk_t - k, send - c), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, c);
+                hipLaunchKernelGGL(update_mid_kernel, dim3(F.nblk_t - k, send - c), dim3(256), 0, st, band, wsrc, wstride, h->d_tri, k0, c);
             // inside a sub-group the diagonal tile of a block column has been factored by the workgroup that applied its last update (DiagNext); the sub-group's first
             // column gets a launch (the wide and mid updates stay small: 32 KB of LDS, four workgroups per CU).  A lean narrow update (32 KB, no fused tile) at the tree
             // heights where several large fronts run side by side was measured without effect (profiles/r05_solver_fuse_maxf_ab.txt) and removed.
             if (!have_diag) hipLaunchKernelGGL(diag_kernel, dim3(1), dim3(256), 0, st, band, linv, dval, h->d_tri, k, stat);
             have_diag = false;
-            if (ni > 0) hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, st, band, linv, dval, wb, h->d_tri, k);
-            if (w == 1 && ni > 0 && !(lazy && k0 == 0)) {
+            if (ni > 0) hipLaunchKernelGGL(panel_kernel, dim3(ni), dim3(256), 0, st, band, linv, dval, GF_BIG_WLESS ? (double*)nullptr : wb, h->d_tri, k);
+            if (w == 1 && ni > 0 && !(lazy && k0 == 0) && !GF_BIG_WLESS) {
                 have_diag = h->fuse_diag && k + 1 < F.nblk_e;
                 hipLaunchKernelGGL(update_kernel, dim3((unsigned)((long long)ni * (ni + 1) / 2)), dim3(256), 0, st, band, wb, h->d_tri, k, ni, DiagNext{linv, dval, stat, have_diag ? 1 : 0});
             } else if (nin > 0) {
                 have_diag = h->fuse_diag;
-                hipLaunchKernelGGL(update_narrow_kernel, dim3(ni, nin), dim3(256), 0, st, band, wb, h->d_tri, k, DiagNext{linv, dval, stat, have_diag ? 1 : 0});
+                hipLaunchKernelGGL(update_narrow_kernel, dim3(ni, nin), dim3(256), 0, st, band, GF_BIG_WLESS ? (const double*)dval : (const double*)wb, h->d_tri, k,
+                                   DiagNext{linv, dval, stat, have_diag ? 1 : 0});
             }
         }
         const int nrow = F.nblk_t - (k0 + w), jassign = (lazy && k0 == 0) ? F.nblk_e : 0x7fffffff;
-        const bool wide = w > 1 || (lazy && k0 == 0);                     // (a single-column group is otherwise served by update_kernel above)
+        const bool wide = w > 1 || (lazy && k0 == 0) || GF_BIG_WLESS;     // (a single-column group is otherwise served by update_kernel above)
         if (GF_UPDATE_DMA && wide && nrow >= h->macro_min_rows) {
             const long long nm = (nrow + 1) / 2;
-            hipLaunchKernelGGL(update_wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow, jassign);
+            hipLaunchKernelGGL(update_wide_macro_kernel, dim3((unsigned)(nm * (nm + 1) / 2)), dim3(256), 0, st, band, wsrc, wstride, h->d_tri, k0, w, nrow, jassign);
         } else if (wide && nrow > 0)
-            hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, wset, wstride, h->d_tri, k0, w, nrow, jassign);
+            hipLaunchKernelGGL(update_wide_kernel, dim3((unsigned)((long long)nrow * (nrow + 1) / 2)), dim3(256), 0, st, band, wsrc, wstride, h->d_tri, k0, w, nrow, jassign);
     }
 }
 // the NR vectors of one kind out of NR workspaces (one workspace per right-hand side)
