@@ -481,25 +481,26 @@ __device__ __forceinline__ void update_wide_tile(double* __restrict__ band, cons
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 // rows 16 wave .. 16 wave + 15 of one operand's part tile (k = HKT h .. HKT h + HKT - 1 of the 64 x 64 row-major tile g) -> dst (64 rows x HKT doubles): HKT / 8 pieces of 1 KB per wave
-template <int HKT> __device__ __forceinline__ void glds_part(const double* __restrict__ g, double* __restrict__ dst, int h, int wave, int lane) {
+// AUX: cache policy bits of the load (0: default; 16 = sc1: the load does not hit in the CU's L1 -- for tiles that this workgroup has read, rewritten in place and reads again)
+template <int HKT, int AUX = 0> __device__ __forceinline__ void glds_part(const double* __restrict__ g, double* __restrict__ dst, int h, int wave, int lane) {
     constexpr int CPR = HKT / 2, RPP = 64 / CPR, NP = 16 / RPP;   // 16-byte chunks per row, rows per piece, pieces per wave
     const int rr = lane / CPR, p = lane % CPR;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int r = 16 * wave + RPP * q + rr;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(g + r * NB + HKT * h + 2 * (p ^ (r & (CPR - 1)))), (lds_void_t*)(dst + (16 * wave + RPP * q) * HKT), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(g + r * NB + HKT * h + 2 * (p ^ (r & (CPR - 1)))), (lds_void_t*)(dst + (16 * wave + RPP * q) * HKT), 16, 0, AUX);
     }
 }
 // acc (+ / -)= sum over ncol pairs of 64 x 64 tiles (A_c, B_c) of A_c B_c^T; src(c, gA, gB) names pair c.  Stage s = (pair s / SPC, part s % SPC) lives in buffer s % 2.
 // SCALE: the A operand of pair c is multiplied by sdv[64 c + k] on its way into the product (W = L D formed on the fly from the L tiles: "W-less" updates below)
-template <int HKT, bool NEG, bool SCALE = false, class Src> __device__ __forceinline__ void mma_pairs_dma(Src&& src, int ncol, d4 (&acc)[4], double* __restrict__ smem, const double* __restrict__ sdv = nullptr) {
+template <int HKT, bool NEG, bool SCALE = false, int AUX = 0, int AUXB = AUX, class Src> __device__ __forceinline__ void mma_pairs_dma(Src&& src, int ncol, d4 (&acc)[4], double* __restrict__ smem, const double* __restrict__ sdv = nullptr) {
     constexpr int PART = NB * HKT, STAGE = 2 * PART, CPR = HKT / 2, SPC = NB / HKT;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
     auto issue = [&](int s) {
         const double *gA, *gB; src(s / SPC, gA, gB);
         double* buf = smem + (s & 1) * STAGE;
-        glds_part<HKT>(gA, buf, s % SPC, wave, lane);
-        glds_part<HKT>(gB, buf + PART, s % SPC, wave, lane);
+        glds_part<HKT, AUX>(gA, buf, s % SPC, wave, lane);
+        glds_part<HKT, AUXB>(gB, buf + PART, s % SPC, wave, lane);
     };
     issue(0);
     const int ns = SPC * ncol;
@@ -532,7 +533,7 @@ template <int HKT, bool NEG, bool SCALE = false, class Src> __device__ __forcein
 // WL ("W-less"): wbuf is the front's dval (d of block column k at wbuf + 64 k); the A operand of column k is the tile L_ik itself, scaled by d on its way into the
 // product, instead of the copy W_ik = L_ik D_k the panel kernels otherwise keep -- the panels write one tile less, and A and B operands come from the same tiles
 // (smem: the two stage buffers + 8 x 64 doubles for the d of the group's columns)
-template <int HKT, bool WL = false> __device__ __forceinline__ void update_wide_tile_dma(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w,
+template <int HKT, bool WL = false, int AUX = 0, int AUXB = AUX> __device__ __forceinline__ void update_wide_tile_dma(double* __restrict__ band, const double* __restrict__ wbuf, long long wstride, const long long* __restrict__ rowoff, int k0, int w,
                                                                         int gi, int gj, double* __restrict__ smem, bool assign = false) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
     const int i = k0 + w + gi, j = k0 + w + gj;
@@ -543,8 +544,11 @@ template <int HKT, bool WL = false> __device__ __forceinline__ void update_wide_
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) acc[nj][rg] = assign ? 0.0 : C[(16 * wave + 4 * rg + kq) * NB + 16 * nj + l16];
     double* sdv = smem + 4 * NB * HKT;
-    if constexpr (WL) for (int q = tid; q < 64 * w; q += 256) sdv[q] = wbuf[(size_t)64 * k0 + q];           // visible behind the first stage's barrier
-    mma_pairs_dma<HKT, true, WL>([&](int c, const double*& gA, const double*& gB) {
+    if constexpr (WL) {
+        for (int q = tid; q < 64 * w; q += 256) sdv[q] = wbuf[(size_t)64 * k0 + q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the loop's barriers are raw s_barrier (they wait for the DMA, vmcnt): this wave's LDS writes must have landed before it passes the first one
+    }
+    mma_pairs_dma<HKT, true, WL, AUX, AUXB>([&](int c, const double*& gA, const double*& gB) {
         const int k = k0 + c;
         gA = WL ? band + (size_t)(rowoff[i] + (i - k)) * NB2 : wbuf + (size_t)((long long)c * wstride + (i - (k + 1))) * NB2;
         gB = band + (size_t)(rowoff[j] + (j - k)) * NB2;
@@ -582,7 +586,10 @@ template <int HKT, bool WL = false> __device__ __forceinline__ void update_wide_
         }
     };
     double* sdv = smem + 2 * STAGE;                               // W-less: the d of the group's block columns (update_wide_tile_dma)
-    if constexpr (WL) for (int q = tid; q < 64 * w; q += 256) sdv[q] = wbuf[(size_t)64 * k0 + q];
+    if constexpr (WL) {
+        for (int q = tid; q < 64 * w; q += 256) sdv[q] = wbuf[(size_t)64 * k0 + q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // as in update_wide_tile_dma
+    }
     issue(0);
     d4 acc[4][4];
 #pragma unroll
@@ -634,12 +641,12 @@ template <int HKT, bool WL = false> __device__ __forceinline__ void update_wide_
     }
 }
 // panel tile in the same form: W = A_ik L_kk^-T (to wbuf), L_ik = W D_k^-1 (in place: the tile's last part has landed in LDS before anything is stored)
-template <int HKT, bool WL = false> __device__ __forceinline__ void panel_body_dma(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf,
+template <int HKT, bool WL = false, int AUX = 0> __device__ __forceinline__ void panel_body_dma(double* __restrict__ band, const double* __restrict__ linv, const double* __restrict__ dval, double* __restrict__ wbuf,
                                                                   const long long* __restrict__ rowoff, int k, int g, double* __restrict__ smem) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double* A = band + (size_t)(rowoff[k + 1 + g] + (g + 1)) * NB2;
     d4 acc[4] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
-    mma_pairs_dma<HKT, false>([&](int, const double*& gA, const double*& gB) { gA = A; gB = linv + (size_t)k * NB2; }, 1, acc, smem);
+    mma_pairs_dma<HKT, false, false, AUX>([&](int, const double*& gA, const double*& gB) { gA = A; gB = linv + (size_t)k * NB2; }, 1, acc, smem);
     double* W = WL ? nullptr : wbuf + (size_t)g * NB2;
 #pragma unroll
     for (int nj = 0; nj < 4; ++nj) {
@@ -739,6 +746,12 @@ __global__ __launch_bounds__(256) void update_narrow_kernel(double* __restrict__
 //      row's own lazy update from the sub-group's earlier columns (left-looking: W_i,c' is this workgroup's, L_k,c' the triangle's) -- a row's tiles are read once and its W / L
 //      written once, where panel + narrow updates re-read and re-wrote them per column.  Both use the tile kernels' device functions; a workgroup sees its own global writes
 //      behind __syncthreads().
+// The tile operations of ONE workgroup hand tiles over through global memory, and a tile may be read, rewritten in place and read again (a panel tile: A_ik in, L_ik out, L_ik as an
+// operand of the next update).  Found the hard way (round 5: one Newton solve in thirty rejected by its backward error, every second run of one test): the second LDS-DMA read of
+// such a tile can be served by the line the FIRST read left in the CU's L1 -- the plain stores in between do not touch it.  The sub-group kernels therefore load with sc1
+// (GF_SC1: the load does not hit in L1) where they read a tile again that they have read before through the DMA and rewritten: everything in subgroup_block (its cost is nothing),
+// the A operand of subgroup_row's lazy update.  Ten of ten runs clean either way; an L1 invalidate behind every tile operation instead cost 10 %, sc1 on every load of both kernels 2 %.
+constexpr int GF_SC1 = 16;
 template <bool WL> __device__ __forceinline__ void subgroup_block(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, double* __restrict__ stat, const long long* __restrict__ tri,
                                                double* __restrict__ wbuf, long long wstride, int k0, int ks, int sg, int nblk_t, double* __restrict__ smem) {
     for (int c = 0; c < sg; ++c) {
@@ -748,13 +761,13 @@ template <bool WL> __device__ __forceinline__ void subgroup_block(double* __rest
         double* wb = wbuf + (size_t)(k - k0) * wstride * NB2;
         const int rin = min(ks + sg, nblk_t) - (k + 1);           // rows of the triangle below block column k
         if constexpr (WL) {                                       // (the d of block column k: dval + 64 k, written by diag_body above)
-            for (int g = 0; g < rin; ++g) { panel_body_dma<HK, true>(band, linv, dval, nullptr, tri, k, g, smem); __syncthreads(); }
+            for (int g = 0; g < rin; ++g) { panel_body_dma<HK, true, GF_SC1>(band, linv, dval, nullptr, tri, k, g, smem); __syncthreads(); }
             for (int gj = 0; gj < rin; ++gj)
-                for (int gi = gj; gi < rin; ++gi) { update_wide_tile_dma<HK, true>(band, dval, 0, tri, k, 1, gi, gj, smem); __syncthreads(); }
+                for (int gi = gj; gi < rin; ++gi) { update_wide_tile_dma<HK, true, GF_SC1>(band, dval, 0, tri, k, 1, gi, gj, smem); __syncthreads(); }
         } else {
-            for (int g = 0; g < rin; ++g) { GF_PANEL_BODY(band, linv, dval, wb, tri, k, g, smem); __syncthreads(); }
+            for (int g = 0; g < rin; ++g) { panel_body_dma<HK, false, GF_SC1>(band, linv, dval, wb, tri, k, g, smem); __syncthreads(); }
             for (int gj = 0; gj < rin; ++gj)
-                for (int gi = gj; gi < rin; ++gi) { GF_UPDATE_TILE(band, wb, tri, k, gi, gj, smem); __syncthreads(); }
+                for (int gi = gj; gi < rin; ++gi) { update_wide_tile_dma<HK, false, GF_SC1>(band, wb, 0, tri, k, 1, gi, gj, smem); __syncthreads(); }
         }
     }
 }
@@ -763,7 +776,7 @@ template <bool WL> __device__ __forceinline__ void subgroup_row(double* __restri
     for (int c = 0; c < sg; ++c) {
         const int k = ks + c;
         if (c > 0) {                                              // A_ik -= sum over the sub-group's earlier columns k' of W_ik' L_kk'^T
-            if constexpr (WL) update_wide_tile_dma<HK, true>(band, dval, 0, tri, ks, c, i - k, 0, smem);
+            if constexpr (WL) update_wide_tile_dma<HK, true, GF_SC1, 0>(band, dval, 0, tri, ks, c, i - k, 0, smem);      // A: this workgroup's own L_ik' (read as A_ik', rewritten); B: the triangle's L_kk' (another launch)
             else GF_UPDATE_WIDE_TILE(band, wbuf + (size_t)(ks - k0) * wstride * NB2, wstride, tri, ks, c, i - k, 0, smem);
             __syncthreads();
         }
