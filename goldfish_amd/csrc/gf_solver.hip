@@ -751,7 +751,10 @@ __global__ __launch_bounds__(256) void update_narrow_kernel(double* __restrict__
 // such a tile can be served by the line the FIRST read left in the CU's L1 -- the plain stores in between do not touch it.  The sub-group kernels therefore load with sc1
 // (GF_SC1: the load does not hit in L1) where they read a tile again that they have read before through the DMA and rewritten: everything in subgroup_block (its cost is nothing),
 // the A operand of subgroup_row's lazy update.  Ten of ten runs clean either way; an L1 invalidate behind every tile operation instead cost 10 %, sc1 on every load of both kernels 2 %.
-constexpr int GF_SC1 = 16;
+#ifndef GF_SC1_BITS
+#define GF_SC1_BITS 16             // -DGF_SC1_BITS=0 rebuilds the hazard (tests/test_gpu_fullsize.py::test_repeated_factorisations_of_a_quarter_of_c4_give_the_same_bits then fails)
+#endif
+constexpr int GF_SC1 = GF_SC1_BITS;
 template <bool WL> __device__ __forceinline__ void subgroup_block(double* __restrict__ band, double* __restrict__ linv, double* __restrict__ dval, double* __restrict__ stat, const long long* __restrict__ tri,
                                                double* __restrict__ wbuf, long long wstride, int k0, int ks, int sg, int nblk_t, double* __restrict__ smem) {
     for (int c = 0; c < sg; ++c) {

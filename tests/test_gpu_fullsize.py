@@ -218,3 +218,30 @@ def test_newton_reaches_the_reference_tolerance_on_a_quarter_of_c4_with_load_ste
         if steps > 1:
             assert nm.newton_load_steps_done == steps and nm.newton_iterations >= steps
         nm._drop_device()
+
+
+def test_repeated_factorisations_of_a_quarter_of_c4_give_the_same_bits():
+    """Round 5 guard: two races of the W-less sub-group kernels (LDS writes not waited for in front of a raw barrier; a tile read through
+    LDS-DMA, rewritten in place and read again by the same workgroup served stale from the CU's L1) showed only as one rejected Newton solve now and then
+    (test_newton_reaches_... above is what caught them: it failed in one of two to six runs).  The factorisation is deterministic: forty factorisations of the same K
+    (498 k dofs: level-batched small fronts, large fronts, the top of the tree) must give the same solution bit for bit, each with a round-off backward error.  (A weaker
+    detector than the Newton test -- back-to-back factorisations did not reproduce the stale reads -- but the cheapest statement of what must hold.)"""
+    from goldfish_amd import _lib, _solver
+    spec = G.synthetic_shell(8, 8, nel=48, p=3, jitter=2)
+    A = arrays_from_spec(spec)
+    D = _lib.DeviceModel(A)
+    D.set_thickness(np.full(A.total_cp, spec.h_th)); D.set_u(G.smooth_displacement(spec, 0.5 * spec.h_th))
+    D.assemble(_lib.ASM_R | _lib.ASM_K); D.sync()
+    b = -D.residual()
+    X = np.stack([A.cp_hom[f] / A.weights for f in range(3)], 1)
+    S = _solver.DeviceSolver(D, coords=X)
+    try:
+        ref = S.solve(b, max_refine=0)
+        assert S.backward_error < 1e-15
+        for rep in range(40):
+            S.refactor()
+            x = S.solve(b, max_refine=0)
+            assert S.backward_error < 1e-15, (rep, S.backward_error)
+            assert np.array_equal(x, ref), (rep, float(np.abs(x - ref).max() / np.abs(ref).max()))
+    finally:
+        S.close(); D.close()
